@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""bench.py - rendered rays/s of the MVSNeRF hot path on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the ray march (`rendering()`: view-dir feature -> trilinear volume lookup + per-view
+colour lookup -> Renderer_ours MLP -> alpha compositing) over one batch of 1024 rays x 128 samples, BASELINE
+config 2 ("DTU scan1, 3 views, 128 planes, 1024 rays x 128 samples, fp32, 1 MI355X"): synthetic 3-view
+512x640 inputs, pad 24 => neural volume 128x176x208x8, the shipped checkpoint's weights (tests/golden) or
+seeded random weights.  Inputs are resident in HBM before the timed region.  The scene encode (plane sweep +
+CostRegNet, once per scene) is timed separately and reported in `encode_ms`.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+For N > 1 the driver launches one rank per GPU via torch.distributed.run; rays shard across ranks with no
+data-path collective (weak scaling: every rank renders its own 1024-ray batches of the same scene).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel (fused MLP, MFMA-bound): achieved = 251 392 FLOP/sample x samples per launch
+                / average launch duration measured with HIP events on the launch stream
+  rooflines     same for the HBM-bound gathers (volume lookup 300 B/sample - the kernel north_star puts the
+                60 % bar on -, colour lookup 204 B/sample)
+  cpu_baseline  the CPU oracle (torch CPU kernels = what the reference runs on a CPU) on the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_RAYS, N_SAMPLES, PAD, D_PLANES = 1024, 128, 24, 128
+H_IMG, W_IMG, N_SRC = 512, 640, 3
+FLOP_PER_SAMPLE = 251392          # Renderer_ours MACs*2
+VOL_BYTES_PER_SAMPLE = 300        # 8 corners x 32 B + 12 B coord + 32 B out
+COL_BYTES_PER_SAMPLE = 204        # 3 views x 48 B + 12 B + 48 B out
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--cpu-batches", type=int, default=20, help="CPU-oracle batches timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--mlp-variant", type=int, default=None)
+    return ap.parse_args()
+
+
+def load_mlp_weights():
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "mvsnerf_v0_weights.npz"))
+    return {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("mlp/")}
+
+
+def event_time(fn, iters, warm=3):
+    """Average duration (ms) of one call of fn, HIP events on the current (= launch) stream."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mvsnerf_amd import _lib, models, ops, renderer
+    from mvsnerf_amd.synth import make_rig, pose_ref_of
+    from mvsnerf_amd.utils import build_rays
+    import types
+    if a.mlp_variant is not None:
+        _lib.lib().mvsnerf_tune(b"mlp_variant", a.mlp_variant)
+
+    # ---------------- scene + network (resident in HBM before timing)
+    rig = make_rig(H_IMG, W_IMG, seed=1234)
+    pose = {k: v.to(dev) for k, v in pose_ref_of(rig).items()}
+    imgs_raw = rig["images_raw"].to(dev)
+    args = types.SimpleNamespace(feat_dim=8 + 4 * N_SRC, img_downscale=1.0, use_color_volume=False, net_type="v0", multires=10,
+                                 i_embed=0, pts_dim=3, multires_views=4, dir_dim=3, netdepth=6, netwidth=128, N_importance=0,
+                                 netchunk=1024, ckpt=None, perturb=1.0, N_samples=N_SAMPLES, use_viewdirs=True, white_bkgd=False,
+                                 raw_noise_std=0.0, pad=PAD)
+    kw, _, _, _ = models.create_nerf_mvs(args, use_mvs=False, dir_embedder=False, pts_embedder=True)
+    net = kw["network_fn"]
+    net.load_state_dict(load_mlp_weights())
+    qfn = kw["network_query_fn"]
+    h, w = H_IMG // 4 + 2 * PAD, W_IMG // 4 + 2 * PAD
+    encode_ms = None
+    try:
+        from mvsnerf_amd import encoder  # plane sweep + CostRegNet (HIP)
+        enc_ready = True
+    except ImportError:
+        enc_ready = False
+    if enc_ready:
+        vol, encode_ms = encoder.bench_encode(rig, dev, PAD)
+        volume_src = "mvsnet-encode"
+    else:
+        vol = torch.randn((1, 8, D_PLANES, h, w), generator=torch.Generator().manual_seed(5)).to(dev)
+        vol = vol.contiguous(memory_format=torch.channels_last_3d)
+        volume_src = "random (encoder kernels not built yet)"
+
+    # ---------------- per-step ray batches: pre-drawn (build_rays is host-side torch in the reference too)
+    torch.manual_seed(1000 + rank)
+    n_batches = 8
+    batches = []
+    depths = torch.zeros(1, 4, 1, 1, device=dev)
+    with torch.no_grad():
+        for _ in range(n_batches):
+            pts, rdir, _tgt, ndc, z, ro, _, _ = build_rays(imgs_raw, depths, pose, pose["w2cs"], pose["c2ws"], pose["intrinsics"],
+                                                           rig["near_fars"].to(dev), N_RAYS, N_SAMPLES, pad=PAD)
+            batches.append(tuple(t.contiguous() for t in (pts, ndc, z, ro, rdir)))
+    src = imgs_raw[:, :N_SRC]
+
+    def step(i):
+        pts, ndc, z, ro, rdir = batches[i % n_batches]
+        return renderer.rendering(args, pose, pts, ndc, z, ro, rdir, vol, src, network_fn=net, network_query_fn=qfn)
+
+    with torch.no_grad():
+        for i in range(a.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    rays_per_s = world * a.steps * N_RAYS / dt
+
+    # ---------------- per-kernel launch durations (HIP events on the launch stream), rank 0
+    roof, roofs, cpu = None, [], None
+    if rank == 0:
+        with torch.no_grad():
+            pts, ndc, z, ro, rdir = batches[0]
+            vol_cl = ops.channels_last_volume(vol)
+            P = N_RAYS * N_SAMPLES
+            F = args.feat_dim
+            feat = torch.empty((N_RAYS, N_SAMPLES, F), device=dev)
+            dirs = ops.dir_feature(rdir, pose["w2cs"][0].contiguous())
+            packed = net.packed(F)
+            t_vol = event_time(lambda: ops.volume_sample(vol_cl, ndc, out=feat, out_stride=F), 200)
+            t_col = event_time(lambda: ops.color_sample(src[0], pose["w2cs"][:N_SRC].contiguous(), pose["intrinsics"][:N_SRC].contiguous(),
+                                                        pts, True, out=feat, out_ptr=feat.data_ptr() + 32, out_stride=F), 200)
+            t_mlp = event_time(lambda: ops.mlp_forward(packed, F, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3,
+                                                       N_RAYS, N_SAMPLES, False, dev), 50)
+            raw = ops.mlp_forward(packed, F, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3, N_RAYS, N_SAMPLES, False, dev)
+            t_cmp = event_time(lambda: ops.composite(raw.view(N_RAYS, N_SAMPLES, 4), z), 200)
+        tf = FLOP_PER_SAMPLE * P / (t_mlp * 1e-3) / 1e12
+        roof = {"kernel": "mlp_fwd_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(t_mlp, 4)}
+        for name, t, bps in (("volume_sample_c8_kernel", t_vol, VOL_BYTES_PER_SAMPLE), ("color_sample_kernel", t_col, COL_BYTES_PER_SAMPLE),
+                             ("composite_kernel", t_cmp, 28)):
+            gbs = bps * P / (t * 1e-3) / 1e9
+            roofs.append({"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_ms": round(t, 5)})
+        # ---------------- CPU baseline: the oracle (torch CPU kernels) on a bounded sample of the same workload
+        if a.cpu_batches > 0:
+            from oracle import mvsnerf_oracle as O
+            sd = load_mlp_weights()
+            cpose = {k: v.cpu() for k, v in pose.items()}
+            cvol = ops.ndhwc_to_ncdhw(ops.channels_last_volume(vol))[None].cpu()
+            cb = [tuple(t.cpu() for t in b) for b in batches[:4]]
+            csrc = src.cpu()
+            with torch.no_grad():
+                O.rendering(cpose, cb[0][0], cb[0][1], cb[0][2], cb[0][4], cvol, csrc, sd)    # warm
+                c0 = time.perf_counter()
+                for i in range(a.cpu_batches):
+                    b = cb[i % len(cb)]
+                    out = O.rendering(cpose, b[0], b[1], b[2], b[4], cvol, csrc, sd)
+                cdt = time.perf_counter() - c0
+            cpu = {"value": round(a.cpu_batches * N_RAYS / cdt, 1), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+                   "sample": f"{a.cpu_batches} batches of {N_RAYS}x{N_SAMPLES} (oracle.rendering, torch CPU fp32, no_grad), {cdt:.1f} s"}
+            # parity of the timed workload itself (same batch, GPU vs CPU oracle)
+            with torch.no_grad():
+                g = step(0)
+                b = cb[0]
+                o = O.rendering(cpose, b[0], b[1], b[2], b[4], cvol, csrc, sd)
+                err = float((g[0].cpu() - o[0]).abs().max())
+                mse = float(((g[0].cpu() - o[0]) ** 2).mean())
+            import math
+            cpu["max_abs_rgb_err_vs_gpu"] = err
+            cpu["psnr_gpu_vs_cpu_db"] = round(10 * math.log10(1.0 / max(mse, 1e-20)), 1)
+
+        print(json.dumps({
+            "metric": "rendered rays/sec (1024-ray batch, 128 samples)", "value": round(rays_per_s, 1), "unit": "rays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "config 2: 3 source views 512x640, 128 depth planes, pad 24 (volume 128x176x208x8), "
+                                   "1024 rays x 128 samples per step, fp32, render-only (volume pre-built)",
+                       "weights": "mvsnerf-v0 checkpoint", "volume": volume_src, "rays_per_step_per_gpu": N_RAYS,
+                       "parallelism": f"ray-sharded x{world}, no data-path collective"},
+            "encode_ms": encode_ms,
+            "roofline": roof, "rooflines": roofs, "cpu_baseline": cpu,
+        }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,132 @@
+/* mvsnerf_hip.h - C ABI of libmvsnerf_hip.so (gfx950 / MI355X).
+ *
+ * The reference (apchenstu/mvsnerf) has no FFI layer: its hot path is Python calling implicit
+ * ATen/cuDNN kernels.  This header is the boundary a maintainer would bind instead (ctypes stub in
+ * INTEGRATION.md).  Each entry point names the reference call site(s) whose arithmetic it replaces
+ * (paths under /root/reference).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types.  Every pointer is a DEVICE pointer (fp32 unless noted)
+ *     owned by the caller; outputs are caller-allocated and fully written.  The library allocates
+ *     nothing and keeps no state.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls only enqueue work.
+ *   - return 0 on success, a negative MVSNERF_E* for rejected arguments (nothing was launched),
+ *     or a positive hipError_t from the launch.
+ *   - volumes are CHANNEL-LAST in HBM: vol[d][y][x][c] (one corner of the 8-channel neural volume is
+ *     one 32-byte sector).  The reference's NCDHW tensors are converted once by
+ *     mvsnerf_ncdhw_to_ndhwc / produced channel-last directly by the encoder kernels.
+ */
+#ifndef MVSNERF_HIP_H
+#define MVSNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVSNERF_OK 0
+#define MVSNERF_EINVAL (-1)  /* bad size / null pointer */
+#define MVSNERF_EUNSUPPORTED (-2) /* shape outside what the kernels are specialised for */
+#define MVSNERF_EALIGN (-3)  /* pointer not 16-byte aligned where required */
+
+/* ABI version; bumped on any signature change. */
+int mvsnerf_abi_version(void);
+
+/* A/B benchmarking knob, not part of the reference surface.  Keys: "mlp_variant" = 0 (32 points/wave,
+ * 2 waves/SIMD), 1 (64 points/wave, 1 wave/SIMD), 2 (32 points/wave, 1 wave/SIMD).  Results are identical. */
+int mvsnerf_tune(const char* key, int value);
+
+/* ---------------------------------------------------------------- layout helpers */
+
+/* (C,D,H,W) -> (D,H,W,C) and back.  Used at the boundary when a caller hands over the reference's
+ * NCDHW volume (models.py:930 `volume_feat.reshape(1,-1,D,h,w)`). */
+int mvsnerf_ncdhw_to_ndhwc(const float* src, float* dst, int C, int D, int H, int W, void* stream);
+int mvsnerf_ndhwc_to_ncdhw(const float* src, float* dst, int C, int D, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------- ray march (L1b) */
+
+/* Trilinear lookup of the channel-last volume: replaces F.grid_sample 5-D in
+ * utils.py:357-383 (index_point_feature) and models.py:941-950 (RefVolume.forward).
+ * vol[D][H][W][C] (C == 8); ndc[P][3] = (x->W, y->H, z->D) in [0,1]; zeros padding, align_corners=True.
+ * out[p*out_stride + c], c < C  (out_stride lets it write the first 8 columns of input_feat). */
+int mvsnerf_volume_sample_fwd(const float* vol, int D, int H, int W, int C,
+                              const float* ndc, int64_t P,
+                              float* out, int out_stride, void* stream);
+
+/* Per-view colour lookup: replaces utils.py:300-332 (build_color_volume, img_feat=None) including
+ * get_ndc_coordinate (utils.py:112-146) for each source view.
+ * imgs[V][3][H][W] un-normalised; w2c[V][4][4]; K[V][3][3] (device); pts[P][3] world.
+ * out[p*out_stride + v*Cv + {0,1,2,(3)}] = (r,g,b,(mask)), Cv = 3 + with_mask.
+ * bilinear, *border* padding, align_corners=True; mask = strict -1<g<1 on both axes. */
+int mvsnerf_color_sample_fwd(const float* imgs, int V, int H, int W,
+                             const float* w2c, const float* K,
+                             const float* pts, int64_t P, int with_mask,
+                             float* out, int out_stride, void* stream);
+
+/* View-direction feature: renderer.py:142-147 + gen_dir_feature renderer.py:111-122.
+ * dirs_out[n] = (rays_dir[n]/|rays_dir[n]|) @ w2c_ref[:3,:3]^T ; w2c_ref may be NULL (no rotation);
+ * normalize == 0 skips the division (gen_dir_feature called on already-unit directions). */
+int mvsnerf_dir_feature_fwd(const float* rays_dir, const float* w2c_ref, int64_t N, int normalize,
+                            float* dirs_out, void* stream);
+
+/* Stand-alone positional encoding, Embedder.embed (models.py:47-51): x[P][d] ->
+ * out[P][d*(1+2L)] = [x | sin(x_c*2^f), f-major | cos(...)].  The MLP kernel below embeds internally;
+ * this exists for callers that use `embed_fn` on its own. */
+int mvsnerf_posenc_fwd(const float* x, int64_t P, int d, int L, float* out, void* stream);
+
+/* Renderer_ours MLP (models.py:145-222) with the Embedder (models.py:17-51, multires=10) fused in.
+ * Specialised for the shipped architecture: netdepth 6, netwidth 128, skips=[4], 63-dim embedding,
+ * 3-dim raw view direction, feat_dim F = 8+4V (even, <= 40).
+ *
+ * mvsnerf_mlp_packed_floats(F) -> number of floats of the packed-weight buffer.
+ * mvsnerf_mlp_pack: re-lays the 11 nn.Linear weight/bias tensors (row-major [out][in], the
+ *   checkpoint's layout) into the MFMA-fragment order the kernel streams through LDS.
+ *   Order of `w`/`b`: pts_linears.0..5, pts_bias, feature_linear, alpha_linear, views_linears.0, rgb_linear.
+ * mvsnerf_mlp_fwd: raw[p] = (r,g,b,sigma).  ndc[p*ndc_stride + {0,1,2}] (embedded inside),
+ *   feat[p*feat_stride + k], dirs[n*dirs_stride + {0,1,2}] per ray (P = N*S, point p belongs to ray
+ *   p / S).  The strides let MVSNeRF.forward(x) (models.py:565) run on the reference's 86-wide rows
+ *   in place: ndc = x, feat = x+63, dirs = x+63+F, all with stride 86, S = 1.
+ *   alpha_only != 0 follows forward_alpha (models.py:176-191): dirs may be NULL, raw is [P][1].
+ */
+size_t mvsnerf_mlp_packed_floats(int F);
+int mvsnerf_mlp_pack(const float* const w[11], const float* const b[11], int F,
+                     float* packed, void* stream);
+int mvsnerf_mlp_fwd(const float* packed, int F,
+                    const float* ndc, int ndc_stride, const float* feat, int feat_stride,
+                    const float* dirs, int dirs_stride, int64_t N, int S, int alpha_only,
+                    float* raw, void* stream);
+
+/* Alpha compositing: raw2alpha + raw2outputs (renderer.py:18-26, 65-92).
+ * raw[N][S][4], z[N][S] -> rgb_map[N][3], disp[N], acc[N], weights[N][S], depth[N], alpha[N][S].
+ * Any output pointer may be NULL (skipped). */
+int mvsnerf_composite_fwd(const float* raw, const float* z, int64_t N, int S, int white_bkgd,
+                          float* rgb_map, float* disp, float* acc, float* weights,
+                          float* depth, float* alpha, void* stream);
+
+/* One-call ray march = rendering() (renderer.py:138-165): dir feature -> volume + colour lookup ->
+ * MLP -> compositing, all enqueued on `stream`.  input_feat[N][S][F] and raw[N][S][4] are outputs too
+ * (rendering returns input_feat; raw carries sigma). */
+typedef struct {
+    const float* vol; int D, H, W;          /* channel-last 8-channel volume */
+    const float* imgs; int V, IH, IW;       /* [V][3][IH][IW] un-normalised source images */
+    const float* w2c;                       /* [V][4][4], view 0 = reference view */
+    const float* K;                         /* [V][3][3] */
+    const float* packed_mlp;                /* from mvsnerf_mlp_pack, F = 8+4V */
+    const float* rays_pts;                  /* [N][S][3] world */
+    const float* rays_ndc;                  /* [N][S][3] reference-view NDC */
+    const float* z_vals;                    /* [N][S] */
+    const float* rays_dir;                  /* [N][3] un-normalised */
+    int64_t N; int S; int white_bkgd;
+    float* dirs_tmp;                        /* [N][3] workspace */
+    float* input_feat;                      /* [N][S][F] out */
+    float* raw;                             /* [N][S][4] out */
+    float* rgb_map; float* disp; float* acc; float* weights; float* depth; float* alpha;  /* outs, may be NULL */
+} mvsnerf_raymarch_args;
+int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,95 @@
+"""ctypes binding of libmvsnerf_hip.so (the C ABI declared in include/mvsnerf_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a RuntimeError
+naming the op is raised.  PyTorch is used only for device memory and streams.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmvsnerf_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_c_fp = ctypes.c_void_p      # device pointers travel as integers
+_c_i = ctypes.c_int
+_c_l = ctypes.c_int64
+
+
+class RaymarchArgs(ctypes.Structure):
+    """mvsnerf_raymarch_args (include/mvsnerf_hip.h)."""
+    _fields_ = [
+        ("vol", _c_fp), ("D", _c_i), ("H", _c_i), ("W", _c_i),
+        ("imgs", _c_fp), ("V", _c_i), ("IH", _c_i), ("IW", _c_i),
+        ("w2c", _c_fp), ("K", _c_fp), ("packed_mlp", _c_fp),
+        ("rays_pts", _c_fp), ("rays_ndc", _c_fp), ("z_vals", _c_fp), ("rays_dir", _c_fp),
+        ("N", _c_l), ("S", _c_i), ("white_bkgd", _c_i),
+        ("dirs_tmp", _c_fp), ("input_feat", _c_fp), ("raw", _c_fp),
+        ("rgb_map", _c_fp), ("disp", _c_fp), ("acc", _c_fp), ("weights", _c_fp), ("depth", _c_fp), ("alpha", _c_fp),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol of include/mvsnerf_hip.h (tests check this)
+SIGNATURES = {
+    "mvsnerf_abi_version": (_c_i, []),
+    "mvsnerf_tune": (_c_i, [ctypes.c_char_p, _c_i]),
+    "mvsnerf_ncdhw_to_ndhwc": (_c_i, [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp]),
+    "mvsnerf_ndhwc_to_ncdhw": (_c_i, [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp]),
+    "mvsnerf_volume_sample_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_l, _c_fp, _c_i, _c_fp]),
+    "mvsnerf_color_sample_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_i, _c_fp]),
+    "mvsnerf_dir_feature_fwd": (_c_i, [_c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_posenc_fwd": (_c_i, [_c_fp, _c_l, _c_i, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_mlp_packed_floats": (ctypes.c_size_t, [_c_i]),
+    "mvsnerf_mlp_pack": (_c_i, [ctypes.POINTER(_c_fp), ctypes.POINTER(_c_fp), _c_i, _c_fp, _c_fp]),
+    "mvsnerf_mlp_fwd": (_c_i, [_c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_composite_fwd": (_c_i, [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_raymarch_fwd": (_c_i, [ctypes.POINTER(RaymarchArgs), _c_fp]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile libmvsnerf_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode:
+        raise RuntimeError("building libmvsnerf_hip.so failed")
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises loudly when it is absent (no CPU / eager fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the MVSNeRF hot path has no fallback. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C mvsnerf_amd/csrc`.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, op):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "unsupported shape", -3: "misaligned pointer"}.get(rc, f"hipError {rc}")
+        raise RuntimeError(f"libmvsnerf_hip: {op} failed: {kind}")
+
+
+def dev_f32(t, name):
+    """Validate a tensor handed to the C ABI: CUDA(HIP) device, fp32, contiguous."""
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise RuntimeError(f"{name}: expected a contiguous float32 tensor on the GPU, got "
+                           f"{type(t).__name__} {getattr(t, 'dtype', None)} {getattr(t, 'device', None)}")
+    return t.data_ptr()

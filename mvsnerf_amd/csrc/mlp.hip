@@ -1,0 +1,384 @@
+// Fused Embedder + Renderer_ours MLP for gfx950 (models.py:17-51, 145-222; renderer.py:42-63).
+//
+// One workgroup = 4 waves = 128 points; each wave owns 32 points for the whole network.  Every layer
+// is computed transposed on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains, 157 TFLOP/s peak) with the
+// weights as A operand streamed through a 64 KB LDS buffer and the activations as B operand straight
+// from the previous layer's accumulator registers (see mlp_layout.h) - the 86-wide input and all
+// 128-wide activations of the reference (~1.5 GB of ATen traffic per 1024x128 batch) never exist in
+// memory.  MFMA-bound: 251 392 FLOP per point against 12 B + 4*F B read and 16 B written.
+#include "common.h"
+#include "mlp_layout.h"
+
+using namespace mlp;
+
+// ------------------------------------------------------------------------------------------ pack
+struct PackArgs {
+    const float* w[11];
+    const float* b[11];
+    int F;
+};
+// order of w/b: 0..5 pts_linears, 6 pts_bias, 7 feature_linear, 8 alpha_linear, 9 views_linears.0, 10 rgb_linear
+
+__device__ inline void pack_segment(float* __restrict__ dst, const float* __restrict__ W, int ld, int col_off,
+                                    int kmap, int steps, int nb, int F, int tid, int nthreads)
+{
+    const int total = steps * nb * 64;
+    for (int i = tid; i < total; i += nthreads) {
+        const int j = i & 3;
+        const int lane = (i >> 2) & 63;
+        const int rest = i >> 8;               // t4*nb + b
+        const int b = rest % nb, t = (rest / nb) * 4 + j;
+        const int col = kmap_col(kmap, t, lane >> 5, F);
+        const int row = b * 32 + (lane & 31);
+        dst[i] = col < 0 ? 0.0f : W[(size_t)row * ld + col_off + col];
+    }
+}
+
+__global__ __launch_bounds__(256) void mlp_pack_kernel(PackArgs a, float* __restrict__ packed)
+{
+    const Layout L = layout(a.F);
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    pack_segment(packed + L.biasw, a.w[6], a.F, 0, K_FEAT, L.fsteps, 4, a.F, tid, nt);
+    pack_segment(packed + L.l0, a.w[0], PE_DIM, 0, K_PE, PE_STEPS, 4, a.F, tid, nt);
+    pack_segment(packed + L.l1, a.w[1], WIDTH, 0, K_ACT, ACT_STEPS, 4, a.F, tid, nt);
+    pack_segment(packed + L.l2, a.w[2], WIDTH, 0, K_ACT, ACT_STEPS, 4, a.F, tid, nt);
+    pack_segment(packed + L.l3, a.w[3], WIDTH, 0, K_ACT, ACT_STEPS, 4, a.F, tid, nt);
+    pack_segment(packed + L.l4, a.w[4], WIDTH, 0, K_ACT, ACT_STEPS, 4, a.F, tid, nt);
+    pack_segment(packed + L.l5a, a.w[5], WIDTH + PE_DIM, 0, K_PE, PE_STEPS, 4, a.F, tid, nt);        // cat([pts, h]) models.py:205
+    pack_segment(packed + L.l5b, a.w[5], WIDTH + PE_DIM, PE_DIM, K_ACT, ACT_STEPS, 4, a.F, tid, nt);
+    pack_segment(packed + L.feat, a.w[7], WIDTH, 0, K_ACT, ACT_STEPS, 4, a.F, tid, nt);
+    pack_segment(packed + L.views, a.w[9], WIDTH + 3, 0, K_VIEWS, VIEW_STEPS, 2, a.F, tid, nt);
+    float* v = packed + L.vec;
+    for (int i = tid; i < V_TOTAL; i += nt) {
+        float x = 0.0f;
+        if (i < V_VIEWS) {                       // eight [2][64] bias vectors
+            const int which = i >> 7, h = (i >> 6) & 1, q = i & 63;
+            const float* src = which == 0 ? a.b[6] : which <= 6 ? a.b[which - 1] : a.b[7];
+            x = src[act_n(q, h)];
+        } else if (i < V_WA) {                   // views bias [2][32]
+            const int k = i - V_VIEWS;
+            x = a.b[9][act_n(k & 31, k >> 5)];
+        } else if (i < V_BA) {                   // alpha weight [2][64]
+            const int k = i - V_WA;
+            x = a.w[8][act_n(k & 63, k >> 6)];
+        } else if (i < V_WR) {
+            x = (i == V_BA) ? a.b[8][0] : 0.0f;
+        } else if (i < V_BR) {                   // rgb weight [3][2][32]
+            const int k = i - V_WR, c = k >> 6, h = (k >> 5) & 1, q = k & 31;
+            x = a.w[10][c * 64 + act_n(q, h)];
+        } else {
+            const int c = i - V_BR;
+            x = c < 3 ? a.b[10][c] : 0.0f;
+        }
+        v[i] = x;
+    }
+}
+
+extern "C" size_t mvsnerf_mlp_packed_floats(int F)
+{
+    if (F < 2 || F > MAX_F || (F & 1)) return 0;
+    return layout(F).total;
+}
+
+extern "C" int mvsnerf_mlp_pack(const float* const w[11], const float* const b[11], int F, float* packed, void* stream)
+{
+    if (!w || !b || !packed) return MVSNERF_EINVAL;
+    if (F < 2 || F > MAX_F || (F & 1)) return MVSNERF_EUNSUPPORTED;
+    if (!mvs_aligned16(packed)) return MVSNERF_EALIGN;
+    PackArgs a;
+    for (int i = 0; i < 11; ++i) {
+        if (!w[i] || !b[i]) return MVSNERF_EINVAL;
+        a.w[i] = w[i]; a.b[i] = b[i];
+    }
+    a.F = F;
+    mlp_pack_kernel<<<64, 256, 0, (hipStream_t)stream>>>(a, packed);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// ------------------------------------------------------------------------------------------ compute
+constexpr int WBUF_FLOATS = 16384;                      // 64 KB weight stage
+constexpr int LDS_FLOATS = WBUF_FLOATS + V_TOTAL;       // + fragment-ordered vectors (5.5 KB)
+
+__device__ __forceinline__ void stage_weights(float* __restrict__ wbuf, const float* __restrict__ src, int n_floats, int tid)
+{
+    // 256 threads x float4, fully coalesced; n_floats is a multiple of 1024
+    const f32x4* s = reinterpret_cast<const f32x4*>(src);
+    f32x4* d = reinterpret_cast<f32x4*>(wbuf);
+    const int n4 = n_floats >> 2;
+#pragma unroll 4
+    for (int i = tid; i < n4; i += 256) d[i] = s[i];
+}
+
+// acc[g][b] += W_frag(t, b) * bfn(g, t) for t in [0, 4*STEPS4); G = 32-point groups per wave
+// (one A fragment read from LDS feeds G MFMAs).
+template <int STEPS4, int NBLK, int G, typename BFN>
+__device__ __forceinline__ void gemm_stage(const float* __restrict__ w, f32x16 (&acc)[G][NBLK], int lane, BFN bfn)
+{
+#pragma unroll
+    for (int t4 = 0; t4 < STEPS4; ++t4) {
+        f32x4 a[NBLK];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b)
+            a[b] = *reinterpret_cast<const f32x4*>(w + ((t4 * NBLK + b) * 64 + lane) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float bv[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) bv[g] = bfn(g, t4 * 4 + j);
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    acc[g][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b][j], bv[g], acc[g][b], 0, 0, 0);
+        }
+    }
+}
+
+template <int NBLK, int G>
+__device__ __forceinline__ void init_acc(f32x16 (&acc)[G][NBLK], const float* __restrict__ vec_h)
+{
+    // vec_h points at this lane-half's [NBLK*16] bias fragment (LDS broadcast reads)
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(vec_h + b * 16 + r4 * 4);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                acc[g][b][r4 * 4 + 0] = v[0]; acc[g][b][r4 * 4 + 1] = v[1]; acc[g][b][r4 * 4 + 2] = v[2]; acc[g][b][r4 * 4 + 3] = v[3];
+            }
+        }
+}
+
+// positional-encoding B operand of k-step t for this lane (point coords px,py,pz; half)
+__device__ __forceinline__ float pe_operand(int t, int half, float px, float py, float pz)
+{
+    if (t == 0) return half ? py : px;
+    if (t == 1) return half ? 0.0f : pz;
+    const int j = t - 2, f = j / 3, c = j - 3 * f;
+    const float x = (c == 0 ? px : c == 1 ? py : pz) * (float)(1 << f);   // exact, as x*2^f in models.py:49
+    float s, co;
+    sincosf(x, &s, &co);
+    return half ? co : s;
+}
+
+// G groups of 32 points per wave; WPS = waves per SIMD the register budget is capped for.
+template <bool ALPHA_ONLY, int G, int WPS>
+__global__ __launch_bounds__(256, WPS) void mlp_fwd_kernel(
+    const float* __restrict__ packed, int F, const float* __restrict__ ndc, int ndc_stride,
+    const float* __restrict__ feat, int feat_stride, const float* __restrict__ dirs, int dirs_stride,
+    int64_t P, int S, float* __restrict__ raw)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wbuf = lds;
+    float* vec = lds + WBUF_FLOATS;
+
+    const Layout L = layout(F);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5;
+    int64_t p_raw[G], p[G];
+    bool live[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        p_raw[g] = ((int64_t)blockIdx.x * 4 + wave) * (32 * G) + g * 32 + (lane & 31);
+        live[g] = p_raw[g] < P;
+        p[g] = live[g] ? p_raw[g] : P - 1;
+    }
+
+    // stage A: fragment vectors + pts_bias weights + layer 0
+    for (int i = tid; i < V_TOTAL; i += 256) vec[i] = packed[L.vec + i];
+    stage_weights(wbuf, packed + L.biasw, (int)(L.l1 - L.biasw), tid);
+
+    float px[G], py[G], pz[G];
+    float fv[G][MAX_F / 2];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        px[g] = ndc[p[g] * ndc_stride + 0]; py[g] = ndc[p[g] * ndc_stride + 1]; pz[g] = ndc[p[g] * ndc_stride + 2];
+        const float* fp = feat + p[g] * feat_stride + half * (F / 2);
+#pragma unroll
+        for (int i = 0; i < MAX_F / 2; ++i) fv[g][i] = i < F / 2 ? fp[i] : 0.0f;
+    }
+    __syncthreads();
+
+    // bias = pts_bias(feat)   (models.py:200)
+    float bias[G][64];
+    {
+        f32x16 acc[G][4];
+        init_acc<4, G>(acc, vec + V_BIASG + half * 64);
+        auto fb = [&](int g, int t) { return fv[g][t]; };          // fv is zero beyond F/2
+        // F/2 <= 20 real k-steps padded to fsteps in {4,8,12,16,20}
+        switch (L.fsteps) {
+            case 4:  gemm_stage<1, 4, G>(wbuf, acc, lane, fb); break;
+            case 8:  gemm_stage<2, 4, G>(wbuf, acc, lane, fb); break;
+            case 12: gemm_stage<3, 4, G>(wbuf, acc, lane, fb); break;
+            case 16: gemm_stage<4, 4, G>(wbuf, acc, lane, fb); break;
+            default: gemm_stage<5, 4, G>(wbuf, acc, lane, fb); break;
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int q = 0; q < 64; ++q) bias[g][q] = acc[g][q >> 4][q & 15];
+    }
+
+    float h[G][64];
+    auto pe = [&](int g, int t) { return pe_operand(t, half, px[g], py[g], pz[g]); };
+    auto hb = [&](int g, int t) { return h[g][t]; };
+    // layer 0: h = relu((W0 pe + b0) * bias)   (models.py:202-203)
+    {
+        f32x16 acc[G][4];
+        init_acc<4, G>(acc, vec + V_L0 + half * 64);
+        gemm_stage<PE_STEPS / 4, 4, G>(wbuf + seg_floats(L.fsteps, 4), acc, lane, pe);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int q = 0; q < 64; ++q) h[g][q] = fmaxf(acc[g][q >> 4][q & 15] * bias[g][q], 0.0f);
+    }
+    // layers 1..4
+#pragma unroll 1
+    for (int layer = 1; layer <= 4; ++layer) {
+        __syncthreads();
+        stage_weights(wbuf, packed + L.l1 + (size_t)(layer - 1) * seg_floats(ACT_STEPS, 4), WBUF_FLOATS, tid);
+        __syncthreads();
+        f32x16 acc[G][4];
+        init_acc<4, G>(acc, vec + V_L0 + 128 * layer + half * 64);
+        gemm_stage<ACT_STEPS / 4, 4, G>(wbuf, acc, lane, hb);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int q = 0; q < 64; ++q) h[g][q] = fmaxf(acc[g][q >> 4][q & 15] * bias[g][q], 0.0f);
+    }
+    // layer 5 on cat([pts, h])  (skip connection after layer 4, models.py:204-205)
+    {
+        f32x16 acc[G][4];
+        __syncthreads();
+        stage_weights(wbuf, packed + L.l5a, (int)seg_floats(PE_STEPS, 4), tid);
+        __syncthreads();
+        init_acc<4, G>(acc, vec + V_L0 + 128 * 5 + half * 64);
+        gemm_stage<PE_STEPS / 4, 4, G>(wbuf, acc, lane, pe);
+        __syncthreads();
+        stage_weights(wbuf, packed + L.l5b, WBUF_FLOATS, tid);
+        __syncthreads();
+        gemm_stage<ACT_STEPS / 4, 4, G>(wbuf, acc, lane, hb);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int q = 0; q < 64; ++q) h[g][q] = fmaxf(acc[g][q >> 4][q & 15] * bias[g][q], 0.0f);
+    }
+    // alpha = relu(alpha_linear(h))   (models.py:209)
+    float sigma[G];
+    {
+        const float* wa = vec + V_WA + half * 64;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float part = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 64; ++q) part = fmaf(wa[q], h[g][q], part);
+            part += __shfl_xor(part, 32);
+            sigma[g] = fmaxf(part + vec[V_BA], 0.0f);
+        }
+    }
+    if (ALPHA_ONLY) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (live[g] && half == 0) raw[p_raw[g]] = sigma[g];
+        return;
+    }
+    // feature = feature_linear(h)  (no activation, models.py:210)
+    {
+        f32x16 acc[G][4];
+        __syncthreads();
+        stage_weights(wbuf, packed + L.feat, WBUF_FLOATS, tid);
+        __syncthreads();
+        init_acc<4, G>(acc, vec + V_FEAT + half * 64);
+        gemm_stage<ACT_STEPS / 4, 4, G>(wbuf, acc, lane, hb);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int q = 0; q < 64; ++q) h[g][q] = acc[g][q >> 4][q & 15];
+    }
+    // h_v = relu(views_linears[0](cat[feature, dir]))   (models.py:211-215)
+    {
+        float d0[G], d1[G], d2[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int64_t ray = p[g] / S;
+            d0[g] = dirs[ray * dirs_stride + 0]; d1[g] = dirs[ray * dirs_stride + 1]; d2[g] = dirs[ray * dirs_stride + 2];
+        }
+        f32x16 acc[G][2];
+        __syncthreads();
+        stage_weights(wbuf, packed + L.views, (int)seg_floats(VIEW_STEPS, 2), tid);
+        __syncthreads();
+        init_acc<2, G>(acc, vec + V_VIEWS + half * 32);
+        gemm_stage<VIEW_STEPS / 4, 2, G>(wbuf, acc, lane, [&](int g, int t) {
+            return t < ACT_STEPS ? h[g][t < ACT_STEPS ? t : 0]
+                 : t == ACT_STEPS ? (half ? d1[g] : d0[g]) : t == ACT_STEPS + 1 ? (half ? 0.0f : d2[g]) : 0.0f;
+        });
+        // rgb = sigmoid(rgb_linear(h_v))   (models.py:217);  out = cat([rgb, alpha]) models.py:218
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float rgb[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* wr = vec + V_WR + c * 64 + half * 32;
+                float part = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 32; ++q) part = fmaf(wr[q], fmaxf(acc[g][q >> 4][q & 15], 0.0f), part);
+                part += __shfl_xor(part, 32);
+                const float x = part + vec[V_BR + c];
+                rgb[c] = 1.0f / (1.0f + expf(-x));
+            }
+            if (live[g] && half == 0)
+                *reinterpret_cast<f32x4*>(raw + p_raw[g] * 4) = f32x4{rgb[0], rgb[1], rgb[2], sigma[g]};
+        }
+    }
+}
+
+// tuning knob (A/B benchmarking only): 0 = 32 pts/wave, 2 waves/SIMD; 1 = 64 pts/wave, 1 wave/SIMD; 2 = 32 pts/wave, 1 wave/SIMD
+static int g_mlp_variant = 0;
+extern "C" int mvsnerf_tune(const char* key, int value)
+{
+    if (!key) return MVSNERF_EINVAL;
+    if (__builtin_strcmp(key, "mlp_variant") == 0) { if (value < 0 || value > 2) return MVSNERF_EINVAL; g_mlp_variant = value; return MVSNERF_OK; }
+    return MVSNERF_EINVAL;
+}
+
+template <bool AO, int G, int WPS>
+static int launch_mlp(const float* packed, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
+                      const float* dirs, int dirs_stride, int64_t P, int S, float* raw, hipStream_t st)
+{
+    const size_t lds_bytes = LDS_FLOATS * sizeof(float);
+    static bool attr_set = false;   // raising the dynamic-LDS cap is idempotent; no other state
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<AO, G, WPS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    mlp_fwd_kernel<AO, G, WPS><<<mvs_cdiv(P, 128 * G), 256, lds_bytes, st>>>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+extern "C" int mvsnerf_mlp_fwd(const float* packed, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
+                               const float* dirs, int dirs_stride, int64_t N, int S, int alpha_only, float* raw, void* stream)
+{
+    if (!packed || !ndc || !feat || !raw || N < 0 || S < 1 || feat_stride < F || ndc_stride < 3) return MVSNERF_EINVAL;
+    if (!alpha_only && dirs_stride < 3) return MVSNERF_EINVAL;
+    if (!alpha_only && !dirs) return MVSNERF_EINVAL;
+    if (F < 2 || F > MAX_F || (F & 1)) return MVSNERF_EUNSUPPORTED;
+    if (!mvs_aligned16(packed) || !mvs_aligned16(raw)) return MVSNERF_EALIGN;
+    const int64_t P = N * S;
+    if (P == 0) return MVSNERF_OK;
+    hipStream_t st = (hipStream_t)stream;
+#define MVS_MLP(AO, G, WPS) launch_mlp<AO, G, WPS>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, st)
+    switch (g_mlp_variant * 2 + (alpha_only ? 1 : 0)) {
+        case 0: return MVS_MLP(false, 1, 2);
+        case 1: return MVS_MLP(true, 1, 2);
+        case 2: return MVS_MLP(false, 2, 1);
+        case 3: return MVS_MLP(true, 2, 1);
+        case 4: return MVS_MLP(false, 1, 1);
+        default: return MVS_MLP(true, 1, 1);
+    }
+#undef MVS_MLP
+}

@@ -1,0 +1,265 @@
+// Gather kernels of the ray march: trilinear volume lookup, per-view colour lookup, view-direction
+// feature, and the NCDHW<->NDHWC boundary transposes.  All HBM/L2-bound; no MFMA.
+//
+// Layout: volume is channel-last vol[d][y][x][8] so that one trilinear corner = one 32-byte sector
+// and the two x-neighbours of a corner pair are one 64-byte contiguous read.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// Trilinear lookup (reference: F.grid_sample 5-D, zeros padding, align_corners=True;
+// utils.py:381-382).  4 lanes cooperate on one sample: lane q = (zc<<1|yc) owns the corner pair
+// (z0+zc, y0+yc, x0..x0+1) = 64 contiguous bytes = 4 x float4; partial sums are combined with two
+// DPP-class shuffles.  16 samples per wave => each wave-level load instruction touches 16 x 64 B.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void volume_sample_c8_kernel(
+    const float* __restrict__ vol, int D, int H, int W,
+    const float* __restrict__ ndc, int64_t P, float* __restrict__ out, int out_stride)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = tid >> 2;
+    const int q = (int)(tid & 3);
+    const bool live = p < P;
+    const int64_t pc = live ? p : (P - 1);
+    // same op order as the reference: grid = ndc*2-1 (utils.py:381); unnormalise ((g+1)/2)*(size-1)
+    const float gx = ndc[pc * 3 + 0] * 2.0f - 1.0f;
+    const float gy = ndc[pc * 3 + 1] * 2.0f - 1.0f;
+    const float gz = ndc[pc * 3 + 2] * 2.0f - 1.0f;
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+    const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+    const float iz = ((gz + 1.0f) / 2.0f) * (float)(D - 1);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const int zc = q >> 1, yc = q & 1;
+    // weights as ATen forms them: (x1-ix) for the low corner, (ix-x0) for the high one
+    const float wx0 = (fx + 1.0f) - ix, wx1 = ix - fx;
+    const float wy = yc ? (iy - fy) : ((fy + 1.0f) - iy);
+    const float wz = zc ? (iz - fz) : ((fz + 1.0f) - iz);
+    // NaN / huge coordinates: the float compares below reject them before any int conversion is used
+    const float cxf = fx, cyf = fy + (float)yc, czf = fz + (float)zc;
+    const bool yz_in = (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
+    const bool x0_in = yz_in && (cxf >= 0.0f) && (cxf <= (float)(W - 1));
+    const bool x1_in = yz_in && (cxf + 1.0f >= 0.0f) && (cxf + 1.0f <= (float)(W - 1));
+    f32x4 a0 = {0, 0, 0, 0}, a1 = a0, b0 = a0, b1 = a0;
+    if (x0_in || x1_in) {
+        const int x = (int)cxf, y = (int)cyf, z = (int)czf;
+        const float* base = vol + ((((int64_t)z * H + y) * W + x) << 3);
+        if (x0_in) { a0 = *reinterpret_cast<const f32x4*>(base);     a1 = *reinterpret_cast<const f32x4*>(base + 4); }
+        if (x1_in) { b0 = *reinterpret_cast<const f32x4*>(base + 8); b1 = *reinterpret_cast<const f32x4*>(base + 12); }
+    }
+    const float w0 = wx0 * wy * wz, w1 = wx1 * wy * wz;
+    f32x4 s0 = a0 * w0 + b0 * w1;
+    f32x4 s1 = a1 * w0 + b1 * w1;
+    // reduce over the 4 lanes of the sample (xor 1, xor 2)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        s0[c] += __shfl_xor(s0[c], 1); s1[c] += __shfl_xor(s1[c], 1);
+        s0[c] += __shfl_xor(s0[c], 2); s1[c] += __shfl_xor(s1[c], 2);
+    }
+    if (live) {
+        float* o = out + p * out_stride;
+        // lane q stores channels 2q, 2q+1 -> the 4 lanes of a sample write 32 contiguous bytes
+        const float v0 = q == 0 ? s0[0] : q == 1 ? s0[2] : q == 2 ? s1[0] : s1[2];
+        const float v1 = q == 0 ? s0[1] : q == 1 ? s0[3] : q == 2 ? s1[1] : s1[3];
+        *reinterpret_cast<float2*>(o + 2 * q) = make_float2(v0, v1);
+    }
+}
+
+// Generic-C fallback of the same op (C != 8, e.g. colour volumes): one thread per (sample, channel).
+__global__ __launch_bounds__(256) void volume_sample_generic_kernel(
+    const float* __restrict__ vol, int D, int H, int W, int C,
+    const float* __restrict__ ndc, int64_t P, float* __restrict__ out, int out_stride)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= P * C) return;
+    const int64_t p = tid / C;
+    const int c = (int)(tid - p * C);
+    const float ix = ((ndc[p * 3 + 0] * 2.0f - 1.0f + 1.0f) / 2.0f) * (float)(W - 1);
+    const float iy = ((ndc[p * 3 + 1] * 2.0f - 1.0f + 1.0f) / 2.0f) * (float)(H - 1);
+    const float iz = ((ndc[p * 3 + 2] * 2.0f - 1.0f + 1.0f) / 2.0f) * (float)(D - 1);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int zc = k >> 2, yc = (k >> 1) & 1, xc = k & 1;
+        const float cx = fx + xc, cy = fy + yc, cz = fz + zc;
+        const float w = (xc ? ix - fx : fx + 1.0f - ix) * (yc ? iy - fy : fy + 1.0f - iy) * (zc ? iz - fz : fz + 1.0f - iz);
+        if (cx >= 0.0f && cx <= (float)(W - 1) && cy >= 0.0f && cy <= (float)(H - 1) && cz >= 0.0f && cz <= (float)(D - 1))
+            acc += vol[((((int64_t)cz * H + (int)cy) * W + (int)cx)) * C + c] * w;
+    }
+    out[p * out_stride + c] = acc;
+}
+
+extern "C" int mvsnerf_volume_sample_fwd(const float* vol, int D, int H, int W, int C,
+                                         const float* ndc, int64_t P, float* out, int out_stride, void* stream)
+{
+    if (!vol || !ndc || !out || D < 1 || H < 1 || W < 1 || C < 1 || P < 0 || out_stride < C) return MVSNERF_EINVAL;
+    if (P == 0) return MVSNERF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 8) {
+        if (!mvs_aligned16(vol)) return MVSNERF_EALIGN;
+        if ((out_stride & 1) || (reinterpret_cast<uintptr_t>(out) & 7u)) return MVSNERF_EALIGN;
+        volume_sample_c8_kernel<<<mvs_cdiv(P * 4, 256), 256, 0, st>>>(vol, D, H, W, ndc, P, out, out_stride);
+    } else {
+        volume_sample_generic_kernel<<<mvs_cdiv(P * C, 256), 256, 0, st>>>(vol, D, H, W, C, ndc, P, out, out_stride);
+    }
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-view colour lookup (utils.py:300-332).  One thread per (sample, view).  Camera matrices are
+// wave-uniform per view only if V divides the wave, so they are read through the vector path from a
+// 21-float-per-view table (L1/L2 resident).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void color_sample_kernel(
+    const float* __restrict__ imgs, int V, int H, int W,
+    const float* __restrict__ w2c, const float* __restrict__ Kmat,
+    const float* __restrict__ pts, int64_t P, int with_mask, float* __restrict__ out, int out_stride)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= P * V) return;
+    const int64_t p = tid / V;
+    const int v = (int)(tid - p * V);
+    const float x = pts[p * 3 + 0], y = pts[p * 3 + 1], z = pts[p * 3 + 2];
+    const float* M = w2c + v * 16;
+    const float* K = Kmat + v * 9;
+    // get_ndc_coordinate utils.py:124: p_cam = pts @ R^T + T   (k-ordered fma chain like sgemm)
+    const float cx = fmaf(z, M[2],  fmaf(y, M[1], x * M[0]))  + M[3];
+    const float cy = fmaf(z, M[6],  fmaf(y, M[5], x * M[4]))  + M[7];
+    const float cz = fmaf(z, M[10], fmaf(y, M[9], x * M[8]))  + M[11];
+    // :128  q = p_cam @ K^T
+    const float qx = fmaf(cz, K[2], fmaf(cy, K[1], cx * K[0]));
+    const float qy = fmaf(cz, K[5], fmaf(cy, K[4], cx * K[3]));
+    const float qz = fmaf(cz, K[8], fmaf(cy, K[7], cx * K[6]));
+    // :129  /z, / inv_scale ; utils.py:317  grid = xy*2-1
+    const float gx = ((qx / qz + 0.0f) / (float)(W - 1)) * 2.0f - 1.0f;
+    const float gy = ((qy / qz + 0.0f) / (float)(H - 1)) * 2.0f - 1.0f;
+    // grid_sample bilinear, border padding, align_corners=True
+    float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+    float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+    ix = fminf(fmaxf(ix, 0.0f), (float)(W - 1));   // clip_coordinates (NaN -> 0 like ATen's min/max order)
+    iy = fminf(fmaxf(iy, 0.0f), (float)(H - 1));
+    if (!(ix == ix)) ix = 0.0f;
+    if (!(iy == iy)) iy = 0.0f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
+    const bool x1in = x0 + 1 <= W - 1, y1in = y0 + 1 <= H - 1;
+    const float wnw = wx0 * wy0, wne = wx1 * wy0, wsw = wx0 * wy1, wse = wx1 * wy1;
+    const int Cv = 3 + (with_mask ? 1 : 0);
+    float* o = out + p * out_stride + v * Cv;
+    const float* img = imgs + (int64_t)v * 3 * H * W;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* pl = img + (int64_t)c * H * W;
+        const int64_t r0 = (int64_t)y0 * W + x0;
+        float acc = pl[r0] * wnw;
+        if (x1in) acc += pl[r0 + 1] * wne;
+        if (y1in) acc += pl[r0 + W] * wsw;
+        if (x1in && y1in) acc += pl[r0 + W + 1] * wse;
+        o[c] = acc;
+    }
+    if (with_mask) o[3] = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;
+}
+
+extern "C" int mvsnerf_color_sample_fwd(const float* imgs, int V, int H, int W, const float* w2c, const float* K,
+                                        const float* pts, int64_t P, int with_mask, float* out, int out_stride, void* stream)
+{
+    if (!imgs || !w2c || !K || !pts || !out || V < 1 || H < 2 || W < 2 || P < 0) return MVSNERF_EINVAL;
+    if (out_stride < V * (3 + (with_mask ? 1 : 0))) return MVSNERF_EINVAL;
+    if (P == 0) return MVSNERF_OK;
+    color_sample_kernel<<<mvs_cdiv(P * V, 256), 256, 0, (hipStream_t)stream>>>(imgs, V, H, W, w2c, K, pts, P, with_mask, out, out_stride);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dirs = normalise(rays_dir) @ R_ref^T     (renderer.py:142-147, 111-122)
+// ---------------------------------------------------------------------------------------------
+__global__ void dir_feature_kernel(const float* __restrict__ rays_dir, const float* __restrict__ w2c, int64_t N, int normalize, float* __restrict__ out)
+{
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float dx = rays_dir[n * 3], dy = rays_dir[n * 3 + 1], dz = rays_dir[n * 3 + 2];
+    const float nrm = normalize ? sqrtf(dx * dx + dy * dy + dz * dz) : 1.0f;   // torch.norm
+    const float ux = dx / nrm, uy = dy / nrm, uz = dz / nrm;
+    if (w2c) {
+        out[n * 3 + 0] = fmaf(uz, w2c[2],  fmaf(uy, w2c[1], ux * w2c[0]));
+        out[n * 3 + 1] = fmaf(uz, w2c[6],  fmaf(uy, w2c[5], ux * w2c[4]));
+        out[n * 3 + 2] = fmaf(uz, w2c[10], fmaf(uy, w2c[9], ux * w2c[8]));
+    } else {
+        out[n * 3 + 0] = ux; out[n * 3 + 1] = uy; out[n * 3 + 2] = uz;
+    }
+}
+
+extern "C" int mvsnerf_dir_feature_fwd(const float* rays_dir, const float* w2c_ref, int64_t N, int normalize, float* dirs_out, void* stream)
+{
+    if (!rays_dir || !dirs_out || N < 0) return MVSNERF_EINVAL;
+    if (N == 0) return MVSNERF_OK;
+    dir_feature_kernel<<<mvs_cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(rays_dir, w2c_ref, N, normalize, dirs_out);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Boundary transposes (C small): one thread per voxel, C strided reads / one contiguous C-vector write.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ncdhw_to_ndhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int64_t n_vox)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_vox) return;
+    for (int c = 0; c < C; ++c) dst[i * C + c] = src[(int64_t)c * n_vox + i];
+}
+__global__ __launch_bounds__(256) void ndhwc_to_ncdhw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int64_t n_vox)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_vox) return;
+    for (int c = 0; c < C; ++c) dst[(int64_t)c * n_vox + i] = src[i * C + c];
+}
+
+extern "C" int mvsnerf_ncdhw_to_ndhwc(const float* src, float* dst, int C, int D, int H, int W, void* stream)
+{
+    if (!src || !dst || C < 1 || D < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
+    const int64_t n = (int64_t)D * H * W;
+    ncdhw_to_ndhwc_kernel<<<mvs_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(src, dst, C, n);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+extern "C" int mvsnerf_ndhwc_to_ncdhw(const float* src, float* dst, int C, int D, int H, int W, void* stream)
+{
+    if (!src || !dst || C < 1 || D < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
+    const int64_t n = (int64_t)D * H * W;
+    ndhwc_to_ncdhw_kernel<<<mvs_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(src, dst, C, n);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stand-alone positional encoding (Embedder.embed models.py:47-51) for callers that use embed_fn
+// directly; the MLP kernel embeds internally and never materialises this.
+// out[p] = [x(d) | sin(x_c 2^f) f-major (d*L) | cos(...) (d*L)]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ x, int64_t P, int d, int L, float* __restrict__ out)
+{
+    const int width = d * (1 + 2 * L);
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= P * width) return;
+    const int64_t p = tid / width;
+    const int k = (int)(tid - p * width);
+    float v;
+    if (k < d) v = x[p * d + k];
+    else {
+        const int j = (k - d) % (d * L), f = j / d, c = j - f * d;
+        const float a = x[p * d + c] * (float)(1u << f);
+        v = (k - d) < d * L ? sinf(a) : cosf(a);
+    }
+    out[tid] = v;
+}
+
+extern "C" int mvsnerf_posenc_fwd(const float* x, int64_t P, int d, int L, float* out, void* stream)
+{
+    if (!x || !out || P < 0 || d < 1 || L < 0 || L > 30) return MVSNERF_EINVAL;
+    if (P == 0) return MVSNERF_OK;
+    posenc_kernel<<<mvs_cdiv(P * d * (1 + 2 * L), 256), 256, 0, (hipStream_t)stream>>>(x, P, d, L, out);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}

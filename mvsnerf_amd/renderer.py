@@ -1,0 +1,123 @@
+"""Drop-in for the reference's renderer.py (same callables) on libmvsnerf_hip.so.
+
+`rendering` takes the fused one-call path (ops.raymarch) whenever it is handed what
+`create_nerf_mvs` builds; every individual function is also HIP-backed so that code calling them
+piecemeal (notebooks, render_density) keeps working.
+"""
+import torch
+
+from . import ops
+from .utils import index_point_feature, build_color_volume, normal_vect  # noqa: F401  (reference re-exports)
+
+
+def depth2dist(z_vals, cos_angle):
+    """renderer.py:5-11.  Kept for API parity; raw2alpha ignores its result (renderer.py:18-26)."""
+    d = z_vals[..., 1:] - z_vals[..., :-1]
+    d = torch.cat([d, torch.full_like(d[..., :1], 1e10)], -1)
+    return d * cos_angle.unsqueeze(-1)
+
+
+def raw2alpha(sigma, dist=None, net_type="v0"):
+    """renderer.py:18-26 -> (alpha, weights, alpha_softmax).  `dist` is ignored, as in the reference.
+    The softmax the reference also returns is never consumed; it is computed lazily with torch only if
+    a caller actually unpacks and uses it."""
+    raw = torch.zeros((*sigma.shape, 4), device=sigma.device, dtype=torch.float32)
+    raw[..., 3] = sigma
+    _, _, _, weights, _, alpha = ops.composite(raw, torch.zeros_like(sigma), False)
+    return alpha, weights, torch.softmax(sigma, 1)
+
+
+def raw2outputs(raw, z_vals, dists=None, white_bkgd=False, net_type="v2"):
+    """renderer.py:65-92 -> (rgb_map, disp_map, acc_map, weights, depth_map, alpha)."""
+    return ops.composite(raw.contiguous(), z_vals.contiguous(), white_bkgd)
+
+
+def batchify(fn, chunk):
+    """renderer.py:28-40.  The fused MLP kernel needs no chunking; kept for callers that pass plain modules."""
+    if chunk is None:
+        return fn
+
+    def ret(inputs, alpha_only):
+        f = fn.forward_alpha if alpha_only else fn
+        return torch.cat([f(inputs[i:i + chunk]) for i in range(0, inputs.shape[0], chunk)], 0)
+    return ret
+
+
+def run_network_mvs(pts, viewdirs, alpha_feat, fn, embed_fn, embeddirs_fn, netchunk=1024):
+    """renderer.py:42-63.  pts (N,S,3) NDC, viewdirs (N,3) or None, alpha_feat (N,S,F) -> (N,S,4|1).
+    With our MVSNeRF + Embedder(10) the 63-wide embedding and the 86-wide concat are never built."""
+    from .models import MVSNeRF, Embedder
+    fused_ok = (isinstance(fn, MVSNeRF) and isinstance(embed_fn, Embedder) and embed_fn.fusable
+                and embeddirs_fn is None and alpha_feat is not None)
+    if not fused_ok:
+        raise NotImplementedError(
+            "run_network_mvs: only the configuration the reference ships is built as a HIP kernel "
+            "(MVSNeRF net_type v0, pts embedder multires=10, no dir embedder, alpha_feat given)")
+    if viewdirs is not None and viewdirs.dim() == 3:
+        raise NotImplementedError("run_network_mvs: per-sample view directions are not on the hot path")
+    N, S = pts.shape[:2]
+    raw = fn.query(pts, alpha_feat, viewdirs, N, S)
+    return raw.view(N, S, -1)
+
+
+def gen_dir_feature(w2c_ref, rays_dir):
+    """renderer.py:111-122: rays_dir @ w2c_ref[:3,:3]^T (caller passes unit directions)."""
+    return ops.dir_feature(rays_dir.contiguous(), w2c_ref.contiguous(), normalize=False)
+
+
+def gen_pts_feats(imgs, volume_feature, rays_pts, pose_ref, rays_ndc, feat_dim, img_feat=None, img_downscale=1.0,
+                  use_color_volume=False, net_type="v0"):
+    """renderer.py:124-136: [8 volume channels | V x (r,g,b,mask)] written in place into one (N,S,feat_dim) tensor."""
+    if img_feat is not None or use_color_volume:
+        raise NotImplementedError("gen_pts_feats: img_feat / use_color_volume are outside the shipped hot path")
+    from .models import RefVolume
+    vol = volume_feature.feat_volume if isinstance(volume_feature, RefVolume) else volume_feature
+    vol_cl = ops.channels_last_volume(vol)
+    N, S = rays_pts.shape[:2]
+    V = imgs.shape[1]
+    if feat_dim != 8 + 4 * V:
+        raise RuntimeError(f"feat_dim {feat_dim} != 8 + 4*V ({V} views)")
+    out = torch.empty((N, S, feat_dim), device=rays_pts.device, dtype=torch.float32)
+    ops.volume_sample(vol_cl, rays_ndc.contiguous(), out=out, out_stride=feat_dim)
+    ops.color_sample(imgs[0].contiguous(), pose_ref["w2cs"][:V].contiguous(), pose_ref["intrinsics"][:V].contiguous(),
+                     rays_pts.contiguous(), with_mask=True, out=out, out_ptr=out.data_ptr() + 8 * 4, out_stride=feat_dim)
+    return out
+
+
+def rendering(args, pose_ref, rays_pts, rays_ndc, depth_candidates, rays_o, rays_dir,
+              volume_feature=None, imgs=None, network_fn=None, img_feat=None, network_query_fn=None, white_bkgd=False, **kwargs):
+    """renderer.py:138-165.  Returns (rgb_map, input_feat, weights, depth_map, alpha, {}) - note that the
+    reference's callers name the 2nd/3rd entries `disp`/`acc` (train_mvs_nerf_pl.py:123)."""
+    from .models import MVSNeRF, RefVolume
+    fused = (pose_ref is not None and isinstance(network_fn, MVSNeRF) and img_feat is None
+             and not getattr(args, "use_color_volume", False) and getattr(network_query_fn, "_mvsnerf_fused", False))
+    if fused:
+        vol = volume_feature.feat_volume if isinstance(volume_feature, RefVolume) else volume_feature
+        V = imgs.shape[1]
+        if args.feat_dim != 8 + 4 * V:
+            raise RuntimeError(f"args.feat_dim {args.feat_dim} != 8 + 4*V ({V} views)")
+        out = ops.raymarch(ops.channels_last_volume(vol), imgs[0].contiguous(),
+                           pose_ref["w2cs"][:V].contiguous(), pose_ref["intrinsics"][:V].contiguous(),
+                           network_fn.packed(args.feat_dim), rays_pts.contiguous(), rays_ndc.contiguous(),
+                           depth_candidates.contiguous(), rays_dir.contiguous(), white_bkgd)
+        rendering.last_raw = out["raw"]          # sigma lives in raw[...,3]; kept for parity tests / density queries
+        return out["rgb_map"], out["input_feat"], out["weights"], out["depth"], out["alpha"], {}
+
+    # generic composition of the individually HIP-backed pieces (same order as the reference)
+    # rays_dir/|rays_dir| then rotation into the reference camera (renderer.py:142-147), one kernel
+    angle = ops.dir_feature(rays_dir.contiguous(), pose_ref["w2cs"][0].contiguous() if pose_ref is not None else None, normalize=True)
+    input_feat = gen_pts_feats(imgs, volume_feature, rays_pts, pose_ref, rays_ndc, args.feat_dim, img_feat,
+                               args.img_downscale, args.use_color_volume, args.net_type)
+    raw = network_query_fn(rays_ndc, angle, input_feat, network_fn)
+    rendering.last_raw = raw
+    rgb_map, _, _, weights, depth_map, alpha = raw2outputs(raw, depth_candidates, None, white_bkgd, args.net_type)
+    return rgb_map, input_feat, weights, depth_map, alpha, {}
+
+
+def render_density(network_fn, rays_pts, density_feature, network_query_fn, chunk=1024 * 5):
+    """renderer.py:167-177: sigma-only queries (forward_alpha path)."""
+    out = []
+    dev = density_feature.device
+    for i in range(0, rays_pts.shape[0], chunk):
+        out.append(network_query_fn(rays_pts[i:i + chunk].to(dev), None, density_feature[i:i + chunk], network_fn))
+    return torch.cat(out)

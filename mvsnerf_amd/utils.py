@@ -1,0 +1,147 @@
+"""Drop-in replacements for the hot-path helpers of the reference's utils.py (same names, argument
+order, defaults and return layouts - SURVEY.md 8b), backed by libmvsnerf_hip.so.
+
+Ray generation (get_rays_mvs / build_rays / build_rays_test / get_ndc_coordinate) stays host-side
+torch, exactly as in the reference, because it owns the RNG draws whose ray indices must be bit-exact
+(pixel ids: CPU RNG, utils.py:93; jitter: device RNG, utils.py:220).
+"""
+import torch
+
+from . import ops
+
+
+# ------------------------------------------------------------------ metrics used by training_step
+def img2mse(x, y):
+    return torch.mean((x - y) ** 2)
+
+
+def mse2psnr(x):
+    return -10.0 * torch.log(x) / torch.log(torch.tensor([10.0], device=x.device if torch.is_tensor(x) else None))
+
+
+# ------------------------------------------------------------------ rays (reference utils.py:86-297)
+def get_rays_mvs(H, W, intrinsic, c2w, N=1024, isRandom=True, is_precrop_iters=False, chunk=-1, idx=-1):
+    """utils.py:86-108.  Pixel ids are drawn on the CPU generator in the order xs then ys, so a seeded run
+    picks bit-identical rays to the reference.  Returns rays_o (3,), rays_d (N,3), pixel_coordinates (2,N)=[row,col]."""
+    dev = c2w.device
+    if isRandom:
+        if is_precrop_iters and torch.rand((1,)) > 0.3:
+            xs = torch.randint(W // 6, W - W // 6, (N,)).float().to(dev)
+            ys = torch.randint(H // 6, H - H // 6, (N,)).float().to(dev)
+        else:
+            xs = torch.randint(0, W, (N,)).float().to(dev)
+            ys = torch.randint(0, H, (N,)).float().to(dev)
+    else:
+        gy, gx = torch.meshgrid(torch.linspace(0, H - 1, H), torch.linspace(0, W - 1, W), indexing="ij")
+        ys, xs = gy.reshape(-1), gx.reshape(-1)
+        if chunk > 0:
+            ys, xs = ys[idx * chunk:(idx + 1) * chunk], xs[idx * chunk:(idx + 1) * chunk]
+        ys, xs = ys.to(dev), xs.to(dev)
+    cam_dirs = torch.stack([(xs - intrinsic[0, 2]) / intrinsic[0, 0],
+                            (ys - intrinsic[1, 2]) / intrinsic[1, 1],
+                            torch.ones_like(xs)], -1)
+    return c2w[:3, -1].clone(), cam_dirs @ c2w[:3, :3].t(), torch.stack((ys, xs))
+
+
+def get_ndc_coordinate(w2c_ref, intrinsic_ref, point_samples, inv_scale, near=2, far=6, pad=0, lindisp=False):
+    """utils.py:112-146: world points (N_rays,N_samples,3) -> reference-view NDC in [0,1]."""
+    n_rays, n_samples = point_samples.shape[:2]
+    p = point_samples.reshape(-1, 3)
+    if w2c_ref is not None:
+        p = torch.matmul(p, w2c_ref[:3, :3].t()) + w2c_ref[:3, 3:].reshape(1, 3)
+    if intrinsic_ref is not None:
+        q = p @ intrinsic_ref.t()
+        xy = (q[:, :2] / q[:, -1:] + 0.0) / inv_scale.reshape(1, 2)
+        z = (q[:, 2] - near) / (far - near) if not lindisp else (1.0 / q[:, 2] - 1.0 / near) / (1.0 / far - 1.0 / near)
+        q = torch.cat([xy, z[:, None]], -1)
+    else:
+        q = (p - near.view(1, 3)) / (far.view(1, 3) - near.view(1, 3))
+    if pad > 0:
+        w_feat, h_feat = (inv_scale + 1) / 4.0
+        x = q[:, 0] * w_feat / (w_feat + pad * 2) + pad / (w_feat + pad * 2)
+        y = q[:, 1] * h_feat / (h_feat + pad * 2) + pad / (h_feat + pad * 2)
+        q = torch.stack([x, y, q[:, 2]], -1)
+    return q.view(n_rays, n_samples, 3)
+
+
+def _stratified(near, far, n_rays, n_samples, device, jitter):
+    t = torch.linspace(0.0, 1.0, steps=n_samples).view(1, n_samples).to(device)
+    z = (near * (1.0 - t) + far * t).expand([n_rays, n_samples])
+    if not jitter:
+        return z
+    mids = 0.5 * (z[..., 1:] + z[..., :-1])
+    upper = torch.cat([mids, z[..., -1:]], -1)
+    lower = torch.cat([z[..., :1], mids], -1)
+    return lower + (upper - lower) * torch.rand(z.shape, device=device)       # device RNG, as utils.py:220
+
+
+def build_rays(imgs, depths, pose_ref, w2cs, c2ws, intrinsics, near_fars, N_rays, N_samples, pad=0,
+               is_precrop_iters=False, ref_idx=0, importanceSampling=False, with_depth=False, is_volume=False):
+    """utils.py:148-241: random target-view rays for one training step (target = last view).
+    Returns (rays_pts, rays_dir, colors, rays_NDC, depth_candidates, rays_o, rays_depth, ndc_parameters)."""
+    dev = imgs.device
+    _, V, _, H, W = imgs.shape
+    w2c_ref, k_ref = pose_ref["w2cs"][ref_idx], pose_ref["intrinsics"][ref_idx]
+    inv_scale = torch.tensor([W - 1, H - 1]).to(dev)
+    near_ref, far_ref = pose_ref["near_fars"][ref_idx, 0], pose_ref["near_fars"][ref_idx, 1]
+    i = V - 1
+    rays_o, rays_d, pix = get_rays_mvs(H, W, intrinsics[i], c2ws[i].clone(), N_rays, is_precrop_iters=is_precrop_iters)
+    pix_i = pix.long()
+    colors = imgs[0, i, :, pix_i[0], pix_i[1]].permute(1, 0)
+    rays_depth = depths[0, i, pix_i[0], pix_i[1]] if depths.shape[2] != 1 else None
+    if with_depth:
+        z = near_fars[pix_i[0], pix_i[1]].reshape(-1, 1)
+    else:
+        if importanceSampling:
+            near, far = (rays_depth - 0.1).view(N_rays, 1), (rays_depth + 0.1).view(N_rays, 1)
+        else:
+            near, far = near_fars[0, i, 0], near_fars[0, i, 1]
+        z = _stratified(near, far, N_rays, N_samples, dev, jitter=True)
+    o = rays_o.reshape(1, 3).expand(N_rays, -1)
+    pts = o.unsqueeze(1) + z.unsqueeze(-1) * rays_d.unsqueeze(1)
+    ndc = get_ndc_coordinate(w2c_ref, k_ref, pts, inv_scale, near=near_ref, far=far_ref, pad=pad)
+    ndc_parameters = {"w2c_ref": w2c_ref, "intrinsic_ref": k_ref, "inv_scale": inv_scale, "near": near_ref, "far": far_ref}
+    return pts, rays_d, colors, ndc, z, o.permute(1, 0), rays_depth, ndc_parameters
+
+
+def build_rays_test(H, W, tgt_to_world, world_to_ref, intrinsic, near_fars_ref, near_fars, N_samples, pad=0, ref_idx=0,
+                    use_cpu=False, chunk=-1, idx=-1):
+    """utils.py:243-297: deterministic row-major rays of one chunk, no jitter."""
+    dev = torch.device("cpu") if use_cpu else tgt_to_world.device
+    if use_cpu:
+        tgt_to_world, world_to_ref, intrinsic = tgt_to_world.cpu(), world_to_ref.cpu(), intrinsic.cpu()
+        near_fars_ref, near_fars = near_fars_ref.cpu(), near_fars.cpu()
+    inv_scale = torch.tensor([W - 1, H - 1]).to(dev)
+    k_render = intrinsic if intrinsic.dim() == 2 else intrinsic.mean(0)
+    rays_o, rays_d, pix = get_rays_mvs(H, W, k_render, tgt_to_world, isRandom=False, chunk=chunk, idx=idx)
+    n = H * W if chunk < 0 else pix.shape[-1]
+    z = _stratified(near_fars[0], near_fars[1], n, N_samples, dev, jitter=False)
+    o = rays_o.reshape(1, 3).expand(n, -1)
+    pts = o.unsqueeze(1) + z.unsqueeze(-1) * rays_d.unsqueeze(1)
+    near, far = near_fars_ref[ref_idx, 0], near_fars_ref[ref_idx, 1]
+    ndc = get_ndc_coordinate(world_to_ref, intrinsic, pts, inv_scale, near=near, far=far, pad=pad)
+    ndc_parameters = {"w2c_ref": world_to_ref, "intrinsic_ref": intrinsic, "inv_scale": inv_scale, "near": near, "far": far}
+    return pts, rays_d, ndc, z, o, ndc_parameters
+
+
+# ------------------------------------------------------------------ gathers (HIP)
+def index_point_feature(volume_feature, ray_coordinate_ref, chunk=-1):
+    """utils.py:357-383: trilinear lookup of the (1,C,D,h,w) volume at NDC (x,y,z) in [0,1].
+    Returns (N_rays, N_samples, C) (squeezed like the reference).  `chunk` is accepted and ignored:
+    the kernel never materialises anything chunk-sized."""
+    vol_cl = ops.channels_last_volume(volume_feature)
+    ndc = ray_coordinate_ref.to(vol_cl.device, torch.float32).contiguous()
+    return ops.volume_sample(vol_cl, ndc).squeeze()
+
+
+def build_color_volume(point_samples, pose_ref, imgs, img_feat=None, downscale=1.0, with_mask=False):
+    """utils.py:300-332: per-view projected colours (+ strict in-frustum mask) -> (N_rays,N_samples,V*C)."""
+    if img_feat is not None:
+        raise NotImplementedError("build_color_volume(img_feat=...) is outside the hot path (training_step passes None)")
+    V = imgs.shape[1]
+    return ops.color_sample(imgs[0].contiguous(), pose_ref["w2cs"][:V].contiguous(), pose_ref["intrinsics"][:V].contiguous(),
+                            point_samples.contiguous(), with_mask=with_mask)
+
+
+def normal_vect(vect, dim=-1):
+    return vect / (torch.sqrt(torch.sum(vect ** 2, dim=dim, keepdim=True)) + 1e-7)
