@@ -34,15 +34,18 @@ def channels_last_volume(volume_feature):
     if cl.is_contiguous():
         dev_f32(cl, "volume")
         return cl
-    key = (v.data_ptr(), v._version, tuple(v.shape))
+    # cache key: storage identity + version.  The entry keeps the source storage alive, so the caching
+    # allocator cannot hand the same address to a different tensor while the entry exists.
+    st = v.untyped_storage()
+    key = (st.data_ptr(), v.storage_offset(), v._version, tuple(v.shape), tuple(v.stride()))
     hit = _cl_cache.get("k")
     if hit is not None and hit[0] == key:
-        return hit[1]
+        return hit[2]
     src = v.detach().contiguous()
     C, D, H, W = src.shape
     dst = torch.empty((D, H, W, C), device=src.device, dtype=torch.float32)
     check(_lib.lib().mvsnerf_ncdhw_to_ndhwc(dev_f32(src, "volume"), dst.data_ptr(), C, D, H, W, stream_ptr()), "ncdhw_to_ndhwc")
-    _cl_cache["k"] = (key, dst)
+    _cl_cache["k"] = (key, st, dst)
     return dst
 
 
