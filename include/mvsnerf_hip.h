@@ -45,6 +45,56 @@ int mvsnerf_tune(const char* key, int value);
 int mvsnerf_ncdhw_to_ndhwc(const float* src, float* dst, int C, int D, int H, int W, void* stream);
 int mvsnerf_ndhwc_to_ncdhw(const float* src, float* dst, int C, int D, int H, int W, void* stream);
 
+/* ---------------------------------------------------------------- scene encode (L1a) */
+
+/* [N][C][H][W] -> [N][H][W][Cpad] (channels >= C zero-filled): source feature maps / thumbnails are made
+ * channel-last once so that a bilinear tap of the plane sweep is one contiguous vector. */
+int mvsnerf_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int Cpad, void* stream);
+
+/* F.interpolate(mode='bilinear', align_corners=False) of NC planes (models.py:859: images -> feature resolution). */
+int mvsnerf_resize_bilinear(const float* src, float* dst, int NC, int Hi, int Wi, int Ho, int Wo, void* stream);
+
+/* Plane-sweep cost volume in one pass: utils.py:580-630 (homo_warp) + models.py:839-893
+ * (build_volume_costvar_img, with_img=1) or models.py:787-837 (build_volume_costvar, with_img=0).
+ * feats_cl[V][H][W][32], imgs_cl[V][H][W][4] (thumbnails, with_img only), proj[V][3][4] (view 0 unused),
+ * depth[D]; cost[D][H+2pad][W+2pad][CP] channel-last:
+ *   with_img: [0:3 ref rgb (padded border = 0) | 3v:3v+3 warped src rgb | 3V:3V+32 variance | zeros to CP]
+ *             masks[V][D][Hp][Wp] per-view in-frustum masks (view 0 = 1)
+ *   else:     [0:32 variance | zeros], masks[D][Hp][Wp] = view count (models.py:814-821). */
+int mvsnerf_planesweep_costvar_fwd(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,
+                                   int V, int C, int H, int W, int D, int pad, float* cost, int CP, float* masks,
+                                   int with_img, void* stream);
+
+/* Stand-alone homo_warp (utils.py:580-630) for one source view: src[C][H][W] (NCHW), proj[3][4], depth[D]
+ * -> warped[C][D][Hp][Wp], grid_out[D*Hp*Wp][2] (either may reuse a given grid_in, as models.py:872 does). */
+int mvsnerf_homo_warp_fwd(const float* src_nchw, const float* proj, const float* depth, const float* grid_in,
+                          int C, int H, int W, int D, int pad, float* warped, float* grid_out, void* stream);
+
+/* CostRegNet building blocks (models.py:674-685, 725-769), channel-last activations x[d][y][x][C].
+ * A conv input is `leaky_relu(x*scale[c]+shift[c], 0.01)` applied on load (scale == NULL: raw input, no
+ * activation), optionally plus a second such tensor (U-Net skip sums, models.py:762-766).
+ *   conv3d_pack_weights: Conv3d (Cout,Cin,3,3,3) or ConvTranspose3d (Cin,Cout,3,3,3) -> [27][cin_pad][Cout]
+ *   conv3d_fwd: k3, padding 1, stride 1|2, no bias -> raw out[Do][Ho][Wo][Cout]
+ *   conv_transpose3d_fwd: k3, stride 2, padding 1, output_padding 1 -> raw out[2D][2H][2W][Cout]
+ *   abn_stats: train-mode InPlaceABN statistics of a raw tensor -> per-channel scale/shift
+ *              (gamma=|w|+eps, biased variance) and the running_mean/var side effect (may be NULL)
+ *   abn_apply_add: materialise leaky(x1*s1+t1) [+ leaky(x2*s2+t2)] */
+int mvsnerf_conv3d_pack_weights(const float* w, int Cout, int Cin, int cin_pad, int transposed, float* packed, void* stream);
+int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const float* shift1,
+                       const float* x2, const float* scale2, const float* shift2,
+                       int Cin, int cin_ld, int D, int H, int W, const float* wpacked, int Cout, int stride,
+                       float* out, void* stream);
+int mvsnerf_conv_transpose3d_fwd(const float* x1, const float* scale1, const float* shift1,
+                                 const float* x2, const float* scale2, const float* shift2,
+                                 int Cin, int D, int H, int W, const float* wpacked, int Cout, float* out, void* stream);
+size_t mvsnerf_abn_workspace_floats(int C);
+int mvsnerf_abn_stats(const float* x, int64_t n_vox, int C, const float* weight, const float* bias,
+                      float* running_mean, float* running_var, float momentum, float eps,
+                      float* scale, float* shift, float* workspace, void* stream);
+int mvsnerf_abn_apply_add(const float* x1, const float* scale1, const float* shift1,
+                          const float* x2, const float* scale2, const float* shift2,
+                          int64_t n_vox, int C, float* out, void* stream);
+
 /* ---------------------------------------------------------------- ray march (L1b) */
 
 /* Trilinear lookup of the channel-last volume: replaces F.grid_sample 5-D in

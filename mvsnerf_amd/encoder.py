@@ -1,0 +1,385 @@
+"""Scene encoder (L1a) of the reference's models.py on libmvsnerf_hip.so: FeatureNet (2-D CNN, stays on
+PyTorch-ROCm/MIOpen for now - SURVEY.md 8f rank 1), plane-sweep variance cost volume and CostRegNet.
+
+Same class / sub-module / parameter names as the reference (models.py:661-932) so that
+`network_mvs_state_dict` of a reference checkpoint loads unchanged.
+
+Internally every 3-D tensor is channel-last in HBM; the tensors handed back to callers are logical
+NCDHW views of that memory (no copies), e.g. the neural volume is (1,8,D,h,w) with channels_last_3d
+strides and feeds the ray-march kernels without a transpose.
+"""
+import time
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, ops
+from ._lib import check, dev_f32, stream_ptr
+
+ABN_EPS, ABN_MOMENTUM, ABN_SLOPE = 1e-5, 0.1, 0.01
+
+
+# ------------------------------------------------------------------ InPlaceABN stand-in
+class InPlaceABN(nn.Module):
+    """Parameter container + 2-D forward for mapillary InPlaceABN (third-party, not in the reference tree;
+    semantics restated: y = leaky_relu(batch_norm(x, gamma=|w|+eps), 0.01)).
+    3-D use goes through the HIP kernels (abn_stats / lazy activation), never through this forward."""
+
+    def __init__(self, num_features, eps=ABN_EPS, momentum=ABN_MOMENTUM, affine=True, activation="leaky_relu", activation_param=ABN_SLOPE):
+        super().__init__()
+        self.num_features, self.eps, self.momentum, self.activation_param = num_features, eps, momentum, activation_param
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x):   # 2-D FeatureNet path (PyTorch-ROCm)
+        y = F.batch_norm(x, self.running_mean, self.running_var, self.weight.abs() + self.eps, self.bias,
+                         self.training, self.momentum, self.eps)
+        return F.leaky_relu(y, self.activation_param)
+
+
+class ConvBnReLU(nn.Module):
+    """reference models.py:661-672 (2-D)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1, norm_act=InPlaceABN):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
+        self.bn = norm_act(out_channels)
+
+    def forward(self, x):
+        return self.bn(self.conv(x))
+
+
+class FeatureNet(nn.Module):
+    """reference models.py:688-722.  (B,3,H,W) -> (B,32,H/4,W/4)."""
+
+    def __init__(self, norm_act=InPlaceABN):
+        super().__init__()
+        self.conv0 = nn.Sequential(ConvBnReLU(3, 8, 3, 1, 1, norm_act=norm_act), ConvBnReLU(8, 8, 3, 1, 1, norm_act=norm_act))
+        self.conv1 = nn.Sequential(ConvBnReLU(8, 16, 5, 2, 2, norm_act=norm_act), ConvBnReLU(16, 16, 3, 1, 1, norm_act=norm_act),
+                                   ConvBnReLU(16, 16, 3, 1, 1, norm_act=norm_act))
+        self.conv2 = nn.Sequential(ConvBnReLU(16, 32, 5, 2, 2, norm_act=norm_act), ConvBnReLU(32, 32, 3, 1, 1, norm_act=norm_act),
+                                   ConvBnReLU(32, 32, 3, 1, 1, norm_act=norm_act))
+        self.toplayer = nn.Conv2d(32, 32, 1)
+
+    def forward(self, x):
+        return self.toplayer(self.conv2(self.conv1(self.conv0(x))))
+
+
+# ------------------------------------------------------------------ channel-last plumbing
+class _Lazy:
+    """A raw conv output x[d][y][x][C] plus the (scale, shift) of its pending InPlaceABN."""
+    __slots__ = ("x", "scale", "shift", "dims")
+
+    def __init__(self, x, scale, shift, dims):
+        self.x, self.scale, self.shift, self.dims = x, scale, shift, dims      # dims = (D,H,W,C)
+
+
+def _cl_view_to_ncdhw(x_cl, C=None):
+    """(D,H,W,Cpad) channel-last buffer -> logical (1,C,D,H,W) view (no copy)."""
+    v = x_cl if C is None else x_cl[..., :C]
+    return v.permute(3, 0, 1, 2).unsqueeze(0)
+
+
+def _as_channel_last(x, cin_pad):
+    """Logical (1,C,D,H,W) tensor -> (buffer, ld) with buffer[d][y][x][ld] holding the channels first.
+    Zero-copy when x is a view produced by _cl_view_to_ncdhw with a padded stride >= cin_pad; else one HIP transpose."""
+    if x.dim() != 5 or x.shape[0] != 1:
+        raise RuntimeError(f"expected a (1,C,D,H,W) volume, got {tuple(x.shape)}")
+    _, C, D, H, W = x.shape
+    st = x.stride()
+    ld = st[4]
+    if (st[1] == 1 and st[3] == W * ld and st[2] == H * W * ld and ld >= cin_pad and ld % 4 == 0 and x.storage_offset() == 0
+            and x.untyped_storage().nbytes() >= D * H * W * ld * 4 and x.dtype == torch.float32 and x.is_cuda):
+        buf = torch.as_strided(x, (D, H, W, ld), (H * W * ld, W * ld, ld, 1))
+        return buf, ld
+    src = x[0].contiguous()
+    dst = torch.empty((D, H, W, cin_pad), device=x.device, dtype=torch.float32)
+    check(_lib.lib().mvsnerf_nchw_to_nhwc(dev_f32(src, "x"), dst.data_ptr(), 1, C, D * H, W, cin_pad, stream_ptr()), "nchw_to_nhwc")
+    return dst, cin_pad
+
+
+class _PackedConv:
+    """Caches the [27][cin_pad][Cout] re-layout of a Conv3d / ConvTranspose3d weight (re-packed when it changes)."""
+
+    def __init__(self, conv, transposed):
+        self.conv, self.transposed, self.key, self.buf = conv, transposed, None, None
+
+    def get(self):
+        w = self.conv.weight
+        key = (w.data_ptr(), w._version)
+        if key != self.key:
+            cin, cout = (w.shape[0], w.shape[1]) if self.transposed else (w.shape[1], w.shape[0])
+            cin_pad = (cin + 3) // 4 * 4
+            buf = torch.empty(27 * cin_pad * cout, device=w.device, dtype=torch.float32)
+            check(_lib.lib().mvsnerf_conv3d_pack_weights(dev_f32(w.detach().contiguous(), "conv weight"), cout, cin, cin_pad,
+                                                         int(self.transposed), buf.data_ptr(), stream_ptr()), "conv3d_pack_weights")
+            self.key, self.buf, self.cin_pad, self.cout = key, buf, cin_pad, cout
+        return self.buf
+
+
+def _abn_stats(raw, n_vox, bn, update_running=True):
+    C = bn.num_features
+    dev = raw.device
+    scale = torch.empty(C, device=dev, dtype=torch.float32)
+    shift = torch.empty(C, device=dev, dtype=torch.float32)
+    ws = torch.empty(_lib.lib().mvsnerf_abn_workspace_floats(C), device=dev, dtype=torch.float32)
+    rm = bn.running_mean.data_ptr() if update_running else 0
+    rv = bn.running_var.data_ptr() if update_running else 0
+    check(_lib.lib().mvsnerf_abn_stats(raw.data_ptr(), n_vox, C, dev_f32(bn.weight.detach(), "bn.weight"), dev_f32(bn.bias.detach(), "bn.bias"),
+                                       rm, rv, bn.momentum, bn.eps, scale.data_ptr(), shift.data_ptr(), ws.data_ptr(), stream_ptr()), "abn_stats")
+    if update_running:
+        bn.num_batches_tracked += 1
+    return scale, shift
+
+
+def _ptrs(src):
+    """(x, scale, shift) pointers of a _Lazy | raw tensor | None."""
+    if src is None:
+        return 0, 0, 0
+    if isinstance(src, _Lazy):
+        return src.x.data_ptr(), src.scale.data_ptr(), src.shift.data_ptr()
+    return src.data_ptr(), 0, 0
+
+
+def _conv(src1, src2, dims_in, cin_ld, packed, stride):
+    D, H, W, _ = dims_in
+    Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
+    w = packed.get()
+    out = torch.empty((Do, Ho, Wo, packed.cout), device=w.device, dtype=torch.float32)
+    check(_lib.lib().mvsnerf_conv3d_fwd(*_ptrs(src1), *_ptrs(src2), packed.cin_pad, cin_ld, D, H, W, w.data_ptr(), packed.cout, stride,
+                                        out.data_ptr(), stream_ptr()), "conv3d_fwd")
+    return out
+
+
+def _conv_t(src1, src2, dims_in, packed):
+    D, H, W, _ = dims_in
+    w = packed.get()
+    out = torch.empty((2 * D, 2 * H, 2 * W, packed.cout), device=w.device, dtype=torch.float32)
+    check(_lib.lib().mvsnerf_conv_transpose3d_fwd(*_ptrs(src1), *_ptrs(src2), packed.cin_pad, D, H, W, w.data_ptr(), packed.cout,
+                                                  out.data_ptr(), stream_ptr()), "conv_transpose3d_fwd")
+    return out
+
+
+def _apply_add(a, b=None):
+    D, H, W, C = a.dims
+    out = torch.empty((D, H, W, C), device=a.x.device, dtype=torch.float32)
+    check(_lib.lib().mvsnerf_abn_apply_add(*_ptrs(a), *_ptrs(b), D * H * W, C, out.data_ptr(), stream_ptr()), "abn_apply_add")
+    return out
+
+
+# ------------------------------------------------------------------ 3-D blocks
+class ConvBnReLU3D(nn.Module):
+    """reference models.py:674-685: Conv3d(k3, bias=False) + InPlaceABN (train-mode statistics)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1, norm_act=InPlaceABN):
+        super().__init__()
+        if kernel_size != 3 or pad != 1 or stride not in (1, 2):
+            raise NotImplementedError("ConvBnReLU3D: the HIP kernel is built for k=3, pad=1, stride 1|2 (all the reference uses)")
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
+        self.bn = norm_act(out_channels)
+        self.stride = stride
+        self._packed = _PackedConv(self.conv, False)
+
+    def lazy(self, src1, dims_in, cin_ld, src2=None):
+        raw = _conv(src1, src2, dims_in, cin_ld, self._packed, self.stride)
+        D, H, W, C = raw.shape
+        scale, shift = _abn_stats(raw, D * H * W, self.bn, update_running=self.bn.training)
+        return _Lazy(raw, scale, shift, (D, H, W, C))
+
+    def forward(self, x):
+        """Stand-alone call on a logical (1,Cin,D,H,W) tensor -> activated (1,Cout,D',H',W') (channel-last memory)."""
+        ops._need_no_grad(x, *self.parameters(), op="ConvBnReLU3D")
+        buf, ld = _as_channel_last(x, self._packed_cin_pad())
+        D, H, W = x.shape[2:]
+        return _cl_view_to_ncdhw(_apply_add(self.lazy(buf, (D, H, W, ld), ld)))
+
+    def _packed_cin_pad(self):
+        self._packed.get()
+        return self._packed.cin_pad
+
+
+class _UpBlock(nn.Sequential):
+    """nn.Sequential(ConvTranspose3d, InPlaceABN) of models.py:739-752 (keys `convN.0.weight`, `convN.1.*`)."""
+
+    def __init__(self, cin, cout, norm_act):
+        super().__init__(nn.ConvTranspose3d(cin, cout, 3, padding=1, output_padding=1, stride=2, bias=False), norm_act(cout))
+        self._packed = _PackedConv(self[0], True)
+
+    def lazy(self, src1, dims_in, src2=None):
+        raw = _conv_t(src1, src2, dims_in, self._packed)
+        D, H, W, C = raw.shape
+        scale, shift = _abn_stats(raw, D * H * W, self[1], update_running=self[1].training)
+        return _Lazy(raw, scale, shift, (D, H, W, C))
+
+    def forward(self, x):
+        ops._need_no_grad(x, *self.parameters(), op="ConvTranspose3d+ABN")
+        self._packed.get()
+        buf, ld = _as_channel_last(x, self._packed.cin_pad)
+        if ld != self._packed.cin_pad:
+            raise RuntimeError("transposed conv input must be densely channel-last")
+        D, H, W = x.shape[2:]
+        return _cl_view_to_ncdhw(_apply_add(self.lazy(buf, (D, H, W, ld))))
+
+
+class CostRegNet(nn.Module):
+    """reference models.py:725-769: 3-D U-Net 41->8->16->32->64->32->16->8 with skip sums."""
+
+    def __init__(self, in_channels, norm_act=InPlaceABN):
+        super().__init__()
+        self.conv0 = ConvBnReLU3D(in_channels, 8, norm_act=norm_act)
+        self.conv1 = ConvBnReLU3D(8, 16, stride=2, norm_act=norm_act)
+        self.conv2 = ConvBnReLU3D(16, 16, norm_act=norm_act)
+        self.conv3 = ConvBnReLU3D(16, 32, stride=2, norm_act=norm_act)
+        self.conv4 = ConvBnReLU3D(32, 32, norm_act=norm_act)
+        self.conv5 = ConvBnReLU3D(32, 64, stride=2, norm_act=norm_act)
+        self.conv6 = ConvBnReLU3D(64, 64, norm_act=norm_act)
+        self.conv7 = _UpBlock(64, 32, norm_act)
+        self.conv9 = _UpBlock(32, 16, norm_act)
+        self.conv11 = _UpBlock(16, 8, norm_act)
+
+    def forward(self, x):
+        """x: logical (1,Cin,D,h,w) cost volume (D,h,w divisible by 8).  Returns (1,8,D,h,w), channel-last memory."""
+        ops._need_no_grad(x, *self.parameters(), op="CostRegNet")
+        _, C, D, H, W = x.shape
+        if D % 8 or H % 8 or W % 8:
+            raise RuntimeError(f"CostRegNet needs D,h,w divisible by 8 (three stride-2 stages), got {(D, H, W)}")
+        cin_pad = self.conv0._packed_cin_pad()
+        buf, ld = _as_channel_last(x, cin_pad)
+        c0 = self.conv0.lazy(buf, (D, H, W, ld), ld)
+        c1 = self.conv1.lazy(c0, c0.dims, 8)
+        c2 = self.conv2.lazy(c1, c1.dims, 16)
+        c3 = self.conv3.lazy(c2, c2.dims, 16)
+        c4 = self.conv4.lazy(c3, c3.dims, 32)
+        c5 = self.conv5.lazy(c4, c4.dims, 32)
+        c6 = self.conv6.lazy(c5, c5.dims, 64)
+        u7 = self.conv7.lazy(c6, c6.dims)                       # x = conv4 + conv7(x)   (models.py:762)
+        u9 = self.conv9.lazy(c4, c4.dims, src2=u7)              # x = conv2 + conv9(x)   (:764)
+        u11 = self.conv11.lazy(c2, c2.dims, src2=u9)            # x = conv0 + conv11(x)  (:766)
+        return _cl_view_to_ncdhw(_apply_add(c0, u11))
+
+
+# ------------------------------------------------------------------ MVSNet
+def homo_warp(src_feat, proj_mat, depth_values, src_grid=None, pad=0):
+    """reference utils.py:580-630.  src_feat (1,C,H,W); proj_mat (1,3,4); depth_values (1,D).
+    Returns warped (1,C,D,H+2p,W+2p) and src_grid (1,D,W+2p,H+2p,2) (the reference's axis naming; flat order d,y,x)."""
+    ops._need_no_grad(src_feat, op="homo_warp")
+    B, C, H, W = src_feat.shape
+    if B != 1:
+        raise RuntimeError("homo_warp: batch must be 1")
+    Hp, Wp = H + 2 * pad, W + 2 * pad
+    dev = src_feat.device
+    if src_grid is None:
+        D = depth_values.shape[1]
+        grid_in, grid_out = 0, torch.empty((1, D, Wp, Hp, 2), device=dev, dtype=torch.float32)
+        proj_p, dep_p = dev_f32(proj_mat[0].contiguous(), "proj_mat"), dev_f32(depth_values[0].contiguous(), "depth_values")
+    else:
+        D = src_grid.shape[1]
+        grid_in, grid_out = dev_f32(src_grid.contiguous(), "src_grid"), src_grid
+        proj_p = dep_p = 0
+    warped = torch.empty((1, C, D, Hp, Wp), device=dev, dtype=torch.float32)
+    check(_lib.lib().mvsnerf_homo_warp_fwd(dev_f32(src_feat.contiguous(), "src_feat"), proj_p, dep_p, grid_in, C, H, W, D, pad,
+                                           warped.data_ptr(), 0 if src_grid is not None else grid_out.data_ptr(), stream_ptr()), "homo_warp_fwd")
+    return warped, grid_out
+
+
+class MVSNet(nn.Module):
+    """reference models.py:771-932."""
+
+    def __init__(self, num_groups=1, norm_act=InPlaceABN, levels=1):
+        super().__init__()
+        self.levels = levels
+        self.n_depths = [128, 32, 8]
+        self.G = num_groups
+        self.feature = FeatureNet()
+        self.N_importance = 0
+        self.chunk = 1024
+        self.cost_reg_2 = CostRegNet(32 + 9, norm_act)
+        self.D = 128          # number of depth planes (hard-coded `D = 128` at models.py:914; settable here for config 1)
+
+    def _sweep(self, imgs, feats, proj_mats, depth_values, pad, with_img):
+        B, V, C, H, W = feats.shape
+        if B != 1:
+            raise RuntimeError("MVSNet: batch size must be 1 (the reference assumes it, models.py:916)")
+        dev = feats.device
+        lib = _lib.lib()
+        D = depth_values.shape[1]
+        Hp, Wp = H + 2 * pad, W + 2 * pad
+        feats_cl = torch.empty((V, H, W, C), device=dev, dtype=torch.float32)
+        check(lib.mvsnerf_nchw_to_nhwc(dev_f32(feats[0].contiguous(), "feats"), feats_cl.data_ptr(), V, C, H, W, C, stream_ptr()), "nchw_to_nhwc")
+        imgs_cl_p = 0
+        if with_img:
+            Hi, Wi = imgs.shape[-2:]
+            small = torch.empty((V, 3, H, W), device=dev, dtype=torch.float32)                      # models.py:859
+            check(lib.mvsnerf_resize_bilinear(dev_f32(imgs[0].contiguous(), "imgs"), small.data_ptr(), V * 3, Hi, Wi, H, W, stream_ptr()), "resize_bilinear")
+            imgs_cl = torch.empty((V, H, W, 4), device=dev, dtype=torch.float32)
+            check(lib.mvsnerf_nchw_to_nhwc(small.data_ptr(), imgs_cl.data_ptr(), V, 3, H, W, 4, stream_ptr()), "nchw_to_nhwc")
+            imgs_cl_p = imgs_cl.data_ptr()
+        n_ch = (3 * V if with_img else 0) + C
+        CP = (n_ch + 3) // 4 * 4
+        cost = torch.empty((D, Hp, Wp, CP), device=dev, dtype=torch.float32)
+        masks = torch.empty((V, D, Hp, Wp) if with_img else (1, D, Hp, Wp), device=dev, dtype=torch.float32)
+        check(lib.mvsnerf_planesweep_costvar_fwd(feats_cl.data_ptr(), imgs_cl_p, dev_f32(proj_mats[0].contiguous(), "proj_mats"),
+                                                 dev_f32(depth_values[0].contiguous(), "depth_values"), V, C, H, W, D, pad,
+                                                 cost.data_ptr(), CP, masks.data_ptr(), int(with_img), stream_ptr()), "planesweep_costvar_fwd")
+        return _cl_view_to_ncdhw(cost, n_ch), masks.unsqueeze(0)
+
+    def build_volume_costvar(self, feats, proj_mats, depth_values, pad=0):
+        """reference models.py:787-837 -> (variance (B,32,D,h,w), in_masks (B,1,D,h,w) view count)."""
+        ops._need_no_grad(feats, op="build_volume_costvar")
+        return self._sweep(None, feats, proj_mats, depth_values, pad, False)
+
+    def build_volume_costvar_img(self, imgs, feats, proj_mats, depth_values, pad=0):
+        """reference models.py:839-893 -> (img_feat (B,3V+32,D,h,w), in_masks (B,V,D,h,w)).
+        The border of channels 0:3 (uninitialised in the reference, models.py:858) is defined as 0."""
+        ops._need_no_grad(imgs, feats, op="build_volume_costvar_img")
+        return self._sweep(imgs, feats, proj_mats, depth_values, pad, True)
+
+    def forward(self, imgs, proj_mats, near_far, pad=0, return_color=False, lindisp=False):
+        """reference models.py:895-932.  imgs (B,V,3,H,W) normalised; proj_mats (B,V,3,4); near_far (2,)."""
+        B, V, _, H, W = imgs.shape
+        feats = self.feature(imgs.reshape(B * V, 3, H, W))
+        feats_l = feats.view(B, V, *feats.shape[1:])
+        t_vals = torch.linspace(0.0, 1.0, steps=self.D, device=imgs.device, dtype=imgs.dtype)
+        near, far = near_far
+        depth_values = (near * (1.0 - t_vals) + far * t_vals) if not lindisp else 1.0 / (1.0 / near * (1.0 - t_vals) + 1.0 / far * t_vals)
+        depth_values = depth_values.unsqueeze(0)
+        volume_feat, in_masks = self.build_volume_costvar_img(imgs, feats_l, proj_mats, depth_values, pad=pad)
+        if return_color:
+            feats_l = torch.cat((volume_feat[:, :V * 3].reshape(B, V, 3, *volume_feat.shape[2:]), in_masks.unsqueeze(2)), dim=2)
+        volume_feat = self.cost_reg_2(volume_feat)
+        return volume_feat, feats_l, depth_values
+
+
+def bench_encode(rig, dev, pad, iters=3):
+    """Used by bench.py: build the neural volume of the synthetic scene; returns (volume, per-stage ms)."""
+    import numpy as np
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "mvsnerf_v0_weights.npz"))
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("mvs/")}
+    net = MVSNet().to(dev)
+    net.load_state_dict(sd)
+    net.train()                                   # the reference keeps MVSNet in train mode at inference (train_mvs_nerf_pl.py:182)
+    imgs = rig["images"][:, :3].to(dev)
+    proj = rig["proj_mats"][:, :3].to(dev)
+    nf = rig["near_fars"][0, 0].to(dev)
+    times = {}
+    with torch.no_grad():
+        for it in range(iters):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            B, V, _, H, W = imgs.shape
+            feats = net.feature(imgs.reshape(B * V, 3, H, W))
+            feats_l = feats.view(B, V, *feats.shape[1:])
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            t_vals = torch.linspace(0.0, 1.0, steps=net.D, device=dev)
+            dv = (nf[0] * (1.0 - t_vals) + nf[1] * t_vals).unsqueeze(0)
+            cost, _ = net.build_volume_costvar_img(imgs, feats_l, proj, dv, pad=pad)
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            vol = net.cost_reg_2(cost)
+            torch.cuda.synchronize(); t3 = time.perf_counter()
+            times = {"feature_net_torch": round((t1 - t0) * 1e3, 3), "planesweep_costvar": round((t2 - t1) * 1e3, 3),
+                     "cost_reg_net": round((t3 - t2) * 1e3, 3), "total": round((t3 - t0) * 1e3, 3)}
+    return vol, times

@@ -223,3 +223,8 @@ def create_nerf_mvs(args, pts_embedder=True, use_mvs=False, dir_embedder=True):
     render_kwargs_test = dict(render_kwargs_train)
     render_kwargs_test["perturb"] = False
     return render_kwargs_train, render_kwargs_test, start, grad_vars
+
+
+# the encoder half of the reference's models.py lives in encoder.py; re-exported here so that
+# `from mvsnerf_amd.models import *` offers the same names as `from models import *`
+from .encoder import InPlaceABN, ConvBnReLU, ConvBnReLU3D, FeatureNet, CostRegNet, MVSNet  # noqa: E402,F401

@@ -145,3 +145,6 @@ def build_color_volume(point_samples, pose_ref, imgs, img_feat=None, downscale=1
 
 def normal_vect(vect, dim=-1):
     return vect / (torch.sqrt(torch.sum(vect ** 2, dim=dim, keepdim=True)) + 1e-7)
+
+
+from .encoder import homo_warp  # noqa: E402,F401  (reference utils.py:580; implemented next to the plane-sweep kernels)
