@@ -315,6 +315,60 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(ActSrc a, ActSrc b, int 
     for (int k = 0; k < CT; k += 4) *reinterpret_cast<f32x4*>(o + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
 }
 
+// LDS-tiled variant for the stride-1 layers (conv0 = 74.5 % of CostRegNet's FLOPs).  A workgroup owns a 4x8x8
+// block of output voxels; the (6x10x10)-voxel input halo is staged through LDS in chunks of CK=12 channels with
+// fully coalesced loads (a voxel's channels are contiguous; the generic kernel's per-tap gathers at a 176-B lane
+// stride touch one cache line per lane).  The pending InPlaceABN of the producer is applied once per staged
+// element instead of once per tap.  Voxel stride 12 floats => conflict-free ds_read_b128 across x-neighbours.
+template <int CIN, int CT>
+__global__ __launch_bounds__(256) void conv3d_k3s1_tiled_kernel(ActSrc a, ActSrc b, int ld, int D, int H, int W,
+                                                               const float* __restrict__ wp, int Cout, float* __restrict__ out)
+{
+    constexpr int CK = 12, IY = 10, IX = 10, NV = 6 * IY * IX;
+    __shared__ __attribute__((aligned(16))) float tile[NV * CK];
+    const int nbx = (W + 7) / 8, nby = (H + 7) / 8;
+    const int bx = blockIdx.x % nbx, by = (blockIdx.x / nbx) % nby, bz = blockIdx.x / (nbx * nby);
+    const int cg = blockIdx.y * CT;
+    const int tid = threadIdx.x, tx = tid & 7, ty = (tid >> 3) & 7, tz = tid >> 6;
+    const int x0 = bx * 8 - 1, y0 = by * 8 - 1, z0 = bz * 4 - 1;
+    float acc[CT];
+#pragma unroll
+    for (int k = 0; k < CT; ++k) acc[k] = 0.f;
+#pragma unroll 1
+    for (int c0 = 0; c0 < CIN; c0 += CK) {
+        const int ck4 = (CIN - c0 < CK ? CIN - c0 : CK) / 4;          // float4s per voxel in this chunk
+        __syncthreads();
+        for (int idx = tid; idx < NV * ck4; idx += 256) {
+            const int v = idx / ck4, c4 = idx - v * ck4;
+            const int vx = v % IX, vy = (v / IX) % IY, vz = v / (IX * IY);
+            const int gx = x0 + vx, gy = y0 + vy, gz = z0 + vz;
+            f32x4 val = {0, 0, 0, 0};
+            if (gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D)
+                load_act4<CIN>(a, b, ((int64_t)gz * H + gy) * W + gx, ld, c0 + c4 * 4, val);
+            *reinterpret_cast<f32x4*>(tile + v * CK + c4 * 4) = val;
+        }
+        __syncthreads();
+        for (int tap = 0; tap < 27; ++tap) {
+            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+            const float* tv = tile + (((tz + dz) * IY + ty + dy) * IX + tx + dx) * CK;
+            const float* wt = wp + ((int64_t)tap * CIN + c0) * Cout + cg;
+            for (int c4 = 0; c4 < ck4; ++c4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(tv + c4 * 4);
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+                    for (int k = 0; k < CT; ++k) acc[k] = fmaf(v[k4], wt[(int64_t)(c4 * 4 + k4) * Cout + k], acc[k]);
+            }
+        }
+    }
+    const int ox = bx * 8 + tx, oy = by * 8 + ty, oz = bz * 4 + tz;
+    if (ox < W && oy < H && oz < D) {
+        float* o = out + (((int64_t)oz * H + oy) * W + ox) * Cout + cg;
+#pragma unroll
+        for (int k = 0; k < CT; k += 4) *reinterpret_cast<f32x4*>(o + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+    }
+}
+
 // Transposed 3x3x3 convolution, stride 2, padding 1, output_padding 1 (models.py:739-752): output size = 2x input.
 // out[o] = sum over taps k with o = 2*i - 1 + k.  One thread = one output voxel x CT channels; per dimension an even
 // output coordinate has one tap (k=1), an odd one two (k=0 from i=(o+1)/2, k=2 from i=(o-1)/2).
@@ -354,6 +408,7 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_kernel(ActSrc a, ActSrc b, i
     for (int k = 0; k < CT; k += 4) *reinterpret_cast<f32x4*>(o + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
 }
 
+int g_conv_tiled = 1;   // A/B knob (mvsnerf_tune "conv_tiled")
 static bool act_ok(const float* x, const float* sc, const float* sh) { return x && ((sc == nullptr) == (sh == nullptr)) && mvs_aligned16(x); }
 
 extern "C" int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const float* shift1,
@@ -371,19 +426,22 @@ extern "C" int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const fl
     hipStream_t st = (hipStream_t)stream;
 #define MVS_CONV(CIN, CT, S)                                                                          \
     conv3d_k3_kernel<CIN, CT, S><<<dim3(mvs_cdiv(nvox, 256), Cout / CT), 256, 0, st>>>(a, b, cin_ld, D, H, W, wpacked, Cout, out, Do, Ho, Wo)
+#define MVS_CONV_TILED(CIN, CT)                                                                       \
+    conv3d_k3s1_tiled_kernel<CIN, CT><<<dim3(((W + 7) / 8) * ((H + 7) / 8) * ((D + 3) / 4), Cout / CT), 256, 0, st>>>(a, b, cin_ld, D, H, W, wpacked, Cout, out)
     // (Cin rounded up to a multiple of 4 by the caller's channel padding; Cout in {8,16,32,64})
     const int key = Cin * 1000 + Cout * 10 + stride;
     switch (key) {
-        case 44 * 1000 + 8 * 10 + 1:  MVS_CONV(44, 8, 1); break;     // conv0 (41 real channels + 3 zero pad)
+        case 44 * 1000 + 8 * 10 + 1:  if (g_conv_tiled) MVS_CONV_TILED(44, 8); else MVS_CONV(44, 8, 1); break;     // conv0 (41 real channels + 3 zero pad)
         case 8 * 1000 + 16 * 10 + 2:  MVS_CONV(8, 16, 2); break;     // conv1
-        case 16 * 1000 + 16 * 10 + 1: MVS_CONV(16, 16, 1); break;    // conv2
+        case 16 * 1000 + 16 * 10 + 1: if (g_conv_tiled) MVS_CONV_TILED(16, 16); else MVS_CONV(16, 16, 1); break;    // conv2
         case 16 * 1000 + 32 * 10 + 2: MVS_CONV(16, 16, 2); break;    // conv3
-        case 32 * 1000 + 32 * 10 + 1: MVS_CONV(32, 16, 1); break;    // conv4
+        case 32 * 1000 + 32 * 10 + 1: if (g_conv_tiled) MVS_CONV_TILED(32, 16); else MVS_CONV(32, 16, 1); break;    // conv4
         case 32 * 1000 + 64 * 10 + 2: MVS_CONV(32, 16, 2); break;    // conv5
-        case 64 * 1000 + 64 * 10 + 1: MVS_CONV(64, 16, 1); break;    // conv6
+        case 64 * 1000 + 64 * 10 + 1: if (g_conv_tiled) MVS_CONV_TILED(64, 16); else MVS_CONV(64, 16, 1); break;    // conv6
         default: return MVSNERF_EUNSUPPORTED;
     }
 #undef MVS_CONV
+#undef MVS_CONV_TILED
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
@@ -443,15 +501,18 @@ __global__ __launch_bounds__(256) void abn_partial_kernel(const float* __restric
     }
 }
 
-__global__ void abn_finalize_kernel(const float* __restrict__ part, int nblocks, int C, int64_t n,
+__global__ __launch_bounds__(64) void abn_finalize_kernel(const float* __restrict__ part, int nblocks, int C, int64_t n,
                                     const float* __restrict__ weight, const float* __restrict__ bias,
                                     float* __restrict__ running_mean, float* __restrict__ running_var,
                                     float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    // one wavefront per channel: lanes stride over the per-block partials (fixed order => deterministic), fp64 combine
+    const int c = blockIdx.x, lane = threadIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblocks; ++b) { s += (double)part[((int64_t)b * 2) * C + c]; q += (double)part[((int64_t)b * 2 + 1) * C + c]; }
+    for (int b = lane; b < nblocks; b += 64) { s += (double)part[((int64_t)b * 2) * C + c]; q += (double)part[((int64_t)b * 2 + 1) * C + c]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { s += __shfl_xor(s, d); q += __shfl_xor(q, d); }
+    if (lane != 0) return;
     const double mean = s / (double)n;
     double var = q / (double)n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -487,7 +548,7 @@ extern "C" int mvsnerf_abn_stats(const float* x, int64_t n_vox, int C, const flo
         default: return MVSNERF_EUNSUPPORTED;
     }
     MVS_LAUNCH_CHECK();
-    abn_finalize_kernel<<<1, 64, 0, st>>>(workspace, nb, C, n_vox, weight, bias, running_mean, running_var, momentum, eps, scale, shift);
+    abn_finalize_kernel<<<C, 64, 0, st>>>(workspace, nb, C, n_vox, weight, bias, running_mean, running_var, momentum, eps, scale, shift);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }

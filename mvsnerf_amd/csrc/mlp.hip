@@ -336,9 +336,11 @@ __global__ __launch_bounds__(256, WPS) void mlp_fwd_kernel(
 
 // tuning knob (A/B benchmarking only): 0 = 32 pts/wave, 2 waves/SIMD; 1 = 64 pts/wave, 1 wave/SIMD; 2 = 32 pts/wave, 1 wave/SIMD
 static int g_mlp_variant = 0;
+extern int g_conv_tiled;
 extern "C" int mvsnerf_tune(const char* key, int value)
 {
     if (!key) return MVSNERF_EINVAL;
+    if (__builtin_strcmp(key, "conv_tiled") == 0) { g_conv_tiled = value ? 1 : 0; return MVSNERF_OK; }
     if (__builtin_strcmp(key, "mlp_variant") == 0) { if (value < 0 || value > 2) return MVSNERF_EINVAL; g_mlp_variant = value; return MVSNERF_OK; }
     return MVSNERF_EINVAL;
 }

@@ -7,9 +7,10 @@
 
 // ---------------------------------------------------------------------------------------------
 // Trilinear lookup (reference: F.grid_sample 5-D, zeros padding, align_corners=True;
-// utils.py:381-382).  4 lanes cooperate on one sample: lane q = (zc<<1|yc) owns the corner pair
-// (z0+zc, y0+yc, x0..x0+1) = 64 contiguous bytes = 4 x float4; partial sums are combined with two
-// DPP-class shuffles.  16 samples per wave => each wave-level load instruction touches 16 x 64 B.
+// utils.py:381-382).  4 lanes cooperate on one sample.  Lane q owns float4 number q of the 64-byte
+// x-pair row  vol[z][y][x0..x0+1][0..7]  (q>>1 = x corner, q&1 = channel half) and walks the four
+// (z,y) rows, so every wave-level load instruction reads 16 samples x 64 CONTIGUOUS bytes (one
+// segment per quad instead of four); one __shfl_xor(.,2) step folds the two x corners.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void volume_sample_c8_kernel(
     const float* __restrict__ vol, int D, int H, int W,
@@ -28,39 +29,27 @@ __global__ __launch_bounds__(256) void volume_sample_c8_kernel(
     const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
     const float iz = ((gz + 1.0f) / 2.0f) * (float)(D - 1);
     const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-    const int zc = q >> 1, yc = q & 1;
+    const int xc = q >> 1, ch = (q & 1) * 4;
     // weights as ATen forms them: (x1-ix) for the low corner, (ix-x0) for the high one
-    const float wx0 = (fx + 1.0f) - ix, wx1 = ix - fx;
-    const float wy = yc ? (iy - fy) : ((fy + 1.0f) - iy);
-    const float wz = zc ? (iz - fz) : ((fz + 1.0f) - iz);
-    // NaN / huge coordinates: the float compares below reject them before any int conversion is used
-    const float cxf = fx, cyf = fy + (float)yc, czf = fz + (float)zc;
-    const bool yz_in = (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
-    const bool x0_in = yz_in && (cxf >= 0.0f) && (cxf <= (float)(W - 1));
-    const bool x1_in = yz_in && (cxf + 1.0f >= 0.0f) && (cxf + 1.0f <= (float)(W - 1));
-    f32x4 a0 = {0, 0, 0, 0}, a1 = a0, b0 = a0, b1 = a0;
-    if (x0_in || x1_in) {
-        const int x = (int)cxf, y = (int)cyf, z = (int)czf;
-        const float* base = vol + ((((int64_t)z * H + y) * W + x) << 3);
-        if (x0_in) { a0 = *reinterpret_cast<const f32x4*>(base);     a1 = *reinterpret_cast<const f32x4*>(base + 4); }
-        if (x1_in) { b0 = *reinterpret_cast<const f32x4*>(base + 8); b1 = *reinterpret_cast<const f32x4*>(base + 12); }
-    }
-    const float w0 = wx0 * wy * wz, w1 = wx1 * wy * wz;
-    f32x4 s0 = a0 * w0 + b0 * w1;
-    f32x4 s1 = a1 * w0 + b1 * w1;
-    // reduce over the 4 lanes of the sample (xor 1, xor 2)
+    const float wx = xc ? (ix - fx) : ((fx + 1.0f) - ix);
+    const float cxf = fx + (float)xc;
+    // NaN / huge coordinates: the float compares reject them before any int conversion is used
+    const bool x_in = (cxf >= 0.0f) && (cxf <= (float)(W - 1));
+    f32x4 acc = {0, 0, 0, 0};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        s0[c] += __shfl_xor(s0[c], 1); s1[c] += __shfl_xor(s1[c], 1);
-        s0[c] += __shfl_xor(s0[c], 2); s1[c] += __shfl_xor(s1[c], 2);
+    for (int k = 0; k < 4; ++k) {
+        const int zc = k >> 1, yc = k & 1;
+        const float cyf = fy + (float)yc, czf = fz + (float)zc;
+        const bool in = x_in && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
+        const float w = wx * (yc ? (iy - fy) : ((fy + 1.0f) - iy)) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
+        f32x4 v = {0, 0, 0, 0};
+        if (in) v = *reinterpret_cast<const f32x4*>(vol + (((((int64_t)czf * H + (int)cyf) * W + (int)cxf) << 3) + ch));
+        acc += v * w;
     }
-    if (live) {
-        float* o = out + p * out_stride;
-        // lane q stores channels 2q, 2q+1 -> the 4 lanes of a sample write 32 contiguous bytes
-        const float v0 = q == 0 ? s0[0] : q == 1 ? s0[2] : q == 2 ? s1[0] : s1[2];
-        const float v1 = q == 0 ? s0[1] : q == 1 ? s0[3] : q == 2 ? s1[1] : s1[3];
-        *reinterpret_cast<float2*>(o + 2 * q) = make_float2(v0, v1);
-    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], 2);      // fold the two x corners
+    if (live && xc == 0)                                               // lanes q=0,1 store channels 0-3 / 4-7
+        *reinterpret_cast<f32x4*>(out + p * out_stride + ch) = acc;
 }
 
 // Generic-C fallback of the same op (C != 8, e.g. colour volumes): one thread per (sample, channel).
@@ -96,7 +85,7 @@ extern "C" int mvsnerf_volume_sample_fwd(const float* vol, int D, int H, int W, 
     hipStream_t st = (hipStream_t)stream;
     if (C == 8) {
         if (!mvs_aligned16(vol)) return MVSNERF_EALIGN;
-        if ((out_stride & 1) || (reinterpret_cast<uintptr_t>(out) & 7u)) return MVSNERF_EALIGN;
+        if ((out_stride & 3) || !mvs_aligned16(out)) return MVSNERF_EALIGN;
         volume_sample_c8_kernel<<<mvs_cdiv(P * 4, 256), 256, 0, st>>>(vol, D, H, W, ndc, P, out, out_stride);
     } else {
         volume_sample_generic_kernel<<<mvs_cdiv(P * C, 256), 256, 0, st>>>(vol, D, H, W, C, ndc, P, out, out_stride);
