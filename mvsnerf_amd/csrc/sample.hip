@@ -11,45 +11,55 @@
 // x-pair row  vol[z][y][x0..x0+1][0..7]  (q>>1 = x corner, q&1 = channel half) and walks the four
 // (z,y) rows, so every wave-level load instruction reads 16 samples x 64 CONTIGUOUS bytes (one
 // segment per quad instead of four); one __shfl_xor(.,2) step folds the two x corners.
+// Measured alternatives (rocprofv3, 1024x128 samples, 128x176x208 volume): this mapping 8.1 us; 2 lanes per
+// sample 11.9 us; 2 or 4 consecutive samples per quad 11.6 / 9.0 us; 1024-thread blocks 8.4 us.
 // ---------------------------------------------------------------------------------------------
+template <int SPQ>   // samples per lane quad (consecutive samples: shared z-rows hit in L1, 4*SPQ loads in flight per lane)
 __global__ __launch_bounds__(256) void volume_sample_c8_kernel(
     const float* __restrict__ vol, int D, int H, int W,
     const float* __restrict__ ndc, int64_t P, float* __restrict__ out, int out_stride)
 {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t p = tid >> 2;
     const int q = (int)(tid & 3);
-    const bool live = p < P;
-    const int64_t pc = live ? p : (P - 1);
-    // same op order as the reference: grid = ndc*2-1 (utils.py:381); unnormalise ((g+1)/2)*(size-1)
-    const float gx = ndc[pc * 3 + 0] * 2.0f - 1.0f;
-    const float gy = ndc[pc * 3 + 1] * 2.0f - 1.0f;
-    const float gz = ndc[pc * 3 + 2] * 2.0f - 1.0f;
-    const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
-    const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
-    const float iz = ((gz + 1.0f) / 2.0f) * (float)(D - 1);
-    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
     const int xc = q >> 1, ch = (q & 1) * 4;
-    // weights as ATen forms them: (x1-ix) for the low corner, (ix-x0) for the high one
-    const float wx = xc ? (ix - fx) : ((fx + 1.0f) - ix);
-    const float cxf = fx + (float)xc;
-    // NaN / huge coordinates: the float compares reject them before any int conversion is used
-    const bool x_in = (cxf >= 0.0f) && (cxf <= (float)(W - 1));
-    f32x4 acc = {0, 0, 0, 0};
+    const int64_t p0 = (tid >> 2) * SPQ;
+    f32x4 acc[SPQ];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int zc = k >> 1, yc = k & 1;
-        const float cyf = fy + (float)yc, czf = fz + (float)zc;
-        const bool in = x_in && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
-        const float w = wx * (yc ? (iy - fy) : ((fy + 1.0f) - iy)) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
-        f32x4 v = {0, 0, 0, 0};
-        if (in) v = *reinterpret_cast<const f32x4*>(vol + (((((int64_t)czf * H + (int)cyf) * W + (int)cxf) << 3) + ch));
-        acc += v * w;
+    for (int j = 0; j < SPQ; ++j) {
+        const int64_t p = p0 + j;
+        const int64_t pc = p < P ? p : (P - 1);
+        // same op order as the reference: grid = ndc*2-1 (utils.py:381); unnormalise ((g+1)/2)*(size-1)
+        const float gx = ndc[pc * 3 + 0] * 2.0f - 1.0f;
+        const float gy = ndc[pc * 3 + 1] * 2.0f - 1.0f;
+        const float gz = ndc[pc * 3 + 2] * 2.0f - 1.0f;
+        const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+        const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+        const float iz = ((gz + 1.0f) / 2.0f) * (float)(D - 1);
+        const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+        // weights as ATen forms them: (x1-ix) for the low corner, (ix-x0) for the high one
+        const float wx = xc ? (ix - fx) : ((fx + 1.0f) - ix);
+        const float cxf = fx + (float)xc;
+        // NaN / huge coordinates: the float compares reject them before any int conversion is used
+        const bool x_in = (cxf >= 0.0f) && (cxf <= (float)(W - 1));
+        acc[j] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int zc = k >> 1, yc = k & 1;
+            const float cyf = fy + (float)yc, czf = fz + (float)zc;
+            const bool in = x_in && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
+            const float w = wx * (yc ? (iy - fy) : ((fy + 1.0f) - iy)) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
+            f32x4 v = {0, 0, 0, 0};
+            if (in) v = *reinterpret_cast<const f32x4*>(vol + (((((int64_t)czf * H + (int)cyf) * W + (int)cxf) << 3) + ch));
+            acc[j] += v * w;
+        }
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], 2);      // fold the two x corners
-    if (live && xc == 0)                                               // lanes q=0,1 store channels 0-3 / 4-7
-        *reinterpret_cast<f32x4*>(out + p * out_stride + ch) = acc;
+    for (int j = 0; j < SPQ; ++j) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[j][c] += __shfl_xor(acc[j][c], 2);      // fold the two x corners
+        if (p0 + j < P && xc == 0)                                                // lanes q=0,1 store channels 0-3 / 4-7
+            *reinterpret_cast<f32x4*>(out + (p0 + j) * out_stride + ch) = acc[j];
+    }
 }
 
 // Generic-C fallback of the same op (C != 8, e.g. colour volumes): one thread per (sample, channel).
@@ -86,7 +96,7 @@ extern "C" int mvsnerf_volume_sample_fwd(const float* vol, int D, int H, int W, 
     if (C == 8) {
         if (!mvs_aligned16(vol)) return MVSNERF_EALIGN;
         if ((out_stride & 3) || !mvs_aligned16(out)) return MVSNERF_EALIGN;
-        volume_sample_c8_kernel<<<mvs_cdiv(P * 4, 256), 256, 0, st>>>(vol, D, H, W, ndc, P, out, out_stride);
+        volume_sample_c8_kernel<1><<<mvs_cdiv(P * 4, 256), 256, 0, st>>>(vol, D, H, W, ndc, P, out, out_stride);
     } else {
         volume_sample_generic_kernel<<<mvs_cdiv(P * C, 256), 256, 0, st>>>(vol, D, H, W, C, ndc, P, out, out_stride);
     }
