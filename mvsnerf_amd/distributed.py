@@ -1,0 +1,126 @@
+"""Multi-GPU plumbing for the hot path: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" in the CPU tests).
+
+The path shards by rays: given the 8-channel volume, the source images and the MLP weights
+(163 MB, replicated) every ray is independent, so
+  * inference is tile-parallel: the row-major chunk index range of `build_rays_test`
+    (reference utils.py:95-98, train_mvs_nerf_pl.py:198) is split into contiguous per-rank ranges and the
+    per-rank RGB/depth strips are concatenated with ONE all_gather - no collective in the data path;
+  * training is ray-sharded DP: all ranks draw the SAME pixel ids (same CPU-RNG seed), each renders its
+    slice, and the gradients are averaged with ONE all-reduce over a single flat fp32 buffer (1.9 MB for
+    MLP + MVSNet: latency-bound, so one message instead of ~100 per-parameter ones).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(device=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract).
+    Returns (rank, world).  No-op for world size 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
+        kw = {"device_id": torch.device(device)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def shard_range(n_items, world, rank):
+    """Contiguous, balanced split of range(n_items): the first (n_items % world) ranks get one extra item."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_rays(n_rays, world, rank):
+    """Slice of a ray batch owned by `rank` (all ranks hold the same seeded batch; indices stay bit-exact)."""
+    lo, hi = shard_range(n_rays, world, rank)
+    return slice(lo, hi)
+
+
+def all_gather_rows(local, n_total, group=None):
+    """Concatenate per-rank row blocks (rank r owns rows shard_range(n_total, world, r)) on every rank.
+    One collective; blocks are padded to the largest shard so that a single all_gather_into_tensor suffices."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    sizes = [shard_range(n_total, world, r) for r in range(world)]
+    width = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((width, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    out = torch.empty((world * width, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return torch.cat([out[r * width:r * width + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], 0)
+
+
+class FlatGradAllReduce:
+    """Averages the gradients of `params` across ranks with ONE all-reduce on a flat fp32 buffer
+    (sum over xGMI, then divide by the world size).  Parameters without a gradient contribute zeros, so every
+    rank sends the same message size."""
+
+    def __init__(self, params, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = None
+
+    def __call__(self):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1 or not self.params:
+            return
+        dev = self.params[0].device
+        if self.flat is None or self.flat.device != dev:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                self.flat[off:off + n].zero_()
+            else:
+                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat.div_(dist.get_world_size(self.group))
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = self.flat[off:off + n].view_as(p).clone()
+            else:
+                p.grad.copy_(self.flat[off:off + n].view_as(p))
+            off += n
+
+
+def render_frame(render_chunk, H, W, chunk, group=None):
+    """Tile-parallel full-frame render (the chunk loop of validation_step, train_mvs_nerf_pl.py:198-208).
+    `render_chunk(idx)` renders chunk `idx` of the row-major pixel order and returns (rgb (n,3), depth (n,)).
+    Each rank renders a contiguous range of chunks; one all_gather assembles (H*W,3) and (H*W,) on every rank."""
+    n_chunks = (H * W + chunk - 1) // chunk
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    lo, hi = shard_range(n_chunks, world, rank)
+    rgbs, depths = [], []
+    for idx in range(lo, hi):
+        rgb, depth = render_chunk(idx)
+        rgbs.append(rgb)
+        depths.append(depth)
+    if rgbs:
+        packed = torch.cat([torch.cat(rgbs, 0), torch.cat(depths, 0)[:, None]], 1)       # (n_local, 4): one message
+    else:
+        packed = None
+    if world == 1:
+        return packed[:, :3], packed[:, 3]
+    # rows are pixels; the per-rank pixel ranges follow from the chunk ranges (the last chunk may be short)
+    px = [(min(l * chunk, H * W), min(h * chunk, H * W)) for l, h in (shard_range(n_chunks, world, r) for r in range(world))]
+    width = max(b - a for a, b in px)
+    ref = packed if packed is not None else None
+    dev = ref.device if ref is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    pad = torch.zeros((width, 4), dtype=torch.float32, device=dev)
+    if packed is not None:
+        pad[:packed.shape[0]] = packed
+    out = torch.empty((world * width, 4), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    full = torch.cat([out[r * width:r * width + (b - a)] for r, (a, b) in enumerate(px)], 0)
+    return full[:, :3], full[:, 3]

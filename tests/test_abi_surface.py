@@ -1,0 +1,46 @@
+"""CPU-only: the C-ABI library builds/loads, exports every symbol include/mvsnerf_hip.h declares, and the ctypes
+table binds exactly that set.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+from mvsnerf_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "mvsnerf_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mvsnerf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    names = _declared()
+    assert len(names) >= 20
+    l = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(l, n)]
+    assert not missing, f"declared in the header but not exported: {missing}"
+    assert sorted(_lib.SIGNATURES) == names, (set(names) ^ set(_lib.SIGNATURES))
+    assert _lib.lib().mvsnerf_abi_version() == 1
+    # pure host-side queries work without a GPU
+    assert _lib.lib().mvsnerf_mlp_packed_floats(20) == 12 * 256 + 8192 * 2 + 16384 * 6 + 68 * 128 + 1416
+    assert _lib.lib().mvsnerf_mlp_packed_floats(21) == 0
+
+
+def test_only_gfx950_code_objects():
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o", f"--input={_lib.LIB_PATH}"],
+                         capture_output=True, text=True).stdout
+    if out.strip():
+        assert "gfx950" in out and not re.search(r"gfx9(0[0-9a]|4[0-9])\b", out)
+
+
+def test_product_path_does_not_import_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "mvsnerf_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(root, f)).read()
+                assert "oracle" not in txt.replace("# oracle", ""), f"{f} mentions the oracle"
