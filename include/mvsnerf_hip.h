@@ -148,6 +148,40 @@ int mvsnerf_mlp_fwd(const float* packed, int F,
                     const float* dirs, int dirs_stride, int64_t N, int S, int alpha_only,
                     float* raw, void* stream);
 
+/* ---- training path of the MLP (autograd of models.py:194-222) ----
+ * mvsnerf_mlp_fwd_train = mvsnerf_mlp_fwd + an activation store `saved` (mvsnerf_mlp_saved_floats(N*S) floats).
+ * mvsnerf_mlp_pack_bwd re-lays W^T fragments for the gradient chain (mvsnerf_mlp_packed_bwd_floats() floats).
+ * mvsnerf_mlp_bwd: given d_raw[P][4] (grad wrt (r,g,b,sigma)) writes
+ *     d_feat8[P][8]   grad wrt the first 8 feature columns (the trilinear volume features)
+ *     gw[i], gb[i]    grads of the 11 nn.Linear weight/bias tensors (order of mvsnerf_mlp_pack), OVERWRITTEN
+ *   gslots: scratch of mvsnerf_mlp_gradslot_floats(N*S) floats; workspace: mvsnerf_mlp_bwd_workspace_floats();
+ *   maps: device int table built by the host side (fragment row -> nn.Linear row/column, mvsnerf_amd/ops.py).
+ *   No gradient is produced for ndc / view directions / colour features (the reference's losses never need them:
+ *   rays and source images carry no parameters). */
+size_t mvsnerf_mlp_saved_floats(int64_t n_points);
+size_t mvsnerf_mlp_gradslot_floats(int64_t n_points);
+size_t mvsnerf_mlp_packed_bwd_floats(void);
+size_t mvsnerf_mlp_bwd_workspace_floats(void);
+int mvsnerf_mlp_pack_bwd(const float* const w[11], int F, float* packed_bwd, void* stream);
+int mvsnerf_mlp_fwd_train(const float* packed, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
+                          const float* dirs, int dirs_stride, int64_t N, int S, float* raw, float* saved, void* stream);
+int mvsnerf_mlp_bwd(const float* packed_fwd, const float* packed_bwd, int F,
+                    const float* raw, const float* d_raw, const float* saved, int64_t N, int S,
+                    float* gslots, float* d_feat8, float* const gw[11], float* const gb[11],
+                    const int* maps, float* workspace, void* stream);
+
+/* Backward of the compositing w.r.t. raw (autograd of renderer.py:18-26,65-92).  Upstream grads g_rgb[N][3],
+ * g_depth[N], g_acc[N], g_weights[N][S], g_alpha[N][S] (any may be NULL = zero) -> d_raw[N][S][4]. */
+int mvsnerf_composite_bwd(const float* raw, const float* z, int64_t N, int S, int white_bkgd,
+                          const float* g_rgb, const float* g_depth, const float* g_acc,
+                          const float* g_weights, const float* g_alpha, float* d_raw, void* stream);
+
+/* Backward of the trilinear lookup w.r.t. the volume: gvol[D][H][W][8] += scatter of g[p*g_stride + c]
+ * (float atomics; gvol must be zero-initialised by the caller).  Needed by RefVolume fine-tuning
+ * (train_mvs_nerf_finetuning_pl.py:54) and, through the encoder, by generalizable training. */
+int mvsnerf_volume_sample_bwd(int D, int H, int W, int C, const float* ndc, int64_t P,
+                              const float* g, int g_stride, float* gvol, void* stream);
+
 /* Alpha compositing: raw2alpha + raw2outputs (renderer.py:18-26, 65-92).
  * raw[N][S][4], z[N][S] -> rgb_map[N][3], disp[N], acc[N], weights[N][S], depth[N], alpha[N][S].
  * Any output pointer may be NULL (skipped). */

@@ -98,3 +98,82 @@ extern "C" int mvsnerf_composite_fwd(const float* raw, const float* z, int64_t N
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the compositing (autograd of renderer.py:18-26, 65-92 w.r.t. raw).
+// With G_i = g_rgb.c_i + g_depth z_i + g_acc + g_w[i]  (total gradient reaching w_i = a_i T_i):
+//   d raw[i][c]   = w_i g_rgb[c]
+//   d sigma_i     = (1-a_i) * (G_i T_i + g_alpha[i]  -  S_i / t_i),   S_i = sum_{j>i} G_j w_j,  t_i = 1-a_i+1e-10
+// One wave per ray: forward quantities are recomputed, S is a reverse (suffix) scan: lane-local reverse
+// loop seeded by a wave-level exclusive suffix sum over lanes (__shfl_down).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void composite_bwd_kernel(
+    const float* __restrict__ raw, const float* __restrict__ z, int64_t N, int S, int chunk, int white_bkgd,
+    const float* __restrict__ g_rgb, const float* __restrict__ g_depth, const float* __restrict__ g_acc,
+    const float* __restrict__ g_w, const float* __restrict__ g_alpha, float* __restrict__ d_raw)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= N) return;
+    const int s0 = lane * chunk;
+    const float* rr = raw + ray * S * 4;
+    const float* zr = z + ray * S;
+    const float gr = g_rgb ? g_rgb[ray * 3] : 0.f, gg = g_rgb ? g_rgb[ray * 3 + 1] : 0.f, gb = g_rgb ? g_rgb[ray * 3 + 2] : 0.f;
+    const float gd = g_depth ? g_depth[ray] : 0.f;
+    // white background adds (1 - acc) to every rgb channel: d/dacc -= sum(g_rgb)
+    const float ga = (g_acc ? g_acc[ray] : 0.f) - (white_bkgd ? (gr + gg + gb) : 0.f);
+
+    float prod = 1.0f;
+    for (int i = 0; i < chunk; ++i) { const int s = s0 + i; if (s < S) prod *= (1.0f - (1.0f - expf(-rr[s * 4 + 3]))) + 1e-10f; }
+    float scan = prod;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_up(scan, d); if (lane >= d) scan *= o; }
+    float T = __shfl_up(scan, 1);
+    if (lane == 0) T = 1.0f;
+    const float T0 = T;
+    // pass 1: lane-local sum of G_i w_i
+    float loc = 0.f;
+    for (int i = 0; i < chunk; ++i) {
+        const int s = s0 + i; if (s >= S) break;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(rr + s * 4);
+        const float a = 1.0f - expf(-v[3]);
+        const float w = a * T;
+        T *= (1.0f - a) + 1e-10f;
+        const float G = gr * v[0] + gg * v[1] + gb * v[2] + gd * zr[s] + ga + (g_w ? g_w[ray * S + s] : 0.f);
+        loc += G * w;
+    }
+    // exclusive suffix sum over lanes
+    float suf = loc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_down(suf, d); if (lane + d < 64) suf += o; }
+    float Sx = suf - loc;                                   // sum over later lanes
+    // pass 2: forward re-walk; S_i = Sx + (sum of this lane's G_j w_j with j > i) = Sx + (loc - inclusive prefix)
+    T = T0;
+    float pre = 0.f;
+    for (int i = 0; i < chunk; ++i) {
+        const int s = s0 + i; if (s >= S) break;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(rr + s * 4);
+        const float a = 1.0f - expf(-v[3]);
+        const float t = (1.0f - a) + 1e-10f;
+        const float w = a * T;
+        const float G = gr * v[0] + gg * v[1] + gb * v[2] + gd * zr[s] + ga + (g_w ? g_w[ray * S + s] : 0.f);
+        pre += G * w;
+        const float Si = Sx + (loc - pre);
+        const float dsig = (1.0f - a) * (G * T + (g_alpha ? g_alpha[ray * S + s] : 0.f) - Si / t);
+        *reinterpret_cast<f32x4*>(d_raw + (ray * S + s) * 4) = f32x4{w * gr, w * gg, w * gb, dsig};
+        T *= t;
+    }
+}
+
+extern "C" int mvsnerf_composite_bwd(const float* raw, const float* z, int64_t N, int S, int white_bkgd,
+                                     const float* g_rgb, const float* g_depth, const float* g_acc,
+                                     const float* g_weights, const float* g_alpha, float* d_raw, void* stream)
+{
+    if (!raw || !z || !d_raw || N < 0 || S < 1) return MVSNERF_EINVAL;
+    if (!mvs_aligned16(raw) || !mvs_aligned16(d_raw)) return MVSNERF_EALIGN;
+    if (N == 0) return MVSNERF_OK;
+    composite_bwd_kernel<<<mvs_cdiv(N, 4), 256, 0, (hipStream_t)stream>>>(raw, z, N, S, (S + 63) / 64, white_bkgd,
+                                                                          g_rgb, g_depth, g_acc, g_weights, g_alpha, d_raw);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}

@@ -164,12 +164,15 @@ __device__ __forceinline__ float pe_operand(int t, int half, float px, float py,
 }
 
 // G groups of 32 points per wave; WPS = waves per SIMD the register budget is capped for.
-template <bool ALPHA_ONLY, int G, int WPS>
+// SAVE (training forward, G == 1): every operand the backward pass needs is written in slot format (mlp_layout.h);
+// the stores are fire-and-forget and hide under the MFMAs.
+template <bool ALPHA_ONLY, int G, int WPS, bool SAVE>
 __global__ __launch_bounds__(256, WPS) void mlp_fwd_kernel(
     const float* __restrict__ packed, int F, const float* __restrict__ ndc, int ndc_stride,
     const float* __restrict__ feat, int feat_stride, const float* __restrict__ dirs, int dirs_stride,
-    int64_t P, int S, float* __restrict__ raw)
+    int64_t P, int S, float* __restrict__ raw, float* __restrict__ saved)
 {
+    static_assert(!SAVE || (G == 1 && !ALPHA_ONLY), "training forward is built for 32 points per wave");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wbuf = lds;
     float* vec = lds + WBUF_FLOATS;
@@ -185,6 +188,10 @@ __global__ __launch_bounds__(256, WPS) void mlp_fwd_kernel(
         live[g] = p_raw[g] < P;
         p[g] = live[g] ? p_raw[g] : P - 1;
     }
+
+    float* sv = nullptr;      // this wave's tile of the activation store
+    if (SAVE) sv = saved + ((int64_t)blockIdx.x * 4 + wave) * (SLOTS_SAVED * 64) + lane;
+    auto save = [&](int slot, float v) { if (SAVE) sv[slot * 64] = v; };
 
     // stage A: fragment vectors + pts_bias weights + layer 0
     for (int i = tid; i < V_TOTAL; i += 256) vec[i] = packed[L.vec + i];
@@ -218,7 +225,13 @@ __global__ __launch_bounds__(256, WPS) void mlp_fwd_kernel(
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int q = 0; q < 64; ++q) bias[g][q] = acc[g][q >> 4][q & 15];
+            for (int q = 0; q < 64; ++q) { bias[g][q] = acc[g][q >> 4][q & 15]; save(S_BM + q, bias[g][q]); }
+        if (SAVE) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) save(S_FV + t, fv[0][t]);
+#pragma unroll
+            for (int t = 0; t < PE_STEPS; ++t) save(S_E + t, pe_operand(t, half, px[0], py[0], pz[0]));
+        }
     }
 
     float h[G][64];
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_fwd_kernel(
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int q = 0; q < 64; ++q) h[g][q] = fmaxf(acc[g][q >> 4][q & 15] * bias[g][q], 0.0f);
+            for (int q = 0; q < 64; ++q) { h[g][q] = fmaxf(acc[g][q >> 4][q & 15] * bias[g][q], 0.0f); save(S_H + q, h[g][q]); }
     }
     // layers 1..4
 #pragma unroll 1
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_fwd_kernel(
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int q = 0; q < 64; ++q) h[g][q] = fmaxf(acc[g][q >> 4][q & 15] * bias[g][q], 0.0f);
+            for (int q = 0; q < 64; ++q) { h[g][q] = fmaxf(acc[g][q >> 4][q & 15] * bias[g][q], 0.0f); save(S_H + layer * 64 + q, h[g][q]); }
     }
     // layer 5 on cat([pts, h])  (skip connection after layer 4, models.py:204-205)
     {
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_fwd_kernel(
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int q = 0; q < 64; ++q) h[g][q] = fmaxf(acc[g][q >> 4][q & 15] * bias[g][q], 0.0f);
+            for (int q = 0; q < 64; ++q) { h[g][q] = fmaxf(acc[g][q >> 4][q & 15] * bias[g][q], 0.0f); save(S_H + 5 * 64 + q, h[g][q]); }
     }
     // alpha = relu(alpha_linear(h))   (models.py:209)
     float sigma[G];
@@ -295,7 +308,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_fwd_kernel(
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int q = 0; q < 64; ++q) h[g][q] = acc[g][q >> 4][q & 15];
+            for (int q = 0; q < 64; ++q) { h[g][q] = acc[g][q >> 4][q & 15]; save(S_FE + q, h[g][q]); }
     }
     // h_v = relu(views_linears[0](cat[feature, dir]))   (models.py:211-215)
     {
@@ -314,6 +327,12 @@ __global__ __launch_bounds__(256, WPS) void mlp_fwd_kernel(
             return t < ACT_STEPS ? h[g][t < ACT_STEPS ? t : 0]
                  : t == ACT_STEPS ? (half ? d1[g] : d0[g]) : t == ACT_STEPS + 1 ? (half ? 0.0f : d2[g]) : 0.0f;
         });
+        if (SAVE) {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) save(S_HV + q, fmaxf(acc[0][q >> 4][q & 15], 0.0f));
+            save(S_DR + 0, half ? d1[0] : d0[0]);
+            save(S_DR + 1, half ? 0.0f : d2[0]);
+        }
         // rgb = sigmoid(rgb_linear(h_v))   (models.py:217);  out = cat([rgb, alpha]) models.py:218
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -345,19 +364,19 @@ extern "C" int mvsnerf_tune(const char* key, int value)
     return MVSNERF_EINVAL;
 }
 
-template <bool AO, int G, int WPS>
+template <bool AO, int G, int WPS, bool SAVE = false>
 static int launch_mlp(const float* packed, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
-                      const float* dirs, int dirs_stride, int64_t P, int S, float* raw, hipStream_t st)
+                      const float* dirs, int dirs_stride, int64_t P, int S, float* raw, hipStream_t st, float* saved = nullptr)
 {
     const size_t lds_bytes = LDS_FLOATS * sizeof(float);
     static bool attr_set = false;   // raising the dynamic-LDS cap is idempotent; no other state
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<AO, G, WPS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<AO, G, WPS, SAVE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    mlp_fwd_kernel<AO, G, WPS><<<mvs_cdiv(P, 128 * G), 256, lds_bytes, st>>>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
+    mlp_fwd_kernel<AO, G, WPS, SAVE><<<mvs_cdiv(P, 128 * G), 256, lds_bytes, st>>>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, saved);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
@@ -383,4 +402,17 @@ extern "C" int mvsnerf_mlp_fwd(const float* packed, int F, const float* ndc, int
         default: return MVS_MLP(true, 1, 1);
     }
 #undef MVS_MLP
+}
+
+// Training forward: identical arithmetic to mvsnerf_mlp_fwd (32 points per wave) + the activation store the
+// backward pass consumes (mvsnerf_mlp_saved_floats(N*S) floats, slot format of mlp_layout.h).
+extern "C" int mvsnerf_mlp_fwd_train(const float* packed, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
+                                     const float* dirs, int dirs_stride, int64_t N, int S, float* raw, float* saved, void* stream)
+{
+    if (!packed || !ndc || !feat || !dirs || !raw || !saved || N < 0 || S < 1 || feat_stride < F || ndc_stride < 3 || dirs_stride < 3) return MVSNERF_EINVAL;
+    if (F < 2 || F > 32 || (F & 1)) return MVSNERF_EUNSUPPORTED;
+    if (!mvs_aligned16(packed) || !mvs_aligned16(raw) || !mvs_aligned16(saved)) return MVSNERF_EALIGN;
+    const int64_t P = N * S;
+    if (P == 0) return MVSNERF_OK;
+    return launch_mlp<false, 1, 2, true>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, (hipStream_t)stream, saved);
 }

@@ -88,4 +88,45 @@ __host__ __device__ inline Layout layout(int F)
     return L;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Training: activations saved by the forward pass / gradients written by the dgrad kernel, in "slot" format.
+// A tile = the 32 points of one wave.  A slot = 64 floats = one register of the wave = two rows (lane half 0
+// and 1) of 32 points each: address = ((tile * SLOTS + slot) * 64 + lane).  A row is the 32-point vector of one
+// feature, which is exactly the 128-byte operand row the weight-gradient MFMAs contract over.
+constexpr int S_E = 0;            // 32 slots: positional-encoding operands, slot t = (kmap PE column (t,0), (t,1))
+constexpr int S_FV = 32;          // 16 slots: feature operands, slot t = feat columns (t, F/2+t)           (F <= 32)
+constexpr int S_BM = 48;          // 64 slots: pts_bias output b, slot q = features n(q,0), n(q,1)
+constexpr int S_H = 112;          // 6 x 64 slots: h_0..h_5 (post-ReLU)
+constexpr int S_FE = 496;         // 64 slots: feature_linear output
+constexpr int S_HV = 560;         // 32 slots: relu(views_linears[0])
+constexpr int S_DR = 592;         // 16 slots: slot 0 = (d0,d1), slot 1 = (d2,0); rest unused
+constexpr int SLOTS_SAVED = 608;
+// written by the dgrad kernel
+constexpr int G_GP = 0;           // 6 x 64 slots: grad wrt the pre-activation of pts_linears[i] (already x bias)
+constexpr int G_GBM = 384;        // 64 slots: grad wrt pts_bias output
+constexpr int G_GF = 448;         // 64 slots: grad wrt feature_linear output
+constexpr int G_GPV = 512;        // 32 slots: grad wrt views_linears[0] pre-activation
+constexpr int G_G4 = 544;         // 16 slots: slot 0 = (d rgb_r pre-sigmoid, d rgb_g), slot 1 = (d rgb_b, d sigma pre-relu)
+constexpr int SLOTS_GRAD = 560;
+
+// Transposed (dgrad) weight segments: A operand = W^T, i.e. fragment(t, kb, lane(i,h)) = W[n(t,h)][col_off + kb*32 + i]
+struct LayoutBwd {
+    size_t views, feat, l5, l4, l3, l2, l1, bias, total;   // views: 32 steps x 4 blocks; feat, l1..l5: 64 x 4; bias: 64 x 1
+};
+__host__ __device__ inline LayoutBwd layout_bwd()
+{
+    LayoutBwd L;
+    size_t o = 0;
+    L.views = o; o += seg_floats(32, 4);
+    L.feat = o;  o += seg_floats(ACT_STEPS, 4);
+    L.l5 = o;    o += seg_floats(ACT_STEPS, 4);
+    L.l4 = o;    o += seg_floats(ACT_STEPS, 4);
+    L.l3 = o;    o += seg_floats(ACT_STEPS, 4);
+    L.l2 = o;    o += seg_floats(ACT_STEPS, 4);
+    L.l1 = o;    o += seg_floats(ACT_STEPS, 4);
+    L.bias = o;  o += seg_floats(ACT_STEPS, 1);
+    L.total = o;
+    return L;
+}
+
 }  // namespace mlp

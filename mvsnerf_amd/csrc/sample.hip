@@ -262,3 +262,47 @@ extern "C" int mvsnerf_posenc_fwd(const float* x, int64_t P, int d, int L, float
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the trilinear lookup w.r.t. the volume: scatter-add of w_corner * g[p][c] into the channel-last
+// gradient volume (zeros padding => out-of-range corners receive nothing).  Same quad mapping as the forward;
+// float atomics => summation order (and the last bits) vary run to run - documented in DESIGN.md.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void volume_sample_c8_bwd_kernel(
+    int D, int H, int W, const float* __restrict__ ndc, int64_t P, const float* __restrict__ g, int g_stride, float* __restrict__ gvol)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = (int)(tid & 3);
+    const int xc = q >> 1, ch = (q & 1) * 4;
+    const int64_t p = tid >> 2;
+    if (p >= P) return;
+    const float gx = ndc[p * 3 + 0] * 2.0f - 1.0f, gy = ndc[p * 3 + 1] * 2.0f - 1.0f, gz = ndc[p * 3 + 2] * 2.0f - 1.0f;
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1), iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1), iz = ((gz + 1.0f) / 2.0f) * (float)(D - 1);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const float wx = xc ? (ix - fx) : ((fx + 1.0f) - ix);
+    const float cxf = fx + (float)xc;
+    if (!((cxf >= 0.0f) && (cxf <= (float)(W - 1)))) return;
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + p * g_stride + ch);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int zc = k >> 1, yc = k & 1;
+        const float cyf = fy + (float)yc, czf = fz + (float)zc;
+        if (!((cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1)))) continue;
+        const float w = wx * (yc ? (iy - fy) : ((fy + 1.0f) - iy)) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
+        float* dst = gvol + (((((int64_t)czf * H + (int)cyf) * W + (int)cxf) << 3) + ch);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) atomicAdd(dst + c, gv[c] * w);
+    }
+}
+
+extern "C" int mvsnerf_volume_sample_bwd(int D, int H, int W, int C, const float* ndc, int64_t P,
+                                         const float* g, int g_stride, float* gvol, void* stream)
+{
+    if (!ndc || !g || !gvol || D < 1 || H < 1 || W < 1 || P < 0 || g_stride < C) return MVSNERF_EINVAL;
+    if (C != 8) return MVSNERF_EUNSUPPORTED;
+    if ((g_stride & 3) || !mvs_aligned16(g)) return MVSNERF_EALIGN;
+    if (P == 0) return MVSNERF_OK;
+    volume_sample_c8_bwd_kernel<<<mvs_cdiv(P * 4, 256), 256, 0, (hipStream_t)stream>>>(D, H, W, ndc, P, g, g_stride, gvol);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}

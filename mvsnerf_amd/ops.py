@@ -175,3 +175,127 @@ def raymarch(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, z_vals,
         out["depth"].data_ptr(), out["alpha"].data_ptr())
     check(_lib.lib().mvsnerf_raymarch_fwd(ctypes.byref(a), stream_ptr()), "raymarch_fwd")
     return out
+
+
+# ------------------------------------------------------------------ training path (autograd)
+def _act_n(q, h):
+    return (q >> 4) * 32 + (q & 3) + 8 * ((q & 15) >> 2) + 4 * h
+
+
+_maps_cache = {}
+
+
+def _mlp_bwd_maps(F, device):
+    """int32 table: fragment row -> nn.Linear row/column (layout documented at mvsnerf_mlp_bwd in csrc/mlp_bwd.hip)."""
+    key = (F, str(device))
+    if key in _maps_cache:
+        return _maps_cache[key]
+    import numpy as np
+    t = -np.ones(1312, dtype=np.int32)
+    act128 = np.array([_act_n(r >> 1, r & 1) for r in range(128)], dtype=np.int32)
+    act64 = act128[:64].copy()
+    pe = np.array([(r & 1) if (r >> 1) == 0 else ((2 if (r & 1) == 0 else -1) if (r >> 1) == 1 else 3 + ((r >> 1) - 2) + 30 * (r & 1))
+                   for r in range(64)], dtype=np.int32)
+    feat = np.array([((r & 1) * (F // 2) + (r >> 1)) if (r >> 1) < F // 2 else -1 for r in range(32)], dtype=np.int32)
+    t[0:128], t[128:192], t[192:256], t[320:352] = act128, act64, pe, feat
+    t[512:515] = [0, 1, 2]
+    t[547] = 0
+    t[576:640], t[640:768] = pe, 63 + act128
+    t[768:896] = act128
+    t[896:899] = [128, 129, 130]
+    t[928:992] = act64
+    t[1184:1312] = act128
+    out = torch.from_numpy(t).to(device)
+    _maps_cache[key] = out
+    return out
+
+
+def mlp_pack_bwd(weights, F):
+    n = _lib.lib().mvsnerf_mlp_packed_bwd_floats()
+    packed = torch.empty(n, device=weights[0].device, dtype=torch.float32)
+    wp = (ctypes.c_void_p * 11)(*[dev_f32(w, "weight") for w in weights])
+    check(_lib.lib().mvsnerf_mlp_pack_bwd(wp, F, packed.data_ptr(), stream_ptr()), "mlp_pack_bwd")
+    return packed
+
+
+class RayMarchFunction(torch.autograd.Function):
+    """rendering() (renderer.py:138-165) with gradients to the neural volume and the 22 MLP tensors.
+    Inputs that never carry gradients in the reference's losses (rays, source images, cameras) are not differentiated."""
+
+    @staticmethod
+    def forward(ctx, volume, imgs, w2cs, intrinsics, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd, packed, *mlp_params):
+        lib = _lib.lib()
+        vol_cl = channels_last_volume(volume)
+        D, H, W, C = vol_cl.shape
+        N, S = z_vals.shape
+        V = imgs.shape[0]
+        F = 8 + 4 * V
+        dev = rays_pts.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        st = stream_ptr()
+        dirs = torch.empty((N, 3), **f32)
+        feat = torch.empty((N, S, F), **f32)
+        raw = torch.empty((N, S, 4), **f32)
+        saved = torch.empty(lib.mvsnerf_mlp_saved_floats(N * S), **f32)
+        check(lib.mvsnerf_dir_feature_fwd(dev_f32(rays_dir, "rays_dir"), dev_f32(w2cs, "w2cs"), N, 1, dirs.data_ptr(), st), "dir_feature_fwd")
+        check(lib.mvsnerf_volume_sample_fwd(dev_f32(vol_cl, "volume"), D, H, W, 8, dev_f32(rays_ndc, "rays_ndc"), N * S, feat.data_ptr(), F, st), "volume_sample_fwd")
+        check(lib.mvsnerf_color_sample_fwd(dev_f32(imgs, "imgs"), V, imgs.shape[2], imgs.shape[3], w2cs.data_ptr(), dev_f32(intrinsics, "intrinsics"),
+                                           dev_f32(rays_pts, "rays_pts"), N * S, 1, feat.data_ptr() + 32, F, st), "color_sample_fwd")
+        check(lib.mvsnerf_mlp_fwd_train(packed.data_ptr(), F, rays_ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3, N, S,
+                                        raw.data_ptr(), saved.data_ptr(), st), "mlp_fwd_train")
+        rgb, disp, acc, weights, depth, alpha = composite(raw, z_vals, white_bkgd)
+        ctx.save_for_backward(rays_ndc, z_vals, raw, saved, packed, *mlp_params)
+        ctx.meta = (tuple(volume.shape), (D, H, W), N, S, F, bool(white_bkgd))
+        ctx.mark_non_differentiable(feat, raw)
+        return rgb, feat, weights, depth, alpha, raw
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_feat, g_weights, g_depth, g_alpha, g_raw):
+        lib = _lib.lib()
+        rays_ndc, z_vals, raw, saved, packed, *mlp_params = ctx.saved_tensors
+        vshape, (D, H, W), N, S, F, white = ctx.meta
+        dev = raw.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        st = stream_ptr()
+        ptr = lambda t: 0 if t is None else dev_f32(t.contiguous(), "grad")
+        d_raw = torch.empty((N, S, 4), **f32)
+        g_rgb_c, g_depth_c = (None if g is None else g.contiguous() for g in (g_rgb, g_depth))
+        g_w_c, g_a_c = (None if g is None else g.contiguous() for g in (g_weights, g_alpha))
+        check(lib.mvsnerf_composite_bwd(raw.data_ptr(), z_vals.data_ptr(), N, S, int(white), ptr(g_rgb_c), ptr(g_depth_c), 0,
+                                        ptr(g_w_c), ptr(g_a_c), d_raw.data_ptr(), st), "composite_bwd")
+        weights = [p.detach() for p in mlp_params[0::2]]
+        packed_bwd = mlp_pack_bwd(weights, F)
+        gslots = torch.empty(lib.mvsnerf_mlp_gradslot_floats(N * S), **f32)
+        ws = torch.empty(lib.mvsnerf_mlp_bwd_workspace_floats(), **f32)
+        d_feat8 = torch.empty((N * S, 8), **f32)
+        gws = [torch.zeros_like(p) for p in mlp_params[0::2]]
+        gbs = [torch.zeros_like(p) for p in mlp_params[1::2]]
+        gwp = (ctypes.c_void_p * 11)(*[g.data_ptr() for g in gws])
+        gbp = (ctypes.c_void_p * 11)(*[g.data_ptr() for g in gbs])
+        maps = _mlp_bwd_maps(F, dev)
+        check(lib.mvsnerf_mlp_bwd(packed.data_ptr(), packed_bwd.data_ptr(), F, raw.data_ptr(), d_raw.data_ptr(), saved.data_ptr(), N, S,
+                                  gslots.data_ptr(), d_feat8.data_ptr(), gwp, gbp, maps.data_ptr(), ws.data_ptr(), st), "mlp_bwd")
+        g_vol = None
+        if ctx.needs_input_grad[0]:
+            gvol_cl = torch.zeros((D, H, W, 8), **f32)
+            check(lib.mvsnerf_volume_sample_bwd(D, H, W, 8, rays_ndc.data_ptr(), N * S, d_feat8.data_ptr(), 8, gvol_cl.data_ptr(), st), "volume_sample_bwd")
+            g_vol = gvol_cl.permute(3, 0, 1, 2)
+            if len(vshape) == 5:
+                g_vol = g_vol.unsqueeze(0)
+        param_grads = []
+        for gw, gb in zip(gws, gbs):
+            param_grads += [gw, gb]
+        return (g_vol, None, None, None, None, None, None, None, None, None, *param_grads)
+
+
+def raymarch_train(volume, imgs, w2cs, intrinsics, net, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd=False):
+    """Differentiable rendering(): `net` is a models.MVSNeRF; returns the dict of ops.raymarch."""
+    V = imgs.shape[0]
+    lins = net.nerf._linears()
+    params = []
+    for l in lins:
+        params += [l.weight, l.bias]
+    packed = net.packed(8 + 4 * V)
+    rgb, feat, weights, depth, alpha, raw = RayMarchFunction.apply(
+        volume, imgs, w2cs, intrinsics, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd, packed, *params)
+    return {"rgb_map": rgb, "input_feat": feat, "weights": weights, "depth": depth, "alpha": alpha, "raw": raw}

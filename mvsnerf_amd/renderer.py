@@ -96,10 +96,16 @@ def rendering(args, pose_ref, rays_pts, rays_ndc, depth_candidates, rays_o, rays
         V = imgs.shape[1]
         if args.feat_dim != 8 + 4 * V:
             raise RuntimeError(f"args.feat_dim {args.feat_dim} != 8 + 4*V ({V} views)")
-        out = ops.raymarch(ops.channels_last_volume(vol), imgs[0].contiguous(),
-                           pose_ref["w2cs"][:V].contiguous(), pose_ref["intrinsics"][:V].contiguous(),
-                           network_fn.packed(args.feat_dim), rays_pts.contiguous(), rays_ndc.contiguous(),
-                           depth_candidates.contiguous(), rays_dir.contiguous(), white_bkgd)
+        needs_grad = torch.is_grad_enabled() and (vol.requires_grad or any(p.requires_grad for p in network_fn.parameters()))
+        if needs_grad:      # training: same kernels + activation store, gradients to the volume and the MLP
+            out = ops.raymarch_train(vol, imgs[0].contiguous(), pose_ref["w2cs"][:V].contiguous(),
+                                     pose_ref["intrinsics"][:V].contiguous(), network_fn, rays_pts.contiguous(),
+                                     rays_ndc.contiguous(), depth_candidates.contiguous(), rays_dir.contiguous(), white_bkgd)
+        else:
+            out = ops.raymarch(ops.channels_last_volume(vol), imgs[0].contiguous(),
+                               pose_ref["w2cs"][:V].contiguous(), pose_ref["intrinsics"][:V].contiguous(),
+                               network_fn.packed(args.feat_dim), rays_pts.contiguous(), rays_ndc.contiguous(),
+                               depth_candidates.contiguous(), rays_dir.contiguous(), white_bkgd)
         rendering.last_raw = out["raw"]          # sigma lives in raw[...,3]; kept for parity tests / density queries
         return out["rgb_map"], out["input_feat"], out["weights"], out["depth"], out["alpha"], {}
 
