@@ -73,13 +73,16 @@ int mvsnerf_homo_warp_fwd(const float* src_nchw, const float* proj, const float*
 /* CostRegNet building blocks (models.py:674-685, 725-769), channel-last activations x[d][y][x][C].
  * A conv input is `leaky_relu(x*scale[c]+shift[c], 0.01)` applied on load (scale == NULL: raw input, no
  * activation), optionally plus a second such tensor (U-Net skip sums, models.py:762-766).
- *   conv3d_pack_weights: Conv3d (Cout,Cin,3,3,3) or ConvTranspose3d (Cin,Cout,3,3,3) -> [27][cin_pad][Cout]
+ *   conv3d_pack_weights: packed[tap][ci][co] = w[ci*s_ci + co*s_co + tap] (zero beyond ci_real/co_real; `flip` mirrors
+ *            the taps): Conv3d (Cout,Cin,27): s_ci=27, s_co=Cin*27; ConvTranspose3d (Cin,Cout,27): s_ci=Cout*27, s_co=27;
+ *            data-gradient kernels are the same convolutions with the roles of the two channel strides swapped
  *   conv3d_fwd: k3, padding 1, stride 1|2, no bias -> raw out[Do][Ho][Wo][Cout]
  *   conv_transpose3d_fwd: k3, stride 2, padding 1, output_padding 1 -> raw out[2D][2H][2W][Cout]
  *   abn_stats: train-mode InPlaceABN statistics of a raw tensor -> per-channel scale/shift
  *              (gamma=|w|+eps, biased variance) and the running_mean/var side effect (may be NULL)
  *   abn_apply_add: materialise leaky(x1*s1+t1) [+ leaky(x2*s2+t2)] */
-int mvsnerf_conv3d_pack_weights(const float* w, int Cout, int Cin, int cin_pad, int transposed, float* packed, void* stream);
+int mvsnerf_conv3d_pack_weights(const float* w, int ci_real, int co_real, int cin_pad, int cout_pad,
+                                int s_ci, int s_co, int flip, float* packed, void* stream);
 int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const float* shift1,
                        const float* x2, const float* scale2, const float* shift2,
                        int Cin, int cin_ld, int D, int H, int W, const float* wpacked, int Cout, int stride,
@@ -90,10 +93,33 @@ int mvsnerf_conv_transpose3d_fwd(const float* x1, const float* scale1, const flo
 size_t mvsnerf_abn_workspace_floats(int C);
 int mvsnerf_abn_stats(const float* x, int64_t n_vox, int C, const float* weight, const float* bias,
                       float* running_mean, float* running_var, float momentum, float eps,
-                      float* scale, float* shift, float* workspace, void* stream);
+                      float* scale, float* shift, float* mean_out, float* invstd_out, float* workspace, void* stream);
 int mvsnerf_abn_apply_add(const float* x1, const float* scale1, const float* shift1,
                           const float* x2, const float* scale2, const float* shift2,
                           int64_t n_vox, int C, float* out, void* stream);
+
+/* ---- encoder backward (generalizable training, train_mvs_nerf_pl.py:104-168) ----
+ * Data gradients of the convolutions reuse the forward kernels with re-packed weights (mvsnerf_conv3d_pack_weights:
+ * `flip` mirrors the taps; a stride-2 conv's data gradient is the transposed conv and vice versa).
+ *   abn_bwd: train-mode InPlaceABN backward of one layer: x raw, (scale,shift,mean,invstd) from abn_stats, upstream
+ *            gradient g1 (+ g2) w.r.t. the ACTIVATED output -> gx (w.r.t. the raw conv output), g_weight, g_bias.
+ *            workspace: mvsnerf_abn_workspace_floats(C).
+ *   conv3d_wgrad: gW[a][b][tap] = sum_o G[o][a] * X[o*stride-1+tap][b]; G on the conv's output grid, X on its input
+ *            grid, each optionally lazily activated / a sum of two tensors.  Conv3d: G = grad of raw output, X = input
+ *            -> (Cout,Cin,27).  ConvTranspose3d: G = its (coarse) input, X = grad of its raw output -> (Cin,Cout,27).
+ *   planesweep_costvar_bwd: d cost (variance channels) -> d feats_cl[V][H][W][32] (+=, float atomics; caller zeroes). */
+int mvsnerf_abn_bwd(const float* x, int64_t n_vox, int C, const float* weight, const float* scale, const float* shift,
+                    const float* mean, const float* invstd, const float* g1, const float* g2,
+                    float* gx, float* g_weight, float* g_bias, float* workspace, void* stream);
+size_t mvsnerf_conv3d_wgrad_workspace_floats(int A, int B);
+int mvsnerf_conv3d_wgrad(const float* g1, const float* g1_scale, const float* g1_shift,
+                         const float* g2, const float* g2_scale, const float* g2_shift, int A,
+                         const float* x1, const float* x1_scale, const float* x1_shift,
+                         const float* x2, const float* x2_scale, const float* x2_shift, int B, int ldx,
+                         int Do, int Ho, int Wo, int Di, int Hi, int Wi, int stride,
+                         float* gw, float* workspace, void* stream);
+int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float* proj, const float* depth, int V, int C, int H, int W, int D, int pad,
+                                   const float* g_cost, int CP, int with_img, float* g_feats_cl, void* stream);
 
 /* ---------------------------------------------------------------- ray march (L1b) */
 

@@ -41,11 +41,15 @@ SIGNATURES = {
     "mvsnerf_resize_bilinear": (_c_i, [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp]),
     "mvsnerf_planesweep_costvar_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp]),
     "mvsnerf_homo_warp_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),
-    "mvsnerf_conv3d_pack_weights": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_conv3d_pack_weights": (_c_i, [_c_fp] + [_c_i] * 7 + [_c_fp, _c_fp]),
     "mvsnerf_conv3d_fwd": (_c_i, [_c_fp] * 6 + [_c_i] * 5 + [_c_fp, _c_i, _c_i, _c_fp, _c_fp]),
     "mvsnerf_conv_transpose3d_fwd": (_c_i, [_c_fp] * 6 + [_c_i] * 4 + [_c_fp, _c_i, _c_fp, _c_fp]),
     "mvsnerf_abn_workspace_floats": (ctypes.c_size_t, [_c_i]),
-    "mvsnerf_abn_stats": (_c_i, [_c_fp, _c_l, _c_i, _c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_float, ctypes.c_float, _c_fp, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_abn_stats": (_c_i, [_c_fp, _c_l, _c_i, _c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_float, ctypes.c_float, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_abn_bwd": (_c_i, [_c_fp, _c_l, _c_i] + [_c_fp] * 12),
+    "mvsnerf_conv3d_wgrad_workspace_floats": (ctypes.c_size_t, [_c_i, _c_i]),
+    "mvsnerf_conv3d_wgrad": (_c_i, [_c_fp] * 6 + [_c_i] + [_c_fp] * 6 + [_c_i] * 9 + [_c_fp, _c_fp, _c_fp]),
+    "mvsnerf_planesweep_costvar_bwd": (_c_i, [_c_fp, _c_fp, _c_fp] + [_c_i] * 6 + [_c_fp, _c_i, _c_i, _c_fp, _c_fp]),
     "mvsnerf_abn_apply_add": (_c_i, [_c_fp] * 6 + [_c_l, _c_i, _c_fp, _c_fp]),
     "mvsnerf_volume_sample_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_l, _c_fp, _c_i, _c_fp]),
     "mvsnerf_color_sample_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_i, _c_fp]),

@@ -258,22 +258,23 @@ __device__ __forceinline__ void load_act4(const ActSrc& a, const ActSrc& b, int6
 
 // weights re-laid as w[tap][ci][co] (co fastest) so that a thread's CT output channels are contiguous and
 // wave-uniform => the compiler fetches them through the scalar cache (s_load) and feeds v_fma from SGPRs.
-__global__ void conv3d_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int cin_pad, int transposed, float* __restrict__ packed)
+__global__ void conv3d_pack_kernel(const float* __restrict__ w, int ci_real, int co_real, int cin_pad, int cout_pad,
+                                   int s_ci, int s_co, int flip, float* __restrict__ packed)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = 27 * cin_pad * Cout;
+    const int total = 27 * cin_pad * cout_pad;
     if (i >= total) return;
-    const int co = i % Cout, ci = (i / Cout) % cin_pad, tap = i / (Cout * cin_pad);
-    float v = 0.f;
-    if (ci < Cin) v = transposed ? w[((int64_t)ci * Cout + co) * 27 + tap]      // ConvTranspose3d weight (Cin,Cout,3,3,3)
-                                 : w[((int64_t)co * Cin + ci) * 27 + tap];      // Conv3d weight (Cout,Cin,3,3,3)
-    packed[i] = v;
+    const int co = i % cout_pad, ci = (i / cout_pad) % cin_pad;
+    int tap = i / (cout_pad * cin_pad);
+    if (flip) tap = 26 - tap;                                                    // spatially mirrored kernel (data gradient)
+    packed[i] = (ci < ci_real && co < co_real) ? w[(int64_t)ci * s_ci + (int64_t)co * s_co + tap] : 0.f;
 }
 
-extern "C" int mvsnerf_conv3d_pack_weights(const float* w, int Cout, int Cin, int cin_pad, int transposed, float* packed, void* stream)
+extern "C" int mvsnerf_conv3d_pack_weights(const float* w, int ci_real, int co_real, int cin_pad, int cout_pad,
+                                           int s_ci, int s_co, int flip, float* packed, void* stream)
 {
-    if (!w || !packed || Cout < 1 || Cin < 1 || cin_pad < Cin) return MVSNERF_EINVAL;
-    conv3d_pack_kernel<<<mvs_cdiv(27 * cin_pad * Cout, 256), 256, 0, (hipStream_t)stream>>>(w, Cout, Cin, cin_pad, transposed, packed);
+    if (!w || !packed || ci_real < 1 || co_real < 1 || cin_pad < ci_real || cout_pad < co_real) return MVSNERF_EINVAL;
+    conv3d_pack_kernel<<<mvs_cdiv(27 * cin_pad * cout_pad, 256), 256, 0, (hipStream_t)stream>>>(w, ci_real, co_real, cin_pad, cout_pad, s_ci, s_co, flip, packed);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
@@ -432,6 +433,7 @@ extern "C" int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const fl
     const int key = Cin * 1000 + Cout * 10 + stride;
     switch (key) {
         case 44 * 1000 + 8 * 10 + 1:  if (g_conv_tiled) MVS_CONV_TILED(44, 8); else MVS_CONV(44, 8, 1); break;     // conv0 (41 real channels + 3 zero pad)
+        case 8 * 1000 + 44 * 10 + 1:  MVS_CONV_TILED(8, 44); break;  // data gradient of conv0
         case 8 * 1000 + 16 * 10 + 2:  MVS_CONV(8, 16, 2); break;     // conv1
         case 16 * 1000 + 16 * 10 + 1: if (g_conv_tiled) MVS_CONV_TILED(16, 16); else MVS_CONV(16, 16, 1); break;    // conv2
         case 16 * 1000 + 32 * 10 + 2: MVS_CONV(16, 16, 2); break;    // conv3
@@ -504,7 +506,8 @@ __global__ __launch_bounds__(256) void abn_partial_kernel(const float* __restric
 __global__ __launch_bounds__(64) void abn_finalize_kernel(const float* __restrict__ part, int nblocks, int C, int64_t n,
                                     const float* __restrict__ weight, const float* __restrict__ bias,
                                     float* __restrict__ running_mean, float* __restrict__ running_var,
-                                    float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift)
+                                    float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                    float* __restrict__ mean_out, float* __restrict__ invstd_out)
 {
     // one wavefront per channel: lanes stride over the per-block partials (fixed order => deterministic), fp64 combine
     const int c = blockIdx.x, lane = threadIdx.x;
@@ -521,6 +524,7 @@ __global__ __launch_bounds__(64) void abn_finalize_kernel(const float* __restric
     const float sc = gamma * invstd;
     scale[c] = sc;
     shift[c] = bias[c] - (float)mean * sc;
+    if (mean_out) { mean_out[c] = (float)mean; invstd_out[c] = invstd; }
     if (running_mean) {
         running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
         const double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
@@ -528,11 +532,11 @@ __global__ __launch_bounds__(64) void abn_finalize_kernel(const float* __restric
     }
 }
 
-extern "C" size_t mvsnerf_abn_workspace_floats(int C) { return (size_t)1024 * 2 * C; }
+extern "C" size_t mvsnerf_abn_workspace_floats(int C) { return (size_t)1024 * 2 * C + 2 * C; }
 
 extern "C" int mvsnerf_abn_stats(const float* x, int64_t n_vox, int C, const float* weight, const float* bias,
                                  float* running_mean, float* running_var, float momentum, float eps,
-                                 float* scale, float* shift, float* workspace, void* stream)
+                                 float* scale, float* shift, float* mean_out, float* invstd_out, float* workspace, void* stream)
 {
     if (!x || !weight || !bias || !scale || !shift || !workspace || n_vox < 1) return MVSNERF_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return MVSNERF_EINVAL;
@@ -548,7 +552,7 @@ extern "C" int mvsnerf_abn_stats(const float* x, int64_t n_vox, int C, const flo
         default: return MVSNERF_EUNSUPPORTED;
     }
     MVS_LAUNCH_CHECK();
-    abn_finalize_kernel<<<C, 64, 0, st>>>(workspace, nb, C, n_vox, weight, bias, running_mean, running_var, momentum, eps, scale, shift);
+    abn_finalize_kernel<<<C, 64, 0, st>>>(workspace, nb, C, n_vox, weight, bias, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
@@ -581,6 +585,315 @@ extern "C" int mvsnerf_abn_apply_add(const float* x1, const float* scale1, const
     const ActSrc a{x1, scale1, shift1}, b{x2, scale2, shift2};
     const int64_t n4 = n_vox * C / 4;
     abn_apply_add_kernel<<<mvs_cdiv(n4, 256), 256, 0, (hipStream_t)stream>>>(a, b, n4, C, out);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// =============================================================================================
+// BACKWARD of the encoder (generalizable training, train_mvs_nerf_pl.py:104-168)
+// =============================================================================================
+// ---- train-mode InPlaceABN backward.  y = leaky(g*xhat + b), xhat = (x-mean)*invstd, g = |w|+eps.
+//   gp = gy * leaky'(pre);  S1 = sum gp;  S2 = sum gp*xhat
+//   gx = g*invstd * (gp - S1/n - xhat*S2/n);   d b = S1;  d w = sign(w) * S2
+// gy may be the sum of two upstream tensors (U-Net skips fan out).
+template <int C>
+__global__ __launch_bounds__(256) void abn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ g1, const float* __restrict__ g2, int64_t n, float* __restrict__ part)
+{
+    constexpr int G = C / 4;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)gridDim.x * blockDim.x;
+    const int g = (int)(t % G);
+    f32x4 sc, sh, mu, is;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sc[k] = scale[g * 4 + k]; sh[k] = shift[g * 4 + k]; mu[k] = mean[g * 4 + k]; is[k] = invstd[g * 4 + k]; }
+    f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+    for (int64_t v = t / G; v < n; v += total / G) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + v * C + g * 4);
+        f32x4 gy = *reinterpret_cast<const f32x4*>(g1 + v * C + g * 4);
+        if (g2) gy += *reinterpret_cast<const f32x4*>(g2 + v * C + g * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float pre = fmaf(a[k], sc[k], sh[k]);
+            const float gp = pre > 0.f ? gy[k] : 0.01f * gy[k];
+            s[k] += gp;
+            q[k] += gp * ((a[k] - mu[k]) * is[k]);
+        }
+    }
+    __shared__ float shm[256 * 8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { shm[threadIdx.x * 8 + k] = s[k]; shm[threadIdx.x * 8 + 4 + k] = q[k]; }
+    __syncthreads();
+    if (threadIdx.x < C * 2) {
+        const int c = threadIdx.x % C, which = threadIdx.x / C;
+        const int gg = c / 4, k = c % 4;
+        float acc = 0.f;
+        for (int j = gg; j < 256; j += G) acc += shm[j * 8 + which * 4 + k];
+        part[((int64_t)blockIdx.x * 2 + which) * C + c] = acc;
+    }
+}
+
+__global__ __launch_bounds__(64) void abn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, int64_t n,
+                                                             const float* __restrict__ weight, float* __restrict__ m1, float* __restrict__ m2,
+                                                             float* __restrict__ g_weight, float* __restrict__ g_bias)
+{
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int b = lane; b < nblocks; b += 64) { s += (double)part[((int64_t)b * 2) * C + c]; q += (double)part[((int64_t)b * 2 + 1) * C + c]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { s += __shfl_xor(s, d); q += __shfl_xor(q, d); }
+    if (lane != 0) return;
+    m1[c] = (float)(s / (double)n);
+    m2[c] = (float)(q / (double)n);
+    g_bias[c] = (float)s;
+    g_weight[c] = weight[c] < 0.f ? -(float)q : (float)q;          // d|w|/dw
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void abn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ g1, const float* __restrict__ g2,
+                                                           const float* __restrict__ m1, const float* __restrict__ m2, int64_t n4, float* __restrict__ gx)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)((i * 4) % C);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 4);
+    f32x4 gy = *reinterpret_cast<const f32x4*>(g1 + i * 4);
+    if (g2) gy += *reinterpret_cast<const f32x4*>(g2 + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float pre = fmaf(a[k], scale[c + k], shift[c + k]);
+        const float gp = pre > 0.f ? gy[k] : 0.01f * gy[k];
+        const float xh = (a[k] - mean[c + k]) * invstd[c + k];
+        o[k] = scale[c + k] * (gp - m1[c + k] - xh * m2[c + k]);
+    }
+    *reinterpret_cast<f32x4*>(gx + i * 4) = o;
+}
+
+extern "C" int mvsnerf_abn_bwd(const float* x, int64_t n_vox, int C, const float* weight, const float* scale, const float* shift,
+                               const float* mean, const float* invstd, const float* g1, const float* g2,
+                               float* gx, float* g_weight, float* g_bias, float* workspace, void* stream)
+{
+    if (!x || !weight || !scale || !shift || !mean || !invstd || !g1 || !gx || !g_weight || !g_bias || !workspace || n_vox < 1) return MVSNERF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int nb = (int)((n_vox * (C / 4) + 255) / 256);
+    if (nb > 1024) nb = 1024;
+    float* m1 = workspace + (size_t)1024 * 2 * C;       // workspace: mvsnerf_abn_workspace_floats(C) + 2*C
+    float* m2 = m1 + C;
+    const int64_t n4 = n_vox * C / 4;
+#define MVS_ABNB(CC)                                                                                                            \
+    abn_bwd_partial_kernel<CC><<<nb, 256, 0, st>>>(x, scale, shift, mean, invstd, g1, g2, n_vox, workspace);                        \
+    abn_bwd_finalize_kernel<<<CC, 64, 0, st>>>(workspace, nb, CC, n_vox, weight, m1, m2, g_weight, g_bias);                         \
+    abn_bwd_apply_kernel<CC><<<mvs_cdiv(n4, 256), 256, 0, st>>>(x, scale, shift, mean, invstd, g1, g2, m1, m2, n4, gx)
+    switch (C) {
+        case 8:  MVS_ABNB(8); break;
+        case 16: MVS_ABNB(16); break;
+        case 32: MVS_ABNB(32); break;
+        case 64: MVS_ABNB(64); break;
+        default: return MVSNERF_EUNSUPPORTED;
+    }
+#undef MVS_ABNB
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// ---- weight gradient of a k3 convolution (stride S, padding 1):
+//   gW[a][b][tap] = sum_o G[o][a] * X[o*S - 1 + tap][b]
+// G lives on the conv's OUTPUT grid (A channels), X on its INPUT grid (B channels).  For Conv3d G = grad of the raw
+// output and X = the (lazily activated) input; for ConvTranspose3d the roles swap (G = activated coarse input,
+// X = grad of the fine raw output) and the result is already in ConvTranspose3d's (Cin,Cout,27) layout.
+// One thread owns NP (tap,b) pairs x A_T channels of `a`; a workgroup walks a contiguous range of output voxels
+// (G values are wave-uniform => scalar loads), partials per workgroup are combined by a second kernel.
+__device__ __forceinline__ float act1(const ActSrc& s, int64_t idx, int c)
+{
+    float v = s.x[idx];
+    if (s.scale) v = act_apply(v, s.scale[c], s.shift[c]);
+    return v;
+}
+
+template <int A_T, int NP, int S>
+__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(ActSrc g1, ActSrc g2, int A, ActSrc x1, ActSrc x2, int B, int ldx,
+                                                          int Do, int Ho, int Wo, int Di, int Hi, int Wi, float* __restrict__ partial)
+{
+    const int a0 = blockIdx.y * A_T;
+    const int64_t nvox = (int64_t)Do * Ho * Wo;
+    const int64_t per = (nvox + gridDim.x - 1) / gridDim.x;
+    const int64_t o0 = blockIdx.x * per, o1 = o0 + per < nvox ? o0 + per : nvox;
+    int tap[NP], bch[NP];
+    bool valid[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int p = threadIdx.x + j * 256;
+        valid[j] = p < 27 * B;
+        tap[j] = valid[j] ? p / B : 0;
+        bch[j] = valid[j] ? p - tap[j] * B : 0;
+    }
+    float acc[NP][A_T];
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+#pragma unroll
+        for (int a = 0; a < A_T; ++a) acc[j][a] = 0.f;
+    for (int64_t o = o0; o < o1; ++o) {
+        const int ox = (int)(o % Wo), oy = (int)((o / Wo) % Ho), oz = (int)(o / ((int64_t)Wo * Ho));
+        float g[A_T];
+#pragma unroll
+        for (int a = 0; a < A_T; ++a) {
+            g[a] = act1(g1, o * A + a0 + a, a0 + a);
+            if (g2.x) g[a] += act1(g2, o * A + a0 + a, a0 + a);
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int dz = tap[j] / 9, dy = (tap[j] / 3) % 3, dx = tap[j] % 3;
+            const int zi = oz * S - 1 + dz, yi = oy * S - 1 + dy, xi = ox * S - 1 + dx;
+            float xv = 0.f;
+            if (valid[j] && zi >= 0 && zi < Di && yi >= 0 && yi < Hi && xi >= 0 && xi < Wi) {
+                const int64_t idx = (((int64_t)zi * Hi + yi) * Wi + xi) * ldx + bch[j];
+                xv = act1(x1, idx, bch[j]);
+                if (x2.x) xv += act1(x2, idx, bch[j]);
+            }
+#pragma unroll
+            for (int a = 0; a < A_T; ++a) acc[j][a] = fmaf(g[a], xv, acc[j][a]);
+        }
+    }
+    // partial[blockIdx.x][a][b][tap]
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+        if (valid[j])
+#pragma unroll
+            for (int a = 0; a < A_T; ++a)
+                partial[((int64_t)blockIdx.x * A + a0 + a) * B * 27 + (int64_t)bch[j] * 27 + tap[j]] = acc[j][a];
+}
+
+__global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* __restrict__ partial, int n_part, int64_t n_out, float* __restrict__ gw)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    float s = 0.f;
+    for (int p = 0; p < n_part; ++p) s += partial[(int64_t)p * n_out + i];
+    gw[i] = s;
+}
+
+extern "C" size_t mvsnerf_conv3d_wgrad_workspace_floats(int A, int B) { return (size_t)512 * A * B * 27; }
+
+extern "C" int mvsnerf_conv3d_wgrad(const float* g1, const float* g1_scale, const float* g1_shift,
+                                    const float* g2, const float* g2_scale, const float* g2_shift, int A,
+                                    const float* x1, const float* x1_scale, const float* x1_shift,
+                                    const float* x2, const float* x2_scale, const float* x2_shift, int B, int ldx,
+                                    int Do, int Ho, int Wo, int Di, int Hi, int Wi, int stride,
+                                    float* gw, float* workspace, void* stream)
+{
+    if (!g1 || !x1 || !gw || !workspace || A < 8 || (A & 7) || B < 1 || ldx < B) return MVSNERF_EINVAL;
+    if (stride != 1 && stride != 2) return MVSNERF_EUNSUPPORTED;
+    const ActSrc G1{g1, g1_scale, g1_shift}, G2{g2, g2_scale, g2_shift}, X1{x1, x1_scale, x1_shift}, X2{x2, x2_scale, x2_shift};
+    const int64_t nvox = (int64_t)Do * Ho * Wo;
+    const int nwg = (int)(nvox < 512 ? nvox : 512);
+    const int np = (27 * B + 255) / 256;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(nwg, A / 8);
+#define MVS_WGR(NP_, S_) conv3d_wgrad_kernel<8, NP_, S_><<<grid, 256, 0, st>>>(G1, G2, A, X1, X2, B, ldx, Do, Ho, Wo, Di, Hi, Wi, workspace)
+    switch (np * 10 + stride) {
+        case 11: MVS_WGR(1, 1); break;  case 12: MVS_WGR(1, 2); break;
+        case 21: MVS_WGR(2, 1); break;  case 22: MVS_WGR(2, 2); break;
+        case 41: MVS_WGR(4, 1); break;  case 42: MVS_WGR(4, 2); break;
+        case 51: MVS_WGR(5, 1); break;
+        case 71: MVS_WGR(7, 1); break;
+        default: return MVSNERF_EUNSUPPORTED;
+    }
+#undef MVS_WGR
+    MVS_LAUNCH_CHECK();
+    const int64_t n_out = (int64_t)A * B * 27;
+    conv3d_wgrad_reduce_kernel<<<mvs_cdiv(n_out, 256), 256, 0, st>>>(workspace, nwg, n_out, gw);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// ---- plane-sweep backward: d cost[...variance channels] -> d feats (channel-last [V][H][W][32]).
+// var_c = s2*inv - (s*inv)^2 with s = sum of warped values, so for every contributing value w:
+//   d w = g_var * 2*inv*(w - s*inv).   Warped values are bilinear gathers => their gradient is a bilinear scatter
+// (float atomics).  Masks/counts are step functions (no gradient); thumbnails carry no parameters.
+template <int C>
+__global__ __launch_bounds__(256) void planesweep_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ proj, const float* __restrict__ depth,
+                                                            int V, int H, int W, int D, int pad, const float* __restrict__ g_cost, int CP, int c_var,
+                                                            float* __restrict__ g_feat)
+{
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const int64_t nvox = (int64_t)D * Hp * Wp;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvox) return;
+    const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), d = (int)(i / ((int64_t)Wp * Hp));
+    const float u = (float)(x - pad), v = (float)(y - pad), dep = depth[d];
+    const bool interior = x >= pad && x < W + pad && y >= pad && y < H + pad;
+    const float* gv = g_cost + i * CP + c_var;
+    // pass 1: s[c] and the view count
+    float s[C];
+    if (interior) {
+        const float* r = feat + ((int64_t)(y - pad) * W + (x - pad)) * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) s[c] = r[c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) s[c] = 0.f;
+    }
+    float cnt = 1.0f;
+    constexpr int MAXV = 8;
+    float tw[MAXV][4];
+    int ta[MAXV][4];
+    for (int vv = 1; vv < V; ++vv) {
+        const float* P = proj + vv * 12;
+        const float p0 = fmaf(P[2], 1.0f, fmaf(P[1], v, P[0] * u)) + P[3] / dep;
+        const float p1 = fmaf(P[6], 1.0f, fmaf(P[5], v, P[4] * u)) + P[7] / dep;
+        const float p2 = fmaf(P[10], 1.0f, fmaf(P[9], v, P[8] * u)) + P[11] / dep;
+        const float gx = (p0 / p2) / ((float)(W - 1) / 2.0f) - 1.0f, gy = (p1 / p2) / ((float)(H - 1) / 2.0f) - 1.0f;
+        cnt += (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;
+        const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1), iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+        const float fx = floorf(ix), fy = floorf(iy);
+        const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
+        const bool x0in = fx >= 0.f && fx <= (float)(W - 1), x1in = fx + 1.f >= 0.f && fx + 1.f <= (float)(W - 1);
+        const bool y0in = fy >= 0.f && fy <= (float)(H - 1), y1in = fy + 1.f >= 0.f && fy + 1.f <= (float)(H - 1);
+        tw[vv][0] = (x0in && y0in) ? wx0 * wy0 : 0.f; tw[vv][1] = (x1in && y0in) ? wx1 * wy0 : 0.f;
+        tw[vv][2] = (x0in && y1in) ? wx0 * wy1 : 0.f; tw[vv][3] = (x1in && y1in) ? wx1 * wy1 : 0.f;
+        const bool any = (x0in || x1in) && (y0in || y1in);
+        const int xa = any ? min(max((int)fx, 0), W - 1) : 0, xb = any ? min(max((int)fx + 1, 0), W - 1) : 0;
+        const int ya = any ? min(max((int)fy, 0), H - 1) : 0, yb = any ? min(max((int)fy + 1, 0), H - 1) : 0;
+        ta[vv][0] = ya * W + xa; ta[vv][1] = ya * W + xb; ta[vv][2] = yb * W + xa; ta[vv][3] = yb * W + xb;
+        const float* fb = feat + (int64_t)vv * H * W * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            s[c] += ((fb[(int64_t)ta[vv][0] * C + c] * tw[vv][0] + fb[(int64_t)ta[vv][1] * C + c] * tw[vv][1]) + fb[(int64_t)ta[vv][2] * C + c] * tw[vv][2]) + fb[(int64_t)ta[vv][3] * C + c] * tw[vv][3];
+    }
+    const float inv = 1.0f / cnt;
+    // pass 2: scatter
+    if (interior) {
+        const float* r = feat + ((int64_t)(y - pad) * W + (x - pad)) * C;
+        float* gr = g_feat + ((int64_t)(y - pad) * W + (x - pad)) * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) atomicAdd(gr + c, gv[c] * 2.0f * inv * (r[c] - s[c] * inv));
+    }
+    for (int vv = 1; vv < V; ++vv) {
+        const float* fb = feat + (int64_t)vv * H * W * C;
+        float* gb = g_feat + (int64_t)vv * H * W * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float wv = ((fb[(int64_t)ta[vv][0] * C + c] * tw[vv][0] + fb[(int64_t)ta[vv][1] * C + c] * tw[vv][1]) + fb[(int64_t)ta[vv][2] * C + c] * tw[vv][2]) + fb[(int64_t)ta[vv][3] * C + c] * tw[vv][3];
+            const float gw_ = gv[c] * 2.0f * inv * (wv - s[c] * inv);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (tw[vv][k] != 0.f) atomicAdd(gb + (int64_t)ta[vv][k] * C + c, gw_ * tw[vv][k]);
+        }
+    }
+}
+
+extern "C" int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float* proj, const float* depth, int V, int C, int H, int W, int D, int pad,
+                                              const float* g_cost, int CP, int with_img, float* g_feats_cl, void* stream)
+{
+    if (!feats_cl || !proj || !depth || !g_cost || !g_feats_cl || V < 1 || V > 8 || H < 2 || W < 2 || D < 1 || pad < 0) return MVSNERF_EINVAL;
+    if (C != 32) return MVSNERF_EUNSUPPORTED;
+    const int64_t nvox = (int64_t)D * (H + 2 * pad) * (W + 2 * pad);
+    planesweep_bwd_kernel<32><<<mvs_cdiv(nvox, 256), 256, 0, (hipStream_t)stream>>>(feats_cl, proj, depth, V, H, W, D, pad, g_cost, CP,
+                                                                                     with_img ? 3 * V : 0, g_feats_cl);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }

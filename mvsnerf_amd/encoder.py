@@ -71,11 +71,12 @@ class FeatureNet(nn.Module):
 
 # ------------------------------------------------------------------ channel-last plumbing
 class _Lazy:
-    """A raw conv output x[d][y][x][C] plus the (scale, shift) of its pending InPlaceABN."""
-    __slots__ = ("x", "scale", "shift", "dims")
+    """A raw conv output x[d][y][x][C] plus the (scale, shift) of its pending InPlaceABN (and the batch statistics
+    the backward pass needs)."""
+    __slots__ = ("x", "scale", "shift", "dims", "mean", "invstd")
 
-    def __init__(self, x, scale, shift, dims):
-        self.x, self.scale, self.shift, self.dims = x, scale, shift, dims      # dims = (D,H,W,C)
+    def __init__(self, x, scale, shift, dims, mean=None, invstd=None):
+        self.x, self.scale, self.shift, self.dims, self.mean, self.invstd = x, scale, shift, dims, mean, invstd
 
 
 def _cl_view_to_ncdhw(x_cl, C=None):
@@ -103,37 +104,52 @@ def _as_channel_last(x, cin_pad):
 
 
 class _PackedConv:
-    """Caches the [27][cin_pad][Cout] re-layout of a Conv3d / ConvTranspose3d weight (re-packed when it changes)."""
+    """Caches the [27][cin_pad][cout_pad] re-layouts of a Conv3d / ConvTranspose3d weight (re-packed when it changes).
+    mode 'fwd': the layer itself.  mode 'dgrad': the convolution that computes its data gradient -
+      Conv3d s1 -> Conv3d s1 with mirrored taps and swapped channel roles; Conv3d s2 -> ConvTranspose3d s2;
+      ConvTranspose3d s2 -> Conv3d s2."""
 
     def __init__(self, conv, transposed):
-        self.conv, self.transposed, self.key, self.buf = conv, transposed, None, None
+        self.conv, self.transposed, self.cache = conv, transposed, {}
+        w = conv.weight
+        self.cin, self.cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+        self.cin_pad = (self.cin + 3) // 4 * 4
 
-    def get(self):
+    def get(self, mode="fwd"):
         w = self.conv.weight
         key = (w.data_ptr(), w._version)
-        if key != self.key:
-            cin, cout = (w.shape[0], w.shape[1]) if self.transposed else (w.shape[1], w.shape[0])
-            cin_pad = (cin + 3) // 4 * 4
-            buf = torch.empty(27 * cin_pad * cout, device=w.device, dtype=torch.float32)
-            check(_lib.lib().mvsnerf_conv3d_pack_weights(dev_f32(w.detach().contiguous(), "conv weight"), cout, cin, cin_pad,
-                                                         int(self.transposed), buf.data_ptr(), stream_ptr()), "conv3d_pack_weights")
-            self.key, self.buf, self.cin_pad, self.cout = key, buf, cin_pad, cout
-        return self.buf
+        hit = self.cache.get(mode)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        cin, cout = self.cin, self.cout
+        if mode == "fwd":
+            ci_real, co_real, ci_pad, co_pad = cin, cout, self.cin_pad, cout
+            s_ci, s_co = (cout * 27, 27) if self.transposed else (27, cin * 27)
+            flip = 0
+        else:   # kernel channels: ci_k = this layer's outputs, co_k = this layer's inputs
+            ci_real, co_real, ci_pad, co_pad = cout, cin, cout, self.cin_pad
+            s_ci, s_co = (27, cout * 27) if self.transposed else (cin * 27, 27)
+            flip = 1 if (not self.transposed and self.conv.stride[0] == 1) else 0
+        buf = torch.empty(27 * ci_pad * co_pad, device=w.device, dtype=torch.float32)
+        check(_lib.lib().mvsnerf_conv3d_pack_weights(dev_f32(w.detach().contiguous(), "conv weight"), ci_real, co_real, ci_pad, co_pad,
+                                                     s_ci, s_co, flip, buf.data_ptr(), stream_ptr()), "conv3d_pack_weights")
+        self.cache[mode] = (key, buf)
+        return buf
 
 
 def _abn_stats(raw, n_vox, bn, update_running=True):
     C = bn.num_features
     dev = raw.device
-    scale = torch.empty(C, device=dev, dtype=torch.float32)
-    shift = torch.empty(C, device=dev, dtype=torch.float32)
+    out = torch.empty((4, C), device=dev, dtype=torch.float32)        # scale, shift, mean, invstd
     ws = torch.empty(_lib.lib().mvsnerf_abn_workspace_floats(C), device=dev, dtype=torch.float32)
     rm = bn.running_mean.data_ptr() if update_running else 0
     rv = bn.running_var.data_ptr() if update_running else 0
     check(_lib.lib().mvsnerf_abn_stats(raw.data_ptr(), n_vox, C, dev_f32(bn.weight.detach(), "bn.weight"), dev_f32(bn.bias.detach(), "bn.bias"),
-                                       rm, rv, bn.momentum, bn.eps, scale.data_ptr(), shift.data_ptr(), ws.data_ptr(), stream_ptr()), "abn_stats")
+                                       rm, rv, bn.momentum, bn.eps, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+                                       ws.data_ptr(), stream_ptr()), "abn_stats")
     if update_running:
         bn.num_batches_tracked += 1
-    return scale, shift
+    return out[0], out[1], out[2], out[3]
 
 
 def _ptrs(src):
@@ -145,21 +161,21 @@ def _ptrs(src):
     return src.data_ptr(), 0, 0
 
 
-def _conv(src1, src2, dims_in, cin_ld, packed, stride):
+def _conv(src1, src2, dims_in, cin_ld, wbuf, cin_k, cout_k, stride):
+    """k3 p1 convolution kernel launch: input (D,H,W) with channel stride cin_ld -> raw (Do,Ho,Wo,cout_k)."""
     D, H, W, _ = dims_in
     Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
-    w = packed.get()
-    out = torch.empty((Do, Ho, Wo, packed.cout), device=w.device, dtype=torch.float32)
-    check(_lib.lib().mvsnerf_conv3d_fwd(*_ptrs(src1), *_ptrs(src2), packed.cin_pad, cin_ld, D, H, W, w.data_ptr(), packed.cout, stride,
+    out = torch.empty((Do, Ho, Wo, cout_k), device=wbuf.device, dtype=torch.float32)
+    check(_lib.lib().mvsnerf_conv3d_fwd(*_ptrs(src1), *_ptrs(src2), cin_k, cin_ld, D, H, W, wbuf.data_ptr(), cout_k, stride,
                                         out.data_ptr(), stream_ptr()), "conv3d_fwd")
     return out
 
 
-def _conv_t(src1, src2, dims_in, packed):
+def _conv_t(src1, src2, dims_in, wbuf, cin_k, cout_k):
+    """k3 s2 p1 op1 transposed-convolution kernel launch: (D,H,W,cin_k) -> raw (2D,2H,2W,cout_k)."""
     D, H, W, _ = dims_in
-    w = packed.get()
-    out = torch.empty((2 * D, 2 * H, 2 * W, packed.cout), device=w.device, dtype=torch.float32)
-    check(_lib.lib().mvsnerf_conv_transpose3d_fwd(*_ptrs(src1), *_ptrs(src2), packed.cin_pad, D, H, W, w.data_ptr(), packed.cout,
+    out = torch.empty((2 * D, 2 * H, 2 * W, cout_k), device=wbuf.device, dtype=torch.float32)
+    check(_lib.lib().mvsnerf_conv_transpose3d_fwd(*_ptrs(src1), *_ptrs(src2), cin_k, D, H, W, wbuf.data_ptr(), cout_k,
                                                   out.data_ptr(), stream_ptr()), "conv_transpose3d_fwd")
     return out
 
@@ -185,10 +201,11 @@ class ConvBnReLU3D(nn.Module):
         self._packed = _PackedConv(self.conv, False)
 
     def lazy(self, src1, dims_in, cin_ld, src2=None):
-        raw = _conv(src1, src2, dims_in, cin_ld, self._packed, self.stride)
+        pk = self._packed
+        raw = _conv(src1, src2, dims_in, cin_ld, pk.get(), pk.cin_pad, pk.cout, self.stride)
         D, H, W, C = raw.shape
-        scale, shift = _abn_stats(raw, D * H * W, self.bn, update_running=self.bn.training)
-        return _Lazy(raw, scale, shift, (D, H, W, C))
+        scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self.bn, update_running=self.bn.training)
+        return _Lazy(raw, scale, shift, (D, H, W, C), mean, invstd)
 
     def forward(self, x):
         """Stand-alone call on a logical (1,Cin,D,H,W) tensor -> activated (1,Cout,D',H',W') (channel-last memory)."""
@@ -198,7 +215,6 @@ class ConvBnReLU3D(nn.Module):
         return _cl_view_to_ncdhw(_apply_add(self.lazy(buf, (D, H, W, ld), ld)))
 
     def _packed_cin_pad(self):
-        self._packed.get()
         return self._packed.cin_pad
 
 
@@ -210,14 +226,14 @@ class _UpBlock(nn.Sequential):
         self._packed = _PackedConv(self[0], True)
 
     def lazy(self, src1, dims_in, src2=None):
-        raw = _conv_t(src1, src2, dims_in, self._packed)
+        pk = self._packed
+        raw = _conv_t(src1, src2, dims_in, pk.get(), pk.cin_pad, pk.cout)
         D, H, W, C = raw.shape
-        scale, shift = _abn_stats(raw, D * H * W, self[1], update_running=self[1].training)
-        return _Lazy(raw, scale, shift, (D, H, W, C))
+        scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self[1], update_running=self[1].training)
+        return _Lazy(raw, scale, shift, (D, H, W, C), mean, invstd)
 
     def forward(self, x):
         ops._need_no_grad(x, *self.parameters(), op="ConvTranspose3d+ABN")
-        self._packed.get()
         buf, ld = _as_channel_last(x, self._packed.cin_pad)
         if ld != self._packed.cin_pad:
             raise RuntimeError("transposed conv input must be densely channel-last")
@@ -241,14 +257,15 @@ class CostRegNet(nn.Module):
         self.conv9 = _UpBlock(32, 16, norm_act)
         self.conv11 = _UpBlock(16, 8, norm_act)
 
-    def forward(self, x):
-        """x: logical (1,Cin,D,h,w) cost volume (D,h,w divisible by 8).  Returns (1,8,D,h,w), channel-last memory."""
-        ops._need_no_grad(x, *self.parameters(), op="CostRegNet")
+    def _layers(self):
+        return [self.conv0, self.conv1, self.conv2, self.conv3, self.conv4, self.conv5, self.conv6, self.conv7, self.conv9, self.conv11]
+
+    def _run(self, x):
+        """The lazily-activated U-Net; returns the 10 _Lazy layer outputs and the channel-last input."""
         _, C, D, H, W = x.shape
         if D % 8 or H % 8 or W % 8:
             raise RuntimeError(f"CostRegNet needs D,h,w divisible by 8 (three stride-2 stages), got {(D, H, W)}")
-        cin_pad = self.conv0._packed_cin_pad()
-        buf, ld = _as_channel_last(x, cin_pad)
+        buf, ld = _as_channel_last(x, self.conv0._packed_cin_pad())
         c0 = self.conv0.lazy(buf, (D, H, W, ld), ld)
         c1 = self.conv1.lazy(c0, c0.dims, 8)
         c2 = self.conv2.lazy(c1, c1.dims, 16)
@@ -259,7 +276,106 @@ class CostRegNet(nn.Module):
         u7 = self.conv7.lazy(c6, c6.dims)                       # x = conv4 + conv7(x)   (models.py:762)
         u9 = self.conv9.lazy(c4, c4.dims, src2=u7)              # x = conv2 + conv9(x)   (:764)
         u11 = self.conv11.lazy(c2, c2.dims, src2=u9)            # x = conv0 + conv11(x)  (:766)
-        return _cl_view_to_ncdhw(_apply_add(c0, u11))
+        return (buf, ld), [c0, c1, c2, c3, c4, c5, c6, u7, u9, u11]
+
+    def forward(self, x):
+        """x: logical (1,Cin,D,h,w) cost volume (D,h,w divisible by 8).  Returns (1,8,D,h,w), channel-last memory."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            params = []
+            for l in self._layers():
+                conv, bn = (l.conv, l.bn) if isinstance(l, ConvBnReLU3D) else (l[0], l[1])
+                params += [conv.weight, bn.weight, bn.bias]
+            return _CostRegFunction.apply(x, self, *params)
+        _, lz = self._run(x)
+        return _cl_view_to_ncdhw(_apply_add(lz[0], lz[9]))
+
+
+def _grad_cl(g, C):
+    """Upstream gradient of a logical (1,C,D,H,W) tensor -> contiguous channel-last (D,H,W,C) buffer."""
+    v = g[0].permute(1, 2, 3, 0)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def _abn_bwd(lz, bn, g1, g2=None):
+    """Train-mode InPlaceABN backward of one lazy layer.  g1 (+g2): grads w.r.t. its ACTIVATED output (channel-last).
+    Returns (grad w.r.t. the raw conv output, d bn.weight, d bn.bias)."""
+    D, H, W, C = lz.dims
+    dev = lz.x.device
+    gx = torch.empty((D, H, W, C), device=dev, dtype=torch.float32)
+    gwb = torch.empty((2, C), device=dev, dtype=torch.float32)
+    ws = torch.empty(_lib.lib().mvsnerf_abn_workspace_floats(C), device=dev, dtype=torch.float32)
+    check(_lib.lib().mvsnerf_abn_bwd(lz.x.data_ptr(), D * H * W, C, dev_f32(bn.weight.detach(), "bn.weight"), lz.scale.data_ptr(), lz.shift.data_ptr(),
+                                     lz.mean.data_ptr(), lz.invstd.data_ptr(), g1.data_ptr(), 0 if g2 is None else g2.data_ptr(),
+                                     gx.data_ptr(), gwb[0].data_ptr(), gwb[1].data_ptr(), ws.data_ptr(), stream_ptr()), "abn_bwd")
+    return gx, gwb[0], gwb[1]
+
+
+def _wgrad(G1, G2, A, X1, X2, B, ldx, g_dims, x_dims, stride, shape):
+    """gW[a][b][tap] = sum_o G[o][a] X[o*stride-1+tap][b]  (see mvsnerf_conv3d_wgrad)."""
+    lib = _lib.lib()
+    dev = (G1.x if isinstance(G1, _Lazy) else G1).device
+    gw = torch.empty(shape, device=dev, dtype=torch.float32)
+    ws = torch.empty(lib.mvsnerf_conv3d_wgrad_workspace_floats(A, B), device=dev, dtype=torch.float32)
+    check(lib.mvsnerf_conv3d_wgrad(*_ptrs(G1), *_ptrs(G2), A, *_ptrs(X1), *_ptrs(X2), B, ldx, g_dims[0], g_dims[1], g_dims[2],
+                                   x_dims[0], x_dims[1], x_dims[2], stride, gw.data_ptr(), ws.data_ptr(), stream_ptr()), "conv3d_wgrad")
+    return gw
+
+
+class _CostRegFunction(torch.autograd.Function):
+    """CostRegNet with gradients to the cost volume, the 10 conv weights and the 10 ABN weight/bias pairs."""
+
+    @staticmethod
+    def forward(ctx, x, net, *params):
+        (buf, ld), lz = net._run(x)
+        ctx.net, ctx.buf, ctx.ld, ctx.lz, ctx.xshape = net, buf, ld, lz, tuple(x.shape)
+        return _cl_view_to_ncdhw(_apply_add(lz[0], lz[9]))
+
+    @staticmethod
+    def backward(ctx, g_out):
+        net, lz, buf, ld = ctx.net, ctx.lz, ctx.buf, ctx.ld
+        c0, c1, c2, c3, c4, c5, c6, u7, u9, u11 = lz
+        L = net._layers()
+        g = _grad_cl(g_out, 8)                                  # grad w.r.t. A(c0) + A(u11)
+        grads = {}
+
+        def up_block(i, lay, out_lz, in1, in2, g_act1, g_act2=None):
+            """ConvTranspose3d+ABN `lay` (output out_lz, input A(in1)+A(in2)): returns grad w.r.t. its activated input."""
+            gx, gbw, gbb = _abn_bwd(out_lz, lay[1], g_act1, g_act2)
+            pk = lay._packed
+            gw = _wgrad(in1, in2, pk.cin, gx, None, pk.cout, pk.cout, in1.dims[:3], out_lz.dims[:3], 2, tuple(lay[0].weight.shape))
+            g_in = _conv(gx, None, out_lz.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin, 2)       # data grad = stride-2 conv
+            grads[i] = (gw, gbw, gbb)
+            return g_in
+
+        def conv_block(i, lay, out_lz, in1, in_dims, in_ld, g_act1, g_act2=None, need_dgrad=True):
+            gx, gbw, gbb = _abn_bwd(out_lz, lay.bn, g_act1, g_act2)
+            pk = lay._packed
+            gw = _wgrad(gx, None, pk.cout, in1, None, pk.cin, in_ld, out_lz.dims[:3], in_dims[:3], lay.stride, tuple(lay.conv.weight.shape))
+            grads[i] = (gw, gbw, gbb)
+            if not need_dgrad:
+                return None
+            if lay.stride == 1:
+                return _conv(gx, None, out_lz.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin_pad, 1)
+            return _conv_t(gx, None, out_lz.dims, pk.get("dgrad"), pk.cout, pk.cin_pad)
+
+        g_u9c2 = up_block(9, L[9], u11, c2, u9, g)               # conv11: grad w.r.t. A(c2)+A(u9)
+        g_u7c4 = up_block(8, L[8], u9, c4, u7, g_u9c2)           # conv9:  grad w.r.t. A(c4)+A(u7)
+        g_c6 = up_block(7, L[7], u7, c6, None, g_u7c4)           # conv7:  grad w.r.t. A(c6)
+        g_c5 = conv_block(6, L[6], c6, c5, c5.dims, 64, g_c6)
+        g_c4 = conv_block(5, L[5], c5, c4, c4.dims, 32, g_c5)
+        g_c3 = conv_block(4, L[4], c4, c3, c3.dims, 32, g_u7c4, g_c4)     # A(c4) feeds conv5 and the conv9 skip
+        g_c2 = conv_block(3, L[3], c3, c2, c2.dims, 16, g_c3)
+        g_c1 = conv_block(2, L[2], c2, c1, c1.dims, 16, g_u9c2, g_c2)     # A(c2) feeds conv3 and the conv11 skip
+        g_c0 = conv_block(1, L[1], c1, c0, c0.dims, 8, g_c1)
+        D, H, W = c0.dims[:3]
+        g_cost = conv_block(0, L[0], c0, buf, (D, H, W, ctx.ld), ctx.ld, g, g_c0, need_dgrad=ctx.needs_input_grad[0])   # A(c0) feeds conv1 and the output sum
+        # conv0's weight gradient covers the padded input channels too: keep the real ones
+        gw0 = grads[0][0]
+        out = [None if g_cost is None else _cl_view_to_ncdhw(g_cost, ctx.xshape[1]), None]
+        for i in range(10):
+            gw, gbw, gbb = grads[i]
+            out += [gw, gbw, gbb]
+        return tuple(out)
 
 
 # ------------------------------------------------------------------ MVSNet
@@ -286,6 +402,55 @@ def homo_warp(src_feat, proj_mat, depth_values, src_grid=None, pad=0):
     return warped, grid_out
 
 
+def _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img):
+    """One-pass plane sweep (homo_warp + cost variance [+ warped thumbnails]).  Returns (cost view, masks, saved)."""
+    B, V, C, H, W = feats.shape
+    dev = feats.device
+    lib = _lib.lib()
+    D = depth_values.shape[1]
+    Hp, Wp = H + 2 * pad, W + 2 * pad
+    feats_cl = torch.empty((V, H, W, C), device=dev, dtype=torch.float32)
+    check(lib.mvsnerf_nchw_to_nhwc(dev_f32(feats[0].detach().contiguous(), "feats"), feats_cl.data_ptr(), V, C, H, W, C, stream_ptr()), "nchw_to_nhwc")
+    imgs_cl_p = 0
+    if with_img:
+        Hi, Wi = imgs.shape[-2:]
+        small = torch.empty((V, 3, H, W), device=dev, dtype=torch.float32)                      # models.py:859
+        check(lib.mvsnerf_resize_bilinear(dev_f32(imgs[0].contiguous(), "imgs"), small.data_ptr(), V * 3, Hi, Wi, H, W, stream_ptr()), "resize_bilinear")
+        imgs_cl = torch.empty((V, H, W, 4), device=dev, dtype=torch.float32)
+        check(lib.mvsnerf_nchw_to_nhwc(small.data_ptr(), imgs_cl.data_ptr(), V, 3, H, W, 4, stream_ptr()), "nchw_to_nhwc")
+        imgs_cl_p = imgs_cl.data_ptr()
+    n_ch = (3 * V if with_img else 0) + C
+    CP = (n_ch + 3) // 4 * 4
+    cost = torch.empty((D, Hp, Wp, CP), device=dev, dtype=torch.float32)
+    masks = torch.empty((V, D, Hp, Wp) if with_img else (1, D, Hp, Wp), device=dev, dtype=torch.float32)
+    proj = proj_mats[0].detach().contiguous()
+    depth = depth_values[0].detach().contiguous()
+    check(lib.mvsnerf_planesweep_costvar_fwd(feats_cl.data_ptr(), imgs_cl_p, dev_f32(proj, "proj_mats"), dev_f32(depth, "depth_values"),
+                                             V, C, H, W, D, pad, cost.data_ptr(), CP, masks.data_ptr(), int(with_img), stream_ptr()),
+          "planesweep_costvar_fwd")
+    return _cl_view_to_ncdhw(cost, n_ch), masks.unsqueeze(0), (feats_cl, proj, depth, (V, C, H, W, D, pad, CP, n_ch))
+
+
+class _PlaneSweepFunction(torch.autograd.Function):
+    """Plane sweep with the gradient of the variance channels w.r.t. the source feature maps (bilinear scatter)."""
+
+    @staticmethod
+    def forward(ctx, feats, imgs, proj_mats, depth_values, pad, with_img):
+        cost, masks, saved = _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img)
+        ctx.saved, ctx.with_img = saved, with_img
+        ctx.mark_non_differentiable(masks)
+        return cost, masks
+
+    @staticmethod
+    def backward(ctx, g_cost, g_masks):
+        feats_cl, proj, depth, (V, C, H, W, D, pad, CP, n_ch) = ctx.saved
+        buf, ld = _as_channel_last(g_cost, CP)
+        g_feats = torch.zeros((V, H, W, C), device=feats_cl.device, dtype=torch.float32)
+        check(_lib.lib().mvsnerf_planesweep_costvar_bwd(feats_cl.data_ptr(), proj.data_ptr(), depth.data_ptr(), V, C, H, W, D, pad,
+                                                        buf.data_ptr(), ld, int(ctx.with_img), g_feats.data_ptr(), stream_ptr()), "planesweep_costvar_bwd")
+        return g_feats.permute(0, 3, 1, 2).unsqueeze(0), None, None, None, None, None
+
+
 class MVSNet(nn.Module):
     """reference models.py:771-932."""
 
@@ -301,41 +466,20 @@ class MVSNet(nn.Module):
         self.D = 128          # number of depth planes (hard-coded `D = 128` at models.py:914; settable here for config 1)
 
     def _sweep(self, imgs, feats, proj_mats, depth_values, pad, with_img):
-        B, V, C, H, W = feats.shape
-        if B != 1:
+        if feats.shape[0] != 1:
             raise RuntimeError("MVSNet: batch size must be 1 (the reference assumes it, models.py:916)")
-        dev = feats.device
-        lib = _lib.lib()
-        D = depth_values.shape[1]
-        Hp, Wp = H + 2 * pad, W + 2 * pad
-        feats_cl = torch.empty((V, H, W, C), device=dev, dtype=torch.float32)
-        check(lib.mvsnerf_nchw_to_nhwc(dev_f32(feats[0].contiguous(), "feats"), feats_cl.data_ptr(), V, C, H, W, C, stream_ptr()), "nchw_to_nhwc")
-        imgs_cl_p = 0
-        if with_img:
-            Hi, Wi = imgs.shape[-2:]
-            small = torch.empty((V, 3, H, W), device=dev, dtype=torch.float32)                      # models.py:859
-            check(lib.mvsnerf_resize_bilinear(dev_f32(imgs[0].contiguous(), "imgs"), small.data_ptr(), V * 3, Hi, Wi, H, W, stream_ptr()), "resize_bilinear")
-            imgs_cl = torch.empty((V, H, W, 4), device=dev, dtype=torch.float32)
-            check(lib.mvsnerf_nchw_to_nhwc(small.data_ptr(), imgs_cl.data_ptr(), V, 3, H, W, 4, stream_ptr()), "nchw_to_nhwc")
-            imgs_cl_p = imgs_cl.data_ptr()
-        n_ch = (3 * V if with_img else 0) + C
-        CP = (n_ch + 3) // 4 * 4
-        cost = torch.empty((D, Hp, Wp, CP), device=dev, dtype=torch.float32)
-        masks = torch.empty((V, D, Hp, Wp) if with_img else (1, D, Hp, Wp), device=dev, dtype=torch.float32)
-        check(lib.mvsnerf_planesweep_costvar_fwd(feats_cl.data_ptr(), imgs_cl_p, dev_f32(proj_mats[0].contiguous(), "proj_mats"),
-                                                 dev_f32(depth_values[0].contiguous(), "depth_values"), V, C, H, W, D, pad,
-                                                 cost.data_ptr(), CP, masks.data_ptr(), int(with_img), stream_ptr()), "planesweep_costvar_fwd")
-        return _cl_view_to_ncdhw(cost, n_ch), masks.unsqueeze(0)
+        if torch.is_grad_enabled() and feats.requires_grad:
+            return _PlaneSweepFunction.apply(feats, imgs, proj_mats, depth_values, pad, with_img)
+        cost, masks, _ = _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img)
+        return cost, masks
 
     def build_volume_costvar(self, feats, proj_mats, depth_values, pad=0):
         """reference models.py:787-837 -> (variance (B,32,D,h,w), in_masks (B,1,D,h,w) view count)."""
-        ops._need_no_grad(feats, op="build_volume_costvar")
         return self._sweep(None, feats, proj_mats, depth_values, pad, False)
 
     def build_volume_costvar_img(self, imgs, feats, proj_mats, depth_values, pad=0):
         """reference models.py:839-893 -> (img_feat (B,3V+32,D,h,w), in_masks (B,V,D,h,w)).
         The border of channels 0:3 (uninitialised in the reference, models.py:858) is defined as 0."""
-        ops._need_no_grad(imgs, feats, op="build_volume_costvar_img")
         return self._sweep(imgs, feats, proj_mats, depth_values, pad, True)
 
     def forward(self, imgs, proj_mats, near_far, pad=0, return_color=False, lindisp=False):

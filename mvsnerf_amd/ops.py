@@ -11,8 +11,9 @@ from ._lib import check, dev_f32, stream_ptr
 def _need_no_grad(*tensors, op):
     if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors):
         raise NotImplementedError(
-            f"{op}: the backward HIP kernel for this op is not built yet (round 1 ships the forward/"
-            "inference path); call under torch.no_grad()")
+            f"{op}: this stand-alone op has no backward kernel (gradients are provided for the fused paths: "
+            "renderer.rendering / RefVolume -> ops.RayMarchFunction, MVSNet.build_volume_costvar* and CostRegNet); "
+            "call it under torch.no_grad() or go through those entry points")
 
 
 # ------------------------------------------------------------------ volume layout

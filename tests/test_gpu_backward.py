@@ -86,3 +86,43 @@ def test_composite_backward_alone():
         torch.cuda.synchronize()
         err = float((d_raw.cpu() - raw.grad).abs().max())
         assert err < 1e-4 * max(1.0, float(raw.grad.abs().max())), (S, err)
+
+
+def test_encoder_backward_vs_autograd():
+    """Plane sweep + CostRegNet backward (grads of all conv / ABN parameters and of the source features) against
+    PyTorch autograd through the CPU oracle.  Small shapes: features 16x24, pad 4, D=16."""
+    from mvsnerf_amd import models
+    from mvsnerf_amd.synth import make_rig
+    from oracle import mvsnerf_oracle as O
+    _, sd0 = load_weights()
+    rig = make_rig(64, 96, seed=31, rot_deg=2.0, smooth=True)
+    pad, D = 4, 16
+    imgs, proj = rig["images"][:, :3], rig["proj_mats"][:, :3]
+    g = torch.Generator().manual_seed(4)
+    feats0 = O.feature_net(imgs[0], sd0)[None].detach()
+    dv = O.depth_planes(2.125, 4.525, D)
+    Rw = torch.randn((1, 8, D, 16 + 2 * pad, 24 + 2 * pad), generator=g)
+
+    # reference: autograd through the oracle
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd0.items()}
+    f_ref = feats0.clone().requires_grad_(True)
+    cost_ref, _ = O.build_volume_costvar_img(imgs, f_ref, proj, dv, pad)
+    vol_ref = O.cost_reg_net(cost_ref, sd)
+    (vol_ref * Rw).sum().backward()
+
+    net = models.MVSNet()
+    net.load_state_dict(sd0)
+    net = net.to(DEV).train()
+    f = feats0.clone().to(DEV).requires_grad_(True)
+    cost, _ = net.build_volume_costvar_img(imgs.to(DEV), f, proj.to(DEV), dv.to(DEV), pad=pad)
+    vol = net.cost_reg_2(cost)
+    assert float((vol.detach().cpu() - vol_ref.detach()).abs().max()) < 2e-3
+    (vol * Rw.to(DEV)).sum().backward()
+
+    def rel(a, b):
+        return float((a.cpu() - b).abs().max() / (b.abs().max() + 1e-12))
+    errs = {"feats": rel(f.grad, f_ref.grad)}
+    for name, p in net.cost_reg_2.named_parameters():
+        errs[name] = rel(p.grad, sd["cost_reg_2." + name].grad)
+    bad = {k: v for k, v in errs.items() if not v < 5e-3}
+    assert not bad, f"encoder gradient mismatches: {bad}\nall: {errs}"

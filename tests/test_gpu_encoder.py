@@ -117,18 +117,19 @@ def test_abn_stats_and_conv_vs_torch_full_size():
     bn = E.InPlaceABN(8).to(DEV)
     with torch.no_grad():
         bn.weight.copy_(torch.rand(8, generator=g) + 0.5); bn.bias.copy_(torch.randn(8, generator=g))
-        scale, shift = E._abn_stats(x, D * H * W, bn, update_running=True)
+        scale, shift, mean_k, invstd_k = E._abn_stats(x, D * H * W, bn, update_running=True)
         xf = x.view(-1, 8).double()
         mean, var = xf.mean(0), xf.var(0, unbiased=False)
         sc_ref = (bn.weight.abs().double() + 1e-5) / torch.sqrt(var + 1e-5)
         assert maxabs(scale.cpu(), sc_ref.cpu().float()) < 1e-6
         assert maxabs(shift.cpu(), (bn.bias.double() - mean * sc_ref).cpu().float()) < 1e-5
         assert maxabs(bn.running_mean.cpu(), (0.1 * mean).cpu().float()) < 1e-6
+        assert maxabs(mean_k.cpu(), mean.cpu().float()) < 1e-6 and maxabs(invstd_k.cpu(), (1 / torch.sqrt(var + 1e-5)).cpu().float()) < 1e-6
         # conv0-shaped convolution on a smaller slab (torch's MIOpen conv as the fp32 reference)
         d = 16
         xin = torch.randn((1, 41, d, H, W), generator=g).to(DEV)
         conv = E.ConvBnReLU3D(41, 8).to(DEV)
         buf, ld = E._as_channel_last(xin, 44)
-        raw = E._conv(buf, None, (d, H, W, ld), ld, conv._packed, 1)
+        raw = E._conv(buf, None, (d, H, W, ld), ld, conv._packed.get(), conv._packed.cin_pad, conv._packed.cout, 1)
         ref = F.conv3d(xin, conv.conv.weight, None, padding=1)[0].permute(1, 2, 3, 0)
         assert maxabs(raw.cpu(), ref.cpu()) < 2e-4
