@@ -1,0 +1,207 @@
+"""Training entry points of the reference on the HIP hot path, without pytorch_lightning (not in this image).
+
+`MVSSystem` mirrors `train_mvs_nerf_pl.py:34-288`: same constructor argument (`args` from opt.py), same
+`decode_batch / unpreprocess / configure_optimizers / training_step(batch, batch_nb) -> {'loss': loss} / save_ckpt`
+methods, same batch dict schema (data/dtu.py:199-211 collated with B=1), same `self.log` keys, same checkpoint keys.
+A real `pytorch_lightning.LightningModule` can be mixed in unchanged; `_ModuleShim` provides the three attributes
+the step uses (`log`, `global_step`, `device`) when Lightning is absent.
+
+Multi-GPU: ray-sharded data parallelism - every rank encodes the same scene and draws the same
+pixel ids (same CPU-RNG state), renders its slice of the rays, and the gradients are averaged by ONE flat-buffer
+all-reduce (mvsnerf_amd.distributed.FlatGradAllReduce; RCCL over xGMI on GPUs).
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from . import distributed as D
+from .models import create_nerf_mvs
+from .renderer import rendering
+from .utils import build_rays, build_rays_test, img2mse
+
+
+def mse2psnr2(x):
+    import math
+    return -10.0 * math.log(max(x, 1e-20)) / math.log(10.0)
+
+
+class SL1Loss(nn.Module):
+    """reference train_mvs_nerf_pl.py:22-32."""
+
+    def __init__(self, levels=3):
+        super().__init__()
+        self.loss = nn.SmoothL1Loss(reduction="mean")
+
+    def forward(self, depth_pred, depth_gt, mask=None):
+        if mask is None:
+            mask = depth_gt > 0
+        return self.loss(depth_pred[mask], depth_gt[mask]) * 2 ** (1 - 2)
+
+
+class _ModuleShim(nn.Module):
+    """What `training_step` needs from LightningModule."""
+
+    def __init__(self):
+        super().__init__()
+        self.global_step = 0
+        self.logged = {}
+
+    def log(self, key, value, prog_bar=False, **kw):
+        self.logged[key] = float(value.detach()) if torch.is_tensor(value) else float(value)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+
+class MVSSystem(_ModuleShim):
+    """reference train_mvs_nerf_pl.py:34-288 (generalizable training)."""
+
+    def __init__(self, args, n_depth_planes=128):
+        super().__init__()
+        self.args = args
+        self.args.feat_dim = 8 + 3 * 4                                   # :38
+        self.idx = 0
+        self.loss = SL1Loss()
+        self.learning_rate = args.lrate
+        kw_train, kw_test, _, self.grad_vars = create_nerf_mvs(args, use_mvs=True, dir_embedder=False, pts_embedder=True)   # :45
+        for k in ("N_samples", "ndc", "lindisp"):                        # filter_keys, utils.py:418-424
+            kw_train.pop(k, None)
+        self.render_kwargs_train, self.render_kwargs_test = kw_train, kw_test
+        self.MVSNet = kw_train.pop("network_mvs")                        # registered as sub-module `MVSNet` like the reference
+        self.MVSNet.D = n_depth_planes
+        self.network_fn = kw_train["network_fn"]                         # registers the MLP parameters
+        self.render_kwargs_train["NDC_local"] = False
+        self.eval_metric = [0.01, 0.05, 0.1]
+        self._allreduce = None
+
+    # -- data plumbing -------------------------------------------------------------------------
+    def decode_batch(self, batch):
+        """:56-62 - move to device, squeeze the B=1 dim of the pose tensors."""
+        dev = self.device
+        data = {k: (v.float().to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        pose_ref = {k: data[k].squeeze(0) if data[k].dim() > 3 or k == "near_fars" else data[k]
+                    for k in ("w2cs", "intrinsics", "c2ws", "near_fars")}
+        return data, pose_ref
+
+    @staticmethod
+    def unpreprocess(data, shape=(1, 1, 3, 1, 1)):
+        """:64-71 - undo the ImageNet normalisation (colour lookups use raw [0,1] images)."""
+        mean = torch.tensor([-0.485 / 0.229, -0.456 / 0.224, -0.406 / 0.225], device=data.device).view(*shape)
+        std = torch.tensor([1 / 0.229, 1 / 0.224, 1 / 0.225], device=data.device).view(*shape)
+        return (data - mean) / std
+
+    def configure_optimizers(self):
+        """:84-88."""
+        self.optimizer = torch.optim.Adam(self.grad_vars, lr=self.learning_rate, betas=(0.9, 0.999))
+        sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=self.args.num_epochs, eta_min=1e-7)
+        return [self.optimizer], [sched]
+
+    # -- the step ------------------------------------------------------------------------------
+    def training_step(self, batch, batch_nb):
+        """:104-168.  Returns {'loss': loss}; gradients are left to the caller (Lightning or `fit_steps`)."""
+        args = self.args
+        batch = dict(batch)
+        batch.pop("scan", None)
+        data_mvs, pose_ref = self.decode_batch(batch)
+        imgs, proj_mats = data_mvs["images"], data_mvs["proj_mats"]
+        near_fars, depths_h = data_mvs["near_fars"], data_mvs["depths_h"]
+
+        volume_feature, _, _ = self.MVSNet(imgs[:, :3], proj_mats[:, :3], near_fars[0, 0], pad=args.pad)        # :113
+        imgs = self.unpreprocess(imgs)
+        N_rays, N_samples = args.batch_size, args.N_samples
+        rays_pts, rays_dir, target_s, rays_NDC, depth_candidates, rays_o, rays_depth, _ = build_rays(
+            imgs, depths_h, pose_ref, pose_ref["w2cs"], pose_ref["c2ws"], pose_ref["intrinsics"], near_fars, N_rays, N_samples, pad=args.pad)  # :119
+        world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        if world > 1:                                                    # ray-sharded DP: same draw on all ranks, local slice
+            sl = D.shard_rays(N_rays, world, torch.distributed.get_rank())
+            rays_pts, rays_dir, target_s, rays_NDC, depth_candidates = (t[sl] for t in (rays_pts, rays_dir, target_s, rays_NDC, depth_candidates))
+            rays_o = rays_o[:, sl]
+            rays_depth = None if rays_depth is None else rays_depth[sl]
+        rgb, disp, acc, depth_pred, alpha, ret = rendering(args, pose_ref, rays_pts, rays_NDC, depth_candidates, rays_o, rays_dir,
+                                                           volume_feature, imgs[:, :-1], img_feat=None, **self.render_kwargs_train)   # :123
+        loss = 0
+        if getattr(args, "with_depth", False):
+            mask = rays_depth > 0
+            if getattr(args, "with_depth_loss", False):
+                loss = loss + self.loss(depth_pred, rays_depth, mask)
+            self.log("train/abs_err", (depth_pred - rays_depth)[mask].abs().mean(), prog_bar=True)
+        img_loss = img2mse(rgb, target_s)                                # :143
+        loss = loss + img_loss
+        with torch.no_grad():
+            self.log("train/loss", loss, prog_bar=True)
+            self.log("train/img_mse_loss", img_loss)
+            self.log("train/PSNR", mse2psnr2(float(img_loss.detach())), prog_bar=True)
+        if self.global_step % 20000 == 19999:
+            self.save_ckpt(f"{self.global_step}")
+        return {"loss": loss}
+
+    @torch.no_grad()
+    def render_view(self, batch, chunk=None):
+        """The rendering part of validation_step (:172-254): encode once, then the chunk loop over the target view's
+        pixels - tile-parallel over ranks (contiguous chunk ranges + one all_gather).  Returns (rgb (H,W,3), depth (H,W))."""
+        args = self.args
+        chunk = chunk or args.chunk
+        data_mvs, pose_ref = self.decode_batch(dict(batch))
+        imgs, proj_mats, near_fars = data_mvs["images"], data_mvs["proj_mats"], pose_ref["near_fars"]
+        H, W = int(imgs.shape[-2]), int(imgs.shape[-1])
+        self.MVSNet.train()                                              # :182 batch-statistics ABN also at inference
+        volume_feature, _, _ = self.MVSNet(imgs[:, :3], proj_mats[:, :3], near_fars[0], pad=args.pad)
+        imgs = self.unpreprocess(imgs)
+        world_to_ref, tgt_to_world, intrinsic = pose_ref["w2cs"][0], pose_ref["c2ws"][-1], pose_ref["intrinsics"][-1]
+
+        def render_chunk(idx):
+            rays_pts, rays_dir, rays_NDC, depth_candidates, rays_o, _ = build_rays_test(
+                H, W, tgt_to_world, world_to_ref, intrinsic, near_fars, near_fars[-1], args.N_samples, pad=args.pad, chunk=chunk, idx=idx)
+            rgb, _, _, depth_pred, _, _ = rendering(args, pose_ref, rays_pts, rays_NDC, depth_candidates, rays_o, rays_dir,
+                                                    volume_feature, imgs[:, :-1], img_feat=None, **self.render_kwargs_train)
+            return rgb, depth_pred
+        rgb, depth = D.render_frame(render_chunk, H, W, chunk)
+        return rgb.reshape(H, W, 3), depth.reshape(H, W)
+
+    def save_ckpt(self, name="latest"):
+        """:277-288 - same dict keys as the reference's .tar checkpoints."""
+        save_dir = f"runs_new/{getattr(self.args, 'expname', 'exp')}/ckpts/"
+        os.makedirs(save_dir, exist_ok=True)
+        path = f"{save_dir}/{name}.tar"
+        torch.save({"global_step": self.global_step, "network_fn_state_dict": self.render_kwargs_train["network_fn"].state_dict(),
+                    "network_mvs_state_dict": self.MVSNet.state_dict()}, path)
+        return path
+
+    # -- minimal trainer -----------------------------------------------------------------------
+    def fit_steps(self, batches, optimizer=None):
+        """Lightning-free loop: training_step -> backward -> (flat-buffer all-reduce) -> Adam step."""
+        if optimizer is None:
+            optimizer = self.configure_optimizers()[0][0]
+        if self._allreduce is None:
+            self._allreduce = D.FlatGradAllReduce(self.grad_vars)
+        losses = []
+        for i, batch in enumerate(batches):
+            optimizer.zero_grad(set_to_none=True)
+            out = self.training_step(batch, i)
+            out["loss"].backward()
+            self._allreduce()
+            optimizer.step()
+            self.global_step += 1
+            losses.append(float(out["loss"].detach()))
+        return losses
+
+
+def synthetic_batch(H=512, W=640, seed=1234, **rig_kw):
+    """A `MVSDatasetDTU.__getitem__`-shaped batch (collated, B=1) from the seeded synthetic rig."""
+    from .synth import make_rig
+    rig = make_rig(H, W, seed=seed, **rig_kw)
+    return {"images": rig["images"], "proj_mats": rig["proj_mats"], "w2cs": rig["w2cs"], "c2ws": rig["c2ws"],
+            "intrinsics": rig["intrinsics"], "near_fars": rig["near_fars"], "depths_h": torch.zeros(1, 4, 1, 1)}
+
+
+def default_args(**over):
+    """opt.py defaults of the fields the hot path reads (the reference parses them with configargparse)."""
+    import types
+    d = dict(expname="exp", pad=24, batch_size=1024, num_epochs=8, pts_dim=3, dir_dim=3, net_type="v0", netdepth=6, netwidth=128,
+             lrate=5e-4, chunk=1024, netchunk=1024, ckpt=None, N_samples=128, N_importance=0, perturb=1.0, use_viewdirs=True,
+             i_embed=0, multires=10, multires_views=4, raw_noise_std=0.0, white_bkgd=False, img_downscale=1.0,
+             use_color_volume=False, with_depth=False, with_depth_loss=False, feat_dim=20)
+    d.update(over)
+    return types.SimpleNamespace(**d)
