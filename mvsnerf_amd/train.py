@@ -205,3 +205,84 @@ def default_args(**over):
              use_color_volume=False, with_depth=False, with_depth_loss=False, feat_dim=20)
     d.update(over)
     return types.SimpleNamespace(**d)
+
+
+# ------------------------------------------------------------------ per-scene fine-tuning (reference train_mvs_nerf_finetuning_pl.py)
+def ray_marcher(rays, N_samples=64, lindisp=False, perturb=0):
+    """reference data/ray_utils.py:152-197 (bbox_3D=None): rays (N,8) = [o(3) | d(3) | near | far] -> z-sampled points.
+    Host-side torch like the reference (it owns the jitter draw)."""
+    n = rays.shape[0]
+    rays_o, rays_d, near, far = rays[:, 0:3], rays[:, 3:6], rays[:, 6:7], rays[:, 7:8]
+    steps = torch.linspace(0, 1, N_samples, device=rays.device)
+    z = near * (1 - steps) + far * steps if not lindisp else 1 / (1 / near * (1 - steps) + 1 / far * steps)
+    z = z.expand(n, N_samples)
+    if perturb > 0:
+        mid = 0.5 * (z[:, :-1] + z[:, 1:])
+        upper, lower = torch.cat([mid, z[:, -1:]], -1), torch.cat([z[:, :1], mid], -1)
+        z = lower + (upper - lower) * (perturb * torch.rand(z.shape, device=rays.device))
+    return rays_o.unsqueeze(1) + rays_d.unsqueeze(1) * z.unsqueeze(2), rays_o, rays_d, z
+
+
+class MVSSystemFinetune(_ModuleShim):
+    """reference train_mvs_nerf_finetuning_pl.py:32-189: the scene is encoded ONCE (`init_volume`), the 8-channel
+    volume becomes a learnable `RefVolume` (checkpoint key `volume.feat_volume`) and only the ray march runs per step;
+    gradients flow to the MLP and to the volume (trilinear scatter kernel)."""
+
+    def __init__(self, args, source_views, n_depth_planes=128):
+        """source_views = (imgs (1,V,3,H,W) normalised, proj_mats (1,V,3,4), near_far (2,), pose_source dict) -
+        what `dataset.read_source_views()` returns in the reference."""
+        super().__init__()
+        from .models import RefVolume
+        self.args = args
+        self.args.feat_dim = 8 + 3 * 4
+        kw_train, _, _, self.grad_vars = create_nerf_mvs(args, use_mvs=True, dir_embedder=False, pts_embedder=True)
+        for k in ("N_samples", "ndc", "lindisp"):
+            kw_train.pop(k, None)
+        self.render_kwargs_train = kw_train
+        self.MVSNet = kw_train.pop("network_mvs")
+        self.MVSNet.D = n_depth_planes
+        self.network_fn = kw_train["network_fn"]
+        imgs, proj_mats, near_far, pose = source_views
+        dev = next(self.MVSNet.parameters()).device
+        self.near_far_source = near_far.to(dev)
+        self.pose_source = {k: v.to(dev) for k, v in pose.items()}
+        self.MVSNet.train()                                               # :62
+        with torch.no_grad():                                             # init_volume :57-89
+            vol, _, _ = self.MVSNet(imgs.to(dev), proj_mats.to(dev), self.near_far_source, pad=args.pad, lindisp=getattr(args, "use_disp", False))
+        self.imgs = MVSSystem.unpreprocess(imgs.to(dev))
+        self.volume = RefVolume(vol.detach())
+        self.grad_vars = [p for p in self.network_fn.parameters()] + list(self.volume.parameters())    # MVSNet stays frozen here
+        self._allreduce = None
+
+    def training_step(self, batch, batch_nb):
+        """:140-189.  batch = {'rays': (1,B,8), 'rgbs': (1,B,3)} from the all-rays buffer."""
+        args = self.args
+        rays, target = batch["rays"].squeeze(0).to(self.imgs.device), batch["rgbs"].squeeze(0).to(self.imgs.device)
+        pts, rays_o, rays_d, z_vals = ray_marcher(rays, N_samples=args.N_samples, lindisp=getattr(args, "use_disp", False), perturb=args.perturb)
+        H, W = self.imgs.shape[-2:]
+        inv_scale = torch.tensor([W - 1, H - 1]).to(self.imgs.device)
+        from .utils import get_ndc_coordinate
+        ndc = get_ndc_coordinate(self.pose_source["w2cs"][0], self.pose_source["intrinsics"][0], pts, inv_scale,
+                                 near=self.near_far_source[0], far=self.near_far_source[1], pad=args.pad, lindisp=getattr(args, "use_disp", False))
+        rgbs, _, _, depth_pred, _, _ = rendering(args, self.pose_source, pts, ndc, z_vals, rays_o, rays_d, self.volume, self.imgs,
+                                                 **self.render_kwargs_train)
+        img_loss = img2mse(rgbs, target)
+        with torch.no_grad():
+            self.log("train/loss", img_loss, prog_bar=True)
+            self.log("train/PSNR", mse2psnr2(float(img_loss.detach())), prog_bar=True)
+        return {"loss": img_loss}
+
+    def save_ckpt(self, name="latest"):
+        """:277-291 of the fine-tuning script: adds the `volume` state dict."""
+        save_dir = f"runs_fine_tuning/{getattr(self.args, 'expname', 'exp')}/ckpts/"
+        os.makedirs(save_dir, exist_ok=True)
+        path = f"{save_dir}/{name}.tar"
+        torch.save({"global_step": self.global_step, "network_fn_state_dict": self.network_fn.state_dict(),
+                    "volume": self.volume.state_dict(), "network_mvs_state_dict": self.MVSNet.state_dict()}, path)
+        return path
+
+    fit_steps = MVSSystem.fit_steps
+
+    def configure_optimizers(self):
+        self.optimizer = torch.optim.Adam(self.grad_vars, lr=self.args.lrate, betas=(0.9, 0.999))
+        return [self.optimizer], []

@@ -114,3 +114,30 @@ def test_render_view_full_frame():
     assert bool(torch.isfinite(rgb).all()) and float(rgb.min()) >= 0 and float(rgb.max()) <= 1.0 + 1e-5
     rgb2, _ = sys_.render_view(batch, chunk=777)          # chunking must not change the image
     assert float((rgb - rgb2).abs().max()) < 1e-5
+
+
+def test_finetune_step_trains_volume_and_mlp():
+    """Config-4 code path (per-scene fine-tune): encode once -> learnable RefVolume + MLP; grads reach both."""
+    from mvsnerf_amd import train
+    from mvsnerf_amd.synth import make_rig, pose_ref_of
+    args = train.default_args(pad=4, batch_size=256, N_samples=32)
+    rig = make_rig(64, 96, seed=8, smooth=True)
+    pose = pose_ref_of(rig)
+    src = (rig["images"][:, :3], rig["proj_mats"][:, :3], rig["near_fars"][0, 0], {k: v[:3] for k, v in pose.items()})
+    ft = train.MVSSystemFinetune(args, src, n_depth_planes=16).to(DEV)
+    mlp_sd, mvs_sd = load_weights()
+    ft.network_fn.load_state_dict(mlp_sd)
+    g = torch.Generator().manual_seed(0)
+    # rays of the 4th view as the all-rays buffer would hold them: [o | d | near | far], target colours
+    from oracle import mvsnerf_oracle as O
+    ro, rd, pix = O.get_rays_mvs(64, 96, pose["intrinsics"][3], pose["c2ws"][3], 256, generator=g)
+    rays = torch.cat([ro.expand(256, 3), rd, torch.full((256, 1), 2.125), torch.full((256, 1), 4.525)], 1)
+    tgt = rig["images_raw"][0, 3][:, pix[0].long(), pix[1].long()].permute(1, 0)
+    batch = {"rays": rays[None], "rgbs": tgt[None]}
+    v0 = ft.volume.feat_volume.detach().clone()
+    torch.manual_seed(0)
+    losses = ft.fit_steps([batch] * 10)
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    assert float((ft.volume.feat_volume.detach() - v0).abs().max()) > 0            # the volume itself is being optimised
+    assert ft.volume.feat_volume.shape == (1, 8, 16, 24, 32)
+    assert "feat_volume" in ft.volume.state_dict()
