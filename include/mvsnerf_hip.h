@@ -34,9 +34,14 @@ extern "C" {
 /* ABI version; bumped on any signature change. */
 int mvsnerf_abi_version(void);
 
-/* A/B benchmarking knob, not part of the reference surface.  Keys: "mlp_variant" = 0 (32 points/wave,
- * 2 waves/SIMD), 1 (64 points/wave, 1 wave/SIMD), 2 (32 points/wave, 1 wave/SIMD).  Results are identical. */
+/* A/B benchmarking knob, not part of the reference surface.  Keys: "mlp_variant" = 3 (default: 32 points/wave,
+ * 2 waves/SIMD, weights double-buffered through LDS by LDS-DMA), 0 (same, register-staged weights), 1 (64 points/wave,
+ * 1 wave/SIMD), 2 (32 points/wave, 1 wave/SIMD); "conv_tiled" = 1|0.  Results are identical up to summation order. */
 int mvsnerf_tune(const char* key, int value);
+/* Diagnostics: resident workgroups per CU the runtime grants the MLP kernel variant (occupancy query). */
+int mvsnerf_debug_mlp_occupancy(int variant);
+/* Diagnostics: when non-NULL, every workgroup of the pipelined MLP kernel records {start, end (100 MHz clock), HW_ID, XCC_ID}. */
+int mvsnerf_debug_set_census(long long* buf);
 
 /* ---------------------------------------------------------------- layout helpers */
 

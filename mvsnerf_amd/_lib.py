@@ -35,6 +35,8 @@ class RaymarchArgs(ctypes.Structure):
 SIGNATURES = {
     "mvsnerf_abi_version": (_c_i, []),
     "mvsnerf_tune": (_c_i, [ctypes.c_char_p, _c_i]),
+    "mvsnerf_debug_mlp_occupancy": (_c_i, [_c_i]),
+    "mvsnerf_debug_set_census": (_c_i, [_c_fp]),
     "mvsnerf_ncdhw_to_ndhwc": (_c_i, [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp]),
     "mvsnerf_ndhwc_to_ncdhw": (_c_i, [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp]),
     "mvsnerf_nchw_to_nhwc": (_c_i, [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp]),

@@ -151,6 +151,29 @@ __device__ __forceinline__ void init_acc(f32x16 (&acc)[G][NBLK], const float* __
         }
 }
 
+// sin or cos of x for the positional encoding (x = ndc * 2^f, f <= 9, ndc in [0,1] inside the volume): Cody-Waite
+// reduction by pi/2 in three fma steps (k*C1 is exact for |k| < 2^16, i.e. |x| < 1e5), cephes minimax polynomials on
+// [-pi/4, pi/4], quadrant select.  cos(x) = sin(x + pi/2) is a quadrant shift, so every lane evaluates one polynomial
+// pair and picks.  Branch-free on purpose (a branch here would cut the unrolled MFMA stream into basic blocks).
+// Max abs error 7.6e-8 on |x| <= 1600 (numpy float32 sin: 6.6e-8).  Arguments are clamped to +-65536, i.e. samples
+// more than 128 volume-widths outside the frustum (where the encoding is physically meaningless anyway).
+__device__ __forceinline__ float pe_sin_or_cos(float x, int want_cos)
+{
+    x = fminf(fmaxf(x, -65536.0f), 65536.0f);
+    const float k = rintf(x * 0.63661977236758134f);
+    float r = fmaf(k, -1.5703125f, x);
+    r = fmaf(k, -4.837512969970703125e-4f, r);
+    r = fmaf(k, -7.54978995489188e-8f, r);
+    const float r2 = r * r;
+    const float sp = fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+    const float sn = fmaf(sp * r2, r, r);
+    const float cp = fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
+    const float cs = fmaf(cp * r2, r2, fmaf(-0.5f, r2, 1.0f));
+    const int q = (int)k + want_cos;
+    const float v = (q & 1) ? cs : sn;
+    return (q & 2) ? -v : v;
+}
+
 // positional-encoding B operand of k-step t for this lane (point coords px,py,pz; half)
 __device__ __forceinline__ float pe_operand(int t, int half, float px, float py, float pz)
 {
@@ -158,9 +181,7 @@ __device__ __forceinline__ float pe_operand(int t, int half, float px, float py,
     if (t == 1) return half ? 0.0f : pz;
     const int j = t - 2, f = j / 3, c = j - 3 * f;
     const float x = (c == 0 ? px : c == 1 ? py : pz) * (float)(1 << f);   // exact, as x*2^f in models.py:49
-    float s, co;
-    sincosf(x, &s, &co);
-    return half ? co : s;
+    return pe_sin_or_cos(x, half);
 }
 
 // G groups of 32 points per wave; WPS = waves per SIMD the register budget is capped for.
@@ -353,14 +374,234 @@ __global__ __launch_bounds__(256, WPS) void mlp_fwd_kernel(
     }
 }
 
-// tuning knob (A/B benchmarking only): 0 = 32 pts/wave, 2 waves/SIMD; 1 = 64 pts/wave, 1 wave/SIMD; 2 = 32 pts/wave, 1 wave/SIMD
-static int g_mlp_variant = 0;
+// ------------------------------------------------------------------------------------------ pipelined forward
+// Measured on MI355X (scratch/census.py, profiles/r01_mlp_census.txt): the shader clock sits at ~2.07 GHz while this kernel
+// runs (DVFS under sustained fp32-MFMA load with real operands), the MFMA pipe is 92-94 % busy while waves are resident
+// (SQ_VALU_MFMA_BUSY_CYCLES vs SQ_WAVE_CYCLES), and the kernel reaches 131 TFLOP/s = 83 % of the 2.4 GHz datasheet peak
+// = 96 % of the peak at the sustained clock.  Negative results kept out of the code: (i) staggering / prioritising the
+// two co-resident workgroups of a CU: no change; (ii) reading A fragments straight from L2 (no LDS stage, no barriers):
+// 114 TFLOP/s; (iii) 64 points per wave at one wave per SIMD: 114 TFLOP/s.
+// Same arithmetic as mlp_fwd_kernel<.., G=1, ..>, different weight logistics: the packed weights are cut into 16 slabs
+// of <= 34 KB (half a 128x128 layer = 32 k-steps) that alternate between two LDS buffers.  While the MFMAs of slab i
+// run, slab i+1 arrives by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write pass); one barrier per slab.
+static long long* g_mlp_census = nullptr;     // diagnostics buffer (4 x int64 per workgroup), set by mvsnerf_debug_set_census
+constexpr int SLAB_FLOATS = 8704;                        // 34 KB = 34 k-steps x 4 blocks x 64 lanes (views: 68 x 2)
+constexpr int PIPE_LDS_FLOATS = 2 * SLAB_FLOATS + V_TOTAL;
+
+__device__ __forceinline__ void slab_dma(float* __restrict__ dst, const float* __restrict__ src, int n_floats, int wave, int lane)
+{
+    const int pieces = n_floats >> 8;                    // 1 KB per wave-instruction
+    for (int pc = wave; pc < pieces; pc += 4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(dst + pc * 256), 16, 0, 0);
+}
+
+__device__ __forceinline__ void slab_sync()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces (and earlier stores) have landed
+    __syncthreads();                                      // ... everybody's have, and everybody left the other buffer
+}
+
+template <bool ALPHA_ONLY, bool SAVE>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
+    const float* __restrict__ packed, int F, const float* __restrict__ ndc, int ndc_stride,
+    const float* __restrict__ feat, int feat_stride, const float* __restrict__ dirs, int dirs_stride,
+    int64_t P, int S, float* __restrict__ raw, float* __restrict__ saved, long long* __restrict__ census)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    long long t_start = 0, c_start = 0;
+    if (census) { t_start = wall_clock64(); c_start = __builtin_amdgcn_s_memtime(); }
+    int stamp_i = 4;
+    auto stamp = [&]() { if (census && threadIdx.x == 0 && stamp_i < 16) census[blockIdx.x * 16 + stamp_i] = wall_clock64(); ++stamp_i; };
+    float* buf0 = lds;
+    float* buf1 = lds + SLAB_FLOATS;
+    float* vec = lds + 2 * SLAB_FLOATS;
+    constexpr int G = 1;
+    const Layout L = layout(F);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int64_t p_raw = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+    const bool live = p_raw < P;
+    const int64_t p = live ? p_raw : P - 1;
+    float* sv = nullptr;
+    if (SAVE) sv = saved + ((int64_t)blockIdx.x * 4 + wave) * (SLOTS_SAVED * 64) + lane;
+    auto save = [&](int slot, float v) { if (SAVE) sv[slot * 64] = v; };
+    constexpr int HALF = (int)(ACT_STEPS / 2) * 4 * 64;                   // floats of half a 128x128 layer
+
+    slab_dma(buf0, packed + L.biasw, (int)seg_floats(L.fsteps, 4), wave, lane);          // slab 0
+    for (int i = tid; i < V_TOTAL; i += 256) vec[i] = packed[L.vec + i];
+    const float px = ndc[p * ndc_stride + 0], py = ndc[p * ndc_stride + 1], pz = ndc[p * ndc_stride + 2];
+    float fv[MAX_F / 2];
+    {
+        const float* fp = feat + p * feat_stride + half * (F / 2);
+#pragma unroll
+        for (int i = 0; i < MAX_F / 2; ++i) fv[i] = i < F / 2 ? fp[i] : 0.0f;
+    }
+    float bias[64], h[64];
+    auto pe = [&](int g, int t) { return pe_operand(t, half, px, py, pz); };
+    auto hlo = [&](int g, int t) { return h[t]; };
+    auto hhi = [&](int g, int t) { return h[32 + t]; };
+
+    // ---- slab 0: bias = pts_bias(feat)
+    slab_sync();
+    stamp();                                                                                // [4] startup done
+    slab_dma(buf1, packed + L.l0, (int)seg_floats(PE_STEPS, 4), wave, lane);              // slab 1
+    {
+        f32x16 acc[G][4];
+        init_acc<4, G>(acc, vec + V_BIASG + half * 64);
+        auto fb = [&](int g, int t) { return fv[t]; };
+        switch (L.fsteps) {
+            case 4:  gemm_stage<1, 4, G>(buf0, acc, lane, fb); break;
+            case 8:  gemm_stage<2, 4, G>(buf0, acc, lane, fb); break;
+            case 12: gemm_stage<3, 4, G>(buf0, acc, lane, fb); break;
+            case 16: gemm_stage<4, 4, G>(buf0, acc, lane, fb); break;
+            default: gemm_stage<5, 4, G>(buf0, acc, lane, fb); break;
+        }
+#pragma unroll
+        for (int q = 0; q < 64; ++q) { bias[q] = acc[0][q >> 4][q & 15]; save(S_BM + q, bias[q]); }
+        if (SAVE) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) save(S_FV + t, fv[t]);
+#pragma unroll
+            for (int t = 0; t < PE_STEPS; ++t) save(S_E + t, pe_operand(t, half, px, py, pz));
+        }
+    }
+    stamp();                                                                                // [5] bias gemm done
+    // ---- slab 1: layer 0
+    slab_sync();
+    slab_dma(buf0, packed + L.l1, HALF, wave, lane);                                      // slab 2
+    {
+        f32x16 acc[G][4];
+        init_acc<4, G>(acc, vec + V_L0 + half * 64);
+        gemm_stage<PE_STEPS / 4, 4, G>(buf1, acc, lane, pe);
+#pragma unroll
+        for (int q = 0; q < 64; ++q) { h[q] = fmaxf(acc[0][q >> 4][q & 15] * bias[q], 0.0f); save(S_H + q, h[q]); }
+    }
+    stamp();                                                                                // [6] layer 0 done
+    // ---- layers 1..4: two slabs each (buf0 then buf1)
+#pragma unroll 1
+    for (int layer = 1; layer <= 4; ++layer) {
+        const float* wl = packed + L.l1 + (size_t)(layer - 1) * seg_floats(ACT_STEPS, 4);
+        f32x16 acc[G][4];
+        slab_sync();
+        slab_dma(buf1, wl + HALF, HALF, wave, lane);
+        init_acc<4, G>(acc, vec + V_L0 + 128 * layer + half * 64);
+        gemm_stage<8, 4, G>(buf0, acc, lane, hlo);
+        slab_sync();
+        // next slab: first half of the next layer, or the positional-encoding part of layer 5
+        slab_dma(buf0, layer < 4 ? wl + 2 * HALF : packed + L.l5a, HALF, wave, lane);
+        gemm_stage<8, 4, G>(buf1, acc, lane, hhi);
+#pragma unroll
+        for (int q = 0; q < 64; ++q) { h[q] = fmaxf(acc[0][q >> 4][q & 15] * bias[q], 0.0f); save(S_H + layer * 64 + q, h[q]); }
+        stamp();                                                                            // [7..10] layers 1..4 done
+    }
+    // ---- layer 5 on cat([pts, h4]): slabs 10 (buf0), 11 (buf1), 12 (buf0)
+    float sigma;
+    {
+        f32x16 acc[G][4];
+        slab_sync();
+        slab_dma(buf1, packed + L.l5b, HALF, wave, lane);
+        init_acc<4, G>(acc, vec + V_L0 + 128 * 5 + half * 64);
+        gemm_stage<PE_STEPS / 4, 4, G>(buf0, acc, lane, pe);
+        slab_sync();
+        slab_dma(buf0, packed + L.l5b + HALF, HALF, wave, lane);
+        gemm_stage<8, 4, G>(buf1, acc, lane, hlo);
+        slab_sync();
+        if (!ALPHA_ONLY) slab_dma(buf1, packed + L.feat, HALF, wave, lane);
+        gemm_stage<8, 4, G>(buf0, acc, lane, hhi);
+#pragma unroll
+        for (int q = 0; q < 64; ++q) { h[q] = fmaxf(acc[0][q >> 4][q & 15] * bias[q], 0.0f); save(S_H + 5 * 64 + q, h[q]); }
+        const float* wa = vec + V_WA + half * 64;
+        float part = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 64; ++q) part = fmaf(wa[q], h[q], part);
+        part += __shfl_xor(part, 32);
+        sigma = fmaxf(part + vec[V_BA], 0.0f);
+    }
+    stamp();                                                                                // [11] layer 5 + sigma head done
+    if (ALPHA_ONLY) {
+        if (live && half == 0) raw[p_raw] = sigma;
+        return;
+    }
+    // ---- feature_linear: slabs 13 (buf1), 14 (buf0)
+    {
+        f32x16 acc[G][4];
+        slab_sync();
+        slab_dma(buf0, packed + L.feat + HALF, HALF, wave, lane);
+        init_acc<4, G>(acc, vec + V_FEAT + half * 64);
+        gemm_stage<8, 4, G>(buf1, acc, lane, hlo);
+        slab_sync();
+        slab_dma(buf1, packed + L.views, (int)seg_floats(VIEW_STEPS, 2), wave, lane);
+        gemm_stage<8, 4, G>(buf0, acc, lane, hhi);
+#pragma unroll
+        for (int q = 0; q < 64; ++q) { h[q] = acc[0][q >> 4][q & 15]; save(S_FE + q, h[q]); }
+    }
+    stamp();                                                                                // [12] feature_linear done
+    // ---- views_linears[0] + rgb head: slab 15 (buf1)
+    {
+        const int64_t ray = p / S;
+        const float d0 = dirs[ray * dirs_stride + 0], d1 = dirs[ray * dirs_stride + 1], d2 = dirs[ray * dirs_stride + 2];
+        f32x16 acc[G][2];
+        slab_sync();
+        init_acc<2, G>(acc, vec + V_VIEWS + half * 32);
+        gemm_stage<VIEW_STEPS / 4, 2, G>(buf1, acc, lane, [&](int g, int t) {
+            return t < ACT_STEPS ? h[t < ACT_STEPS ? t : 0] : t == ACT_STEPS ? (half ? d1 : d0) : t == ACT_STEPS + 1 ? (half ? 0.0f : d2) : 0.0f;
+        });
+        if (SAVE) {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) save(S_HV + q, fmaxf(acc[0][q >> 4][q & 15], 0.0f));
+            save(S_DR + 0, half ? d1 : d0);
+            save(S_DR + 1, half ? 0.0f : d2);
+        }
+        float rgb[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* wr = vec + V_WR + c * 64 + half * 32;
+            float part = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) part = fmaf(wr[q], fmaxf(acc[0][q >> 4][q & 15], 0.0f), part);
+            part += __shfl_xor(part, 32);
+            const float x = part + vec[V_BR + c];
+            rgb[c] = 1.0f / (1.0f + expf(-x));
+        }
+        if (live && half == 0) *reinterpret_cast<f32x4*>(raw + p_raw * 4) = f32x4{rgb[0], rgb[1], rgb[2], sigma};
+    }
+    if (census && tid == 0) {
+        census[blockIdx.x * 16 + 0] = t_start;
+        census[blockIdx.x * 16 + 1] = wall_clock64();
+        census[blockIdx.x * 16 + 2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+        census[blockIdx.x * 16 + 3] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
+        census[blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memtime() - c_start;                      // shader-clock ticks of this workgroup
+    }
+}
+
+template <bool AO, bool SAVE>
+static int launch_mlp_pipe(const float* packed, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
+                           const float* dirs, int dirs_stride, int64_t P, int S, float* raw, hipStream_t st, float* saved = nullptr)
+{
+    const size_t lds_bytes = PIPE_LDS_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_pipe_kernel<AO, SAVE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    mlp_fwd_pipe_kernel<AO, SAVE><<<mvs_cdiv(P, 128), 256, lds_bytes, st>>>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, saved, g_mlp_census);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// tuning knob (A/B benchmarking only): 0 = 32 pts/wave, 2 waves/SIMD, register-staged weights; 1 = 64 pts/wave, 1 wave/SIMD;
+// 2 = 32 pts/wave, 1 wave/SIMD; 3 = 32 pts/wave, 2 waves/SIMD, double-buffered LDS-DMA weight slabs (default)
+static int g_mlp_variant = 3;
 extern int g_conv_tiled;
 extern "C" int mvsnerf_tune(const char* key, int value)
 {
     if (!key) return MVSNERF_EINVAL;
     if (__builtin_strcmp(key, "conv_tiled") == 0) { g_conv_tiled = value ? 1 : 0; return MVSNERF_OK; }
-    if (__builtin_strcmp(key, "mlp_variant") == 0) { if (value < 0 || value > 2) return MVSNERF_EINVAL; g_mlp_variant = value; return MVSNERF_OK; }
+    if (__builtin_strcmp(key, "mlp_variant") == 0) { if (value < 0 || value > 3) return MVSNERF_EINVAL; g_mlp_variant = value; return MVSNERF_OK; }
     return MVSNERF_EINVAL;
 }
 
@@ -399,7 +640,9 @@ extern "C" int mvsnerf_mlp_fwd(const float* packed, int F, const float* ndc, int
         case 2: return MVS_MLP(false, 2, 1);
         case 3: return MVS_MLP(true, 2, 1);
         case 4: return MVS_MLP(false, 1, 1);
-        default: return MVS_MLP(true, 1, 1);
+        case 5: return MVS_MLP(true, 1, 1);
+        case 6: return launch_mlp_pipe<false, false>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, st);
+        default: return launch_mlp_pipe<true, false>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, st);
     }
 #undef MVS_MLP
 }
@@ -414,5 +657,24 @@ extern "C" int mvsnerf_mlp_fwd_train(const float* packed, int F, const float* nd
     if (!mvs_aligned16(packed) || !mvs_aligned16(raw) || !mvs_aligned16(saved)) return MVSNERF_EALIGN;
     const int64_t P = N * S;
     if (P == 0) return MVSNERF_OK;
+    if (g_mlp_variant == 3)
+        return launch_mlp_pipe<false, true>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, (hipStream_t)stream, saved);
     return launch_mlp<false, 1, 2, true>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, (hipStream_t)stream, saved);
 }
+
+// diagnostics: resident workgroups per CU the runtime grants the MLP kernels (A/B tooling, not part of the reference surface)
+extern "C" int mvsnerf_debug_mlp_occupancy(int variant)
+{
+    int n = -1;
+    hipError_t e;
+    if (variant == 3) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_pipe_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PIPE_LDS_FLOATS * sizeof(float)));
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mlp_fwd_pipe_kernel<false, false>, 256, PIPE_LDS_FLOATS * sizeof(float));
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<false, 1, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_FLOATS * sizeof(float)));
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mlp_fwd_kernel<false, 1, 2, false>, 256, LDS_FLOATS * sizeof(float));
+    }
+    return e == hipSuccess ? n : -(int)e;
+}
+
+extern "C" int mvsnerf_debug_set_census(long long* buf) { g_mlp_census = buf; return MVSNERF_OK; }

@@ -183,14 +183,15 @@ def test_mlp_variants_agree(net):
     emb, _ = M.get_embedder(10, 0, 3)
     outs = []
     with torch.no_grad():
-        for v in (0, 1, 2):
+        for v in (0, 1, 2, 3):
             assert _lib.lib().mvsnerf_tune(b"mlp_variant", v) == 0
             outs.append(R.run_network_mvs(g["ref_rays_ndc"], g["ref_dirs"], g["ref_input_feat"], net, emb, None).cpu())
-        _lib.lib().mvsnerf_tune(b"mlp_variant", 0)
+        _lib.lib().mvsnerf_tune(b"mlp_variant", 3)
     for o in outs:
         ok, e = close(o, c["ref_raw"])
         assert ok, e
     assert torch.equal(outs[0], outs[2])        # same per-wave arithmetic, different occupancy
+    assert torch.equal(outs[0], outs[3])        # same arithmetic, weights arrive by LDS-DMA instead of through registers
     assert maxabs(outs[0], outs[1]) < 1e-5
 
 
