@@ -39,6 +39,24 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 
 PEAK_HBM_GBS = 8000.0
 
 
+def _load_pmc_traffic():
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE collected in
+    separate --pmc passes over this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950's
+    16-B/lane reads; counters are in KiB).  bench.py cannot run rocprof on itself, so `traffic` cites that measurement."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+    except Exception:
+        return {}
+    out = {}
+    for k, v in d.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            out[k.split("_kernel")[0]] = int((2 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * 1024)
+    return out
+
+
+PMC_TRAFFIC = _load_pmc_traffic()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,6 +64,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cpu-batches", type=int, default=20, help="CPU-oracle batches timed for cpu_baseline (0 = skip)")
     ap.add_argument("--mlp-variant", type=int, default=None)
+    ap.add_argument("--no-extras", action="store_true", help="skip the end-to-end frame / training-step timings")
     return ap.parse_args()
 
 
@@ -55,11 +74,33 @@ def load_mlp_weights():
     return {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("mlp/")}
 
 
-def event_time(fn, iters, warm=3):
-    """Average duration (ms) of one call of fn, HIP events on the current (= launch) stream."""
+def event_time(fn, iters, warm=3, graph_batch=0):
+    """Average duration (ms) of one call of fn, HIP events on the current (= launch) stream.
+    graph_batch > 0: the launches are captured into a hipGraph of `graph_batch` back-to-back calls and replayed, so that
+    kernels of a few microseconds are not timed through the ~8 us of Python/ctypes launch overhead (the ~1.5 us
+    dependent-launch boundary between kernels remains included)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    if graph_batch:
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(graph_batch):
+                    fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g.replay()
+        torch.cuda.synchronize()
+        reps = max(1, iters // graph_batch)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (reps * graph_batch)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
@@ -67,6 +108,19 @@ def event_time(fn, iters, warm=3):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
+
+
+def sustained_clock_ghz(lib, run_mlp, n_wg, dev):
+    """Shader clock while the MLP kernel runs: every workgroup records s_memtime ticks and the 100 MHz wall clock."""
+    cen = torch.zeros((n_wg, 16), dtype=torch.int64, device=dev)
+    lib.mvsnerf_debug_set_census(cen.data_ptr())
+    run_mlp()
+    torch.cuda.synchronize()
+    lib.mvsnerf_debug_set_census(0)
+    c = cen.cpu().numpy().astype("float64")
+    dur_us = (c[:, 1] - c[:, 0]) / 100.0
+    ok = dur_us > 0
+    return float((c[ok, 13] / dur_us[ok] / 1e3).mean())
 
 
 def main():
@@ -165,21 +219,35 @@ def main():
             feat = torch.empty((N_RAYS, N_SAMPLES, F), device=dev)
             dirs = ops.dir_feature(rdir, pose["w2cs"][0].contiguous())
             packed = net.packed(F)
-            t_vol = event_time(lambda: ops.volume_sample(vol_cl, ndc, out=feat, out_stride=F), 200)
-            t_col = event_time(lambda: ops.color_sample(src[0], pose["w2cs"][:N_SRC].contiguous(), pose["intrinsics"][:N_SRC].contiguous(),
-                                                        pts, True, out=feat, out_ptr=feat.data_ptr() + 32, out_stride=F), 200)
-            t_mlp = event_time(lambda: ops.mlp_forward(packed, F, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3,
-                                                       N_RAYS, N_SAMPLES, False, dev), 50)
-            raw = ops.mlp_forward(packed, F, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3, N_RAYS, N_SAMPLES, False, dev)
-            t_cmp = event_time(lambda: ops.composite(raw.view(N_RAYS, N_SAMPLES, 4), z), 200)
+            w2c3, k3 = pose["w2cs"][:N_SRC].contiguous(), pose["intrinsics"][:N_SRC].contiguous()
+            lib = _lib.lib()
+            st = torch.cuda.current_stream
+            raw = torch.empty((N_RAYS, N_SAMPLES, 4), device=dev)
+            outs = [torch.empty(sh, device=dev) for sh in ((N_RAYS, 3), (N_RAYS,), (N_RAYS,), (N_RAYS, N_SAMPLES), (N_RAYS,), (N_RAYS, N_SAMPLES))]
+            # raw C-ABI calls with pre-allocated outputs (capturable into a hipGraph)
+            k_vol = lambda: lib.mvsnerf_volume_sample_fwd(vol_cl.data_ptr(), vol_cl.shape[0], vol_cl.shape[1], vol_cl.shape[2], 8, ndc.data_ptr(), P,
+                                                          feat.data_ptr(), F, st().cuda_stream)
+            k_col = lambda: lib.mvsnerf_color_sample_fwd(src[0].data_ptr(), N_SRC, H_IMG, W_IMG, w2c3.data_ptr(), k3.data_ptr(), pts.data_ptr(), P, 1,
+                                                         feat.data_ptr() + 32, F, st().cuda_stream)
+            k_mlp = lambda: lib.mvsnerf_mlp_fwd(packed.data_ptr(), F, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3, N_RAYS, N_SAMPLES, 0,
+                                                raw.data_ptr(), st().cuda_stream)
+            k_cmp = lambda: lib.mvsnerf_composite_fwd(raw.data_ptr(), z.data_ptr(), N_RAYS, N_SAMPLES, 0, *[o.data_ptr() for o in outs], st().cuda_stream)
+            t_vol = event_time(k_vol, 400, graph_batch=40)
+            t_col = event_time(k_col, 400, graph_batch=40)
+            t_mlp = event_time(k_mlp, 60)
+            t_cmp = event_time(k_cmp, 400, graph_batch=40)
+            clock = sustained_clock_ghz(lib, k_mlp, (P + 127) // 128, dev)
         tf = FLOP_PER_SAMPLE * P / (t_mlp * 1e-3) / 1e12
-        roof = {"kernel": "mlp_fwd_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(t_mlp, 4)}
+        roof = {"kernel": "mlp_fwd_pipe_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": PMC_TRAFFIC.get("mlp_fwd"), "avg_launch_ms": round(t_mlp, 4),
+                "sustained_clock_ghz": round(clock, 3),
+                "frac_at_sustained_clock": round(tf / (PEAK_F32_MFMA_TFLOPS * clock / 2.4), 4)}
         for name, t, bps in (("volume_sample_c8_kernel", t_vol, VOL_BYTES_PER_SAMPLE), ("color_sample_kernel", t_col, COL_BYTES_PER_SAMPLE),
                              ("composite_kernel", t_cmp, 28)):
             gbs = bps * P / (t * 1e-3) / 1e9
             roofs.append({"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                          "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_ms": round(t, 5)})
+                          "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": PMC_TRAFFIC.get(name.split("_kernel")[0]), "avg_launch_ms": round(t, 5),
+                          "timing": "hipGraph replay of 40 back-to-back launches (includes the ~1.5 us launch boundary)"})
         # ---------------- CPU baseline: the oracle (torch CPU kernels) on a bounded sample of the same workload
         if a.cpu_batches > 0:
             from oracle import mvsnerf_oracle as O
@@ -208,6 +276,32 @@ def main():
             cpu["max_abs_rgb_err_vs_gpu"] = err
             cpu["psnr_gpu_vs_cpu_db"] = round(10 * math.log10(1.0 / max(mse, 1e-20)), 1)
 
+        extras = {}
+        if not a.no_extras:
+            from mvsnerf_amd import train
+            # (i) end-to-end frame: encode + 320 batches of 1024 rays (one 512x640 target view), validation_step's loop
+            targs = train.default_args(pad=PAD, batch_size=N_RAYS, N_samples=N_SAMPLES, chunk=N_RAYS)
+            system = train.MVSSystem(targs).to(dev)
+            system.render_kwargs_train["network_fn"].load_state_dict(load_mlp_weights())
+            import numpy as np
+            zz = np.load(os.path.join(ROOT, "tests", "golden", "mvsnerf_v0_weights.npz"))
+            system.MVSNet.load_state_dict({k[4:]: torch.from_numpy(zz[k]) for k in zz.files if k.startswith("mvs/")})
+            batch = train.synthetic_batch(H_IMG, W_IMG, seed=1234)
+            system.render_view(batch)
+            torch.cuda.synchronize(); f0 = time.perf_counter()
+            system.render_view(batch)
+            torch.cuda.synchronize(); fdt = time.perf_counter() - f0
+            extras["frame_512x640"] = {"seconds": round(fdt, 4), "rays_per_s_incl_encode": round(H_IMG * W_IMG / fdt, 1),
+                                       "note": "MVSNet encode + 320 chunks x (ray-generation kernel + ray march) of 1024 rays x 128 samples"}
+            # (ii) one generalizable-training step (config 3 shapes, fp32): encode + ray march + full backward + Adam
+            opt = system.configure_optimizers()[0][0]
+            torch.manual_seed(0)
+            system.fit_steps([batch] * 3, opt)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            losses = system.fit_steps([batch] * 5, opt)
+            torch.cuda.synchronize(); tdt = (time.perf_counter() - t0) / 5
+            extras["train_step"] = {"ms": round(tdt * 1e3, 2), "rays_per_s": round(N_RAYS / tdt, 1), "loss_last": round(losses[-1], 5),
+                                    "note": "MVSSystem.training_step fwd+bwd (HIP) + FeatureNet (torch-ROCm) + Adam, 1024x128, fp32"}
         print(json.dumps({
             "metric": "rendered rays/sec (1024-ray batch, 128 samples)", "value": round(rays_per_s, 1), "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
@@ -217,7 +311,7 @@ def main():
                        "weights": "mvsnerf-v0 checkpoint", "volume": volume_src, "rays_per_step_per_gpu": N_RAYS,
                        "parallelism": f"ray-sharded x{world}, no data-path collective"},
             "encode_ms": encode_ms,
-            "roofline": roof, "rooflines": roofs, "cpu_baseline": cpu,
+            "roofline": roof, "rooflines": roofs, "cpu_baseline": cpu, "extras": extras,
         }))
     if world > 1:
         dist.destroy_process_group()

@@ -128,6 +128,17 @@ int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float* proj, con
 
 /* ---------------------------------------------------------------- ray march (L1b) */
 
+/* Ray generation: the arithmetic of build_rays / build_rays_test (utils.py:86-108, 148-297) downstream of the RNG
+ * draws.  xs/ys[N]: pixel ids as floats drawn by the caller, or NULL for the row-major ids first_pixel + n of
+ * build_rays_test.  K_*[3][3], c2w_tgt / w2c_ref [4][4] row-major, near_far_*[2]: all DEVICE pointers (read with
+ * wave-uniform loads, so no host synchronisation is needed to launch).  t_rand[N][S]: stratified jitter or NULL.
+ * Outputs: rays_pts[N][S][3], rays_dir[N][3], rays_ndc[N][S][3], z_vals[N][S], pix[2][N] (= (ys,xs), may be NULL). */
+int mvsnerf_raygen_fwd(const float* xs, const float* ys, int64_t first_pixel, int W_img, int H_img,
+                       const float* K_tgt, const float* c2w_tgt, const float* K_ref, const float* w2c_ref,
+                       const float* near_far_tgt, const float* near_far_ref, int pad, int lindisp,
+                       const float* t_rand, int64_t N, int S,
+                       float* rays_pts, float* rays_dir, float* rays_ndc, float* z_vals, float* pix, void* stream);
+
 /* Trilinear lookup of the channel-last volume: replaces F.grid_sample 5-D in
  * utils.py:357-383 (index_point_feature) and models.py:941-950 (RefVolume.forward).
  * vol[D][H][W][C] (C == 8); ndc[P][3] = (x->W, y->H, z->D) in [0,1]; zeros padding, align_corners=True.

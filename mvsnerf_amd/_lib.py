@@ -53,6 +53,7 @@ SIGNATURES = {
     "mvsnerf_conv3d_wgrad": (_c_i, [_c_fp] * 6 + [_c_i] + [_c_fp] * 6 + [_c_i] * 9 + [_c_fp, _c_fp, _c_fp]),
     "mvsnerf_planesweep_costvar_bwd": (_c_i, [_c_fp, _c_fp, _c_fp] + [_c_i] * 6 + [_c_fp, _c_i, _c_i, _c_fp, _c_fp]),
     "mvsnerf_abn_apply_add": (_c_i, [_c_fp] * 6 + [_c_l, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_raygen_fwd": (_c_i, [_c_fp, _c_fp, _c_l, _c_i, _c_i] + [_c_fp] * 6 + [_c_i, _c_i, _c_fp, _c_l, _c_i] + [_c_fp] * 6),
     "mvsnerf_volume_sample_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_l, _c_fp, _c_i, _c_fp]),
     "mvsnerf_color_sample_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_i, _c_fp]),
     "mvsnerf_dir_feature_fwd": (_c_i, [_c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp]),

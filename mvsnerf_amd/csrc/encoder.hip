@@ -81,15 +81,17 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
 {
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const int64_t nvox = (int64_t)D * Hp * Wp;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nvox) return;
+    const int64_t i_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i_raw < nvox;
+    const int64_t i = live ? i_raw : nvox - 1;                   // tail threads recompute the last voxel (their stores are masked)
     const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), d = (int)(i / ((int64_t)Wp * Hp));
     const float u = (float)(x - pad), v = (float)(y - pad);     // utils.py:603-605
     const float dep = depth[d];
     const bool interior = x >= pad && x < W + pad && y >= pad && y < H + pad;
 
     float s[C], s2[C];
-    float* o = cost + i * CP;
+    extern __shared__ __attribute__((aligned(16))) float stage[];     // [256][CP+4]: +4 floats per row breaks the bank stride
+    float* o = stage + threadIdx.x * (CP + 4);
     const int c_var = with_img ? 3 * V : 0;
     if (interior) {                                              // ref volume: zero-padded ref feature (models.py:856,862)
         const f32x4* r = reinterpret_cast<const f32x4*>(feat + ((int64_t)(y - pad) * W + (x - pad)) * C);
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
     if (with_img) {                                              // channels 0:3 = ref thumbnail, border := 0 (models.py:858-860)
         const float* ri = img + ((int64_t)(y - pad) * W + (x - pad)) * 4;
         o[0] = interior ? ri[0] : 0.f; o[1] = interior ? ri[1] : 0.f; o[2] = interior ? ri[2] : 0.f;
-        masks[i] = 1.0f;                                         // view 0 mask (models.py:869)
+        if (live) masks[i] = 1.0f;                               // view 0 mask (models.py:869)
     }
     float cnt = 1.0f;
     for (int vv = 1; vv < V; ++vv) {
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
         const float gy = (p1 / p2) / ((float)(H - 1) / 2.0f) - 1.0f;
         const float m = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;   // models.py:875-876
         cnt += m;
-        if (with_img) masks[(int64_t)vv * nvox + i] = m;
+        if (with_img && live) masks[(int64_t)vv * nvox + i] = m;
         // F.grid_sample bilinear, zeros padding, align_corners=True (utils.py:625)
         const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
         const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
             for (int k = 0; k < 3; ++k) o[3 * vv + k] = ((a[k] * w_nw + b[k] * w_ne) + c_[k] * w_sw) + e[k] * w_se;
         }
     }
-    if (!with_img) masks[i] = cnt;                               // build_volume_costvar returns the count (models.py:821)
+    if (!with_img && live) masks[i] = cnt;                       // build_volume_costvar returns the count (models.py:821)
     const float inv = 1.0f / cnt;                                // models.py:889
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -166,6 +168,19 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
         o[c_var + c] = s2[c] * inv - mean * mean;                // :890
     }
     for (int c = c_var + C; c < CP; ++c) o[c] = 0.0f;
+    // `o` points into the LDS staging row of this thread; flush the block's 256 consecutive voxels (one contiguous
+    // CP*256*4-byte span of the cost volume) with coalesced 16-byte stores
+    __syncthreads();
+    {
+        const int64_t v0 = (int64_t)blockIdx.x * 256;
+        const int64_t nv = nvox - v0 < 256 ? nvox - v0 : 256;
+        const int n4 = (int)(nv * CP / 4);
+        f32x4* dst = reinterpret_cast<f32x4*>(cost + v0 * CP);
+        for (int k = threadIdx.x; k < n4; k += 256) {
+            const int vox = (k * 4) / CP, c = (k * 4) - vox * CP;
+            dst[k] = *reinterpret_cast<const f32x4*>(stage + vox * (CP + 4) + c);
+        }
+    }
 }
 
 extern "C" int mvsnerf_planesweep_costvar_fwd(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,
@@ -178,7 +193,9 @@ extern "C" int mvsnerf_planesweep_costvar_fwd(const float* feats_cl, const float
     if (CP < (with_img ? 3 * V : 0) + C) return MVSNERF_EINVAL;
     if (!mvs_aligned16(feats_cl) || (imgs_cl && !mvs_aligned16(imgs_cl))) return MVSNERF_EALIGN;
     const int64_t nvox = (int64_t)D * (H + 2 * pad) * (W + 2 * pad);
-    planesweep_kernel<32><<<mvs_cdiv(nvox, 256), 256, 0, (hipStream_t)stream>>>(feats_cl, imgs_cl, proj, depth, V, H, W, D, pad, cost, CP, masks, with_img);
+    if ((CP & 3) || !mvs_aligned16(cost)) return MVSNERF_EALIGN;
+    const size_t lds = (size_t)256 * (CP + 4) * sizeof(float);
+    planesweep_kernel<32><<<mvs_cdiv(nvox, 256), 256, lds, (hipStream_t)stream>>>(feats_cl, imgs_cl, proj, depth, V, H, W, D, pad, cost, CP, masks, with_img);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
@@ -317,16 +334,55 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(ActSrc a, ActSrc b, int 
 }
 
 // LDS-tiled variant for the stride-1 layers (conv0 = 74.5 % of CostRegNet's FLOPs).  A workgroup owns a 4x8x8
-// block of output voxels; the (6x10x10)-voxel input halo is staged through LDS in chunks of CK=12 channels with
+// block of output voxels; the (6x10x10)-voxel input halo is staged through LDS in chunks of <= 12 channels with
 // fully coalesced loads (a voxel's channels are contiguous; the generic kernel's per-tap gathers at a 176-B lane
 // stride touch one cache line per lane).  The pending InPlaceABN of the producer is applied once per staged
-// element instead of once per tap.  Voxel stride 12 floats => conflict-free ds_read_b128 across x-neighbours.
+// element instead of once per tap.  Chunk sizes are compile-time and the x-taps are unrolled so that the LDS reads
+// and the scalar weight loads of one (dz,dy) step are in flight while the previous step's FMAs issue.
+template <int CIN, int CT, int C0, int CKC>     // one channel chunk [C0, C0+CKC) of the tile
+__device__ __forceinline__ void conv_tile_chunk(const ActSrc& a, const ActSrc& b, int ld, int D, int H, int W, int x0, int y0, int z0,
+                                                const float* __restrict__ wp, int Cout, int cg, float* __restrict__ tile,
+                                                int tid, int tx, int ty, int tz, float (&acc)[CT])
+{
+    constexpr int CK = 12, IY = 10, IX = 10, NV = 6 * IY * IX, K4 = CKC / 4;
+    __syncthreads();
+    for (int idx = tid; idx < NV * K4; idx += 256) {
+        const int v = idx / K4, c4 = idx - v * K4;
+        const int vx = v % IX, vy = (v / IX) % IY, vz = v / (IX * IY);
+        const int gx = x0 + vx, gy = y0 + vy, gz = z0 + vz;
+        f32x4 val = {0, 0, 0, 0};
+        if (gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D)
+            load_act4<CIN>(a, b, ((int64_t)gz * H + gy) * W + gx, ld, C0 + c4 * 4, val);
+        *reinterpret_cast<f32x4*>(tile + v * CK + c4 * 4) = val;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int dzy = 0; dzy < 9; ++dzy) {
+        const int dz = dzy / 3, dy = dzy - dz * 3;
+        const float* tv = tile + (((tz + dz) * IY + ty + dy) * IX + tx) * CK;
+        const float* wt = wp + ((int64_t)(dzy * 3) * CIN + C0) * Cout + cg;
+        f32x4 v[3][K4];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int c4 = 0; c4 < K4; ++c4) v[dx][c4] = *reinterpret_cast<const f32x4*>(tv + dx * CK + c4 * 4);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int c4 = 0; c4 < K4; ++c4)
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+                    for (int k = 0; k < CT; ++k)
+                        acc[k] = fmaf(v[dx][c4][k4], wt[((int64_t)dx * CIN + c4 * 4 + k4) * Cout + k], acc[k]);
+    }
+}
+
 template <int CIN, int CT>
 __global__ __launch_bounds__(256) void conv3d_k3s1_tiled_kernel(ActSrc a, ActSrc b, int ld, int D, int H, int W,
                                                                const float* __restrict__ wp, int Cout, float* __restrict__ out)
 {
-    constexpr int CK = 12, IY = 10, IX = 10, NV = 6 * IY * IX;
-    __shared__ __attribute__((aligned(16))) float tile[NV * CK];
+    __shared__ __attribute__((aligned(16))) float tile[600 * 12];
     const int nbx = (W + 7) / 8, nby = (H + 7) / 8;
     const int bx = blockIdx.x % nbx, by = (blockIdx.x / nbx) % nby, bz = blockIdx.x / (nbx * nby);
     const int cg = blockIdx.y * CT;
@@ -335,33 +391,14 @@ __global__ __launch_bounds__(256) void conv3d_k3s1_tiled_kernel(ActSrc a, ActSrc
     float acc[CT];
 #pragma unroll
     for (int k = 0; k < CT; ++k) acc[k] = 0.f;
-#pragma unroll 1
-    for (int c0 = 0; c0 < CIN; c0 += CK) {
-        const int ck4 = (CIN - c0 < CK ? CIN - c0 : CK) / 4;          // float4s per voxel in this chunk
-        __syncthreads();
-        for (int idx = tid; idx < NV * ck4; idx += 256) {
-            const int v = idx / ck4, c4 = idx - v * ck4;
-            const int vx = v % IX, vy = (v / IX) % IY, vz = v / (IX * IY);
-            const int gx = x0 + vx, gy = y0 + vy, gz = z0 + vz;
-            f32x4 val = {0, 0, 0, 0};
-            if (gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D)
-                load_act4<CIN>(a, b, ((int64_t)gz * H + gy) * W + gx, ld, c0 + c4 * 4, val);
-            *reinterpret_cast<f32x4*>(tile + v * CK + c4 * 4) = val;
-        }
-        __syncthreads();
-        for (int tap = 0; tap < 27; ++tap) {
-            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-            const float* tv = tile + (((tz + dz) * IY + ty + dy) * IX + tx + dx) * CK;
-            const float* wt = wp + ((int64_t)tap * CIN + c0) * Cout + cg;
-            for (int c4 = 0; c4 < ck4; ++c4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(tv + c4 * 4);
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4)
-#pragma unroll
-                    for (int k = 0; k < CT; ++k) acc[k] = fmaf(v[k4], wt[(int64_t)(c4 * 4 + k4) * Cout + k], acc[k]);
-            }
-        }
-    }
+#define MVS_CHUNK(C0_, CKC_) conv_tile_chunk<CIN, CT, C0_, CKC_>(a, b, ld, D, H, W, x0, y0, z0, wp, Cout, cg, tile, tid, tx, ty, tz, acc)
+    if constexpr (CIN >= 12) MVS_CHUNK(0, 12); else MVS_CHUNK(0, CIN);
+    if constexpr (CIN >= 24) MVS_CHUNK(12, 12); else if constexpr (CIN > 12) MVS_CHUNK(12, CIN - 12);
+    if constexpr (CIN >= 36) MVS_CHUNK(24, 12); else if constexpr (CIN > 24) MVS_CHUNK(24, CIN - 24);
+    if constexpr (CIN >= 48) MVS_CHUNK(36, 12); else if constexpr (CIN > 36) MVS_CHUNK(36, CIN - 36);
+    if constexpr (CIN >= 60) MVS_CHUNK(48, 12); else if constexpr (CIN > 48) MVS_CHUNK(48, CIN - 48);
+    if constexpr (CIN > 60) MVS_CHUNK(60, CIN - 60);
+#undef MVS_CHUNK
     const int ox = bx * 8 + tx, oy = by * 8 + ty, oz = bz * 4 + tz;
     if (ox < W && oy < H && oz < D) {
         float* o = out + (((int64_t)oz * H + oy) * W + ox) * Cout + cg;
@@ -722,49 +759,65 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(ActSrc g1, ActSrc g2,
     const int64_t nvox = (int64_t)Do * Ho * Wo;
     const int64_t per = (nvox + gridDim.x - 1) / gridDim.x;
     const int64_t o0 = blockIdx.x * per, o1 = o0 + per < nvox ? o0 + per : nvox;
-    int tap[NP], bch[NP];
+    int dz[NP], dy[NP], dx[NP], bch[NP];
     bool valid[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const int p = threadIdx.x + j * 256;
         valid[j] = p < 27 * B;
-        tap[j] = valid[j] ? p / B : 0;
-        bch[j] = valid[j] ? p - tap[j] * B : 0;
+        const int tap = valid[j] ? p / B : 0;
+        bch[j] = valid[j] ? p - tap * B : 0;
+        dz[j] = tap / 9 - 1; dy[j] = (tap / 3) % 3 - 1; dx[j] = tap % 3 - 1;
     }
     float acc[NP][A_T];
 #pragma unroll
     for (int j = 0; j < NP; ++j)
 #pragma unroll
         for (int a = 0; a < A_T; ++a) acc[j][a] = 0.f;
-    for (int64_t o = o0; o < o1; ++o) {
-        const int ox = (int)(o % Wo), oy = (int)((o / Wo) % Ho), oz = (int)(o / ((int64_t)Wo * Ho));
-        float g[A_T];
+    constexpr int U = 4;                                     // output voxels in flight per iteration (independent loads)
+    // 32-bit voxel walk with incrementally maintained coordinates (a 64-bit div/mod per voxel costs more than the FMAs)
+    const int n0 = (int)o0, n1 = (int)o1;
+    int cx = n0 % Wo, cy = (n0 / Wo) % Ho, cz = n0 / (Wo * Ho);
+    for (int ob = n0; ob < n1; ob += U) {
+        float g[U][A_T], xv[U][NP];
 #pragma unroll
-        for (int a = 0; a < A_T; ++a) {
-            g[a] = act1(g1, o * A + a0 + a, a0 + a);
-            if (g2.x) g[a] += act1(g2, o * A + a0 + a, a0 + a);
-        }
+        for (int u_ = 0; u_ < U; ++u_) {
+            const bool live = ob + u_ < n1;
+            const int o = live ? ob + u_ : n1 - 1;
+            const int ox = cx, oy = cy, oz = cz;
+            if (live) { if (++cx == Wo) { cx = 0; if (++cy == Ho) { cy = 0; ++cz; } } }
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int dz = tap[j] / 9, dy = (tap[j] / 3) % 3, dx = tap[j] % 3;
-            const int zi = oz * S - 1 + dz, yi = oy * S - 1 + dy, xi = ox * S - 1 + dx;
-            float xv = 0.f;
-            if (valid[j] && zi >= 0 && zi < Di && yi >= 0 && yi < Hi && xi >= 0 && xi < Wi) {
-                const int64_t idx = (((int64_t)zi * Hi + yi) * Wi + xi) * ldx + bch[j];
-                xv = act1(x1, idx, bch[j]);
-                if (x2.x) xv += act1(x2, idx, bch[j]);
+            for (int a = 0; a < A_T; ++a) {
+                float t = act1(g1, (int64_t)o * A + a0 + a, a0 + a);
+                if (g2.x) t += act1(g2, (int64_t)o * A + a0 + a, a0 + a);
+                g[u_][a] = live ? t : 0.f;
             }
 #pragma unroll
-            for (int a = 0; a < A_T; ++a) acc[j][a] = fmaf(g[a], xv, acc[j][a]);
+            for (int j = 0; j < NP; ++j) {
+                const int zi = oz * S + dz[j], yi = oy * S + dy[j], xi = ox * S + dx[j];
+                const bool in = valid[j] && (unsigned)zi < (unsigned)Di && (unsigned)yi < (unsigned)Hi && (unsigned)xi < (unsigned)Wi;
+                const int64_t idx = in ? (((int64_t)zi * Hi + yi) * Wi + xi) * ldx + bch[j] : 0;
+                float t = act1(x1, idx, bch[j]);
+                if (x2.x) t += act1(x2, idx, bch[j]);
+                xv[u_][j] = in ? t : 0.f;
+            }
         }
+#pragma unroll
+        for (int u_ = 0; u_ < U; ++u_)
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+#pragma unroll
+                for (int a = 0; a < A_T; ++a) acc[j][a] = fmaf(g[u_][a], xv[u_][j], acc[j][a]);
     }
     // partial[blockIdx.x][a][b][tap]
 #pragma unroll
     for (int j = 0; j < NP; ++j)
-        if (valid[j])
+        if (valid[j]) {
+            const int tap = (dz[j] + 1) * 9 + (dy[j] + 1) * 3 + (dx[j] + 1);
 #pragma unroll
             for (int a = 0; a < A_T; ++a)
-                partial[((int64_t)blockIdx.x * A + a0 + a) * B * 27 + (int64_t)bch[j] * 27 + tap[j]] = acc[j][a];
+                partial[((int64_t)blockIdx.x * A + a0 + a) * B * 27 + (int64_t)bch[j] * 27 + tap] = acc[j][a];
+        }
 }
 
 __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* __restrict__ partial, int n_part, int64_t n_out, float* __restrict__ gw)
@@ -776,7 +829,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* _
     gw[i] = s;
 }
 
-extern "C" size_t mvsnerf_conv3d_wgrad_workspace_floats(int A, int B) { return (size_t)512 * A * B * 27; }
+extern "C" size_t mvsnerf_conv3d_wgrad_workspace_floats(int A, int B) { return (size_t)2048 * A * B * 27; }
 
 extern "C" int mvsnerf_conv3d_wgrad(const float* g1, const float* g1_scale, const float* g1_shift,
                                     const float* g2, const float* g2_scale, const float* g2_shift, int A,
@@ -789,7 +842,7 @@ extern "C" int mvsnerf_conv3d_wgrad(const float* g1, const float* g1_scale, cons
     if (stride != 1 && stride != 2) return MVSNERF_EUNSUPPORTED;
     const ActSrc G1{g1, g1_scale, g1_shift}, G2{g2, g2_scale, g2_shift}, X1{x1, x1_scale, x1_shift}, X2{x2, x2_scale, x2_shift};
     const int64_t nvox = (int64_t)Do * Ho * Wo;
-    const int nwg = (int)(nvox < 512 ? nvox : 512);
+    const int nwg = (int)(nvox / 64 < 1 ? 1 : (nvox / 64 < 2048 ? nvox / 64 : 2048));     // >= 64 voxels per workgroup, <= 8 workgroups per CU
     const int np = (27 * B + 255) / 256;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(nwg, A / 8);
@@ -819,27 +872,22 @@ __global__ __launch_bounds__(256) void planesweep_bwd_kernel(const float* __rest
                                                             int V, int H, int W, int D, int pad, const float* __restrict__ g_cost, int CP, int c_var,
                                                             float* __restrict__ g_feat)
 {
+    // one thread per (voxel, channel): the C = 32 lanes of a voxel read / atomically update one contiguous 128-byte
+    // channel vector per bilinear tap (a per-voxel thread with a channel loop issues 4-byte atomics 128 B apart: 10x slower)
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const int64_t nvox = (int64_t)D * Hp * Wp;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = t / C;
+    const int c = (int)(t - i * C);
     if (i >= nvox) return;
     const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), d = (int)(i / ((int64_t)Wp * Hp));
     const float u = (float)(x - pad), v = (float)(y - pad), dep = depth[d];
     const bool interior = x >= pad && x < W + pad && y >= pad && y < H + pad;
-    const float* gv = g_cost + i * CP + c_var;
-    // pass 1: s[c] and the view count
-    float s[C];
-    if (interior) {
-        const float* r = feat + ((int64_t)(y - pad) * W + (x - pad)) * C;
-#pragma unroll
-        for (int c = 0; c < C; ++c) s[c] = r[c];
-    } else {
-#pragma unroll
-        for (int c = 0; c < C; ++c) s[c] = 0.f;
-    }
-    float cnt = 1.0f;
+    const float gv = g_cost[i * CP + c_var + c];
+    const float ref = interior ? feat[((int64_t)(y - pad) * W + (x - pad)) * C + c] : 0.f;
+    float s = ref, cnt = 1.0f;
     constexpr int MAXV = 8;
-    float tw[MAXV][4];
+    float tw[MAXV][4], wv[MAXV];
     int ta[MAXV][4];
     for (int vv = 1; vv < V; ++vv) {
         const float* P = proj + vv * 12;
@@ -859,30 +907,19 @@ __global__ __launch_bounds__(256) void planesweep_bwd_kernel(const float* __rest
         const int xa = any ? min(max((int)fx, 0), W - 1) : 0, xb = any ? min(max((int)fx + 1, 0), W - 1) : 0;
         const int ya = any ? min(max((int)fy, 0), H - 1) : 0, yb = any ? min(max((int)fy + 1, 0), H - 1) : 0;
         ta[vv][0] = ya * W + xa; ta[vv][1] = ya * W + xb; ta[vv][2] = yb * W + xa; ta[vv][3] = yb * W + xb;
-        const float* fb = feat + (int64_t)vv * H * W * C;
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-            s[c] += ((fb[(int64_t)ta[vv][0] * C + c] * tw[vv][0] + fb[(int64_t)ta[vv][1] * C + c] * tw[vv][1]) + fb[(int64_t)ta[vv][2] * C + c] * tw[vv][2]) + fb[(int64_t)ta[vv][3] * C + c] * tw[vv][3];
+        const float* fb = feat + (int64_t)vv * H * W * C + c;
+        wv[vv] = ((fb[(int64_t)ta[vv][0] * C] * tw[vv][0] + fb[(int64_t)ta[vv][1] * C] * tw[vv][1]) + fb[(int64_t)ta[vv][2] * C] * tw[vv][2]) + fb[(int64_t)ta[vv][3] * C] * tw[vv][3];
+        s += wv[vv];
     }
     const float inv = 1.0f / cnt;
-    // pass 2: scatter
-    if (interior) {
-        const float* r = feat + ((int64_t)(y - pad) * W + (x - pad)) * C;
-        float* gr = g_feat + ((int64_t)(y - pad) * W + (x - pad)) * C;
-#pragma unroll
-        for (int c = 0; c < C; ++c) atomicAdd(gr + c, gv[c] * 2.0f * inv * (r[c] - s[c] * inv));
-    }
+    const float k2 = gv * 2.0f * inv, mean = s * inv;
+    if (interior) atomicAdd(g_feat + ((int64_t)(y - pad) * W + (x - pad)) * C + c, k2 * (ref - mean));
     for (int vv = 1; vv < V; ++vv) {
-        const float* fb = feat + (int64_t)vv * H * W * C;
-        float* gb = g_feat + (int64_t)vv * H * W * C;
+        float* gb = g_feat + (int64_t)vv * H * W * C + c;
+        const float gw_ = k2 * (wv[vv] - mean);
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const float wv = ((fb[(int64_t)ta[vv][0] * C + c] * tw[vv][0] + fb[(int64_t)ta[vv][1] * C + c] * tw[vv][1]) + fb[(int64_t)ta[vv][2] * C + c] * tw[vv][2]) + fb[(int64_t)ta[vv][3] * C + c] * tw[vv][3];
-            const float gw_ = gv[c] * 2.0f * inv * (wv - s[c] * inv);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (tw[vv][k] != 0.f) atomicAdd(gb + (int64_t)ta[vv][k] * C + c, gw_ * tw[vv][k]);
-        }
+        for (int k = 0; k < 4; ++k)
+            if (tw[vv][k] != 0.f) atomicAdd(gb + (int64_t)ta[vv][k] * C, gw_ * tw[vv][k]);
     }
 }
 
@@ -892,7 +929,7 @@ extern "C" int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float
     if (!feats_cl || !proj || !depth || !g_cost || !g_feats_cl || V < 1 || V > 8 || H < 2 || W < 2 || D < 1 || pad < 0) return MVSNERF_EINVAL;
     if (C != 32) return MVSNERF_EUNSUPPORTED;
     const int64_t nvox = (int64_t)D * (H + 2 * pad) * (W + 2 * pad);
-    planesweep_bwd_kernel<32><<<mvs_cdiv(nvox, 256), 256, 0, (hipStream_t)stream>>>(feats_cl, proj, depth, V, H, W, D, pad, g_cost, CP,
+    planesweep_bwd_kernel<32><<<mvs_cdiv(nvox * 32, 256), 256, 0, (hipStream_t)stream>>>(feats_cl, proj, depth, V, H, W, D, pad, g_cost, CP,
                                                                                      with_img ? 3 * V : 0, g_feats_cl);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;

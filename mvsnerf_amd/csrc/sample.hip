@@ -306,3 +306,103 @@ extern "C" int mvsnerf_volume_sample_bwd(int D, int H, int W, int C, const float
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Ray generation: the arithmetic of build_rays / build_rays_test (utils.py:86-108, 148-297) after the RNG draws.
+// Pixel ids (CPU RNG) and the stratified jitter (device RNG) stay with the caller, so ray indices are bit-exact with
+// the reference; everything downstream of them is one kernel instead of ~25 ATen launches per batch:
+//   dirs   = [(x-cx)/fx, (y-cy)/fy, 1] @ c2w[:3,:3]^T                      (utils.py:101-104)
+//   z_s    = near*(1-t_s) + far*t_s, t = linspace(0,1,S) [+ stratified jitter]  (:211-221 / :279-282)
+//   pts    = o + z*d                                                        (:223)
+//   ndc    = get_ndc_coordinate(w2c_ref, K_ref, pts, (W-1,H-1), near_ref, far_ref, pad)   (:112-146)
+// One thread per sample.
+// ---------------------------------------------------------------------------------------------
+struct RayGenArgs {
+    const float* xs; const float* ys;      // [N] pixel ids as floats, or null: row-major ids first_pixel + n
+    int64_t first_pixel; int W_img, H_img;
+    const float* Kt; const float* c2w;     // target camera: intrinsics [3][3], c2w [4][4]   (device, wave-uniform loads)
+    const float* Kr; const float* w2c;     // reference camera: intrinsics [3][3], w2c [4][4]
+    const float* nf_tgt; const float* nf_ref;   // [2] = (near, far) of the target / reference view
+    int pad, lindisp;
+    const float* t_rand;                    // [N][S] or null
+    int64_t N; int S;
+    float* rays_pts; float* rays_dir; float* rays_ndc; float* z_vals; float* pix;   // pix: [2][N] = (ys, xs), may be null
+};
+
+__device__ __forceinline__ float linspace01(int i, int steps)
+{
+    // torch.linspace(0,1,steps): symmetric evaluation (start + i*step below the midpoint, end - (steps-1-i)*step above)
+    if (steps == 1) return 0.0f;
+    const float step = 1.0f / (float)(steps - 1);
+    return i < steps / 2 ? step * (float)i : 1.0f - step * (float)(steps - 1 - i);
+}
+
+__global__ __launch_bounds__(256) void raygen_kernel(RayGenArgs a)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.N * a.S) return;
+    const int64_t n = t / a.S;
+    const int s = (int)(t - n * a.S);
+    float x, y;
+    if (a.xs) { x = a.xs[n]; y = a.ys[n]; }
+    else { const int64_t p = a.first_pixel + n; y = (float)(p / a.W_img); x = (float)(p % a.W_img); }
+    const float near = a.nf_tgt[0], far = a.nf_tgt[1], near_ref = a.nf_ref[0], far_ref = a.nf_ref[1];
+    const float cxd = (x - a.Kt[2]) / a.Kt[0], cyd = (y - a.Kt[5]) / a.Kt[4];
+    const float dx = fmaf(1.0f, a.c2w[2], fmaf(cyd, a.c2w[1], cxd * a.c2w[0]));
+    const float dy = fmaf(1.0f, a.c2w[6], fmaf(cyd, a.c2w[5], cxd * a.c2w[4]));
+    const float dz = fmaf(1.0f, a.c2w[10], fmaf(cyd, a.c2w[9], cxd * a.c2w[8]));
+    auto zplain = [&](int i) {
+        const float tv = linspace01(i, a.S);
+        return a.lindisp ? 1.0f / (1.0f / near * (1.0f - tv) + 1.0f / far * tv) : near * (1.0f - tv) + far * tv;
+    };
+    float z = zplain(s);
+    if (a.t_rand) {
+        const float lo = s == 0 ? z : 0.5f * (z + zplain(s - 1));
+        const float up = s == a.S - 1 ? z : 0.5f * (zplain(s + 1) + z);
+        z = lo + (up - lo) * a.t_rand[t];
+    }
+    const float ox = a.c2w[3], oy = a.c2w[7], oz = a.c2w[11];
+    const float px = ox + z * dx, py = oy + z * dy, pz = oz + z * dz;
+    // reference camera: R x + t, K p, /z, /(W-1,H-1), depth normalisation, pad re-scale
+    const float cx = fmaf(pz, a.w2c[2], fmaf(py, a.w2c[1], px * a.w2c[0])) + a.w2c[3];
+    const float cy = fmaf(pz, a.w2c[6], fmaf(py, a.w2c[5], px * a.w2c[4])) + a.w2c[7];
+    const float cz = fmaf(pz, a.w2c[10], fmaf(py, a.w2c[9], px * a.w2c[8])) + a.w2c[11];
+    const float qx = fmaf(cz, a.Kr[2], fmaf(cy, a.Kr[1], cx * a.Kr[0]));
+    const float qy = fmaf(cz, a.Kr[5], fmaf(cy, a.Kr[4], cx * a.Kr[3]));
+    const float qz = fmaf(cz, a.Kr[8], fmaf(cy, a.Kr[7], cx * a.Kr[6]));
+    float nx = (qx / qz + 0.0f) / (float)(a.W_img - 1);
+    float ny = (qy / qz + 0.0f) / (float)(a.H_img - 1);
+    const float nz = a.lindisp ? (1.0f / qz - 1.0f / near_ref) / (1.0f / far_ref - 1.0f / near_ref)
+                               : (qz - near_ref) / (far_ref - near_ref);
+    if (a.pad > 0) {
+        const float Wf = (float)a.W_img / 4.0f, Hf = (float)a.H_img / 4.0f;          // (inv_scale+1)/4
+        ny = ny * Hf / (Hf + (float)(a.pad * 2)) + (float)a.pad / (Hf + (float)(a.pad * 2));
+        nx = nx * Wf / (Wf + (float)(a.pad * 2)) + (float)a.pad / (Wf + (float)(a.pad * 2));
+    }
+    a.rays_pts[t * 3 + 0] = px; a.rays_pts[t * 3 + 1] = py; a.rays_pts[t * 3 + 2] = pz;
+    a.rays_ndc[t * 3 + 0] = nx; a.rays_ndc[t * 3 + 1] = ny; a.rays_ndc[t * 3 + 2] = nz;
+    a.z_vals[t] = z;
+    if (s == 0) {
+        a.rays_dir[n * 3 + 0] = dx; a.rays_dir[n * 3 + 1] = dy; a.rays_dir[n * 3 + 2] = dz;
+        if (a.pix) { a.pix[n] = y; a.pix[a.N + n] = x; }
+    }
+}
+
+extern "C" int mvsnerf_raygen_fwd(const float* xs, const float* ys, int64_t first_pixel, int W_img, int H_img,
+                                  const float* K_tgt, const float* c2w_tgt, const float* K_ref, const float* w2c_ref,
+                                  const float* near_far_tgt, const float* near_far_ref, int pad, int lindisp,
+                                  const float* t_rand, int64_t N, int S,
+                                  float* rays_pts, float* rays_dir, float* rays_ndc, float* z_vals, float* pix, void* stream)
+{
+    if (!K_tgt || !c2w_tgt || !K_ref || !w2c_ref || !near_far_tgt || !near_far_ref || !rays_pts || !rays_dir || !rays_ndc || !z_vals || N < 0 || S < 1) return MVSNERF_EINVAL;
+    if ((xs == nullptr) != (ys == nullptr) || W_img < 2 || H_img < 2) return MVSNERF_EINVAL;
+    if (N == 0) return MVSNERF_OK;
+    RayGenArgs a;
+    a.xs = xs; a.ys = ys; a.first_pixel = first_pixel; a.W_img = W_img; a.H_img = H_img;
+    a.Kt = K_tgt; a.c2w = c2w_tgt; a.Kr = K_ref; a.w2c = w2c_ref; a.nf_tgt = near_far_tgt; a.nf_ref = near_far_ref;
+    a.pad = pad; a.lindisp = lindisp; a.t_rand = t_rand; a.N = N; a.S = S;
+    a.rays_pts = rays_pts; a.rays_dir = rays_dir; a.rays_ndc = rays_ndc; a.z_vals = z_vals; a.pix = pix;
+    raygen_kernel<<<mvs_cdiv(N * S, 256), 256, 0, (hipStream_t)stream>>>(a);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}

@@ -103,6 +103,28 @@ def posenc(x, num_freqs):
     return out
 
 
+def raygen(H, W, K_tgt, c2w_tgt, K_ref, w2c_ref, nf_tgt, nf_ref, N_samples, pad=0, lindisp=False,
+           xs=None, ys=None, first_pixel=0, n_rays=None, t_rand=None):
+    """Ray generation kernel (utils.build_rays / build_rays_test downstream of the RNG draws).
+    Either xs/ys (float pixel ids, (N,)) or first_pixel + n_rays (row-major ids).  All camera tensors stay on the device.
+    Returns rays_pts (N,S,3), rays_dir (N,3), rays_ndc (N,S,3), z_vals (N,S), pix (2,N)."""
+    dev = c2w_tgt.device
+    N = int(xs.shape[0]) if xs is not None else int(n_rays)
+    f32 = dict(device=dev, dtype=torch.float32)
+    pts = torch.empty((N, N_samples, 3), **f32)
+    ndc = torch.empty((N, N_samples, 3), **f32)
+    dirs = torch.empty((N, 3), **f32)
+    z = torch.empty((N, N_samples), **f32)
+    pix = torch.empty((2, N), **f32)
+    c = lambda t, name: dev_f32(t.contiguous(), name)
+    check(_lib.lib().mvsnerf_raygen_fwd(0 if xs is None else c(xs, "xs"), 0 if ys is None else c(ys, "ys"), int(first_pixel), W, H,
+                                        c(K_tgt, "K_tgt"), c(c2w_tgt, "c2w_tgt"), c(K_ref, "K_ref"), c(w2c_ref, "w2c_ref"),
+                                        c(nf_tgt, "near_far_tgt"), c(nf_ref, "near_far_ref"), int(pad), int(bool(lindisp)),
+                                        0 if t_rand is None else c(t_rand, "t_rand"), N, N_samples,
+                                        pts.data_ptr(), dirs.data_ptr(), ndc.data_ptr(), z.data_ptr(), pix.data_ptr(), stream_ptr()), "raygen_fwd")
+    return pts, dirs, ndc, z, pix
+
+
 # ------------------------------------------------------------------ MLP
 MLP_ORDER = [f"pts_linears.{i}" for i in range(6)] + ["pts_bias", "feature_linear", "alpha_linear", "views_linears.0", "rgb_linear"]
 

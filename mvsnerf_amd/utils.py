@@ -75,10 +75,45 @@ def _stratified(near, far, n_rays, n_samples, device, jitter):
     return lower + (upper - lower) * torch.rand(z.shape, device=device)       # device RNG, as utils.py:220
 
 
+def _nf_pair(near_fars_row):
+    return near_fars_row.reshape(-1)[:2].to(torch.float32).contiguous()
+
+
 def build_rays(imgs, depths, pose_ref, w2cs, c2ws, intrinsics, near_fars, N_rays, N_samples, pad=0,
                is_precrop_iters=False, ref_idx=0, importanceSampling=False, with_depth=False, is_volume=False):
     """utils.py:148-241: random target-view rays for one training step (target = last view).
-    Returns (rays_pts, rays_dir, colors, rays_NDC, depth_candidates, rays_o, rays_depth, ndc_parameters)."""
+    Returns (rays_pts, rays_dir, colors, rays_NDC, depth_candidates, rays_o, rays_depth, ndc_parameters).
+    The RNG draws happen here exactly as in the reference (pixel ids: CPU generator, xs then ys; jitter: device
+    generator), everything downstream is one HIP kernel (mvsnerf_raygen_fwd) on GPU tensors."""
+    dev = imgs.device
+    _, V, _, H, W = imgs.shape
+    w2c_ref, k_ref = pose_ref["w2cs"][ref_idx], pose_ref["intrinsics"][ref_idx]
+    inv_scale = torch.tensor([W - 1, H - 1]).to(dev)
+    near_ref, far_ref = pose_ref["near_fars"][ref_idx, 0], pose_ref["near_fars"][ref_idx, 1]
+    i = V - 1
+    if with_depth or importanceSampling or not imgs.is_cuda:
+        return _build_rays_torch(imgs, depths, pose_ref, w2cs, c2ws, intrinsics, near_fars, N_rays, N_samples, pad,
+                                 is_precrop_iters, ref_idx, importanceSampling, with_depth)
+    if is_precrop_iters and torch.rand((1,)) > 0.3:                                  # utils.py:90-93
+        xs = torch.randint(W // 6, W - W // 6, (N_rays,)).float().to(dev)
+        ys = torch.randint(H // 6, H - H // 6, (N_rays,)).float().to(dev)
+    else:
+        xs = torch.randint(0, W, (N_rays,)).float().to(dev)
+        ys = torch.randint(0, H, (N_rays,)).float().to(dev)
+    t_rand = torch.rand((N_rays, N_samples), device=dev)                             # utils.py:220
+    pts, rays_d, ndc, z, pix = ops.raygen(H, W, intrinsics[i], c2ws[i], k_ref, w2c_ref, _nf_pair(near_fars[0, i]),
+                                          _nf_pair(pose_ref["near_fars"][ref_idx]), N_samples, pad=pad, xs=xs, ys=ys, t_rand=t_rand)
+    pix_i = pix.long()
+    colors = imgs[0, i, :, pix_i[0], pix_i[1]].permute(1, 0)
+    rays_depth = depths[0, i, pix_i[0], pix_i[1]] if depths.shape[2] != 1 else None
+    rays_o = c2ws[i][:3, -1].reshape(3, 1).expand(3, N_rays)
+    ndc_parameters = {"w2c_ref": w2c_ref, "intrinsic_ref": k_ref, "inv_scale": inv_scale, "near": near_ref, "far": far_ref}
+    return pts, rays_d, colors, ndc, z, rays_o, rays_depth, ndc_parameters
+
+
+def _build_rays_torch(imgs, depths, pose_ref, w2cs, c2ws, intrinsics, near_fars, N_rays, N_samples, pad,
+                      is_precrop_iters, ref_idx, importanceSampling, with_depth):
+    """Host-side torch version of build_rays for the rarely used variants (per-pixel depth ranges) and CPU tensors."""
     dev = imgs.device
     _, V, _, H, W = imgs.shape
     w2c_ref, k_ref = pose_ref["w2cs"][ref_idx], pose_ref["intrinsics"][ref_idx]
@@ -106,7 +141,25 @@ def build_rays(imgs, depths, pose_ref, w2cs, c2ws, intrinsics, near_fars, N_rays
 
 def build_rays_test(H, W, tgt_to_world, world_to_ref, intrinsic, near_fars_ref, near_fars, N_samples, pad=0, ref_idx=0,
                     use_cpu=False, chunk=-1, idx=-1):
-    """utils.py:243-297: deterministic row-major rays of one chunk, no jitter."""
+    """utils.py:243-297: deterministic row-major rays of one chunk, no jitter.  On the GPU: one HIP kernel (the
+    reference rebuilds a full-frame meshgrid for every chunk, utils.py:95-98)."""
+    dev = torch.device("cpu") if use_cpu else tgt_to_world.device
+    if use_cpu or dev.type != "cuda":
+        return _build_rays_test_torch(H, W, tgt_to_world, world_to_ref, intrinsic, near_fars_ref, near_fars, N_samples, pad, ref_idx, use_cpu, chunk, idx)
+    inv_scale = torch.tensor([W - 1, H - 1]).to(dev)
+    k_render = intrinsic if intrinsic.dim() == 2 else intrinsic.mean(0)
+    first = 0 if chunk < 0 else idx * chunk
+    n = H * W if chunk < 0 else max(0, min(chunk, H * W - first))
+    pts, rays_d, ndc, z, _ = ops.raygen(H, W, k_render, tgt_to_world, k_render, world_to_ref, _nf_pair(near_fars),
+                                        _nf_pair(near_fars_ref[ref_idx]), N_samples, pad=pad, first_pixel=first, n_rays=n)
+    o = tgt_to_world[:3, -1].reshape(1, 3).expand(n, -1)
+    near, far = near_fars_ref[ref_idx, 0], near_fars_ref[ref_idx, 1]
+    ndc_parameters = {"w2c_ref": world_to_ref, "intrinsic_ref": intrinsic, "inv_scale": inv_scale, "near": near, "far": far}
+    return pts, rays_d, ndc, z, o, ndc_parameters
+
+
+def _build_rays_test_torch(H, W, tgt_to_world, world_to_ref, intrinsic, near_fars_ref, near_fars, N_samples, pad=0, ref_idx=0,
+                           use_cpu=False, chunk=-1, idx=-1):
     dev = torch.device("cpu") if use_cpu else tgt_to_world.device
     if use_cpu:
         tgt_to_world, world_to_ref, intrinsic = tgt_to_world.cpu(), world_to_ref.cpu(), intrinsic.cpu()

@@ -1,0 +1,17 @@
+import sys, time, torch, os
+sys.path.insert(0,'.')
+import numpy as np
+from mvsnerf_amd import train
+dev='cuda'
+args = train.default_args(pad=24, batch_size=1024, N_samples=128, chunk=1024)
+system = train.MVSSystem(args).to(dev)
+z = np.load('tests/golden/mvsnerf_v0_weights.npz')
+system.render_kwargs_train["network_fn"].load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("mlp/")})
+system.MVSNet.load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("mvs/")})
+batch = train.synthetic_batch(512, 640, seed=1234)
+opt = system.configure_optimizers()[0][0]
+torch.manual_seed(0)
+system.fit_steps([batch]*2, opt)
+torch.cuda.synchronize(); t0=time.perf_counter()
+system.fit_steps([batch]*3, opt)
+torch.cuda.synchronize(); print("train step ms", (time.perf_counter()-t0)/3*1e3)
