@@ -249,7 +249,7 @@ def main():
                           "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": PMC_TRAFFIC.get(name.split("_kernel")[0]), "avg_launch_ms": round(t, 5),
                           "timing": "hipGraph replay of 40 back-to-back launches (includes the ~1.5 us launch boundary)"})
         # ---------------- CPU baseline: the oracle (torch CPU kernels) on a bounded sample of the same workload
-        if a.cpu_batches > 0:
+        if a.cpu_batches > 0 and world == 1:          # reported at N=1 only (bench contract)
             from oracle import mvsnerf_oracle as O
             sd = load_mlp_weights()
             cpose = {k: v.cpu() for k, v in pose.items()}
@@ -277,7 +277,7 @@ def main():
             cpu["psnr_gpu_vs_cpu_db"] = round(10 * math.log10(1.0 / max(mse, 1e-20)), 1)
 
         extras = {}
-        if not a.no_extras:
+        if not a.no_extras and world == 1:
             from mvsnerf_amd import train
             # (i) end-to-end frame: encode + 320 batches of 1024 rays (one 512x640 target view), validation_step's loop
             targs = train.default_args(pad=PAD, batch_size=N_RAYS, N_samples=N_SAMPLES, chunk=N_RAYS)

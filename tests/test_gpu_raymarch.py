@@ -254,3 +254,42 @@ def test_raygen_vs_reference_golden(name):
     assert maxabs(z2.cpu(), c["ref_depth_cand"]) < 1e-6
     assert maxabs(p2.cpu(), c["ref_rays_pts"]) < 2e-6 and maxabs(n2.cpu(), c["ref_rays_ndc"]) < 2e-6
     assert torch.equal(pix[1].cpu().long(), c["pix_xs"]) and torch.equal(pix[0].cpu().long(), c["pix_ys"])
+
+
+def test_config1_end_to_end_vs_oracle(net):
+    """BASELINE config 1 ("3 source views, 64 depth planes, 256 rays x 64 samples, CPU plumbing case"), at DTU resolution:
+    encode (FeatureNet -> plane sweep -> CostRegNet) + ray march on the HIP path vs. the CPU oracle end to end."""
+    from mvsnerf_amd import models, renderer as R, utils as U
+    from mvsnerf_amd.synth import make_rig, pose_ref_of
+    from oracle import mvsnerf_oracle as O
+    mlp_sd, mvs_sd = load_weights()
+    H, W, pad, D, n_rays, n_samples = 256, 320, 24, 64, 256, 64          # half-resolution DTU frame keeps the CPU oracle at a few seconds
+    rig = make_rig(H, W, seed=1234, smooth=True)
+    pose = pose_ref_of(rig)
+    imgs_n, proj, nf = rig["images"][:, :3], rig["proj_mats"][:, :3], rig["near_fars"][0, 0]
+    vol_ref, feats_ref, dv, _, _ = O.mvsnet_forward(imgs_n, proj, nf, mvs_sd, pad=pad, D=D)
+    g = torch.Generator().manual_seed(3)
+    pts, dirs, _, ndc, z, ro, _ = O.build_rays(rig["images_raw"], pose, rig["near_fars"], n_rays, n_samples, pad=pad,
+                                               t_rand=torch.rand((n_rays, n_samples), generator=g), generator=g)
+    ref = O.rendering(pose, pts, ndc, z, dirs, vol_ref, rig["images_raw"][:, :3], mlp_sd)
+
+    mvs = models.MVSNet()
+    mvs.load_state_dict(mvs_sd)
+    mvs = mvs.to(DEV).train()
+    mvs.D = D
+    emb, _ = models.get_embedder(10, 0, 3)
+    qfn = lambda p, vd, f, fn: R.run_network_mvs(p, vd, f, fn, emb, None)
+    qfn._mvsnerf_fused = True
+    pose_d = {k: v.to(DEV) for k, v in pose.items()}
+    with torch.no_grad():
+        vol, _, dv_g = mvs(imgs_n.to(DEV), proj.to(DEV), nf.to(DEV), pad=pad)
+        assert vol.shape == (1, 8, D, H // 4 + 2 * pad, W // 4 + 2 * pad)
+        rgb, feat, w, depth, alpha, _ = R.rendering(_args(N_samples=n_samples), pose_d, pts.to(DEV), ndc.to(DEV), z.to(DEV), ro.to(DEV), dirs.to(DEV),
+                                                    vol, rig["images_raw"][:, :3].to(DEV), network_fn=net, network_query_fn=qfn)
+    # the volume passes through FeatureNet on MIOpen vs oneDNN and a batch-statistics U-Net: 1e-3-level agreement
+    frac_bad = float(((vol.cpu() - vol_ref).abs() > 5e-3).float().mean())
+    assert frac_bad < 1e-4, frac_bad
+    mse = float(((rgb.cpu() - ref[0]) ** 2).mean())
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
+    print("config-1 end-to-end PSNR(new vs oracle) = %.1f dB, max |rgb err| = %.2e" % (psnr, float((rgb.cpu() - ref[0]).abs().max())))
+    assert psnr > 60.0
