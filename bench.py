@@ -302,6 +302,31 @@ def main():
             torch.cuda.synchronize(); tdt = (time.perf_counter() - t0) / 5
             extras["train_step"] = {"ms": round(tdt * 1e3, 2), "rays_per_s": round(N_RAYS / tdt, 1), "loss_last": round(losses[-1], 5),
                                     "note": "MVSSystem.training_step fwd+bwd (HIP) + FeatureNet (torch-ROCm) + Adam, 1024x128, fp32"}
+        if not a.no_extras and world == 1:
+            # (iii) opt-in bf16-MFMA MLP (BASELINE configs 3/4); NOT the headline: results differ from fp32 at the 1e-2 level
+            ops.set_mlp_precision("bf16")
+            try:
+                with torch.no_grad():
+                    for i in range(10):
+                        step(i)
+                    torch.cuda.synchronize(); b0 = time.perf_counter()
+                    for i in range(100):
+                        step(i)
+                    torch.cuda.synchronize(); bdt = (time.perf_counter() - b0) / 100
+                    g = step(0)
+                    pb = net.packed_bf16(F)
+                    t_b = event_time(lambda: lib.mvsnerf_mlp_fwd_bf16(pb.data_ptr(), packed.data_ptr(), F, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3,
+                                                                      N_RAYS, N_SAMPLES, 0, raw.data_ptr(), st().cuda_stream), 100)
+            finally:
+                ops.set_mlp_precision("fp32")
+            with torch.no_grad():
+                g32 = step(0)
+            mse_b = float(((g[0] - g32[0]) ** 2).mean())
+            import math
+            extras["bf16_mlp_mode"] = {"rays_per_s": round(N_RAYS / bdt, 1), "ms_per_step": round(bdt * 1e3, 4), "mlp_kernel_ms": round(t_b, 4),
+                                       "mlp_tflops_equiv": round(FLOP_PER_SAMPLE * P / (t_b * 1e-3) / 1e12, 1),
+                                       "psnr_vs_fp32_path_db": round(10 * math.log10(1.0 / max(mse_b, 1e-20)), 1),
+                                       "note": "v_mfma_f32_32x32x16_bf16, fp32 accumulate; opt-in via ops.set_mlp_precision('bf16')"}
         print(json.dumps({
             "metric": "rendered rays/sec (1024-ray batch, 128 samples)", "value": round(rays_per_s, 1), "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),

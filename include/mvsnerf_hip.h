@@ -190,6 +190,16 @@ int mvsnerf_mlp_fwd(const float* packed, int F,
                     const float* dirs, int dirs_stride, int64_t N, int S, int alpha_only,
                     float* raw, void* stream);
 
+/* bf16-MFMA variant of the MLP forward (BASELINE configs 3/4: "bf16", "MFMA-bf16 MLP"): weights and layer inputs are
+ * rounded to bf16, products accumulate in fp32; biases, modulation, ReLU, positional encoding and the heads stay fp32.
+ * Opt-in (results differ from the fp32 path at the 1e-2 level); `packed_f32` is the buffer of mvsnerf_mlp_pack (its
+ * bias/head vectors are reused), `packed_bf16` holds mvsnerf_mlp_packed_bf16_elems(F) 16-bit elements. */
+size_t mvsnerf_mlp_packed_bf16_elems(int F);
+int mvsnerf_mlp_pack_bf16(const float* const w[11], int F, void* packed_bf16, void* stream);
+int mvsnerf_mlp_fwd_bf16(const void* packed_bf16, const float* packed_f32, int F, const float* ndc, int ndc_stride,
+                         const float* feat, int feat_stride, const float* dirs, int dirs_stride,
+                         int64_t N, int S, int alpha_only, float* raw, void* stream);
+
 /* ---- training path of the MLP (autograd of models.py:194-222) ----
  * mvsnerf_mlp_fwd_train = mvsnerf_mlp_fwd + an activation store `saved` (mvsnerf_mlp_saved_floats(N*S) floats).
  * mvsnerf_mlp_pack_bwd re-lays W^T fragments for the gradient chain (mvsnerf_mlp_packed_bwd_floats() floats).
@@ -249,6 +259,7 @@ typedef struct {
     float* input_feat;                      /* [N][S][F] out */
     float* raw;                             /* [N][S][4] out */
     float* rgb_map; float* disp; float* acc; float* weights; float* depth; float* alpha;  /* outs, may be NULL */
+    const void* packed_mlp_bf16;            /* NULL: fp32-MFMA MLP (default); else the bf16-MFMA variant is used (ABI v2) */
 } mvsnerf_raymarch_args;
 int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream);
 

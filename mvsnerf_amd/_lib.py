@@ -28,6 +28,7 @@ class RaymarchArgs(ctypes.Structure):
         ("N", _c_l), ("S", _c_i), ("white_bkgd", _c_i),
         ("dirs_tmp", _c_fp), ("input_feat", _c_fp), ("raw", _c_fp),
         ("rgb_map", _c_fp), ("disp", _c_fp), ("acc", _c_fp), ("weights", _c_fp), ("depth", _c_fp), ("alpha", _c_fp),
+        ("packed_mlp_bf16", _c_fp),
     ]
 
 
@@ -61,6 +62,9 @@ SIGNATURES = {
     "mvsnerf_mlp_packed_floats": (ctypes.c_size_t, [_c_i]),
     "mvsnerf_mlp_pack": (_c_i, [ctypes.POINTER(_c_fp), ctypes.POINTER(_c_fp), _c_i, _c_fp, _c_fp]),
     "mvsnerf_mlp_fwd": (_c_i, [_c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_mlp_packed_bf16_elems": (ctypes.c_size_t, [_c_i]),
+    "mvsnerf_mlp_pack_bf16": (_c_i, [ctypes.POINTER(_c_fp), _c_i, _c_fp, _c_fp]),
+    "mvsnerf_mlp_fwd_bf16": (_c_i, [_c_fp, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp]),
     "mvsnerf_mlp_saved_floats": (ctypes.c_size_t, [_c_l]),
     "mvsnerf_mlp_gradslot_floats": (ctypes.c_size_t, [_c_l]),
     "mvsnerf_mlp_packed_bwd_floats": (ctypes.c_size_t, []),

@@ -3,7 +3,7 @@
 // ATen launches).
 #include "common.h"
 
-extern "C" int mvsnerf_abi_version(void) { return 1; }
+extern "C" int mvsnerf_abi_version(void) { return 2; }
 
 extern "C" int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream)
 {
@@ -21,7 +21,11 @@ extern "C" int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream
     if ((rc = mvsnerf_volume_sample_fwd(a->vol, a->D, a->H, a->W, 8, a->rays_ndc, P, a->input_feat, F, stream))) return rc;
     if ((rc = mvsnerf_color_sample_fwd(a->imgs, a->V, a->IH, a->IW, a->w2c, a->K, a->rays_pts, P, 1, a->input_feat + 8, F, stream))) return rc;
     // network_query_fn (renderer.py:156 -> run_network_mvs 42-63)
-    if ((rc = mvsnerf_mlp_fwd(a->packed_mlp, F, a->rays_ndc, 3, a->input_feat, F, a->dirs_tmp, 3, a->N, a->S, 0, a->raw, stream))) return rc;
+    if (a->packed_mlp_bf16)
+        rc = mvsnerf_mlp_fwd_bf16(a->packed_mlp_bf16, a->packed_mlp, F, a->rays_ndc, 3, a->input_feat, F, a->dirs_tmp, 3, a->N, a->S, 0, a->raw, stream);
+    else
+        rc = mvsnerf_mlp_fwd(a->packed_mlp, F, a->rays_ndc, 3, a->input_feat, F, a->dirs_tmp, 3, a->N, a->S, 0, a->raw, stream);
+    if (rc) return rc;
     // raw2outputs (renderer.py:162)
     return mvsnerf_composite_fwd(a->raw, a->z_vals, a->N, a->S, a->white_bkgd, a->rgb_map, a->disp, a->acc, a->weights, a->depth, a->alpha, stream);
 }

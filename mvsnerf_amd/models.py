@@ -101,6 +101,15 @@ class Renderer_ours(nn.Module):
             self._packed_key = key
         return self._packed
 
+    def packed_bf16(self, feat_dim=None):
+        """bf16 fragment-ordered weights for the opt-in bf16-MFMA kernel (same cache policy as packed())."""
+        F = self.in_ch_feat if feat_dim is None else feat_dim
+        self.packed(F)                      # validates the architecture and keeps the fp32 vectors current
+        if getattr(self, "_packed_b", None) is None or self._packed_b_key != self._packed_key:
+            self._packed_b = ops.mlp_pack_bf16([l.weight.detach() for l in self._linears()], F)
+            self._packed_b_key = self._packed_key
+        return self._packed_b
+
     # -- queries ----------------------------------------------------------------------------
     def query(self, pts, feat, viewdirs, N, S):
         """pts (N,S,3) NDC, feat (N,S,F), viewdirs (N,3) per ray or None (sigma only) -> (N*S, 4|1)."""
@@ -108,8 +117,11 @@ class Renderer_ours(nn.Module):
         pts, feat = pts.contiguous(), feat.contiguous()
         alpha_only = viewdirs is None
         F = feat.shape[-1]
-        return ops.mlp_forward(self.packed(F), F, ops.dev_f32(pts, "pts"), 3, ops.dev_f32(feat, "feat"), F,
-                               0 if alpha_only else ops.dev_f32(viewdirs.contiguous(), "viewdirs"), 3, N, S, alpha_only, pts.device)
+        dptr = 0 if alpha_only else ops.dev_f32(viewdirs.contiguous(), "viewdirs")
+        if ops.MLP_PRECISION == "bf16":
+            return ops.mlp_forward_bf16(self.packed_bf16(F), self.packed(F), F, ops.dev_f32(pts, "pts"), 3, ops.dev_f32(feat, "feat"), F,
+                                        dptr, 3, N, S, alpha_only, pts.device)
+        return ops.mlp_forward(self.packed(F), F, ops.dev_f32(pts, "pts"), 3, ops.dev_f32(feat, "feat"), F, dptr, 3, N, S, alpha_only, pts.device)
 
     def _rows(self, x, alpha_only):
         ops._need_no_grad(x, *self.parameters(), op="Renderer_ours")
@@ -144,6 +156,9 @@ class MVSNeRF(nn.Module):
 
     def packed(self, feat_dim=None):
         return self.nerf.packed(feat_dim)
+
+    def packed_bf16(self, feat_dim=None):
+        return self.nerf.packed_bf16(feat_dim)
 
     def query(self, pts, feat, viewdirs, N, S):
         return self.nerf.query(pts, feat, viewdirs, N, S)

@@ -146,6 +146,32 @@ def mlp_pack(weights, biases, F):
     return packed
 
 
+MLP_PRECISION = "fp32"      # "fp32" (default, parity 1e-4) | "bf16" (opt-in: BASELINE configs 3/4); see set_mlp_precision
+
+
+def set_mlp_precision(mode):
+    """Select the MFMA data type of the inference MLP: "fp32" (v_mfma_f32_32x32x2_f32) or "bf16" (v_mfma_f32_32x32x16_bf16)."""
+    global MLP_PRECISION
+    if mode not in ("fp32", "bf16"):
+        raise ValueError("mlp precision must be 'fp32' or 'bf16'")
+    MLP_PRECISION = mode
+
+
+def mlp_pack_bf16(weights, F):
+    n = _lib.lib().mvsnerf_mlp_packed_bf16_elems(F)
+    packed = torch.empty(n, device=weights[0].device, dtype=torch.bfloat16)
+    wp = (ctypes.c_void_p * 11)(*[dev_f32(w, "weight") for w in weights])
+    check(_lib.lib().mvsnerf_mlp_pack_bf16(wp, F, packed.data_ptr(), stream_ptr()), "mlp_pack_bf16")
+    return packed
+
+
+def mlp_forward_bf16(packed_bf16, packed, F, ndc_ptr, ndc_stride, feat_ptr, feat_stride, dirs_ptr, dirs_stride, N, S, alpha_only, device):
+    raw = torch.empty((N * S, 1 if alpha_only else 4), device=device, dtype=torch.float32)
+    check(_lib.lib().mvsnerf_mlp_fwd_bf16(packed_bf16.data_ptr(), packed.data_ptr(), F, ndc_ptr, ndc_stride, feat_ptr, feat_stride,
+                                          dirs_ptr, dirs_stride, N, S, int(alpha_only), raw.data_ptr(), stream_ptr()), "mlp_fwd_bf16")
+    return raw
+
+
 def mlp_forward(packed, F, ndc_ptr, ndc_stride, feat_ptr, feat_stride, dirs_ptr, dirs_stride, N, S, alpha_only, device):
     raw = torch.empty((N * S, 1 if alpha_only else 4), device=device, dtype=torch.float32)
     check(_lib.lib().mvsnerf_mlp_fwd(packed.data_ptr(), F, ndc_ptr, ndc_stride, feat_ptr, feat_stride, dirs_ptr, dirs_stride,
@@ -172,7 +198,7 @@ def composite(raw, z_vals, white_bkgd=False):
 
 
 # ------------------------------------------------------------------ fused ray march
-def raymarch(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd=False):
+def raymarch(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd=False, packed_bf16=None):
     """One FFI call for rendering() (renderer.py:138-165).  Returns dict of outputs."""
     _need_no_grad(vol_cl, imgs, rays_pts, rays_ndc, z_vals, rays_dir, op="raymarch")
     N, S = z_vals.shape
@@ -195,7 +221,7 @@ def raymarch(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, z_vals,
         dev_f32(rays_pts, "rays_pts"), dev_f32(rays_ndc, "rays_ndc"), dev_f32(z_vals, "z_vals"), dev_f32(rays_dir, "rays_dir"),
         N, S, int(bool(white_bkgd)), dirs_tmp.data_ptr(), out["input_feat"].data_ptr(), out["raw"].data_ptr(),
         out["rgb_map"].data_ptr(), out["disp"].data_ptr(), out["acc"].data_ptr(), out["weights"].data_ptr(),
-        out["depth"].data_ptr(), out["alpha"].data_ptr())
+        out["depth"].data_ptr(), out["alpha"].data_ptr(), 0 if packed_bf16 is None else packed_bf16.data_ptr())
     check(_lib.lib().mvsnerf_raymarch_fwd(ctypes.byref(a), stream_ptr()), "raymarch_fwd")
     return out
 
