@@ -471,6 +471,13 @@ extern "C" int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const fl
     switch (key) {
         case 44 * 1000 + 8 * 10 + 1:  if (g_conv_tiled) MVS_CONV_TILED(44, 8); else MVS_CONV(44, 8, 1); break;     // conv0 (41 real channels + 3 zero pad)
         case 8 * 1000 + 44 * 10 + 1:  MVS_CONV_TILED(8, 44); break;  // data gradient of conv0
+        // conv0 for other source-view counts: Cin = 32 + 3V rounded up to 4 (V=0: plain variance volume; V=1,2,5,6,7,8)
+        case 32 * 1000 + 8 * 10 + 1:  MVS_CONV_TILED(32, 8); break;   case 8 * 1000 + 32 * 10 + 1:  MVS_CONV_TILED(8, 32); break;
+        case 36 * 1000 + 8 * 10 + 1:  MVS_CONV_TILED(36, 8); break;   case 8 * 1000 + 36 * 10 + 1:  MVS_CONV_TILED(8, 36); break;
+        case 40 * 1000 + 8 * 10 + 1:  MVS_CONV_TILED(40, 8); break;   case 8 * 1000 + 40 * 10 + 1:  MVS_CONV_TILED(8, 40); break;
+        case 48 * 1000 + 8 * 10 + 1:  MVS_CONV_TILED(48, 8); break;   case 8 * 1000 + 48 * 10 + 1:  MVS_CONV_TILED(8, 48); break;
+        case 52 * 1000 + 8 * 10 + 1:  MVS_CONV_TILED(52, 8); break;   case 8 * 1000 + 52 * 10 + 1:  MVS_CONV_TILED(8, 52); break;
+        case 56 * 1000 + 8 * 10 + 1:  MVS_CONV_TILED(56, 8); break;   case 8 * 1000 + 56 * 10 + 1:  MVS_CONV_TILED(8, 56); break;
         case 8 * 1000 + 16 * 10 + 2:  MVS_CONV(8, 16, 2); break;     // conv1
         case 16 * 1000 + 16 * 10 + 1: if (g_conv_tiled) MVS_CONV_TILED(16, 16); else MVS_CONV(16, 16, 1); break;    // conv2
         case 16 * 1000 + 32 * 10 + 2: MVS_CONV(16, 16, 2); break;    // conv3
@@ -852,6 +859,7 @@ extern "C" int mvsnerf_conv3d_wgrad(const float* g1, const float* g1_scale, cons
         case 21: MVS_WGR(2, 1); break;  case 22: MVS_WGR(2, 2); break;
         case 41: MVS_WGR(4, 1); break;  case 42: MVS_WGR(4, 2); break;
         case 51: MVS_WGR(5, 1); break;
+        case 61: MVS_WGR(6, 1); break;
         case 71: MVS_WGR(7, 1); break;
         default: return MVSNERF_EUNSUPPORTED;
     }

@@ -454,7 +454,7 @@ class _PlaneSweepFunction(torch.autograd.Function):
 class MVSNet(nn.Module):
     """reference models.py:771-932."""
 
-    def __init__(self, num_groups=1, norm_act=InPlaceABN, levels=1):
+    def __init__(self, num_groups=1, norm_act=InPlaceABN, levels=1, n_views=3):
         super().__init__()
         self.levels = levels
         self.n_depths = [128, 32, 8]
@@ -462,7 +462,9 @@ class MVSNet(nn.Module):
         self.feature = FeatureNet()
         self.N_importance = 0
         self.chunk = 1024
-        self.cost_reg_2 = CostRegNet(32 + 9, norm_act)
+        # the reference hard-wires 3 source views (32 + 9 channels, models.py:785); n_views is an extension for
+        # BASELINE config 4 (5 views => 47 input channels, no shipped checkpoint fits)
+        self.cost_reg_2 = CostRegNet(32 + 3 * n_views, norm_act)
         self.D = 128          # number of depth planes (hard-coded `D = 128` at models.py:914; settable here for config 1)
 
     def _sweep(self, imgs, feats, proj_mats, depth_values, pad, with_img):
