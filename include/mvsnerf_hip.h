@@ -126,6 +126,30 @@ int mvsnerf_conv3d_wgrad(const float* g1, const float* g1_scale, const float* g1
 int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float* proj, const float* depth, int V, int C, int H, int W, int D, int pad,
                                    const float* g_cost, int CP, int with_img, float* g_feats_cl, void* stream);
 
+/* ---- FeatureNet (models.py:688-722; ConvBnReLU :661-672): 2-D convolutions over N images, channel-last
+ * act[n][y][x][C], same lazy-InPlaceABN convention as the 3-D blocks (statistics via mvsnerf_abn_stats / mvsnerf_abn_bwd
+ * with n_vox = N*H*W).
+ *   conv2d_pack_weights: packed[tap][ci][co] = w[ci*s_ci + co*s_co + tap], ksize*ksize taps (`flip` mirrors them).
+ *            Conv2d (Cout,Cin,k,k): s_ci = k*k, s_co = Cin*k*k; data gradient: strides swapped (+ flip when stride 1).
+ *   conv2d_fwd: k in {1,3,5}, padding k/2, stride 1|2, optional bias[Cout] -> raw out[N][Ho][Wo][Cout]; the input is
+ *            leaky(x*scale+shift) when scale != NULL.  Also computes the data gradient of every stride-1 layer.
+ *   conv2d_dgrad_k5s2: data gradient of a k5 s2 p2 layer: g[N][Ho][Wo][Cin] -> out[N][Hi][Wi][Cout].
+ *   conv2d_wgrad: gW[a][b][tap] = sum_o G[o][a] * X[o*stride - k/2 + tap][b]  -> (A,B,k,k) = Conv2d's weight layout.
+ *   channel_sum: out[c] = sum_i g[i][c]  (bias gradient of `toplayer`). */
+int mvsnerf_conv2d_pack_weights(const float* w, int ci_real, int co_real, int cin_pad, int cout_pad,
+                                int s_ci, int s_co, int ksize, int flip, float* packed, void* stream);
+int mvsnerf_conv2d_fwd(const float* x, const float* scale, const float* shift, int Cin, int cin_ld,
+                       int N, int H, int W, const float* wpacked, const float* bias, int Cout,
+                       int ksize, int stride, float* out, void* stream);
+int mvsnerf_conv2d_dgrad_k5s2(const float* g, int Cin, int N, int Ho, int Wo, const float* wpacked, int Cout,
+                              int Hi, int Wi, float* out, void* stream);
+size_t mvsnerf_conv2d_wgrad_workspace_floats(int A, int B, int ksize);
+int mvsnerf_conv2d_wgrad(const float* g, int A, const float* x, const float* x_scale, const float* x_shift, int B, int ldx,
+                         int N, int Ho, int Wo, int Hi, int Wi, int ksize, int stride,
+                         float* gw, float* workspace, void* stream);
+size_t mvsnerf_channel_sum_workspace_floats(int C);
+int mvsnerf_channel_sum(const float* g, int64_t n, int C, float* out, float* workspace, void* stream);
+
 /* ---------------------------------------------------------------- ray march (L1b) */
 
 /* Ray generation: the arithmetic of build_rays / build_rays_test (utils.py:86-108, 148-297) downstream of the RNG

@@ -10,6 +10,7 @@
 // into per-channel (scale, shift); every consumer applies leaky_relu(x*scale+shift) while loading.
 // Skip additions (models.py:762-766) are the sum of two such lazily-activated tensors.
 #include "common.h"
+#include "act.h"
 
 // =============================================================================================
 // small layout / resize helpers
@@ -252,27 +253,6 @@ extern "C" int mvsnerf_homo_warp_fwd(const float* src_nchw, const float* proj, c
 // =============================================================================================
 // CostRegNet building blocks (models.py:674-685, 725-769)
 // =============================================================================================
-// lazily-activated operand: value = leaky(x*scale[c]+shift[c]) (scale == null: identity, no activation),
-// optionally + a second such tensor (the U-Net skip sums).
-struct ActSrc { const float* x; const float* scale; const float* shift; };
-
-__device__ __forceinline__ float act_apply(float x, float sc, float sh) { const float y = fmaf(x, sc, sh); return y > 0.f ? y : 0.01f * y; }
-
-template <int CIN>
-__device__ __forceinline__ void load_act4(const ActSrc& a, const ActSrc& b, int64_t vox, int ld, int c, f32x4& out)
-{
-    out = *reinterpret_cast<const f32x4*>(a.x + vox * ld + c);
-    if (a.scale) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) out[k] = act_apply(out[k], a.scale[c + k], a.shift[c + k]);
-    }
-    if (b.x) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(b.x + vox * ld + c);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) out[k] += act_apply(t[k], b.scale[c + k], b.shift[c + k]);
-    }
-}
-
 // weights re-laid as w[tap][ci][co] (co fastest) so that a thread's CT output channels are contiguous and
 // wave-uniform => the compiler fetches them through the scalar cache (s_load) and feeds v_fma from SGPRs.
 __global__ void conv3d_pack_kernel(const float* __restrict__ w, int ci_real, int co_real, int cin_pad, int cout_pad,
@@ -749,94 +729,139 @@ extern "C" int mvsnerf_abn_bwd(const float* x, int64_t n_vox, int C, const float
 // G lives on the conv's OUTPUT grid (A channels), X on its INPUT grid (B channels).  For Conv3d G = grad of the raw
 // output and X = the (lazily activated) input; for ConvTranspose3d the roles swap (G = activated coarse input,
 // X = grad of the fine raw output) and the result is already in ConvTranspose3d's (Cin,Cout,27) layout.
-// One thread owns NP (tap,b) pairs x A_T channels of `a`; a workgroup walks a contiguous range of output voxels
-// (G values are wave-uniform => scalar loads), partials per workgroup are combined by a second kernel.
-__device__ __forceinline__ float act1(const ActSrc& s, int64_t idx, int c)
+// Organisation: a lane owns one (dz,dy) tap row x 4 consecutive input channels (one 16-byte vector of X) and
+// accumulates all 3 dx taps x 4 channels x 8 `a` channels = 96 sums in registers while it walks ONE output row along x.
+// Walking along x the three dx taps slide over the same X vectors, so a step costs one new 16-byte X load (two for
+// stride 2) and one 32-byte G load per 96 FMAs (the pair-per-thread predecessor did one 4-byte load per 8 FMAs and
+// ran at 7.5 TFLOP/s).  npr = 9*ceil(B/4) lanes cover one output row; a 256-thread workgroup carries R = 256/npr rows
+// at a time and grid-strides over row groups; every (workgroup,row slot) leaves one partial that stage 2 reduces.
+__device__ __forceinline__ f32x4 wg_load_x(const ActSrc& x1, const ActSrc& x2, const float* p1, const float* p2, int ix, int Wi, int ldx, bool row_ok,
+                                           const f32x4& s1, const f32x4& h1, const f32x4& s2, const f32x4& h2)
 {
-    float v = s.x[idx];
-    if (s.scale) v = act_apply(v, s.scale[c], s.shift[c]);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row_ok && (unsigned)ix < (unsigned)Wi) {
+        v = *reinterpret_cast<const f32x4*>(p1 + (int64_t)ix * ldx);
+        if (x1.scale) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = act_apply(v[k], s1[k], h1[k]);
+        }
+        if (x2.x) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p2 + (int64_t)ix * ldx);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += act_apply(t[k], s2[k], h2[k]);
+        }
+    }
     return v;
 }
 
-template <int A_T, int NP, int S>
-__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(ActSrc g1, ActSrc g2, int A, ActSrc x1, ActSrc x2, int B, int ldx,
-                                                          int Do, int Ho, int Wo, int Di, int Hi, int Wi, float* __restrict__ partial)
+struct G8 { f32x4 lo, hi; };
+
+__device__ __forceinline__ G8 wg_load_g(const ActSrc& g1, const ActSrc& g2, const float* p1, const float* p2, int ox, int Wo, int A, int a0, bool live)
 {
-    const int a0 = blockIdx.y * A_T;
-    const int64_t nvox = (int64_t)Do * Ho * Wo;
-    const int64_t per = (nvox + gridDim.x - 1) / gridDim.x;
-    const int64_t o0 = blockIdx.x * per, o1 = o0 + per < nvox ? o0 + per : nvox;
-    int dz[NP], dy[NP], dx[NP], bch[NP];
-    bool valid[NP];
+    G8 g{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (live && ox < Wo) {
+        g.lo = *reinterpret_cast<const f32x4*>(p1 + (int64_t)ox * A);
+        g.hi = *reinterpret_cast<const f32x4*>(p1 + (int64_t)ox * A + 4);
+        if (g1.scale) {
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const int p = threadIdx.x + j * 256;
-        valid[j] = p < 27 * B;
-        const int tap = valid[j] ? p / B : 0;
-        bch[j] = valid[j] ? p - tap * B : 0;
-        dz[j] = tap / 9 - 1; dy[j] = (tap / 3) % 3 - 1; dx[j] = tap % 3 - 1;
-    }
-    float acc[NP][A_T];
-#pragma unroll
-    for (int j = 0; j < NP; ++j)
-#pragma unroll
-        for (int a = 0; a < A_T; ++a) acc[j][a] = 0.f;
-    constexpr int U = 4;                                     // output voxels in flight per iteration (independent loads)
-    // 32-bit voxel walk with incrementally maintained coordinates (a 64-bit div/mod per voxel costs more than the FMAs)
-    const int n0 = (int)o0, n1 = (int)o1;
-    int cx = n0 % Wo, cy = (n0 / Wo) % Ho, cz = n0 / (Wo * Ho);
-    for (int ob = n0; ob < n1; ob += U) {
-        float g[U][A_T], xv[U][NP];
-#pragma unroll
-        for (int u_ = 0; u_ < U; ++u_) {
-            const bool live = ob + u_ < n1;
-            const int o = live ? ob + u_ : n1 - 1;
-            const int ox = cx, oy = cy, oz = cz;
-            if (live) { if (++cx == Wo) { cx = 0; if (++cy == Ho) { cy = 0; ++cz; } } }
-#pragma unroll
-            for (int a = 0; a < A_T; ++a) {
-                float t = act1(g1, (int64_t)o * A + a0 + a, a0 + a);
-                if (g2.x) t += act1(g2, (int64_t)o * A + a0 + a, a0 + a);
-                g[u_][a] = live ? t : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const int zi = oz * S + dz[j], yi = oy * S + dy[j], xi = ox * S + dx[j];
-                const bool in = valid[j] && (unsigned)zi < (unsigned)Di && (unsigned)yi < (unsigned)Hi && (unsigned)xi < (unsigned)Wi;
-                const int64_t idx = in ? (((int64_t)zi * Hi + yi) * Wi + xi) * ldx + bch[j] : 0;
-                float t = act1(x1, idx, bch[j]);
-                if (x2.x) t += act1(x2, idx, bch[j]);
-                xv[u_][j] = in ? t : 0.f;
-            }
+            for (int k = 0; k < 4; ++k) { g.lo[k] = act_apply(g.lo[k], g1.scale[a0 + k], g1.shift[a0 + k]); g.hi[k] = act_apply(g.hi[k], g1.scale[a0 + 4 + k], g1.shift[a0 + 4 + k]); }
         }
+        if (g2.x) {
+            const f32x4 tl = *reinterpret_cast<const f32x4*>(p2 + (int64_t)ox * A), th = *reinterpret_cast<const f32x4*>(p2 + (int64_t)ox * A + 4);
 #pragma unroll
-        for (int u_ = 0; u_ < U; ++u_)
-#pragma unroll
-            for (int j = 0; j < NP; ++j)
-#pragma unroll
-                for (int a = 0; a < A_T; ++a) acc[j][a] = fmaf(g[u_][a], xv[u_][j], acc[j][a]);
-    }
-    // partial[blockIdx.x][a][b][tap]
-#pragma unroll
-    for (int j = 0; j < NP; ++j)
-        if (valid[j]) {
-            const int tap = (dz[j] + 1) * 9 + (dy[j] + 1) * 3 + (dx[j] + 1);
-#pragma unroll
-            for (int a = 0; a < A_T; ++a)
-                partial[((int64_t)blockIdx.x * A + a0 + a) * B * 27 + (int64_t)bch[j] * 27 + tap] = acc[j][a];
+            for (int k = 0; k < 4; ++k) { g.lo[k] += act_apply(tl[k], g2.scale[a0 + k], g2.shift[a0 + k]); g.hi[k] += act_apply(th[k], g2.scale[a0 + 4 + k], g2.shift[a0 + 4 + k]); }
         }
+    }
+    return g;
 }
 
-__global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* __restrict__ partial, int n_part, int64_t n_out, float* __restrict__ gw)
+template <int S>
+__global__ __launch_bounds__(256) void conv3d_wgrad_rows_kernel(ActSrc g1, ActSrc g2, int A, ActSrc x1, ActSrc x2, int B, int ldx,
+                                                               int Do, int Ho, int Wo, int Di, int Hi, int Wi, int nb4, int R,
+                                                               float* __restrict__ partial)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_out) return;
-    float s = 0.f;
-    for (int p = 0; p < n_part; ++p) s += partial[(int64_t)p * n_out + i];
-    gw[i] = s;
+    const int a0 = blockIdx.y * 8;
+    const int npr = nb4 * 9;
+    const int r = threadIdx.x / npr, it = threadIdx.x - r * npr;
+    const bool active = r < R;
+    const int b4 = it % nb4, dyz = it / nb4;
+    const int dy = dyz % 3 - 1, dz = dyz / 3 - 1;
+    const int c0 = b4 * 4;
+    f32x4 s1 = {1, 1, 1, 1}, h1 = {0, 0, 0, 0}, s2 = s1, h2 = h1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + k < B ? c0 + k : B - 1;
+        if (x1.scale) { s1[k] = x1.scale[c]; h1[k] = x1.shift[c]; }
+        if (x2.x) { s2[k] = x2.scale[c]; h2[k] = x2.shift[c]; }
+    }
+    float acc[3][4][8];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int a = 0; a < 8; ++a) acc[d][k][a] = 0.f;
+    const int nrows = Do * Ho;
+    for (int grp = blockIdx.x; grp * R < nrows; grp += gridDim.x) {
+        const int row = grp * R + r;
+        const bool live = active && row < nrows;
+        const int oz = live ? row / Ho : 0, oy = live ? row - oz * Ho : 0;
+        const int zi = oz * S + dz, yi = oy * S + dy;
+        const bool row_ok = live && (unsigned)zi < (unsigned)Di && (unsigned)yi < (unsigned)Hi;
+        const int64_t xoff = row_ok ? (((int64_t)zi * Hi + yi) * Wi) * ldx + c0 : 0;
+        const float* px1 = x1.x + xoff;
+        const float* px2 = x2.x ? x2.x + xoff : nullptr;
+        const int64_t goff = live ? ((int64_t)row * Wo) * A + a0 : 0;
+        const float* pg1 = g1.x + goff;
+        const float* pg2 = g2.x ? g2.x + goff : nullptr;
+#define MVS_LX(ix) wg_load_x(x1, x2, px1, px2, (ix), Wi, ldx, row_ok, s1, h1, s2, h2)
+#define MVS_LG(ox) wg_load_g(g1, g2, pg1, pg2, (ox), Wo, A, a0, live)
+        f32x4 w0 = MVS_LX(-1), w1 = MVS_LX(0), w2 = MVS_LX(1);
+        G8 gc = MVS_LG(0);
+        for (int ox = 0; ox < Wo; ++ox) {
+            // next step's operands are requested before this step's 96 FMAs
+            const G8 gn = MVS_LG(ox + 1);
+            f32x4 n1, n2;
+            if (S == 1) { n2 = MVS_LX(ox + 2); }
+            else        { n1 = MVS_LX(2 * ox + 2); n2 = MVS_LX(2 * ox + 3); }
+            const float gv[8] = {gc.lo[0], gc.lo[1], gc.lo[2], gc.lo[3], gc.hi[0], gc.hi[1], gc.hi[2], gc.hi[3]};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    acc[0][k][a] = fmaf(gv[a], w0[k], acc[0][k][a]);
+                    acc[1][k][a] = fmaf(gv[a], w1[k], acc[1][k][a]);
+                    acc[2][k][a] = fmaf(gv[a], w2[k], acc[2][k][a]);
+                }
+            if (S == 1) { w0 = w1; w1 = w2; w2 = n2; }
+            else        { w0 = w2; w1 = n1; w2 = n2; }
+            gc = gn;
+        }
+#undef MVS_LX
+#undef MVS_LG
+    }
+    if (!active) return;
+    // partial[(blockIdx.x*R + r)][a][b][tap], tap = (dz*3 + dy)*3 + dx
+    float* po = partial + ((int64_t)(blockIdx.x * R + r) * A + a0) * B * 27;
+    const int tap0 = ((dz + 1) * 3 + (dy + 1)) * 3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (c0 + k >= B) continue;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) po[((int64_t)a * B + c0 + k) * 27 + tap0 + d] = acc[d][k][a];
+    }
 }
 
-extern "C" size_t mvsnerf_conv3d_wgrad_workspace_floats(int A, int B) { return (size_t)2048 * A * B * 27; }
+// number of partial results the workspace is sized for
+static int wgrad3d_part_cap(int A, int B)
+{
+    const int64_t n_out = (int64_t)A * B * 27, by_mem = ((int64_t)16 << 20) / n_out;
+    return (int)(by_mem < 2048 ? 2048 : (by_mem > 16384 ? 16384 : by_mem));
+}
+
+extern "C" size_t mvsnerf_conv3d_wgrad_workspace_floats(int A, int B) { return (size_t)(wgrad3d_part_cap(A, B) + MVS_RED_SLICES) * A * B * 27; }
 
 extern "C" int mvsnerf_conv3d_wgrad(const float* g1, const float* g1_scale, const float* g1_shift,
                                     const float* g2, const float* g2_scale, const float* g2_shift, int A,
@@ -845,28 +870,23 @@ extern "C" int mvsnerf_conv3d_wgrad(const float* g1, const float* g1_scale, cons
                                     int Do, int Ho, int Wo, int Di, int Hi, int Wi, int stride,
                                     float* gw, float* workspace, void* stream)
 {
-    if (!g1 || !x1 || !gw || !workspace || A < 8 || (A & 7) || B < 1 || ldx < B) return MVSNERF_EINVAL;
+    if (!g1 || !x1 || !gw || !workspace || A < 8 || (A & 7) || B < 1 || ldx < B || (ldx & 3)) return MVSNERF_EINVAL;
     if (stride != 1 && stride != 2) return MVSNERF_EUNSUPPORTED;
+    if (!mvs_aligned16(g1) || !mvs_aligned16(x1) || (g2 && !mvs_aligned16(g2)) || (x2 && !mvs_aligned16(x2))) return MVSNERF_EALIGN;
+    const int nb4 = (B + 3) / 4, npr = nb4 * 9;
+    if (npr > 256 || (nb4 * 4 > ldx)) return MVSNERF_EUNSUPPORTED;
     const ActSrc G1{g1, g1_scale, g1_shift}, G2{g2, g2_scale, g2_shift}, X1{x1, x1_scale, x1_shift}, X2{x2, x2_scale, x2_shift};
-    const int64_t nvox = (int64_t)Do * Ho * Wo;
-    const int nwg = (int)(nvox / 64 < 1 ? 1 : (nvox / 64 < 2048 ? nvox / 64 : 2048));     // >= 64 voxels per workgroup, <= 8 workgroups per CU
-    const int np = (27 * B + 255) / 256;
+    const int R = 256 / npr;
+    const int nrows = Do * Ho, ngroups = (nrows + R - 1) / R;
+    const int cap = wgrad3d_part_cap(A, B) / R;
+    const int nwg = ngroups < cap ? ngroups : cap;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(nwg, A / 8);
-#define MVS_WGR(NP_, S_) conv3d_wgrad_kernel<8, NP_, S_><<<grid, 256, 0, st>>>(G1, G2, A, X1, X2, B, ldx, Do, Ho, Wo, Di, Hi, Wi, workspace)
-    switch (np * 10 + stride) {
-        case 11: MVS_WGR(1, 1); break;  case 12: MVS_WGR(1, 2); break;
-        case 21: MVS_WGR(2, 1); break;  case 22: MVS_WGR(2, 2); break;
-        case 41: MVS_WGR(4, 1); break;  case 42: MVS_WGR(4, 2); break;
-        case 51: MVS_WGR(5, 1); break;
-        case 61: MVS_WGR(6, 1); break;
-        case 71: MVS_WGR(7, 1); break;
-        default: return MVSNERF_EUNSUPPORTED;
-    }
-#undef MVS_WGR
+    if (stride == 1) conv3d_wgrad_rows_kernel<1><<<grid, 256, 0, st>>>(G1, G2, A, X1, X2, B, ldx, Do, Ho, Wo, Di, Hi, Wi, nb4, R, workspace);
+    else             conv3d_wgrad_rows_kernel<2><<<grid, 256, 0, st>>>(G1, G2, A, X1, X2, B, ldx, Do, Ho, Wo, Di, Hi, Wi, nb4, R, workspace);
     MVS_LAUNCH_CHECK();
     const int64_t n_out = (int64_t)A * B * 27;
-    conv3d_wgrad_reduce_kernel<<<mvs_cdiv(n_out, 256), 256, 0, st>>>(workspace, nwg, n_out, gw);
+    mvs_partial_sum(workspace, nwg * R, n_out, workspace + (size_t)wgrad3d_part_cap(A, B) * n_out, gw, st);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }

@@ -1,0 +1,315 @@
+// FeatureNet (reference models.py:688-722) building blocks: 2-D convolutions over a batch of N images, channel-last
+//   act[n][y][x][C]   C in {4 (rgb + pad), 8, 16, 32}
+// with the same lazy InPlaceABN convention as the 3-D U-Net (encoder.hip): a conv writes its RAW output, the
+// statistics kernel (mvsnerf_abn_stats over N*H*W pixels) turns batch statistics into (scale, shift), and every
+// consumer applies leaky_relu(x*scale+shift) on load.  Kernels here:
+//   conv2d_kernel        k in {1,3,5}, stride in {1,2}, padding k/2; also the data gradient of the stride-1 layers
+//                        (mirrored taps, swapped channel roles) and the biased 1x1 `toplayer`
+//   conv2d_dgrad_s2      data gradient of the k5 s2 p2 layers (a gather-form transposed convolution)
+//   conv2d_wgrad         weight gradient, any k / stride
+//   channel_sum          bias gradient of `toplayer`
+// All fp32 FMA work (the north star reserves MFMA for the MLP).  Weights are re-laid as w[tap][ci][co] and, being
+// wave-uniform, are fetched through the scalar cache.
+#include "common.h"
+#include "act.h"
+
+__global__ void conv2d_pack_kernel(const float* __restrict__ w, int ci_real, int co_real, int cin_pad, int cout_pad,
+                                   int s_ci, int s_co, int ntaps, int flip, float* __restrict__ packed)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = ntaps * cin_pad * cout_pad;
+    if (i >= total) return;
+    const int co = i % cout_pad, ci = (i / cout_pad) % cin_pad;
+    int tap = i / (cout_pad * cin_pad);
+    if (flip) tap = ntaps - 1 - tap;
+    packed[i] = (ci < ci_real && co < co_real) ? w[(int64_t)ci * s_ci + (int64_t)co * s_co + tap] : 0.f;
+}
+
+extern "C" int mvsnerf_conv2d_pack_weights(const float* w, int ci_real, int co_real, int cin_pad, int cout_pad,
+                                           int s_ci, int s_co, int ksize, int flip, float* packed, void* stream)
+{
+    if (!w || !packed || ci_real < 1 || co_real < 1 || cin_pad < ci_real || cout_pad < co_real || ksize < 1) return MVSNERF_EINVAL;
+    const int ntaps = ksize * ksize;
+    conv2d_pack_kernel<<<mvs_cdiv((int64_t)ntaps * cin_pad * cout_pad, 256), 256, 0, (hipStream_t)stream>>>(
+        w, ci_real, co_real, cin_pad, cout_pad, s_ci, s_co, ntaps, flip, packed);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// One thread = one output pixel x CT output channels; a workgroup owns a 16x16 pixel tile so that the K*K-fold input
+// reuse is served by L1 (a pixel's channels are one contiguous vector, 16 lanes of a row read one contiguous span).
+template <int CIN, int CT, int K, int S>
+__global__ __launch_bounds__(256) void conv2d_kernel(ActSrc a, int ld, int Hi, int Wi, const float* __restrict__ wp,
+                                                     const float* __restrict__ bias, int Cout,
+                                                     float* __restrict__ out, int Ho, int Wo)
+{
+    constexpr int P = K / 2;
+    const int nbx = (Wo + 15) >> 4, nby = (Ho + 15) >> 4;
+    const int bx = blockIdx.x % nbx, by = (blockIdx.x / nbx) % nby, n = blockIdx.x / (nbx * nby);
+    const int cg = blockIdx.y * CT;
+    const int x = bx * 16 + (threadIdx.x & 15), y = by * 16 + (threadIdx.x >> 4);
+    const bool live = x < Wo && y < Ho;
+    float acc[CT];
+#pragma unroll
+    for (int k = 0; k < CT; ++k) acc[k] = bias ? bias[cg + k] : 0.f;
+    const ActSrc none{nullptr, nullptr, nullptr};
+    const int64_t img0 = (int64_t)n * Hi * Wi;
+#pragma unroll 1
+    for (int ky = 0; ky < K; ++ky) {
+        const int yi = y * S - P + ky;
+        const bool yin = live && yi >= 0 && yi < Hi;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const int xi = x * S - P + kx;
+            const bool in = yin && xi >= 0 && xi < Wi;
+            const int64_t pix = img0 + (in ? (int64_t)yi * Wi + xi : 0);
+            const float* wt = wp + (int64_t)(ky * K + kx) * CIN * Cout + cg;
+#pragma unroll
+            for (int c = 0; c < CIN; c += 4) {
+                f32x4 v;
+                load_act4<CIN>(a, none, pix, ld, c, v);
+                if (!in) v = f32x4{0, 0, 0, 0};              // zero padding of the *activated* input
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+                    for (int k = 0; k < CT; ++k) acc[k] = fmaf(v[k4], wt[(int64_t)(c + k4) * Cout + k], acc[k]);
+            }
+        }
+    }
+    if (live) {
+        float* o = out + (((int64_t)n * Ho + y) * Wo + x) * Cout + cg;
+#pragma unroll
+        for (int k = 0; k < CT; k += 4) *reinterpret_cast<f32x4*>(o + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+    }
+}
+
+extern "C" int mvsnerf_conv2d_fwd(const float* x, const float* scale, const float* shift, int Cin, int cin_ld,
+                                  int N, int H, int W, const float* wpacked, const float* bias, int Cout,
+                                  int ksize, int stride, float* out, void* stream)
+{
+    if (!x || !wpacked || !out || ((scale == nullptr) != (shift == nullptr)) || N < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
+    if ((cin_ld & 3) || cin_ld < Cin || !mvs_aligned16(x) || !mvs_aligned16(out)) return MVSNERF_EALIGN;
+    const int P = ksize / 2;
+    const int Ho = (H + 2 * P - ksize) / stride + 1, Wo = (W + 2 * P - ksize) / stride + 1;
+    const ActSrc a{x, scale, shift};
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned tiles = (unsigned)(((Wo + 15) / 16) * ((Ho + 15) / 16) * N);
+#define MVS_C2D(CIN, CT, K, S) conv2d_kernel<CIN, CT, K, S><<<dim3(tiles, Cout / CT), 256, 0, st>>>(a, cin_ld, H, W, wpacked, bias, Cout, out, Ho, Wo)
+    const int key = ((Cin * 100 + Cout) * 10 + ksize) * 10 + stride;
+    switch (key) {
+        case ((4 * 100 + 8) * 10 + 3) * 10 + 1:   MVS_C2D(4, 8, 3, 1); break;      // conv0.0  (rgb + pad -> 8)
+        case ((8 * 100 + 8) * 10 + 3) * 10 + 1:   MVS_C2D(8, 8, 3, 1); break;      // conv0.1 and its data gradient
+        case ((8 * 100 + 16) * 10 + 5) * 10 + 2:  MVS_C2D(8, 16, 5, 2); break;     // conv1.0
+        case ((16 * 100 + 16) * 10 + 3) * 10 + 1: MVS_C2D(16, 16, 3, 1); break;    // conv1.1, conv1.2 (+ data gradients)
+        case ((16 * 100 + 32) * 10 + 5) * 10 + 2: MVS_C2D(16, 16, 5, 2); break;    // conv2.0
+        case ((32 * 100 + 32) * 10 + 3) * 10 + 1: MVS_C2D(32, 16, 3, 1); break;    // conv2.1, conv2.2 (+ data gradients)
+        case ((32 * 100 + 32) * 10 + 1) * 10 + 1: MVS_C2D(32, 16, 1, 1); break;    // toplayer (+ data gradient)
+        default: return MVSNERF_EUNSUPPORTED;
+    }
+#undef MVS_C2D
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// Data gradient of a k5 s2 p2 convolution: gx[yi][xi][co] = sum_{ky,kx,ci} g[(yi+2-ky)/2][(xi+2-kx)/2][ci] w[ky][kx][ci][co]
+// over the taps whose (yi+2-ky), (xi+2-kx) are even and land inside the (Ho,Wo) grid.  Thread per input-grid pixel.
+template <int CIN, int CT>
+__global__ __launch_bounds__(256) void conv2d_dgrad_k5s2_kernel(const float* __restrict__ g, int Ho, int Wo, const float* __restrict__ wp,
+                                                                int Cout, float* __restrict__ out, int Hi, int Wi)
+{
+    // blockIdx.z = pixel parity class (y&1, x&1): the contributing taps - hence the weight addresses - are then
+    // uniform over the workgroup and stay on the scalar path
+    const int py = blockIdx.z >> 1, px = blockIdx.z & 1;
+    const int Wh = (Wi + 1) >> 1, Hh = (Hi + 1) >> 1;
+    const int nbx = (Wh + 15) >> 4, nby = (Hh + 15) >> 4;
+    const int bx = blockIdx.x % nbx, by = (blockIdx.x / nbx) % nby, n = blockIdx.x / (nbx * nby);
+    const int cg = blockIdx.y * CT;
+    const int x = (bx * 16 + (threadIdx.x & 15)) * 2 + px, y = (by * 16 + (threadIdx.x >> 4)) * 2 + py;
+    const bool live = x < Wi && y < Hi;
+    float acc[CT];
+#pragma unroll
+    for (int k = 0; k < CT; ++k) acc[k] = 0.f;
+    const float* gi = g + (int64_t)n * Ho * Wo * CIN;
+    for (int ky = py; ky < 5; ky += 2) {                      // y + 2 - ky even  <=>  ky has y's parity
+        const int yo = (y + 2 - ky) >> 1;
+        const bool yin = live && yo >= 0 && yo < Ho;
+        for (int kx = px; kx < 5; kx += 2) {
+            const int xo = (x + 2 - kx) >> 1;
+            const bool in = yin && xo >= 0 && xo < Wo;
+            const float* gp = gi + (in ? ((int64_t)yo * Wo + xo) * CIN : 0);
+            const float* wt = wp + (int64_t)(ky * 5 + kx) * CIN * Cout + cg;
+#pragma unroll
+            for (int c = 0; c < CIN; c += 4) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(gp + c);
+                if (!in) v = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+                    for (int k = 0; k < CT; ++k) acc[k] = fmaf(v[k4], wt[(int64_t)(c + k4) * Cout + k], acc[k]);
+            }
+        }
+    }
+    if (live) {
+        float* o = out + (((int64_t)n * Hi + y) * Wi + x) * Cout + cg;
+#pragma unroll
+        for (int k = 0; k < CT; k += 4) *reinterpret_cast<f32x4*>(o + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+    }
+}
+
+extern "C" int mvsnerf_conv2d_dgrad_k5s2(const float* g, int Cin, int N, int Ho, int Wo, const float* wpacked, int Cout,
+                                         int Hi, int Wi, float* out, void* stream)
+{
+    if (!g || !wpacked || !out || N < 1 || Ho < 1 || Wo < 1 || Hi < 1 || Wi < 1) return MVSNERF_EINVAL;
+    if ((Hi - 1) / 2 + 1 != Ho || (Wi - 1) / 2 + 1 != Wo) return MVSNERF_EINVAL;
+    if (!mvs_aligned16(g) || !mvs_aligned16(out)) return MVSNERF_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned tiles = (unsigned)((((Wi + 1) / 2 + 15) / 16) * (((Hi + 1) / 2 + 15) / 16) * N);
+    switch (Cin * 100 + Cout) {
+        case 16 * 100 + 8:  conv2d_dgrad_k5s2_kernel<16, 8><<<dim3(tiles, 1, 4), 256, 0, st>>>(g, Ho, Wo, wpacked, Cout, out, Hi, Wi); break;    // conv1.0
+        case 32 * 100 + 16: conv2d_dgrad_k5s2_kernel<32, 16><<<dim3(tiles, 1, 4), 256, 0, st>>>(g, Ho, Wo, wpacked, Cout, out, Hi, Wi); break;   // conv2.0
+        default: return MVSNERF_EUNSUPPORTED;
+    }
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// Weight gradient: gW[a][b][tap] = sum_o G[o][a] * X[o*S - P + tap][b]   (G raw output gradient on the (Ho,Wo) grid,
+// X the lazily-activated input).  Same organisation as the 3-D kernel: a thread owns NP (tap,b) pairs x 8 channels of
+// `a`, a workgroup walks a contiguous pixel range (G is wave-uniform => scalar loads), partials are reduced afterwards.
+template <int NP, int S, int K>
+__global__ __launch_bounds__(256) void conv2d_wgrad_kernel(const float* __restrict__ g, int A, ActSrc x1, int B, int ldx,
+                                                           int N, int Ho, int Wo, int Hi, int Wi, float* __restrict__ partial)
+{
+    constexpr int A_T = 8, P = K / 2, U = 4;
+    const int a0 = blockIdx.y * A_T;
+    const int npix = N * Ho * Wo;
+    const int per = (npix + gridDim.x - 1) / gridDim.x;
+    const int n0 = blockIdx.x * per, n1 = n0 + per < npix ? n0 + per : npix;
+    int dy[NP], dx[NP], bch[NP];
+    bool valid[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int p = threadIdx.x + j * blockDim.x;
+        valid[j] = p < K * K * B;
+        const int tap = valid[j] ? p / B : 0;
+        bch[j] = valid[j] ? p - tap * B : 0;
+        dy[j] = tap / K - P; dx[j] = tap % K - P;
+    }
+    float acc[NP][A_T];
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+#pragma unroll
+        for (int a = 0; a < A_T; ++a) acc[j][a] = 0.f;
+    int cx = 0, cy = 0, cn = 0;
+    if (n0 < n1) { cx = n0 % Wo; cy = (n0 / Wo) % Ho; cn = n0 / (Wo * Ho); }
+    for (int ob = n0; ob < n1; ob += U) {
+        float gv[U][A_T], xv[U][NP];
+#pragma unroll
+        for (int u_ = 0; u_ < U; ++u_) {
+            const bool live = ob + u_ < n1;
+            const int o = live ? ob + u_ : n1 - 1;
+            const int ox = cx, oy = cy, on = cn;
+            if (live) { if (++cx == Wo) { cx = 0; if (++cy == Ho) { cy = 0; ++cn; } } }
+#pragma unroll
+            for (int a = 0; a < A_T; ++a) gv[u_][a] = live ? g[(int64_t)o * A + a0 + a] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const int yi = oy * S + dy[j], xi = ox * S + dx[j];
+                const bool in = valid[j] && (unsigned)yi < (unsigned)Hi && (unsigned)xi < (unsigned)Wi;
+                const int64_t idx = in ? (((int64_t)on * Hi + yi) * Wi + xi) * ldx + bch[j] : 0;
+                const float t = act1(x1, idx, bch[j]);
+                xv[u_][j] = in ? t : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u_ = 0; u_ < U; ++u_)
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+#pragma unroll
+                for (int a = 0; a < A_T; ++a) acc[j][a] = fmaf(gv[u_][a], xv[u_][j], acc[j][a]);
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+        if (valid[j]) {
+            const int tap = (dy[j] + P) * K + (dx[j] + P);
+#pragma unroll
+            for (int a = 0; a < A_T; ++a)
+                partial[((int64_t)blockIdx.x * A + a0 + a) * B * (K * K) + (int64_t)bch[j] * (K * K) + tap] = acc[j][a];
+        }
+}
+
+// >= 64 pixels per workgroup, <= 4096 workgroups over all channel groups (bounds the partials to 32768*B*k*k floats)
+static int wgrad2d_nwg(int64_t npix, int A)
+{
+    const int64_t cap = 4096 / (A / 8 > 0 ? A / 8 : 1), want = npix / 64;
+    return (int)(want < 1 ? 1 : (want < cap ? want : cap));
+}
+
+extern "C" size_t mvsnerf_conv2d_wgrad_workspace_floats(int A, int B, int ksize)
+{
+    return (size_t)(4096 / (A / 8 > 0 ? A / 8 : 1) + MVS_RED_SLICES) * A * B * ksize * ksize;
+}
+
+extern "C" int mvsnerf_conv2d_wgrad(const float* g, int A, const float* x, const float* x_scale, const float* x_shift, int B, int ldx,
+                                    int N, int Ho, int Wo, int Hi, int Wi, int ksize, int stride,
+                                    float* gw, float* workspace, void* stream)
+{
+    if (!g || !x || !gw || !workspace || A < 8 || (A & 7) || B < 1 || ldx < B || N < 1) return MVSNERF_EINVAL;
+    if (((x_scale == nullptr) != (x_shift == nullptr))) return MVSNERF_EINVAL;
+    const ActSrc X1{x, x_scale, x_shift};
+    const int64_t npix = (int64_t)N * Ho * Wo;
+    if (npix > 0x7fffffff) return MVSNERF_EUNSUPPORTED;
+    const int nwg = wgrad2d_nwg(npix, A);
+    const int pairs = ksize * ksize * B;
+    const int threads = pairs >= 256 ? 256 : (pairs + 63) / 64 * 64;      // waves without any (tap,b) pair are not launched
+    const int np = (pairs + threads - 1) / threads;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(nwg, A / 8);
+#define MVS_WG2(NP_, S_, K_) conv2d_wgrad_kernel<NP_, S_, K_><<<grid, threads, 0, st>>>(g, A, X1, B, ldx, N, Ho, Wo, Hi, Wi, workspace)
+    switch ((np * 10 + stride) * 10 + ksize) {
+        case (1 * 10 + 1) * 10 + 3: MVS_WG2(1, 1, 3); break;     // 9B <= 256: B = 3, 8, 16
+        case (2 * 10 + 1) * 10 + 3: MVS_WG2(2, 1, 3); break;     // B = 32
+        case (1 * 10 + 2) * 10 + 5: MVS_WG2(1, 2, 5); break;     // conv1.0 (25*8 = 200)
+        case (2 * 10 + 2) * 10 + 5: MVS_WG2(2, 2, 5); break;     // conv2.0 (25*16 = 400)
+        case (1 * 10 + 1) * 10 + 1: MVS_WG2(1, 1, 1); break;     // toplayer
+        default: return MVSNERF_EUNSUPPORTED;
+    }
+#undef MVS_WG2
+    MVS_LAUNCH_CHECK();
+    const int64_t n_out = (int64_t)A * B * ksize * ksize;
+    mvs_partial_sum(workspace, nwg, n_out, workspace + (size_t)(4096 / (A / 8)) * n_out, gw, st);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// per-channel sum over n rows of a dense [n][C] tensor (C <= 64, 256 % C == 0): the bias gradient of `toplayer`
+__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ g, int64_t n, int C, float* __restrict__ partial)
+{
+    __shared__ float red[256];
+    const int c = threadIdx.x % C, r = threadIdx.x / C, rows = 256 / C;
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * rows + r; i < n; i += (int64_t)gridDim.x * rows) s += g[i * C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float t = 0.f;
+        for (int k = 0; k < rows; ++k) t += red[k * C + threadIdx.x];
+        partial[(int64_t)blockIdx.x * C + threadIdx.x] = t;
+    }
+}
+
+extern "C" size_t mvsnerf_channel_sum_workspace_floats(int C) { return (size_t)(256 + MVS_RED_SLICES) * C; }
+
+extern "C" int mvsnerf_channel_sum(const float* g, int64_t n, int C, float* out, float* workspace, void* stream)
+{
+    if (!g || !out || !workspace || n < 1 || C < 1 || C > 64 || (256 % C)) return MVSNERF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = 256 / C;
+    int nb = (int)((n + rows - 1) / rows);
+    if (nb > 256) nb = 256;
+    channel_sum_partial_kernel<<<nb, 256, 0, st>>>(g, n, C, workspace);
+    MVS_LAUNCH_CHECK();
+    mvs_partial_sum(workspace, nb, C, workspace + (size_t)256 * C, out, st);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}

@@ -41,20 +41,89 @@ class InPlaceABN(nn.Module):
         return F.leaky_relu(y, self.activation_param)
 
 
+class _PackedConv2d:
+    """Caches the [k*k][cin_pad][cout] re-layouts of a Conv2d weight (re-packed when it changes).
+    mode 'fwd': the layer itself; mode 'dgrad': the convolution computing its data gradient (channel roles swapped,
+    taps mirrored for stride 1; the stride-2 layers use the gather-form kernel with un-mirrored taps)."""
+
+    def __init__(self, conv):
+        self.conv, self.cache = conv, {}
+        self.cout, self.cin, self.k = conv.weight.shape[0], conv.weight.shape[1], conv.weight.shape[2]
+        self.cin_pad = (self.cin + 3) // 4 * 4
+
+    def get(self, mode="fwd"):
+        w = self.conv.weight
+        key = (w.data_ptr(), w._version)
+        hit = self.cache.get(mode)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        kk = self.k * self.k
+        if mode == "fwd":
+            args = (self.cin, self.cout, self.cin_pad, self.cout, kk, self.cin * kk, self.k, 0)
+        else:
+            args = (self.cout, self.cin, self.cout, self.cin_pad, self.cin * kk, kk, self.k, 1 if self.conv.stride[0] == 1 else 0)
+        buf = torch.empty(kk * args[2] * args[3], device=w.device, dtype=torch.float32)
+        check(_lib.lib().mvsnerf_conv2d_pack_weights(dev_f32(w.detach().contiguous(), "conv weight"), *args, buf.data_ptr(), stream_ptr()),
+              "conv2d_pack_weights")
+        self.cache[mode] = (key, buf)
+        return buf
+
+
+def _conv2d(src, dims_in, cin_ld, wbuf, cin_k, cout_k, ksize, stride, bias=None):
+    """2-D convolution kernel launch (padding k//2): input (N,H,W) with channel stride cin_ld -> raw (N,Ho,Wo,cout_k)."""
+    N, H, W, _ = dims_in
+    P = ksize // 2
+    Ho, Wo = (H + 2 * P - ksize) // stride + 1, (W + 2 * P - ksize) // stride + 1
+    out = torch.empty((N, Ho, Wo, cout_k), device=wbuf.device, dtype=torch.float32)
+    check(_lib.lib().mvsnerf_conv2d_fwd(*_ptrs(src), cin_k, cin_ld, N, H, W, wbuf.data_ptr(), 0 if bias is None else bias.data_ptr(), cout_k,
+                                        ksize, stride, out.data_ptr(), stream_ptr()), "conv2d_fwd")
+    return out
+
+
 class ConvBnReLU(nn.Module):
-    """reference models.py:661-672 (2-D)."""
+    """reference models.py:661-672 (2-D): Conv2d(bias=False) + InPlaceABN, on the HIP kernels of csrc/featnet.hip."""
 
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1, norm_act=InPlaceABN):
         super().__init__()
+        if (kernel_size, stride, pad) not in ((3, 1, 1), (5, 2, 2)):
+            raise NotImplementedError("ConvBnReLU: the HIP kernels cover (k3,s1,p1) and (k5,s2,p2) - all FeatureNet uses")
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
         self.bn = norm_act(out_channels)
+        self.k, self.stride = kernel_size, stride
+        self._packed = _PackedConv2d(self.conv)
+
+    def lazy(self, src, dims_in, cin_ld):
+        pk = self._packed
+        raw = _conv2d(src, dims_in, cin_ld, pk.get(), pk.cin_pad, pk.cout, self.k, self.stride)
+        N, H, W, C = raw.shape
+        scale, shift, mean, invstd = _abn_stats(raw, N * H * W, self.bn, update_running=self.bn.training)
+        return _Lazy(raw, scale, shift, (N, H, W, C), mean, invstd)
 
     def forward(self, x):
-        return self.bn(self.conv(x))
+        """Stand-alone call on (N,Cin,H,W) -> activated (N,Cout,H',W') (channel-last memory)."""
+        ops._need_no_grad(x, *self.parameters(), op="ConvBnReLU")
+        buf, ld = _images_channel_last(x, self._packed.cin_pad)
+        N, _, H, W = x.shape
+        return _apply_add(self.lazy(buf, (N, H, W, ld), ld)).permute(0, 3, 1, 2)
+
+
+def _images_channel_last(x, cin_pad):
+    """(N,C,H,W) -> ([N][H][W][ld] buffer, ld).  Zero-copy for permuted channel-last views (what this module emits)."""
+    N, C, H, W = x.shape
+    st = x.stride()
+    ld = st[3]
+    if (x.is_cuda and x.dtype == torch.float32 and st[1] == 1 and ld >= cin_pad and ld % 4 == 0 and st[2] == W * ld and st[0] == H * W * ld
+            and x.storage_offset() % 4 == 0):
+        return torch.as_strided(x, (N, H, W, ld), (H * W * ld, W * ld, ld, 1)), ld
+    dst = torch.empty((N, H, W, cin_pad), device=x.device, dtype=torch.float32)
+    check(_lib.lib().mvsnerf_nchw_to_nhwc(dev_f32(x.detach().contiguous(), "x"), dst.data_ptr(), N, C, H, W, cin_pad, stream_ptr()), "nchw_to_nhwc")
+    return dst, cin_pad
 
 
 class FeatureNet(nn.Module):
-    """reference models.py:688-722.  (B,3,H,W) -> (B,32,H/4,W/4)."""
+    """reference models.py:688-722.  (N,3,H,W) -> (N,32,H/4,W/4) (channel-last memory behind an NCHW view).
+    Eight ConvBnReLU layers with lazily-applied InPlaceABN (statistics over all N images, as the reference's B*V batch)
+    and the biased 1x1 `toplayer`, all on HIP kernels; differentiable through _FeatureNetFunction."""
 
     def __init__(self, norm_act=InPlaceABN):
         super().__init__()
@@ -64,9 +133,101 @@ class FeatureNet(nn.Module):
         self.conv2 = nn.Sequential(ConvBnReLU(16, 32, 5, 2, 2, norm_act=norm_act), ConvBnReLU(32, 32, 3, 1, 1, norm_act=norm_act),
                                    ConvBnReLU(32, 32, 3, 1, 1, norm_act=norm_act))
         self.toplayer = nn.Conv2d(32, 32, 1)
+        self._top_packed = _PackedConv2d(self.toplayer)
+
+    def _layers(self):
+        return [*self.conv0, *self.conv1, *self.conv2]
+
+    def _run(self, x):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError(f"FeatureNet: expected (N,3,H,W) images, got {tuple(x.shape)}")
+        N, _, H, W = x.shape
+        img, ld = _images_channel_last(x, 4)
+        src, dims = img, (N, H, W, ld)
+        lz = []
+        for lay in self._layers():
+            z = lay.lazy(src, dims, ld)
+            lz.append(z)
+            src, dims, ld = z, z.dims, z.dims[3]
+        top = _conv2d(src, dims, ld, self._top_packed.get(), 32, 32, 1, 1, bias=dev_f32_tensor(self.toplayer.bias))
+        return (img, img.shape[3]), lz, top
 
     def forward(self, x):
-        return self.toplayer(self.conv2(self.conv1(self.conv0(x))))
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            params = []
+            for lay in self._layers():
+                params += [lay.conv.weight, lay.bn.weight, lay.bn.bias]
+            return _FeatureNetFunction.apply(x, self, *params, self.toplayer.weight, self.toplayer.bias)
+        _, _, top = self._run(x)
+        return top.permute(0, 3, 1, 2)
+
+
+def dev_f32_tensor(t):
+    t = t.detach()
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise RuntimeError("expected a contiguous fp32 device tensor")
+    return t
+
+
+def _wgrad2d(gx, A, X, B, ldx, g_dims, x_dims, ksize, stride, shape):
+    """gW[a][b][tap] = sum_o G[o][a] X[o*stride - k//2 + tap][b]  (mvsnerf_conv2d_wgrad)."""
+    lib = _lib.lib()
+    gw = torch.empty(shape, device=gx.device, dtype=torch.float32)
+    ws = torch.empty(lib.mvsnerf_conv2d_wgrad_workspace_floats(A, B, ksize), device=gx.device, dtype=torch.float32)
+    check(lib.mvsnerf_conv2d_wgrad(gx.data_ptr(), A, *_ptrs(X), B, ldx, g_dims[0], g_dims[1], g_dims[2], x_dims[1], x_dims[2], ksize, stride,
+                                   gw.data_ptr(), ws.data_ptr(), stream_ptr()), "conv2d_wgrad")
+    return gw
+
+
+class _FeatureNetFunction(torch.autograd.Function):
+    """FeatureNet with gradients to its 8 conv weights, 8 ABN weight/bias pairs and the toplayer weight/bias
+    (the input images carry no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, net, *params):
+        (img, ld), lz, top = net._run(x)
+        ctx.net, ctx.img, ctx.ld, ctx.lz = net, img, ld, lz
+        return top.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        net, lz, lib = ctx.net, ctx.lz, _lib.lib()
+        L = net._layers()
+        g = g_out.permute(0, 2, 3, 1)
+        g = g if g.is_contiguous() else g.contiguous()                 # (N,h,w,32) grad of the toplayer output
+        N, h, w, _ = g.shape
+        last = lz[-1]
+        # toplayer: bias, weight (against the activated conv2.2 output), data gradient (1x1 conv with W^T)
+        gb = torch.empty(32, device=g.device, dtype=torch.float32)
+        ws = torch.empty(lib.mvsnerf_channel_sum_workspace_floats(32), device=g.device, dtype=torch.float32)
+        check(lib.mvsnerf_channel_sum(g.data_ptr(), N * h * w, 32, gb.data_ptr(), ws.data_ptr(), stream_ptr()), "channel_sum")
+        gw_top = _wgrad2d(g, 32, last, 32, 32, (N, h, w), last.dims, 1, 1, tuple(net.toplayer.weight.shape))
+        g_act = _conv2d(g, (N, h, w, 32), 32, net._top_packed.get("dgrad"), 32, 32, 1, 1)
+        grads = [None] * len(L)
+        for i in range(len(L) - 1, -1, -1):
+            lay, out_lz = L[i], lz[i]
+            pk = lay._packed
+            gx, gbw, gbb = _abn_bwd(out_lz, lay.bn, g_act)
+            if i > 0:
+                xin, x_dims, x_ld = lz[i - 1], lz[i - 1].dims, lz[i - 1].dims[3]
+            else:
+                xin, x_dims, x_ld = ctx.img, tuple(ctx.img.shape), ctx.ld
+            gw = _wgrad2d(gx, pk.cout, xin, pk.cin, x_ld, out_lz.dims[:3], x_dims, lay.k, lay.stride, tuple(lay.conv.weight.shape))
+            grads[i] = (gw, gbw, gbb)
+            if i == 0:
+                break
+            if lay.stride == 1:
+                g_act = _conv2d(gx, out_lz.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin, lay.k, 1)
+            else:
+                Nn, Ho, Wo, _ = out_lz.dims
+                Hi, Wi = x_dims[1], x_dims[2]
+                g_act = torch.empty((Nn, Hi, Wi, pk.cin), device=g.device, dtype=torch.float32)
+                check(lib.mvsnerf_conv2d_dgrad_k5s2(gx.data_ptr(), pk.cout, Nn, Ho, Wo, pk.get("dgrad").data_ptr(), pk.cin, Hi, Wi,
+                                                    g_act.data_ptr(), stream_ptr()), "conv2d_dgrad_k5s2")
+        out = [None, None]
+        for gw, gbw, gbb in grads:
+            out += [gw, gbw, gbb]
+        return tuple(out + [gw_top, gb])
 
 
 # ------------------------------------------------------------------ channel-last plumbing
@@ -141,6 +302,15 @@ def _abn_stats(raw, n_vox, bn, update_running=True):
     C = bn.num_features
     dev = raw.device
     out = torch.empty((4, C), device=dev, dtype=torch.float32)        # scale, shift, mean, invstd
+    if not bn.training:
+        # eval-mode InPlaceABN: running statistics (the reference never leaves .train() for MVSNet -
+        # train_mvs_nerf_pl.py:182 - so this is plumbing on C-element vectors, not a hot path; no backward)
+        with torch.no_grad():
+            out[3] = torch.rsqrt(bn.running_var + bn.eps)
+            out[2] = bn.running_mean
+            out[0] = (bn.weight.abs() + bn.eps) * out[3]
+            out[1] = bn.bias - bn.running_mean * out[0]
+        return out[0], out[1], out[2], out[3]
     ws = torch.empty(_lib.lib().mvsnerf_abn_workspace_floats(C), device=dev, dtype=torch.float32)
     rm = bn.running_mean.data_ptr() if update_running else 0
     rv = bn.running_var.data_ptr() if update_running else 0
@@ -299,6 +469,9 @@ def _grad_cl(g, C):
 def _abn_bwd(lz, bn, g1, g2=None):
     """Train-mode InPlaceABN backward of one lazy layer.  g1 (+g2): grads w.r.t. its ACTIVATED output (channel-last).
     Returns (grad w.r.t. the raw conv output, d bn.weight, d bn.bias)."""
+    if not bn.training:
+        raise RuntimeError("InPlaceABN backward is implemented for train-mode (batch-statistics) layers only - the reference "
+                           "keeps MVSNet in .train() (train_mvs_nerf_pl.py:182)")
     D, H, W, C = lz.dims
     dev = lz.x.device
     gx = torch.empty((D, H, W, C), device=dev, dtype=torch.float32)
@@ -409,8 +582,9 @@ def _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img):
     lib = _lib.lib()
     D = depth_values.shape[1]
     Hp, Wp = H + 2 * pad, W + 2 * pad
-    feats_cl = torch.empty((V, H, W, C), device=dev, dtype=torch.float32)
-    check(lib.mvsnerf_nchw_to_nhwc(dev_f32(feats[0].detach().contiguous(), "feats"), feats_cl.data_ptr(), V, C, H, W, C, stream_ptr()), "nchw_to_nhwc")
+    feats_cl, f_ld = _images_channel_last(feats[0].detach(), C)       # zero-copy for FeatureNet's channel-last output
+    if f_ld != C:
+        feats_cl = feats_cl[..., :C].contiguous()
     imgs_cl_p = 0
     if with_img:
         Hi, Wi = imgs.shape[-2:]
