@@ -301,7 +301,7 @@ def main():
             losses = system.fit_steps([batch] * 5, opt)
             torch.cuda.synchronize(); tdt = (time.perf_counter() - t0) / 5
             extras["train_step"] = {"ms": round(tdt * 1e3, 2), "rays_per_s": round(N_RAYS / tdt, 1), "loss_last": round(losses[-1], 5),
-                                    "note": "MVSSystem.training_step fwd+bwd (HIP) + FeatureNet (torch-ROCm) + Adam, 1024x128, fp32"}
+                                    "note": "MVSSystem.training_step fwd+bwd (HIP) + Adam (torch), encoder incl. FeatureNet on HIP, 1024x128, fp32"}
         if not a.no_extras and world == 1:
             # (iii) opt-in bf16-MFMA MLP (BASELINE configs 3/4); NOT the headline: results differ from fp32 at the 1e-2 level
             ops.set_mlp_precision("bf16")

@@ -187,6 +187,15 @@ int mvsnerf_color_sample_fwd(const float* imgs, int V, int H, int W,
 int mvsnerf_dir_feature_fwd(const float* rays_dir, const float* w2c_ref, int64_t N, int normalize,
                             float* dirs_out, void* stream);
 
+/* gen_pts_feats + gen_dir_feature (renderer.py:111-136) in one launch: the three lookups above for N rays x S samples.
+ * imgs_nhwc4[V][IH][IW][4]: the un-normalised source images re-laid channel-last (rgb + one pad float; mvsnerf_nchw_to_nhwc
+ * with Cpad = 4) so that a bilinear tap is one 16-byte load.  feat[p*feat_stride + {0..7 | 8+4v..8+4v+3}] = volume features |
+ * (r,g,b,mask) of view v; dirs_out[N][3] (may be NULL) = normalised rays_dir rotated into view 0's frame (w2c[0]).
+ * Results are bit-identical to volume_sample_fwd / color_sample_fwd(with_mask=1) / dir_feature_fwd(normalize=1). */
+int mvsnerf_gather_fwd(const float* vol, int D, int H, int W, const float* imgs_nhwc4, int V, int IH, int IW,
+                       const float* w2c, const float* K, const float* pts, const float* ndc, int64_t N, int S,
+                       const float* rays_dir, float* feat, int feat_stride, float* dirs_out, void* stream);
+
 /* Stand-alone positional encoding, Embedder.embed (models.py:47-51): x[P][d] ->
  * out[P][d*(1+2L)] = [x | sin(x_c*2^f), f-major | cos(...)].  The MLP kernel below embeds internally;
  * this exists for callers that use `embed_fn` on its own. */
@@ -284,6 +293,8 @@ typedef struct {
     float* raw;                             /* [N][S][4] out */
     float* rgb_map; float* disp; float* acc; float* weights; float* depth; float* alpha;  /* outs, may be NULL */
     const void* packed_mlp_bf16;            /* NULL: fp32-MFMA MLP (default); else the bf16-MFMA variant is used (ABI v2) */
+    const float* imgs_nhwc4;                /* NULL: three gather launches from `imgs` (NCHW); else [V][IH][IW][4] copies of the
+                                               same images and ONE fused gather launch (mvsnerf_gather_fwd) (ABI v3) */
 } mvsnerf_raymarch_args;
 int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream);
 

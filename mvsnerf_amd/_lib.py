@@ -28,7 +28,7 @@ class RaymarchArgs(ctypes.Structure):
         ("N", _c_l), ("S", _c_i), ("white_bkgd", _c_i),
         ("dirs_tmp", _c_fp), ("input_feat", _c_fp), ("raw", _c_fp),
         ("rgb_map", _c_fp), ("disp", _c_fp), ("acc", _c_fp), ("weights", _c_fp), ("depth", _c_fp), ("alpha", _c_fp),
-        ("packed_mlp_bf16", _c_fp),
+        ("packed_mlp_bf16", _c_fp), ("imgs_nhwc4", _c_fp),
     ]
 
 
@@ -60,6 +60,7 @@ SIGNATURES = {
     "mvsnerf_conv2d_wgrad": (_c_i, [_c_fp, _c_i] + [_c_fp] * 3 + [_c_i] * 9 + [_c_fp, _c_fp, _c_fp]),
     "mvsnerf_channel_sum_workspace_floats": (ctypes.c_size_t, [_c_i]),
     "mvsnerf_channel_sum": (_c_i, [_c_fp, _c_l, _c_i, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_gather_fwd": (_c_i, [_c_fp] + [_c_i] * 3 + [_c_fp] + [_c_i] * 3 + [_c_fp] * 4 + [_c_l, _c_i, _c_fp, _c_fp, _c_i, _c_fp, _c_fp]),
     "mvsnerf_abn_apply_add": (_c_i, [_c_fp] * 6 + [_c_l, _c_i, _c_fp, _c_fp]),
     "mvsnerf_raygen_fwd": (_c_i, [_c_fp, _c_fp, _c_l, _c_i, _c_i] + [_c_fp] * 6 + [_c_i, _c_i, _c_fp, _c_l, _c_i] + [_c_fp] * 6),
     "mvsnerf_volume_sample_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_l, _c_fp, _c_i, _c_fp]),

@@ -105,6 +105,71 @@ extern "C" int mvsnerf_volume_sample_fwd(const float* vol, int D, int H, int W, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Shared arithmetic of the colour lookup and the direction feature.  Written with explicit fmaf/mul/add and fp
+// contraction OFF so that the stand-alone kernels and the fused gather kernel produce the same bits whatever the
+// surrounding code looks like to the optimiser.
+// ---------------------------------------------------------------------------------------------
+struct ColorTap { float gx, gy, wnw, wne, wsw, wse; int x0, y0; bool x1in, y1in; };
+
+__device__ __forceinline__ ColorTap color_project(float x, float y, float z, const float* __restrict__ M, const float* __restrict__ K, int W, int H)
+{
+#pragma clang fp contract(off)
+    ColorTap t;
+    // get_ndc_coordinate utils.py:124: p_cam = pts @ R^T + T   (k-ordered fma chain like sgemm)
+    const float cx = fmaf(z, M[2],  fmaf(y, M[1], x * M[0]))  + M[3];
+    const float cy = fmaf(z, M[6],  fmaf(y, M[5], x * M[4]))  + M[7];
+    const float cz = fmaf(z, M[10], fmaf(y, M[9], x * M[8]))  + M[11];
+    // :128  q = p_cam @ K^T
+    const float qx = fmaf(cz, K[2], fmaf(cy, K[1], cx * K[0]));
+    const float qy = fmaf(cz, K[5], fmaf(cy, K[4], cx * K[3]));
+    const float qz = fmaf(cz, K[8], fmaf(cy, K[7], cx * K[6]));
+    // :129  /z, / inv_scale ; utils.py:317  grid = xy*2-1
+    t.gx = ((qx / qz + 0.0f) / (float)(W - 1)) * 2.0f - 1.0f;
+    t.gy = ((qy / qz + 0.0f) / (float)(H - 1)) * 2.0f - 1.0f;
+    // grid_sample bilinear, border padding, align_corners=True
+    float ix = ((t.gx + 1.0f) / 2.0f) * (float)(W - 1);
+    float iy = ((t.gy + 1.0f) / 2.0f) * (float)(H - 1);
+    ix = fminf(fmaxf(ix, 0.0f), (float)(W - 1));   // clip_coordinates (NaN -> 0 like ATen's min/max order)
+    iy = fminf(fmaxf(iy, 0.0f), (float)(H - 1));
+    if (!(ix == ix)) ix = 0.0f;
+    if (!(iy == iy)) iy = 0.0f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    t.x0 = (int)fx; t.y0 = (int)fy;
+    const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
+    t.x1in = t.x0 + 1 <= W - 1; t.y1in = t.y0 + 1 <= H - 1;
+    t.wnw = wx0 * wy0; t.wne = wx1 * wy0; t.wsw = wx0 * wy1; t.wse = wx1 * wy1;
+    return t;
+}
+
+__device__ __forceinline__ float color_blend(const ColorTap& t, float nw, float ne, float sw, float se)
+{
+#pragma clang fp contract(off)
+    float acc = nw * t.wnw;
+    if (t.x1in) acc = fmaf(ne, t.wne, acc);
+    if (t.y1in) acc = fmaf(sw, t.wsw, acc);
+    if (t.x1in && t.y1in) acc = fmaf(se, t.wse, acc);
+    return acc;
+}
+
+__device__ __forceinline__ float color_mask(const ColorTap& t) { return (t.gx > -1.0f && t.gx < 1.0f && t.gy > -1.0f && t.gy < 1.0f) ? 1.0f : 0.0f; }
+
+// dirs = normalise(d) @ R^T  (renderer.py:142-147, 111-122); R == null: no rotation
+__device__ __forceinline__ void dir_feature_of(const float* __restrict__ d3, const float* __restrict__ R, int normalize, float* __restrict__ o3)
+{
+#pragma clang fp contract(off)
+    const float dx = d3[0], dy = d3[1], dz = d3[2];
+    const float nrm = normalize ? sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx))) : 1.0f;   // torch.norm
+    const float ux = dx / nrm, uy = dy / nrm, uz = dz / nrm;
+    if (R) {
+        o3[0] = fmaf(uz, R[2],  fmaf(uy, R[1], ux * R[0]));
+        o3[1] = fmaf(uz, R[6],  fmaf(uy, R[5], ux * R[4]));
+        o3[2] = fmaf(uz, R[10], fmaf(uy, R[9], ux * R[8]));
+    } else {
+        o3[0] = ux; o3[1] = uy; o3[2] = uz;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Per-view colour lookup (utils.py:300-332).  One thread per (sample, view).  Camera matrices are
 // wave-uniform per view only if V divides the wave, so they are read through the vector path from a
 // 21-float-per-view table (L1/L2 resident).
@@ -118,46 +183,16 @@ __global__ __launch_bounds__(256) void color_sample_kernel(
     if (tid >= P * V) return;
     const int64_t p = tid / V;
     const int v = (int)(tid - p * V);
-    const float x = pts[p * 3 + 0], y = pts[p * 3 + 1], z = pts[p * 3 + 2];
-    const float* M = w2c + v * 16;
-    const float* K = Kmat + v * 9;
-    // get_ndc_coordinate utils.py:124: p_cam = pts @ R^T + T   (k-ordered fma chain like sgemm)
-    const float cx = fmaf(z, M[2],  fmaf(y, M[1], x * M[0]))  + M[3];
-    const float cy = fmaf(z, M[6],  fmaf(y, M[5], x * M[4]))  + M[7];
-    const float cz = fmaf(z, M[10], fmaf(y, M[9], x * M[8]))  + M[11];
-    // :128  q = p_cam @ K^T
-    const float qx = fmaf(cz, K[2], fmaf(cy, K[1], cx * K[0]));
-    const float qy = fmaf(cz, K[5], fmaf(cy, K[4], cx * K[3]));
-    const float qz = fmaf(cz, K[8], fmaf(cy, K[7], cx * K[6]));
-    // :129  /z, / inv_scale ; utils.py:317  grid = xy*2-1
-    const float gx = ((qx / qz + 0.0f) / (float)(W - 1)) * 2.0f - 1.0f;
-    const float gy = ((qy / qz + 0.0f) / (float)(H - 1)) * 2.0f - 1.0f;
-    // grid_sample bilinear, border padding, align_corners=True
-    float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
-    float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
-    ix = fminf(fmaxf(ix, 0.0f), (float)(W - 1));   // clip_coordinates (NaN -> 0 like ATen's min/max order)
-    iy = fminf(fmaxf(iy, 0.0f), (float)(H - 1));
-    if (!(ix == ix)) ix = 0.0f;
-    if (!(iy == iy)) iy = 0.0f;
-    const float fx = floorf(ix), fy = floorf(iy);
-    const int x0 = (int)fx, y0 = (int)fy;
-    const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
-    const bool x1in = x0 + 1 <= W - 1, y1in = y0 + 1 <= H - 1;
-    const float wnw = wx0 * wy0, wne = wx1 * wy0, wsw = wx0 * wy1, wse = wx1 * wy1;
+    const ColorTap t = color_project(pts[p * 3 + 0], pts[p * 3 + 1], pts[p * 3 + 2], w2c + v * 16, Kmat + v * 9, W, H);
     const int Cv = 3 + (with_mask ? 1 : 0);
     float* o = out + p * out_stride + v * Cv;
     const float* img = imgs + (int64_t)v * 3 * H * W;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float* pl = img + (int64_t)c * H * W;
-        const int64_t r0 = (int64_t)y0 * W + x0;
-        float acc = pl[r0] * wnw;
-        if (x1in) acc += pl[r0 + 1] * wne;
-        if (y1in) acc += pl[r0 + W] * wsw;
-        if (x1in && y1in) acc += pl[r0 + W + 1] * wse;
-        o[c] = acc;
+        const float* pl = img + (int64_t)c * H * W + (int64_t)t.y0 * W + t.x0;
+        o[c] = color_blend(t, pl[0], t.x1in ? pl[1] : 0.f, t.y1in ? pl[W] : 0.f, (t.x1in && t.y1in) ? pl[W + 1] : 0.f);
     }
-    if (with_mask) o[3] = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;
+    if (with_mask) o[3] = color_mask(t);
 }
 
 extern "C" int mvsnerf_color_sample_fwd(const float* imgs, int V, int H, int W, const float* w2c, const float* K,
@@ -178,16 +213,7 @@ __global__ void dir_feature_kernel(const float* __restrict__ rays_dir, const flo
 {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    const float dx = rays_dir[n * 3], dy = rays_dir[n * 3 + 1], dz = rays_dir[n * 3 + 2];
-    const float nrm = normalize ? sqrtf(dx * dx + dy * dy + dz * dz) : 1.0f;   // torch.norm
-    const float ux = dx / nrm, uy = dy / nrm, uz = dz / nrm;
-    if (w2c) {
-        out[n * 3 + 0] = fmaf(uz, w2c[2],  fmaf(uy, w2c[1], ux * w2c[0]));
-        out[n * 3 + 1] = fmaf(uz, w2c[6],  fmaf(uy, w2c[5], ux * w2c[4]));
-        out[n * 3 + 2] = fmaf(uz, w2c[10], fmaf(uy, w2c[9], ux * w2c[8]));
-    } else {
-        out[n * 3 + 0] = ux; out[n * 3 + 1] = uy; out[n * 3 + 2] = uz;
-    }
+    dir_feature_of(rays_dir + n * 3, w2c, normalize, out + n * 3);
 }
 
 extern "C" int mvsnerf_dir_feature_fwd(const float* rays_dir, const float* w2c_ref, int64_t N, int normalize, float* dirs_out, void* stream)
@@ -195,6 +221,104 @@ extern "C" int mvsnerf_dir_feature_fwd(const float* rays_dir, const float* w2c_r
     if (!rays_dir || !dirs_out || N < 0) return MVSNERF_EINVAL;
     if (N == 0) return MVSNERF_OK;
     dir_feature_kernel<<<mvs_cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(rays_dir, w2c_ref, N, normalize, dirs_out);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// gen_pts_feats + gen_dir_feature in ONE launch (renderer.py:111-136): the three gathers above are each a few
+// microseconds of exposed memory latency, so one kernel that has all of a sample's loads in flight at once costs
+// about as much as the slowest of them.  Same lane quad per sample as the trilinear kernel: lane q folds its share of
+// the 8 volume corners, lanes q < V additionally project the sample into source view q (q, q+4 for V > 4) and fetch
+// the 4 bilinear taps as 16-byte pixels from channel-last images img[v][y][x][4], and the quad of a ray's first
+// sample writes the ray's view-direction feature.  Arithmetic (operation order included) is that of the separate
+// kernels, so results are bit-identical to them.
+// ---------------------------------------------------------------------------------------------
+struct GatherArgs {
+    const float* vol; int D, H, W;
+    const float* img; int V, IH, IW;            // [V][IH][IW][4]
+    const float* w2c; const float* Kmat;        // [V][4][4], [V][3][3]
+    const float* pts; const float* ndc; int64_t P; int S;
+    const float* rays_dir;                      // [P/S][3]
+    float* feat; int feat_stride; float* dirs_out;
+};
+
+__global__ __launch_bounds__(256) void gather_fused_kernel(GatherArgs a)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = (int)(tid & 3);
+    const int64_t p_raw = tid >> 2;
+    const bool live = p_raw < a.P;
+    const int64_t p = live ? p_raw : a.P - 1;
+    const int D = a.D, H = a.H, W = a.W;
+    // ---- trilinear volume lookup (identical to volume_sample_c8_kernel<1>)
+    const int xc = q >> 1, ch = (q & 1) * 4;
+    const float gx = a.ndc[p * 3 + 0] * 2.0f - 1.0f;
+    const float gy = a.ndc[p * 3 + 1] * 2.0f - 1.0f;
+    const float gz = a.ndc[p * 3 + 2] * 2.0f - 1.0f;
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+    const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+    const float iz = ((gz + 1.0f) / 2.0f) * (float)(D - 1);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const float wx = xc ? (ix - fx) : ((fx + 1.0f) - ix);
+    const float cxf = fx + (float)xc;
+    const bool x_in = (cxf >= 0.0f) && (cxf <= (float)(W - 1));
+    f32x4 vv[4];
+    float vw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int zc = k >> 1, yc = k & 1;
+        const float cyf = fy + (float)yc, czf = fz + (float)zc;
+        const bool in = x_in && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
+        vw[k] = wx * (yc ? (iy - fy) : ((fy + 1.0f) - iy)) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
+        vv[k] = f32x4{0, 0, 0, 0};
+        if (in) vv[k] = *reinterpret_cast<const f32x4*>(a.vol + (((((int64_t)czf * H + (int)cyf) * W + (int)cxf) << 3) + ch));
+    }
+    // ---- colour lookup of view q (+4): issue its taps before the volume taps are consumed
+    const float px = a.pts[p * 3 + 0], py = a.pts[p * 3 + 1], pz = a.pts[p * 3 + 2];
+    float* frow = a.feat + p * a.feat_stride;
+    for (int v = q; v < a.V; v += 4) {
+        const int IW = a.IW, IH = a.IH;
+        const ColorTap t = color_project(px, py, pz, a.w2c + v * 16, a.Kmat + v * 9, IW, IH);
+        const float* pl = a.img + (((int64_t)v * IH + t.y0) * IW + t.x0) * 4;
+        const f32x4 z4 = {0, 0, 0, 0};
+        const f32x4 t_nw = *reinterpret_cast<const f32x4*>(pl);
+        const f32x4 t_ne = t.x1in ? *reinterpret_cast<const f32x4*>(pl + 4) : z4;
+        const f32x4 t_sw = t.y1in ? *reinterpret_cast<const f32x4*>(pl + (int64_t)IW * 4) : z4;
+        const f32x4 t_se = (t.x1in && t.y1in) ? *reinterpret_cast<const f32x4*>(pl + (int64_t)IW * 4 + 4) : z4;
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = color_blend(t, t_nw[c], t_ne[c], t_sw[c], t_se[c]);
+        o[3] = color_mask(t);
+        if (live) *reinterpret_cast<f32x4*>(frow + 8 + 4 * v) = o;
+    }
+    // ---- fold the volume taps (same order as the stand-alone kernel: k = 0..3, then the x-corner shuffle)
+    f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc += vv[k] * vw[k];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], 2);
+    if (live && xc == 0) *reinterpret_cast<f32x4*>(frow + ch) = acc;
+    // ---- view-direction feature of the ray (written once, by lane 3 of the ray's first sample)
+    if (live && q == 3 && a.dirs_out && (p % a.S) == 0) {
+        const int64_t n = p / a.S;
+        dir_feature_of(a.rays_dir + n * 3, a.w2c, 1, a.dirs_out + n * 3);      // reference view = view 0
+    }
+}
+
+extern "C" int mvsnerf_gather_fwd(const float* vol, int D, int H, int W, const float* imgs_nhwc4, int V, int IH, int IW,
+                                  const float* w2c, const float* K, const float* pts, const float* ndc, int64_t N, int S,
+                                  const float* rays_dir, float* feat, int feat_stride, float* dirs_out, void* stream)
+{
+    if (!vol || !imgs_nhwc4 || !w2c || !K || !pts || !ndc || !feat || D < 1 || H < 1 || W < 1 || V < 1 || IH < 2 || IW < 2 || N < 0 || S < 1)
+        return MVSNERF_EINVAL;
+    if (dirs_out && !rays_dir) return MVSNERF_EINVAL;
+    if (feat_stride < 8 + 4 * V) return MVSNERF_EINVAL;
+    if ((feat_stride & 3) || !mvs_aligned16(feat) || !mvs_aligned16(vol) || !mvs_aligned16(imgs_nhwc4)) return MVSNERF_EALIGN;
+    if (N == 0) return MVSNERF_OK;
+    const int64_t P = N * S;
+    const GatherArgs a{vol, D, H, W, imgs_nhwc4, V, IH, IW, w2c, K, pts, ndc, P, S, rays_dir, feat, feat_stride, dirs_out};
+    gather_fused_kernel<<<mvs_cdiv(P * 4, 256), 256, 0, (hipStream_t)stream>>>(a);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }

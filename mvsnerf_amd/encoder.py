@@ -1,5 +1,5 @@
-"""Scene encoder (L1a) of the reference's models.py on libmvsnerf_hip.so: FeatureNet (2-D CNN, stays on
-PyTorch-ROCm/MIOpen for now - SURVEY.md 8f rank 1), plane-sweep variance cost volume and CostRegNet.
+"""Scene encoder (L1a) of the reference's models.py on libmvsnerf_hip.so: FeatureNet (2-D CNN, csrc/featnet.hip),
+plane-sweep variance cost volume and CostRegNet (csrc/encoder.hip) - no ATen/MIOpen compute between images and volume.
 
 Same class / sub-module / parameter names as the reference (models.py:661-932) so that
 `network_mvs_state_dict` of a reference checkpoint loads unchanged.
@@ -700,6 +700,6 @@ def bench_encode(rig, dev, pad, iters=3):
             torch.cuda.synchronize(); t2 = time.perf_counter()
             vol = net.cost_reg_2(cost)
             torch.cuda.synchronize(); t3 = time.perf_counter()
-            times = {"feature_net_torch": round((t1 - t0) * 1e3, 3), "planesweep_costvar": round((t2 - t1) * 1e3, 3),
+            times = {"feature_net": round((t1 - t0) * 1e3, 3), "planesweep_costvar": round((t2 - t1) * 1e3, 3),
                      "cost_reg_net": round((t3 - t2) * 1e3, 3), "total": round((t3 - t0) * 1e3, 3)}
     return vol, times

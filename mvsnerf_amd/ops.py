@@ -18,6 +18,7 @@ def _need_no_grad(*tensors, op):
 
 # ------------------------------------------------------------------ volume layout
 _cl_cache = {}
+FUSED_GATHER = True      # ops.raymarch: one gather launch (False: the three stand-alone lookups; same bits)
 
 
 def channels_last_volume(volume_feature):
@@ -48,6 +49,43 @@ def channels_last_volume(volume_feature):
     check(_lib.lib().mvsnerf_ncdhw_to_ndhwc(dev_f32(src, "volume"), dst.data_ptr(), C, D, H, W, stream_ptr()), "ncdhw_to_ndhwc")
     _cl_cache["k"] = (key, st, dst)
     return dst
+
+
+def channels_last_images(imgs):
+    """(V,3,H,W) un-normalised source images -> (V,H,W,4) copy (rgb + pad) for the fused gather; one HIP transpose per
+    scene, cached on (storage, version) like the volume."""
+    if imgs.dim() != 4 or imgs.shape[1] != 3:
+        raise RuntimeError(f"imgs must be (V,3,H,W), got {tuple(imgs.shape)}")
+    st = imgs.untyped_storage()
+    key = (st.data_ptr(), imgs.storage_offset(), imgs._version, tuple(imgs.shape), tuple(imgs.stride()))
+    hit = _cl_cache.get("imgs")
+    if hit is not None and hit[0] == key:
+        return hit[2]
+    src = imgs.detach().contiguous()
+    V, _, H, W = src.shape
+    dst = torch.empty((V, H, W, 4), device=src.device, dtype=torch.float32)
+    check(_lib.lib().mvsnerf_nchw_to_nhwc(dev_f32(src, "imgs"), dst.data_ptr(), V, 3, H, W, 4, stream_ptr()), "nchw_to_nhwc")
+    _cl_cache["imgs"] = (key, st, dst)
+    return dst
+
+
+def gather(vol_cl, imgs, w2cs, intrinsics, rays_pts, rays_ndc, rays_dir=None):
+    """Fused gen_pts_feats (+ gen_dir_feature when rays_dir is given): -> (input_feat (N,S,8+4V), dirs (N,3) | None)."""
+    _need_no_grad(vol_cl, imgs, rays_pts, rays_ndc, op="gather")
+    N, S = rays_ndc.shape[:2]
+    V = imgs.shape[0]
+    F = 8 + 4 * V
+    D, H, W, C = vol_cl.shape
+    if C != 8:
+        raise RuntimeError("gather: the neural volume must have 8 channels")
+    feat = torch.empty((N, S, F), device=rays_ndc.device, dtype=torch.float32)
+    dirs = None if rays_dir is None else torch.empty((N, 3), device=rays_ndc.device, dtype=torch.float32)
+    icl = channels_last_images(imgs)
+    check(_lib.lib().mvsnerf_gather_fwd(dev_f32(vol_cl, "volume"), D, H, W, icl.data_ptr(), V, imgs.shape[2], imgs.shape[3],
+                                        dev_f32(w2cs, "w2cs"), dev_f32(intrinsics, "intrinsics"), dev_f32(rays_pts, "rays_pts"),
+                                        dev_f32(rays_ndc, "rays_ndc"), N, S, 0 if rays_dir is None else dev_f32(rays_dir, "rays_dir"),
+                                        feat.data_ptr(), F, 0 if dirs is None else dirs.data_ptr(), stream_ptr()), "gather_fwd")
+    return feat, dirs
 
 
 def ndhwc_to_ncdhw(vol_cl):
@@ -221,7 +259,8 @@ def raymarch(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, z_vals,
         dev_f32(rays_pts, "rays_pts"), dev_f32(rays_ndc, "rays_ndc"), dev_f32(z_vals, "z_vals"), dev_f32(rays_dir, "rays_dir"),
         N, S, int(bool(white_bkgd)), dirs_tmp.data_ptr(), out["input_feat"].data_ptr(), out["raw"].data_ptr(),
         out["rgb_map"].data_ptr(), out["disp"].data_ptr(), out["acc"].data_ptr(), out["weights"].data_ptr(),
-        out["depth"].data_ptr(), out["alpha"].data_ptr(), 0 if packed_bf16 is None else packed_bf16.data_ptr())
+        out["depth"].data_ptr(), out["alpha"].data_ptr(), 0 if packed_bf16 is None else packed_bf16.data_ptr(),
+        channels_last_images(imgs).data_ptr() if FUSED_GATHER else 0)
     check(_lib.lib().mvsnerf_raymarch_fwd(ctypes.byref(a), stream_ptr()), "raymarch_fwd")
     return out
 
@@ -286,10 +325,9 @@ class RayMarchFunction(torch.autograd.Function):
         feat = torch.empty((N, S, F), **f32)
         raw = torch.empty((N, S, 4), **f32)
         saved = torch.empty(lib.mvsnerf_mlp_saved_floats(N * S), **f32)
-        check(lib.mvsnerf_dir_feature_fwd(dev_f32(rays_dir, "rays_dir"), dev_f32(w2cs, "w2cs"), N, 1, dirs.data_ptr(), st), "dir_feature_fwd")
-        check(lib.mvsnerf_volume_sample_fwd(dev_f32(vol_cl, "volume"), D, H, W, 8, dev_f32(rays_ndc, "rays_ndc"), N * S, feat.data_ptr(), F, st), "volume_sample_fwd")
-        check(lib.mvsnerf_color_sample_fwd(dev_f32(imgs, "imgs"), V, imgs.shape[2], imgs.shape[3], w2cs.data_ptr(), dev_f32(intrinsics, "intrinsics"),
-                                           dev_f32(rays_pts, "rays_pts"), N * S, 1, feat.data_ptr() + 32, F, st), "color_sample_fwd")
+        check(lib.mvsnerf_gather_fwd(dev_f32(vol_cl, "volume"), D, H, W, channels_last_images(imgs).data_ptr(), V, imgs.shape[2], imgs.shape[3],
+                                     dev_f32(w2cs, "w2cs"), dev_f32(intrinsics, "intrinsics"), dev_f32(rays_pts, "rays_pts"), dev_f32(rays_ndc, "rays_ndc"),
+                                     N, S, dev_f32(rays_dir, "rays_dir"), feat.data_ptr(), F, dirs.data_ptr(), st), "gather_fwd")
         check(lib.mvsnerf_mlp_fwd_train(packed.data_ptr(), F, rays_ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3, N, S,
                                         raw.data_ptr(), saved.data_ptr(), st), "mlp_fwd_train")
         rgb, disp, acc, weights, depth, alpha = composite(raw, z_vals, white_bkgd)

@@ -45,7 +45,7 @@ def _args(**kw):
 def test_library_loaded_is_in_tree():
     from mvsnerf_amd import _lib
     l = _lib.lib()
-    assert l.mvsnerf_abi_version() == 2
+    assert l.mvsnerf_abi_version() == 3
     assert "mvsnerf_amd/lib/libmvsnerf_hip.so" in open("/proc/self/maps").read()
 
 
@@ -344,3 +344,47 @@ def test_bf16_mlp_mode(net):
     hv = Fn.relu(lin("views_linears.0", torch.cat([feat_out, q(ang)[:, None].expand(-1, 128, -1)], -1)))
     rgb_emul = torch.sigmoid(lin("rgb_linear", hv))
     assert maxabs(raw[..., :3], rgb_emul) < 2e-3, maxabs(raw[..., :3], rgb_emul)
+
+
+@pytest.mark.parametrize("V,n_rays,n_samples", [(3, 1024, 128), (3, 37, 5), (5, 130, 16), (1, 9, 33), (6, 64, 8)])
+def test_fused_gather_is_bit_identical_to_the_three_lookups(V, n_rays, n_samples):
+    """mvsnerf_gather_fwd (one launch) vs volume_sample + color_sample + dir_feature: identical bits, including samples
+    outside the volume / images and view counts that wrap the lane quad (V > 4)."""
+    from mvsnerf_amd import ops
+    from mvsnerf_amd.synth import make_rig
+    g = torch.Generator().manual_seed(V * 100 + n_rays)
+    base = (0.0, 0.25, -0.25, 0.12, -0.12, 0.2, -0.2)
+    rig = make_rig(96, 128, n_views=V + 1, seed=7, baselines=base[:V] + (0.1,), rot_deg=2.0)
+    imgs = rig["images_raw"][0, :V].to(DEV)
+    w2cs, Ks = rig["w2cs"][0, :V].contiguous().to(DEV), rig["intrinsics"][0, :V].contiguous().to(DEV)
+    vol = torch.randn((12, 20, 28, 8), generator=g).to(DEV)
+    ndc = (torch.rand((n_rays, n_samples, 3), generator=g) * 1.3 - 0.15).to(DEV)          # some samples outside [0,1]
+    pts = (torch.randn((n_rays, n_samples, 3), generator=g) * torch.tensor([0.8, 0.6, 0.5]) + torch.tensor([0.0, 0.0, 3.0])).to(DEV)
+    rays_dir = torch.randn((n_rays, 3), generator=g).to(DEV)
+    with torch.no_grad():
+        feat, dirs = ops.gather(vol, imgs, w2cs, Ks, pts, ndc, rays_dir)
+        ref = torch.empty_like(feat)
+        ops.volume_sample(vol, ndc, out=ref, out_stride=8 + 4 * V)
+        ops.color_sample(imgs, w2cs, Ks, pts, out=ref, out_ptr=ref.data_ptr() + 32, out_stride=8 + 4 * V)
+        dref = ops.dir_feature(rays_dir, w2cs[0])
+    assert torch.equal(feat, ref)
+    assert torch.equal(dirs, dref)
+
+
+def test_raymarch_fused_and_unfused_gather_agree(net):
+    from mvsnerf_amd import ops
+    rig, pose, vol, pts, dirs, ndc, z, ro = _config2_inputs(300, 64, D=16, h=24, w=32, H=96, W=128, seed=9)
+    vol_cl = ops.channels_last_volume(vol.to(DEV))
+    imgs = rig["images_raw"][0, :3].to(DEV)
+    w2cs, Ks = pose["w2cs"][:3].contiguous().to(DEV), pose["intrinsics"][:3].contiguous().to(DEV)
+    packed = net.packed(20)
+    outs = []
+    for fused in (True, False):
+        ops.FUSED_GATHER = fused
+        try:
+            with torch.no_grad():
+                outs.append(ops.raymarch(vol_cl, imgs, w2cs, Ks, packed, pts.to(DEV), ndc.to(DEV), z.to(DEV), dirs.to(DEV)))
+        finally:
+            ops.FUSED_GATHER = True
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
