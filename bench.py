@@ -232,6 +232,12 @@ def main():
             k_mlp = lambda: lib.mvsnerf_mlp_fwd(packed.data_ptr(), F, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3, N_RAYS, N_SAMPLES, 0,
                                                 raw.data_ptr(), st().cuda_stream)
             k_cmp = lambda: lib.mvsnerf_composite_fwd(raw.data_ptr(), z.data_ptr(), N_RAYS, N_SAMPLES, 0, *[o.data_ptr() for o in outs], st().cuda_stream)
+            icl = ops.channels_last_images(src[0])
+            dirs_g = torch.empty_like(dirs)
+            k_gat = lambda: lib.mvsnerf_gather_fwd(vol_cl.data_ptr(), vol_cl.shape[0], vol_cl.shape[1], vol_cl.shape[2], icl.data_ptr(), N_SRC, H_IMG, W_IMG,
+                                                   w2c3.data_ptr(), k3.data_ptr(), pts.data_ptr(), ndc.data_ptr(), N_RAYS, N_SAMPLES, rdir.data_ptr(),
+                                                   feat.data_ptr(), F, dirs_g.data_ptr(), st().cuda_stream)
+            t_gat = event_time(k_gat, 400, graph_batch=40)
             t_vol = event_time(k_vol, 400, graph_batch=40)
             t_col = event_time(k_col, 400, graph_batch=40)
             t_mlp = event_time(k_mlp, 60)
@@ -242,7 +248,8 @@ def main():
                 "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": PMC_TRAFFIC.get("mlp_fwd"), "avg_launch_ms": round(t_mlp, 4),
                 "sustained_clock_ghz": round(clock, 3),
                 "frac_at_sustained_clock": round(tf / (PEAK_F32_MFMA_TFLOPS * clock / 2.4), 4)}
-        for name, t, bps in (("volume_sample_c8_kernel", t_vol, VOL_BYTES_PER_SAMPLE), ("color_sample_kernel", t_col, COL_BYTES_PER_SAMPLE),
+        for name, t, bps in (("gather_fused_kernel", t_gat, VOL_BYTES_PER_SAMPLE + COL_BYTES_PER_SAMPLE),
+                             ("volume_sample_c8_kernel", t_vol, VOL_BYTES_PER_SAMPLE), ("color_sample_kernel", t_col, COL_BYTES_PER_SAMPLE),
                              ("composite_kernel", t_cmp, 28)):
             gbs = bps * P / (t * 1e-3) / 1e9
             roofs.append({"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -5,7 +5,7 @@ mkdir -p gpurun_out/pmc
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
   rm -rf gpurun_out/pmc/$tag
-  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d gpurun_out/pmc/$tag -o p -- python bench.py --steps 20 --warmup 3 --cpu-batches 0 > gpurun_out/pmc/$tag.log 2>&1
+  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d gpurun_out/pmc/$tag -o p -- python bench.py --steps 20 --warmup 3 --cpu-batches 0 --no-extras > gpurun_out/pmc/$tag.log 2>&1
   ls gpurun_out/pmc/$tag | head -3
 done
 python - <<'PY'
@@ -19,7 +19,7 @@ for f in glob.glob('gpurun_out/pmc/*/p_counter_collection.csv'):
     for k, cs in acc.items():
         for c, v in cs.items():
             out.setdefault(k, {})[c] = {"mean": sum(v) / len(v), "n": len(v)}
-keep = {k: v for k, v in out.items() if any(s in k for s in ('mlp_fwd', 'volume_sample', 'color_sample', 'composite', 'planesweep', 'conv3d', 'convT', 'abn', 'dir_feature'))}
+keep = {k: v for k, v in out.items() if any(s in k for s in ('mlp_fwd', 'volume_sample', 'color_sample', 'composite', 'planesweep', 'conv3d', 'convT', 'abn', 'dir_feature', 'gather_fused', 'conv2d'))}
 json.dump(keep, open('gpurun_out/pmc/summary.json', 'w'), indent=1)
 for k, v in keep.items():
     print(k, {c: round(x['mean'], 1) for c, x in v.items()})
