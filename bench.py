@@ -299,7 +299,7 @@ def main():
             system.render_view(batch)
             torch.cuda.synchronize(); fdt = time.perf_counter() - f0
             extras["frame_512x640"] = {"seconds": round(fdt, 4), "rays_per_s_incl_encode": round(H_IMG * W_IMG / fdt, 1),
-                                       "note": "MVSNet encode + 320 chunks x (ray-generation kernel + ray march) of 1024 rays x 128 samples"}
+                                       "note": "MVSSystem.render_view: MVSNet encode + 327680 rays x 128 samples through mvsnerf_render_pixels_fwd (one FFI call; ray generation, fused gather, MLP, compositing per 4096-ray sub-batch)"}
             # (ii) one generalizable-training step (config 3 shapes, fp32): encode + ray march + full backward + Adam
             opt = system.configure_optimizers()[0][0]
             torch.manual_seed(0)

@@ -298,6 +298,31 @@ typedef struct {
 } mvsnerf_raymarch_args;
 int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream);
 
+/* Pixel-range render of one target view = the chunk loop of validation_step (train_mvs_nerf_pl.py:198-208:
+ * build_rays_test utils.py:243-297 -> rendering renderer.py:138-165 per chunk) enqueued from one host call.
+ * Renders row-major pixels [first_pixel, first_pixel + n_pixels) of a W_img x H_img target view in sub-batches of
+ * `batch_rays` rays (free parameter: rays are independent, results do not depend on it) and writes rgb[n_pixels][3] and,
+ * when non-NULL, depth/acc/disp[n_pixels].  Cameras and near/far pairs are DEVICE pointers (as for mvsnerf_raygen_fwd);
+ * workspace: mvsnerf_render_workspace_floats(batch_rays, S, V) floats, 16-byte aligned. */
+typedef struct {
+    const float* vol; int D, H, W;          /* [D][H][W][8] */
+    const float* imgs_nhwc4; int V, IH, IW; /* [V][IH][IW][4] un-normalised source images, channel-last */
+    const float* w2c;                       /* [V][4][4] source views (view 0 = reference) */
+    const float* K;                         /* [V][3][3] */
+    const float* packed_mlp;                /* mvsnerf_mlp_pack output for F = 8+4V */
+    const void* packed_mlp_bf16;            /* NULL or mvsnerf_mlp_pack_bf16 output */
+    const float* K_tgt; const float* c2w_tgt;       /* target camera [3][3], [4][4] */
+    const float* K_ref; const float* w2c_ref;       /* camera the NDC coordinates refer to */
+    const float* near_far_tgt; const float* near_far_ref;   /* [2] each */
+    int W_img, H_img, pad, lindisp;
+    int64_t first_pixel, n_pixels;
+    int S, white_bkgd, batch_rays;
+    float* workspace; size_t workspace_floats;
+    float* rgb; float* depth; float* acc; float* disp;      /* rgb required, others may be NULL */
+} mvsnerf_render_args;
+size_t mvsnerf_render_workspace_floats(int batch_rays, int S, int V);
+int mvsnerf_render_pixels_fwd(const mvsnerf_render_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,21 @@ class RaymarchArgs(ctypes.Structure):
     ]
 
 
+class RenderArgs(ctypes.Structure):
+    """mvsnerf_render_args (include/mvsnerf_hip.h)."""
+    _fields_ = [
+        ("vol", _c_fp), ("D", _c_i), ("H", _c_i), ("W", _c_i),
+        ("imgs_nhwc4", _c_fp), ("V", _c_i), ("IH", _c_i), ("IW", _c_i),
+        ("w2c", _c_fp), ("K", _c_fp), ("packed_mlp", _c_fp), ("packed_mlp_bf16", _c_fp),
+        ("K_tgt", _c_fp), ("c2w_tgt", _c_fp), ("K_ref", _c_fp), ("w2c_ref", _c_fp), ("near_far_tgt", _c_fp), ("near_far_ref", _c_fp),
+        ("W_img", _c_i), ("H_img", _c_i), ("pad", _c_i), ("lindisp", _c_i),
+        ("first_pixel", _c_l), ("n_pixels", _c_l),
+        ("S", _c_i), ("white_bkgd", _c_i), ("batch_rays", _c_i),
+        ("workspace", _c_fp), ("workspace_floats", ctypes.c_size_t),
+        ("rgb", _c_fp), ("depth", _c_fp), ("acc", _c_fp), ("disp", _c_fp),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol of include/mvsnerf_hip.h (tests check this)
 SIGNATURES = {
     "mvsnerf_abi_version": (_c_i, []),
@@ -60,6 +75,8 @@ SIGNATURES = {
     "mvsnerf_conv2d_wgrad": (_c_i, [_c_fp, _c_i] + [_c_fp] * 3 + [_c_i] * 9 + [_c_fp, _c_fp, _c_fp]),
     "mvsnerf_channel_sum_workspace_floats": (ctypes.c_size_t, [_c_i]),
     "mvsnerf_channel_sum": (_c_i, [_c_fp, _c_l, _c_i, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_render_workspace_floats": (ctypes.c_size_t, [_c_i, _c_i, _c_i]),
+    "mvsnerf_render_pixels_fwd": (_c_i, [ctypes.POINTER(RenderArgs), _c_fp]),
     "mvsnerf_gather_fwd": (_c_i, [_c_fp] + [_c_i] * 3 + [_c_fp] + [_c_i] * 3 + [_c_fp] * 4 + [_c_l, _c_i, _c_fp, _c_fp, _c_i, _c_fp, _c_fp]),
     "mvsnerf_abn_apply_add": (_c_i, [_c_fp] * 6 + [_c_l, _c_i, _c_fp, _c_fp]),
     "mvsnerf_raygen_fwd": (_c_i, [_c_fp, _c_fp, _c_l, _c_i, _c_i] + [_c_fp] * 6 + [_c_i, _c_i, _c_fp, _c_l, _c_i] + [_c_fp] * 6),

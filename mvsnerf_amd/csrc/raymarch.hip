@@ -35,3 +35,62 @@ extern "C" int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream
     // raw2outputs (renderer.py:162)
     return mvsnerf_composite_fwd(a->raw, a->z_vals, a->N, a->S, a->white_bkgd, a->rgb_map, a->disp, a->acc, a->weights, a->depth, a->alpha, stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Full-frame / pixel-range render = the chunk loop of validation_step (train_mvs_nerf_pl.py:198-208):
+//   for each chunk: build_rays_test (utils.py:243-297) -> rendering (renderer.py:138-165) -> keep rgb and depth.
+// The whole loop is enqueued from ONE host call (4 launches per sub-batch: ray generation, fused gather, MLP,
+// compositing), so a frame is not paced by ~0.1 ms of Python/ctypes work per 1024-ray chunk.  Rays are independent,
+// so the sub-batch size is free (results do not depend on it); temporaries live in a caller-provided workspace that is
+// reused by every sub-batch (stream order makes that safe).
+// ---------------------------------------------------------------------------------------------
+static size_t render_ws_floats(int64_t B, int S, int V)
+{
+    const int64_t P = B * S, F = 8 + 4 * V;
+    // pts, ndc (3P each), z (P), feat (F*P), raw (4P), rays_dir + dirs (3B each); every block rounded up to 16 bytes
+    auto r4 = [](int64_t n) { return (n + 3) & ~(int64_t)3; };
+    return (size_t)(r4(3 * P) * 2 + r4(P) + r4(F * P) + r4(4 * P) + r4(3 * B) * 2);
+}
+
+extern "C" size_t mvsnerf_render_workspace_floats(int batch_rays, int S, int V)
+{
+    if (batch_rays < 1 || S < 1 || V < 1) return 0;
+    return render_ws_floats(batch_rays, S, V);
+}
+
+extern "C" int mvsnerf_render_pixels_fwd(const mvsnerf_render_args* a, void* stream)
+{
+    if (!a) return MVSNERF_EINVAL;
+    if (!a->vol || !a->imgs_nhwc4 || !a->w2c || !a->K || !a->packed_mlp || !a->K_tgt || !a->c2w_tgt || !a->K_ref || !a->w2c_ref ||
+        !a->near_far_tgt || !a->near_far_ref || !a->workspace || !a->rgb)
+        return MVSNERF_EINVAL;
+    if (a->n_pixels < 0 || a->first_pixel < 0 || a->S < 1 || a->V < 1 || a->batch_rays < 1 || a->W_img < 2 || a->H_img < 2) return MVSNERF_EINVAL;
+    if (a->first_pixel + a->n_pixels > (int64_t)a->W_img * a->H_img) return MVSNERF_EINVAL;
+    if (a->workspace_floats < render_ws_floats(a->batch_rays, a->S, a->V)) return MVSNERF_EINVAL;
+    const int F = 8 + 4 * a->V, S = a->S;
+    const int64_t B = a->batch_rays, P = B * S;
+    auto r4 = [](int64_t n) { return (n + 3) & ~(int64_t)3; };
+    float* pts = a->workspace;
+    float* ndc = pts + r4(3 * P);
+    float* z = ndc + r4(3 * P);
+    float* feat = z + r4(P);
+    float* raw = feat + r4((int64_t)F * P);
+    float* rdir = raw + r4(4 * P);
+    float* dirs = rdir + r4(3 * B);
+    int rc;
+    for (int64_t off = 0; off < a->n_pixels; off += B) {
+        const int64_t n = a->n_pixels - off < B ? a->n_pixels - off : B;
+        if ((rc = mvsnerf_raygen_fwd(nullptr, nullptr, a->first_pixel + off, a->W_img, a->H_img, a->K_tgt, a->c2w_tgt, a->K_ref, a->w2c_ref,
+                                     a->near_far_tgt, a->near_far_ref, a->pad, a->lindisp, nullptr, n, S, pts, rdir, ndc, z, nullptr, stream))) return rc;
+        if ((rc = mvsnerf_gather_fwd(a->vol, a->D, a->H, a->W, a->imgs_nhwc4, a->V, a->IH, a->IW, a->w2c, a->K, pts, ndc, n, S, rdir,
+                                     feat, F, dirs, stream))) return rc;
+        if (a->packed_mlp_bf16)
+            rc = mvsnerf_mlp_fwd_bf16(a->packed_mlp_bf16, a->packed_mlp, F, ndc, 3, feat, F, dirs, 3, n, S, 0, raw, stream);
+        else
+            rc = mvsnerf_mlp_fwd(a->packed_mlp, F, ndc, 3, feat, F, dirs, 3, n, S, 0, raw, stream);
+        if (rc) return rc;
+        if ((rc = mvsnerf_composite_fwd(raw, z, n, S, a->white_bkgd, a->rgb + off * 3, a->disp ? a->disp + off : nullptr,
+                                        a->acc ? a->acc + off : nullptr, nullptr, a->depth ? a->depth + off : nullptr, nullptr, stream))) return rc;
+    }
+    return MVSNERF_OK;
+}

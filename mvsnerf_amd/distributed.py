@@ -110,13 +110,35 @@ def render_frame(render_chunk, H, W, chunk, group=None):
         packed = torch.cat([torch.cat(rgbs, 0), torch.cat(depths, 0)[:, None]], 1)       # (n_local, 4): one message
     else:
         packed = None
+    return _assemble_frame(packed, H, W, chunk, n_chunks, world, group)
+
+
+def render_frame_pixels(render_range, H, W, chunk, group=None, device=None):
+    """Same sharding as render_frame, but the rank's whole contiguous pixel range is rendered by ONE call
+    `render_range(first_pixel, n_pixels) -> (rgb (n,3), depth (n,))` (ops.render_pixels: the chunk loop runs inside the
+    library, one FFI crossing per rank and frame)."""
+    n_chunks = (H * W + chunk - 1) // chunk
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    lo, hi = shard_range(n_chunks, world, rank)
+    first, last = min(lo * chunk, H * W), min(hi * chunk, H * W)
+    packed = None
+    if last > first:
+        rgb, depth = render_range(first, last - first)
+        packed = torch.cat([rgb, depth[:, None]], 1)
+    return _assemble_frame(packed, H, W, chunk, n_chunks, world, group, device)
+
+
+def _assemble_frame(packed, H, W, chunk, n_chunks, world, group, device=None):
     if world == 1:
         return packed[:, :3], packed[:, 3]
     # rows are pixels; the per-rank pixel ranges follow from the chunk ranges (the last chunk may be short)
     px = [(min(l * chunk, H * W), min(h * chunk, H * W)) for l, h in (shard_range(n_chunks, world, r) for r in range(world))]
     width = max(b - a for a, b in px)
-    ref = packed if packed is not None else None
-    dev = ref.device if ref is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    if packed is not None:
+        dev = packed.device
+    else:
+        dev = device if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
     pad = torch.zeros((width, 4), dtype=torch.float32, device=dev)
     if packed is not None:
         pad[:packed.shape[0]] = packed

@@ -265,6 +265,44 @@ def raymarch(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, z_vals,
     return out
 
 
+def render_pixels(vol_cl, imgs, w2cs, intrinsics, packed, H, W, K_tgt, c2w_tgt, K_ref, w2c_ref, nf_tgt, nf_ref, N_samples,
+                  first_pixel=0, n_pixels=None, pad=0, lindisp=False, white_bkgd=False, packed_bf16=None, batch_rays=4096,
+                  want=("depth",)):
+    """Pixel range of one target view in ONE FFI call (the chunk loop of validation_step, train_mvs_nerf_pl.py:198-208).
+    Returns dict with rgb (n,3) and the requested extras among depth/acc/disp (n,)."""
+    _need_no_grad(vol_cl, imgs, op="render_pixels")
+    lib = _lib.lib()
+    n = H * W - first_pixel if n_pixels is None else int(n_pixels)
+    V = imgs.shape[0]
+    D, Hv, Wv, C = vol_cl.shape
+    if C != 8:
+        raise RuntimeError("render_pixels: the neural volume must have 8 channels")
+    dev = vol_cl.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    B = int(min(batch_rays, max(n, 1)))
+    ws_n = lib.mvsnerf_render_workspace_floats(B, N_samples, V)
+    key = (ws_n, str(dev))
+    ws = _render_ws.get(key)
+    if ws is None:
+        _render_ws.clear()
+        ws = _render_ws[key] = torch.empty(ws_n, **f32)
+    out = {"rgb": torch.empty((n, 3), **f32)}
+    for k in ("depth", "acc", "disp"):
+        out[k] = torch.empty((n,), **f32) if k in want else None
+    c = lambda t, name: dev_f32(t.contiguous(), name)
+    a = _lib.RenderArgs(
+        dev_f32(vol_cl, "volume"), D, Hv, Wv, channels_last_images(imgs).data_ptr(), V, imgs.shape[2], imgs.shape[3],
+        c(w2cs, "w2cs"), c(intrinsics, "intrinsics"), packed.data_ptr(), 0 if packed_bf16 is None else packed_bf16.data_ptr(),
+        c(K_tgt, "K_tgt"), c(c2w_tgt, "c2w_tgt"), c(K_ref, "K_ref"), c(w2c_ref, "w2c_ref"), c(nf_tgt, "near_far_tgt"), c(nf_ref, "near_far_ref"),
+        W, H, int(pad), int(bool(lindisp)), int(first_pixel), n, int(N_samples), int(bool(white_bkgd)), B,
+        ws.data_ptr(), ws_n, out["rgb"].data_ptr(), *[0 if out[k] is None else out[k].data_ptr() for k in ("depth", "acc", "disp")])
+    check(lib.mvsnerf_render_pixels_fwd(ctypes.byref(a), stream_ptr()), "render_pixels_fwd")
+    return {k: v for k, v in out.items() if v is not None}
+
+
+_render_ws = {}
+
+
 # ------------------------------------------------------------------ training path (autograd)
 def _act_n(q, h):
     return (q >> 4) * 32 + (q & 3) + 8 * ((q & 15) >> 2) + 4 * h

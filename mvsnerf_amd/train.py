@@ -16,7 +16,8 @@ import torch
 import torch.nn as nn
 
 from . import distributed as D
-from .models import create_nerf_mvs
+from . import ops
+from .models import MVSNeRF, create_nerf_mvs
 from .renderer import rendering
 from .utils import build_rays, build_rays_test, img2mse
 
@@ -138,9 +139,11 @@ class MVSSystem(_ModuleShim):
         return {"loss": loss}
 
     @torch.no_grad()
-    def render_view(self, batch, chunk=None):
+    def render_view(self, batch, chunk=None, whole_frame_off=False):
         """The rendering part of validation_step (:172-254): encode once, then the chunk loop over the target view's
-        pixels - tile-parallel over ranks (contiguous chunk ranges + one all_gather).  Returns (rgb (H,W,3), depth (H,W))."""
+        pixels - tile-parallel over ranks (contiguous chunk ranges + one all_gather).  Returns (rgb (H,W,3), depth (H,W)).
+        whole_frame_off=True keeps the per-chunk Python loop (build_rays_test + rendering per chunk) instead of the single
+        mvsnerf_render_pixels_fwd call; both produce the same pixels."""
         args = self.args
         chunk = chunk or args.chunk
         data_mvs, pose_ref = self.decode_batch(dict(batch))
@@ -150,6 +153,27 @@ class MVSSystem(_ModuleShim):
         volume_feature, _, _ = self.MVSNet(imgs[:, :3], proj_mats[:, :3], near_fars[0], pad=args.pad)
         imgs = self.unpreprocess(imgs)
         world_to_ref, tgt_to_world, intrinsic = pose_ref["w2cs"][0], pose_ref["c2ws"][-1], pose_ref["intrinsics"][-1]
+
+        kw = self.render_kwargs_train
+        net = kw["network_fn"]
+        V = imgs.shape[1] - 1
+        fused = (isinstance(net, MVSNeRF) and getattr(kw.get("network_query_fn"), "_mvsnerf_fused", False)
+                 and not getattr(args, "use_color_volume", False) and args.feat_dim == 8 + 4 * V and not whole_frame_off)
+        if fused:
+            # one FFI call per rank: the chunk loop (build_rays_test + rendering per chunk) runs inside the library
+            k_render = intrinsic if intrinsic.dim() == 2 else intrinsic.mean(0)
+            nf_t, nf_r = near_fars[-1].reshape(-1)[:2].contiguous(), near_fars[0].reshape(-1)[:2].contiguous()
+            vol_cl = ops.channels_last_volume(volume_feature)
+            src = imgs[0, :-1].contiguous()
+
+            def render_range(first, n):
+                o = ops.render_pixels(vol_cl, src, pose_ref["w2cs"][:V].contiguous(), pose_ref["intrinsics"][:V].contiguous(),
+                                      net.packed(args.feat_dim), H, W, k_render, tgt_to_world, k_render, world_to_ref, nf_t, nf_r,
+                                      args.N_samples, first_pixel=first, n_pixels=n, pad=args.pad, white_bkgd=kw.get("white_bkgd", False),
+                                      packed_bf16=net.packed_bf16(args.feat_dim) if ops.MLP_PRECISION == "bf16" else None)
+                return o["rgb"], o["depth"]
+            rgb, depth = D.render_frame_pixels(render_range, H, W, chunk, device=imgs.device)
+            return rgb.reshape(H, W, 3), depth.reshape(H, W)
 
         def render_chunk(idx):
             rays_pts, rays_dir, rays_NDC, depth_candidates, rays_o, _ = build_rays_test(

@@ -114,6 +114,39 @@ def test_render_view_full_frame():
     assert bool(torch.isfinite(rgb).all()) and float(rgb.min()) >= 0 and float(rgb.max()) <= 1.0 + 1e-5
     rgb2, _ = sys_.render_view(batch, chunk=777)          # chunking must not change the image
     assert float((rgb - rgb2).abs().max()) < 1e-5
+    # one-call pixel-range render (mvsnerf_render_pixels_fwd) vs. the per-chunk loop build_rays_test + rendering
+    rgb3, depth3 = sys_.render_view(batch, chunk=1000, whole_frame_off=True)
+    assert float((rgb - rgb3).abs().max()) < 1e-6 and float((depth - depth3).abs().max()) < 1e-5
+
+
+def test_render_pixels_subrange_and_oracle():
+    """ops.render_pixels on an arbitrary pixel range (ragged against the sub-batch size) against the CPU oracle:
+    build_rays_test -> rendering for the same pixels."""
+    from mvsnerf_amd import ops, models
+    from mvsnerf_amd.synth import make_rig, pose_ref_of
+    from oracle import mvsnerf_oracle as O
+    mlp_sd, _ = load_weights()
+    H, W, S, pad = 48, 64, 24, 4
+    rig = make_rig(H, W, seed=11, rot_deg=2.0, smooth=True)
+    pose = pose_ref_of(rig)
+    g = torch.Generator().manual_seed(2)
+    vol = torch.randn((1, 8, 16, H // 4 + 2 * pad, W // 4 + 2 * pad), generator=g)
+    first, n = 1234, 777
+    pts, dirs, ndc, z = O.build_rays_test(H, W, pose["c2ws"][-1], pose["w2cs"][0], pose["intrinsics"][-1], pose["near_fars"], pose["near_fars"][-1], S, pad=pad)[:4]
+    sl = slice(first, first + n)
+    ref = O.rendering(pose, pts[sl], ndc[sl], z[sl], dirs[sl], vol, rig["images_raw"][:, :3], mlp_sd)
+    net = models.MVSNeRF(D=6, W=128, input_ch_pts=63, input_ch_views=3, input_ch_feat=20, skips=[4], net_type="v0")
+    net.load_state_dict(mlp_sd)
+    net = net.to(DEV)
+    pd = {k: v.to(DEV) for k, v in pose.items()}
+    with torch.no_grad():
+        out = ops.render_pixels(ops.channels_last_volume(vol.to(DEV)), rig["images_raw"][0, :3].to(DEV), pd["w2cs"][:3].contiguous(),
+                                pd["intrinsics"][:3].contiguous(), net.packed(20), H, W, pd["intrinsics"][-1], pd["c2ws"][-1], pd["intrinsics"][-1],
+                                pd["w2cs"][0], pd["near_fars"][-1], pd["near_fars"][0], S, first_pixel=first, n_pixels=n, pad=pad,
+                                batch_rays=200, want=("depth", "acc", "disp"))
+    assert float((out["rgb"].cpu() - ref[0]).abs().max()) < 1e-4
+    assert float((out["depth"].cpu() - ref[3]).abs().max()) < 1e-4
+    assert float((out["acc"].cpu() - ref[2].sum(-1)).abs().max()) < 1e-4
 
 
 def test_finetune_step_trains_volume_and_mlp():
