@@ -156,8 +156,11 @@ int mvsnerf_channel_sum(const float* g, int64_t n, int C, float* out, float* wor
  * draws.  xs/ys[N]: pixel ids as floats drawn by the caller, or NULL for the row-major ids first_pixel + n of
  * build_rays_test.  K_*[3][3], c2w_tgt / w2c_ref [4][4] row-major, near_far_*[2]: all DEVICE pointers (read with
  * wave-uniform loads, so no host synchronisation is needed to launch).  t_rand[N][S]: stratified jitter or NULL.
+ * W_img x H_img: the target view (pixel ids); W_ref x H_ref: the view whose pixel grid the NDC coordinates are normalised by
+ * (`inv_scale` of utils.py:112-146).  The reference uses the target size for both (utils.py:252); pass 0 for that, or the
+ * source-view size when the target grid differs from the sources (BASELINE config 5: 1008x756 rays over 960x640 sources).
  * Outputs: rays_pts[N][S][3], rays_dir[N][3], rays_ndc[N][S][3], z_vals[N][S], pix[2][N] (= (ys,xs), may be NULL). */
-int mvsnerf_raygen_fwd(const float* xs, const float* ys, int64_t first_pixel, int W_img, int H_img,
+int mvsnerf_raygen_fwd(const float* xs, const float* ys, int64_t first_pixel, int W_img, int H_img, int W_ref, int H_ref,
                        const float* K_tgt, const float* c2w_tgt, const float* K_ref, const float* w2c_ref,
                        const float* near_far_tgt, const float* near_far_ref, int pad, int lindisp,
                        const float* t_rand, int64_t N, int S,
@@ -315,6 +318,7 @@ typedef struct {
     const float* K_ref; const float* w2c_ref;       /* camera the NDC coordinates refer to */
     const float* near_far_tgt; const float* near_far_ref;   /* [2] each */
     int W_img, H_img, pad, lindisp;
+    int W_ref, H_ref;                       /* 0: same as the target (the reference's assumption); see mvsnerf_raygen_fwd */
     int64_t first_pixel, n_pixels;
     int S, white_bkgd, batch_rays;
     float* workspace; size_t workspace_floats;

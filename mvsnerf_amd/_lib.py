@@ -39,7 +39,7 @@ class RenderArgs(ctypes.Structure):
         ("imgs_nhwc4", _c_fp), ("V", _c_i), ("IH", _c_i), ("IW", _c_i),
         ("w2c", _c_fp), ("K", _c_fp), ("packed_mlp", _c_fp), ("packed_mlp_bf16", _c_fp),
         ("K_tgt", _c_fp), ("c2w_tgt", _c_fp), ("K_ref", _c_fp), ("w2c_ref", _c_fp), ("near_far_tgt", _c_fp), ("near_far_ref", _c_fp),
-        ("W_img", _c_i), ("H_img", _c_i), ("pad", _c_i), ("lindisp", _c_i),
+        ("W_img", _c_i), ("H_img", _c_i), ("pad", _c_i), ("lindisp", _c_i), ("W_ref", _c_i), ("H_ref", _c_i),
         ("first_pixel", _c_l), ("n_pixels", _c_l),
         ("S", _c_i), ("white_bkgd", _c_i), ("batch_rays", _c_i),
         ("workspace", _c_fp), ("workspace_floats", ctypes.c_size_t),
@@ -79,7 +79,7 @@ SIGNATURES = {
     "mvsnerf_render_pixels_fwd": (_c_i, [ctypes.POINTER(RenderArgs), _c_fp]),
     "mvsnerf_gather_fwd": (_c_i, [_c_fp] + [_c_i] * 3 + [_c_fp] + [_c_i] * 3 + [_c_fp] * 4 + [_c_l, _c_i, _c_fp, _c_fp, _c_i, _c_fp, _c_fp]),
     "mvsnerf_abn_apply_add": (_c_i, [_c_fp] * 6 + [_c_l, _c_i, _c_fp, _c_fp]),
-    "mvsnerf_raygen_fwd": (_c_i, [_c_fp, _c_fp, _c_l, _c_i, _c_i] + [_c_fp] * 6 + [_c_i, _c_i, _c_fp, _c_l, _c_i] + [_c_fp] * 6),
+    "mvsnerf_raygen_fwd": (_c_i, [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i] + [_c_fp] * 6 + [_c_i, _c_i, _c_fp, _c_l, _c_i] + [_c_fp] * 6),
     "mvsnerf_volume_sample_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_l, _c_fp, _c_i, _c_fp]),
     "mvsnerf_color_sample_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_i, _c_fp]),
     "mvsnerf_dir_feature_fwd": (_c_i, [_c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp]),

@@ -3,7 +3,7 @@
 // ATen launches).
 #include "common.h"
 
-extern "C" int mvsnerf_abi_version(void) { return 3; }
+extern "C" int mvsnerf_abi_version(void) { return 4; }
 
 extern "C" int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream)
 {
@@ -80,7 +80,7 @@ extern "C" int mvsnerf_render_pixels_fwd(const mvsnerf_render_args* a, void* str
     int rc;
     for (int64_t off = 0; off < a->n_pixels; off += B) {
         const int64_t n = a->n_pixels - off < B ? a->n_pixels - off : B;
-        if ((rc = mvsnerf_raygen_fwd(nullptr, nullptr, a->first_pixel + off, a->W_img, a->H_img, a->K_tgt, a->c2w_tgt, a->K_ref, a->w2c_ref,
+        if ((rc = mvsnerf_raygen_fwd(nullptr, nullptr, a->first_pixel + off, a->W_img, a->H_img, a->W_ref, a->H_ref, a->K_tgt, a->c2w_tgt, a->K_ref, a->w2c_ref,
                                      a->near_far_tgt, a->near_far_ref, a->pad, a->lindisp, nullptr, n, S, pts, rdir, ndc, z, nullptr, stream))) return rc;
         if ((rc = mvsnerf_gather_fwd(a->vol, a->D, a->H, a->W, a->imgs_nhwc4, a->V, a->IH, a->IW, a->w2c, a->K, pts, ndc, n, S, rdir,
                                      feat, F, dirs, stream))) return rc;

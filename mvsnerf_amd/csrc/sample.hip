@@ -443,7 +443,8 @@ extern "C" int mvsnerf_volume_sample_bwd(int D, int H, int W, int C, const float
 // ---------------------------------------------------------------------------------------------
 struct RayGenArgs {
     const float* xs; const float* ys;      // [N] pixel ids as floats, or null: row-major ids first_pixel + n
-    int64_t first_pixel; int W_img, H_img;
+    int64_t first_pixel; int W_img, H_img;   // target view (row-major pixel ids)
+    int W_ref, H_ref;                        // size of the view the NDC coordinates refer to (the reference assumes == target)
     const float* Kt; const float* c2w;     // target camera: intrinsics [3][3], c2w [4][4]   (device, wave-uniform loads)
     const float* Kr; const float* w2c;     // reference camera: intrinsics [3][3], w2c [4][4]
     const float* nf_tgt; const float* nf_ref;   // [2] = (near, far) of the target / reference view
@@ -494,12 +495,12 @@ __global__ __launch_bounds__(256) void raygen_kernel(RayGenArgs a)
     const float qx = fmaf(cz, a.Kr[2], fmaf(cy, a.Kr[1], cx * a.Kr[0]));
     const float qy = fmaf(cz, a.Kr[5], fmaf(cy, a.Kr[4], cx * a.Kr[3]));
     const float qz = fmaf(cz, a.Kr[8], fmaf(cy, a.Kr[7], cx * a.Kr[6]));
-    float nx = (qx / qz + 0.0f) / (float)(a.W_img - 1);
-    float ny = (qy / qz + 0.0f) / (float)(a.H_img - 1);
+    float nx = (qx / qz + 0.0f) / (float)(a.W_ref - 1);
+    float ny = (qy / qz + 0.0f) / (float)(a.H_ref - 1);
     const float nz = a.lindisp ? (1.0f / qz - 1.0f / near_ref) / (1.0f / far_ref - 1.0f / near_ref)
                                : (qz - near_ref) / (far_ref - near_ref);
     if (a.pad > 0) {
-        const float Wf = (float)a.W_img / 4.0f, Hf = (float)a.H_img / 4.0f;          // (inv_scale+1)/4
+        const float Wf = (float)a.W_ref / 4.0f, Hf = (float)a.H_ref / 4.0f;          // (inv_scale+1)/4
         ny = ny * Hf / (Hf + (float)(a.pad * 2)) + (float)a.pad / (Hf + (float)(a.pad * 2));
         nx = nx * Wf / (Wf + (float)(a.pad * 2)) + (float)a.pad / (Wf + (float)(a.pad * 2));
     }
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(256) void raygen_kernel(RayGenArgs a)
     }
 }
 
-extern "C" int mvsnerf_raygen_fwd(const float* xs, const float* ys, int64_t first_pixel, int W_img, int H_img,
+extern "C" int mvsnerf_raygen_fwd(const float* xs, const float* ys, int64_t first_pixel, int W_img, int H_img, int W_ref, int H_ref,
                                   const float* K_tgt, const float* c2w_tgt, const float* K_ref, const float* w2c_ref,
                                   const float* near_far_tgt, const float* near_far_ref, int pad, int lindisp,
                                   const float* t_rand, int64_t N, int S,
@@ -520,9 +521,12 @@ extern "C" int mvsnerf_raygen_fwd(const float* xs, const float* ys, int64_t firs
 {
     if (!K_tgt || !c2w_tgt || !K_ref || !w2c_ref || !near_far_tgt || !near_far_ref || !rays_pts || !rays_dir || !rays_ndc || !z_vals || N < 0 || S < 1) return MVSNERF_EINVAL;
     if ((xs == nullptr) != (ys == nullptr) || W_img < 2 || H_img < 2) return MVSNERF_EINVAL;
+    if (W_ref <= 0) W_ref = W_img;
+    if (H_ref <= 0) H_ref = H_img;
+    if (W_ref < 2 || H_ref < 2) return MVSNERF_EINVAL;
     if (N == 0) return MVSNERF_OK;
     RayGenArgs a;
-    a.xs = xs; a.ys = ys; a.first_pixel = first_pixel; a.W_img = W_img; a.H_img = H_img;
+    a.xs = xs; a.ys = ys; a.first_pixel = first_pixel; a.W_img = W_img; a.H_img = H_img; a.W_ref = W_ref; a.H_ref = H_ref;
     a.Kt = K_tgt; a.c2w = c2w_tgt; a.Kr = K_ref; a.w2c = w2c_ref; a.nf_tgt = near_far_tgt; a.nf_ref = near_far_ref;
     a.pad = pad; a.lindisp = lindisp; a.t_rand = t_rand; a.N = N; a.S = S;
     a.rays_pts = rays_pts; a.rays_dir = rays_dir; a.rays_ndc = rays_ndc; a.z_vals = z_vals; a.pix = pix;

@@ -142,7 +142,7 @@ def posenc(x, num_freqs):
 
 
 def raygen(H, W, K_tgt, c2w_tgt, K_ref, w2c_ref, nf_tgt, nf_ref, N_samples, pad=0, lindisp=False,
-           xs=None, ys=None, first_pixel=0, n_rays=None, t_rand=None):
+           xs=None, ys=None, first_pixel=0, n_rays=None, t_rand=None, ref_hw=None):
     """Ray generation kernel (utils.build_rays / build_rays_test downstream of the RNG draws).
     Either xs/ys (float pixel ids, (N,)) or first_pixel + n_rays (row-major ids).  All camera tensors stay on the device.
     Returns rays_pts (N,S,3), rays_dir (N,3), rays_ndc (N,S,3), z_vals (N,S), pix (2,N)."""
@@ -156,6 +156,7 @@ def raygen(H, W, K_tgt, c2w_tgt, K_ref, w2c_ref, nf_tgt, nf_ref, N_samples, pad=
     pix = torch.empty((2, N), **f32)
     c = lambda t, name: dev_f32(t.contiguous(), name)
     check(_lib.lib().mvsnerf_raygen_fwd(0 if xs is None else c(xs, "xs"), 0 if ys is None else c(ys, "ys"), int(first_pixel), W, H,
+                                        0 if ref_hw is None else int(ref_hw[1]), 0 if ref_hw is None else int(ref_hw[0]),
                                         c(K_tgt, "K_tgt"), c(c2w_tgt, "c2w_tgt"), c(K_ref, "K_ref"), c(w2c_ref, "w2c_ref"),
                                         c(nf_tgt, "near_far_tgt"), c(nf_ref, "near_far_ref"), int(pad), int(bool(lindisp)),
                                         0 if t_rand is None else c(t_rand, "t_rand"), N, N_samples,
@@ -267,7 +268,7 @@ def raymarch(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, z_vals,
 
 def render_pixels(vol_cl, imgs, w2cs, intrinsics, packed, H, W, K_tgt, c2w_tgt, K_ref, w2c_ref, nf_tgt, nf_ref, N_samples,
                   first_pixel=0, n_pixels=None, pad=0, lindisp=False, white_bkgd=False, packed_bf16=None, batch_rays=4096,
-                  want=("depth",)):
+                  want=("depth",), ref_hw=None):
     """Pixel range of one target view in ONE FFI call (the chunk loop of validation_step, train_mvs_nerf_pl.py:198-208).
     Returns dict with rgb (n,3) and the requested extras among depth/acc/disp (n,)."""
     _need_no_grad(vol_cl, imgs, op="render_pixels")
@@ -294,7 +295,7 @@ def render_pixels(vol_cl, imgs, w2cs, intrinsics, packed, H, W, K_tgt, c2w_tgt, 
         dev_f32(vol_cl, "volume"), D, Hv, Wv, channels_last_images(imgs).data_ptr(), V, imgs.shape[2], imgs.shape[3],
         c(w2cs, "w2cs"), c(intrinsics, "intrinsics"), packed.data_ptr(), 0 if packed_bf16 is None else packed_bf16.data_ptr(),
         c(K_tgt, "K_tgt"), c(c2w_tgt, "c2w_tgt"), c(K_ref, "K_ref"), c(w2c_ref, "w2c_ref"), c(nf_tgt, "near_far_tgt"), c(nf_ref, "near_far_ref"),
-        W, H, int(pad), int(bool(lindisp)), int(first_pixel), n, int(N_samples), int(bool(white_bkgd)), B,
+        W, H, int(pad), int(bool(lindisp)), 0 if ref_hw is None else int(ref_hw[1]), 0 if ref_hw is None else int(ref_hw[0]), int(first_pixel), n, int(N_samples), int(bool(white_bkgd)), B,
         ws.data_ptr(), ws_n, out["rgb"].data_ptr(), *[0 if out[k] is None else out[k].data_ptr() for k in ("depth", "acc", "disp")])
     check(lib.mvsnerf_render_pixels_fwd(ctypes.byref(a), stream_ptr()), "render_pixels_fwd")
     return {k: v for k, v in out.items() if v is not None}

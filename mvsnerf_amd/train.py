@@ -139,37 +139,52 @@ class MVSSystem(_ModuleShim):
         return {"loss": loss}
 
     @torch.no_grad()
-    def render_view(self, batch, chunk=None, whole_frame_off=False):
+    def render_view(self, batch, chunk=None, whole_frame_off=False, target=None):
         """The rendering part of validation_step (:172-254): encode once, then the chunk loop over the target view's
         pixels - tile-parallel over ranks (contiguous chunk ranges + one all_gather).  Returns (rgb (H,W,3), depth (H,W)).
         whole_frame_off=True keeps the per-chunk Python loop (build_rays_test + rendering per chunk) instead of the single
-        mvsnerf_render_pixels_fwd call; both produce the same pixels."""
+        mvsnerf_render_pixels_fwd call; both produce the same pixels.
+        target (extension, BASELINE config 5): dict(hw=(H,W), intrinsic (3,3), c2w (4,4)[, near_far (2,)]) renders a camera whose
+        pixel grid differs from the source views' (e.g. 1008x756 rays over 960x640 sources).  The reference normalises the NDC
+        coordinates with the *target* size and intrinsics (utils.py:252-253, fine when all views share both); with `target` the
+        reference view's own intrinsics and size are used, which is what the volume is aligned with."""
         args = self.args
         chunk = chunk or args.chunk
         data_mvs, pose_ref = self.decode_batch(dict(batch))
         imgs, proj_mats, near_fars = data_mvs["images"], data_mvs["proj_mats"], pose_ref["near_fars"]
         H, W = int(imgs.shape[-2]), int(imgs.shape[-1])
+        V = imgs.shape[1] - 1                                            # source views (3 in the reference's batches, :193)
         self.MVSNet.train()                                              # :182 batch-statistics ABN also at inference
-        volume_feature, _, _ = self.MVSNet(imgs[:, :3], proj_mats[:, :3], near_fars[0], pad=args.pad)
+        volume_feature, _, _ = self.MVSNet(imgs[:, :V], proj_mats[:, :V], near_fars[0], pad=args.pad)
         imgs = self.unpreprocess(imgs)
         world_to_ref, tgt_to_world, intrinsic = pose_ref["w2cs"][0], pose_ref["c2ws"][-1], pose_ref["intrinsics"][-1]
+        k_ref, ref_hw, nf_tgt = None, None, near_fars[-1]
+        if target is not None:
+            dev = imgs.device
+            ref_hw, (H, W) = (H, W), (int(target["hw"][0]), int(target["hw"][1]))
+            intrinsic, tgt_to_world = target["intrinsic"].to(dev, torch.float32), target["c2w"].to(dev, torch.float32)
+            k_ref = pose_ref["intrinsics"][0]
+            if "near_far" in target:
+                nf_tgt = target["near_far"].to(dev, torch.float32)
 
         kw = self.render_kwargs_train
         net = kw["network_fn"]
-        V = imgs.shape[1] - 1
         fused = (isinstance(net, MVSNeRF) and getattr(kw.get("network_query_fn"), "_mvsnerf_fused", False)
                  and not getattr(args, "use_color_volume", False) and args.feat_dim == 8 + 4 * V and not whole_frame_off)
+        if target is not None and not fused:
+            raise RuntimeError("render_view(target=...) needs the fused ray-march path (MVSNeRF + fused network_query_fn)")
         if fused:
             # one FFI call per rank: the chunk loop (build_rays_test + rendering per chunk) runs inside the library
             k_render = intrinsic if intrinsic.dim() == 2 else intrinsic.mean(0)
-            nf_t, nf_r = near_fars[-1].reshape(-1)[:2].contiguous(), near_fars[0].reshape(-1)[:2].contiguous()
+            nf_t, nf_r = nf_tgt.reshape(-1)[:2].contiguous(), near_fars[0].reshape(-1)[:2].contiguous()
             vol_cl = ops.channels_last_volume(volume_feature)
             src = imgs[0, :-1].contiguous()
 
             def render_range(first, n):
                 o = ops.render_pixels(vol_cl, src, pose_ref["w2cs"][:V].contiguous(), pose_ref["intrinsics"][:V].contiguous(),
-                                      net.packed(args.feat_dim), H, W, k_render, tgt_to_world, k_render, world_to_ref, nf_t, nf_r,
-                                      args.N_samples, first_pixel=first, n_pixels=n, pad=args.pad, white_bkgd=kw.get("white_bkgd", False),
+                                      net.packed(args.feat_dim), H, W, k_render, tgt_to_world, k_render if k_ref is None else k_ref,
+                                      world_to_ref, nf_t, nf_r, args.N_samples, first_pixel=first, n_pixels=n, pad=args.pad,
+                                      white_bkgd=kw.get("white_bkgd", False), ref_hw=ref_hw,
                                       packed_bf16=net.packed_bf16(args.feat_dim) if ops.MLP_PRECISION == "bf16" else None)
                 return o["rgb"], o["depth"]
             rgb, depth = D.render_frame_pixels(render_range, H, W, chunk, device=imgs.device)

@@ -244,15 +244,21 @@ def build_rays(imgs, pose_ref, near_fars, N_rays, N_samples, pad=0, t_rand=None,
     return pts, rays_d, target, ndc, z, ro.permute(1, 0), pix_i
 
 
-def build_rays_test(H, W, tgt_to_world, world_to_ref, intrinsic, near_fars_ref, near_fars, N_samples, pad=0, chunk=-1, idx=-1):
-    """utils.py:243-297: deterministic row-major pixels, no jitter."""
-    inv_scale = torch.tensor([W - 1, H - 1], dtype=torch.float32)
+def build_rays_test(H, W, tgt_to_world, world_to_ref, intrinsic, near_fars_ref, near_fars, N_samples, pad=0, chunk=-1, idx=-1,
+                    ref_intrinsic=None, ref_hw=None):
+    """utils.py:243-297: deterministic row-major pixels, no jitter.
+    ref_intrinsic / ref_hw are NOT in the reference (it normalises the reference-view NDC with the target's intrinsics and
+    size, utils.py:252-253,288): they restate the same arithmetic for a target grid that differs from the source views
+    (BASELINE config 5); None reproduces the reference."""
+    Hr, Wr = (H, W) if ref_hw is None else ref_hw
+    inv_scale = torch.tensor([Wr - 1, Hr - 1], dtype=torch.float32)
     rays_o, rays_d, pix = get_rays_mvs(H, W, intrinsic, tgt_to_world, isRandom=False, chunk=chunk, idx=idx)
     n = pix.shape[-1]
     z = stratified_depths(near_fars[0], near_fars[1], n, N_samples, None)
     ro = rays_o.reshape(1, 3).expand(n, -1)
     pts = ro.unsqueeze(1) + z.unsqueeze(-1) * rays_d.unsqueeze(1)
-    ndc = get_ndc_coordinate(world_to_ref, intrinsic, pts, inv_scale, near=near_fars_ref[0, 0], far=near_fars_ref[0, 1], pad=pad)
+    ndc = get_ndc_coordinate(world_to_ref, intrinsic if ref_intrinsic is None else ref_intrinsic, pts, inv_scale,
+                             near=near_fars_ref[0, 0], far=near_fars_ref[0, 1], pad=pad)
     return pts, rays_d, ndc, z, ro
 
 

@@ -174,3 +174,36 @@ def test_finetune_step_trains_volume_and_mlp():
     assert float((ft.volume.feat_volume.detach() - v0).abs().max()) > 0            # the volume itself is being optimised
     assert ft.volume.feat_volume.shape == (1, 8, 16, 24, 32)
     assert "feat_volume" in ft.volume.state_dict()
+
+
+def test_render_view_target_grid_differs_from_sources():
+    """BASELINE config 5 shape of the problem (1008x756 rays over 960x640 sources), small: a target camera whose pixel
+    grid and intrinsics differ from the source views', rendered by one mvsnerf_render_pixels_fwd call, vs. the oracle."""
+    import numpy as np
+    from mvsnerf_amd import train
+    from oracle import mvsnerf_oracle as O
+    pad, S, D = 4, 24, 16
+    sys_, args, mlp_sd, mvs_sd = _system(pad, 256, S, D)
+    batch = train.synthetic_batch(64, 96, seed=8, rot_deg=2.0, smooth=True)
+    Ht, Wt = 76, 100
+    K_src = batch["intrinsics"][0, 0]
+    K_t = K_src.clone()
+    K_t[0] *= Wt / 96.0
+    K_t[1] *= Ht / 64.0
+    c2w_t = batch["c2ws"][0, -1].clone()
+    c2w_t[0, 3] += 0.03
+    target = {"hw": (Ht, Wt), "intrinsic": K_t, "c2w": c2w_t, "near_far": batch["near_fars"][0, -1]}
+    rgb, depth = sys_.render_view(batch, chunk=1024, target=target)
+    assert rgb.shape == (Ht, Wt, 3) and depth.shape == (Ht, Wt)
+
+    imgs_n = batch["images"]
+    pose = {k: batch[k][0] for k in ("w2cs", "c2ws", "intrinsics", "near_fars")}
+    vol, *_ = O.mvsnet_forward(imgs_n[:, :3], batch["proj_mats"][:, :3], batch["near_fars"][0, 0], mvs_sd, pad=pad, D=D)
+    raw_imgs = train.MVSSystem.unpreprocess(imgs_n)
+    pts, dirs, ndc, z, _ = O.build_rays_test(Ht, Wt, c2w_t, pose["w2cs"][0], K_t, pose["near_fars"], pose["near_fars"][-1], S, pad=pad,
+                                             ref_intrinsic=pose["intrinsics"][0], ref_hw=(64, 96))
+    ref = O.rendering(pose, pts, ndc, z, dirs, vol, raw_imgs[:, :3], mlp_sd)
+    mse = float(((rgb.cpu().reshape(-1, 3) - ref[0]) ** 2).mean())
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
+    assert psnr > 55.0, psnr
+    assert float((depth.cpu().reshape(-1) - ref[3]).abs().max()) < 5e-3
