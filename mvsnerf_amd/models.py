@@ -218,7 +218,7 @@ def create_nerf_mvs(args, pts_embedder=True, use_mvs=False, dir_embedder=True):
     EncodingNet = None
     if use_mvs:
         from .encoder import MVSNet
-        EncodingNet = MVSNet().to(device)
+        EncodingNet = MVSNet(n_views=getattr(args, "n_views", 3)).to(device)     # n_views: extension (config 4), default = reference
         grad_vars += list(EncodingNet.parameters())
 
     start = 0

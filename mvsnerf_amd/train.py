@@ -62,7 +62,8 @@ class MVSSystem(_ModuleShim):
     def __init__(self, args, n_depth_planes=128):
         super().__init__()
         self.args = args
-        self.args.feat_dim = 8 + 3 * 4                                   # :38
+        self.n_views = getattr(args, "n_views", 3)                       # extension (config 4: 5 views); the reference fixes 3
+        self.args.feat_dim = 8 + self.n_views * 4                        # :38
         self.idx = 0
         self.loss = SL1Loss()
         self.learning_rate = args.lrate
@@ -109,7 +110,8 @@ class MVSSystem(_ModuleShim):
         imgs, proj_mats = data_mvs["images"], data_mvs["proj_mats"]
         near_fars, depths_h = data_mvs["near_fars"], data_mvs["depths_h"]
 
-        volume_feature, _, _ = self.MVSNet(imgs[:, :3], proj_mats[:, :3], near_fars[0, 0], pad=args.pad)        # :113
+        nv = self.n_views
+        volume_feature, _, _ = self.MVSNet(imgs[:, :nv], proj_mats[:, :nv], near_fars[0, 0], pad=args.pad)      # :113
         imgs = self.unpreprocess(imgs)
         N_rays, N_samples = args.batch_size, args.N_samples
         rays_pts, rays_dir, target_s, rays_NDC, depth_candidates, rays_o, rays_depth, _ = build_rays(
