@@ -31,6 +31,12 @@ def _worker(rank, world, port, H, W, chunk, q):
     rgb, depth = D.render_frame(_fake_render(H, W, chunk), H, W, chunk)
     ids = torch.arange(H * W, dtype=torch.float32)
     ok_frame = torch.equal(rgb, torch.stack([ids, ids * 2, ids * 3], -1)) and torch.equal(depth, ids * 0.5)
+    # 1b. the same frame with one pixel-range call per rank (what MVSSystem.render_view issues: mvsnerf_render_pixels_fwd)
+    def render_range(first, n):
+        p = torch.arange(first, first + n, dtype=torch.float32)
+        return torch.stack([p, p * 2, p * 3], -1), p * 0.5
+    rgb2, depth2 = D.render_frame_pixels(render_range, H, W, chunk, device=torch.device("cpu"))
+    ok_frame = ok_frame and torch.equal(rgb2, rgb) and torch.equal(depth2, depth)
     # 2. row gather of a ray-sharded batch
     n = 1001
     sl = D.shard_rays(n, world, rank)
@@ -80,5 +86,7 @@ def test_shard_range_partitions():
 def test_single_process_paths():
     rgb, depth = D.render_frame(_fake_render(5, 6, 4), 5, 6, 4)
     assert rgb.shape == (30, 3) and depth.shape == (30,)
+    rgb2, depth2 = D.render_frame_pixels(lambda f, n: (torch.zeros(n, 3) + f, torch.zeros(n)), 5, 6, 4)
+    assert rgb2.shape == (30, 3) and depth2.shape == (30,)
     t = torch.ones(4, 2)
     assert D.all_gather_rows(t, 4) is t

@@ -1,0 +1,49 @@
+"""CPU-only: error behaviour of the boundary.  Argument validation happens before any launch, so the negative MVSNERF_E*
+codes can be exercised without a GPU; the Python layer must raise (never fall back) on a missing library, on host
+tensors and on unsupported shapes."""
+import ctypes
+
+import pytest
+import torch
+
+from mvsnerf_amd import _lib, ops
+
+EINVAL, EUNSUPPORTED, EALIGN = -1, -2, -3
+
+
+def test_c_abi_rejects_bad_arguments_without_launching():
+    l = _lib.lib()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.addressof(buf)
+    assert l.mvsnerf_volume_sample_fwd(0, 4, 4, 4, 8, p, 1, p, 8, 0) == EINVAL                # null volume
+    assert l.mvsnerf_volume_sample_fwd(p, 4, 4, 4, 8, p, -1, p, 8, 0) == EINVAL               # negative count
+    assert l.mvsnerf_volume_sample_fwd(p, 4, 4, 4, 8, p, 0, p, 8, 0) == 0                     # empty input is a no-op
+    assert l.mvsnerf_volume_sample_fwd(p, 4, 4, 4, 8, p, 1, p + 4, 8, 0) == EALIGN            # misaligned output row
+    assert l.mvsnerf_composite_fwd(0, p, 1, 4, 0, p, p, p, p, p, p, 0) == EINVAL
+    assert l.mvsnerf_composite_fwd(p, p, 0, 4, 0, p, p, p, p, p, p, 0) == 0
+    assert l.mvsnerf_mlp_fwd(p, 21, p, 3, p, 21, p, 3, 1, 1, 0, p, 0) == EUNSUPPORTED         # odd feat_dim
+    assert l.mvsnerf_conv3d_fwd(p, 0, 0, 0, 0, 0, 12, 12, 8, 8, 8, p, 8, 1, p, 0) == EUNSUPPORTED     # no kernel for 12->8
+    assert l.mvsnerf_conv3d_fwd(p, 0, 0, 0, 0, 0, 8, 8, 8, 8, 8, p, 16, 3, p, 0) == EUNSUPPORTED      # stride 3
+    assert l.mvsnerf_conv2d_fwd(p, p, 0, 8, 8, 1, 8, 8, p, 0, 8, 3, 1, p, 0) == EINVAL                 # scale without shift
+    assert l.mvsnerf_planesweep_costvar_fwd(p, 0, p, p, 3, 16, 8, 8, 4, 0, p, 16, p, 0, 0) == EUNSUPPORTED   # C != 32
+    assert l.mvsnerf_raymarch_fwd(None, 0) == EINVAL and l.mvsnerf_render_pixels_fwd(None, 0) == EINVAL
+    assert l.mvsnerf_render_workspace_floats(0, 128, 3) == 0
+    assert l.mvsnerf_tune(b"no_such_knob", 1) != 0
+
+
+def test_python_layer_raises_and_names_the_op():
+    with pytest.raises(RuntimeError, match="volume_sample_fwd failed: invalid argument"):
+        _lib.check(EINVAL, "volume_sample_fwd")
+    with pytest.raises(RuntimeError, match="hipError 719"):
+        _lib.check(719, "mlp_fwd")
+    with pytest.raises(RuntimeError, match="expected a contiguous float32 tensor on the GPU"):
+        ops.volume_sample(torch.zeros(4, 4, 4, 8), torch.zeros(2, 3))                         # host tensors: no CPU fallback
+    with pytest.raises(RuntimeError, match="feat_dim 21 unsupported"):
+        ops.mlp_pack([], [], 21)
+
+
+def test_missing_library_is_loud(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmvsnerf_hip.so")
+    with pytest.raises(RuntimeError, match="has no fallback"):
+        _lib.lib()
