@@ -301,6 +301,22 @@ typedef struct {
 } mvsnerf_raymarch_args;
 int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream);
 
+/* ---- importance sampling of the fine-tuning option --use_density_volume ----
+ * sample_pdf (data/ray_utils.py:96-139): bins[N][n_bins] ascending, weights[N][n_bins-1], u[N][n_importance] uniform draws
+ *   supplied by the caller (the reference draws them with torch.rand, :109) -> samples[N][n_importance].
+ * ray_marcher_fine (data/ray_utils.py:199-224): density[D][H][W]; ndc[N][S][3] reference-view NDC of the coarse samples;
+ *   z_vals[N][S] ascending; u[N][n_importance] -> z_out[N][S+n_importance] = sort(cat(sample_pdf(mid points, weights[1:-1]),
+ *   z_vals)).  The density lookup applies the reference's double [-1,1] mapping (:209-210) as is.  S, n_importance <= 512.
+ * ray_points: pts = o + d*z (rays_o [N][3], or one shared origin when o_is_per_ray == 0) and, when rays_ndc != NULL, their
+ *   NDC coordinates in the reference view (get_ndc_coordinate, utils.py:112-146; cameras are DEVICE pointers). */
+int mvsnerf_sample_pdf_fwd(const float* bins, const float* weights, const float* u, int64_t N, int n_bins, int n_importance,
+                           float* samples, void* stream);
+int mvsnerf_ray_marcher_fine_fwd(const float* density, int D, int H, int W, const float* ndc, const float* z_vals, const float* u,
+                                 int64_t N, int S, int n_importance, float* z_out, void* stream);
+int mvsnerf_ray_points_fwd(const float* rays_o, int o_is_per_ray, const float* rays_d, const float* z_vals,
+                           const float* w2c_ref, const float* K_ref, const float* near_far_ref, int W_ref, int H_ref, int pad, int lindisp,
+                           int64_t N, int S, float* rays_pts, float* rays_ndc, void* stream);
+
 /* Pixel-range render of one target view = the chunk loop of validation_step (train_mvs_nerf_pl.py:198-208:
  * build_rays_test utils.py:243-297 -> rendering renderer.py:138-165 per chunk) enqueued from one host call.
  * Renders row-major pixels [first_pixel, first_pixel + n_pixels) of a W_img x H_img target view in sub-batches of

@@ -75,6 +75,9 @@ SIGNATURES = {
     "mvsnerf_conv2d_wgrad": (_c_i, [_c_fp, _c_i] + [_c_fp] * 3 + [_c_i] * 9 + [_c_fp, _c_fp, _c_fp]),
     "mvsnerf_channel_sum_workspace_floats": (ctypes.c_size_t, [_c_i]),
     "mvsnerf_channel_sum": (_c_i, [_c_fp, _c_l, _c_i, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_sample_pdf_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_ray_marcher_fine_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_ray_points_fwd": (_c_i, [_c_fp, _c_i, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_l, _c_i, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_render_workspace_floats": (ctypes.c_size_t, [_c_i, _c_i, _c_i]),
     "mvsnerf_render_pixels_fwd": (_c_i, [ctypes.POINTER(RenderArgs), _c_fp]),
     "mvsnerf_gather_fwd": (_c_i, [_c_fp] + [_c_i] * 3 + [_c_fp] + [_c_i] * 3 + [_c_fp] * 4 + [_c_l, _c_i, _c_fp, _c_fp, _c_i, _c_fp, _c_fp]),

@@ -117,7 +117,8 @@ class Renderer_ours(nn.Module):
         pts, feat = pts.contiguous(), feat.contiguous()
         alpha_only = viewdirs is None
         F = feat.shape[-1]
-        dptr = 0 if alpha_only else ops.dev_f32(viewdirs.contiguous(), "viewdirs")
+        vd = None if alpha_only else viewdirs.contiguous()        # named: a temporary would be freed before the launch
+        dptr = 0 if alpha_only else ops.dev_f32(vd, "viewdirs")
         if ops.MLP_PRECISION == "bf16":
             return ops.mlp_forward_bf16(self.packed_bf16(F), self.packed(F), F, ops.dev_f32(pts, "pts"), 3, ops.dev_f32(feat, "feat"), F,
                                         dptr, 3, N, S, alpha_only, pts.device)

@@ -21,6 +21,20 @@ _cl_cache = {}
 FUSED_GATHER = True      # ops.raymarch: one gather launch (False: the three stand-alone lookups; same bits)
 
 
+class _Keep:
+    """Pointer helper for one C-ABI call: makes a tensor contiguous fp32 if needed and keeps that (possibly temporary) tensor
+    alive until the call has been issued - a temporary's block may otherwise be handed to the next temporary by the caching
+    allocator before the kernel is even enqueued."""
+
+    def __init__(self):
+        self.alive = []
+
+    def __call__(self, t, name):
+        t = t.to(torch.float32).contiguous()
+        self.alive.append(t)
+        return dev_f32(t, name)
+
+
 def channels_last_volume(volume_feature):
     """(1,C,D,H,W) reference-layout volume -> contiguous (D,H,W,C) tensor the kernels read.
     Zero-copy when the tensor is already channels_last_3d (what our MVSNet / RefVolume produce);
@@ -154,7 +168,7 @@ def raygen(H, W, K_tgt, c2w_tgt, K_ref, w2c_ref, nf_tgt, nf_ref, N_samples, pad=
     dirs = torch.empty((N, 3), **f32)
     z = torch.empty((N, N_samples), **f32)
     pix = torch.empty((2, N), **f32)
-    c = lambda t, name: dev_f32(t.contiguous(), name)
+    c = _Keep()
     check(_lib.lib().mvsnerf_raygen_fwd(0 if xs is None else c(xs, "xs"), 0 if ys is None else c(ys, "ys"), int(first_pixel), W, H,
                                         0 if ref_hw is None else int(ref_hw[1]), 0 if ref_hw is None else int(ref_hw[0]),
                                         c(K_tgt, "K_tgt"), c(c2w_tgt, "c2w_tgt"), c(K_ref, "K_ref"), c(w2c_ref, "w2c_ref"),
@@ -162,6 +176,47 @@ def raygen(H, W, K_tgt, c2w_tgt, K_ref, w2c_ref, nf_tgt, nf_ref, N_samples, pad=
                                         0 if t_rand is None else c(t_rand, "t_rand"), N, N_samples,
                                         pts.data_ptr(), dirs.data_ptr(), ndc.data_ptr(), z.data_ptr(), pix.data_ptr(), stream_ptr()), "raygen_fwd")
     return pts, dirs, ndc, z, pix
+
+
+def ray_points(rays_o, rays_d, z_vals, w2c_ref=None, K_ref=None, near_far_ref=None, ref_hw=None, pad=0, lindisp=False):
+    """pts = o + d*z (N,S,3) and, when the reference camera is given, their NDC coordinates (get_ndc_coordinate)."""
+    _need_no_grad(rays_o, rays_d, z_vals, op="ray_points")
+    N, S = z_vals.shape
+    dev = z_vals.device
+    c = _Keep()
+    per_ray = int(rays_o.dim() == 2 and rays_o.shape[0] == N and N > 1)
+    pts = torch.empty((N, S, 3), device=dev, dtype=torch.float32)
+    ndc = None if w2c_ref is None else torch.empty((N, S, 3), device=dev, dtype=torch.float32)
+    check(_lib.lib().mvsnerf_ray_points_fwd(c(rays_o.reshape(-1, 3), "rays_o"), per_ray, c(rays_d, "rays_d"), c(z_vals, "z_vals"),
+                                            0 if ndc is None else c(w2c_ref, "w2c_ref"), 0 if ndc is None else c(K_ref, "K_ref"),
+                                            0 if ndc is None else c(near_far_ref.reshape(-1)[:2], "near_far_ref"),
+                                            0 if ndc is None else int(ref_hw[1]), 0 if ndc is None else int(ref_hw[0]), int(pad), int(bool(lindisp)),
+                                            N, S, pts.data_ptr(), 0 if ndc is None else ndc.data_ptr(), stream_ptr()), "ray_points_fwd")
+    return pts, ndc
+
+
+def sample_pdf(bins, weights, u):
+    """data/ray_utils.py:96-139 with the uniform draws supplied: bins (N,nb), weights (N,nb-1), u (N,NI) -> (N,NI)."""
+    _need_no_grad(bins, weights, u, op="sample_pdf")
+    N, nb = bins.shape
+    out = torch.empty(tuple(u.shape), device=u.device, dtype=torch.float32)
+    c = _Keep()
+    check(_lib.lib().mvsnerf_sample_pdf_fwd(c(bins, "bins"), c(weights, "weights"), c(u, "u"),
+                                            N, nb, u.shape[1], out.data_ptr(), stream_ptr()), "sample_pdf_fwd")
+    return out
+
+
+def ray_marcher_fine_z(density_volume, rays_ndc, z_vals, u):
+    """data/ray_utils.py:207-219: density (D,H,W), ndc (N,S,3), z (N,S), u (N,NI) -> sorted depths (N,S+NI)."""
+    _need_no_grad(density_volume, rays_ndc, z_vals, u, op="ray_marcher_fine")
+    N, S = z_vals.shape
+    D, H, W = density_volume.shape
+    out = torch.empty((N, S + u.shape[1]), device=z_vals.device, dtype=torch.float32)
+    c = _Keep()
+    check(_lib.lib().mvsnerf_ray_marcher_fine_fwd(c(density_volume, "density_volume"), D, H, W, c(rays_ndc, "rays_ndc"),
+                                                  c(z_vals, "z_vals"), c(u, "u"), N, S, u.shape[1],
+                                                  out.data_ptr(), stream_ptr()), "ray_marcher_fine_fwd")
+    return out
 
 
 # ------------------------------------------------------------------ MLP
@@ -290,7 +345,7 @@ def render_pixels(vol_cl, imgs, w2cs, intrinsics, packed, H, W, K_tgt, c2w_tgt, 
     out = {"rgb": torch.empty((n, 3), **f32)}
     for k in ("depth", "acc", "disp"):
         out[k] = torch.empty((n,), **f32) if k in want else None
-    c = lambda t, name: dev_f32(t.contiguous(), name)
+    c = _Keep()
     a = _lib.RenderArgs(
         dev_f32(vol_cl, "volume"), D, Hv, Wv, channels_last_images(imgs).data_ptr(), V, imgs.shape[2], imgs.shape[3],
         c(w2cs, "w2cs"), c(intrinsics, "intrinsics"), packed.data_ptr(), 0 if packed_bf16 is None else packed_bf16.data_ptr(),

@@ -264,6 +264,31 @@ def ray_marcher(rays, N_samples=64, lindisp=False, perturb=0):
     return rays_o.unsqueeze(1) + rays_d.unsqueeze(1) * z.unsqueeze(2), rays_o, rays_d, z
 
 
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False, u=None):
+    """reference data/ray_utils.py:96-139.  The uniform draw stays here (torch.rand on the device like :109, or `u` supplied);
+    CDF construction + inversion is one HIP kernel (one wave per ray)."""
+    if pytest:
+        raise NotImplementedError("sample_pdf(pytest=True) overwrites u with numpy's RNG in the reference; pass u= instead")
+    shape = list(weights.shape[:-1]) + [N_samples]
+    if u is None:
+        u = (torch.linspace(0.0, 1.0, steps=N_samples, device=weights.device).expand(shape) if det
+             else torch.rand(shape, device=weights.device))
+    return ops.sample_pdf(bins.detach(), weights.detach(), u.contiguous())
+
+
+def ray_marcher_fine(rays, density_volume, z_vals, pts_NDC, N_importance=64, lindisp=False, u=None):
+    """reference data/ray_utils.py:199-224: importance samples from the density volume merged into the coarse depths.
+    Returns (xyz (N,S+NI,3), rays_o, rays_d, z_vals (N,S+NI)).  Density lookup, weights, sample_pdf and the sort are one
+    kernel; `u` is the torch.rand draw of sample_pdf (drawn here when not supplied)."""
+    rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
+    if u is None:
+        u = torch.rand((rays.shape[0], N_importance), device=rays.device)
+    with torch.no_grad():
+        z = ops.ray_marcher_fine_z(density_volume.detach(), pts_NDC.detach(), z_vals.detach(), u)
+        xyz, _ = ops.ray_points(rays_o, rays_d, z)
+    return xyz, rays_o, rays_d, z
+
+
 class MVSSystemFinetune(_ModuleShim):
     """reference train_mvs_nerf_finetuning_pl.py:32-189: the scene is encoded ONCE (`init_volume`), the 8-channel
     volume becomes a learnable `RefVolume` (checkpoint key `volume.feat_volume`) and only the ray march runs per step;
@@ -291,20 +316,47 @@ class MVSSystemFinetune(_ModuleShim):
         with torch.no_grad():                                             # init_volume :57-89
             vol, _, _ = self.MVSNet(imgs.to(dev), proj_mats.to(dev), self.near_far_source, pad=args.pad, lindisp=getattr(args, "use_disp", False))
         self.imgs = MVSSystem.unpreprocess(imgs.to(dev))
+        # importance sampling from a density volume (:73-86): voxel positions + per-voxel colour features, once per scene
+        self.density_volume = None
+        if getattr(args, "use_density_volume", False):
+            from .utils import get_ptsvolume, build_color_volume
+            Dv, Hv, Wv = vol.shape[-3:]
+            intrinsic, c2w = self.pose_source["intrinsics"][0].clone(), self.pose_source["c2ws"][0]
+            intrinsic[:2] /= 4
+            self.vox_pts = get_ptsvolume(Hv - 2 * args.pad, Wv - 2 * args.pad, Dv, args.pad, self.near_far_source, intrinsic, c2w).contiguous()
+            with torch.no_grad():
+                self.color_feature = build_color_volume(self.vox_pts, self.pose_source, self.imgs, with_mask=True)   # (D*H, W, 4V)
         self.volume = RefVolume(vol.detach())
         self.grad_vars = [p for p in self.network_fn.parameters()] + list(self.volume.parameters())    # MVSNet stays frozen here
         self._allreduce = None
+
+    def update_density_volume(self):
+        """:91-99: sigma of every voxel centre from the current volume + MLP (forward_alpha queries), -> (D,H,W)."""
+        from .renderer import render_density
+        with torch.no_grad():
+            Dv, Hv, Wv = self.volume.feat_volume.shape[-3:]
+            vol_cl = ops.channels_last_volume(self.volume.feat_volume.detach())                     # (D,H,W,8)
+            features = torch.cat((vol_cl.reshape(Dv * Hv, Wv, 8), self.color_feature), -1)           # = cat(...).permute(0,2,3,4,1) :96
+            self.density_volume = render_density(self.network_fn, self.vox_pts, features,
+                                                 self.render_kwargs_train["network_query_fn"]).reshape(Dv, Hv, Wv)
 
     def training_step(self, batch, batch_nb):
         """:140-189.  batch = {'rays': (1,B,8), 'rgbs': (1,B,3)} from the all-rays buffer."""
         args = self.args
         rays, target = batch["rays"].squeeze(0).to(self.imgs.device), batch["rgbs"].squeeze(0).to(self.imgs.device)
-        pts, rays_o, rays_d, z_vals = ray_marcher(rays, N_samples=args.N_samples, lindisp=getattr(args, "use_disp", False), perturb=args.perturb)
+        if getattr(args, "use_density_volume", False) and 0 == self.global_step % 200:              # :144-145
+            self.update_density_volume()
+        lindisp = getattr(args, "use_disp", False)
+        pts, rays_o, rays_d, z_vals = ray_marcher(rays, N_samples=args.N_samples, lindisp=lindisp, perturb=args.perturb)
         H, W = self.imgs.shape[-2:]
-        inv_scale = torch.tensor([W - 1, H - 1]).to(self.imgs.device)
-        from .utils import get_ndc_coordinate
-        ndc = get_ndc_coordinate(self.pose_source["w2cs"][0], self.pose_source["intrinsics"][0], pts, inv_scale,
-                                 near=self.near_far_source[0], far=self.near_far_source[1], pad=args.pad, lindisp=getattr(args, "use_disp", False))
+
+        def to_ndc(z):     # o + d*z and get_ndc_coordinate (:150-156) in one kernel
+            return ops.ray_points(rays_o, rays_d, z, self.pose_source["w2cs"][0], self.pose_source["intrinsics"][0], self.near_far_source,
+                                  ref_hw=(H, W), pad=args.pad, lindisp=lindisp)
+        pts, ndc = to_ndc(z_vals)
+        if self.density_volume is not None and getattr(args, "N_importance", 0) > 0:                # :158-163
+            pts, rays_o, rays_d, z_vals = ray_marcher_fine(rays, self.density_volume, z_vals, ndc, N_importance=args.N_importance)
+            pts, ndc = to_ndc(z_vals)
         rgbs, _, _, depth_pred, _, _ = rendering(args, self.pose_source, pts, ndc, z_vals, rays_o, rays_d, self.volume, self.imgs,
                                                  **self.render_kwargs_train)
         img_loss = img2mse(rgbs, target)

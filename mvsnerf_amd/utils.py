@@ -196,6 +196,23 @@ def build_color_volume(point_samples, pose_ref, imgs, img_feat=None, downscale=1
                             point_samples.contiguous(), with_mask=with_mask)
 
 
+def get_ptsvolume(H, W, D, pad, near_far, intrinsic, c2w):
+    """utils.py:338-355: world positions of the voxel centres of the (D, H+2p, W+2p) reference-frustum volume, as
+    (D*(H+2p), W+2p, 3).  Once-per-scene set-up arithmetic (host-side torch like the reference)."""
+    dev = intrinsic.device
+    near, far = near_far
+    corners = torch.tensor([[-pad, -pad, 1.0], [W + pad, -pad, 1.0], [-pad, H + pad, 1.0], [W + pad, H + pad, 1.0]], device=dev)
+    corners = torch.matmul(corners, torch.inverse(intrinsic).t())
+    xs_l = torch.linspace(float(corners[0, 0]), float(corners[1, 0]), W + 2 * pad)
+    ys_l = torch.linspace(float(corners[0, 1]), float(corners[2, 1]), H + 2 * pad)
+    ys, xs = torch.meshgrid(ys_l, xs_l, indexing="ij")
+    plane = torch.stack((xs, ys, torch.ones_like(xs)), dim=-1).to(dev)
+    lz = torch.linspace(1.0, 0.0, D).view(D, 1, 1, 1).to(dev)
+    pts = lz * (plane * near) + (1.0 - lz) * (plane * far)
+    pts = torch.matmul(pts.view(-1, 3), c2w[:3, :3].t()) + c2w[:3, 3].view(1, 3)
+    return pts.view(D * (H + pad * 2), W + pad * 2, 3)
+
+
 def normal_vect(vect, dim=-1):
     return vect / (torch.sqrt(torch.sum(vect ** 2, dim=dim, keepdim=True)) + 1e-7)
 

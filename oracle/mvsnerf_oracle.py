@@ -370,3 +370,71 @@ def rendering(pose_ref, rays_pts, rays_ndc, depth_candidates, rays_dir, volume, 
     raw = run_network_mvs(rays_ndc, angle, input_feat, sd)                   # :156
     rgb_map, _, _, weights, depth_map, alpha = raw2outputs(raw, depth_candidates, white_bkgd)  # :162
     return rgb_map, input_feat, weights, depth_map, alpha, {}, raw
+
+
+# --------------------------------------------------------------------------- importance sampling (fine-tuning option)
+
+def get_ptsvolume(H, W, D, pad, near_far, intrinsic, c2w):
+    """utils.py:338-355: world positions of the (D, H+2p, W+2p) voxel centres of the reference frustum volume."""
+    near, far = near_far
+    corners = torch.tensor([[-pad, -pad, 1.0], [W + pad, -pad, 1.0], [-pad, H + pad, 1.0], [W + pad, H + pad, 1.0]])
+    corners = torch.matmul(corners, torch.inverse(intrinsic).t())                 # :343
+    xs_l = torch.linspace(float(corners[0, 0]), float(corners[1, 0]), W + 2 * pad)
+    ys_l = torch.linspace(float(corners[0, 1]), float(corners[2, 1]), H + 2 * pad)
+    ys, xs = torch.meshgrid(ys_l, xs_l, indexing="ij")
+    plane = torch.stack((xs, ys, torch.ones_like(xs)), dim=-1)
+    near_plane, far_plane = plane * near, plane * far                             # :348-349
+    lz = torch.linspace(1.0, 0.0, D).view(D, 1, 1, 1)
+    pts = lz * near_plane + (1.0 - lz) * far_plane                                # :352
+    pts = torch.matmul(pts.view(-1, 3), c2w[:3, :3].t()) + c2w[:3, 3].view(1, 3)
+    return pts.view(D * (H + pad * 2), W + pad * 2, 3)
+
+
+def render_density(pts, feat, sd, chunk=1024 * 5):
+    """renderer.py:167-177: sigma-only MLP queries (forward_alpha); pts rows are embedded as they are (:172-174)."""
+    return torch.cat([run_network_mvs(pts[i:i + chunk], None, feat[i:i + chunk], sd) for i in range(0, pts.shape[0], chunk)])
+
+
+def ray_marcher(rays, N_samples=64, lindisp=False, perturb=0, perturb_rand=None):
+    """data/ray_utils.py:152-197 (bbox_3D=None).  rays (N,8) = [o | d | near | far]; perturb_rand = the torch.rand draw of :187."""
+    n = rays.shape[0]
+    rays_o, rays_d, near, far = rays[:, 0:3], rays[:, 3:6], rays[:, 6:7], rays[:, 7:8]
+    steps = torch.linspace(0, 1, N_samples)
+    z = near * (1 - steps) + far * steps if not lindisp else 1 / (1 / near * (1 - steps) + 1 / far * steps)
+    z = z.expand(n, N_samples)
+    if perturb > 0:
+        mid = 0.5 * (z[:, :-1] + z[:, 1:])
+        upper, lower = torch.cat([mid, z[:, -1:]], -1), torch.cat([z[:, :1], mid], -1)
+        z = lower + (upper - lower) * (perturb * perturb_rand)
+    return rays_o.unsqueeze(1) + rays_d.unsqueeze(1) * z.unsqueeze(2), rays_o, rays_d, z
+
+
+def sample_pdf(bins, weights, u):
+    """data/ray_utils.py:96-139 with the uniform draw `u` (N, N_importance) supplied (:105-109)."""
+    weights = weights + 1e-5                                                       # :99
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)                    # (N, len(bins))
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)                                  # :126
+    below = torch.clamp(inds - 1, min=0)
+    above = torch.clamp(inds, max=cdf.shape[-1] - 1)
+    cdf_b, cdf_a = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)
+    bins_b, bins_a = torch.gather(bins, 1, below), torch.gather(bins, 1, above)
+    denom = cdf_a - cdf_b
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)               # :135
+    t = (u - cdf_b) / denom
+    return bins_b + t * (bins_a - bins_b)
+
+
+def ray_marcher_fine(rays, density_volume, z_vals, pts_NDC, u):
+    """data/ray_utils.py:199-224.  Note the reference's double transform: pts_NDC*2-1 is handed to index_point_feature,
+    which maps to [-1,1] once more (:209-210) - restated as is.  u: the torch.rand draw inside sample_pdf."""
+    rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
+    sigma = index_point_feature(density_volume[None, None], pts_NDC * 2 - 1.0)[..., 0]
+    alpha = 1.0 - torch.exp(-torch.relu(sigma))
+    weights = alpha * torch.cumprod(torch.cat([torch.ones(alpha.shape[0], 1), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]
+    z_mid = 0.5 * (z_vals[:, :-1] + z_vals[:, 1:])
+    z_samples = sample_pdf(z_mid, weights[:, 1:-1], u)
+    z = torch.sort(torch.cat([z_samples, z_vals], -1), -1)[0]
+    return rays_o.unsqueeze(1) + rays_d.unsqueeze(1) * z.unsqueeze(2), rays_o, rays_d, z

@@ -127,6 +127,26 @@ def reference_args(**over):
     return types.SimpleNamespace(**d)
 
 
+def load_reference_ray_utils():
+    """data/ray_utils.py of the real reference (ray_marcher, ray_marcher_fine, sample_pdf).  Loaded from its file so that
+    data/__init__.py (dataset classes, PIL/cv2 readers) is not executed; it star-needs `renderer` and `utils` by name."""
+    import importlib.util
+    ref_models, ref_renderer, ref_utils = load_reference()
+    saved = {n: sys.modules.get(n) for n in ("renderer", "utils")}
+    sys.modules["renderer"], sys.modules["utils"] = ref_renderer, ref_utils
+    try:
+        spec = importlib.util.spec_from_file_location("ref_ray_utils", os.path.join(REF_ROOT, "data", "ray_utils.py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+    finally:
+        for n, v in saved.items():
+            if v is None:
+                sys.modules.pop(n, None)
+            else:
+                sys.modules[n] = v
+    return m
+
+
 def load_reference_networks(args=None, ckpt=os.path.join(REF_ROOT, "ckpts/mvsnerf-v0.tar")):
     """create_nerf_mvs(use_mvs=True, dir_embedder=False, pts_embedder=True) as train_mvs_nerf_pl.py:45."""
     ref_models, _, _ = load_reference()
