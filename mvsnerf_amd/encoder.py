@@ -561,16 +561,17 @@ def homo_warp(src_feat, proj_mat, depth_values, src_grid=None, pad=0):
         raise RuntimeError("homo_warp: batch must be 1")
     Hp, Wp = H + 2 * pad, W + 2 * pad
     dev = src_feat.device
+    keep = ops._Keep()          # contiguous copies (if any were needed) stay alive until the launch is issued
     if src_grid is None:
         D = depth_values.shape[1]
         grid_in, grid_out = 0, torch.empty((1, D, Wp, Hp, 2), device=dev, dtype=torch.float32)
-        proj_p, dep_p = dev_f32(proj_mat[0].contiguous(), "proj_mat"), dev_f32(depth_values[0].contiguous(), "depth_values")
+        proj_p, dep_p = keep(proj_mat[0], "proj_mat"), keep(depth_values[0], "depth_values")
     else:
         D = src_grid.shape[1]
-        grid_in, grid_out = dev_f32(src_grid.contiguous(), "src_grid"), src_grid
+        grid_in, grid_out = keep(src_grid, "src_grid"), src_grid
         proj_p = dep_p = 0
     warped = torch.empty((1, C, D, Hp, Wp), device=dev, dtype=torch.float32)
-    check(_lib.lib().mvsnerf_homo_warp_fwd(dev_f32(src_feat.contiguous(), "src_feat"), proj_p, dep_p, grid_in, C, H, W, D, pad,
+    check(_lib.lib().mvsnerf_homo_warp_fwd(keep(src_feat, "src_feat"), proj_p, dep_p, grid_in, C, H, W, D, pad,
                                            warped.data_ptr(), 0 if src_grid is not None else grid_out.data_ptr(), stream_ptr()), "homo_warp_fwd")
     return warped, grid_out
 
