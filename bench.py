@@ -334,6 +334,27 @@ def main():
                                        "mlp_tflops_equiv": round(FLOP_PER_SAMPLE * P / (t_b * 1e-3) / 1e12, 1),
                                        "psnr_vs_fp32_path_db": round(10 * math.log10(1.0 / max(mse_b, 1e-20)), 1),
                                        "note": "v_mfma_f32_32x32x16_bf16, fp32 accumulate; opt-in via ops.set_mlp_precision('bf16')"}
+            # (iv) opt-in split-bf16 fp32 emulation ("bf16x6"): fp32-grade results on the bf16 matrix cores; NOT the headline
+            ops.set_mlp_precision("bf16x6")
+            try:
+                with torch.no_grad():
+                    for i in range(10):
+                        step(i)
+                    torch.cuda.synchronize(); b0 = time.perf_counter()
+                    for i in range(100):
+                        step(i)
+                    torch.cuda.synchronize(); xdt = (time.perf_counter() - b0) / 100
+                    gx = step(0)
+                    ps, ns = net.packed_split(F, 3)
+                    t_x = event_time(lambda: lib.mvsnerf_mlp_fwd_split(ps.data_ptr(), packed.data_ptr(), F, ns, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3,
+                                                                       N_RAYS, N_SAMPLES, 0, raw.data_ptr(), st().cuda_stream), 100)
+            finally:
+                ops.set_mlp_precision("fp32")
+            extras["bf16x6_mlp_mode"] = {"rays_per_s": round(N_RAYS / xdt, 1), "ms_per_step": round(xdt * 1e3, 4), "mlp_kernel_ms": round(t_x, 4),
+                                         "mlp_tflops_fp32_equiv": round(FLOP_PER_SAMPLE * P / (t_x * 1e-3) / 1e12, 1),
+                                         "max_abs_rgb_diff_vs_fp32_path": float((gx[0] - g32[0]).abs().max()),
+                                         "note": "fp32 operands split into 3 bf16 pieces, 6 v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate: meets the "
+                                                 "same 1e-4 parity bound as the fp32-MFMA kernel (tests/test_gpu_raymarch.py); opt-in via ops.set_mlp_precision('bf16x6')"}
         print(json.dumps({
             "metric": "rendered rays/sec (1024-ray batch, 128 samples)", "value": round(rays_per_s, 1), "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),

@@ -298,8 +298,20 @@ typedef struct {
     const void* packed_mlp_bf16;            /* NULL: fp32-MFMA MLP (default); else the bf16-MFMA variant is used (ABI v2) */
     const float* imgs_nhwc4;                /* NULL: three gather launches from `imgs` (NCHW); else [V][IH][IW][4] copies of the
                                                same images and ONE fused gather launch (mvsnerf_gather_fwd) (ABI v3) */
+    const void* packed_mlp_split; int n_split;   /* NULL/0, or mvsnerf_mlp_pack_split output: split-bf16 MLP (ABI v5) */
 } mvsnerf_raymarch_args;
 int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream);
+
+/* Split-bf16 MLP ("bf16x3" n_split = 2, "bf16x6" n_split = 3; n_split = 1 is plain bf16 on the same kernel): every fp32
+ * operand is the sum of n_split bf16 pieces and a product is accumulated in fp32 from the piece products of combined order
+ * < n_split, so n_split = 3 reproduces fp32 products to ~2^-24 on the bf16 matrix cores at 6/16 of the fp32-MFMA time
+ * (the technique BLAS libraries ship as "BF16x9/x6 FP32 emulation").  Same arguments and results layout as mvsnerf_mlp_fwd;
+ * `packed_f32` (mvsnerf_mlp_pack) supplies the fp32 bias / head vectors.  Opt-in: the default path is the fp32 MFMA kernel. */
+size_t mvsnerf_mlp_packed_split_elems(int F, int n_split);
+int mvsnerf_mlp_pack_split(const float* const w[11], int F, int n_split, void* packed_split, void* stream);
+int mvsnerf_mlp_fwd_split(const void* packed_split, const float* packed_f32, int F, int n_split, const float* ndc, int ndc_stride,
+                          const float* feat, int feat_stride, const float* dirs, int dirs_stride,
+                          int64_t N, int S, int alpha_only, float* raw, void* stream);
 
 /* ---- importance sampling of the fine-tuning option --use_density_volume ----
  * sample_pdf (data/ray_utils.py:96-139): bins[N][n_bins] ascending, weights[N][n_bins-1], u[N][n_importance] uniform draws
@@ -339,6 +351,7 @@ typedef struct {
     int S, white_bkgd, batch_rays;
     float* workspace; size_t workspace_floats;
     float* rgb; float* depth; float* acc; float* disp;      /* rgb required, others may be NULL */
+    const void* packed_mlp_split; int n_split;              /* NULL/0, or mvsnerf_mlp_pack_split output (ABI v5) */
 } mvsnerf_render_args;
 size_t mvsnerf_render_workspace_floats(int batch_rays, int S, int V);
 int mvsnerf_render_pixels_fwd(const mvsnerf_render_args* a, void* stream);

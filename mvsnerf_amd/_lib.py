@@ -28,7 +28,7 @@ class RaymarchArgs(ctypes.Structure):
         ("N", _c_l), ("S", _c_i), ("white_bkgd", _c_i),
         ("dirs_tmp", _c_fp), ("input_feat", _c_fp), ("raw", _c_fp),
         ("rgb_map", _c_fp), ("disp", _c_fp), ("acc", _c_fp), ("weights", _c_fp), ("depth", _c_fp), ("alpha", _c_fp),
-        ("packed_mlp_bf16", _c_fp), ("imgs_nhwc4", _c_fp),
+        ("packed_mlp_bf16", _c_fp), ("imgs_nhwc4", _c_fp), ("packed_mlp_split", _c_fp), ("n_split", _c_i),
     ]
 
 
@@ -43,7 +43,7 @@ class RenderArgs(ctypes.Structure):
         ("first_pixel", _c_l), ("n_pixels", _c_l),
         ("S", _c_i), ("white_bkgd", _c_i), ("batch_rays", _c_i),
         ("workspace", _c_fp), ("workspace_floats", ctypes.c_size_t),
-        ("rgb", _c_fp), ("depth", _c_fp), ("acc", _c_fp), ("disp", _c_fp),
+        ("rgb", _c_fp), ("depth", _c_fp), ("acc", _c_fp), ("disp", _c_fp), ("packed_mlp_split", _c_fp), ("n_split", _c_i),
     ]
 
 
@@ -90,6 +90,9 @@ SIGNATURES = {
     "mvsnerf_mlp_packed_floats": (ctypes.c_size_t, [_c_i]),
     "mvsnerf_mlp_pack": (_c_i, [ctypes.POINTER(_c_fp), ctypes.POINTER(_c_fp), _c_i, _c_fp, _c_fp]),
     "mvsnerf_mlp_fwd": (_c_i, [_c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_mlp_packed_split_elems": (ctypes.c_size_t, [_c_i, _c_i]),
+    "mvsnerf_mlp_pack_split": (_c_i, [ctypes.POINTER(_c_fp), _c_i, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_mlp_fwd_split": (_c_i, [_c_fp, _c_fp, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp]),
     "mvsnerf_mlp_packed_bf16_elems": (ctypes.c_size_t, [_c_i]),
     "mvsnerf_mlp_pack_bf16": (_c_i, [ctypes.POINTER(_c_fp), _c_i, _c_fp, _c_fp]),
     "mvsnerf_mlp_fwd_bf16": (_c_i, [_c_fp, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp]),

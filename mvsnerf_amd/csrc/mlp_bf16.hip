@@ -300,6 +300,320 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_bf16_kernel(
     }
 }
 
+
+// ==========================================================================================================
+// Split-bf16 variant ("bf16x6"): fp32-grade results from the bf16 matrix cores.
+// Every fp32 operand is written as the sum of NS bf16 pieces (x = x0 + x1 + x2, each piece the bf16 rounding of what is left),
+// and a product a*w is accumulated (in fp32, by the MFMA) from the piece products whose combined order is < NS:
+//   NS = 3:  a0w0 + a0w1 + a1w0 + a1w1 + a0w2 + a2w0      (dropped terms are <= 2^-24 relative)   -> 6 MFMAs per k-step
+//   NS = 2:  a0w0 + a0w1 + a1w0                            (<= 2^-16)                              -> 3 MFMAs
+//   NS = 1:  plain bf16                                                                             -> 1 MFMA
+// 6 bf16 MFMAs cost 6/16 of one fp32 MFMA k-step's time for the same inputs.  Weights are split at pack time (NS planes),
+// activations in the layer epilogue (v_cvt_pk_bf16_f32 + subtract).  Weight planes stream through LDS in slabs of two
+// k-steps (NS * 8 KB for a 128-wide layer), double-buffered by LDS-DMA, in exactly the order the kernel consumes them, so the
+// stream is one running pointer.  Everything outside the GEMMs (positional encoding, bias modulation, ReLU, heads) is fp32.
+// ==========================================================================================================
+__host__ __device__ constexpr int sp_slab_elems(int ns, int nb) { return ns * 2 * nb * 64 * 8; }
+__host__ __device__ inline int sp_slabs(int steps) { return (steps + 1) / 2; }
+__host__ __device__ inline size_t sp_total_elems(int ns, int F)
+{
+    (void)F;
+    return (size_t)(2 + 2 + 4 * 4 + 2 + 4 + 4) * sp_slab_elems(ns, 4) + (size_t)5 * sp_slab_elems(ns, 2);
+}
+
+__device__ inline void pack_split_segment(__bf16* __restrict__ dst, const float* __restrict__ W, int ld, int col_off, int kmap,
+                                          int steps, int nb, int ns, int F, int tid, int nthreads)
+{
+    const int slabs = sp_slabs(steps);
+    const int per_slab = sp_slab_elems(ns, nb);
+    const int total = slabs * per_slab;
+    for (int i = tid; i < total; i += nthreads) {
+        const int sl = i / per_slab, r = i - sl * per_slab;
+        const int j = r & 7, lane = (r >> 3) & 63, rest = r >> 9;                // rest = (plane*2 + s_local)*nb + b
+        const int b = rest % nb, ps = rest / nb, s_local = ps & 1, plane = ps >> 1;
+        const int st = 2 * sl + s_local;
+        const int col = st < steps ? b_col(kmap, 8 * st + j, lane >> 5, F) : -1;
+        float w = col < 0 ? 0.0f : W[(size_t)(b * 32 + (lane & 31)) * ld + col_off + col];
+        __bf16 piece = (__bf16)w;
+        for (int k = 0; k < plane; ++k) { w -= (float)piece; piece = (__bf16)w; }
+        dst[i] = piece;
+    }
+}
+
+__global__ __launch_bounds__(256) void mlp_pack_split_kernel(PackBArgs a, int ns, __bf16* __restrict__ packed)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    const size_t s4 = sp_slab_elems(ns, 4);
+    size_t o = 0;
+    pack_split_segment(packed + o, a.w[6], a.F, 0, K_FEAT, 4, 4, ns, a.F, tid, nt);                         o += 2 * s4;   // always 2 slabs (zero-padded)
+    pack_split_segment(packed + o, a.w[0], PE_DIM, 0, K_PE, B_PE_STEPS, 4, ns, a.F, tid, nt);               o += 2 * s4;
+    for (int l = 1; l <= 4; ++l) { pack_split_segment(packed + o, a.w[l], WIDTH, 0, K_ACT, B_ACT_STEPS, 4, ns, a.F, tid, nt); o += 4 * s4; }
+    pack_split_segment(packed + o, a.w[5], WIDTH + PE_DIM, 0, K_PE, B_PE_STEPS, 4, ns, a.F, tid, nt);       o += 2 * s4;
+    pack_split_segment(packed + o, a.w[5], WIDTH + PE_DIM, PE_DIM, K_ACT, B_ACT_STEPS, 4, ns, a.F, tid, nt); o += 4 * s4;
+    pack_split_segment(packed + o, a.w[7], WIDTH, 0, K_ACT, B_ACT_STEPS, 4, ns, a.F, tid, nt);              o += 4 * s4;
+    pack_split_segment(packed + o, a.w[9], WIDTH + 3, 0, K_VIEWS, B_VIEW_STEPS, 2, ns, a.F, tid, nt);
+}
+
+__host__ __device__ constexpr int split_nbuf(int ns) { return ns == 3 ? 2 : 3; }
+
+template <int NS> struct Pieces { bf16x8 p[NS]; };
+
+template <int NS>
+__device__ __forceinline__ Pieces<NS> split8(const float* v)
+{
+    Pieces<NS> r;
+    float rem[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rem[j] = v[j];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const __bf16 h = (__bf16)rem[j];
+            r.p[k][j] = h;
+            if (k + 1 < NS) rem[j] -= (float)h;
+        }
+    }
+    return r;
+}
+
+// Slab stream: slab k of the packed buffer lives in buf[k % 3]; while slab k is consumed, slabs k+1 and k+2 are in flight
+// (a slab is only 2 k-steps = ~1500 MFMA cycles of work per wave, less than the L2 latency of its own DMA, so a prefetch
+// distance of one slab would expose that latency 35 times per tile).
+struct SlabStream {
+    const char* g;          // next slab to fetch
+    char* base; int stride; // buffer i = base + i*stride, i in 0..nbuf-1
+    int cur;                // buffer `cur`: the slab about to be consumed
+    int nbuf;               // 3: two slabs in flight (one workgroup per CU); 2: one in flight (two workgroups per CU cover for each other)
+    __device__ __forceinline__ char* buf(int i) const { return base + i * stride; }
+    __device__ __forceinline__ void prefetch(int bytes, int wave, int lane)
+    {
+        int into = cur + nbuf - 1; if (into >= nbuf) into -= nbuf;
+        if (bytes > 0) slabb_dma(buf(into), reinterpret_cast<const __bf16*>(g), (size_t)bytes >> 1, wave, lane);
+        g += bytes;
+    }
+};
+
+// wait until at most `newer` of this wave's DMA instructions are outstanding (= the slab about to be used has landed), then
+// make it visible to / release the oldest buffer from all four waves
+template <int NEWER>
+__device__ __forceinline__ void slab_wait()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER) : "memory");
+    __syncthreads();
+}
+
+// One segment = SLABS slabs of two k-steps each.  ahead1 / ahead2: byte sizes of the first and second slab AFTER this segment
+// (0 = end of the stream); they decide what is prefetched and how many newer DMA instructions may stay in flight.
+template <int NS, int SLABS, int NBLK, int AHEAD1, int AHEAD2, int VALU_PER_MFMA, typename BFN>
+__device__ __forceinline__ void run_segment(SlabStream& st, f32x16 (&acc)[NBLK], int wave, int lane, BFN bfn)
+{
+    constexpr int SLAB_BYTES = sp_slab_elems(NS, NBLK) * 2;
+    constexpr int NPROD = NS == 3 ? 6 : (NS == 2 ? 3 : 1);
+    constexpr bool LEAN = NS == 3;
+    constexpr int NBUF = split_nbuf(NS);
+    // the B pieces of k-step s+1 are produced (VALU) while the MFMAs of k-step s issue: a wave issues in order, so the
+    // split/encoding work only overlaps the matrix pipe if it sits BETWEEN the MFMAs in program order
+    Pieces<NS> cur = bfn(0);
+#pragma unroll
+    for (int sl = 0; sl < SLABS; ++sl) {
+        const int nxt1 = sl + 1 < SLABS ? SLAB_BYTES : AHEAD1;                       // slab k+1
+        const int nxt2 = sl + 2 < SLABS ? SLAB_BYTES : (sl + 1 < SLABS ? AHEAD1 : AHEAD2);   // slab k+2
+        if (NBUF == 2) {
+            slab_wait<0>();                          // slab k has landed; k+1 is requested now
+            st.prefetch(nxt1, wave, lane);
+        } else {
+            // slab k+1 was requested one step ago and may stay in flight: its DMA instructions per wave = bytes / 1 KB / 4 waves
+            if (nxt1 == 0) slab_wait<0>();
+            else if (nxt1 / 4096 == 2 * NS) slab_wait<2 * NS>();
+            else slab_wait<NS>();
+            st.prefetch(nxt2, wave, lane);
+        }
+        const char* w = st.buf(st.cur);
+#pragma unroll
+        for (int s_local = 0; s_local < 2; ++s_local) {
+            const int s = 2 * sl + s_local;
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // piece products, smallest first
+            if (LEAN) {
+                // two waves per SIMD (the other wave's MFMAs cover this wave's VALU work): keep the register footprint minimal
+                const Pieces<NS> b = s == 0 ? cur : bfn(s);
+#pragma unroll
+                for (int nb = 0; nb < NBLK; nb += 2) {           // two accumulators alternate: consecutive MFMAs are independent
+                    bf16x8 a[NS][2];
+#pragma unroll
+                    for (int k = 0; k < NS; ++k)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            a[k][e] = *reinterpret_cast<const bf16x8*>(w + ((((k * 2 + s_local) * NBLK) + nb + e) * 64 + lane) * 16);
+#pragma unroll
+                    for (int pr = 6 - NPROD; pr < 6; ++pr)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            acc[nb + e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[pr] < NS ? PA[pr] : 0][e], b.p[PB[pr] < NS ? PB[pr] : 0], acc[nb + e], 0, 0, 0);
+                }
+            } else {
+                Pieces<NS> nxt = cur;
+                if (s + 1 < 2 * SLABS) nxt = bfn(s + 1);
+                bf16x8 a[NS][NBLK];
+#pragma unroll
+                for (int k = 0; k < NS; ++k)
+#pragma unroll
+                    for (int nb = 0; nb < NBLK; ++nb)
+                        a[k][nb] = *reinterpret_cast<const bf16x8*>(w + ((((k * 2 + s_local) * NBLK) + nb) * 64 + lane) * 16);
+                // the NBLK accumulators rotate so that consecutive MFMAs are independent
+#pragma unroll
+                for (int pr = 6 - NPROD; pr < 6; ++pr)
+#pragma unroll
+                    for (int nb = 0; nb < NBLK; ++nb)
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[pr] < NS ? PA[pr] : 0][nb], cur.p[PB[pr] < NS ? PB[pr] : 0], acc[nb], 0, 0, 0);
+                cur = nxt;
+            }
+        }
+        st.cur = st.cur + 1 == NBUF ? 0 : st.cur + 1;
+    }
+}
+
+template <int NS, bool ALPHA_ONLY>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_split_kernel(
+    const __bf16* __restrict__ wq, const float* __restrict__ packed_f32, int F, const float* __restrict__ ndc, int ndc_stride,
+    const float* __restrict__ feat, int feat_stride, const float* __restrict__ dirs, int dirs_stride,
+    int64_t P, int S, float* __restrict__ raw)
+{
+    constexpr int SB4 = sp_slab_elems(NS, 4) * 2, SB2 = sp_slab_elems(NS, 2) * 2;      // slab bytes for 4 / 2 output blocks
+    extern __shared__ __attribute__((aligned(16))) char lds_s[];
+    constexpr int NBUF = split_nbuf(NS);
+    float* vec = reinterpret_cast<float*>(lds_s + NBUF * SB4);
+    const Layout LF = layout(F);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int64_t p_raw = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+    const bool live = p_raw < P;
+    const int64_t p = live ? p_raw : P - 1;
+
+    // stream order (sizes are static: the pts_bias segment is always packed as 2 slabs): 30 slabs of SB4, then 5 of SB2
+    SlabStream st{reinterpret_cast<const char*>(wq), lds_s, SB4, 1, NBUF};
+    st.prefetch(SB4, wave, lane);                 // slab 0 -> buffer 0   (cur = 1: the prefetch target cur+NBUF-1 wraps to 0)
+    if (NBUF == 3) {
+        st.cur = 2;
+        st.prefetch(SB4, wave, lane);             // slab 1 -> buffer 1
+    }
+    st.cur = 0;
+    for (int i = tid; i < V_TOTAL; i += 256) vec[i] = packed_f32[LF.vec + i];
+    const float px = ndc[p * ndc_stride + 0], py = ndc[p * ndc_stride + 1], pz = ndc[p * ndc_stride + 2];
+    float fv[32];
+    {
+        const float* fp = feat + p * feat_stride + half * (F / 2);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) fv[i] = i < F / 2 ? fp[i] : 0.0f;
+    }
+    auto pe_b = [&](int s) {
+        float t8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t8[j] = pe_op(8 * s + j, half, px, py, pz);
+        return split8<NS>(t8);
+    };
+    float bias[64];
+    // the activations stay fp32 in registers and are split into bf16 pieces per k-step inside the GEMM loop (each value is
+    // split once per layer either way; holding NS planes instead would cost 32*NS registers and spill at two waves per SIMD)
+    float h[64];
+    auto hb = [&](int s) { return split8<NS>(h + 8 * (s & 7)); };
+    auto finish = [&](f32x16 (&acc)[4], bool relu, bool mod) {
+#pragma unroll
+        for (int q = 0; q < 64; ++q) {
+            float v = acc[q >> 4][q & 15];
+            if (mod) v *= bias[q];
+            h[q] = relu ? fmaxf(v, 0.0f) : v;
+        }
+    };
+    {   // bias = pts_bias(feat)
+        f32x16 acc[4];
+        init_acc_b<4>(acc, vec + V_BIASG + half * 64);
+        run_segment<NS, 2, 4, SB4, SB4, 3>(st, acc, wave, lane, [&](int s) { return split8<NS>(fv + 8 * (s & 3)); });
+#pragma unroll
+        for (int q = 0; q < 64; ++q) bias[q] = acc[q >> 4][q & 15];
+    }
+    {   // layer 0
+        f32x16 acc[4];
+        init_acc_b<4>(acc, vec + V_L0 + half * 64);
+        run_segment<NS, 2, 4, SB4, SB4, 10>(st, acc, wave, lane, pe_b);
+        finish(acc, true, true);
+    }
+#pragma unroll 1
+    for (int layer = 1; layer <= 4; ++layer) {
+        f32x16 acc[4];
+        init_acc_b<4>(acc, vec + V_L0 + 128 * layer + half * 64);
+        run_segment<NS, 4, 4, SB4, SB4, 3>(st, acc, wave, lane, hb);
+        finish(acc, true, true);
+    }
+    float sigma;
+    {   // layer 5 on cat([pts, h4]); the positional encoding is recomputed instead of held in 16*NS registers since layer 0
+        f32x16 acc[4];
+        init_acc_b<4>(acc, vec + V_L0 + 128 * 5 + half * 64);
+        run_segment<NS, 2, 4, SB4, SB4, 10>(st, acc, wave, lane, pe_b);
+        run_segment<NS, 4, 4, ALPHA_ONLY ? 0 : SB4, ALPHA_ONLY ? 0 : SB4, 3>(st, acc, wave, lane, hb);
+        const float* wa = vec + V_WA + half * 64;
+        float part = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 64; ++q) part = fmaf(wa[q], fmaxf(acc[q >> 4][q & 15] * bias[q], 0.0f), part);
+        part += __shfl_xor(part, 32);
+        sigma = fmaxf(part + vec[V_BA], 0.0f);
+        if (!ALPHA_ONLY) finish(acc, true, true);
+    }
+    if (ALPHA_ONLY) {
+        if (live && half == 0) raw[p_raw] = sigma;
+        return;
+    }
+    {   // feature_linear (no activation)
+        f32x16 acc[4];
+        init_acc_b<4>(acc, vec + V_FEAT + half * 64);
+        run_segment<NS, 4, 4, SB2, SB2, 3>(st, acc, wave, lane, hb);
+        finish(acc, false, false);
+    }
+    {   // views_linears[0] + rgb head
+        const int64_t ray = p / S;
+        float dl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        dl[0] = half ? dirs[ray * dirs_stride + 1] : dirs[ray * dirs_stride + 0];
+        dl[1] = half ? 0.0f : dirs[ray * dirs_stride + 2];
+        const Pieces<NS> d8 = split8<NS>(dl);
+        const float zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const Pieces<NS> z8 = split8<NS>(zero8);
+        f32x16 acc[2];
+        init_acc_b<2>(acc, vec + V_VIEWS + half * 32);
+        run_segment<NS, 5, 2, 0, 0, 6>(st, acc, wave, lane, [&](int s) { return s < 8 ? hb(s) : (s == 8 ? d8 : z8); });
+        float rgb[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* wr = vec + V_WR + c * 64 + half * 32;
+            float part = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) part = fmaf(wr[q], fmaxf(acc[q >> 4][q & 15], 0.0f), part);
+            part += __shfl_xor(part, 32);
+            rgb[c] = 1.0f / (1.0f + expf(-(part + vec[V_BR + c])));
+        }
+        if (live && half == 0) *reinterpret_cast<f32x4*>(raw + p_raw * 4) = f32x4{rgb[0], rgb[1], rgb[2], sigma};
+    }
+}
+
+template <int NS>
+int launch_split(const __bf16* wq, const float* packed_f32, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
+                 const float* dirs, int dirs_stride, int64_t P, int S, int alpha_only, float* raw, hipStream_t st)
+{
+    constexpr int LDS = split_nbuf(NS) * sp_slab_elems(NS, 4) * 2 + V_TOTAL * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_split_kernel<NS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_split_kernel<NS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    if (alpha_only)
+        mlp_fwd_split_kernel<NS, true><<<mvs_cdiv(P, 128), 256, LDS, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
+    else
+        mlp_fwd_split_kernel<NS, false><<<mvs_cdiv(P, 128), 256, LDS, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" size_t mvsnerf_mlp_packed_bf16_elems(int F)
@@ -344,6 +658,48 @@ extern "C" int mvsnerf_mlp_fwd_bf16(const void* packed_bf16, const float* packed
         mlp_fwd_bf16_kernel<true><<<mvs_cdiv(P, 128), 256, B_LDS_BYTES, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
     else
         mlp_fwd_bf16_kernel<false><<<mvs_cdiv(P, 128), 256, B_LDS_BYTES, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+extern "C" size_t mvsnerf_mlp_packed_split_elems(int F, int n_split)
+{
+    if (F < 2 || F > MAX_F || (F & 1) || n_split < 1 || n_split > 3) return 0;
+    return sp_total_elems(n_split, F);
+}
+
+extern "C" int mvsnerf_mlp_pack_split(const float* const w[11], int F, int n_split, void* packed_split, void* stream)
+{
+    if (!w || !packed_split) return MVSNERF_EINVAL;
+    if (F < 2 || F > MAX_F || (F & 1) || n_split < 1 || n_split > 3) return MVSNERF_EUNSUPPORTED;
+    if (!mvs_aligned16(packed_split)) return MVSNERF_EALIGN;
+    PackBArgs a;
+    for (int i = 0; i < 11; ++i) { if (!w[i]) return MVSNERF_EINVAL; a.w[i] = w[i]; }
+    a.F = F;
+    mlp_pack_split_kernel<<<64, 256, 0, (hipStream_t)stream>>>(a, n_split, reinterpret_cast<__bf16*>(packed_split));
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+extern "C" int mvsnerf_mlp_fwd_split(const void* packed_split, const float* packed_f32, int F, int n_split, const float* ndc, int ndc_stride,
+                                     const float* feat, int feat_stride, const float* dirs, int dirs_stride,
+                                     int64_t N, int S, int alpha_only, float* raw, void* stream)
+{
+    if (!packed_split || !packed_f32 || !ndc || !feat || !raw || N < 0 || S < 1 || feat_stride < F || ndc_stride < 3) return MVSNERF_EINVAL;
+    if (!alpha_only && (!dirs || dirs_stride < 3)) return MVSNERF_EINVAL;
+    if (F < 2 || F > MAX_F || (F & 1) || n_split < 1 || n_split > 3) return MVSNERF_EUNSUPPORTED;
+    if (!mvs_aligned16(packed_split) || !mvs_aligned16(raw)) return MVSNERF_EALIGN;
+    const int64_t P = N * S;
+    if (P == 0) return MVSNERF_OK;
+    const __bf16* wq = reinterpret_cast<const __bf16*>(packed_split);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    switch (n_split) {
+        case 1: rc = launch_split<1>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st); break;
+        case 2: rc = launch_split<2>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st); break;
+        default: rc = launch_split<3>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st); break;
+    }
+    if (rc) return rc;
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }

@@ -3,7 +3,7 @@
 // ATen launches).
 #include "common.h"
 
-extern "C" int mvsnerf_abi_version(void) { return 4; }
+extern "C" int mvsnerf_abi_version(void) { return 5; }
 
 extern "C" int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream)
 {
@@ -27,7 +27,9 @@ extern "C" int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream
         if ((rc = mvsnerf_color_sample_fwd(a->imgs, a->V, a->IH, a->IW, a->w2c, a->K, a->rays_pts, P, 1, a->input_feat + 8, F, stream))) return rc;
     }
     // network_query_fn (renderer.py:156 -> run_network_mvs 42-63)
-    if (a->packed_mlp_bf16)
+    if (a->packed_mlp_split)
+        rc = mvsnerf_mlp_fwd_split(a->packed_mlp_split, a->packed_mlp, F, a->n_split, a->rays_ndc, 3, a->input_feat, F, a->dirs_tmp, 3, a->N, a->S, 0, a->raw, stream);
+    else if (a->packed_mlp_bf16)
         rc = mvsnerf_mlp_fwd_bf16(a->packed_mlp_bf16, a->packed_mlp, F, a->rays_ndc, 3, a->input_feat, F, a->dirs_tmp, 3, a->N, a->S, 0, a->raw, stream);
     else
         rc = mvsnerf_mlp_fwd(a->packed_mlp, F, a->rays_ndc, 3, a->input_feat, F, a->dirs_tmp, 3, a->N, a->S, 0, a->raw, stream);
@@ -84,7 +86,9 @@ extern "C" int mvsnerf_render_pixels_fwd(const mvsnerf_render_args* a, void* str
                                      a->near_far_tgt, a->near_far_ref, a->pad, a->lindisp, nullptr, n, S, pts, rdir, ndc, z, nullptr, stream))) return rc;
         if ((rc = mvsnerf_gather_fwd(a->vol, a->D, a->H, a->W, a->imgs_nhwc4, a->V, a->IH, a->IW, a->w2c, a->K, pts, ndc, n, S, rdir,
                                      feat, F, dirs, stream))) return rc;
-        if (a->packed_mlp_bf16)
+        if (a->packed_mlp_split)
+            rc = mvsnerf_mlp_fwd_split(a->packed_mlp_split, a->packed_mlp, F, a->n_split, ndc, 3, feat, F, dirs, 3, n, S, 0, raw, stream);
+        else if (a->packed_mlp_bf16)
             rc = mvsnerf_mlp_fwd_bf16(a->packed_mlp_bf16, a->packed_mlp, F, ndc, 3, feat, F, dirs, 3, n, S, 0, raw, stream);
         else
             rc = mvsnerf_mlp_fwd(a->packed_mlp, F, ndc, 3, feat, F, dirs, 3, n, S, 0, raw, stream);

@@ -110,6 +110,23 @@ class Renderer_ours(nn.Module):
             self._packed_b_key = self._packed_key
         return self._packed_b
 
+    def packed_split(self, feat_dim=None, n_split=3):
+        """(split-bf16 weight planes, n_split) for the opt-in bf16x3 / bf16x6 kernels (same cache policy as packed())."""
+        F = self.in_ch_feat if feat_dim is None else feat_dim
+        self.packed(F)
+        cache = getattr(self, "_packed_s", None)
+        if cache is None or cache[0] != (self._packed_key, n_split):
+            self._packed_s = ((self._packed_key, n_split), ops.mlp_pack_split([l.weight.detach() for l in self._linears()], F, n_split))
+        return self._packed_s[1], n_split
+
+    def packed_alt(self, feat_dim=None):
+        """Keyword arguments selecting the MLP kernel of ops.raymarch / ops.render_pixels for the current ops.MLP_PRECISION."""
+        if ops.MLP_PRECISION == "bf16":
+            return {"packed_bf16": self.packed_bf16(feat_dim)}
+        if ops.MLP_PRECISION in ops.N_SPLIT:
+            return {"packed_split": self.packed_split(feat_dim, ops.N_SPLIT[ops.MLP_PRECISION])}
+        return {}
+
     # -- queries ----------------------------------------------------------------------------
     def query(self, pts, feat, viewdirs, N, S):
         """pts (N,S,3) NDC, feat (N,S,F), viewdirs (N,3) per ray or None (sigma only) -> (N*S, 4|1)."""
@@ -122,6 +139,10 @@ class Renderer_ours(nn.Module):
         if ops.MLP_PRECISION == "bf16":
             return ops.mlp_forward_bf16(self.packed_bf16(F), self.packed(F), F, ops.dev_f32(pts, "pts"), 3, ops.dev_f32(feat, "feat"), F,
                                         dptr, 3, N, S, alpha_only, pts.device)
+        if ops.MLP_PRECISION in ops.N_SPLIT:
+            ps, ns = self.packed_split(F, ops.N_SPLIT[ops.MLP_PRECISION])
+            return ops.mlp_forward_split(ps, ns, self.packed(F), F, ops.dev_f32(pts, "pts"), 3, ops.dev_f32(feat, "feat"), F,
+                                         dptr, 3, N, S, alpha_only, pts.device)
         return ops.mlp_forward(self.packed(F), F, ops.dev_f32(pts, "pts"), 3, ops.dev_f32(feat, "feat"), F, dptr, 3, N, S, alpha_only, pts.device)
 
     def _rows(self, x, alpha_only):
@@ -160,6 +181,12 @@ class MVSNeRF(nn.Module):
 
     def packed_bf16(self, feat_dim=None):
         return self.nerf.packed_bf16(feat_dim)
+
+    def packed_split(self, feat_dim=None, n_split=3):
+        return self.nerf.packed_split(feat_dim, n_split)
+
+    def packed_alt(self, feat_dim=None):
+        return self.nerf.packed_alt(feat_dim)
 
     def query(self, pts, feat, viewdirs, N, S):
         return self.nerf.query(pts, feat, viewdirs, N, S)

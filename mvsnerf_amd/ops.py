@@ -240,15 +240,37 @@ def mlp_pack(weights, biases, F):
     return packed
 
 
-MLP_PRECISION = "fp32"      # "fp32" (default, parity 1e-4) | "bf16" (opt-in: BASELINE configs 3/4); see set_mlp_precision
+MLP_PRECISION = "fp32"      # "fp32" (default) | "bf16" | "bf16x3" | "bf16x6" (opt-in); see set_mlp_precision
+N_SPLIT = {"bf16x3": 2, "bf16x6": 3}
 
 
 def set_mlp_precision(mode):
-    """Select the MFMA data type of the inference MLP: "fp32" (v_mfma_f32_32x32x2_f32) or "bf16" (v_mfma_f32_32x32x16_bf16)."""
+    """Select the matrix-core arithmetic of the inference MLP:
+      "fp32"    v_mfma_f32_32x32x2_f32 (default; the headline / parity path)
+      "bf16"    v_mfma_f32_32x32x16_bf16, operands rounded to bf16 (BASELINE configs 3/4; ~1e-2 errors)
+      "bf16x6"  split-bf16 fp32 emulation: operands as 3 bf16 pieces, 6 bf16 MFMAs per product (fp32-grade results)
+      "bf16x3"  2 pieces, 3 MFMAs (~1e-5 relative)"""
     global MLP_PRECISION
-    if mode not in ("fp32", "bf16"):
-        raise ValueError("mlp precision must be 'fp32' or 'bf16'")
+    if mode not in ("fp32", "bf16", "bf16x3", "bf16x6"):
+        raise ValueError("mlp precision must be 'fp32', 'bf16', 'bf16x3' or 'bf16x6'")
     MLP_PRECISION = mode
+
+
+def mlp_pack_split(weights, F, n_split):
+    n = _lib.lib().mvsnerf_mlp_packed_split_elems(F, n_split)
+    if n == 0:
+        raise RuntimeError(f"mlp_pack_split: feat_dim {F} / n_split {n_split} unsupported")
+    packed = torch.empty(n, device=weights[0].device, dtype=torch.bfloat16)
+    wp = (ctypes.c_void_p * 11)(*[dev_f32(w, "weight") for w in weights])
+    check(_lib.lib().mvsnerf_mlp_pack_split(wp, F, n_split, packed.data_ptr(), stream_ptr()), "mlp_pack_split")
+    return packed
+
+
+def mlp_forward_split(packed_split, n_split, packed, F, ndc_ptr, ndc_stride, feat_ptr, feat_stride, dirs_ptr, dirs_stride, N, S, alpha_only, device):
+    raw = torch.empty((N * S, 1 if alpha_only else 4), device=device, dtype=torch.float32)
+    check(_lib.lib().mvsnerf_mlp_fwd_split(packed_split.data_ptr(), packed.data_ptr(), F, n_split, ndc_ptr, ndc_stride, feat_ptr, feat_stride,
+                                           dirs_ptr, dirs_stride, N, S, int(alpha_only), raw.data_ptr(), stream_ptr()), "mlp_fwd_split")
+    return raw
 
 
 def mlp_pack_bf16(weights, F):
@@ -292,7 +314,7 @@ def composite(raw, z_vals, white_bkgd=False):
 
 
 # ------------------------------------------------------------------ fused ray march
-def raymarch(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd=False, packed_bf16=None):
+def raymarch(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd=False, packed_bf16=None, packed_split=None):
     """One FFI call for rendering() (renderer.py:138-165).  Returns dict of outputs."""
     _need_no_grad(vol_cl, imgs, rays_pts, rays_ndc, z_vals, rays_dir, op="raymarch")
     N, S = z_vals.shape
@@ -316,14 +338,15 @@ def raymarch(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, z_vals,
         N, S, int(bool(white_bkgd)), dirs_tmp.data_ptr(), out["input_feat"].data_ptr(), out["raw"].data_ptr(),
         out["rgb_map"].data_ptr(), out["disp"].data_ptr(), out["acc"].data_ptr(), out["weights"].data_ptr(),
         out["depth"].data_ptr(), out["alpha"].data_ptr(), 0 if packed_bf16 is None else packed_bf16.data_ptr(),
-        channels_last_images(imgs).data_ptr() if FUSED_GATHER else 0)
+        channels_last_images(imgs).data_ptr() if FUSED_GATHER else 0,
+        0 if packed_split is None else packed_split[0].data_ptr(), 0 if packed_split is None else int(packed_split[1]))
     check(_lib.lib().mvsnerf_raymarch_fwd(ctypes.byref(a), stream_ptr()), "raymarch_fwd")
     return out
 
 
 def render_pixels(vol_cl, imgs, w2cs, intrinsics, packed, H, W, K_tgt, c2w_tgt, K_ref, w2c_ref, nf_tgt, nf_ref, N_samples,
                   first_pixel=0, n_pixels=None, pad=0, lindisp=False, white_bkgd=False, packed_bf16=None, batch_rays=4096,
-                  want=("depth",), ref_hw=None):
+                  want=("depth",), ref_hw=None, packed_split=None):
     """Pixel range of one target view in ONE FFI call (the chunk loop of validation_step, train_mvs_nerf_pl.py:198-208).
     Returns dict with rgb (n,3) and the requested extras among depth/acc/disp (n,)."""
     _need_no_grad(vol_cl, imgs, op="render_pixels")
@@ -351,7 +374,8 @@ def render_pixels(vol_cl, imgs, w2cs, intrinsics, packed, H, W, K_tgt, c2w_tgt, 
         c(w2cs, "w2cs"), c(intrinsics, "intrinsics"), packed.data_ptr(), 0 if packed_bf16 is None else packed_bf16.data_ptr(),
         c(K_tgt, "K_tgt"), c(c2w_tgt, "c2w_tgt"), c(K_ref, "K_ref"), c(w2c_ref, "w2c_ref"), c(nf_tgt, "near_far_tgt"), c(nf_ref, "near_far_ref"),
         W, H, int(pad), int(bool(lindisp)), 0 if ref_hw is None else int(ref_hw[1]), 0 if ref_hw is None else int(ref_hw[0]), int(first_pixel), n, int(N_samples), int(bool(white_bkgd)), B,
-        ws.data_ptr(), ws_n, out["rgb"].data_ptr(), *[0 if out[k] is None else out[k].data_ptr() for k in ("depth", "acc", "disp")])
+        ws.data_ptr(), ws_n, out["rgb"].data_ptr(), *[0 if out[k] is None else out[k].data_ptr() for k in ("depth", "acc", "disp")],
+        0 if packed_split is None else packed_split[0].data_ptr(), 0 if packed_split is None else int(packed_split[1]))
     check(lib.mvsnerf_render_pixels_fwd(ctypes.byref(a), stream_ptr()), "render_pixels_fwd")
     return {k: v for k, v in out.items() if v is not None}
 

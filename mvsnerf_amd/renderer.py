@@ -105,8 +105,7 @@ def rendering(args, pose_ref, rays_pts, rays_ndc, depth_candidates, rays_o, rays
             out = ops.raymarch(ops.channels_last_volume(vol), imgs[0].contiguous(),
                                pose_ref["w2cs"][:V].contiguous(), pose_ref["intrinsics"][:V].contiguous(),
                                network_fn.packed(args.feat_dim), rays_pts.contiguous(), rays_ndc.contiguous(),
-                               depth_candidates.contiguous(), rays_dir.contiguous(), white_bkgd,
-                               packed_bf16=network_fn.packed_bf16(args.feat_dim) if ops.MLP_PRECISION == "bf16" else None)
+                               depth_candidates.contiguous(), rays_dir.contiguous(), white_bkgd, **network_fn.packed_alt(args.feat_dim))
         rendering.last_raw = out["raw"]          # sigma lives in raw[...,3]; kept for parity tests / density queries
         return out["rgb_map"], out["input_feat"], out["weights"], out["depth"], out["alpha"], {}
 

@@ -186,8 +186,7 @@ class MVSSystem(_ModuleShim):
                 o = ops.render_pixels(vol_cl, src, pose_ref["w2cs"][:V].contiguous(), pose_ref["intrinsics"][:V].contiguous(),
                                       net.packed(args.feat_dim), H, W, k_render, tgt_to_world, k_render if k_ref is None else k_ref,
                                       world_to_ref, nf_t, nf_r, args.N_samples, first_pixel=first, n_pixels=n, pad=args.pad,
-                                      white_bkgd=kw.get("white_bkgd", False), ref_hw=ref_hw,
-                                      packed_bf16=net.packed_bf16(args.feat_dim) if ops.MLP_PRECISION == "bf16" else None)
+                                      white_bkgd=kw.get("white_bkgd", False), ref_hw=ref_hw, **net.packed_alt(args.feat_dim))
                 return o["rgb"], o["depth"]
             rgb, depth = D.render_frame_pixels(render_range, H, W, chunk, device=imgs.device)
             return rgb.reshape(H, W, 3), depth.reshape(H, W)

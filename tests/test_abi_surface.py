@@ -25,7 +25,7 @@ def test_library_builds_and_exports_header_symbols():
     missing = [n for n in names if not hasattr(l, n)]
     assert not missing, f"declared in the header but not exported: {missing}"
     assert sorted(_lib.SIGNATURES) == names, (set(names) ^ set(_lib.SIGNATURES))
-    assert _lib.lib().mvsnerf_abi_version() == 4
+    assert _lib.lib().mvsnerf_abi_version() == 5
     # pure host-side queries work without a GPU
     assert _lib.lib().mvsnerf_mlp_packed_floats(20) == 12 * 256 + 8192 * 2 + 16384 * 6 + 68 * 128 + 1416
     assert _lib.lib().mvsnerf_mlp_packed_floats(21) == 0
