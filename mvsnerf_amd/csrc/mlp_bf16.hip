@@ -473,15 +473,98 @@ __device__ __forceinline__ void run_segment(SlabStream& st, f32x16 (&acc)[NBLK],
     }
 }
 
-template <int NS, bool ALPHA_ONLY>
-__global__ __launch_bounds__(256, 2) void mlp_fwd_split_kernel(
+// ---- interleaved schedule (one wave per SIMD, three buffers).  A wave issues in order and an MFMA blocks issue until the
+// matrix pipe is free, so VALU work only overlaps the pipe if it sits BETWEEN MFMAs in program order.  Here the split of
+// k-step s+1's operands (and, for the embedding layers, their sin/cos) is cut into 12 micro-ops (plane x value pair) that are
+// placed after every other MFMA of k-step s, and the A fragments of the next output block are requested one block ahead.
+// __builtin_amdgcn_sched_barrier(0) pins that order.  The readiness barrier of slab k+1 sits in the MIDDLE of slab k
+// (prefetch distance 1.5 slabs) so that the first fragments of slab k+1 can be requested before slab k's last MFMAs.
+template <int NS, int NBLK>
+__device__ __forceinline__ void load_a(bf16x8 (&a)[NS], const char* w, int s_local, int nb, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < NS; ++k) a[k] = *reinterpret_cast<const bf16x8*>(w + ((((k * 2 + s_local) * NBLK) + nb) * 64 + lane) * 16);
+}
+
+template <int NS, int SLABS, int NBLK, int AHEAD1, int AHEAD2, typename VFN>
+__device__ __forceinline__ void run_segment_il(SlabStream& st, f32x16 (&acc)[NBLK], int wave, int lane, VFN vfn)
+{
+    static_assert(NS == 3, "interleaved schedule is written for the 3-piece split");
+    constexpr int SLAB_BYTES = sp_slab_elems(NS, NBLK) * 2;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int NSTEPS = 2 * SLABS;
+    Pieces<NS> cur;
+    {   // operands of k-step 0 (exposed: they depend on the previous layer's epilogue)
+        float v8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = vfn(0, j);
+        cur = split8<NS>(v8);
+    }
+    // entry contract: slab `cur` of this segment has landed and is visible (the previous segment's mid-slab barrier, or the
+    // kernel prologue, took care of it); slab cur+1 has been requested.
+    bf16x8 a[NS], an[NS];
+    load_a<NS, NBLK>(a, st.buf(st.cur), 0, 0, lane);
+#pragma unroll
+    for (int sl = 0; sl < SLABS; ++sl) {
+        const int nxt1 = sl + 1 < SLABS ? SLAB_BYTES : AHEAD1;                               // slab k+1 (requested earlier)
+        const int nxt2 = sl + 2 < SLABS ? SLAB_BYTES : (sl + 1 < SLABS ? AHEAD1 : AHEAD2);   // slab k+2 (requested at mid-slab)
+        const char* w = st.buf(st.cur);
+        const int ncur = st.cur + 1 == 3 ? 0 : st.cur + 1;
+#pragma unroll
+        for (int s_local = 0; s_local < 2; ++s_local) {
+            const int s = 2 * sl + s_local;
+            const bool has_next = s + 1 < NSTEPS;
+            Pieces<NS> nxt = cur;
+            float rem[8];
+            if (s_local == 1) {
+                // mid-slab: slab k+1 must have landed before its fragments are requested below; then slab k+2 may overwrite the
+                // buffer of slab k-1 (every wave is past it)
+                if (nxt1 != 0) { slab_wait<0>(); st.prefetch(nxt2, wave, lane); }
+            }
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb) {
+                // request the next block's fragments: same step, next step of this slab, or step 0 of the next slab
+                // (six MFMAs on one accumulator in a row are fine: srcC forwarding; rotating the accumulators instead needs all
+                // NBLK blocks' fragments in registers and measured slower)
+                const bool more = nb + 1 < NBLK || s_local == 0 || (sl + 1 < SLABS);
+                if (more) {
+                    if (nb + 1 < NBLK) load_a<NS, NBLK>(an, w, s_local, nb + 1, lane);
+                    else if (s_local == 0) load_a<NS, NBLK>(an, w, 1, 0, lane);
+                    else load_a<NS, NBLK>(an, st.buf(ncur), 0, 0, lane);
+                }
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr) {
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[pr]], cur.p[PB[pr]], acc[nb], 0, 0, 0);
+                    const int slot = nb * 6 + pr;
+                    if (has_next && (slot % (NBLK == 4 ? 2 : 1)) == 0 && slot / (NBLK == 4 ? 2 : 1) < 12) {
+                        const int mm = slot / (NBLK == 4 ? 2 : 1), plane = mm / 4, pair = mm % 4;
+                        if (plane == 0) { rem[2 * pair] = vfn(s + 1, 2 * pair); rem[2 * pair + 1] = vfn(s + 1, 2 * pair + 1); }
+                        const __bf16 h0 = (__bf16)rem[2 * pair], h1 = (__bf16)rem[2 * pair + 1];
+                        nxt.p[plane][2 * pair] = h0; nxt.p[plane][2 * pair + 1] = h1;
+                        if (plane + 1 < NS) { rem[2 * pair] -= (float)h0; rem[2 * pair + 1] -= (float)h1; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (more) {
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) a[k] = an[k];
+                }
+            }
+            cur = nxt;
+        }
+        st.cur = ncur;
+    }
+}
+
+template <int NS, bool ALPHA_ONLY, int SCHED>     // SCHED 0: two waves per SIMD, lean registers; 1: one wave per SIMD, hand-interleaved
+__global__ __launch_bounds__(256, SCHED == 1 ? 1 : 2) void mlp_fwd_split_kernel(
     const __bf16* __restrict__ wq, const float* __restrict__ packed_f32, int F, const float* __restrict__ ndc, int ndc_stride,
     const float* __restrict__ feat, int feat_stride, const float* __restrict__ dirs, int dirs_stride,
     int64_t P, int S, float* __restrict__ raw)
 {
     constexpr int SB4 = sp_slab_elems(NS, 4) * 2, SB2 = sp_slab_elems(NS, 2) * 2;      // slab bytes for 4 / 2 output blocks
     extern __shared__ __attribute__((aligned(16))) char lds_s[];
-    constexpr int NBUF = split_nbuf(NS);
+    constexpr int NBUF = SCHED == 1 ? 3 : split_nbuf(NS);
     float* vec = reinterpret_cast<float*>(lds_s + NBUF * SB4);
     const Layout LF = layout(F);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -507,6 +590,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_split_kernel(
 #pragma unroll
         for (int i = 0; i < 32; ++i) fv[i] = i < F / 2 ? fp[i] : 0.0f;
     }
+    if (SCHED == 1) slab_wait<0>();               // interleaved schedule: a segment starts with its first slab (and `vec`) visible
     auto pe_b = [&](int s) {
         float t8[8];
 #pragma unroll
@@ -518,6 +602,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_split_kernel(
     // split once per layer either way; holding NS planes instead would cost 32*NS registers and spill at two waves per SIMD)
     float h[64];
     auto hb = [&](int s) { return split8<NS>(h + 8 * (s & 7)); };
+    auto hv = [&](int s, int j) { return h[8 * (s & 7) + j]; };
+    auto pe_v = [&](int s, int j) { return pe_op(8 * s + j, half, px, py, pz); };
     auto finish = [&](f32x16 (&acc)[4], bool relu, bool mod) {
 #pragma unroll
         for (int q = 0; q < 64; ++q) {
@@ -529,29 +615,34 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_split_kernel(
     {   // bias = pts_bias(feat)
         f32x16 acc[4];
         init_acc_b<4>(acc, vec + V_BIASG + half * 64);
-        run_segment<NS, 2, 4, SB4, SB4, 3>(st, acc, wave, lane, [&](int s) { return split8<NS>(fv + 8 * (s & 3)); });
+        if constexpr (SCHED == 1) run_segment_il<NS, 2, 4, SB4, SB4>(st, acc, wave, lane, [&](int s, int j) { return fv[8 * (s & 3) + j]; });
+        else run_segment<NS, 2, 4, SB4, SB4, 3>(st, acc, wave, lane, [&](int s) { return split8<NS>(fv + 8 * (s & 3)); });
 #pragma unroll
         for (int q = 0; q < 64; ++q) bias[q] = acc[q >> 4][q & 15];
     }
     {   // layer 0
         f32x16 acc[4];
         init_acc_b<4>(acc, vec + V_L0 + half * 64);
-        run_segment<NS, 2, 4, SB4, SB4, 10>(st, acc, wave, lane, pe_b);
+        if constexpr (SCHED == 1) run_segment_il<NS, 2, 4, SB4, SB4>(st, acc, wave, lane, pe_v);
+        else run_segment<NS, 2, 4, SB4, SB4, 10>(st, acc, wave, lane, pe_b);
         finish(acc, true, true);
     }
 #pragma unroll 1
     for (int layer = 1; layer <= 4; ++layer) {
         f32x16 acc[4];
         init_acc_b<4>(acc, vec + V_L0 + 128 * layer + half * 64);
-        run_segment<NS, 4, 4, SB4, SB4, 3>(st, acc, wave, lane, hb);
+        if constexpr (SCHED == 1) run_segment_il<NS, 4, 4, SB4, SB4>(st, acc, wave, lane, hv);
+        else run_segment<NS, 4, 4, SB4, SB4, 3>(st, acc, wave, lane, hb);
         finish(acc, true, true);
     }
     float sigma;
     {   // layer 5 on cat([pts, h4]); the positional encoding is recomputed instead of held in 16*NS registers since layer 0
         f32x16 acc[4];
         init_acc_b<4>(acc, vec + V_L0 + 128 * 5 + half * 64);
-        run_segment<NS, 2, 4, SB4, SB4, 10>(st, acc, wave, lane, pe_b);
-        run_segment<NS, 4, 4, ALPHA_ONLY ? 0 : SB4, ALPHA_ONLY ? 0 : SB4, 3>(st, acc, wave, lane, hb);
+        if constexpr (SCHED == 1) run_segment_il<NS, 2, 4, SB4, SB4>(st, acc, wave, lane, pe_v);
+        else run_segment<NS, 2, 4, SB4, SB4, 10>(st, acc, wave, lane, pe_b);
+        if constexpr (SCHED == 1) run_segment_il<NS, 4, 4, ALPHA_ONLY ? 0 : SB4, ALPHA_ONLY ? 0 : SB4>(st, acc, wave, lane, hv);
+        else run_segment<NS, 4, 4, ALPHA_ONLY ? 0 : SB4, ALPHA_ONLY ? 0 : SB4, 3>(st, acc, wave, lane, hb);
         const float* wa = vec + V_WA + half * 64;
         float part = 0.0f;
 #pragma unroll
@@ -567,7 +658,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_split_kernel(
     {   // feature_linear (no activation)
         f32x16 acc[4];
         init_acc_b<4>(acc, vec + V_FEAT + half * 64);
-        run_segment<NS, 4, 4, SB2, SB2, 3>(st, acc, wave, lane, hb);
+        if constexpr (SCHED == 1) run_segment_il<NS, 4, 4, SB2, SB2>(st, acc, wave, lane, hv);
+        else run_segment<NS, 4, 4, SB2, SB2, 3>(st, acc, wave, lane, hb);
         finish(acc, false, false);
     }
     {   // views_linears[0] + rgb head
@@ -580,7 +672,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_split_kernel(
         const Pieces<NS> z8 = split8<NS>(zero8);
         f32x16 acc[2];
         init_acc_b<2>(acc, vec + V_VIEWS + half * 32);
-        run_segment<NS, 5, 2, 0, 0, 6>(st, acc, wave, lane, [&](int s) { return s < 8 ? hb(s) : (s == 8 ? d8 : z8); });
+        if constexpr (SCHED == 1) run_segment_il<NS, 5, 2, 0, 0>(st, acc, wave, lane, [&](int s, int j) { return s < 8 ? h[8 * (s & 7) + j] : (s == 8 ? dl[j] : 0.0f); });
+        else run_segment<NS, 5, 2, 0, 0, 6>(st, acc, wave, lane, [&](int s) { return s < 8 ? hb(s) : (s == 8 ? d8 : z8); });
         float rgb[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -595,22 +688,22 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_split_kernel(
     }
 }
 
-template <int NS>
+template <int NS, int SCHED>
 int launch_split(const __bf16* wq, const float* packed_f32, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
                  const float* dirs, int dirs_stride, int64_t P, int S, int alpha_only, float* raw, hipStream_t st)
 {
-    constexpr int LDS = split_nbuf(NS) * sp_slab_elems(NS, 4) * 2 + V_TOTAL * 4;
+    constexpr int LDS = (SCHED == 1 ? 3 : split_nbuf(NS)) * sp_slab_elems(NS, 4) * 2 + V_TOTAL * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_split_kernel<NS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_split_kernel<NS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_split_kernel<NS, false, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_split_kernel<NS, true, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     if (alpha_only)
-        mlp_fwd_split_kernel<NS, true><<<mvs_cdiv(P, 128), 256, LDS, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
+        mlp_fwd_split_kernel<NS, true, SCHED><<<mvs_cdiv(P, 128), 256, LDS, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
     else
-        mlp_fwd_split_kernel<NS, false><<<mvs_cdiv(P, 128), 256, LDS, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
+        mlp_fwd_split_kernel<NS, false, SCHED><<<mvs_cdiv(P, 128), 256, LDS, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
     return 0;
 }
 
@@ -662,6 +755,8 @@ extern "C" int mvsnerf_mlp_fwd_bf16(const void* packed_bf16, const float* packed
     return MVSNERF_OK;
 }
 
+int g_split_sched = 0;    // A/B knob (mvsnerf_tune "split_sched"): schedule of the 3-piece kernel
+
 extern "C" size_t mvsnerf_mlp_packed_split_elems(int F, int n_split)
 {
     if (F < 2 || F > MAX_F || (F & 1) || n_split < 1 || n_split > 3) return 0;
@@ -695,9 +790,12 @@ extern "C" int mvsnerf_mlp_fwd_split(const void* packed_split, const float* pack
     hipStream_t st = (hipStream_t)stream;
     int rc;
     switch (n_split) {
-        case 1: rc = launch_split<1>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st); break;
-        case 2: rc = launch_split<2>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st); break;
-        default: rc = launch_split<3>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st); break;
+        case 1: rc = launch_split<1, 0>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st); break;
+        case 2: rc = launch_split<2, 0>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st); break;
+        default:
+            if (g_split_sched == 1) rc = launch_split<3, 1>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st);
+            else rc = launch_split<3, 0>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st);
+            break;
     }
     if (rc) return rc;
     MVS_LAUNCH_CHECK();
