@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cpu-batches", type=int, default=20, help="CPU-oracle batches timed for cpu_baseline (0 = skip)")
     ap.add_argument("--mlp-variant", type=int, default=None)
+    ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16", "bf16x3", "bf16x6"],
+                    help="matrix-core arithmetic of the timed MLP (default fp32 = the headline; the others are the opt-in modes)")
     ap.add_argument("--no-extras", action="store_true", help="skip the end-to-end frame / training-step timings")
     return ap.parse_args()
 
@@ -144,6 +146,7 @@ def main():
     import types
     if a.mlp_variant is not None:
         _lib.lib().mvsnerf_tune(b"mlp_variant", a.mlp_variant)
+    ops.set_mlp_precision(a.mlp_precision)        # fp32 unless asked otherwise; restored to fp32 for the per-kernel section
 
     # ---------------- scene + network (resident in HBM before timing)
     rig = make_rig(H_IMG, W_IMG, seed=1234)
@@ -208,6 +211,7 @@ def main():
         dt = float(t.item())
     rays_per_s = world * a.steps * N_RAYS / dt
 
+    ops.set_mlp_precision("fp32")
     # ---------------- per-kernel launch durations (HIP events on the launch stream), rank 0
     roof, roofs, cpu = None, [], None
     if rank == 0:
@@ -358,9 +362,11 @@ def main():
         print(json.dumps({
             "metric": "rendered rays/sec (1024-ray batch, 128 samples)", "value": round(rays_per_s, 1), "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3 (split-bf16 products, fp32 accumulate)",
+                      "bf16x6": "bf16x6 (fp32 emulated by split-bf16 products, fp32 accumulate)"}[a.mlp_precision], "data": "synthetic",
             "config": {"workload": "config 2: 3 source views 512x640, 128 depth planes, pad 24 (volume 128x176x208x8), "
-                                   "1024 rays x 128 samples per step, fp32, render-only (volume pre-built)",
+                                   f"1024 rays x 128 samples per step, MLP arithmetic {a.mlp_precision}, render-only (volume pre-built)",
                        "weights": "mvsnerf-v0 checkpoint", "volume": volume_src, "rays_per_step_per_gpu": N_RAYS,
                        "parallelism": f"ray-sharded x{world}, no data-path collective"},
             "encode_ms": encode_ms,
