@@ -63,6 +63,7 @@ extern "C" size_t mvsnerf_render_workspace_floats(int batch_rays, int S, int V)
 extern "C" int mvsnerf_render_pixels_fwd(const mvsnerf_render_args* a, void* stream)
 {
     if (!a) return MVSNERF_EINVAL;
+    if (a->n_pixels == 0) return MVSNERF_OK;                       // empty pixel range (a rank with no chunks): nothing to do
     if (!a->vol || !a->imgs_nhwc4 || !a->w2c || !a->K || !a->packed_mlp || !a->K_tgt || !a->c2w_tgt || !a->K_ref || !a->w2c_ref ||
         !a->near_far_tgt || !a->near_far_ref || !a->workspace || !a->rgb)
         return MVSNERF_EINVAL;

@@ -368,6 +368,8 @@ def render_pixels(vol_cl, imgs, w2cs, intrinsics, packed, H, W, K_tgt, c2w_tgt, 
     out = {"rgb": torch.empty((n, 3), **f32)}
     for k in ("depth", "acc", "disp"):
         out[k] = torch.empty((n,), **f32) if k in want else None
+    if n == 0:
+        return {k: v for k, v in out.items() if v is not None}
     c = _Keep()
     a = _lib.RenderArgs(
         dev_f32(vol_cl, "volume"), D, Hv, Wv, channels_last_images(imgs).data_ptr(), V, imgs.shape[2], imgs.shape[3],

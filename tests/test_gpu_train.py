@@ -207,3 +207,33 @@ def test_render_view_target_grid_differs_from_sources():
     psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
     assert psnr > 55.0, psnr
     assert float((depth.cpu().reshape(-1) - ref[3]).abs().max()) < 5e-3
+
+
+def test_render_pixels_edge_cases():
+    """Empty range, range clipped at the frame end, out-of-frame range (rejected, nothing launched), batch_rays larger than the range."""
+    from mvsnerf_amd import ops, models
+    from mvsnerf_amd.synth import make_rig, pose_ref_of
+    mlp_sd, _ = load_weights()
+    H, W, S, pad = 16, 24, 8, 0
+    rig = make_rig(H, W, seed=3)
+    pd = {k: v.to(DEV) for k, v in pose_ref_of(rig).items()}
+    net = models.MVSNeRF(D=6, W=128, input_ch_pts=63, input_ch_views=3, input_ch_feat=20, skips=[4], net_type="v0")
+    net.load_state_dict(mlp_sd)
+    net = net.to(DEV)
+    vol = ops.channels_last_volume(torch.randn((1, 8, 8, H // 4, W // 4), generator=torch.Generator().manual_seed(0)).to(DEV))
+    imgs = rig["images_raw"][0, :3].to(DEV)
+
+    def run(first, n, **kw):
+        with torch.no_grad():
+            return ops.render_pixels(vol, imgs, pd["w2cs"][:3].contiguous(), pd["intrinsics"][:3].contiguous(), net.packed(20), H, W, pd["intrinsics"][-1],
+                                     pd["c2ws"][-1], pd["intrinsics"][-1], pd["w2cs"][0], pd["near_fars"][-1], pd["near_fars"][0], S,
+                                     first_pixel=first, n_pixels=n, pad=pad, **kw)
+    full = run(0, None)
+    assert full["rgb"].shape == (H * W, 3) and bool(torch.isfinite(full["rgb"]).all())
+    assert run(5, 0)["rgb"].shape == (0, 3)
+    tail = run(H * W - 7, 7, batch_rays=100000)
+    assert torch.equal(tail["rgb"], full["rgb"][-7:]) and torch.equal(tail["depth"], full["depth"][-7:])
+    part = run(11, 50, batch_rays=16)                      # sub-batching does not change the pixels
+    assert torch.equal(part["rgb"], full["rgb"][11:61])
+    with pytest.raises(RuntimeError, match="render_pixels_fwd failed: invalid argument"):
+        run(H * W - 3, 10)
