@@ -10,6 +10,7 @@
 //          no transposes.  Work-groups own contiguous tile ranges; partials are combined by a deterministic second
 //          kernel (no float atomics), which also un-permutes fragment order back to nn.Linear's [out][in].
 #include "common.h"
+#include "act.h"
 #include "mlp_layout.h"
 
 using namespace mlp;
@@ -62,16 +63,26 @@ extern "C" size_t mvsnerf_mlp_saved_floats(int64_t n_points) { return (size_t)((
 extern "C" size_t mvsnerf_mlp_gradslot_floats(int64_t n_points) { return (size_t)((n_points + 127) / 128) * 4 * SLOTS_GRAD * 64; }
 
 // ------------------------------------------------------------------------------------------ dgrad
+// One workgroup per CU (4 waves, one 32-point tile each).  The eight transposed weight segments stream through two 64 KB LDS
+// buffers by LDS-DMA: segment g+1 is in flight while GEMM g runs (the first version staged each segment through registers
+// between two barriers and stalled the matrix pipe for every one of them).  The saved post-ReLU activations a layer's
+// epilogue needs are requested before the previous GEMM, and the gradient slots are stored after the buffer barrier, so that
+// neither global loads nor stores sit between a barrier and the MFMAs that follow it.
 constexpr int WBUF_FLOATS = 16384;
-constexpr int LDS_FLOATS = WBUF_FLOATS + V_TOTAL;
+constexpr int LDS_FLOATS = 2 * WBUF_FLOATS + V_TOTAL;
 
-__device__ __forceinline__ void stage_w(float* __restrict__ wbuf, const float* __restrict__ src, int n_floats, int tid)
+__device__ __forceinline__ void wdma(float* __restrict__ dst, const float* __restrict__ src, int n_floats, int wave, int lane)
 {
-    const f32x4* s = reinterpret_cast<const f32x4*>(src);
-    f32x4* d = reinterpret_cast<f32x4*>(wbuf);
-    const int n4 = n_floats >> 2;
-#pragma unroll 4
-    for (int i = tid; i < n4; i += 256) d[i] = s[i];
+    const int pieces = n_floats >> 8;                    // 1 KB per wave-instruction
+    for (int pc = wave; pc < pieces; pc += 4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(dst + pc * 256), 16, 0, 0);
+}
+
+__device__ __forceinline__ void wsync()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces have landed
+    __syncthreads();                                      // ... everybody's have, and everybody left the other buffer
 }
 
 template <int STEPS4, int NBLK, typename BFN>
@@ -106,28 +117,34 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
     int64_t P, float* __restrict__ gslots, float* __restrict__ d_feat8)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* wbuf = lds;
-    float* vec = lds + WBUF_FLOATS;
+    float* buf0 = lds;
+    float* buf1 = lds + WBUF_FLOATS;
+    float* vec = lds + 2 * WBUF_FLOATS;
     const Layout LF = layout(F);
     const LayoutBwd L = layout_bwd();
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     const int64_t p_raw = tile * 32 + (lane & 31);
     const bool live = p_raw < P;
     const float* sv = saved + tile * (SLOTS_SAVED * 64) + lane;
     float* gs = gslots + tile * (SLOTS_GRAD * 64) + lane;
 
+    wdma(buf0, packed_bwd + L.views, (int)seg_floats(32, 4), wave, lane);            // segment 0 -> buf0
     for (int i = tid; i < V_TOTAL; i += 256) vec[i] = packed_fwd[LF.vec + i];
-    stage_w(wbuf, packed_bwd + L.views, (int)seg_floats(32, 4), tid);
 
     // heads: rgb = sigmoid(z), sigma = relu(s)   (models.py:209,217)
     f32x4 o = {0, 0, 0, 0}, g = {0, 0, 0, 0};
     if (live) { o = *reinterpret_cast<const f32x4*>(raw + p_raw * 4); g = *reinterpret_cast<const f32x4*>(d_raw + p_raw * 4); }
     const float gz0 = g[0] * o[0] * (1.0f - o[0]), gz1 = g[1] * o[1] * (1.0f - o[1]), gz2 = g[2] * o[2] * (1.0f - o[2]);
     const float gsg = o[3] > 0.0f ? g[3] : 0.0f;
+    float hv[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) hv[q] = sv[(S_HV + q) * 64];
+    wsync();                                                                           // vec + segment 0 visible
+    wdma(buf1, packed_bwd + L.feat, WBUF_FLOATS, wave, lane);                        // segment 1 -> buf1
     gs[(G_G4 + 0) * 64] = half ? gz1 : gz0;
     gs[(G_G4 + 1) * 64] = half ? gsg : gz2;
-    __syncthreads();
 
     // grad wrt views_linears[0] pre-activation: ghv = Wr^T gz, masked by relu
     float gh[64];
@@ -136,8 +153,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
 #pragma unroll
         for (int q = 0; q < 32; ++q) {
             const float ghv = fmaf(wr[128 + q], gz2, fmaf(wr[64 + q], gz1, wr[q] * gz0));
-            const float hv = sv[(S_HV + q) * 64];
-            gh[q] = hv > 0.0f ? ghv : 0.0f;
+            gh[q] = hv[q] > 0.0f ? ghv : 0.0f;
             gs[(G_GPV + q) * 64] = gh[q];
         }
     }
@@ -145,18 +161,22 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
     {
         f32x16 acc[4];
         zero_acc<4>(acc);
-        gemm_t<8, 4>(wbuf, acc, lane, [&](int t) { return gh[t]; });
+        gemm_t<8, 4>(buf0, acc, lane, [&](int t) { return gh[t]; });
 #pragma unroll
-        for (int q = 0; q < 64; ++q) { gh[q] = acc[q >> 4][q & 15]; gs[(G_GF + q) * 64] = gh[q]; }
+        for (int q = 0; q < 64; ++q) gh[q] = acc[q >> 4][q & 15];
     }
     // gh5 = feature_linear^T gF + alpha_linear^T gsigma
+    float hq[64];                          // saved post-ReLU activations of the layer whose epilogue comes next
     {
         f32x16 acc[4];
-        __syncthreads();
-        stage_w(wbuf, packed_bwd + L.feat, WBUF_FLOATS, tid);
-        __syncthreads();
+        wsync();                                                                       // segment 1 landed; buf0 free
+        wdma(buf0, packed_bwd + L.l5, WBUF_FLOATS, wave, lane);                      // segment 2 -> buf0
+#pragma unroll
+        for (int q = 0; q < 64; ++q) gs[(G_GF + q) * 64] = gh[q];
+#pragma unroll
+        for (int q = 0; q < 64; ++q) hq[q] = sv[(S_H + 5 * 64 + q) * 64];
         zero_acc<4>(acc);
-        gemm_t<16, 4>(wbuf, acc, lane, [&](int t) { return gh[t]; });
+        gemm_t<16, 4>(buf1, acc, lane, [&](int t) { return gh[t]; });
         const float* wa = vec + V_WA + half * 64;
 #pragma unroll
         for (int q = 0; q < 64; ++q) gh[q] = fmaf(wa[q], gsg, acc[q >> 4][q & 15]);
@@ -169,33 +189,36 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
     for (int layer = 5; layer >= 0; --layer) {
 #pragma unroll
         for (int q = 0; q < 64; ++q) {
-            const float hq = sv[(S_H + layer * 64 + q) * 64];
-            const bool on = hq > 0.0f;
+            const bool on = hq[q] > 0.0f;
             const float gq = on ? gh[q] : 0.0f;
-            gbm[q] += on ? gq * (hq / bm[q]) : 0.0f;
+            gbm[q] += on ? gq * (hq[q] / bm[q]) : 0.0f;
             gh[q] = gq * bm[q];
-            gs[(G_GP + layer * 64 + q) * 64] = gh[q];
         }
+        // segment (7 - layer) for this layer's transposed GEMM sits in buf[(layer + 1) & 1]: l5 -> buf0, l4 -> buf1, ...
+        float* cur = (layer & 1) ? buf0 : buf1;
+        float* nxt = (layer & 1) ? buf1 : buf0;
+        wsync();                                                                       // this layer's segment landed; the other buffer is free
+        if (layer >= 2) wdma(nxt, packed_bwd + L.l5 + (size_t)(6 - layer) * seg_floats(ACT_STEPS, 4), WBUF_FLOATS, wave, lane);
+        else if (layer == 1) wdma(nxt, packed_bwd + L.bias, (int)seg_floats(ACT_STEPS, 1), wave, lane);
+#pragma unroll
+        for (int q = 0; q < 64; ++q) gs[(G_GP + layer * 64 + q) * 64] = gh[q];
         if (layer == 0) break;
+#pragma unroll
+        for (int q = 0; q < 64; ++q) hq[q] = sv[(S_H + (layer - 1) * 64 + q) * 64];
         f32x16 acc[4];
-        __syncthreads();
-        stage_w(wbuf, packed_bwd + L.l5 + (size_t)(5 - layer) * seg_floats(ACT_STEPS, 4), WBUF_FLOATS, tid);
-        __syncthreads();
         zero_acc<4>(acc);
-        gemm_t<16, 4>(wbuf, acc, lane, [&](int t) { return gh[t]; });
+        gemm_t<16, 4>(cur, acc, lane, [&](int t) { return gh[t]; });
 #pragma unroll
         for (int q = 0; q < 64; ++q) gh[q] = acc[q >> 4][q & 15];
     }
 #pragma unroll
     for (int q = 0; q < 64; ++q) gs[(G_GBM + q) * 64] = gbm[q];
-    // grad wrt the first 8 feature columns (the trilinear volume features): gf = pts_bias^T gb
+    // grad wrt the first 8 feature columns (the trilinear volume features): gf = pts_bias^T gb ; the bias segment was
+    // requested during layer 1 into buf1 and made visible by the barrier of layer 0
     {
         f32x16 acc[1];
-        __syncthreads();
-        stage_w(wbuf, packed_bwd + L.bias, (int)seg_floats(ACT_STEPS, 1), tid);
-        __syncthreads();
         zero_acc<1>(acc);
-        gemm_t<16, 1>(wbuf, acc, lane, [&](int t) { return gbm[t]; });
+        gemm_t<16, 1>(buf1, acc, lane, [&](int t) { return gbm[t]; });
         // C/D rows (r&3)+8*(r>>2)+4*half: r = 0..3 are feature columns 4*half + r
         if (live) *reinterpret_cast<f32x4*>(d_feat8 + p_raw * 8 + half * 4) = f32x4{acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
     }
@@ -292,7 +315,7 @@ static int launch_wgrad(int ra_blocks, int nbb, const WgradArgs& w, int grid, hi
     return MVSNERF_OK;
 }
 
-extern "C" size_t mvsnerf_mlp_bwd_workspace_floats(void) { return (size_t)256 * 128 * (192 + 1); }
+extern "C" size_t mvsnerf_mlp_bwd_workspace_floats(void) { return (size_t)(256 + MVS_RED_SLICES + 1) * 128 * (192 + 1); }
 
 // maps: device int array of 8 consecutive tables (see mvsnerf_amd/ops.py:_mlp_bwd_maps):
 //   [0] act128 (128): slot-row r=2q+h -> n(q,h)            [1] act64 (64): same for q<32
@@ -330,8 +353,14 @@ extern "C" int mvsnerf_mlp_bwd(const float* packed_fwd, const float* packed_bwd,
         WgradArgs w{gslots, ts_g, a_slot, saved, ts_s, b_slot0, nblk0, b_slot1, n_tiles, workspace};
         return launch_wgrad(ra_blocks, nbb, w, grid, st);
     };
-    auto reduce = [&](int RA, int RB, const int* rowmap, const int* colmap, float* w_out, int ld, float* b_out) -> int {
-        mlp_wgrad_reduce_kernel<<<mvs_cdiv((int64_t)RA * (RB + 1), 256), 256, 0, st>>>(workspace, grid, RA, RB, rowmap, colmap, w_out, ld, b_out);
+    // partials [grid][RA*(RB+1)] -> one slice (two-stage sum over the workgroups: a single pass walks `grid` strided values per
+    // thread on a few dozen workgroups and cost 61 us per call), then the fragment-order -> nn.Linear scatter
+    float* red_scratch = workspace + (size_t)256 * 128 * (192 + 1);
+    float* red_out = red_scratch + (size_t)MVS_RED_SLICES * 128 * (192 + 1);
+    auto reduce = [&](int RA, int RB, const int* rowmap, const int* colmap, float* w_out, int ld, float* b_out, bool fresh = true) -> int {
+        const int64_t n_out = (int64_t)RA * (RB + 1);
+        if (fresh) mvs_partial_sum(workspace, grid, n_out, red_scratch, red_out, st);
+        mlp_wgrad_reduce_kernel<<<mvs_cdiv(n_out, 256), 256, 0, st>>>(red_out, 1, RA, RB, rowmap, colmap, w_out, ld, b_out);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : (int)e;
     };
@@ -369,7 +398,7 @@ extern "C" int mvsnerf_mlp_bwd(const float* packed_fwd, const float* packed_bwd,
         const int* M_HEAD_RGB = maps + 928;     // 192 entries: [act64 | -1 x128]
         const int* M_HEAD_A = maps + 1120;      // 192 entries: [-1 x64 | act128]
         if ((rc = reduce(32, 192, M_G4RGB, M_HEAD_RGB, gw[10], 64, gb[10]))) return rc;
-        if ((rc = reduce(32, 192, M_G4A, M_HEAD_A, gw[8], WIDTH, gb[8]))) return rc;
+        if ((rc = reduce(32, 192, M_G4A, M_HEAD_A, gw[8], WIDTH, gb[8], false))) return rc;      // same partials, second scatter
     }
     (void)M_HL5; (void)M_DIR;
     return MVSNERF_OK;
