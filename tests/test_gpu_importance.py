@@ -126,3 +126,40 @@ def test_finetune_with_density_volume_and_importance_sampling():
     sd = {k: v.detach().cpu() for k, v in ft.network_fn.state_dict().items()}
     ref = O.render_density(ft.vox_pts.cpu(), feats, sd).reshape(16, 24, 32)
     assert float((ft.density_volume.cpu() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+def test_lindisp_paths_vs_oracle():
+    """`--use_disp` (inverse-depth parametrisation) of the fine-tuning script: ray_marcher sampling, the NDC z of
+    get_ndc_coordinate (utils.py:130-133) in the ray_points kernel, and MVSNet.forward's inverse-depth planes (models.py:917-920)."""
+    from mvsnerf_amd import ops, train, models
+    from mvsnerf_amd.synth import make_rig, pose_ref_of
+    from oracle import mvsnerf_oracle as O
+    H, W, pad, D, N, S = 64, 96, 4, 16, 77, 20
+    rig = make_rig(H, W, seed=13, rot_deg=2.0, smooth=True)
+    pose = pose_ref_of(rig)
+    nf = rig["near_fars"][0, 0]
+    g = torch.Generator().manual_seed(1)
+    K, c2w = pose["intrinsics"][-1], pose["c2ws"][-1]
+    xs, ys = torch.rand(N, generator=g) * (W - 1), torch.rand(N, generator=g) * (H - 1)
+    d = torch.stack([(xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1], torch.ones(N)], -1) @ c2w[:3, :3].t()
+    rays = torch.cat([c2w[:3, 3].expand(N, 3), d, nf[0].expand(N, 1), nf[1].expand(N, 1)], -1)
+    pts_ref, _, _, z_ref = O.ray_marcher(rays, S, lindisp=True)
+    ndc_ref = O.get_ndc_coordinate(pose["w2cs"][0], pose["intrinsics"][0], pts_ref, torch.tensor([W - 1.0, H - 1.0]), near=nf[0], far=nf[1], pad=pad, lindisp=True)
+    pts_t, _, _, z_t = train.ray_marcher(rays.to(DEV), S, lindisp=True)
+    assert float((z_t.cpu() - z_ref).abs().max()) < 1e-6
+    with torch.no_grad():
+        pts, ndc = ops.ray_points(rays[:, :3].to(DEV), rays[:, 3:6].to(DEV), z_t, pose["w2cs"][0].to(DEV), pose["intrinsics"][0].to(DEV), nf.to(DEV),
+                                  ref_hw=(H, W), pad=pad, lindisp=True)
+    assert float((pts.cpu() - pts_ref).abs().max()) < 1e-5
+    assert float((ndc.cpu() - ndc_ref).abs().max()) < 1e-5
+    # inverse-depth plane sweep through the whole encoder
+    _, mvs_sd = load_weights()
+    vol_ref, _, dv_ref, _, _ = O.mvsnet_forward(rig["images"][:, :3], rig["proj_mats"][:, :3], nf, mvs_sd, pad=pad, D=D, lindisp=True)
+    mvs = models.MVSNet()
+    mvs.load_state_dict(mvs_sd)
+    mvs = mvs.to(DEV).train()
+    mvs.D = D
+    with torch.no_grad():
+        vol, _, dv = mvs(rig["images"][:, :3].to(DEV), rig["proj_mats"][:, :3].to(DEV), nf.to(DEV), pad=pad, lindisp=True)
+    assert float((dv.cpu() - dv_ref).abs().max()) < 1e-6
+    assert float(((vol.cpu() - vol_ref).abs() > 5e-3).float().mean()) < 1e-3
