@@ -152,6 +152,13 @@ def test_lindisp_paths_vs_oracle():
                                   ref_hw=(H, W), pad=pad, lindisp=True)
     assert float((pts.cpu() - pts_ref).abs().max()) < 1e-5
     assert float((ndc.cpu() - ndc_ref).abs().max()) < 1e-5
+    # the ray-generation kernel's lindisp flag (same sampling + NDC arithmetic from pixel ids)
+    pd = {k: v.to(DEV) for k, v in pose.items()}
+    with torch.no_grad():
+        rp, rd, rn, rz, _ = ops.raygen(H, W, pd["intrinsics"][-1], pd["c2ws"][-1], pd["intrinsics"][0], pd["w2cs"][0], nf.to(DEV), nf.to(DEV), S,
+                                       pad=pad, lindisp=True, xs=xs.to(DEV), ys=ys.to(DEV))
+    assert float((rz.cpu() - z_ref).abs().max()) < 1e-6 and float((rd.cpu() - d).abs().max()) < 1e-6
+    assert float((rp.cpu() - pts_ref).abs().max()) < 1e-5 and float((rn.cpu() - ndc_ref).abs().max()) < 1e-5
     # inverse-depth plane sweep through the whole encoder
     _, mvs_sd = load_weights()
     vol_ref, _, dv_ref, _, _ = O.mvsnet_forward(rig["images"][:, :3], rig["proj_mats"][:, :3], nf, mvs_sd, pad=pad, D=D, lindisp=True)
