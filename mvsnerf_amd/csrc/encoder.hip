@@ -585,30 +585,40 @@ extern "C" int mvsnerf_abn_stats(const float* x, int64_t n_vox, int C, const flo
 // 8-channel neural volume  conv0 + conv11(x), models.py:766)
 __global__ __launch_bounds__(256) void abn_apply_add_kernel(ActSrc a, ActSrc b, int64_t n4, int C, float* __restrict__ out)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    const int c = (int)((i * 4) % C);
-    f32x4 v = *reinterpret_cast<const f32x4*>(a.x + i * 4);
+    // a thread keeps its channel group for the whole grid-stride walk (the stride is a multiple of C/4), so the per-channel
+    // (scale, shift) are loaded once and no 64-bit modulo sits on the streaming path (the first version did one per float4
+    // and ran at 1.7 TB/s)
+    const int g4 = C >> 2;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;          // multiple of 256, hence of g4 (C in {8,16,32,64})
+    const int c = (int)(t0 % g4) * 4;
+    f32x4 sa, ha, sb = {0, 0, 0, 0}, hb = {0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = act_apply(v[k], a.scale[c + k], a.shift[c + k]);
-    if (b.x) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(b.x + i * 4);
+    for (int k = 0; k < 4; ++k) { sa[k] = a.scale[c + k]; ha[k] = a.shift[c + k]; if (b.x) { sb[k] = b.scale[c + k]; hb[k] = b.shift[c + k]; } }
+    for (int64_t i = t0; i < n4; i += stride) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(a.x + i * 4);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] += act_apply(t[k], b.scale[c + k], b.shift[c + k]);
+        for (int k = 0; k < 4; ++k) v[k] = act_apply(v[k], sa[k], ha[k]);
+        if (b.x) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(b.x + i * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += act_apply(t[k], sb[k], hb[k]);
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = v;
     }
-    *reinterpret_cast<f32x4*>(out + i * 4) = v;
 }
 
 extern "C" int mvsnerf_abn_apply_add(const float* x1, const float* scale1, const float* shift1,
                                      const float* x2, const float* scale2, const float* shift2,
                                      int64_t n_vox, int C, float* out, void* stream)
 {
-    if (!x1 || !scale1 || !shift1 || !out || n_vox < 1 || (C & 3)) return MVSNERF_EINVAL;
+    if (!x1 || !scale1 || !shift1 || !out || n_vox < 1 || (C & 3) || (1024 % C)) return MVSNERF_EINVAL;
     if (x2 && (!scale2 || !shift2)) return MVSNERF_EINVAL;
     if (!mvs_aligned16(x1) || !mvs_aligned16(out) || (x2 && !mvs_aligned16(x2))) return MVSNERF_EALIGN;
     const ActSrc a{x1, scale1, shift1}, b{x2, scale2, shift2};
     const int64_t n4 = n_vox * C / 4;
-    abn_apply_add_kernel<<<mvs_cdiv(n4, 256), 256, 0, (hipStream_t)stream>>>(a, b, n4, C, out);
+    const unsigned nblk = mvs_cdiv(n4, 256) < 8192u ? mvs_cdiv(n4, 256) : 8192u;       // <= 32 workgroups per CU, grid-stride beyond
+    abn_apply_add_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>(a, b, n4, C, out);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }

@@ -104,7 +104,9 @@ class ConvBnReLU(nn.Module):
         ops._need_no_grad(x, *self.parameters(), op="ConvBnReLU")
         buf, ld = _images_channel_last(x, self._packed.cin_pad)
         N, _, H, W = x.shape
-        return _apply_add(self.lazy(buf, (N, H, W, ld), ld)).permute(0, 3, 1, 2)
+        out = _apply_add(self.lazy(buf, (N, H, W, ld), ld)).permute(0, 3, 1, 2)
+        _flush_nbt()
+        return out
 
 
 def _images_channel_last(x, cin_pad):
@@ -150,6 +152,7 @@ class FeatureNet(nn.Module):
             lz.append(z)
             src, dims, ld = z, z.dims, z.dims[3]
         top = _conv2d(src, dims, ld, self._top_packed.get(), 32, 32, 1, 1, bias=dev_f32_tensor(self.toplayer.bias))
+        _flush_nbt()
         return (img, img.shape[3]), lz, top
 
     def forward(self, x):
@@ -318,8 +321,19 @@ def _abn_stats(raw, n_vox, bn, update_running=True):
                                        rm, rv, bn.momentum, bn.eps, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
                                        ws.data_ptr(), stream_ptr()), "abn_stats")
     if update_running:
-        bn.num_batches_tracked += 1
+        _NBT_PENDING.append(bn.num_batches_tracked)
     return out[0], out[1], out[2], out[3]
+
+
+_NBT_PENDING = []
+
+
+def _flush_nbt():
+    """`num_batches_tracked += 1` of every layer that ran, as ONE foreach launch per network pass instead of one tiny ATen
+    kernel per layer (18 of them per scene encode)."""
+    if _NBT_PENDING:
+        torch._foreach_add_(list(_NBT_PENDING), 1)
+        _NBT_PENDING.clear()
 
 
 def _ptrs(src):
@@ -382,7 +396,9 @@ class ConvBnReLU3D(nn.Module):
         ops._need_no_grad(x, *self.parameters(), op="ConvBnReLU3D")
         buf, ld = _as_channel_last(x, self._packed_cin_pad())
         D, H, W = x.shape[2:]
-        return _cl_view_to_ncdhw(_apply_add(self.lazy(buf, (D, H, W, ld), ld)))
+        out = _cl_view_to_ncdhw(_apply_add(self.lazy(buf, (D, H, W, ld), ld)))
+        _flush_nbt()
+        return out
 
     def _packed_cin_pad(self):
         return self._packed.cin_pad
@@ -408,7 +424,9 @@ class _UpBlock(nn.Sequential):
         if ld != self._packed.cin_pad:
             raise RuntimeError("transposed conv input must be densely channel-last")
         D, H, W = x.shape[2:]
-        return _cl_view_to_ncdhw(_apply_add(self.lazy(buf, (D, H, W, ld))))
+        out = _cl_view_to_ncdhw(_apply_add(self.lazy(buf, (D, H, W, ld))))
+        _flush_nbt()
+        return out
 
 
 class CostRegNet(nn.Module):
@@ -446,6 +464,7 @@ class CostRegNet(nn.Module):
         u7 = self.conv7.lazy(c6, c6.dims)                       # x = conv4 + conv7(x)   (models.py:762)
         u9 = self.conv9.lazy(c4, c4.dims, src2=u7)              # x = conv2 + conv9(x)   (:764)
         u11 = self.conv11.lazy(c2, c2.dims, src2=u9)            # x = conv0 + conv11(x)  (:766)
+        _flush_nbt()
         return (buf, ld), [c0, c1, c2, c3, c4, c5, c6, u7, u9, u11]
 
     def forward(self, x):
