@@ -25,13 +25,14 @@ def test_featurenet_forward_vs_oracle(N, H, W):
     x = torch.randn((N, 3, H, W), generator=g)
     ref = O.feature_net(x, sd)
     rm0 = fn.conv0[0].bn.running_mean.clone()
+    nbt0 = [int(l.bn.num_batches_tracked) for l in fn._layers()]
     with torch.no_grad():
         out = fn(x.to(DEV))
     assert out.shape == ref.shape
     err = float((out.cpu() - ref).abs().max())
     assert err < 1e-4 * max(1.0, float(ref.abs().max())), err
     assert not torch.equal(rm0, fn.conv0[0].bn.running_mean)            # train mode updates the running statistics
-    assert all(int(l.bn.num_batches_tracked) == 1 for l in fn._layers())  # ... and counts the batch, once per layer
+    assert [int(l.bn.num_batches_tracked) for l in fn._layers()] == [n + 1 for n in nbt0]   # ... and counts the batch, once per layer
     # eval mode: running statistics, against torch's own batch_norm in eval mode
     fn.eval()
     with torch.no_grad():
