@@ -389,7 +389,10 @@ __global__ __launch_bounds__(256) void conv3d_k3s1_tiled_kernel(ActSrc a, ActSrc
 
 // Transposed 3x3x3 convolution, stride 2, padding 1, output_padding 1 (models.py:739-752): output size = 2x input.
 // out[o] = sum over taps k with o = 2*i - 1 + k.  One thread = one output voxel x CT channels; per dimension an even
-// output coordinate has one tap (k=1), an odd one two (k=0 from i=(o+1)/2, k=2 from i=(o-1)/2).
+// output coordinate has one tap (k=1), an odd one two (k=0 from i=(o+1)/2, k=2 from i=(o-1)/2).  The tap loop is wave-uniform
+// (only its predicate is per lane), so weights stay on the scalar path; a wave spans one (z,y) row, i.e. it skips the
+// (kz,ky) combinations of the wrong parity as a whole.  Measured alternatives, both slower: one workgroup per output parity
+// class with strided stores (conv11 436 -> ~600 us), and one thread per x pair with three weight sets per channel chunk.
 template <int CIN, int CT>
 __global__ __launch_bounds__(256) void convT3d_k3s2_kernel(ActSrc a, ActSrc b, int Di, int Hi, int Wi,
                                                           const float* __restrict__ wp, int Cout, float* __restrict__ out)
