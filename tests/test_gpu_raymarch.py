@@ -419,3 +419,27 @@ def test_split_bf16x6_mode_meets_the_fp32_tolerance(net, n_rays, n_samples):
         assert float((rgb.cpu() - ref[0]).abs().max()) < tol, mode
         assert bool(((sig - ref_sigma).abs() <= tol + tol * ref_sigma.abs()).all()), mode
         assert float((w.cpu() - ref[2]).abs().max()) < tol and float((depth.cpu() - ref[3]).abs().max()) < 10 * tol
+
+
+def test_large_batch_is_chunk_invariant(net):
+    """Size-independent property at a size the CPU oracle cannot reach (98 304 rays x 128 samples = 12.6 M samples through every
+    kernel of the ray march): rendering the batch at once equals rendering it in three uneven pieces, bit for bit."""
+    from mvsnerf_amd import ops
+    rig, pose, vol, pts, dirs, ndc, z, ro = _config2_inputs(4096, 128, D=32, h=48, w=64, H=128, W=160, seed=21)
+    rep = 24
+    vol_cl = ops.channels_last_volume(vol.to(DEV))
+    imgs = rig["images_raw"][0, :3].to(DEV)
+    w2cs, Ks = pose["w2cs"][:3].contiguous().to(DEV), pose["intrinsics"][:3].contiguous().to(DEV)
+    packed = net.packed(20)
+    g = torch.Generator().manual_seed(0)
+    jit = lambda t, s: (t.repeat(rep, *([1] * (t.dim() - 1))) + torch.randn((t.shape[0] * rep, *t.shape[1:]), generator=g) * s).to(DEV)
+    P, N, Z, Dr = jit(pts, 1e-3), jit(ndc, 1e-3), jit(z, 0.0), jit(dirs, 1e-3)
+    n = P.shape[0]
+    with torch.no_grad():
+        full = ops.raymarch(vol_cl, imgs, w2cs, Ks, packed, P, N, Z, Dr)
+        cuts = [0, 1, 40001, n]
+        parts = [ops.raymarch(vol_cl, imgs, w2cs, Ks, packed, P[a:b].contiguous(), N[a:b].contiguous(), Z[a:b].contiguous(), Dr[a:b].contiguous())
+                 for a, b in zip(cuts[:-1], cuts[1:])]
+    for k in ("rgb_map", "depth", "weights", "raw", "input_feat"):
+        assert torch.equal(full[k], torch.cat([p[k] for p in parts], 0)), k
+    assert bool(torch.isfinite(full["rgb_map"]).all())
