@@ -355,6 +355,7 @@ __global__ __launch_bounds__(256) void mlp_pack_split_kernel(PackBArgs a, int ns
 }
 
 __host__ __device__ constexpr int split_nbuf(int ns) { return ns == 3 ? 2 : 3; }
+constexpr int IL_NBUF = 4;           // interleaved schedule: slabs k+1 and k+2 in flight behind the one being consumed
 
 template <int NS> struct Pieces { bf16x8 p[NS]; };
 
@@ -384,7 +385,10 @@ struct SlabStream {
     const char* g;          // next slab to fetch
     char* base; int stride; // buffer i = base + i*stride, i in 0..nbuf-1
     int cur;                // buffer `cur`: the slab about to be consumed
-    int nbuf;               // 3: two slabs in flight (one workgroup per CU); 2: one in flight (two workgroups per CU cover for each other)
+    int nbuf;               // number of LDS buffers = slabs in flight + 1
+    int k, n4, n2;          // (interleaved schedule) stream position: slab k is in buffer `cur`; the stream is n4 slabs of `stride`
+                            // bytes followed by n2 slabs of stride/2 bytes
+    __device__ __forceinline__ int bytes_of(int idx) const { return idx < n4 ? stride : (idx < n4 + n2 ? stride >> 1 : 0); }
     __device__ __forceinline__ char* buf(int i) const { return base + i * stride; }
     __device__ __forceinline__ void prefetch(int bytes, int wave, int lane)
     {
@@ -506,10 +510,8 @@ __device__ __forceinline__ void run_segment_il(SlabStream& st, f32x16 (&acc)[NBL
     load_a<NS, NBLK>(a, st.buf(st.cur), 0, 0, lane);
 #pragma unroll
     for (int sl = 0; sl < SLABS; ++sl) {
-        const int nxt1 = sl + 1 < SLABS ? SLAB_BYTES : AHEAD1;                               // slab k+1 (requested earlier)
-        const int nxt2 = sl + 2 < SLABS ? SLAB_BYTES : (sl + 1 < SLABS ? AHEAD1 : AHEAD2);   // slab k+2 (requested at mid-slab)
         const char* w = st.buf(st.cur);
-        const int ncur = st.cur + 1 == 3 ? 0 : st.cur + 1;
+        const int ncur = st.cur + 1 == st.nbuf ? 0 : st.cur + 1;
 #pragma unroll
         for (int s_local = 0; s_local < 2; ++s_local) {
             const int s = 2 * sl + s_local;
@@ -517,9 +519,16 @@ __device__ __forceinline__ void run_segment_il(SlabStream& st, f32x16 (&acc)[NBL
             Pieces<NS> nxt = cur;
             float rem[8];
             if (s_local == 1) {
-                // mid-slab: slab k+1 must have landed before its fragments are requested below; then slab k+2 may overwrite the
-                // buffer of slab k-1 (every wave is past it)
-                if (nxt1 != 0) { slab_wait<0>(); st.prefetch(nxt2, wave, lane); }
+                // mid-slab: slab k+1 must have landed before its fragments are requested below (slabs k+2 .. k+nbuf-2 may stay in
+                // flight: DMA instructions per wave = bytes / 1 KB / 4 waves); then slab k+nbuf-1 may overwrite the buffer of slab
+                // k-1 (every wave is past it)
+                if (st.bytes_of(st.k + 1) != 0) {
+                    const int newer = st.nbuf >= 4 ? st.bytes_of(st.k + 2) : 0;
+                    if (newer == 0) slab_wait<0>();
+                    else if (newer == st.stride) slab_wait<2 * NS>();
+                    else slab_wait<NS>();
+                    st.prefetch(st.bytes_of(st.k + st.nbuf - 1), wave, lane);
+                }
             }
 #pragma unroll
             for (int nb = 0; nb < NBLK; ++nb) {
@@ -553,6 +562,7 @@ __device__ __forceinline__ void run_segment_il(SlabStream& st, f32x16 (&acc)[NBL
             cur = nxt;
         }
         st.cur = ncur;
+        st.k += 1;
     }
 }
 
@@ -564,7 +574,7 @@ __global__ __launch_bounds__(256, SCHED == 1 ? 1 : 2) void mlp_fwd_split_kernel(
 {
     constexpr int SB4 = sp_slab_elems(NS, 4) * 2, SB2 = sp_slab_elems(NS, 2) * 2;      // slab bytes for 4 / 2 output blocks
     extern __shared__ __attribute__((aligned(16))) char lds_s[];
-    constexpr int NBUF = SCHED == 1 ? 3 : split_nbuf(NS);
+    constexpr int NBUF = SCHED == 1 ? IL_NBUF : split_nbuf(NS);
     float* vec = reinterpret_cast<float*>(lds_s + NBUF * SB4);
     const Layout LF = layout(F);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -575,11 +585,11 @@ __global__ __launch_bounds__(256, SCHED == 1 ? 1 : 2) void mlp_fwd_split_kernel(
     const int64_t p = live ? p_raw : P - 1;
 
     // stream order (sizes are static: the pts_bias segment is always packed as 2 slabs): 30 slabs of SB4, then 5 of SB2
-    SlabStream st{reinterpret_cast<const char*>(wq), lds_s, SB4, 1, NBUF};
-    st.prefetch(SB4, wave, lane);                 // slab 0 -> buffer 0   (cur = 1: the prefetch target cur+NBUF-1 wraps to 0)
-    if (NBUF == 3) {
-        st.cur = 2;
-        st.prefetch(SB4, wave, lane);             // slab 1 -> buffer 1
+    SlabStream st{reinterpret_cast<const char*>(wq), lds_s, SB4, 1, NBUF, 0, ALPHA_ONLY ? 26 : 30, ALPHA_ONLY ? 0 : 5};
+#pragma unroll
+    for (int i = 0; i + 1 < NBUF; ++i) {          // slabs 0 .. NBUF-2 -> buffers 0 .. NBUF-2 (prefetch targets cur + NBUF - 1)
+        st.cur = (i + 1) % NBUF;
+        st.prefetch(SB4, wave, lane);
     }
     st.cur = 0;
     for (int i = tid; i < V_TOTAL; i += 256) vec[i] = packed_f32[LF.vec + i];
@@ -692,7 +702,7 @@ template <int NS, int SCHED>
 int launch_split(const __bf16* wq, const float* packed_f32, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
                  const float* dirs, int dirs_stride, int64_t P, int S, int alpha_only, float* raw, hipStream_t st)
 {
-    constexpr int LDS = (SCHED == 1 ? 3 : split_nbuf(NS)) * sp_slab_elems(NS, 4) * 2 + V_TOTAL * 4;
+    constexpr int LDS = (SCHED == 1 ? IL_NBUF : split_nbuf(NS)) * sp_slab_elems(NS, 4) * 2 + V_TOTAL * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_split_kernel<NS, false, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
