@@ -359,6 +359,12 @@ constexpr int IL_NBUF = 4;           // interleaved schedule: slabs k+1 and k+2 
 
 template <int NS> struct Pieces { bf16x8 p[NS]; };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Split 8 fp32 values into NS bf16 pieces each.  For NS == 3 the pieces are taken by TRUNCATION (top 16 bits of the fp32 word):
+// the remainder after each truncation has at most 16, then 8 significant bits, so x = p0 + p1 + p2 holds exactly (not just to
+// rounding), and the work is full-rate bit operations (and / perm / packed subtract) instead of float->bf16 conversions.
+// Fewer pieces keep round-to-nearest (v_cvt_pk_bf16_f32), where the rounding of the last piece matters.
 template <int NS>
 __device__ __forceinline__ Pieces<NS> split8(const float* v)
 {
@@ -366,13 +372,31 @@ __device__ __forceinline__ Pieces<NS> split8(const float* v)
     float rem[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) rem[j] = v[j];
+    if constexpr (NS == 3) {
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
+        for (int k = 0; k < NS; ++k) {
+            u32x4 w;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const __bf16 h = (__bf16)rem[j];
-            r.p[k][j] = h;
-            if (k + 1 < NS) rem[j] -= (float)h;
+            for (int pr = 0; pr < 4; ++pr) {
+                const unsigned lo = __builtin_bit_cast(unsigned, rem[2 * pr]) & 0xffff0000u;
+                const unsigned hi = __builtin_bit_cast(unsigned, rem[2 * pr + 1]) & 0xffff0000u;
+                w[pr] = hi | (lo >> 16);
+                if (k + 1 < NS) {
+                    rem[2 * pr] -= __builtin_bit_cast(float, lo);
+                    rem[2 * pr + 1] -= __builtin_bit_cast(float, hi);
+                }
+            }
+            r.p[k] = __builtin_bit_cast(bf16x8, w);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const __bf16 h = (__bf16)rem[j];
+                r.p[k][j] = h;
+                if (k + 1 < NS) rem[j] -= (float)h;
+            }
         }
     }
     return r;
