@@ -141,7 +141,7 @@ class MVSSystem(_ModuleShim):
         return {"loss": loss}
 
     @torch.no_grad()
-    def render_view(self, batch, chunk=None, whole_frame_off=False, target=None):
+    def render_view(self, batch, chunk=None, whole_frame_off=False, target=None, batch_rays=4096):
         """The rendering part of validation_step (:172-254): encode once, then the chunk loop over the target view's
         pixels - tile-parallel over ranks (contiguous chunk ranges + one all_gather).  Returns (rgb (H,W,3), depth (H,W)).
         whole_frame_off=True keeps the per-chunk Python loop (build_rays_test + rendering per chunk) instead of the single
@@ -149,7 +149,8 @@ class MVSSystem(_ModuleShim):
         target (extension, BASELINE config 5): dict(hw=(H,W), intrinsic (3,3), c2w (4,4)[, near_far (2,)]) renders a camera whose
         pixel grid differs from the source views' (e.g. 1008x756 rays over 960x640 sources).  The reference normalises the NDC
         coordinates with the *target* size and intrinsics (utils.py:252-253, fine when all views share both); with `target` the
-        reference view's own intrinsics and size are used, which is what the volume is aligned with."""
+        reference view's own intrinsics and size are used, which is what the volume is aligned with.
+        batch_rays: rays per sub-batch inside the library call (free parameter: the pixels do not depend on it)."""
         args = self.args
         chunk = chunk or args.chunk
         data_mvs, pose_ref = self.decode_batch(dict(batch))
@@ -186,7 +187,8 @@ class MVSSystem(_ModuleShim):
                 o = ops.render_pixels(vol_cl, src, pose_ref["w2cs"][:V].contiguous(), pose_ref["intrinsics"][:V].contiguous(),
                                       net.packed(args.feat_dim), H, W, k_render, tgt_to_world, k_render if k_ref is None else k_ref,
                                       world_to_ref, nf_t, nf_r, args.N_samples, first_pixel=first, n_pixels=n, pad=args.pad,
-                                      white_bkgd=kw.get("white_bkgd", False), ref_hw=ref_hw, **net.packed_alt(args.feat_dim))
+                                      white_bkgd=kw.get("white_bkgd", False), ref_hw=ref_hw, batch_rays=batch_rays,
+                                      **net.packed_alt(args.feat_dim))
                 return o["rgb"], o["depth"]
             rgb, depth = D.render_frame_pixels(render_range, H, W, chunk, device=imgs.device)
             return rgb.reshape(H, W, 3), depth.reshape(H, W)
