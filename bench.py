@@ -54,6 +54,19 @@ def _load_pmc_traffic():
     return out
 
 
+def pmc_mfma_busy_frac(kernel_prefix):
+    """Fraction of the kernel's duration the matrix pipes were busy, from the committed PMC passes:
+    (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+    except Exception:
+        return None
+    for k, v in d.items():
+        if k.startswith(kernel_prefix) and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
+            return round((v["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / 1024.0) / (v["GRBM_GUI_ACTIVE"]["mean"] / 8.0), 4)
+    return None
+
+
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of the first profiled kernel whose name starts with `kernel_prefix` (None if not profiled)."""
     for k, v in PMC_TRAFFIC.items():
@@ -258,8 +271,8 @@ def main():
         tf = FLOP_PER_SAMPLE * P / (t_mlp * 1e-3) / 1e12
         roof = {"kernel": "mlp_fwd_pipe_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic("mlp_fwd_pipe_kernel"), "avg_launch_ms": round(t_mlp, 4),
-                "sustained_clock_ghz": round(clock, 3),
-                "frac_at_sustained_clock": round(tf / (PEAK_F32_MFMA_TFLOPS * clock / 2.4), 4)}
+                "mfma_pipe_busy_frac_pmc": pmc_mfma_busy_frac("mlp_fwd_pipe_kernel"),
+                "s_memtime_ghz": round(clock, 3)}
         for name, t, bps in (("gather_fused_kernel", t_gat, VOL_BYTES_PER_SAMPLE + COL_BYTES_PER_SAMPLE),
                              ("volume_sample_c8_kernel", t_vol, VOL_BYTES_PER_SAMPLE), ("color_sample_kernel", t_col, COL_BYTES_PER_SAMPLE),
                              ("composite_kernel", t_cmp, 28)):
