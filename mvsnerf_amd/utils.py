@@ -1,9 +1,10 @@
 """Drop-in replacements for the hot-path helpers of the reference's utils.py (same names, argument
 order, defaults and return layouts - SURVEY.md 8b), backed by libmvsnerf_hip.so.
 
-Ray generation (get_rays_mvs / build_rays / build_rays_test / get_ndc_coordinate) stays host-side
-torch, exactly as in the reference, because it owns the RNG draws whose ray indices must be bit-exact
-(pixel ids: CPU RNG, utils.py:93; jitter: device RNG, utils.py:220).
+Ray generation: the RNG draws stay here, exactly as in the reference, because the ray indices must be bit-exact
+(pixel ids: CPU RNG, utils.py:93; jitter: device RNG, utils.py:220); everything downstream of them in build_rays /
+build_rays_test is one HIP kernel (mvsnerf_raygen_fwd).  get_rays_mvs / get_ndc_coordinate keep host-side torch bodies
+for callers that use them on their own (and for CPU tensors).
 """
 import torch
 
