@@ -530,8 +530,17 @@ __device__ __forceinline__ void run_segment_il(SlabStream& st, f32x16 (&acc)[NBL
     }
     // entry contract: slab `cur` of this segment has landed and is visible (the previous segment's mid-slab barrier, or the
     // kernel prologue, took care of it); slab cur+1 has been requested.
-    bf16x8 a[NS], an[NS];
-    load_a<NS, NBLK>(a, st.buf(st.cur), 0, 0, lane);
+    // MFMA order within a k-step: the six piece products are the OUTER loop and the NBLK accumulators the inner one, so that
+    // consecutive MFMAs never wait on each other's result:  (w2,b0) (w0,b2) (w1,b1) (w1,b0) (w0,b1) (w0,b0), each over all blocks.
+    // Weight plane 2 is dead after the first group and plane 1 lives for two, so at most two planes (+ the next step's two
+    // prefetched ones) are in registers.
+    auto load_plane = [&](bf16x8 (&f)[NBLK], const char* w, int s_local, int plane) {
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) f[nb] = *reinterpret_cast<const bf16x8*>(w + ((((plane * 2 + s_local) * NBLK) + nb) * 64 + lane) * 16);
+    };
+    bf16x8 f0[NBLK], f1[NBLK], f2[NBLK], n0[NBLK], n2[NBLK];
+    load_plane(f2, st.buf(st.cur), 0, 2);
+    load_plane(f0, st.buf(st.cur), 0, 0);
 #pragma unroll
     for (int sl = 0; sl < SLABS; ++sl) {
         const char* w = st.buf(st.cur);
@@ -554,21 +563,20 @@ __device__ __forceinline__ void run_segment_il(SlabStream& st, f32x16 (&acc)[NBL
                     st.prefetch(st.bytes_of(st.k + st.nbuf - 1), wave, lane);
                 }
             }
+            load_plane(f1, w, s_local, 1);
+            const bool more = s_local == 0 || (sl + 1 < SLABS);       // next k-step of this segment: same slab, or step 0 of the next
 #pragma unroll
-            for (int nb = 0; nb < NBLK; ++nb) {
-                // request the next block's fragments: same step, next step of this slab, or step 0 of the next slab
-                // (six MFMAs on one accumulator in a row are fine: srcC forwarding; rotating the accumulators instead needs all
-                // NBLK blocks' fragments in registers and measured slower)
-                const bool more = nb + 1 < NBLK || s_local == 0 || (sl + 1 < SLABS);
-                if (more) {
-                    if (nb + 1 < NBLK) load_a<NS, NBLK>(an, w, s_local, nb + 1, lane);
-                    else if (s_local == 0) load_a<NS, NBLK>(an, w, 1, 0, lane);
-                    else load_a<NS, NBLK>(an, st.buf(ncur), 0, 0, lane);
+            for (int grp = 0; grp < 6; ++grp) {
+                if (grp == 4 && more) {
+                    if (s_local == 0) { load_plane(n2, w, 1, 2); load_plane(n0, w, 1, 0); }
+                    else { load_plane(n2, st.buf(ncur), 0, 2); load_plane(n0, st.buf(ncur), 0, 0); }
                 }
 #pragma unroll
-                for (int pr = 0; pr < 6; ++pr) {
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[pr]], cur.p[PB[pr]], acc[nb], 0, 0, 0);
-                    const int slot = nb * 6 + pr;
+                for (int nb = 0; nb < NBLK; ++nb) {
+                    const bf16x8 wa = grp == 0 ? f2[nb] : (grp == 2 || grp == 3 ? f1[nb] : f0[nb]);
+                    const bf16x8 bb = grp == 1 ? cur.p[2] : (grp == 2 || grp == 4 ? cur.p[1] : cur.p[0]);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, bb, acc[nb], 0, 0, 0);
+                    const int slot = grp * NBLK + nb;
                     if (has_next && (slot % (NBLK == 4 ? 2 : 1)) == 0 && slot / (NBLK == 4 ? 2 : 1) < 12) {
                         const int mm = slot / (NBLK == 4 ? 2 : 1), plane = mm / 4, pair = mm % 4;
                         if (plane == 0) { rem[2 * pair] = vfn(s + 1, 2 * pair); rem[2 * pair + 1] = vfn(s + 1, 2 * pair + 1); }
@@ -578,10 +586,10 @@ __device__ __forceinline__ void run_segment_il(SlabStream& st, f32x16 (&acc)[NBL
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (more) {
+            }
+            if (more) {
 #pragma unroll
-                    for (int k = 0; k < NS; ++k) a[k] = an[k];
-                }
+                for (int nb = 0; nb < NBLK; ++nb) { f2[nb] = n2[nb]; f0[nb] = n0[nb]; }
             }
             cur = nxt;
         }
