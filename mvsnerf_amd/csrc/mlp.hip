@@ -74,10 +74,17 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(PackArgs a, float* __rest
     }
 }
 
+// 16-point-tile variant (mlp16.hip): its own fragment order, appended to the packed buffer
+size_t mvs_mlp16_packed_floats(int F);
+int mvs_mlp16_pack(const float* const w[11], const float* const b[11], int F, float* packed16, hipStream_t st);
+int mvs_mlp16_fwd(const float* packed16, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
+                  const float* dirs, int dirs_stride, int64_t P, int S, int alpha_only, float* raw, hipStream_t st);
+static size_t off16(int F) { return (layout(F).total + 3) & ~(size_t)3; }
+
 extern "C" size_t mvsnerf_mlp_packed_floats(int F)
 {
     if (F < 2 || F > MAX_F || (F & 1)) return 0;
-    return layout(F).total;
+    return off16(F) + mvs_mlp16_packed_floats(F);
 }
 
 extern "C" int mvsnerf_mlp_pack(const float* const w[11], const float* const b[11], int F, float* packed, void* stream)
@@ -93,7 +100,7 @@ extern "C" int mvsnerf_mlp_pack(const float* const w[11], const float* const b[1
     a.F = F;
     mlp_pack_kernel<<<64, 256, 0, (hipStream_t)stream>>>(a, packed);
     MVS_LAUNCH_CHECK();
-    return MVSNERF_OK;
+    return mvs_mlp16_pack(w, b, F, packed + off16(F), (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------ compute
@@ -377,8 +384,8 @@ __global__ __launch_bounds__(256, WPS) void mlp_fwd_kernel(
 // ------------------------------------------------------------------------------------------ pipelined forward
 // Measured on MI355X (scratch/census.py, profiles/r01_mlp_census.txt): the shader clock sits at ~2.07 GHz while this kernel
 // runs (DVFS under sustained fp32-MFMA load with real operands), the MFMA pipe is 92-94 % busy while waves are resident
-// (SQ_VALU_MFMA_BUSY_CYCLES vs SQ_WAVE_CYCLES), and the kernel reaches 131 TFLOP/s = 83 % of the 2.4 GHz datasheet peak
-// = 96 % of the peak at the sustained clock.  Negative results kept out of the code: (i) staggering / prioritising the
+// (SQ_VALU_MFMA_BUSY_CYCLES vs SQ_WAVE_CYCLES), and the kernel reaches 123-131 TFLOP/s = 78-83 % of the 2.4 GHz datasheet peak
+// (PMC: matrix pipes busy 80 % of the kernel's duration at ~2.4 GHz).  Negative results kept out of the code: (i) staggering / prioritising the
 // two co-resident workgroups of a CU: no change; (ii) reading A fragments straight from L2 (no LDS stage, no barriers):
 // 114 TFLOP/s; (iii) 64 points per wave at one wave per SIMD: 114 TFLOP/s.
 // Same arithmetic as mlp_fwd_kernel<.., G=1, ..>, different weight logistics: the packed weights are cut into 16 slabs
@@ -603,7 +610,7 @@ extern "C" int mvsnerf_tune(const char* key, int value)
 {
     if (!key) return MVSNERF_EINVAL;
     if (__builtin_strcmp(key, "conv_tiled") == 0) { g_conv_tiled = value ? 1 : 0; return MVSNERF_OK; }
-    if (__builtin_strcmp(key, "mlp_variant") == 0) { if (value < 0 || value > 3) return MVSNERF_EINVAL; g_mlp_variant = value; return MVSNERF_OK; }
+    if (__builtin_strcmp(key, "mlp_variant") == 0) { if (value < 0 || value > 4) return MVSNERF_EINVAL; g_mlp_variant = value; return MVSNERF_OK; }
     if (__builtin_strcmp(key, "split_sched") == 0) { if (value < 0 || value > 1) return MVSNERF_EINVAL; g_split_sched = value; return MVSNERF_OK; }
     return MVSNERF_EINVAL;
 }
@@ -636,6 +643,10 @@ extern "C" int mvsnerf_mlp_fwd(const float* packed, int F, const float* ndc, int
     const int64_t P = N * S;
     if (P == 0) return MVSNERF_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (g_mlp_variant == 4) {                      // 16 points per wave (mlp16.hip), its weights follow the 32-point layout in `packed`
+        const int rc = mvs_mlp16_fwd(packed + off16(F), F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st);
+        return rc;
+    }
 #define MVS_MLP(AO, G, WPS) launch_mlp<AO, G, WPS>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, st)
     switch (g_mlp_variant * 2 + (alpha_only ? 1 : 0)) {
         case 0: return MVS_MLP(false, 1, 2);

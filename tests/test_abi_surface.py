@@ -27,7 +27,10 @@ def test_library_builds_and_exports_header_symbols():
     assert sorted(_lib.SIGNATURES) == names, (set(names) ^ set(_lib.SIGNATURES))
     assert _lib.lib().mvsnerf_abi_version() == 5
     # pure host-side queries work without a GPU
-    assert _lib.lib().mvsnerf_mlp_packed_floats(20) == 12 * 256 + 8192 * 2 + 16384 * 6 + 68 * 128 + 1416
+    # 32-point layout (12 feature k-steps x 4 blocks x 64 lanes, ...) followed by the 16-point layout of the same weights
+    n32 = 12 * 256 + 8192 * 2 + 16384 * 6 + 68 * 128 + 1416
+    n16 = 8 * 512 + 8192 * 2 + 16384 * 6 + 36 * 256 + 1416
+    assert _lib.lib().mvsnerf_mlp_packed_floats(20) == n32 + n16
     assert _lib.lib().mvsnerf_mlp_packed_floats(21) == 0
 
 
