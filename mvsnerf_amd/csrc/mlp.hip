@@ -8,6 +8,7 @@
 // memory.  MFMA-bound: 251 392 FLOP per point against 12 B + 4*F B read and 16 B written.
 #include "common.h"
 #include "mlp_layout.h"
+#include "lds_dma.h"
 
 using namespace mlp;
 
@@ -397,10 +398,12 @@ constexpr int PIPE_LDS_FLOATS = 2 * SLAB_FLOATS + V_TOTAL;
 
 __device__ __forceinline__ void slab_dma(float* __restrict__ dst, const float* __restrict__ src, int n_floats, int wave, int lane)
 {
-    const int pieces = n_floats >> 8;                    // 1 KB per wave-instruction
-    for (int pc = wave; pc < pieces; pc += 4)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 256 + lane * 4),
-                                         (__attribute__((address_space(3))) void*)(dst + pc * 256), 16, 0, 0);
+    lds_dma<4>(dst, src, n_floats >> 8, wave, lane);     // 1 KB per wave-instruction, scalar base + one lane offset (lds_dma.h)
+}
+template <int N_FLOATS>
+__device__ __forceinline__ void slab_dma_c(float* __restrict__ dst, const float* __restrict__ src, int wave, int lane)
+{
+    lds_dma_c<4, N_FLOATS / 256>(dst, src, wave, lane);
 }
 
 __device__ __forceinline__ void slab_sync()
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
     // ---- slab 0: bias = pts_bias(feat)
     slab_sync();
     stamp();                                                                                // [4] startup done
-    slab_dma(buf1, packed + L.l0, (int)seg_floats(PE_STEPS, 4), wave, lane);              // slab 1
+    slab_dma_c<(int)seg_floats(PE_STEPS, 4)>(buf1, packed + L.l0, wave, lane);              // slab 1
     {
         f32x16 acc[G][4];
         init_acc<4, G>(acc, vec + V_BIASG + half * 64);
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
     stamp();                                                                                // [5] bias gemm done
     // ---- slab 1: layer 0
     slab_sync();
-    slab_dma(buf0, packed + L.l1, HALF, wave, lane);                                      // slab 2
+    slab_dma_c<HALF>(buf0, packed + L.l1, wave, lane);                                      // slab 2
     {
         f32x16 acc[G][4];
         init_acc<4, G>(acc, vec + V_L0 + half * 64);
@@ -492,12 +495,12 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
         const float* wl = packed + L.l1 + (size_t)(layer - 1) * seg_floats(ACT_STEPS, 4);
         f32x16 acc[G][4];
         slab_sync();
-        slab_dma(buf1, wl + HALF, HALF, wave, lane);
+        slab_dma_c<HALF>(buf1, wl + HALF, wave, lane);
         init_acc<4, G>(acc, vec + V_L0 + 128 * layer + half * 64);
         gemm_stage<8, 4, G>(buf0, acc, lane, hlo);
         slab_sync();
         // next slab: first half of the next layer, or the positional-encoding part of layer 5
-        slab_dma(buf0, layer < 4 ? wl + 2 * HALF : packed + L.l5a, HALF, wave, lane);
+        slab_dma_c<HALF>(buf0, layer < 4 ? wl + 2 * HALF : packed + L.l5a, wave, lane);
         gemm_stage<8, 4, G>(buf1, acc, lane, hhi);
 #pragma unroll
         for (int q = 0; q < 64; ++q) { h[q] = fmaxf(acc[0][q >> 4][q & 15] * bias[q], 0.0f); save(S_H + layer * 64 + q, h[q]); }
@@ -508,14 +511,14 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
     {
         f32x16 acc[G][4];
         slab_sync();
-        slab_dma(buf1, packed + L.l5b, HALF, wave, lane);
+        slab_dma_c<HALF>(buf1, packed + L.l5b, wave, lane);
         init_acc<4, G>(acc, vec + V_L0 + 128 * 5 + half * 64);
         gemm_stage<PE_STEPS / 4, 4, G>(buf0, acc, lane, pe);
         slab_sync();
-        slab_dma(buf0, packed + L.l5b + HALF, HALF, wave, lane);
+        slab_dma_c<HALF>(buf0, packed + L.l5b + HALF, wave, lane);
         gemm_stage<8, 4, G>(buf1, acc, lane, hlo);
         slab_sync();
-        if (!ALPHA_ONLY) slab_dma(buf1, packed + L.feat, HALF, wave, lane);
+        if (!ALPHA_ONLY) slab_dma_c<HALF>(buf1, packed + L.feat, wave, lane);
         gemm_stage<8, 4, G>(buf0, acc, lane, hhi);
 #pragma unroll
         for (int q = 0; q < 64; ++q) { h[q] = fmaxf(acc[0][q >> 4][q & 15] * bias[q], 0.0f); save(S_H + 5 * 64 + q, h[q]); }
@@ -535,11 +538,11 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
     {
         f32x16 acc[G][4];
         slab_sync();
-        slab_dma(buf0, packed + L.feat + HALF, HALF, wave, lane);
+        slab_dma_c<HALF>(buf0, packed + L.feat + HALF, wave, lane);
         init_acc<4, G>(acc, vec + V_FEAT + half * 64);
         gemm_stage<8, 4, G>(buf1, acc, lane, hlo);
         slab_sync();
-        slab_dma(buf1, packed + L.views, (int)seg_floats(VIEW_STEPS, 2), wave, lane);
+        slab_dma_c<(int)seg_floats(VIEW_STEPS, 2)>(buf1, packed + L.views, wave, lane);
         gemm_stage<8, 4, G>(buf0, acc, lane, hhi);
 #pragma unroll
         for (int q = 0; q < 64; ++q) { h[q] = acc[0][q >> 4][q & 15]; save(S_FE + q, h[q]); }

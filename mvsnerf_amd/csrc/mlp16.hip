@@ -16,6 +16,7 @@
 // A workgroup = 8 waves = 128 points shares the weight slabs (LDS-DMA double buffering as in mlp_fwd_pipe_kernel); 6 waves per
 // workgroup load the four SIMDs unevenly (two of them carry twice the MFMA work) and ran at 0.389 ms.
 #include "common.h"
+#include "lds_dma.h"
 #include "mlp_layout.h"
 
 using namespace mlp;
@@ -135,10 +136,12 @@ constexpr int HALF = (ACT_ST / 2) * 8 * 64;               // floats of half a 12
 
 __device__ __forceinline__ void slab_dma(float* __restrict__ dst, const float* __restrict__ src, int n_floats, int wave, int lane)
 {
-    const int pieces = n_floats >> 8;                      // 1 KB per wave-instruction
-    for (int pc = wave; pc < pieces; pc += WAVES)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 256 + lane * 4),
-                                         (__attribute__((address_space(3))) void*)(dst + pc * 256), 16, 0, 0);
+    lds_dma<WAVES>(dst, src, n_floats >> 8, wave, lane);   // 1 KB per wave-instruction (lds_dma.h)
+}
+template <int N_FLOATS>
+__device__ __forceinline__ void slab_dma_c(float* __restrict__ dst, const float* __restrict__ src, int wave, int lane)
+{
+    lds_dma_c<WAVES, N_FLOATS / 256>(dst, src, wave, lane);
 }
 
 __device__ __forceinline__ void slab_sync()
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_fwd16_kernel(
     }
     // ---- slab 1: layer 0
     slab_sync();
-    slab_dma(buf0, packed + L.l1, HALF, wave, lane);                                     // slab 2
+    slab_dma_c<HALF>(buf0, packed + L.l1, wave, lane);                                     // slab 2
     {
         f32x4 acc[8];
         init16<8>(acc, vec + W_L0 + g * 32);
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_fwd16_kernel(
         const float* wl = packed + L.l1 + (size_t)(layer - 1) * seg(ACT_ST, 8);
         f32x4 acc[8];
         slab_sync();
-        slab_dma(buf1, wl + HALF, HALF, wave, lane);
+        slab_dma_c<HALF>(buf1, wl + HALF, wave, lane);
         init16<8>(acc, vec + W_L0 + 128 * layer + g * 32);
         gemm16<4, 8>(buf0, acc, lane, hlo);
         slab_sync();
@@ -292,14 +295,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_fwd16_kernel(
     {
         f32x4 acc[8];
         slab_sync();
-        slab_dma(buf1, packed + L.l5b, HALF, wave, lane);
+        slab_dma_c<HALF>(buf1, packed + L.l5b, wave, lane);
         init16<8>(acc, vec + W_L0 + 128 * 5 + g * 32);
         gemm16<PE_ST / 4, 8>(buf0, acc, lane, pe);
         slab_sync();
-        slab_dma(buf0, packed + L.l5b + HALF, HALF, wave, lane);
+        slab_dma_c<HALF>(buf0, packed + L.l5b + HALF, wave, lane);
         gemm16<4, 8>(buf1, acc, lane, hlo);
         slab_sync();
-        if (!ALPHA_ONLY) slab_dma(buf1, packed + L.feat, HALF, wave, lane);
+        if (!ALPHA_ONLY) slab_dma_c<HALF>(buf1, packed + L.feat, wave, lane);
         gemm16<4, 8>(buf0, acc, lane, hhi);
 #pragma unroll
         for (int q = 0; q < 32; ++q) h[q] = fmaxf(acc[q >> 2][q & 3] * bias[q], 0.0f);
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_fwd16_kernel(
     {
         f32x4 acc[8];
         slab_sync();
-        slab_dma(buf0, packed + L.feat + HALF, HALF, wave, lane);
+        slab_dma_c<HALF>(buf0, packed + L.feat + HALF, wave, lane);
         init16<8>(acc, vec + W_FEAT + g * 32);
         gemm16<4, 8>(buf1, acc, lane, hlo);
         slab_sync();

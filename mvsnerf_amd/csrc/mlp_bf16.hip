@@ -8,6 +8,7 @@
 // multiplicative modulation, ReLU, the positional encoding and the two small heads stay fp32.  With the MFMA work cut 16x the
 // kernel is VALU-bound (sin/cos, epilogues, conversions).
 #include "common.h"
+#include "lds_dma.h"
 #include "mlp_layout.h"
 
 using namespace mlp;
@@ -92,11 +93,7 @@ constexpr int B_LDS_BYTES = 2 * SLABB_BYTES + V_TOTAL * 4;
 
 __device__ __forceinline__ void slabb_dma(char* __restrict__ dst, const __bf16* __restrict__ src, size_t n_elems, int wave, int lane)
 {
-    const int pieces = (int)(n_elems >> 9);                          // 1 KB (512 bf16) per wave-instruction
-    const char* s = reinterpret_cast<const char*>(src);
-    for (int pc = wave; pc < pieces; pc += 4)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + pc * 1024 + lane * 16),
-                                         (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+    lds_dma<4>(dst, src, (int)(n_elems >> 9), wave, lane);           // 1 KB (512 bf16) per wave-instruction (lds_dma.h)
 }
 
 __device__ __forceinline__ void slabb_sync()

@@ -10,6 +10,7 @@
 //          no transposes.  Work-groups own contiguous tile ranges; partials are combined by a deterministic second
 //          kernel (no float atomics), which also un-permutes fragment order back to nn.Linear's [out][in].
 #include "common.h"
+#include "lds_dma.h"
 #include "act.h"
 #include "mlp_layout.h"
 
@@ -73,10 +74,7 @@ constexpr int LDS_FLOATS = 2 * WBUF_FLOATS + V_TOTAL;
 
 __device__ __forceinline__ void wdma(float* __restrict__ dst, const float* __restrict__ src, int n_floats, int wave, int lane)
 {
-    const int pieces = n_floats >> 8;                    // 1 KB per wave-instruction
-    for (int pc = wave; pc < pieces; pc += 4)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 256 + lane * 4),
-                                         (__attribute__((address_space(3))) void*)(dst + pc * 256), 16, 0, 0);
+    lds_dma<4>(dst, src, n_floats >> 8, wave, lane);     // 1 KB per wave-instruction (lds_dma.h)
 }
 
 __device__ __forceinline__ void wsync()

@@ -50,7 +50,7 @@ __host__ __device__ inline int kmap_col(int kmap, int t, int h, int F)
 __host__ __device__ inline int feat_steps(int F) { return ((F / 2) + 3) & ~3; }
 
 // segment sizes in floats: steps * blocks * 64 lanes
-__host__ __device__ inline size_t seg_floats(int steps, int nb) { return (size_t)steps * nb * 64; }
+__host__ __device__ constexpr inline size_t seg_floats(int steps, int nb) { return (size_t)steps * nb * 64; }
 
 // Offsets (floats) of the weight segments, in the order the kernel streams them.
 struct Layout {
