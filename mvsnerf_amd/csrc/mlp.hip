@@ -11,6 +11,7 @@
 #include "lds_dma.h"
 
 using namespace mlp;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------ pack
 struct PackArgs {
@@ -120,8 +121,12 @@ __device__ __forceinline__ void stage_weights(float* __restrict__ wbuf, const fl
 
 // acc[g][b] += W_frag(t, b) * bfn(g, t) for t in [0, 4*STEPS4); G = 32-point groups per wave
 // (one A fragment read from LDS feeds G MFMAs).
-template <int STEPS4, int NBLK, int G, typename BFN>
-__device__ __forceinline__ void gemm_stage(const float* __restrict__ w, f32x16 (&acc)[G][NBLK], int lane, BFN bfn)
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `after_first_reads` runs once, between the LDS reads of the first fragment group and its MFMAs: the pipelined kernel
+// issues the next slab's DMA there, so that the DMA instructions fill the LDS latency instead of preceding the reads.
+template <int STEPS4, int NBLK, int G, typename BFN, typename HOOK = NoHook>
+__device__ __forceinline__ void gemm_stage(const float* __restrict__ w, f32x16 (&acc)[G][NBLK], int lane, BFN bfn, HOOK after_first_reads = HOOK())
 {
 #pragma unroll
     for (int t4 = 0; t4 < STEPS4; ++t4) {
@@ -129,6 +134,7 @@ __device__ __forceinline__ void gemm_stage(const float* __restrict__ w, f32x16 (
 #pragma unroll
         for (int b = 0; b < NBLK; ++b)
             a[b] = *reinterpret_cast<const f32x4*>(w + ((t4 * NBLK + b) * 64 + lane) * 4);
+        if (t4 == 0) after_first_reads();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float bv[G];
@@ -486,7 +492,11 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
         init_acc<4, G>(acc, vec + V_L0 + half * 64);
         gemm_stage<PE_STEPS / 4, 4, G>(buf1, acc, lane, pe);
 #pragma unroll
-        for (int q = 0; q < 64; ++q) { h[q] = fmaxf(acc[0][q >> 4][q & 15] * bias[q], 0.0f); save(S_H + q, h[q]); }
+        for (int q = 0; q < 64; q += 2) {
+            const f32x2 m2 = f32x2{acc[0][q >> 4][q & 15], acc[0][q >> 4][(q & 15) + 1]} * f32x2{bias[q], bias[q + 1]};   // v_pk_mul_f32
+            h[q] = fmaxf(m2[0], 0.0f); h[q + 1] = fmaxf(m2[1], 0.0f);
+            save(S_H + q, h[q]); save(S_H + q + 1, h[q + 1]);
+        }
     }
     stamp();                                                                                // [6] layer 0 done
     // ---- layers 1..4: two slabs each (buf0 then buf1)
@@ -495,15 +505,17 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
         const float* wl = packed + L.l1 + (size_t)(layer - 1) * seg_floats(ACT_STEPS, 4);
         f32x16 acc[G][4];
         slab_sync();
-        slab_dma_c<HALF>(buf1, wl + HALF, wave, lane);
         init_acc<4, G>(acc, vec + V_L0 + 128 * layer + half * 64);
-        gemm_stage<8, 4, G>(buf0, acc, lane, hlo);
+        gemm_stage<8, 4, G>(buf0, acc, lane, hlo, [&]() { slab_dma_c<HALF>(buf1, wl + HALF, wave, lane); });
         slab_sync();
         // next slab: first half of the next layer, or the positional-encoding part of layer 5
-        slab_dma_c<HALF>(buf0, layer < 4 ? wl + 2 * HALF : packed + L.l5a, wave, lane);
-        gemm_stage<8, 4, G>(buf1, acc, lane, hhi);
+        gemm_stage<8, 4, G>(buf1, acc, lane, hhi, [&]() { slab_dma_c<HALF>(buf0, layer < 4 ? wl + 2 * HALF : packed + L.l5a, wave, lane); });
 #pragma unroll
-        for (int q = 0; q < 64; ++q) { h[q] = fmaxf(acc[0][q >> 4][q & 15] * bias[q], 0.0f); save(S_H + layer * 64 + q, h[q]); }
+        for (int q = 0; q < 64; q += 2) {
+            const f32x2 m2 = f32x2{acc[0][q >> 4][q & 15], acc[0][q >> 4][(q & 15) + 1]} * f32x2{bias[q], bias[q + 1]};   // v_pk_mul_f32
+            h[q] = fmaxf(m2[0], 0.0f); h[q + 1] = fmaxf(m2[1], 0.0f);
+            save(S_H + layer * 64 + q, h[q]); save(S_H + layer * 64 + q + 1, h[q + 1]);
+        }
         stamp();                                                                            // [7..10] layers 1..4 done
     }
     // ---- layer 5 on cat([pts, h4]): slabs 10 (buf0), 11 (buf1), 12 (buf0)
@@ -511,17 +523,18 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
     {
         f32x16 acc[G][4];
         slab_sync();
-        slab_dma_c<HALF>(buf1, packed + L.l5b, wave, lane);
         init_acc<4, G>(acc, vec + V_L0 + 128 * 5 + half * 64);
-        gemm_stage<PE_STEPS / 4, 4, G>(buf0, acc, lane, pe);
+        gemm_stage<PE_STEPS / 4, 4, G>(buf0, acc, lane, pe, [&]() { slab_dma_c<HALF>(buf1, packed + L.l5b, wave, lane); });
         slab_sync();
-        slab_dma_c<HALF>(buf0, packed + L.l5b + HALF, wave, lane);
-        gemm_stage<8, 4, G>(buf1, acc, lane, hlo);
+        gemm_stage<8, 4, G>(buf1, acc, lane, hlo, [&]() { slab_dma_c<HALF>(buf0, packed + L.l5b + HALF, wave, lane); });
         slab_sync();
-        if (!ALPHA_ONLY) slab_dma_c<HALF>(buf1, packed + L.feat, wave, lane);
-        gemm_stage<8, 4, G>(buf0, acc, lane, hhi);
+        gemm_stage<8, 4, G>(buf0, acc, lane, hhi, [&]() { if (!ALPHA_ONLY) slab_dma_c<HALF>(buf1, packed + L.feat, wave, lane); });
 #pragma unroll
-        for (int q = 0; q < 64; ++q) { h[q] = fmaxf(acc[0][q >> 4][q & 15] * bias[q], 0.0f); save(S_H + 5 * 64 + q, h[q]); }
+        for (int q = 0; q < 64; q += 2) {
+            const f32x2 m2 = f32x2{acc[0][q >> 4][q & 15], acc[0][q >> 4][(q & 15) + 1]} * f32x2{bias[q], bias[q + 1]};   // v_pk_mul_f32
+            h[q] = fmaxf(m2[0], 0.0f); h[q + 1] = fmaxf(m2[1], 0.0f);
+            save(S_H + 5 * 64 + q, h[q]); save(S_H + 5 * 64 + q + 1, h[q + 1]);
+        }
         const float* wa = vec + V_WA + half * 64;
         float part = 0.0f;
 #pragma unroll
@@ -538,12 +551,10 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
     {
         f32x16 acc[G][4];
         slab_sync();
-        slab_dma_c<HALF>(buf0, packed + L.feat + HALF, wave, lane);
         init_acc<4, G>(acc, vec + V_FEAT + half * 64);
-        gemm_stage<8, 4, G>(buf1, acc, lane, hlo);
+        gemm_stage<8, 4, G>(buf1, acc, lane, hlo, [&]() { slab_dma_c<HALF>(buf0, packed + L.feat + HALF, wave, lane); });
         slab_sync();
-        slab_dma_c<(int)seg_floats(VIEW_STEPS, 2)>(buf1, packed + L.views, wave, lane);
-        gemm_stage<8, 4, G>(buf0, acc, lane, hhi);
+        gemm_stage<8, 4, G>(buf0, acc, lane, hhi, [&]() { slab_dma_c<(int)seg_floats(VIEW_STEPS, 2)>(buf1, packed + L.views, wave, lane); });
 #pragma unroll
         for (int q = 0; q < 64; ++q) { h[q] = acc[0][q >> 4][q & 15]; save(S_FE + q, h[q]); }
     }
