@@ -87,6 +87,8 @@ def parse():
     ap.add_argument("--mlp-variant", type=int, default=None)
     ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16", "bf16x3", "bf16x6"],
                     help="matrix-core arithmetic of the timed MLP (default fp32 = the headline; the others are the opt-in modes)")
+    ap.add_argument("--settle-ms", type=float, default=100.0,
+                    help="untimed steps of the same workload run before the W warmup steps until the GPU clocks have left the idle state")
     ap.add_argument("--no-extras", action="store_true", help="skip the end-to-end frame / training-step timings")
     return ap.parse_args()
 
@@ -97,7 +99,23 @@ def load_mlp_weights():
     return {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("mlp/")}
 
 
-def event_time(fn, iters, warm=3, graph_batch=0):
+def settle(fn, ms, indexed=False):
+    """Untimed launches of fn for >= `ms` of wall time.  The GPU leaves its idle power state over the first ~25 ms of sustained
+    load (scratch/ramp.py: the MLP kernel runs 0.288 -> 0.239 ms/launch over the first 100 launches after a 1 s pause), so
+    every timed region is preceded by this much of the same work; what is reported is the steady state."""
+    if ms <= 0:
+        return
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    i = 0
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(20):
+            fn(i) if indexed else fn()
+            i += 1
+        torch.cuda.synchronize()
+
+
+def event_time(fn, iters, warm=3, graph_batch=0, settle_ms=40):
     """Average duration (ms) of one call of fn, HIP events on the current (= launch) stream.
     graph_batch > 0: the launches are captured into a hipGraph of `graph_batch` back-to-back calls and replayed, so that
     kernels of a few microseconds are not timed through the ~8 us of Python/ctypes launch overhead (the ~1.5 us
@@ -116,6 +134,7 @@ def event_time(fn, iters, warm=3, graph_batch=0):
         torch.cuda.current_stream().wait_stream(side)
         g.replay()
         torch.cuda.synchronize()
+        settle(g.replay, settle_ms)
         reps = max(1, iters // graph_batch)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -124,6 +143,7 @@ def event_time(fn, iters, warm=3, graph_batch=0):
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / (reps * graph_batch)
+    settle(fn, settle_ms)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
@@ -213,6 +233,7 @@ def main():
         return renderer.rendering(args, pose, pts, ndc, z, ro, rdir, vol, src, network_fn=net, network_query_fn=qfn)
 
     with torch.no_grad():
+        settle(step, a.settle_ms, indexed=True)
         for i in range(a.warmup):
             step(i)
         torch.cuda.synchronize()
@@ -393,7 +414,8 @@ def main():
             "config": {"workload": "config 2: 3 source views 512x640, 128 depth planes, pad 24 (volume 128x176x208x8), "
                                    f"1024 rays x 128 samples per step, MLP arithmetic {a.mlp_precision}, render-only (volume pre-built)",
                        "weights": "mvsnerf-v0 checkpoint", "volume": volume_src, "rays_per_step_per_gpu": N_RAYS,
-                       "parallelism": f"ray-sharded x{world}, no data-path collective"},
+                       "parallelism": f"ray-sharded x{world}, no data-path collective",
+                       "clock_settle_ms": a.settle_ms},
             "encode_ms": encode_ms,
             "roofline": roof, "rooflines": roofs, "cpu_baseline": cpu, "extras": extras,
         }))

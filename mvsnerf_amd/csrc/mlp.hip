@@ -389,12 +389,12 @@ __global__ __launch_bounds__(256, WPS) void mlp_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------ pipelined forward
-// Measured on MI355X (scratch/census.py, profiles/r01_mlp_census.txt): the shader clock sits at ~2.07 GHz while this kernel
-// runs (DVFS under sustained fp32-MFMA load with real operands), the MFMA pipe is 92-94 % busy while waves are resident
-// (SQ_VALU_MFMA_BUSY_CYCLES vs SQ_WAVE_CYCLES), and the kernel reaches 123-131 TFLOP/s = 78-83 % of the 2.4 GHz datasheet peak
-// (PMC: matrix pipes busy 80 % of the kernel's duration at ~2.4 GHz).  Negative results kept out of the code: (i) staggering / prioritising the
-// two co-resident workgroups of a CU: no change; (ii) reading A fragments straight from L2 (no LDS stage, no barriers):
-// 114 TFLOP/s; (iii) 64 points per wave at one wave per SIMD: 114 TFLOP/s.
+// Measured on MI355X: 0.237 ms per 1024x128 batch = 139 TFLOP/s = 88 % of the 157.3 TFLOP/s fp32-MFMA peak; PMC:
+// matrix pipes busy 85 % of the kernel's duration.  What the rest is: VALU instructions cost matrix-pipe issue time on this
+// chip whichever wave issues them (scratch/mfma_mix.hip: one v_fma per MFMA takes 12 % off the MFMA rate), ~1 950 of them per
+// 1 976 MFMAs here; launch ramp / tail of a two-round grid.  Negative results kept out of the code: (i) staggering /
+// prioritising the two co-resident workgroups of a CU: no change; (ii) reading A fragments straight from L2 (no LDS stage, no
+// barriers): 114 TFLOP/s; (iii) 64 points per wave at one wave per SIMD: 114 TFLOP/s.
 // Same arithmetic as mlp_fwd_kernel<.., G=1, ..>, different weight logistics: the packed weights are cut into 16 slabs
 // of <= 34 KB (half a 128x128 layer = 32 k-steps) that alternate between two LDS buffers.  While the MFMAs of slab i
 // run, slab i+1 arrives by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write pass); one barrier per slab.
