@@ -64,11 +64,13 @@ extern "C" int mvsnerf_resize_bilinear(const float* src, float* dst, int NC, int
 
 // =============================================================================================
 // plane sweep: homo_warp (utils.py:580-630) + build_volume_costvar[_img] (models.py:787-893) in ONE pass.
-// One thread per voxel (d,y,x), x fastest.  Reads ~1 KB of L2-resident source features per voxel,
-// writes the voxel's CP-channel vector once (the reference moves ~10 GB for the same result).
+// FOUR lanes per voxel (d,y,x; x fastest): lane q owns the channel quads {q, q+4} of the 32-channel feature vector, so a
+// wave-level 16-byte load covers 16 voxels x 64 CONTIGUOUS bytes of a source pixel.  The first version gave a whole voxel
+// (8 x 16-byte loads per tap) to one lane: every load instruction touched 64 different 128-byte lines for 16 useful bytes
+// each and the kernel ran at the L1 line rate (0.57 ms); the projection arithmetic is repeated by the four lanes, which
+// costs nothing per instruction.  Reads ~1 KB of L2-resident source features per voxel, writes the voxel's CP-channel
+// vector once (the reference moves ~10 GB for the same result).
 // =============================================================================================
-struct SweepGeom { float R[9]; float T[3]; };    // one source view: proj_mat[:, :3], proj_mat[:, 3]
-
 template <int C>   // feature channels (32)
 __global__ __launch_bounds__(256) void planesweep_kernel(
     const float* __restrict__ feat,   // [V][H][W][C]
@@ -80,33 +82,33 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
     float* __restrict__ masks,          // with img: [V][D][Hp][Wp] per-view; else [D][Hp][Wp] count
     int with_img)
 {
+    static_assert(C == 32, "lane q owns float4 numbers q and q + 4 of a 32-channel pixel");
+    constexpr int VPB = 64;                                      // voxels per block (4 lanes each)
+    const int q = threadIdx.x & 3, vloc = threadIdx.x >> 2;
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const int64_t nvox = (int64_t)D * Hp * Wp;
-    const int64_t i_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i_raw = (int64_t)blockIdx.x * VPB + vloc;
     const bool live = i_raw < nvox;
-    const int64_t i = live ? i_raw : nvox - 1;                   // tail threads recompute the last voxel (their stores are masked)
+    const int64_t i = live ? i_raw : nvox - 1;                   // tail lanes recompute the last voxel (their stores are masked)
     const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), d = (int)(i / ((int64_t)Wp * Hp));
     const float u = (float)(x - pad), v = (float)(y - pad);     // utils.py:603-605
     const float dep = depth[d];
     const bool interior = x >= pad && x < W + pad && y >= pad && y < H + pad;
 
-    float s[C], s2[C];
-    extern __shared__ __attribute__((aligned(16))) float stage[];     // [256][CP+4]: +4 floats per row breaks the bank stride
-    float* o = stage + threadIdx.x * (CP + 4);
+    float s[8], s2[8];                                           // channels 4q..4q+3 and 16+4q..16+4q+3
+    extern __shared__ __attribute__((aligned(16))) float stage[];     // [VPB][CP+4]: +4 floats per row breaks the bank stride
+    float* o = stage + vloc * (CP + 4);
     const int c_var = with_img ? 3 * V : 0;
     if (interior) {                                              // ref volume: zero-padded ref feature (models.py:856,862)
         const f32x4* r = reinterpret_cast<const f32x4*>(feat + ((int64_t)(y - pad) * W + (x - pad)) * C);
+        const f32x4 t0 = r[q], t1 = r[q + 4];
 #pragma unroll
-        for (int c4 = 0; c4 < C / 4; ++c4) {
-            const f32x4 t = r[c4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { s[c4 * 4 + k] = t[k]; s2[c4 * 4 + k] = t[k] * t[k]; }
-        }
+        for (int k = 0; k < 4; ++k) { s[k] = t0[k]; s2[k] = t0[k] * t0[k]; s[4 + k] = t1[k]; s2[4 + k] = t1[k] * t1[k]; }
     } else {
 #pragma unroll
-        for (int c = 0; c < C; ++c) { s[c] = 0.f; s2[c] = 0.f; }
+        for (int c = 0; c < 8; ++c) { s[c] = 0.f; s2[c] = 0.f; }
     }
-    if (with_img) {                                              // channels 0:3 = ref thumbnail, border := 0 (models.py:858-860)
+    if (with_img && q == 0) {                                    // channels 0:3 = ref thumbnail, border := 0 (models.py:858-860)
         const float* ri = img + ((int64_t)(y - pad) * W + (x - pad)) * 4;
         o[0] = interior ? ri[0] : 0.f; o[1] = interior ? ri[1] : 0.f; o[2] = interior ? ri[2] : 0.f;
         if (live) masks[i] = 1.0f;                               // view 0 mask (models.py:869)
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
         const float gy = (p1 / p2) / ((float)(H - 1) / 2.0f) - 1.0f;
         const float m = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;   // models.py:875-876
         cnt += m;
-        if (with_img && live) masks[(int64_t)vv * nvox + i] = m;
+        if (with_img && live && q == 0) masks[(int64_t)vv * nvox + i] = m;
         // F.grid_sample bilinear, zeros padding, align_corners=True (utils.py:625)
         const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
         const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
@@ -142,16 +144,16 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
         const f32x4* t_sw = reinterpret_cast<const f32x4*>(fb + ((int64_t)yb * W + xa) * C);
         const f32x4* t_se = reinterpret_cast<const f32x4*>(fb + ((int64_t)yb * W + xb) * C);
 #pragma unroll
-        for (int c4 = 0; c4 < C / 4; ++c4) {
-            const f32x4 a = t_nw[c4], b = t_ne[c4], c_ = t_sw[c4], e = t_se[c4];
+        for (int hh = 0; hh < 2; ++hh) {
+            const f32x4 a = t_nw[q + 4 * hh], b = t_ne[q + 4 * hh], c_ = t_sw[q + 4 * hh], e = t_se[q + 4 * hh];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float wv = ((a[k] * w_nw + b[k] * w_ne) + c_[k] * w_sw) + e[k] * w_se;   // ATen's nw,ne,sw,se order
-                s[c4 * 4 + k] += wv;                             // models.py:880
-                s2[c4 * 4 + k] += wv * wv;                       // :881
+                s[hh * 4 + k] += wv;                             // models.py:880
+                s2[hh * 4 + k] += wv * wv;                       // :881
             }
         }
-        if (with_img) {                                          // warped thumbnail with the same grid (models.py:872)
+        if (with_img && q == (vv & 3)) {                         // warped thumbnail with the same grid (models.py:872), one lane per view
             const float* ib = img + (int64_t)vv * H * W * 4;
             const f32x4 a = *reinterpret_cast<const f32x4*>(ib + ((int64_t)ya * W + xa) * 4);
             const f32x4 b = *reinterpret_cast<const f32x4*>(ib + ((int64_t)ya * W + xb) * 4);
@@ -161,20 +163,22 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
             for (int k = 0; k < 3; ++k) o[3 * vv + k] = ((a[k] * w_nw + b[k] * w_ne) + c_[k] * w_sw) + e[k] * w_se;
         }
     }
-    if (!with_img && live) masks[i] = cnt;                       // build_volume_costvar returns the count (models.py:821)
+    if (!with_img && live && q == 0) masks[i] = cnt;             // build_volume_costvar returns the count (models.py:821)
     const float inv = 1.0f / cnt;                                // models.py:889
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const float mean = s[c] * inv;
-        o[c_var + c] = s2[c] * inv - mean * mean;                // :890
+    for (int j = 0; j < 8; ++j) {
+        const int c = (j < 4 ? 4 * q : 16 + 4 * q - 4) + j;
+        const float mean = s[j] * inv;
+        o[c_var + c] = s2[j] * inv - mean * mean;                // :890
     }
-    for (int c = c_var + C; c < CP; ++c) o[c] = 0.0f;
-    // `o` points into the LDS staging row of this thread; flush the block's 256 consecutive voxels (one contiguous
-    // CP*256*4-byte span of the cost volume) with coalesced 16-byte stores
+    if (q == 0)
+        for (int c = c_var + C; c < CP; ++c) o[c] = 0.0f;
+    // `o` points into the LDS staging row of this voxel; flush the block's 64 consecutive voxels (one contiguous
+    // CP*64*4-byte span of the cost volume) with coalesced 16-byte stores
     __syncthreads();
     {
-        const int64_t v0 = (int64_t)blockIdx.x * 256;
-        const int64_t nv = nvox - v0 < 256 ? nvox - v0 : 256;
+        const int64_t v0 = (int64_t)blockIdx.x * VPB;
+        const int64_t nv = nvox - v0 < VPB ? nvox - v0 : VPB;
         const int n4 = (int)(nv * CP / 4);
         f32x4* dst = reinterpret_cast<f32x4*>(cost + v0 * CP);
         for (int k = threadIdx.x; k < n4; k += 256) {
@@ -195,8 +199,8 @@ extern "C" int mvsnerf_planesweep_costvar_fwd(const float* feats_cl, const float
     if (!mvs_aligned16(feats_cl) || (imgs_cl && !mvs_aligned16(imgs_cl))) return MVSNERF_EALIGN;
     const int64_t nvox = (int64_t)D * (H + 2 * pad) * (W + 2 * pad);
     if ((CP & 3) || !mvs_aligned16(cost)) return MVSNERF_EALIGN;
-    const size_t lds = (size_t)256 * (CP + 4) * sizeof(float);
-    planesweep_kernel<32><<<mvs_cdiv(nvox, 256), 256, lds, (hipStream_t)stream>>>(feats_cl, imgs_cl, proj, depth, V, H, W, D, pad, cost, CP, masks, with_img);
+    const size_t lds = (size_t)64 * (CP + 4) * sizeof(float);
+    planesweep_kernel<32><<<mvs_cdiv(nvox, 64), 256, lds, (hipStream_t)stream>>>(feats_cl, imgs_cl, proj, depth, V, H, W, D, pad, cost, CP, masks, with_img);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
