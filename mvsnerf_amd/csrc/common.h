@@ -15,3 +15,13 @@ static inline unsigned mvs_cdiv(int64_t a, int64_t b) { return (unsigned)((a + b
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Workgroups are dealt to the 8 XCDs round-robin by their linear id (workgroup i runs on XCD i % 8) and every XCD has its own L2.
+// Kernels whose neighbouring workgroups share input (convolution halos) renumber their tiles so that an XCD walks a CONTIGUOUS
+// range of tile ids: tile = xcd_contiguous_tile(blockIdx.x, gridDim.x).
+__device__ __forceinline__ int xcd_contiguous_tile(int bid, int nb)
+{
+    const int per = nb >> 3, rem = nb & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return xcd * per + (xcd < rem ? xcd : rem) + idx;
+}
