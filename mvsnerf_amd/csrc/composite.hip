@@ -4,75 +4,67 @@
 // by a wave-level exclusive multiplicative scan (6 __shfl_up steps) of the per-lane chunk products.
 // HBM-bound: 20 B read + 8 B written per sample.
 #include "common.h"
+#include "composite_wave.h"
 
-template <int CHUNK>   // CHUNK > 0: samples per lane known at compile time (values stay in registers)
+template <int CHUNK>   // CHUNK > 0: samples per lane known at compile time (values stay in registers, composite_wave.h)
 __global__ __launch_bounds__(256) void composite_kernel(
-    const float* __restrict__ raw, const float* __restrict__ z, int64_t N, int S, int chunk_rt, int white_bkgd,
-    float* __restrict__ rgb_map, float* __restrict__ disp, float* __restrict__ acc_map,
-    float* __restrict__ weights, float* __restrict__ depth_map, float* __restrict__ alpha_out)
+    const float* __restrict__ raw, const float* __restrict__ z, int64_t N, int S, int chunk_rt, CompositeOut o)
 {
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (ray >= N) return;                                   // wave-uniform
-    constexpr int NR = CHUNK > 0 ? CHUNK : 1;
-    const int chunk = CHUNK > 0 ? CHUNK : chunk_rt;
-    const int s0 = lane * chunk;
     const float* rr = raw + ray * S * 4;
     const float* zr = z + ray * S;
-
-    f32x4 rv[NR];
-    float prod = 1.0f;
-    if (CHUNK > 0) {
+    if constexpr (CHUNK > 0) {
+        f32x4 rv[CHUNK];
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int s = s0 + i;
+        for (int i = 0; i < CHUNK; ++i) {
+            const int s = lane * CHUNK + i;
             rv[i] = (s < S) ? *reinterpret_cast<const f32x4*>(rr + s * 4) : f32x4{0, 0, 0, 0};
-            if (s < S) prod *= (1.0f - (1.0f - expf(-rv[i][3]))) + 1e-10f;
         }
+        composite_wave<CHUNK>(rv, zr, ray, S, lane, o);
     } else {
+        // long rays (more than 4 samples per lane): the same walk with the samples re-read from memory
+        const int chunk = chunk_rt, s0 = lane * chunk;
+        float prod = 1.0f;
         for (int i = 0; i < chunk; ++i) {
             const int s = s0 + i;
             if (s < S) prod *= (1.0f - (1.0f - expf(-rr[s * 4 + 3]))) + 1e-10f;
         }
-    }
-    // inclusive multiplicative scan over lanes, then shift to exclusive
-    float scan = prod;
+        float scan = prod;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const float o = __shfl_up(scan, d);
-        if (lane >= d) scan *= o;
-    }
-    float T = __shfl_up(scan, 1);
-    if (lane == 0) T = 1.0f;
-
-    float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
-    auto step = [&](int s, const f32x4& v) {
-        const float a = 1.0f - expf(-v[3]);                 // renderer.py:22  (dist ignored)
-        const float w = a * T;                              // :25
-        T *= (1.0f - a) + 1e-10f;                           // :24
-        sr += w * v[0]; sg += w * v[1]; sb += w * v[2];
-        sd += w * zr[s]; sa += w;
-        if (weights) weights[ray * S + s] = w;
-        if (alpha_out) alpha_out[ray * S + s] = a;
-    };
-    if (CHUNK > 0) {
+        for (int d = 1; d < 64; d <<= 1) {
+            const float t = __shfl_up(scan, d);
+            if (lane >= d) scan *= t;
+        }
+        float T = __shfl_up(scan, 1);
+        if (lane == 0) T = 1.0f;
+        float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+        for (int i = 0; i < chunk; ++i) {
+            const int s = s0 + i;
+            if (s >= S) break;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rr + s * 4);
+            const float a = 1.0f - expf(-v[3]);
+            const float w = a * T;
+            T *= (1.0f - a) + 1e-10f;
+            sr += w * v[0]; sg += w * v[1]; sb += w * v[2];
+            sd += w * zr[s]; sa += w;
+            if (o.weights) o.weights[ray * S + s] = w;
+            if (o.alpha_out) o.alpha_out[ray * S + s] = a;
+        }
 #pragma unroll
-        for (int i = 0; i < NR; ++i) if (s0 + i < S) step(s0 + i, rv[i]);
-    } else {
-        for (int i = 0; i < chunk; ++i) if (s0 + i < S) step(s0 + i, *reinterpret_cast<const f32x4*>(rr + (s0 + i) * 4));
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        sr += __shfl_xor(sr, d); sg += __shfl_xor(sg, d); sb += __shfl_xor(sb, d);
-        sd += __shfl_xor(sd, d); sa += __shfl_xor(sa, d);
-    }
-    if (lane == 0) {
-        const float dsp = 1.0f / fmaxf(1e-10f, sd / sa);                                 // :87
-        if (white_bkgd) { const float bg = 1.0f - sa; sr += bg; sg += bg; sb += bg; }   // :90-91
-        if (rgb_map) { rgb_map[ray * 3] = sr; rgb_map[ray * 3 + 1] = sg; rgb_map[ray * 3 + 2] = sb; }
-        if (depth_map) depth_map[ray] = sd;
-        if (acc_map) acc_map[ray] = sa;
-        if (disp) disp[ray] = dsp;
+        for (int d = 32; d >= 1; d >>= 1) {
+            sr += __shfl_xor(sr, d); sg += __shfl_xor(sg, d); sb += __shfl_xor(sb, d);
+            sd += __shfl_xor(sd, d); sa += __shfl_xor(sa, d);
+        }
+        if (lane == 0) {
+            const float dsp = 1.0f / fmaxf(1e-10f, sd / sa);
+            if (o.white_bkgd) { const float bg = 1.0f - sa; sr += bg; sg += bg; sb += bg; }
+            if (o.rgb_map) { o.rgb_map[ray * 3] = sr; o.rgb_map[ray * 3 + 1] = sg; o.rgb_map[ray * 3 + 2] = sb; }
+            if (o.depth_map) o.depth_map[ray] = sd;
+            if (o.acc_map) o.acc_map[ray] = sa;
+            if (o.disp) o.disp[ray] = dsp;
+        }
     }
 }
 
@@ -86,7 +78,8 @@ extern "C" int mvsnerf_composite_fwd(const float* raw, const float* z, int64_t N
     hipStream_t st = (hipStream_t)stream;
     const int chunk = (S + 63) / 64;
     const unsigned grid = mvs_cdiv(N, 4);
-#define MVS_COMP(C) composite_kernel<C><<<grid, 256, 0, st>>>(raw, z, N, S, chunk, white_bkgd, rgb_map, disp, acc, weights, depth, alpha)
+const CompositeOut o{rgb_map, disp, acc, weights, depth, alpha, white_bkgd};
+#define MVS_COMP(C) composite_kernel<C><<<grid, 256, 0, st>>>(raw, z, N, S, chunk, o)
     switch (chunk) {
         case 1: MVS_COMP(1); break;
         case 2: MVS_COMP(2); break;
