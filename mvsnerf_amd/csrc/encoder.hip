@@ -285,10 +285,10 @@ extern "C" int mvsnerf_conv3d_pack_weights(const float* w, int ci_real, int co_r
 template <int CIN, int CT, int S>
 __global__ __launch_bounds__(256) void conv3d_k3_kernel(ActSrc a, ActSrc b, int ld, int Di, int Hi, int Wi,
                                                        const float* __restrict__ wp, int Cout,
-                                                       float* __restrict__ out, int Do, int Ho, int Wo)
+                                                       float* __restrict__ out, int Do, int Ho, int Wo, int swz)
 {
     const int64_t nvox = (int64_t)Do * Ho * Wo;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = (int64_t)(swz ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x) * blockDim.x + threadIdx.x;   // an XCD walks contiguous voxels
     const int cg = blockIdx.y * CT;                       // first output channel of this thread
     if (i >= nvox) return;
     const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho), z = (int)(i / ((int64_t)Wo * Ho));
@@ -405,11 +405,11 @@ __global__ __launch_bounds__(256) void conv3d_k3s1_tiled_kernel(ActSrc a, ActSrc
 // class with strided stores (conv11 436 -> ~600 us), and one thread per x pair with three weight sets per channel chunk.
 template <int CIN, int CT>
 __global__ __launch_bounds__(256) void convT3d_k3s2_kernel(ActSrc a, ActSrc b, int Di, int Hi, int Wi,
-                                                          const float* __restrict__ wp, int Cout, float* __restrict__ out)
+                                                          const float* __restrict__ wp, int Cout, float* __restrict__ out, int swz)
 {
     const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
     const int64_t nvox = (int64_t)Do * Ho * Wo;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = (int64_t)(swz ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x) * blockDim.x + threadIdx.x;
     const int cg = blockIdx.y * CT;
     if (i >= nvox) return;
     const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho), z = (int)(i / ((int64_t)Wo * Ho));
@@ -457,7 +457,7 @@ extern "C" int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const fl
     const int64_t nvox = (int64_t)Do * Ho * Wo;
     hipStream_t st = (hipStream_t)stream;
 #define MVS_CONV(CIN, CT, S)                                                                          \
-    conv3d_k3_kernel<CIN, CT, S><<<dim3(mvs_cdiv(nvox, 256), Cout / CT), 256, 0, st>>>(a, b, cin_ld, D, H, W, wpacked, Cout, out, Do, Ho, Wo)
+    conv3d_k3_kernel<CIN, CT, S><<<dim3(mvs_cdiv(nvox, 256), Cout / CT), 256, 0, st>>>(a, b, cin_ld, D, H, W, wpacked, Cout, out, Do, Ho, Wo, g_conv_xcd)
 #define MVS_CONV_TILED(CIN, CT)                                                                       \
     conv3d_k3s1_tiled_kernel<CIN, CT><<<dim3(((W + 7) / 8) * ((H + 7) / 8) * ((D + 3) / 4), Cout / CT), 256, 0, st>>>(a, b, cin_ld, D, H, W, wpacked, Cout, out, g_conv_xcd)
     // (Cin rounded up to a multiple of 4 by the caller's channel padding; Cout in {8,16,32,64})
@@ -495,7 +495,7 @@ extern "C" int mvsnerf_conv_transpose3d_fwd(const float* x1, const float* scale1
     const ActSrc a{x1, scale1, shift1}, b{x2, scale2, shift2};
     const int64_t nvox = (int64_t)8 * D * H * W;
     hipStream_t st = (hipStream_t)stream;
-#define MVS_CONVT(CIN, CT) convT3d_k3s2_kernel<CIN, CT><<<dim3(mvs_cdiv(nvox, 256), Cout / CT), 256, 0, st>>>(a, b, D, H, W, wpacked, Cout, out)
+#define MVS_CONVT(CIN, CT) convT3d_k3s2_kernel<CIN, CT><<<dim3(mvs_cdiv(nvox, 256), Cout / CT), 256, 0, st>>>(a, b, D, H, W, wpacked, Cout, out, g_conv_xcd)
     switch (Cin * 100 + Cout) {
         case 64 * 100 + 32: MVS_CONVT(64, 16); break;   // conv7
         case 32 * 100 + 16: MVS_CONVT(32, 16); break;   // conv9

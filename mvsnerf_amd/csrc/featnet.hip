@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ActSrc a, int ld, int Hi, i
 {
     constexpr int P = K / 2;
     const int nbx = (Wo + 15) >> 4, nby = (Ho + 15) >> 4;
-    const int bx = blockIdx.x % nbx, by = (blockIdx.x / nbx) % nby, n = blockIdx.x / (nbx * nby);
+    const int tile_id = xcd_contiguous_tile(blockIdx.x, gridDim.x);      // halo neighbours share an XCD's L2 (common.h)
+    const int bx = tile_id % nbx, by = (tile_id / nbx) % nby, n = tile_id / (nbx * nby);
     const int cg = blockIdx.y * CT;
     const int x = bx * 16 + (threadIdx.x & 15), y = by * 16 + (threadIdx.x >> 4);
     const bool live = x < Wo && y < Ho;
