@@ -282,9 +282,9 @@ extern "C" int mvsnerf_conv3d_pack_weights(const float* w, int ci_real, int co_r
 
 // Direct 3x3x3 convolution, padding 1, stride S.  One thread = one output voxel x CT output channels.
 // Neighbouring threads re-read each other's input voxels through L1/L2 (27-fold reuse).
-template <int CIN, int CT, int S>
+template <int CIN, int CT, int S, int COUT>      // COUT a template constant: weight offsets become s_load immediates
 __global__ __launch_bounds__(256) void conv3d_k3_kernel(ActSrc a, ActSrc b, int ld, int Di, int Hi, int Wi,
-                                                       const float* __restrict__ wp, int Cout,
+                                                       const float* __restrict__ wp,
                                                        float* __restrict__ out, int Do, int Ho, int Wo, int swz)
 {
     const int64_t nvox = (int64_t)Do * Ho * Wo;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(ActSrc a, ActSrc b, int 
         const int zi = z * S - 1 + dz, yi = y * S - 1 + dy, xi = x * S - 1 + dx;
         const bool in = zi >= 0 && zi < Di && yi >= 0 && yi < Hi && xi >= 0 && xi < Wi;
         const int64_t vox = in ? ((int64_t)zi * Hi + yi) * Wi + xi : 0;
-        const float* wt = wp + (int64_t)tap * CIN * Cout + cg;
+        const float* wt = wp + (int64_t)tap * CIN * COUT + cg;
 #pragma unroll 2
         for (int c = 0; c < CIN; c += 4) {
             f32x4 v;
@@ -309,10 +309,10 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(ActSrc a, ActSrc b, int 
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4)
 #pragma unroll
-                for (int k = 0; k < CT; ++k) acc[k] = fmaf(v[k4], wt[(int64_t)(c + k4) * Cout + k], acc[k]);
+                for (int k = 0; k < CT; ++k) acc[k] = fmaf(v[k4], wt[(c + k4) * COUT + k], acc[k]);
         }
     }
-    float* o = out + i * Cout + cg;
+    float* o = out + i * COUT + cg;
 #pragma unroll
     for (int k = 0; k < CT; k += 4) *reinterpret_cast<f32x4*>(o + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
 }
@@ -323,9 +323,9 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(ActSrc a, ActSrc b, int 
 // stride touch one cache line per lane).  The pending InPlaceABN of the producer is applied once per staged
 // element instead of once per tap.  Chunk sizes are compile-time and the x-taps are unrolled so that the LDS reads
 // and the scalar weight loads of one (dz,dy) step are in flight while the previous step's FMAs issue.
-template <int CIN, int CT, int C0, int CKC>     // one channel chunk [C0, C0+CKC) of the tile
+template <int CIN, int CT, int COUT, int C0, int CKC>     // one channel chunk [C0, C0+CKC) of the tile
 __device__ __forceinline__ void conv_tile_chunk(const ActSrc& a, const ActSrc& b, int ld, int D, int H, int W, int x0, int y0, int z0,
-                                                const float* __restrict__ wp, int Cout, int cg, float* __restrict__ tile,
+                                                const float* __restrict__ wp, int cg, float* __restrict__ tile,
                                                 int tid, int tx, int ty, int tz, float (&acc)[CT])
 {
     constexpr int CK = 12, IY = 10, IX = 10, NV = 6 * IY * IX, K4 = CKC / 4;
@@ -344,21 +344,50 @@ __device__ __forceinline__ void conv_tile_chunk(const ActSrc& a, const ActSrc& b
     for (int dzy = 0; dzy < 9; ++dzy) {
         const int dz = dzy / 3, dy = dzy - dz * 3;
         const float* tv = tile + (((tz + dz) * IY + ty + dy) * IX + tx) * CK;
-        const float* wt = wp + ((int64_t)(dzy * 3) * CIN + C0) * Cout + cg;
+        const float* wt = wp + ((int64_t)(dzy * 3) * CIN + C0) * COUT + cg;   // COUT is a template constant: the weight offsets below are s_load immediates
         f32x4 v[3][K4];
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
             for (int c4 = 0; c4 < K4; ++c4) v[dx][c4] = *reinterpret_cast<const f32x4*>(tv + dx * CK + c4 * 4);
+        if constexpr (CT <= 16) {
+            // Weights in groups of 32 (scalar loads, SGPRs), group g+1 requested before the FMAs of group g and a scheduling
+            // fence after each group: left alone the scheduler hoists several groups of s_load_dwordx16, runs out of SGPRs and
+            // parks weights in VGPR lanes (v_writelane / v_readlane per weight) - and this kernel is bound by the NUMBER of
+            // instructions a SIMD can issue, scalar ones included (PMC: 0.6 scalar instructions per packed FMA cost 27 % of
+            // the issue cycles; with Cout a template constant the weight offsets are s_load immediates: conv0 2.0 -> 1.65 ms).
+            constexpr int KPG = CT <= 8 ? 4 : 2;                 // k4 values per weight group
+            constexpr int GPC = 4 / KPG, NG = 3 * K4 * GPC;       // groups per float4 of x, groups per row
+            float w[2][KPG * CT];
+            auto wload = [&](float (&wd)[KPG * CT], int g) {
+                const int dx = g / (K4 * GPC), r = g - dx * (K4 * GPC), c4 = r / GPC, kb = (r - c4 * GPC) * KPG;
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
+                for (int j = 0; j < KPG; ++j)
 #pragma unroll
-            for (int c4 = 0; c4 < K4; ++c4)
+                    for (int k = 0; k < CT; ++k) wd[j * CT + k] = wt[(dx * CIN + c4 * 4 + kb + j) * COUT + k];
+            };
+            wload(w[0], 0);
 #pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4)
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) wload(w[(g + 1) & 1], g + 1);
+                const int dx = g / (K4 * GPC), r = g - dx * (K4 * GPC), c4 = r / GPC, kb = (r - c4 * GPC) * KPG;
 #pragma unroll
-                    for (int k = 0; k < CT; ++k)
-                        acc[k] = fmaf(v[dx][c4][k4], wt[((int64_t)dx * CIN + c4 * 4 + k4) * Cout + k], acc[k]);
+                for (int j = 0; j < KPG; ++j)
+#pragma unroll
+                    for (int k = 0; k < CT; ++k) acc[k] = fmaf(v[dx][c4][kb + j], w[g & 1][j * CT + k], acc[k]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int c4 = 0; c4 < K4; ++c4)
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+                        for (int k = 0; k < CT; ++k)
+                            acc[k] = fmaf(v[dx][c4][k4], wt[(dx * CIN + c4 * 4 + k4) * COUT + k], acc[k]);
+        }
     }
 }
 
@@ -367,9 +396,9 @@ __device__ __forceinline__ void conv_tile_chunk(const ActSrc& a, const ActSrc& b
 // traffic and 2/3 of the LDS reads per FMA) -2.5 %; the same with 8-channel chunks -4 %; next chunk's halo prefetched into
 // registers during the FMAs (software pipeline, 128 VGPRs) +9 %.  PMC of the kernel as it is: waves spend 62 % of their cycles in
 // s_waitcnt, VALU issues 45 % of the time, scalar-cache miss rate 1.5 %, LDS busy 24 % (63 % of that bank conflicts).
-template <int CIN, int CT>
+template <int CIN, int CT, int COUT>
 __global__ __launch_bounds__(256) void conv3d_k3s1_tiled_kernel(ActSrc a, ActSrc b, int ld, int D, int H, int W,
-                                                               const float* __restrict__ wp, int Cout, float* __restrict__ out, int swz)
+                                                               const float* __restrict__ wp, float* __restrict__ out, int swz)
 {
     __shared__ __attribute__((aligned(16))) float tile[600 * 12];
     const int nbx = (W + 7) / 8, nby = (H + 7) / 8;
@@ -381,7 +410,7 @@ __global__ __launch_bounds__(256) void conv3d_k3s1_tiled_kernel(ActSrc a, ActSrc
     float acc[CT];
 #pragma unroll
     for (int k = 0; k < CT; ++k) acc[k] = 0.f;
-#define MVS_CHUNK(C0_, CKC_) conv_tile_chunk<CIN, CT, C0_, CKC_>(a, b, ld, D, H, W, x0, y0, z0, wp, Cout, cg, tile, tid, tx, ty, tz, acc)
+#define MVS_CHUNK(C0_, CKC_) conv_tile_chunk<CIN, CT, COUT, C0_, CKC_>(a, b, ld, D, H, W, x0, y0, z0, wp, cg, tile, tid, tx, ty, tz, acc)
     if constexpr (CIN >= 12) MVS_CHUNK(0, 12); else MVS_CHUNK(0, CIN);
     if constexpr (CIN >= 24) MVS_CHUNK(12, 12); else if constexpr (CIN > 12) MVS_CHUNK(12, CIN - 12);
     if constexpr (CIN >= 36) MVS_CHUNK(24, 12); else if constexpr (CIN > 24) MVS_CHUNK(24, CIN - 24);
@@ -391,7 +420,7 @@ __global__ __launch_bounds__(256) void conv3d_k3s1_tiled_kernel(ActSrc a, ActSrc
 #undef MVS_CHUNK
     const int ox = bx * 8 + tx, oy = by * 8 + ty, oz = bz * 4 + tz;
     if (ox < W && oy < H && oz < D) {
-        float* o = out + (((int64_t)oz * H + oy) * W + ox) * Cout + cg;
+        float* o = out + (((int64_t)oz * H + oy) * W + ox) * COUT + cg;
 #pragma unroll
         for (int k = 0; k < CT; k += 4) *reinterpret_cast<f32x4*>(o + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
     }
@@ -403,9 +432,9 @@ __global__ __launch_bounds__(256) void conv3d_k3s1_tiled_kernel(ActSrc a, ActSrc
 // (only its predicate is per lane), so weights stay on the scalar path; a wave spans one (z,y) row, i.e. it skips the
 // (kz,ky) combinations of the wrong parity as a whole.  Measured alternatives, both slower: one workgroup per output parity
 // class with strided stores (conv11 436 -> ~600 us), and one thread per x pair with three weight sets per channel chunk.
-template <int CIN, int CT>
+template <int CIN, int CT, int COUT>
 __global__ __launch_bounds__(256) void convT3d_k3s2_kernel(ActSrc a, ActSrc b, int Di, int Hi, int Wi,
-                                                          const float* __restrict__ wp, int Cout, float* __restrict__ out, int swz)
+                                                          const float* __restrict__ wp, float* __restrict__ out, int swz)
 {
     const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
     const int64_t nvox = (int64_t)Do * Ho * Wo;
@@ -424,17 +453,17 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_kernel(ActSrc a, ActSrc b, i
         const int zi = tz >> 1, yi = ty >> 1, xi = tx >> 1;
         if (zi >= Di || yi >= Hi || xi >= Wi) continue;
         const int64_t vox = ((int64_t)zi * Hi + yi) * Wi + xi;
-        const float* wt = wp + (int64_t)tap * CIN * Cout + cg;
+        const float* wt = wp + (int64_t)tap * CIN * COUT + cg;
         for (int c = 0; c < CIN; c += 4) {
             f32x4 v;
             load_act4<CIN>(a, b, vox, CIN, c, v);
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4)
 #pragma unroll
-                for (int k = 0; k < CT; ++k) acc[k] = fmaf(v[k4], wt[(int64_t)(c + k4) * Cout + k], acc[k]);
+                for (int k = 0; k < CT; ++k) acc[k] = fmaf(v[k4], wt[(c + k4) * COUT + k], acc[k]);
         }
     }
-    float* o = out + i * Cout + cg;
+    float* o = out + i * COUT + cg;
 #pragma unroll
     for (int k = 0; k < CT; k += 4) *reinterpret_cast<f32x4*>(o + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
 }
@@ -456,28 +485,28 @@ extern "C" int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const fl
     const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;   // k3 p1
     const int64_t nvox = (int64_t)Do * Ho * Wo;
     hipStream_t st = (hipStream_t)stream;
-#define MVS_CONV(CIN, CT, S)                                                                          \
-    conv3d_k3_kernel<CIN, CT, S><<<dim3(mvs_cdiv(nvox, 256), Cout / CT), 256, 0, st>>>(a, b, cin_ld, D, H, W, wpacked, Cout, out, Do, Ho, Wo, g_conv_xcd)
-#define MVS_CONV_TILED(CIN, CT)                                                                       \
-    conv3d_k3s1_tiled_kernel<CIN, CT><<<dim3(((W + 7) / 8) * ((H + 7) / 8) * ((D + 3) / 4), Cout / CT), 256, 0, st>>>(a, b, cin_ld, D, H, W, wpacked, Cout, out, g_conv_xcd)
+#define MVS_CONV(CIN, CT, S, COUT)                                                                    \
+    conv3d_k3_kernel<CIN, CT, S, COUT><<<dim3(mvs_cdiv(nvox, 256), COUT / CT), 256, 0, st>>>(a, b, cin_ld, D, H, W, wpacked, out, Do, Ho, Wo, g_conv_xcd)
+#define MVS_CONV_TILED(CIN, CT, COUT)                                                                 \
+    conv3d_k3s1_tiled_kernel<CIN, CT, COUT><<<dim3(((W + 7) / 8) * ((H + 7) / 8) * ((D + 3) / 4), COUT / CT), 256, 0, st>>>(a, b, cin_ld, D, H, W, wpacked, out, g_conv_xcd)
     // (Cin rounded up to a multiple of 4 by the caller's channel padding; Cout in {8,16,32,64})
     const int key = Cin * 1000 + Cout * 10 + stride;
     switch (key) {
-        case 44 * 1000 + 8 * 10 + 1:  if (g_conv_tiled) MVS_CONV_TILED(44, 8); else MVS_CONV(44, 8, 1); break;     // conv0 (41 real channels + 3 zero pad)
-        case 8 * 1000 + 44 * 10 + 1:  MVS_CONV_TILED(8, 44); break;  // data gradient of conv0
+        case 44 * 1000 + 8 * 10 + 1:  if (g_conv_tiled) MVS_CONV_TILED(44, 8, 8); else MVS_CONV(44, 8, 1, 8); break;     // conv0 (41 real channels + 3 zero pad)
+        case 8 * 1000 + 44 * 10 + 1:  MVS_CONV_TILED(8, 44, 44); break;  // data gradient of conv0
         // conv0 for other source-view counts: Cin = 32 + 3V rounded up to 4 (V=0: plain variance volume; V=1,2,5,6,7,8)
-        case 32 * 1000 + 8 * 10 + 1:  MVS_CONV_TILED(32, 8); break;   case 8 * 1000 + 32 * 10 + 1:  MVS_CONV_TILED(8, 32); break;
-        case 36 * 1000 + 8 * 10 + 1:  MVS_CONV_TILED(36, 8); break;   case 8 * 1000 + 36 * 10 + 1:  MVS_CONV_TILED(8, 36); break;
-        case 40 * 1000 + 8 * 10 + 1:  MVS_CONV_TILED(40, 8); break;   case 8 * 1000 + 40 * 10 + 1:  MVS_CONV_TILED(8, 40); break;
-        case 48 * 1000 + 8 * 10 + 1:  MVS_CONV_TILED(48, 8); break;   case 8 * 1000 + 48 * 10 + 1:  MVS_CONV_TILED(8, 48); break;
-        case 52 * 1000 + 8 * 10 + 1:  MVS_CONV_TILED(52, 8); break;   case 8 * 1000 + 52 * 10 + 1:  MVS_CONV_TILED(8, 52); break;
-        case 56 * 1000 + 8 * 10 + 1:  MVS_CONV_TILED(56, 8); break;   case 8 * 1000 + 56 * 10 + 1:  MVS_CONV_TILED(8, 56); break;
-        case 8 * 1000 + 16 * 10 + 2:  MVS_CONV(8, 16, 2); break;     // conv1
-        case 16 * 1000 + 16 * 10 + 1: if (g_conv_tiled) MVS_CONV_TILED(16, 16); else MVS_CONV(16, 16, 1); break;    // conv2
-        case 16 * 1000 + 32 * 10 + 2: MVS_CONV(16, 16, 2); break;    // conv3
-        case 32 * 1000 + 32 * 10 + 1: if (g_conv_tiled) MVS_CONV_TILED(32, 16); else MVS_CONV(32, 16, 1); break;    // conv4
-        case 32 * 1000 + 64 * 10 + 2: MVS_CONV(32, 16, 2); break;    // conv5
-        case 64 * 1000 + 64 * 10 + 1: if (g_conv_tiled) MVS_CONV_TILED(64, 16); else MVS_CONV(64, 16, 1); break;    // conv6
+        case 32 * 1000 + 8 * 10 + 1:  MVS_CONV_TILED(32, 8, 8); break;   case 8 * 1000 + 32 * 10 + 1:  MVS_CONV_TILED(8, 32, 32); break;
+        case 36 * 1000 + 8 * 10 + 1:  MVS_CONV_TILED(36, 8, 8); break;   case 8 * 1000 + 36 * 10 + 1:  MVS_CONV_TILED(8, 36, 36); break;
+        case 40 * 1000 + 8 * 10 + 1:  MVS_CONV_TILED(40, 8, 8); break;   case 8 * 1000 + 40 * 10 + 1:  MVS_CONV_TILED(8, 40, 40); break;
+        case 48 * 1000 + 8 * 10 + 1:  MVS_CONV_TILED(48, 8, 8); break;   case 8 * 1000 + 48 * 10 + 1:  MVS_CONV_TILED(8, 48, 48); break;
+        case 52 * 1000 + 8 * 10 + 1:  MVS_CONV_TILED(52, 8, 8); break;   case 8 * 1000 + 52 * 10 + 1:  MVS_CONV_TILED(8, 52, 52); break;
+        case 56 * 1000 + 8 * 10 + 1:  MVS_CONV_TILED(56, 8, 8); break;   case 8 * 1000 + 56 * 10 + 1:  MVS_CONV_TILED(8, 56, 56); break;
+        case 8 * 1000 + 16 * 10 + 2:  MVS_CONV(8, 16, 2, 16); break;     // conv1
+        case 16 * 1000 + 16 * 10 + 1: if (g_conv_tiled) MVS_CONV_TILED(16, 16, 16); else MVS_CONV(16, 16, 1, 16); break;    // conv2
+        case 16 * 1000 + 32 * 10 + 2: MVS_CONV(16, 16, 2, 32); break;    // conv3
+        case 32 * 1000 + 32 * 10 + 1: if (g_conv_tiled) MVS_CONV_TILED(32, 16, 32); else MVS_CONV(32, 16, 1, 32); break;    // conv4
+        case 32 * 1000 + 64 * 10 + 2: MVS_CONV(32, 16, 2, 64); break;    // conv5
+        case 64 * 1000 + 64 * 10 + 1: if (g_conv_tiled) MVS_CONV_TILED(64, 16, 64); else MVS_CONV(64, 16, 1, 64); break;    // conv6
         default: return MVSNERF_EUNSUPPORTED;
     }
 #undef MVS_CONV
@@ -495,11 +524,11 @@ extern "C" int mvsnerf_conv_transpose3d_fwd(const float* x1, const float* scale1
     const ActSrc a{x1, scale1, shift1}, b{x2, scale2, shift2};
     const int64_t nvox = (int64_t)8 * D * H * W;
     hipStream_t st = (hipStream_t)stream;
-#define MVS_CONVT(CIN, CT) convT3d_k3s2_kernel<CIN, CT><<<dim3(mvs_cdiv(nvox, 256), Cout / CT), 256, 0, st>>>(a, b, D, H, W, wpacked, Cout, out, g_conv_xcd)
+#define MVS_CONVT(CIN, CT, COUT) convT3d_k3s2_kernel<CIN, CT, COUT><<<dim3(mvs_cdiv(nvox, 256), COUT / CT), 256, 0, st>>>(a, b, D, H, W, wpacked, out, g_conv_xcd)
     switch (Cin * 100 + Cout) {
-        case 64 * 100 + 32: MVS_CONVT(64, 16); break;   // conv7
-        case 32 * 100 + 16: MVS_CONVT(32, 16); break;   // conv9
-        case 16 * 100 + 8:  MVS_CONVT(16, 8); break;    // conv11
+        case 64 * 100 + 32: MVS_CONVT(64, 16, 32); break;   // conv7
+        case 32 * 100 + 16: MVS_CONVT(32, 16, 16); break;   // conv9
+        case 16 * 100 + 8:  MVS_CONVT(16, 8, 8); break;    // conv11
         default: return MVSNERF_EUNSUPPORTED;
     }
 #undef MVS_CONVT

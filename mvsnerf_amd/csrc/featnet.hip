@@ -38,9 +38,9 @@ extern "C" int mvsnerf_conv2d_pack_weights(const float* w, int ci_real, int co_r
 
 // One thread = one output pixel x CT output channels; a workgroup owns a 16x16 pixel tile so that the K*K-fold input
 // reuse is served by L1 (a pixel's channels are one contiguous vector, 16 lanes of a row read one contiguous span).
-template <int CIN, int CT, int K, int S>
+template <int CIN, int CT, int K, int S, int COUT>     // COUT a template constant: weight offsets are s_load immediates (see encoder.hip)
 __global__ __launch_bounds__(256) void conv2d_kernel(ActSrc a, int ld, int Hi, int Wi, const float* __restrict__ wp,
-                                                     const float* __restrict__ bias, int Cout,
+                                                     const float* __restrict__ bias,
                                                      float* __restrict__ out, int Ho, int Wo)
 {
     constexpr int P = K / 2;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ActSrc a, int ld, int Hi, i
             const int xi = x * S - P + kx;
             const bool in = yin && xi >= 0 && xi < Wi;
             const int64_t pix = img0 + (in ? (int64_t)yi * Wi + xi : 0);
-            const float* wt = wp + (int64_t)(ky * K + kx) * CIN * Cout + cg;
+            const float* wt = wp + (int64_t)(ky * K + kx) * CIN * COUT + cg;
 #pragma unroll
             for (int c = 0; c < CIN; c += 4) {
                 f32x4 v;
@@ -73,12 +73,12 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ActSrc a, int ld, int Hi, i
 #pragma unroll
                 for (int k4 = 0; k4 < 4; ++k4)
 #pragma unroll
-                    for (int k = 0; k < CT; ++k) acc[k] = fmaf(v[k4], wt[(int64_t)(c + k4) * Cout + k], acc[k]);
+                    for (int k = 0; k < CT; ++k) acc[k] = fmaf(v[k4], wt[(c + k4) * COUT + k], acc[k]);
             }
         }
     }
     if (live) {
-        float* o = out + (((int64_t)n * Ho + y) * Wo + x) * Cout + cg;
+        float* o = out + (((int64_t)n * Ho + y) * Wo + x) * COUT + cg;
 #pragma unroll
         for (int k = 0; k < CT; k += 4) *reinterpret_cast<f32x4*>(o + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
     }
@@ -95,16 +95,16 @@ extern "C" int mvsnerf_conv2d_fwd(const float* x, const float* scale, const floa
     const ActSrc a{x, scale, shift};
     hipStream_t st = (hipStream_t)stream;
     const unsigned tiles = (unsigned)(((Wo + 15) / 16) * ((Ho + 15) / 16) * N);
-#define MVS_C2D(CIN, CT, K, S) conv2d_kernel<CIN, CT, K, S><<<dim3(tiles, Cout / CT), 256, 0, st>>>(a, cin_ld, H, W, wpacked, bias, Cout, out, Ho, Wo)
+#define MVS_C2D(CIN, CT, K, S, COUT) conv2d_kernel<CIN, CT, K, S, COUT><<<dim3(tiles, COUT / CT), 256, 0, st>>>(a, cin_ld, H, W, wpacked, bias, out, Ho, Wo)
     const int key = ((Cin * 100 + Cout) * 10 + ksize) * 10 + stride;
     switch (key) {
-        case ((4 * 100 + 8) * 10 + 3) * 10 + 1:   MVS_C2D(4, 8, 3, 1); break;      // conv0.0  (rgb + pad -> 8)
-        case ((8 * 100 + 8) * 10 + 3) * 10 + 1:   MVS_C2D(8, 8, 3, 1); break;      // conv0.1 and its data gradient
-        case ((8 * 100 + 16) * 10 + 5) * 10 + 2:  MVS_C2D(8, 16, 5, 2); break;     // conv1.0
-        case ((16 * 100 + 16) * 10 + 3) * 10 + 1: MVS_C2D(16, 16, 3, 1); break;    // conv1.1, conv1.2 (+ data gradients)
-        case ((16 * 100 + 32) * 10 + 5) * 10 + 2: MVS_C2D(16, 16, 5, 2); break;    // conv2.0
-        case ((32 * 100 + 32) * 10 + 3) * 10 + 1: MVS_C2D(32, 16, 3, 1); break;    // conv2.1, conv2.2 (+ data gradients)
-        case ((32 * 100 + 32) * 10 + 1) * 10 + 1: MVS_C2D(32, 16, 1, 1); break;    // toplayer (+ data gradient)
+        case ((4 * 100 + 8) * 10 + 3) * 10 + 1:   MVS_C2D(4, 8, 3, 1, 8); break;      // conv0.0  (rgb + pad -> 8)
+        case ((8 * 100 + 8) * 10 + 3) * 10 + 1:   MVS_C2D(8, 8, 3, 1, 8); break;      // conv0.1 and its data gradient
+        case ((8 * 100 + 16) * 10 + 5) * 10 + 2:  MVS_C2D(8, 16, 5, 2, 16); break;     // conv1.0
+        case ((16 * 100 + 16) * 10 + 3) * 10 + 1: MVS_C2D(16, 16, 3, 1, 16); break;    // conv1.1, conv1.2 (+ data gradients)
+        case ((16 * 100 + 32) * 10 + 5) * 10 + 2: MVS_C2D(16, 16, 5, 2, 32); break;    // conv2.0
+        case ((32 * 100 + 32) * 10 + 3) * 10 + 1: MVS_C2D(32, 16, 3, 1, 32); break;    // conv2.1, conv2.2 (+ data gradients)
+        case ((32 * 100 + 32) * 10 + 1) * 10 + 1: MVS_C2D(32, 16, 1, 1, 32); break;    // toplayer (+ data gradient)
         default: return MVSNERF_EUNSUPPORTED;
     }
 #undef MVS_C2D
