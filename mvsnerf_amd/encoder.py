@@ -404,6 +404,9 @@ class ConvBnReLU3D(nn.Module):
         return self._packed.cin_pad
 
 
+MATERIALIZE_UP_INPUT = True     # A/B switch (scratch/enc_time.py)
+
+
 class _UpBlock(nn.Sequential):
     """nn.Sequential(ConvTranspose3d, InPlaceABN) of models.py:739-752 (keys `convN.0.weight`, `convN.1.*`)."""
 
@@ -413,6 +416,9 @@ class _UpBlock(nn.Sequential):
 
     def lazy(self, src1, dims_in, src2=None):
         pk = self._packed
+        if MATERIALIZE_UP_INPUT and isinstance(src1, _Lazy):
+            # every input voxel feeds 27/8 output voxels on average: activate (and sum the skip) once instead of per tap
+            src1, src2 = _apply_add(src1, src2), None
         raw = _conv_t(src1, src2, dims_in, pk.get(), pk.cin_pad, pk.cout)
         D, H, W, C = raw.shape
         scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self[1], update_running=self[1].training)
