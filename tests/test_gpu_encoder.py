@@ -133,3 +133,23 @@ def test_abn_stats_and_conv_vs_torch_full_size():
         raw = E._conv(buf, None, (d, H, W, ld), ld, conv._packed.get(), conv._packed.cin_pad, conv._packed.cout, 1)
         ref = F.conv3d(xin, conv.conv.weight, None, padding=1)[0].permute(1, 2, 3, 0)
         assert maxabs(raw.cpu(), ref.cpu()) < 2e-4
+
+
+@pytest.mark.parametrize("dims", [(8, 24, 40), (16, 24, 32), (8, 8, 8)])
+def test_xcd_tile_numbering_does_not_change_results(dims, mvs):
+    """The convolution kernels renumber their tiles so that an XCD owns a contiguous range (common.h: xcd_contiguous_tile).
+    A pure permutation of the workgroups: outputs must be bit-identical with the numbering switched off, also when the tile
+    count is not a multiple of 8 (8x24x40 -> 30 tiles of the stride-1 layers)."""
+    from mvsnerf_amd import _lib
+    D, H, W = dims
+    x = torch.randn((1, 41, D, H, W), generator=torch.Generator().manual_seed(3)).to(DEV)
+    outs = []
+    for on in (1, 0):
+        assert _lib.lib().mvsnerf_tune(b"conv_xcd", on) == 0
+        try:
+            with torch.no_grad():
+                outs.append(mvs.cost_reg_2(x).clone())
+        finally:
+            _lib.lib().mvsnerf_tune(b"conv_xcd", 1)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.isfinite(outs[0]).all()
