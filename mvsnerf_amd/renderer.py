@@ -68,11 +68,17 @@ def gen_dir_feature(w2c_ref, rays_dir):
 def gen_pts_feats(imgs, volume_feature, rays_pts, pose_ref, rays_ndc, feat_dim, img_feat=None, img_downscale=1.0,
                   use_color_volume=False, net_type="v0"):
     """renderer.py:124-136: [8 volume channels | V x (r,g,b,mask)] written in place into one (N,S,feat_dim) tensor."""
-    if img_feat is not None or use_color_volume:
-        raise NotImplementedError("gen_pts_feats: img_feat / use_color_volume are outside the shipped hot path")
+    if img_feat is not None:
+        raise NotImplementedError("gen_pts_feats: img_feat is outside the shipped hot path (training_step passes None)")
     from .models import RefVolume
     vol = volume_feature.feat_volume if isinstance(volume_feature, RefVolume) else volume_feature
     vol_cl = ops.channels_last_volume(vol)
+    if use_color_volume:
+        # renderer.py:134-135 (--use_color_volume fine-tuning): the colours were projected into the volume once
+        # (train_mvs_nerf_finetuning_pl.py:72-82), so the per-sample feature is ONE lookup of the (8 + 4V)-channel volume
+        if vol_cl.shape[-1] != feat_dim:
+            raise RuntimeError(f"use_color_volume: the volume has {vol_cl.shape[-1]} channels, feat_dim is {feat_dim}")
+        return ops.volume_sample(vol_cl, rays_ndc.contiguous())
     N, S = rays_pts.shape[:2]
     V = imgs.shape[1]
     if feat_dim != 8 + 4 * V:

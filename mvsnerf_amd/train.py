@@ -300,6 +300,11 @@ class MVSSystemFinetune(_ModuleShim):
         what `dataset.read_source_views()` returns in the reference."""
         super().__init__()
         from .models import RefVolume
+        if getattr(args, "use_color_volume", False):
+            # :79-80 concatenates the projected colours to the learnable volume (20 channels).  renderer.gen_pts_feats renders such
+            # a volume; training it needs the C != 8 scatter (backward of the lookup), which this path does not have.
+            raise NotImplementedError("MVSSystemFinetune: --use_color_volume fine-tuning is not built (rendering a colour volume is: "
+                                      "renderer.gen_pts_feats(use_color_volume=True))")
         self.args = args
         self.args.feat_dim = 8 + 3 * 4
         kw_train, _, _, self.grad_vars = create_nerf_mvs(args, use_mvs=True, dir_embedder=False, pts_embedder=True)

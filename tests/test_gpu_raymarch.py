@@ -391,6 +391,33 @@ def test_raymarch_fused_and_unfused_gather_agree(net):
         assert torch.equal(outs[0][k], outs[1][k]), k
 
 
+def test_use_color_volume_rendering_vs_oracle(net):
+    """--use_color_volume (renderer.py:134-135): the per-sample feature is ONE lookup of an (8 + 4V)-channel volume (colours
+    projected into the volume once at fine-tuning start) instead of 8 channels + per-view colour lookups."""
+    from mvsnerf_amd import renderer as R, models as M
+    from oracle import mvsnerf_oracle as O
+    rig, pose, vol8, pts, dirs, ndc, z, ro = _config2_inputs(200, 48, D=16, h=24, w=32, H=96, W=128, seed=31)
+    g = torch.Generator().manual_seed(7)
+    vol = torch.cat((vol8, torch.rand((1, 12, *vol8.shape[2:]), generator=g)), 1)          # [features | projected colours + masks]
+    mlp_sd, _ = load_weights()
+    ang = O.gen_dir_feature(pose["w2cs"][0], dirs / dirs.norm(dim=-1, keepdim=True))
+    feat_ref = O.index_point_feature(vol, ndc)
+    raw_ref = O.run_network_mvs(ndc, ang, feat_ref, mlp_sd)
+    rgb_ref, _, _, w_ref, depth_ref, alpha_ref = O.raw2outputs(raw_ref, z)
+    emb, _ = M.get_embedder(10, 0, 3)
+    qfn = lambda p, vd, f, fn: R.run_network_mvs(p, vd, f, fn, emb, None)
+    pose_d = {k: v.to(DEV) for k, v in pose.items()}
+    with torch.no_grad():
+        rgb, feat, w, depth, alpha, _ = R.rendering(_args(use_color_volume=True), pose_d, pts.to(DEV), ndc.to(DEV), z.to(DEV), ro.to(DEV),
+                                                    dirs.to(DEV), vol.to(DEV), rig["images_raw"][:, :3].to(DEV), network_fn=net, network_query_fn=qfn)
+    assert feat.shape == (200, 48, 20)
+    assert maxabs(feat.cpu(), feat_ref) < 1e-5                  # trilinear summation order (generic-C kernel: one thread per channel)
+    for a, b, name in ((rgb, rgb_ref, "rgb"), (w, w_ref, "weights"), (depth, depth_ref, "depth"), (alpha, alpha_ref, "alpha")):
+        assert torch.allclose(a.cpu(), b, atol=1e-4, rtol=1e-4), name
+    with pytest.raises(RuntimeError):                       # channel count must match feat_dim
+        R.gen_pts_feats(rig["images_raw"][:, :3].to(DEV), vol8.to(DEV), pts.to(DEV), pose_d, ndc.to(DEV), 20, use_color_volume=True)
+
+
 @pytest.mark.parametrize("n_rays,n_samples", [(256, 128), (37, 5), (1, 1), (130, 33)])
 def test_split_bf16x6_mode_meets_the_fp32_tolerance(net, n_rays, n_samples):
     """Opt-in bf16x6 MLP (fp32 operands as three bf16 pieces, six bf16 MFMAs per product, fp32 accumulation): same 1e-4 bound
