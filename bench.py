@@ -309,15 +309,29 @@ def main():
             cvol = ops.ndhwc_to_ncdhw(ops.channels_last_volume(vol))[None].cpu()
             cb = [tuple(t.cpu() for t in b) for b in batches[:4]]
             csrc = src.cpu()
+            n_default = torch.get_num_threads()
             with torch.no_grad():
-                O.rendering(cpose, cb[0][0], cb[0][1], cb[0][2], cb[0][4], cvol, csrc, sd)    # warm
+                # the thread count this path runs fastest at on this host (all hardware threads is rarely it: the batch is
+                # 45 MB of activations per layer and the ATen kernels stop scaling long before 128 threads)
+                probe = {}
+                for nt in sorted({t for t in (8, 16, 32, 64, n_default) if t <= n_default}):
+                    torch.set_num_threads(nt)
+                    O.rendering(cpose, cb[0][0], cb[0][1], cb[0][2], cb[0][4], cvol, csrc, sd)    # warm
+                    p0 = time.perf_counter()
+                    O.rendering(cpose, cb[1][0], cb[1][1], cb[1][2], cb[1][4], cvol, csrc, sd)
+                    probe[nt] = time.perf_counter() - p0
+                best = min(probe, key=probe.get)
+                torch.set_num_threads(best)
+                O.rendering(cpose, cb[0][0], cb[0][1], cb[0][2], cb[0][4], cvol, csrc, sd)        # warm
                 c0 = time.perf_counter()
                 for i in range(a.cpu_batches):
                     b = cb[i % len(cb)]
                     out = O.rendering(cpose, b[0], b[1], b[2], b[4], cvol, csrc, sd)
                 cdt = time.perf_counter() - c0
-            cpu = {"value": round(a.cpu_batches * N_RAYS / cdt, 1), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-                   "sample": f"{a.cpu_batches} batches of {N_RAYS}x{N_SAMPLES} (oracle.rendering, torch CPU fp32, no_grad), {cdt:.1f} s"}
+                torch.set_num_threads(n_default)
+            cpu = {"value": round(a.cpu_batches * N_RAYS / cdt, 1), "unit": "rays/s", "cores": best, "kind": "port",
+                   "sample": f"{a.cpu_batches} batches of {N_RAYS}x{N_SAMPLES} (oracle.rendering, torch CPU fp32, no_grad), {cdt:.1f} s, at the fastest of "
+                             f"{sorted(probe)} threads (one probe batch each: " + ", ".join(f"{t}: {N_RAYS / probe[t]:.0f} rays/s" for t in sorted(probe)) + ")"}
             # parity of the timed workload itself (same batch, GPU vs CPU oracle)
             with torch.no_grad():
                 g = step(0)
