@@ -5,6 +5,25 @@
 // and the two x-neighbours of a corner pair are one 64-byte contiguous read.
 #include "common.h"
 
+// A 16-byte block of zeros: out-of-volume taps read it instead of branching around the load (zeros padding, exactly).
+__device__ const f32x4 g_zero_tap = {0.0f, 0.0f, 0.0f, 0.0f};
+
+// float offset of voxel (z,y,x)'s 8-channel vector.  SMALL: 32-bit arithmetic on full-rate 24-bit multiplies (the launcher
+// checks D*H < 2^24, W < 2^24, D*H*W*8 < 2^31); v_mul_lo_u32 / v_mad_u64_u32 are quarter-rate and were 40 % of the lookup's
+// instruction slots.
+template <bool SMALL>
+__device__ __forceinline__ int64_t vox_off8(int z, int y, int x, int H, int W)
+{
+    if constexpr (SMALL) return (int64_t)((__umul24(__umul24(z, H) + y, W) + x) << 3);
+    else return (((int64_t)z * H + y) * W + x) << 3;
+}
+
+// swap with the lane two places away inside the quad (lanes 0<->2, 1<->3): what __shfl_xor(v, 2) returns, as one DPP move
+__device__ __forceinline__ float quad_swap2(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4e, 0xf, 0xf, false));   // quad_perm:[2,3,0,1]
+}
+
 // ---------------------------------------------------------------------------------------------
 // Trilinear lookup (reference: F.grid_sample 5-D, zeros padding, align_corners=True;
 // utils.py:381-382).  4 lanes cooperate on one sample.  Lane q owns float4 number q of the 64-byte
@@ -14,7 +33,7 @@
 // Measured alternatives (rocprofv3, 1024x128 samples, 128x176x208 volume): this mapping 8.1 us; 2 lanes per
 // sample 11.9 us; 2 or 4 consecutive samples per quad 11.6 / 9.0 us; 1024-thread blocks 8.4 us.
 // ---------------------------------------------------------------------------------------------
-template <int SPQ>   // samples per lane quad (consecutive samples: shared z-rows hit in L1, 4*SPQ loads in flight per lane)
+template <int SPQ, bool SMALL>   // samples per lane quad; SMALL: 32-bit voxel offsets (vox_off8)
 __global__ __launch_bounds__(256) void volume_sample_c8_kernel(
     const float* __restrict__ vol, int D, int H, int W,
     const float* __restrict__ ndc, int64_t P, float* __restrict__ out, int out_stride)
@@ -48,15 +67,15 @@ __global__ __launch_bounds__(256) void volume_sample_c8_kernel(
             const float cyf = fy + (float)yc, czf = fz + (float)zc;
             const bool in = x_in && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
             const float w = wx * (yc ? (iy - fy) : ((fy + 1.0f) - iy)) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
-            f32x4 v = {0, 0, 0, 0};
-            if (in) v = *reinterpret_cast<const f32x4*>(vol + (((((int64_t)czf * H + (int)cyf) * W + (int)cxf) << 3) + ch));
+            const float* src = in ? vol + vox_off8<SMALL>((int)czf, (int)cyf, (int)cxf, H, W) + ch : reinterpret_cast<const float*>(&g_zero_tap);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src);
             acc[j] += v * w;
         }
     }
 #pragma unroll
     for (int j = 0; j < SPQ; ++j) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[j][c] += __shfl_xor(acc[j][c], 2);      // fold the two x corners
+        for (int c = 0; c < 4; ++c) acc[j][c] += quad_swap2(acc[j][c]);         // fold the two x corners
         if (p0 + j < P && xc == 0)                                                // lanes q=0,1 store channels 0-3 / 4-7
             *reinterpret_cast<f32x4*>(out + (p0 + j) * out_stride + ch) = acc[j];
     }
@@ -96,7 +115,9 @@ extern "C" int mvsnerf_volume_sample_fwd(const float* vol, int D, int H, int W, 
     if (C == 8) {
         if (!mvs_aligned16(vol)) return MVSNERF_EALIGN;
         if ((out_stride & 3) || !mvs_aligned16(out)) return MVSNERF_EALIGN;
-        volume_sample_c8_kernel<1><<<mvs_cdiv(P * 4, 256), 256, 0, st>>>(vol, D, H, W, ndc, P, out, out_stride);
+        const bool small = (int64_t)D * H < (1 << 24) && W < (1 << 24) && (int64_t)D * H * W * 8 < ((int64_t)1 << 31);
+        if (small) volume_sample_c8_kernel<1, true><<<mvs_cdiv(P * 4, 256), 256, 0, st>>>(vol, D, H, W, ndc, P, out, out_stride);
+        else volume_sample_c8_kernel<1, false><<<mvs_cdiv(P * 4, 256), 256, 0, st>>>(vol, D, H, W, ndc, P, out, out_stride);
     } else {
         volume_sample_generic_kernel<<<mvs_cdiv(P * C, 256), 256, 0, st>>>(vol, D, H, W, C, ndc, P, out, out_stride);
     }
@@ -243,6 +264,7 @@ struct GatherArgs {
     float* feat; int feat_stride; float* dirs_out;
 };
 
+template <bool SMALL>
 __global__ __launch_bounds__(256) void gather_fused_kernel(GatherArgs a)
 {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -271,8 +293,8 @@ __global__ __launch_bounds__(256) void gather_fused_kernel(GatherArgs a)
         const float cyf = fy + (float)yc, czf = fz + (float)zc;
         const bool in = x_in && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
         vw[k] = wx * (yc ? (iy - fy) : ((fy + 1.0f) - iy)) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
-        vv[k] = f32x4{0, 0, 0, 0};
-        if (in) vv[k] = *reinterpret_cast<const f32x4*>(a.vol + (((((int64_t)czf * H + (int)cyf) * W + (int)cxf) << 3) + ch));
+        const float* src = in ? a.vol + vox_off8<SMALL>((int)czf, (int)cyf, (int)cxf, H, W) + ch : reinterpret_cast<const float*>(&g_zero_tap);
+        vv[k] = *reinterpret_cast<const f32x4*>(src);
     }
     // ---- colour lookup of view q (+4): issue its taps before the volume taps are consumed
     const float px = a.pts[p * 3 + 0], py = a.pts[p * 3 + 1], pz = a.pts[p * 3 + 2];
@@ -280,12 +302,12 @@ __global__ __launch_bounds__(256) void gather_fused_kernel(GatherArgs a)
     for (int v = q; v < a.V; v += 4) {
         const int IW = a.IW, IH = a.IH;
         const ColorTap t = color_project(px, py, pz, a.w2c + v * 16, a.Kmat + v * 9, IW, IH);
-        const float* pl = a.img + (((int64_t)v * IH + t.y0) * IW + t.x0) * 4;
-        const f32x4 z4 = {0, 0, 0, 0};
+        const float* pl = a.img + (SMALL ? (int64_t)((__umul24(v * IH + t.y0, IW) + t.x0) << 2) : (((int64_t)v * IH + t.y0) * IW + t.x0) * 4);
+        const float* zt = reinterpret_cast<const float*>(&g_zero_tap);
         const f32x4 t_nw = *reinterpret_cast<const f32x4*>(pl);
-        const f32x4 t_ne = t.x1in ? *reinterpret_cast<const f32x4*>(pl + 4) : z4;
-        const f32x4 t_sw = t.y1in ? *reinterpret_cast<const f32x4*>(pl + (int64_t)IW * 4) : z4;
-        const f32x4 t_se = (t.x1in && t.y1in) ? *reinterpret_cast<const f32x4*>(pl + (int64_t)IW * 4 + 4) : z4;
+        const f32x4 t_ne = *reinterpret_cast<const f32x4*>(t.x1in ? pl + 4 : zt);
+        const f32x4 t_sw = *reinterpret_cast<const f32x4*>(t.y1in ? pl + (int64_t)IW * 4 : zt);
+        const f32x4 t_se = *reinterpret_cast<const f32x4*>((t.x1in && t.y1in) ? pl + (int64_t)IW * 4 + 4 : zt);
         f32x4 o;
 #pragma unroll
         for (int c = 0; c < 3; ++c) o[c] = color_blend(t, t_nw[c], t_ne[c], t_sw[c], t_se[c]);
@@ -297,7 +319,7 @@ __global__ __launch_bounds__(256) void gather_fused_kernel(GatherArgs a)
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc += vv[k] * vw[k];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], 2);
+    for (int c = 0; c < 4; ++c) acc[c] += quad_swap2(acc[c]);
     if (live && xc == 0) *reinterpret_cast<f32x4*>(frow + ch) = acc;
     // ---- view-direction feature of the ray (written once, by lane 3 of the ray's first sample)
     if (live && q == 3 && a.dirs_out && (p % a.S) == 0) {
@@ -318,7 +340,10 @@ extern "C" int mvsnerf_gather_fwd(const float* vol, int D, int H, int W, const f
     if (N == 0) return MVSNERF_OK;
     const int64_t P = N * S;
     const GatherArgs a{vol, D, H, W, imgs_nhwc4, V, IH, IW, w2c, K, pts, ndc, P, S, rays_dir, feat, feat_stride, dirs_out};
-    gather_fused_kernel<<<mvs_cdiv(P * 4, 256), 256, 0, (hipStream_t)stream>>>(a);
+    const bool small = (int64_t)D * H < (1 << 24) && W < (1 << 24) && (int64_t)D * H * W * 8 < ((int64_t)1 << 31) &&
+                       (int64_t)V * IH < (1 << 24) && IW < (1 << 24) && (int64_t)V * IH * IW * 4 < ((int64_t)1 << 31);
+    if (small) gather_fused_kernel<true><<<mvs_cdiv(P * 4, 256), 256, 0, (hipStream_t)stream>>>(a);
+    else gather_fused_kernel<false><<<mvs_cdiv(P * 4, 256), 256, 0, (hipStream_t)stream>>>(a);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
