@@ -4,6 +4,7 @@
 // Layout: volume is channel-last vol[d][y][x][8] so that one trilinear corner = one 32-byte sector
 // and the two x-neighbours of a corner pair are one 64-byte contiguous read.
 #include "common.h"
+#include <type_traits>
 
 // A 16-byte block of zeros: out-of-volume taps read it instead of branching around the load (zeros padding, exactly).
 __device__ const f32x4 g_zero_tap = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -259,7 +260,7 @@ struct GatherArgs {
     const float* vol; int D, H, W;
     const float* img; int V, IH, IW;            // [V][IH][IW][4]
     const float* w2c; const float* Kmat;        // [V][4][4], [V][3][3]
-    const float* pts; const float* ndc; int64_t P; int S;
+    const float* pts; const float* ndc; int64_t P; int64_t N;
     const float* rays_dir;                      // [P/S][3]
     float* feat; int feat_stride; float* dirs_out;
 };
@@ -271,7 +272,8 @@ __global__ __launch_bounds__(256) void gather_fused_kernel(GatherArgs a)
     const int q = (int)(tid & 3);
     const int64_t p_raw = tid >> 2;
     const bool live = p_raw < a.P;
-    const int64_t p = live ? p_raw : a.P - 1;
+    using idx_t = typename std::conditional<SMALL, unsigned, int64_t>::type;      // SMALL: sample offsets fit 32 bits (checked by the launcher)
+    const idx_t p = (idx_t)(live ? p_raw : a.P - 1);
     const int D = a.D, H = a.H, W = a.W;
     // ---- trilinear volume lookup (identical to volume_sample_c8_kernel<1>)
     const int xc = q >> 1, ch = (q & 1) * 4;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void gather_fused_kernel(GatherArgs a)
     }
     // ---- colour lookup of view q (+4): issue its taps before the volume taps are consumed
     const float px = a.pts[p * 3 + 0], py = a.pts[p * 3 + 1], pz = a.pts[p * 3 + 2];
-    float* frow = a.feat + p * a.feat_stride;
+    float* frow = a.feat + p * (idx_t)a.feat_stride;
     for (int v = q; v < a.V; v += 4) {
         const int IW = a.IW, IH = a.IH;
         const ColorTap t = color_project(px, py, pz, a.w2c + v * 16, a.Kmat + v * 9, IW, IH);
@@ -321,11 +323,9 @@ __global__ __launch_bounds__(256) void gather_fused_kernel(GatherArgs a)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] += quad_swap2(acc[c]);
     if (live && xc == 0) *reinterpret_cast<f32x4*>(frow + ch) = acc;
-    // ---- view-direction feature of the ray (written once, by lane 3 of the ray's first sample)
-    if (live && q == 3 && a.dirs_out && (p % a.S) == 0) {
-        const int64_t n = p / a.S;
-        dir_feature_of(a.rays_dir + n * 3, a.w2c, 1, a.dirs_out + n * 3);      // reference view = view 0
-    }
+    // ---- view-direction feature: lane 3 of quad number n < N handles ray n (no p / S: a 64-bit division costs every lane of
+    // the wave dozens of instruction slots)
+    if (q == 3 && a.dirs_out && p_raw < a.N) dir_feature_of(a.rays_dir + p_raw * 3, a.w2c, 1, a.dirs_out + p_raw * 3);   // reference view = view 0
 }
 
 extern "C" int mvsnerf_gather_fwd(const float* vol, int D, int H, int W, const float* imgs_nhwc4, int V, int IH, int IW,
@@ -339,9 +339,10 @@ extern "C" int mvsnerf_gather_fwd(const float* vol, int D, int H, int W, const f
     if ((feat_stride & 3) || !mvs_aligned16(feat) || !mvs_aligned16(vol) || !mvs_aligned16(imgs_nhwc4)) return MVSNERF_EALIGN;
     if (N == 0) return MVSNERF_OK;
     const int64_t P = N * S;
-    const GatherArgs a{vol, D, H, W, imgs_nhwc4, V, IH, IW, w2c, K, pts, ndc, P, S, rays_dir, feat, feat_stride, dirs_out};
+    const GatherArgs a{vol, D, H, W, imgs_nhwc4, V, IH, IW, w2c, K, pts, ndc, P, N, rays_dir, feat, feat_stride, dirs_out};
     const bool small = (int64_t)D * H < (1 << 24) && W < (1 << 24) && (int64_t)D * H * W * 8 < ((int64_t)1 << 31) &&
-                       (int64_t)V * IH < (1 << 24) && IW < (1 << 24) && (int64_t)V * IH * IW * 4 < ((int64_t)1 << 31);
+                       (int64_t)V * IH < (1 << 24) && IW < (1 << 24) && (int64_t)V * IH * IW * 4 < ((int64_t)1 << 31) &&
+                       P * (int64_t)(feat_stride > 3 ? feat_stride : 3) < ((int64_t)1 << 31);
     if (small) gather_fused_kernel<true><<<mvs_cdiv(P * 4, 256), 256, 0, (hipStream_t)stream>>>(a);
     else gather_fused_kernel<false><<<mvs_cdiv(P * 4, 256), 256, 0, (hipStream_t)stream>>>(a);
     MVS_LAUNCH_CHECK();
