@@ -446,6 +446,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
     constexpr int HALF = (int)(ACT_STEPS / 2) * 4 * 64;                   // floats of half a 128x128 layer
 
     slab_dma(buf0, packed + L.biasw, (int)seg_floats(L.fsteps, 4), wave, lane);          // slab 0
+    slab_dma_c<(int)seg_floats(PE_STEPS, 4)>(buf1, packed + L.l0, wave, lane);              // slab 1 (buf1 is free at tile start)
     for (int i = tid; i < V_TOTAL; i += 256) vec[i] = packed[L.vec + i];
     const float px = ndc[p * ndc_stride + 0], py = ndc[p * ndc_stride + 1], pz = ndc[p * ndc_stride + 2];
     float fv[MAX_F / 2];
@@ -462,7 +463,6 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
     // ---- slab 0: bias = pts_bias(feat)
     slab_sync();
     stamp();                                                                                // [4] startup done
-    slab_dma_c<(int)seg_floats(PE_STEPS, 4)>(buf1, packed + L.l0, wave, lane);              // slab 1
     {
         f32x16 acc[G][4];
         init_acc<4, G>(acc, vec + V_BIASG + half * 64);
