@@ -65,7 +65,10 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ActSrc a, int ld, int Hi, i
             const bool in = yin && xi >= 0 && xi < Wi;
             const int64_t pix = img0 + (in ? (int64_t)yi * Wi + xi : 0);
             const float* wt = wp + (int64_t)(ky * K + kx) * CIN * COUT + cg;
-#pragma unroll
+            // a REAL loop over the channel quads (not unrolled): unrolled, the scheduler requests every weight of the kernel row
+            // (K*CIN*CT floats) at the top of the block, which does not fit the SGPR file - the weights were parked in VGPR lanes
+            // and came back through two v_readlane per packed FMA (1 456 v_readlane around 816 v_pk_fma_f32 in the 32->32 layer)
+#pragma unroll 1
             for (int c = 0; c < CIN; c += 4) {
                 f32x4 v;
                 load_act4<CIN>(a, none, pix, ld, c, v);
