@@ -456,6 +456,7 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_kernel(ActSrc a, ActSrc b, i
         if (zi >= Di || yi >= Hi || xi >= Wi) continue;
         const int64_t vox = ((int64_t)zi * Hi + yi) * Wi + xi;
         const float* wt = wp + (int64_t)tap * CIN * COUT + cg;
+#pragma unroll 1                                            // unrolled, a tap's CIN*CT weights overflow the SGPR file into VGPR lanes
         for (int c = 0; c < CIN; c += 4) {
             f32x4 v;
             load_act4<CIN>(a, b, vox, CIN, c, v);
