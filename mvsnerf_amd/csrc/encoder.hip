@@ -357,7 +357,8 @@ __device__ __forceinline__ void conv_tile_chunk(const ActSrc& a, const ActSrc& b
             // instructions a SIMD can issue, scalar ones included (PMC: 0.6 scalar instructions per packed FMA cost 27 % of
             // the issue cycles; with Cout a template constant the weight offsets are s_load immediates: conv0 2.0 -> 1.5 ms).
             // Tried and dropped: groups of 16 with the requests for the next pair issued after the first FMAs of a pair (so that
-            // the compiler's lgkmcnt(0) only covers loads that are ~50 cycles old): CostRegNet 3.03 -> 3.39 ms.
+            // the compiler's lgkmcnt(0) only covers loads that are ~50 cycles old): CostRegNet 3.03 -> 3.39 ms; 8 instead of 12
+            // channels staged per pass (8 instead of 5 workgroups per CU): -1 %, 4 channels: +6 %.
             constexpr int KPG = CT <= 8 ? 4 : 2;                 // k4 values per weight group
             constexpr int GPC = 4 / KPG, NG = 3 * K4 * GPC;       // groups per float4 of x, groups per row
             float w[2][KPG * CT];
