@@ -875,6 +875,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_rows_kernel(ActSrc g1, ActSr
 #define MVS_LG(ox) wg_load_g(g1, g2, pg1, pg2, (ox), Wo, A, a0, live)
         f32x4 w0 = MVS_LX(-1), w1 = MVS_LX(0), w2 = MVS_LX(1);
         G8 gc = MVS_LG(0);
+#pragma unroll 3                                            // three steps per trip: the sliding window (w0 <- w1 <- w2) renames instead of moving 20 registers per step
         for (int ox = 0; ox < Wo; ++ox) {
             // next step's operands are requested before this step's 96 FMAs
             const G8 gn = MVS_LG(ox + 1);
