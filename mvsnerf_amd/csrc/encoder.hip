@@ -958,54 +958,80 @@ __global__ __launch_bounds__(256) void planesweep_bwd_kernel(const float* __rest
                                                             int V, int H, int W, int D, int pad, const float* __restrict__ g_cost, int CP, int c_var,
                                                             float* __restrict__ g_feat)
 {
-    // one thread per (voxel, channel): the C = 32 lanes of a voxel read / atomically update one contiguous 128-byte
-    // channel vector per bilinear tap (a per-voxel thread with a channel loop issues 4-byte atomics 128 B apart: 10x slower)
+    // Two phases per workgroup of 256 voxels.  (1) one thread per voxel: projection into every source view (7 divisions per view),
+    // bilinear weights and tap indices -> LDS.  (2) one thread per (voxel, channel), 8 voxels per pass: the 32 lanes of a voxel read /
+    // atomically update one contiguous 128-byte channel vector per tap (a per-voxel thread with a channel loop issues 4-byte atomics
+    // 128 B apart: 10x slower; eight lanes x four channels per voxel: 4x the L2 atomic line visits, slower as well).  Phase 1 used to
+    // be repeated by all 32 lanes of every voxel, and the kernel was bound by that arithmetic (2.3 ms).
+    constexpr int VPB = 256;
+    extern __shared__ __attribute__((aligned(16))) float geo[];    // [VPB][GS]: per source view {w_nw,w_ne,w_sw,w_se, t_nw,t_ne,t_sw,t_se}, then {1/count, ref pixel}
+    const int GS = (V - 1) * 8 + 2;
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const int64_t nvox = (int64_t)D * Hp * Wp;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t i = t / C;
-    const int c = (int)(t - i * C);
-    if (i >= nvox) return;
-    const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), d = (int)(i / ((int64_t)Wp * Hp));
-    const float u = (float)(x - pad), v = (float)(y - pad), dep = depth[d];
-    const bool interior = x >= pad && x < W + pad && y >= pad && y < H + pad;
-    const float gv = g_cost[i * CP + c_var + c];
-    const float ref = interior ? feat[((int64_t)(y - pad) * W + (x - pad)) * C + c] : 0.f;
-    float s = ref, cnt = 1.0f;
-    constexpr int MAXV = 8;
-    float tw[MAXV][4], wv[MAXV];
-    int ta[MAXV][4];
-    for (int vv = 1; vv < V; ++vv) {
-        const float* P = proj + vv * 12;
-        const float p0 = fmaf(P[2], 1.0f, fmaf(P[1], v, P[0] * u)) + P[3] / dep;
-        const float p1 = fmaf(P[6], 1.0f, fmaf(P[5], v, P[4] * u)) + P[7] / dep;
-        const float p2 = fmaf(P[10], 1.0f, fmaf(P[9], v, P[8] * u)) + P[11] / dep;
-        const float gx = (p0 / p2) / ((float)(W - 1) / 2.0f) - 1.0f, gy = (p1 / p2) / ((float)(H - 1) / 2.0f) - 1.0f;
-        cnt += (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;
-        const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1), iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
-        const float fx = floorf(ix), fy = floorf(iy);
-        const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
-        const bool x0in = fx >= 0.f && fx <= (float)(W - 1), x1in = fx + 1.f >= 0.f && fx + 1.f <= (float)(W - 1);
-        const bool y0in = fy >= 0.f && fy <= (float)(H - 1), y1in = fy + 1.f >= 0.f && fy + 1.f <= (float)(H - 1);
-        tw[vv][0] = (x0in && y0in) ? wx0 * wy0 : 0.f; tw[vv][1] = (x1in && y0in) ? wx1 * wy0 : 0.f;
-        tw[vv][2] = (x0in && y1in) ? wx0 * wy1 : 0.f; tw[vv][3] = (x1in && y1in) ? wx1 * wy1 : 0.f;
-        const bool any = (x0in || x1in) && (y0in || y1in);
-        const int xa = any ? min(max((int)fx, 0), W - 1) : 0, xb = any ? min(max((int)fx + 1, 0), W - 1) : 0;
-        const int ya = any ? min(max((int)fy, 0), H - 1) : 0, yb = any ? min(max((int)fy + 1, 0), H - 1) : 0;
-        ta[vv][0] = ya * W + xa; ta[vv][1] = ya * W + xb; ta[vv][2] = yb * W + xa; ta[vv][3] = yb * W + xb;
-        const float* fb = feat + (int64_t)vv * H * W * C + c;
-        wv[vv] = ((fb[(int64_t)ta[vv][0] * C] * tw[vv][0] + fb[(int64_t)ta[vv][1] * C] * tw[vv][1]) + fb[(int64_t)ta[vv][2] * C] * tw[vv][2]) + fb[(int64_t)ta[vv][3] * C] * tw[vv][3];
-        s += wv[vv];
+    const int64_t v0 = (int64_t)blockIdx.x * VPB;
+    {
+        const int64_t i = v0 + threadIdx.x;
+        if (i < nvox) {
+            float* o = geo + threadIdx.x * GS;
+            const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), d = (int)(i / ((int64_t)Wp * Hp));
+            const float u = (float)(x - pad), v = (float)(y - pad), dep = depth[d];
+            const bool interior = x >= pad && x < W + pad && y >= pad && y < H + pad;
+            float cnt = 1.0f;
+            for (int vv = 1; vv < V; ++vv) {
+                const float* P = proj + vv * 12;
+                const float p0 = fmaf(P[2], 1.0f, fmaf(P[1], v, P[0] * u)) + P[3] / dep;
+                const float p1 = fmaf(P[6], 1.0f, fmaf(P[5], v, P[4] * u)) + P[7] / dep;
+                const float p2 = fmaf(P[10], 1.0f, fmaf(P[9], v, P[8] * u)) + P[11] / dep;
+                const float gx = (p0 / p2) / ((float)(W - 1) / 2.0f) - 1.0f, gy = (p1 / p2) / ((float)(H - 1) / 2.0f) - 1.0f;
+                cnt += (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;
+                const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1), iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+                const float fx = floorf(ix), fy = floorf(iy);
+                const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
+                const bool x0in = fx >= 0.f && fx <= (float)(W - 1), x1in = fx + 1.f >= 0.f && fx + 1.f <= (float)(W - 1);
+                const bool y0in = fy >= 0.f && fy <= (float)(H - 1), y1in = fy + 1.f >= 0.f && fy + 1.f <= (float)(H - 1);
+                float* ov = o + (vv - 1) * 8;
+                ov[0] = (x0in && y0in) ? wx0 * wy0 : 0.f; ov[1] = (x1in && y0in) ? wx1 * wy0 : 0.f;
+                ov[2] = (x0in && y1in) ? wx0 * wy1 : 0.f; ov[3] = (x1in && y1in) ? wx1 * wy1 : 0.f;
+                const bool any = (x0in || x1in) && (y0in || y1in);
+                const int xa = any ? min(max((int)fx, 0), W - 1) : 0, xb = any ? min(max((int)fx + 1, 0), W - 1) : 0;
+                const int ya = any ? min(max((int)fy, 0), H - 1) : 0, yb = any ? min(max((int)fy + 1, 0), H - 1) : 0;
+                ov[4] = __int_as_float(ya * W + xa); ov[5] = __int_as_float(ya * W + xb);
+                ov[6] = __int_as_float(yb * W + xa); ov[7] = __int_as_float(yb * W + xb);
+            }
+            o[(V - 1) * 8] = 1.0f / cnt;
+            o[(V - 1) * 8 + 1] = __int_as_float(interior ? (y - pad) * W + (x - pad) : -1);
+        }
     }
-    const float inv = 1.0f / cnt;
-    const float k2 = gv * 2.0f * inv, mean = s * inv;
-    if (interior) atomicAdd(g_feat + ((int64_t)(y - pad) * W + (x - pad)) * C + c, k2 * (ref - mean));
-    for (int vv = 1; vv < V; ++vv) {
-        float* gb = g_feat + (int64_t)vv * H * W * C + c;
-        const float gw_ = k2 * (wv[vv] - mean);
+    __syncthreads();
+    const int c = threadIdx.x & (C - 1);
+    constexpr int MAXV = 8;
+    for (int vl = threadIdx.x / C; vl < VPB; vl += 256 / C) {
+        const int64_t i = v0 + vl;
+        if (i >= nvox) break;
+        const float* o = geo + vl * GS;
+        const float inv = o[(V - 1) * 8];
+        const int refpix = __float_as_int(o[(V - 1) * 8 + 1]);
+        const float gv = g_cost[i * CP + c_var + c];
+        const float ref = refpix >= 0 ? feat[(int64_t)refpix * C + c] : 0.f;
+        float s = ref;
+        float wv[MAXV];
+        for (int vv = 1; vv < V; ++vv) {
+            const float* ov = o + (vv - 1) * 8;
+            const float* fb = feat + (int64_t)vv * H * W * C + c;
+            wv[vv] = ((fb[(int64_t)__float_as_int(ov[4]) * C] * ov[0] + fb[(int64_t)__float_as_int(ov[5]) * C] * ov[1]) +
+                      fb[(int64_t)__float_as_int(ov[6]) * C] * ov[2]) + fb[(int64_t)__float_as_int(ov[7]) * C] * ov[3];
+            s += wv[vv];
+        }
+        const float k2 = gv * 2.0f * inv, mean = s * inv;
+        if (refpix >= 0) atomicAdd(g_feat + (int64_t)refpix * C + c, k2 * (ref - mean));
+        for (int vv = 1; vv < V; ++vv) {
+            const float* ov = o + (vv - 1) * 8;
+            float* gb = g_feat + (int64_t)vv * H * W * C + c;
+            const float gw_ = k2 * (wv[vv] - mean);
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (tw[vv][k] != 0.f) atomicAdd(gb + (int64_t)ta[vv][k] * C, gw_ * tw[vv][k]);
+            for (int k = 0; k < 4; ++k)
+                if (ov[k] != 0.f) atomicAdd(gb + (int64_t)__float_as_int(ov[4 + k]) * C, gw_ * ov[k]);
+        }
     }
 }
 
@@ -1015,8 +1041,9 @@ extern "C" int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float
     if (!feats_cl || !proj || !depth || !g_cost || !g_feats_cl || V < 1 || V > 8 || H < 2 || W < 2 || D < 1 || pad < 0) return MVSNERF_EINVAL;
     if (C != 32) return MVSNERF_EUNSUPPORTED;
     const int64_t nvox = (int64_t)D * (H + 2 * pad) * (W + 2 * pad);
-    planesweep_bwd_kernel<32><<<mvs_cdiv(nvox * 32, 256), 256, 0, (hipStream_t)stream>>>(feats_cl, proj, depth, V, H, W, D, pad, g_cost, CP,
-                                                                                     with_img ? 3 * V : 0, g_feats_cl);
+    const size_t lds = (size_t)256 * ((V - 1) * 8 + 2) * sizeof(float);
+    planesweep_bwd_kernel<32><<<mvs_cdiv(nvox, 256), 256, lds, (hipStream_t)stream>>>(feats_cl, proj, depth, V, H, W, D, pad, g_cost, CP,
+                                                                                    with_img ? 3 * V : 0, g_feats_cl);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
