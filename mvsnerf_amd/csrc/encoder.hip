@@ -64,12 +64,16 @@ extern "C" int mvsnerf_resize_bilinear(const float* src, float* dst, int NC, int
 
 // =============================================================================================
 // plane sweep: homo_warp (utils.py:580-630) + build_volume_costvar[_img] (models.py:787-893) in ONE pass.
-// FOUR lanes per voxel (d,y,x; x fastest): lane q owns the channel quads {q, q+4} of the 32-channel feature vector, so a
-// wave-level 16-byte load covers 16 voxels x 64 CONTIGUOUS bytes of a source pixel.  The first version gave a whole voxel
-// (8 x 16-byte loads per tap) to one lane: every load instruction touched 64 different 128-byte lines for 16 useful bytes
-// each and the kernel ran at the L1 line rate (0.57 ms); the projection arithmetic is repeated by the four lanes, which
-// costs nothing per instruction.  Reads ~1 KB of L2-resident source features per voxel, writes the voxel's CP-channel
-// vector once (the reference moves ~10 GB for the same result).
+// A workgroup owns 256 consecutive voxels (d,y,x; x fastest) and works in two phases:
+//  (1) one thread per voxel: projection into every source view (7 divisions per view), in-frustum mask, bilinear weights and
+//      tap indices -> LDS; the per-view masks and the view count are written from here;
+//  (2) four passes of 64 voxels, FOUR lanes per voxel, lane q owning the channel quads {q, q+4} of the 32-channel feature
+//      vector: a wave-level 16-byte load covers 16 voxels x 64 CONTIGUOUS bytes of a source pixel; Sigma / Sigma^2 / variance;
+//      the 64 finished voxel vectors are staged in LDS and flushed as one contiguous span of coalesced 16-byte stores.
+// History: one lane per voxel (8 x 16-byte loads per tap: every load instruction touched 64 different 128-byte lines for 16
+// useful bytes each, the kernel ran at the L1 line rate) 0.57 ms; four lanes per voxel each repeating phase 1: 0.39 ms, bound
+// by that arithmetic (VALU issuing 80 % of the time).  Reads ~1 KB of L2-resident source features per voxel, writes the voxel's
+// CP-channel vector once (the reference moves ~10 GB for the same result).
 // =============================================================================================
 template <int C>   // feature channels (32)
 __global__ __launch_bounds__(256) void planesweep_kernel(
@@ -83,108 +87,134 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
     int with_img)
 {
     static_assert(C == 32, "lane q owns float4 numbers q and q + 4 of a 32-channel pixel");
-    constexpr int VPB = 64;                                      // voxels per block (4 lanes each)
-    const int q = threadIdx.x & 3, vloc = threadIdx.x >> 2;
+    constexpr int VPB = 256, VPP = 64;                           // voxels per block / per pass
+    extern __shared__ __attribute__((aligned(16))) float lds_[];
+    const int GS = (V - 1) * 8 + 2;                              // per voxel: per source view {w_nw,w_ne,w_sw,w_se, t_nw,t_ne,t_sw,t_se}; then {1/count, ref pixel}
+    float* geo = lds_;                                           // [VPB][GS]
+    float* stage = lds_ + ((VPB * GS + 3) & ~3);                 // [VPP][CP+4]: +4 floats per row breaks the bank stride
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const int64_t nvox = (int64_t)D * Hp * Wp;
-    const int64_t i_raw = (int64_t)blockIdx.x * VPB + vloc;
-    const bool live = i_raw < nvox;
-    const int64_t i = live ? i_raw : nvox - 1;                   // tail lanes recompute the last voxel (their stores are masked)
-    const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), d = (int)(i / ((int64_t)Wp * Hp));
-    const float u = (float)(x - pad), v = (float)(y - pad);     // utils.py:603-605
-    const float dep = depth[d];
-    const bool interior = x >= pad && x < W + pad && y >= pad && y < H + pad;
-
-    float s[8], s2[8];                                           // channels 4q..4q+3 and 16+4q..16+4q+3
-    extern __shared__ __attribute__((aligned(16))) float stage[];     // [VPB][CP+4]: +4 floats per row breaks the bank stride
-    float* o = stage + vloc * (CP + 4);
+    const int64_t v0 = (int64_t)blockIdx.x * VPB;
+    {   // ---- phase 1
+        const int64_t i = v0 + threadIdx.x;
+        if (i < nvox) {
+            float* o = geo + threadIdx.x * GS;
+            const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), d = (int)(i / ((int64_t)Wp * Hp));
+            const float u = (float)(x - pad), v = (float)(y - pad);     // utils.py:603-605
+            const float dep = depth[d];
+            const bool interior = x >= pad && x < W + pad && y >= pad && y < H + pad;
+            if (with_img) masks[i] = 1.0f;                          // view 0 mask (models.py:869)
+            float cnt = 1.0f;
+            for (int vv = 1; vv < V; ++vv) {
+                const float* P = proj + vv * 12;
+                // utils.py:612  R @ (u,v,1) + T/depth   (k-ordered fma chain like the reference's bmm)
+                const float p0 = fmaf(P[2], 1.0f, fmaf(P[1], v, P[0] * u)) + P[3] / dep;
+                const float p1 = fmaf(P[6], 1.0f, fmaf(P[5], v, P[4] * u)) + P[7] / dep;
+                const float p2 = fmaf(P[10], 1.0f, fmaf(P[9], v, P[8] * u)) + P[11] / dep;
+                const float gx = (p0 / p2) / ((float)(W - 1) / 2.0f) - 1.0f;          // :617-620 (un-padded W,H)
+                const float gy = (p1 / p2) / ((float)(H - 1) / 2.0f) - 1.0f;
+                const float m = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;   // models.py:875-876
+                cnt += m;
+                if (with_img) masks[(int64_t)vv * nvox + i] = m;
+                // F.grid_sample bilinear, zeros padding, align_corners=True (utils.py:625)
+                const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+                const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+                const float fx = floorf(ix), fy = floorf(iy);
+                const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
+                const bool x0in = fx >= 0.f && fx <= (float)(W - 1), x1in = fx + 1.f >= 0.f && fx + 1.f <= (float)(W - 1);
+                const bool y0in = fy >= 0.f && fy <= (float)(H - 1), y1in = fy + 1.f >= 0.f && fy + 1.f <= (float)(H - 1);
+                float* ov = o + (vv - 1) * 8;
+                ov[0] = (x0in && y0in) ? wx0 * wy0 : 0.f; ov[1] = (x1in && y0in) ? wx1 * wy0 : 0.f;
+                ov[2] = (x0in && y1in) ? wx0 * wy1 : 0.f; ov[3] = (x1in && y1in) ? wx1 * wy1 : 0.f;
+                // clamp the tap addresses (weights are already zero where a tap is outside)
+                const bool any = (x0in || x1in) && (y0in || y1in);
+                const int xa = any ? min(max((int)fx, 0), W - 1) : 0, xb = any ? min(max((int)fx + 1, 0), W - 1) : 0;
+                const int ya = any ? min(max((int)fy, 0), H - 1) : 0, yb = any ? min(max((int)fy + 1, 0), H - 1) : 0;
+                ov[4] = __int_as_float(ya * W + xa); ov[5] = __int_as_float(ya * W + xb);
+                ov[6] = __int_as_float(yb * W + xa); ov[7] = __int_as_float(yb * W + xb);
+            }
+            if (!with_img) masks[i] = cnt;                          // build_volume_costvar returns the count (models.py:821)
+            o[(V - 1) * 8] = 1.0f / cnt;                            // models.py:889
+            o[(V - 1) * 8 + 1] = __int_as_float(interior ? (y - pad) * W + (x - pad) : -1);
+        }
+    }
+    __syncthreads();
+    // ---- phase 2
+    const int q = threadIdx.x & 3, vloc = threadIdx.x >> 2;
     const int c_var = with_img ? 3 * V : 0;
-    if (interior) {                                              // ref volume: zero-padded ref feature (models.py:856,862)
-        const f32x4* r = reinterpret_cast<const f32x4*>(feat + ((int64_t)(y - pad) * W + (x - pad)) * C);
-        const f32x4 t0 = r[q], t1 = r[q + 4];
+    float* o = stage + vloc * (CP + 4);
+    for (int pass = 0; pass < VPB / VPP; ++pass) {
+        const int vb = pass * VPP + vloc;
+        const int64_t i_raw = v0 + vb;
+        const bool live = i_raw < nvox;
+        const float* g = geo + (live ? vb : 0) * GS;             // dead lanes recompute the block's first voxel (their rows are not flushed)
+        const float inv = g[(V - 1) * 8];
+        const int refpix = __float_as_int(g[(V - 1) * 8 + 1]);
+        const bool interior = refpix >= 0;
+        float s[8], s2[8];                                       // channels 4q..4q+3 and 16+4q..16+4q+3
+        if (interior) {                                          // ref volume: zero-padded ref feature (models.py:856,862)
+            const f32x4* r = reinterpret_cast<const f32x4*>(feat + (int64_t)refpix * C);
+            const f32x4 t0 = r[q], t1 = r[q + 4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { s[k] = t0[k]; s2[k] = t0[k] * t0[k]; s[4 + k] = t1[k]; s2[4 + k] = t1[k] * t1[k]; }
-    } else {
+            for (int k = 0; k < 4; ++k) { s[k] = t0[k]; s2[k] = t0[k] * t0[k]; s[4 + k] = t1[k]; s2[4 + k] = t1[k] * t1[k]; }
+        } else {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { s[c] = 0.f; s2[c] = 0.f; }
-    }
-    if (with_img && q == 0) {                                    // channels 0:3 = ref thumbnail, border := 0 (models.py:858-860)
-        const float* ri = img + ((int64_t)(y - pad) * W + (x - pad)) * 4;
-        o[0] = interior ? ri[0] : 0.f; o[1] = interior ? ri[1] : 0.f; o[2] = interior ? ri[2] : 0.f;
-        if (live) masks[i] = 1.0f;                               // view 0 mask (models.py:869)
-    }
-    float cnt = 1.0f;
-    for (int vv = 1; vv < V; ++vv) {
-        const float* P = proj + vv * 12;
-        // utils.py:612  R @ (u,v,1) + T/depth   (k-ordered fma chain like the reference's bmm)
-        const float p0 = fmaf(P[2], 1.0f, fmaf(P[1], v, P[0] * u)) + P[3] / dep;
-        const float p1 = fmaf(P[6], 1.0f, fmaf(P[5], v, P[4] * u)) + P[7] / dep;
-        const float p2 = fmaf(P[10], 1.0f, fmaf(P[9], v, P[8] * u)) + P[11] / dep;
-        const float gx = (p0 / p2) / ((float)(W - 1) / 2.0f) - 1.0f;          // :617-620 (un-padded W,H)
-        const float gy = (p1 / p2) / ((float)(H - 1) / 2.0f) - 1.0f;
-        const float m = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;   // models.py:875-876
-        cnt += m;
-        if (with_img && live && q == 0) masks[(int64_t)vv * nvox + i] = m;
-        // F.grid_sample bilinear, zeros padding, align_corners=True (utils.py:625)
-        const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
-        const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
-        const float fx = floorf(ix), fy = floorf(iy);
-        const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
-        const bool x0in = fx >= 0.f && fx <= (float)(W - 1), x1in = fx + 1.f >= 0.f && fx + 1.f <= (float)(W - 1);
-        const bool y0in = fy >= 0.f && fy <= (float)(H - 1), y1in = fy + 1.f >= 0.f && fy + 1.f <= (float)(H - 1);
-        const float w_nw = (x0in && y0in) ? wx0 * wy0 : 0.f, w_ne = (x1in && y0in) ? wx1 * wy0 : 0.f;
-        const float w_sw = (x0in && y1in) ? wx0 * wy1 : 0.f, w_se = (x1in && y1in) ? wx1 * wy1 : 0.f;
-        // clamp the tap addresses (weights are already zero where a tap is outside)
-        const bool any = (x0in || x1in) && (y0in || y1in);
-        const int xa = any ? min(max((int)fx, 0), W - 1) : 0, xb = any ? min(max((int)fx + 1, 0), W - 1) : 0;
-        const int ya = any ? min(max((int)fy, 0), H - 1) : 0, yb = any ? min(max((int)fy + 1, 0), H - 1) : 0;
-        const float* fb = feat + (int64_t)vv * H * W * C;
-        const f32x4* t_nw = reinterpret_cast<const f32x4*>(fb + ((int64_t)ya * W + xa) * C);
-        const f32x4* t_ne = reinterpret_cast<const f32x4*>(fb + ((int64_t)ya * W + xb) * C);
-        const f32x4* t_sw = reinterpret_cast<const f32x4*>(fb + ((int64_t)yb * W + xa) * C);
-        const f32x4* t_se = reinterpret_cast<const f32x4*>(fb + ((int64_t)yb * W + xb) * C);
+            for (int c = 0; c < 8; ++c) { s[c] = 0.f; s2[c] = 0.f; }
+        }
+        if (with_img && q == 0) {                                // channels 0:3 = ref thumbnail, border := 0 (models.py:858-860)
+            const float* ri = img + (int64_t)(interior ? refpix : 0) * 4;
+            o[0] = interior ? ri[0] : 0.f; o[1] = interior ? ri[1] : 0.f; o[2] = interior ? ri[2] : 0.f;
+        }
+        for (int vv = 1; vv < V; ++vv) {
+            const float* gv = g + (vv - 1) * 8;
+            const float w_nw = gv[0], w_ne = gv[1], w_sw = gv[2], w_se = gv[3];
+            const int a_nw = __float_as_int(gv[4]), a_ne = __float_as_int(gv[5]), a_sw = __float_as_int(gv[6]), a_se = __float_as_int(gv[7]);
+            const float* fb = feat + (int64_t)vv * H * W * C;
+            const f32x4* t_nw = reinterpret_cast<const f32x4*>(fb + (int64_t)a_nw * C);
+            const f32x4* t_ne = reinterpret_cast<const f32x4*>(fb + (int64_t)a_ne * C);
+            const f32x4* t_sw = reinterpret_cast<const f32x4*>(fb + (int64_t)a_sw * C);
+            const f32x4* t_se = reinterpret_cast<const f32x4*>(fb + (int64_t)a_se * C);
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const f32x4 a = t_nw[q + 4 * hh], b = t_ne[q + 4 * hh], c_ = t_sw[q + 4 * hh], e = t_se[q + 4 * hh];
+            for (int hh = 0; hh < 2; ++hh) {
+                const f32x4 a = t_nw[q + 4 * hh], b = t_ne[q + 4 * hh], c_ = t_sw[q + 4 * hh], e = t_se[q + 4 * hh];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float wv = ((a[k] * w_nw + b[k] * w_ne) + c_[k] * w_sw) + e[k] * w_se;   // ATen's nw,ne,sw,se order
-                s[hh * 4 + k] += wv;                             // models.py:880
-                s2[hh * 4 + k] += wv * wv;                       // :881
+                for (int k = 0; k < 4; ++k) {
+                    const float wv = ((a[k] * w_nw + b[k] * w_ne) + c_[k] * w_sw) + e[k] * w_se;   // ATen's nw,ne,sw,se order
+                    s[hh * 4 + k] += wv;                             // models.py:880
+                    s2[hh * 4 + k] += wv * wv;                       // :881
+                }
+            }
+            if (with_img && q == (vv & 3)) {                         // warped thumbnail with the same grid (models.py:872), one lane per view
+                const float* ib = img + (int64_t)vv * H * W * 4;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(ib + (int64_t)a_nw * 4);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(ib + (int64_t)a_ne * 4);
+                const f32x4 c_ = *reinterpret_cast<const f32x4*>(ib + (int64_t)a_sw * 4);
+                const f32x4 e = *reinterpret_cast<const f32x4*>(ib + (int64_t)a_se * 4);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) o[3 * vv + k] = ((a[k] * w_nw + b[k] * w_ne) + c_[k] * w_sw) + e[k] * w_se;
             }
         }
-        if (with_img && q == (vv & 3)) {                         // warped thumbnail with the same grid (models.py:872), one lane per view
-            const float* ib = img + (int64_t)vv * H * W * 4;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(ib + ((int64_t)ya * W + xa) * 4);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(ib + ((int64_t)ya * W + xb) * 4);
-            const f32x4 c_ = *reinterpret_cast<const f32x4*>(ib + ((int64_t)yb * W + xa) * 4);
-            const f32x4 e = *reinterpret_cast<const f32x4*>(ib + ((int64_t)yb * W + xb) * 4);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) o[3 * vv + k] = ((a[k] * w_nw + b[k] * w_ne) + c_[k] * w_sw) + e[k] * w_se;
+        for (int j = 0; j < 8; ++j) {
+            const int c = (j < 4 ? 4 * q : 16 + 4 * q - 4) + j;
+            const float mean = s[j] * inv;
+            o[c_var + c] = s2[j] * inv - mean * mean;                // :890
         }
-    }
-    if (!with_img && live && q == 0) masks[i] = cnt;             // build_volume_costvar returns the count (models.py:821)
-    const float inv = 1.0f / cnt;                                // models.py:889
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int c = (j < 4 ? 4 * q : 16 + 4 * q - 4) + j;
-        const float mean = s[j] * inv;
-        o[c_var + c] = s2[j] * inv - mean * mean;                // :890
-    }
-    if (q == 0)
-        for (int c = c_var + C; c < CP; ++c) o[c] = 0.0f;
-    // `o` points into the LDS staging row of this voxel; flush the block's 64 consecutive voxels (one contiguous
-    // CP*64*4-byte span of the cost volume) with coalesced 16-byte stores
-    __syncthreads();
-    {
-        const int64_t v0 = (int64_t)blockIdx.x * VPB;
-        const int64_t nv = nvox - v0 < VPB ? nvox - v0 : VPB;
-        const int n4 = (int)(nv * CP / 4);
-        f32x4* dst = reinterpret_cast<f32x4*>(cost + v0 * CP);
-        for (int k = threadIdx.x; k < n4; k += 256) {
-            const int vox = (k * 4) / CP, c = (k * 4) - vox * CP;
-            dst[k] = *reinterpret_cast<const f32x4*>(stage + vox * (CP + 4) + c);
+        if (q == 0)
+            for (int c = c_var + C; c < CP; ++c) o[c] = 0.0f;
+        // flush this pass's 64 consecutive voxels (one contiguous CP*64*4-byte span of the cost volume) with coalesced 16-byte stores
+        __syncthreads();
+        {
+            const int64_t p0 = v0 + pass * VPP;
+            const int64_t nv = nvox - p0 < VPP ? (nvox - p0 > 0 ? nvox - p0 : 0) : VPP;
+            const int n4 = (int)(nv * CP / 4);
+            f32x4* dst = reinterpret_cast<f32x4*>(cost + p0 * CP);
+            for (int k = threadIdx.x; k < n4; k += 256) {
+                const int vox = (k * 4) / CP, c = (k * 4) - vox * CP;
+                dst[k] = *reinterpret_cast<const f32x4*>(stage + vox * (CP + 4) + c);
+            }
         }
+        __syncthreads();                                         // the staging rows are rewritten by the next pass
     }
 }
 
@@ -199,8 +229,12 @@ extern "C" int mvsnerf_planesweep_costvar_fwd(const float* feats_cl, const float
     if (!mvs_aligned16(feats_cl) || (imgs_cl && !mvs_aligned16(imgs_cl))) return MVSNERF_EALIGN;
     const int64_t nvox = (int64_t)D * (H + 2 * pad) * (W + 2 * pad);
     if ((CP & 3) || !mvs_aligned16(cost)) return MVSNERF_EALIGN;
-    const size_t lds = (size_t)64 * (CP + 4) * sizeof(float);
-    planesweep_kernel<32><<<mvs_cdiv(nvox, 64), 256, lds, (hipStream_t)stream>>>(feats_cl, imgs_cl, proj, depth, V, H, W, D, pad, cost, CP, masks, with_img);
+    const size_t lds = ((((size_t)256 * ((V - 1) * 8 + 2) + 3) & ~(size_t)3) + (size_t)64 * (CP + 4)) * sizeof(float);
+    if (lds > 48 * 1024) {      // many source views: raise the dynamic-LDS cap (idempotent)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(planesweep_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    planesweep_kernel<32><<<mvs_cdiv(nvox, 256), 256, lds, (hipStream_t)stream>>>(feats_cl, imgs_cl, proj, depth, V, H, W, D, pad, cost, CP, masks, with_img);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
