@@ -166,20 +166,45 @@ def sustained_clock_ghz(lib, run_mlp, n_wg, dev):
     return float((c[ok, 13] / dur_us[ok] / 1e3).mean())
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): re-execute under torch.distributed.run with one rank per
+    GPU - the same command line the driver uses.  Never degrades to fewer ranks: too few visible GPUs is an error."""
+    import socket
+    import subprocess
+    n_vis = torch.cuda.device_count()
+    if n_vis < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {n_vis} GPU(s) visible; refusing to report a {a.gpus}-GPU number from fewer ranks")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher must start exactly one rank per requested GPU")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {a.gpus}")
 
     from mvsnerf_amd import _lib, models, ops, renderer
     from mvsnerf_amd.synth import make_rig, pose_ref_of

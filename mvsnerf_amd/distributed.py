@@ -10,10 +10,50 @@ The path shards by rays: given the 8-channel volume, the source i
     slice, and the gradients are averaged with ONE all-reduce over a single flat fp32 buffer (1.9 MB for
     MLP + MVSNet: latency-bound, so one message instead of ~100 per-parameter ones).
 """
+import contextlib
 import os
 
 import torch
 import torch.distributed as dist
+
+_SINGLE = False          # inside `single_rank()`: behave as world size 1 (local full-frame reference renders in bench/tests)
+_FORCE_COLLECTIVES = False   # tests on a 1-GPU box: issue the collectives even at world size 1 (exercises RCCL itself)
+
+
+@contextlib.contextmanager
+def single_rank():
+    """Everything in this module acts as if no process group existed (each rank does the whole job locally)."""
+    global _SINGLE
+    prev, _SINGLE = _SINGLE, True
+    try:
+        yield
+    finally:
+        _SINGLE = prev
+
+
+@contextlib.contextmanager
+def force_collectives():
+    """World-size-1 groups normally skip their collectives; inside this context they are issued (an all-reduce / all-gather
+    over one rank is the identity, but it goes through RCCL - what a 1-GPU test box can check)."""
+    global _FORCE_COLLECTIVES
+    prev, _FORCE_COLLECTIVES = _FORCE_COLLECTIVES, True
+    try:
+        yield
+    finally:
+        _FORCE_COLLECTIVES = prev
+
+
+def world_rank(group=None):
+    """(world, rank) of the default (or given) group; (1, 0) without a group or inside single_rank()."""
+    if _SINGLE or not (dist.is_available() and dist.is_initialized()):
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+def _collective_needed(group=None):
+    if _SINGLE or not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or _FORCE_COLLECTIVES
 
 
 def init_from_env(device=None):
@@ -44,7 +84,7 @@ def shard_rays(n_rays, world, rank):
 def all_gather_rows(local, n_total, group=None):
     """Concatenate per-rank row blocks (rank r owns rows shard_range(n_total, world, r)) on every rank.
     One collective; blocks are padded to the largest shard so that a single all_gather_into_tensor suffices."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _collective_needed(group):
         return local
     world = dist.get_world_size(group)
     sizes = [shard_range(n_total, world, r) for r in range(world)]
@@ -68,7 +108,7 @@ class FlatGradAllReduce:
         self.flat = None
 
     def __call__(self):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1 or not self.params:
+        if not _collective_needed(self.group) or not self.params:
             return
         dev = self.params[0].device
         if self.flat is None or self.flat.device != dev:
@@ -98,8 +138,7 @@ def render_frame(render_chunk, H, W, chunk, group=None):
     `render_chunk(idx)` renders chunk `idx` of the row-major pixel order and returns (rgb (n,3), depth (n,)).
     Each rank renders a contiguous range of chunks; one all_gather assembles (H*W,3) and (H*W,) on every rank."""
     n_chunks = (H * W + chunk - 1) // chunk
-    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-    rank = dist.get_rank(group) if world > 1 else 0
+    world, rank = world_rank(group)
     lo, hi = shard_range(n_chunks, world, rank)
     rgbs, depths = [], []
     for idx in range(lo, hi):
@@ -118,8 +157,7 @@ def render_frame_pixels(render_range, H, W, chunk, group=None, device=None):
     `render_range(first_pixel, n_pixels) -> (rgb (n,3), depth (n,))` (ops.render_pixels: the chunk loop runs inside the
     library, one FFI crossing per rank and frame)."""
     n_chunks = (H * W + chunk - 1) // chunk
-    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-    rank = dist.get_rank(group) if world > 1 else 0
+    world, rank = world_rank(group)
     lo, hi = shard_range(n_chunks, world, rank)
     first, last = min(lo * chunk, H * W), min(hi * chunk, H * W)
     packed = None
@@ -130,7 +168,7 @@ def render_frame_pixels(render_range, H, W, chunk, group=None, device=None):
 
 
 def _assemble_frame(packed, H, W, chunk, n_chunks, world, group, device=None):
-    if world == 1:
+    if world == 1 and not _collective_needed(group):
         return packed[:, :3], packed[:, 3]
     # rows are pixels; the per-rank pixel ranges follow from the chunk ranges (the last chunk may be short)
     px = [(min(l * chunk, H * W), min(h * chunk, H * W)) for l, h in (shard_range(n_chunks, world, r) for r in range(world))]
@@ -146,3 +184,45 @@ def _assemble_frame(packed, H, W, chunk, n_chunks, world, group, device=None):
     dist.all_gather_into_tensor(out, pad, group=group)
     full = torch.cat([out[r * width:r * width + (b - a)] for r, (a, b) in enumerate(px)], 0)
     return full[:, :3], full[:, 3]
+
+
+# ------------------------------------------------------------------ data-parallel training
+def shard_ray_batch(tensors, n_rays, group=None, dim=0):
+    """Ray-sharded DP: every rank holds the SAME batch of n_rays rays (same seeded draw); returns this rank's slice of each tensor
+    in `tensors` (sliced along `dim`; None entries pass through) and the factor its mean-over-local-rays loss must be multiplied
+    with so that the rank-AVERAGED gradient (FlatGradAllReduce) is the gradient of the mean over all n_rays rays:
+    sum_r (n_r/N) g_r = (1/world) sum_r (n_r world / N) g_r - which differs from 1 only when n_rays % world != 0."""
+    world, rank = world_rank(group)
+    if world == 1:
+        return list(tensors), 1.0
+    sl = shard_rays(n_rays, world, rank)
+    out = []
+    for t in tensors:
+        if t is None:
+            out.append(None)
+        else:
+            idx = [slice(None)] * t.dim()
+            idx[dim if t.shape[dim] == n_rays else 1] = sl          # rays_o-style (3, N) tensors carry the rays in dim 1
+            out.append(t[tuple(idx)])
+    n_local = sl.stop - sl.start
+    return out, n_local * world / float(n_rays)
+
+
+def common_seed(device=None, group=None):
+    """One int64 drawn on rank 0 and broadcast: ray-sharded DP needs the same pixel ids (CPU RNG, reference utils.py:93) and the
+    same stratified jitter (device RNG, utils.py:220) on every rank.  Seeding both generators with a broadcast value per step makes
+    that true by construction instead of by an unchecked 'all ranks were seeded alike' assumption."""
+    seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
+    if _collective_needed(group):
+        t = seed.to(device) if device is not None else seed
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        seed = t.cpu()
+    return int(seed.item())
+
+
+def scene_shard(items, group=None):
+    """Scene-sharded DP (what Lightning DDP's DistributedSampler gives the reference, train_mvs_nerf_pl.py:306,313): rank r takes
+    items r, r+world, r+2 world, ... of the sample list; all ranks take the same NUMBER of steps (the tail is dropped)."""
+    world, rank = world_rank(group)
+    n = len(items) // world * world
+    return [items[i] for i in range(rank, n, world)]

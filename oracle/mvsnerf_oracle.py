@@ -32,6 +32,43 @@ ABN_EPS = 1e-5
 ABN_SLOPE = 0.01
 
 
+def _dt():
+    return torch.get_default_dtype()
+
+
+class precision:
+    """`with precision(torch.float64):` evaluates the same restatement in double precision (inputs and weights must be passed
+    as doubles).  Not the reference's arithmetic - the reference runs fp32 - but the yardstick for it: the distance between
+    the fp32 oracle and the fp64 evaluation is the rounding noise of the reference's own fp32 path, and a HIP result that
+    is as close to the fp64 evaluation as the fp32 oracle is has nothing left to fix (tests/test_gpu_headline_parity.py)."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.prev = torch.get_default_dtype()
+        torch.set_default_dtype(self.dtype)
+
+    def __exit__(self, *a):
+        torch.set_default_dtype(self.prev)
+
+
+def _conv3d_s1(x, w):
+    """F.conv3d(stride 1, padding 1).  fp64 on CPU has no oneDNN kernel and ATen's fallback unfolds the whole input
+    (41 x 27 x 4.7 M doubles = 41 GB at the headline shape): evaluate in depth slabs with a one-plane halo."""
+    if x.dtype != torch.float64 or x.shape[1] * x.shape[2] * x.shape[3] * x.shape[4] < (1 << 26):
+        return F.conv3d(x, w, None, stride=1, padding=1)
+    D = x.shape[2]
+    step = max(1, (1 << 26) // (x.shape[1] * x.shape[3] * x.shape[4]))
+    out = []
+    for d0 in range(0, D, step):
+        d1 = min(D, d0 + step)
+        lo, hi = max(0, d0 - 1), min(D, d1 + 1)
+        slab = F.pad(x[:, :, lo:hi], (0, 0, 0, 0, 1 if d0 == 0 else 0, 1 if d1 == D else 0))
+        out.append(F.conv3d(slab, w, None, stride=1, padding=(0, 1, 1)))
+    return torch.cat(out, 2)
+
+
 # --------------------------------------------------------------------------- encoder (L1a)
 
 def abn(x, sd, prefix, training=True, update_running=False, momentum=0.1):
@@ -70,8 +107,8 @@ def homo_warp(src_feat, proj_mat, depth_values, src_grid=None, pad=0):
         Hp, Wp = H + 2 * pad, W + 2 * pad
         D = depth_values.shape[1]
         R, T = proj_mat[:, :, :3], proj_mat[:, :, 3:]                       # :600-601
-        ys, xs = torch.meshgrid(torch.arange(Hp, dtype=torch.float32) - pad,
-                                torch.arange(Wp, dtype=torch.float32) - pad, indexing="ij")  # :603-605
+        ys, xs = torch.meshgrid(torch.arange(Hp, dtype=_dt()) - pad,
+                                torch.arange(Wp, dtype=_dt()) - pad, indexing="ij")  # :603-605
         uv1 = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(Hp * Wp)], 0)[None].expand(B, -1, -1)
         uv1 = uv1.repeat(1, 1, D)                                            # :611  (B,3,D*Hp*Wp) order d,y,x
         dv = depth_values[:, :, None].expand(B, D, Hp * Wp).reshape(B, 1, -1)
@@ -99,7 +136,7 @@ def build_volume_costvar(feats, proj_mats, depth_values, pad=0):
     for v in range(1, V):
         warped, grid = homo_warp(feats[:, v], proj_mats[:, v], depth_values, pad=pad)
         grid = grid.view(B, 1, D, H + 2 * pad, W + 2 * pad, 2)
-        inb = ((grid > -1.0) & (grid < 1.0)).all(-1).float()               # :819-820
+        inb = ((grid > -1.0) & (grid < 1.0)).all(-1).to(_dt())               # :819-820
         cnt = cnt + inb
         s, s2 = s + warped, s2 + warped ** 2
     inv = 1.0 / cnt
@@ -127,7 +164,7 @@ def build_volume_costvar_img(imgs, feats, proj_mats, depth_values, pad=0):
         warped, grid = homo_warp(feats[:, v], proj_mats[:, v], depth_values, pad=pad)       # :871
         out[:, 3 * v:3 * v + 3], _ = homo_warp(small[:, v], proj_mats[:, v], depth_values, src_grid=grid, pad=pad)  # :872
         g = grid.view(B, D, Hp, Wp, 2)
-        masks[:, v] = ((g > -1.0) & (g < 1.0)).all(-1).float()              # :875-877
+        masks[:, v] = ((g > -1.0) & (g < 1.0)).all(-1).to(_dt())              # :875-877
         s, s2 = s + warped, s2 + warped ** 2                                 # :880-881
     inv = 1.0 / masks.sum(1, keepdim=True)                                   # :889
     out[:, -C:] = s2 * inv - (s * inv) ** 2                                  # :890
@@ -138,7 +175,8 @@ def cost_reg_net(x, sd, prefix="cost_reg_2."):
     """CostRegNet.forward models.py:756-769; ConvBnReLU3D :674-685.  ABN follows every conv
     including the three transposed ones, *before* the skip add (:762-766)."""
     def cbr(x, name, stride=1):
-        x = F.conv3d(x, sd[prefix + name + ".conv.weight"], None, stride=stride, padding=1)
+        w = sd[prefix + name + ".conv.weight"]
+        x = _conv3d_s1(x, w) if stride == 1 else F.conv3d(x, w, None, stride=stride, padding=1)
         return abn(x, sd, prefix + name + ".bn")
 
     def up(x, name):
@@ -231,7 +269,7 @@ def build_rays(imgs, pose_ref, near_fars, N_rays, N_samples, pad=0, t_rand=None,
     Returns rays_pts, rays_dir, target_rgb, rays_ndc, depth_candidates, rays_o (3,N) , pixel ids (2,N) long."""
     _, V, _, H, W = imgs.shape
     tgt = tgt % V
-    inv_scale = torch.tensor([W - 1, H - 1], dtype=torch.float32)
+    inv_scale = torch.tensor([W - 1, H - 1], dtype=_dt())
     rays_o, rays_d, pix = get_rays_mvs(H, W, pose_ref["intrinsics"][tgt], pose_ref["c2ws"][tgt], N_rays, generator=generator)
     pix_i = pix.long()
     target = imgs[0, tgt][:, pix_i[0], pix_i[1]].permute(1, 0)              # :194,233
@@ -251,7 +289,7 @@ def build_rays_test(H, W, tgt_to_world, world_to_ref, intrinsic, near_fars_ref, 
     size, utils.py:252-253,288): they restate the same arithmetic for a target grid that differs from the source views
     (BASELINE config 5); None reproduces the reference."""
     Hr, Wr = (H, W) if ref_hw is None else ref_hw
-    inv_scale = torch.tensor([Wr - 1, Hr - 1], dtype=torch.float32)
+    inv_scale = torch.tensor([Wr - 1, Hr - 1], dtype=_dt())
     rays_o, rays_d, pix = get_rays_mvs(H, W, intrinsic, tgt_to_world, isRandom=False, chunk=chunk, idx=idx)
     n = pix.shape[-1]
     z = stratified_depths(near_fars[0], near_fars[1], n, N_samples, None)
@@ -283,7 +321,7 @@ def build_color_volume(pts, pose_ref, imgs, with_mask=True):
     Per view: project (:316), bilinear with *border* padding (:320), strict in-bounds mask (:325-326).
     -> (N,S,V*(3+mask))."""
     _, V, C, H, W = imgs.shape
-    inv_scale = torch.tensor([W - 1, H - 1], dtype=torch.float32)
+    inv_scale = torch.tensor([W - 1, H - 1], dtype=_dt())
     Cv = C + int(with_mask)
     out = torch.empty(*pts.shape[:2], V * Cv)
     for v in range(V):
@@ -291,7 +329,7 @@ def build_color_volume(pts, pose_ref, imgs, with_mask=True):
         grid = ndc[..., :2] * 2.0 - 1.0                                      # :317
         data = F.grid_sample(imgs[:, v], grid, align_corners=True, mode="bilinear", padding_mode="border")
         if with_mask:
-            m = ((grid > -1.0) & (grid < 1.0)).all(-1).float()
+            m = ((grid > -1.0) & (grid < 1.0)).all(-1).to(_dt())
             data = torch.cat((data, m.unsqueeze(1)), 1)
         out[..., v * Cv:(v + 1) * Cv] = data[0].permute(1, 2, 0)            # :329
     return out
