@@ -37,6 +37,7 @@ VOL_BYTES_PER_SAMPLE = 300        # 8 corners x 32 B + 12 B coord + 32 B out
 COL_BYTES_PER_SAMPLE = 204        # 3 views x 48 B + 12 B + 48 B out
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
+PMC_FILE = "profiles/r01_pmc_summary.json"
 
 
 def _load_pmc_traffic():
@@ -44,7 +45,7 @@ def _load_pmc_traffic():
     separate --pmc passes over this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950's
     16-B/lane reads; counters are in KiB).  bench.py cannot run rocprof on itself, so `traffic` cites that measurement."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        d = json.load(open(os.path.join(ROOT, PMC_FILE)))
     except Exception:
         return {}
     out = {}
@@ -58,7 +59,7 @@ def pmc_mfma_busy_frac(kernel_prefix):
     """Fraction of the kernel's duration the matrix pipes were busy, from the committed PMC passes:
     (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        d = json.load(open(os.path.join(ROOT, PMC_FILE)))
     except Exception:
         return None
     for k, v in d.items():
@@ -90,6 +91,8 @@ def parse():
     ap.add_argument("--settle-ms", type=float, default=100.0,
                     help="untimed steps of the same workload run before the W warmup steps until the GPU clocks have left the idle state")
     ap.add_argument("--no-extras", action="store_true", help="skip the end-to-end frame / training-step timings")
+    ap.add_argument("--multi-gpu-legs", action="store_true", help="run the collective-carrying legs (tile-parallel frame, DP training step) "
+                                                                  "also at N = 1 (they always run at N > 1)")
     return ap.parse_args()
 
 
@@ -183,6 +186,98 @@ def self_launch(a):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def load_system(dev, **over):
+    """train.MVSSystem at the config-2 shapes with the checkpoint's weights."""
+    import numpy as np
+    from mvsnerf_amd import train
+    targs = train.default_args(pad=PAD, batch_size=N_RAYS, N_samples=N_SAMPLES, chunk=N_RAYS, **over)
+    system = train.MVSSystem(targs).to(dev)
+    system.render_kwargs_train["network_fn"].load_state_dict(load_mlp_weights())
+    zz = np.load(os.path.join(ROOT, "tests", "golden", "mvsnerf_v0_weights.npz"))
+    system.MVSNet.load_state_dict({k[4:]: torch.from_numpy(zz[k]) for k in zz.files if k.startswith("mvs/")})
+    return system
+
+
+def timed_collective(fn, dev, world):
+    """barrier + synchronize on both sides of fn(); returns the MAX over ranks of the elapsed seconds."""
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, out
+
+
+def all_ranks_true(flag, dev, world):
+    import torch.distributed as dist
+    t = torch.tensor([1 if flag else 0], device=dev, dtype=torch.int32)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def multi_gpu_legs(dev, rank, world, train_steps=5):
+    """The two collective-carrying paths of SURVEY.md 8(e), run by every rank (N > 1; also valid at N = 1):
+       frame_tile_parallel  MVSSystem.render_view: encode replicated, contiguous pixel ranges per rank, ONE all_gather (RCCL)
+       train_step_dp        MVSSystem.fit_steps: training_step + backward + ONE flat-buffer all-reduce + Adam, in both DP modes."""
+    import torch.distributed as dist
+    from mvsnerf_amd import distributed as D, train
+    out = {}
+    # ---- (i) tile-parallel frame
+    system = load_system(dev)
+    batch = train.synthetic_batch(H_IMG, W_IMG, seed=1234)
+    system.render_view(batch, batch_rays=N_RAYS)
+    dt, (rgb, depth) = timed_collective(lambda: system.render_view(batch, batch_rays=N_RAYS), dev, world)
+    with D.single_rank():                                   # the whole frame on this rank alone: must be the same pixels, bit for bit
+        rgb1, depth1 = system.render_view(batch, batch_rays=N_RAYS)
+    same = all_ranks_true(torch.equal(rgb, rgb1) and torch.equal(depth, depth1), dev, world)
+    if not same:
+        raise SystemExit(f"rank {rank}: tile-parallel frame differs from the single-rank frame")
+    out["frame_tile_parallel"] = {"seconds": round(dt, 4), "rays_per_s_incl_encode": round(H_IMG * W_IMG / dt, 1), "n_ranks": world,
+                                  "equals_single_rank_frame": same,
+                                  "note": "MVSSystem.render_view 512x640: MVSNet encode replicated on every rank, contiguous chunk ranges of 1024-ray "
+                                          "sub-batches per rank, one all_gather of (rgb, depth); strong scaling of the ray part only"}
+    del system
+    # ---- (ii) data-parallel training step, both modes
+    for mode in ("ray", "scene"):
+        system = load_system(dev, dp_mode=mode)
+        opt = system.configure_optimizers()[0][0]
+        torch.manual_seed(0)
+        n_warm = 2
+        if mode == "ray":
+            bl = [batch] * (n_warm + train_steps)
+            take = lambda lst, a, b: lst[a:b]
+        else:      # scene j goes to rank j % world (distributed.scene_shard): build only this rank's scenes
+            bl = [train.synthetic_batch(H_IMG, W_IMG, seed=1234 + j) if j % world == rank else None for j in range(world * (n_warm + train_steps))]
+            take = lambda lst, a, b: lst[a * world:b * world]
+        system.fit_steps(take(bl, 0, n_warm), opt)
+        dt, losses = timed_collective(lambda: system.fit_steps(take(bl, n_warm, n_warm + train_steps), opt), dev, world)
+        chk = torch.stack([p.detach().double().sum() for p in system.grad_vars]).sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        if world > 1:
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool((lo == hi).item())
+        if not in_sync:
+            raise SystemExit(f"rank {rank}: parameters diverged across ranks after {mode}-sharded steps")
+        rays = N_RAYS * (world if mode == "scene" else 1)
+        out[f"train_step_dp_{mode}"] = {"ms": round(dt / train_steps * 1e3, 2), "rays_per_s": round(rays * train_steps / dt, 1), "n_ranks": world,
+                                        "global_rays_per_step": rays, "params_in_sync": in_sync, "loss_last_rank0": round(losses[-1], 5),
+                                        "scaling": "strong (same 1024-ray step, encoder replicated)" if mode == "ray" else "weak (one scene + 1024 rays per rank)",
+                                        "note": "fit_steps: training_step fwd+bwd (HIP) + one flat fp32 all-reduce of all gradients (RCCL) + Adam"}
+        del system, opt
+    return out
 
 
 def main():
@@ -279,6 +374,10 @@ def main():
     rays_per_s = world * a.steps * N_RAYS / dt
 
     ops.set_mlp_precision("fp32")
+    # ---------------- N > 1: the collective-carrying paths (every rank takes part; rank 0 reports)
+    multi = None
+    if (world > 1 and not a.no_extras) or a.multi_gpu_legs:
+        multi = multi_gpu_legs(dev, rank, world)
     # ---------------- per-kernel launch durations (HIP events on the launch stream), rank 0
     roof, roofs, cpu = None, [], None
     if rank == 0:
@@ -316,7 +415,9 @@ def main():
             clock = sustained_clock_ghz(lib, k_mlp, (P + 127) // 128, dev)
         tf = FLOP_PER_SAMPLE * P / (t_mlp * 1e-3) / 1e12
         roof = {"kernel": "mlp_fwd_pipe_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic("mlp_fwd_pipe_kernel"), "avg_launch_ms": round(t_mlp, 4),
+                "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic("mlp_fwd_pipe_kernel"),
+                "traffic_source": PMC_FILE + " (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)",
+                "avg_launch_ms": round(t_mlp, 4),
                 "mfma_pipe_busy_frac_pmc": pmc_mfma_busy_frac("mlp_fwd_pipe_kernel"),
                 "s_memtime_ghz": round(clock, 3)}
         for name, t, bps in (("gather_fused_kernel", t_gat, VOL_BYTES_PER_SAMPLE + COL_BYTES_PER_SAMPLE),
@@ -354,7 +455,9 @@ def main():
                     out = O.rendering(cpose, b[0], b[1], b[2], b[4], cvol, csrc, sd)
                 cdt = time.perf_counter() - c0
                 torch.set_num_threads(n_default)
-            cpu = {"value": round(a.cpu_batches * N_RAYS / cdt, 1), "unit": "rays/s", "cores": best, "kind": "port",
+            cpu = {"value": round(a.cpu_batches * N_RAYS / cdt, 1), "unit": "rays/s", "cores": best, "host_cores": os.cpu_count(), "kind": "port",
+                   "kind_note": "oracle/mvsnerf_oracle.py: a restatement of the reference on the torch CPU kernels the reference itself would run on a "
+                                "CPU (the reference is Python and cannot travel to the GPU box); pinned to outputs of the imported reference (tests/golden)",
                    "sample": f"{a.cpu_batches} batches of {N_RAYS}x{N_SAMPLES} (oracle.rendering, torch CPU fp32, no_grad), {cdt:.1f} s, at the fastest of "
                              f"{sorted(probe)} threads (one probe batch each: " + ", ".join(f"{t}: {N_RAYS / probe[t]:.0f} rays/s" for t in sorted(probe)) + ")"}
             # parity of the timed workload itself (same batch, GPU vs CPU oracle)
@@ -367,17 +470,32 @@ def main():
             import math
             cpu["max_abs_rgb_err_vs_gpu"] = err
             cpu["psnr_gpu_vs_cpu_db"] = round(10 * math.log10(1.0 / max(mse, 1e-20)), 1)
+            cpu["max_abs_rgb_err_vs_gpu_note"] = "same GPU-built volume on both sides: the ray march alone"
+            # end to end: images -> volume on the CPU oracle as well (FeatureNet, plane sweep, CostRegNet), then the same batch;
+            # the GPU side is the timed step on the HIP-built volume.  tests/test_gpu_headline_parity.py breaks this down by stage.
+            if enc_ready:
+                import numpy as np
+                zz = np.load(os.path.join(ROOT, "tests", "golden", "mvsnerf_v0_weights.npz"))
+                mvs_sd = {k[4:]: torch.from_numpy(zz[k]) for k in zz.files if k.startswith("mvs/")}
+                with torch.no_grad():
+                    torch.set_num_threads(min(32, n_default))
+                    e0 = time.perf_counter()
+                    ovol = O.mvsnet_forward(rig["images"][:, :3], rig["proj_mats"][:, :3], rig["near_fars"][0, 0], mvs_sd, pad=PAD, D=D_PLANES)[0]
+                    cpu["encode_seconds_cpu"] = round(time.perf_counter() - e0, 2)
+                    o2 = O.rendering(cpose, b[0], b[1], b[2], b[4], ovol, csrc, sd)
+                    torch.set_num_threads(n_default)
+                cpu["max_abs_rgb_err_end_to_end"] = float((g[0].cpu() - o2[0]).abs().max())
+                cpu["max_abs_volume_err_end_to_end"] = float((cvol - ovol).abs().max())
+                raw_g = renderer.rendering.last_raw.view(N_RAYS, N_SAMPLES, 4).cpu()
+                cpu["max_abs_sigma_err_end_to_end"] = float((raw_g[..., 3] - o2[6][..., 3]).abs().max())
+                cpu["sigma_abs_max"] = float(o2[6][..., 3].abs().max())
+                del ovol
 
         extras = {}
         if not a.no_extras and world == 1:
             from mvsnerf_amd import train
             # (i) end-to-end frame: encode + 320 batches of 1024 rays (one 512x640 target view), validation_step's loop
-            targs = train.default_args(pad=PAD, batch_size=N_RAYS, N_samples=N_SAMPLES, chunk=N_RAYS)
-            system = train.MVSSystem(targs).to(dev)
-            system.render_kwargs_train["network_fn"].load_state_dict(load_mlp_weights())
-            import numpy as np
-            zz = np.load(os.path.join(ROOT, "tests", "golden", "mvsnerf_v0_weights.npz"))
-            system.MVSNet.load_state_dict({k[4:]: torch.from_numpy(zz[k]) for k in zz.files if k.startswith("mvs/")})
+            system = load_system(dev)
             batch = train.synthetic_batch(H_IMG, W_IMG, seed=1234)
             # sub-batches of 1024 rays = the reference's chunk (and the headline batch): every launch of the MLP kernel in this
             # process then has the same size, so its rocprofv3 average is comparable with roofline.avg_launch_ms
@@ -456,7 +574,7 @@ def main():
                        "parallelism": f"ray-sharded x{world}, no data-path collective",
                        "clock_settle_ms": a.settle_ms},
             "encode_ms": encode_ms,
-            "roofline": roof, "rooflines": roofs, "cpu_baseline": cpu, "extras": extras,
+            "roofline": roof, "rooflines": roofs, "cpu_baseline": cpu, "multi_gpu": multi, "extras": extras,
         }))
     if world > 1:
         dist.destroy_process_group()

@@ -153,4 +153,9 @@ def dev_f32(t, name):
     if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
         raise RuntimeError(f"{name}: expected a contiguous float32 tensor on the GPU, got "
                            f"{type(t).__name__} {getattr(t, 'dtype', None)} {getattr(t, 'device', None)}")
+    if t.device.index != torch.cuda.current_device():
+        # kernels are launched on the CURRENT device's stream (stream_ptr): a tensor living on another GPU would be dereferenced
+        # by the wrong device.  One process per GPU with torch.cuda.set_device(LOCAL_RANK) is the supported layout.
+        raise RuntimeError(f"{name}: tensor is on {t.device} but the current device is cuda:{torch.cuda.current_device()} "
+                           "(call torch.cuda.set_device / use `with torch.cuda.device(...)` around the call)")
     return t.data_ptr()

@@ -13,6 +13,21 @@
 static inline bool mvs_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline unsigned mvs_cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
+// Raising a kernel's dynamic-LDS cap is a per-DEVICE attribute: remember it per device (bit d of *done_mask), so that a process that
+// touches a second GPU sets it there too.  Idempotent; the mask is the only state and it caches nothing but "already raised here".
+static inline int mvs_raise_lds_cap(const void* fn, int bytes, unsigned long long* done_mask)
+{
+    int d = 0;
+    hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess) return (int)e;
+    const unsigned long long bit = 1ull << (d & 63);
+    if (__atomic_load_n(done_mask, __ATOMIC_RELAXED) & bit) return 0;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    __atomic_fetch_or(done_mask, bit, __ATOMIC_RELAXED);
+    return 0;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

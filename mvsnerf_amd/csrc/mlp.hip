@@ -602,13 +602,8 @@ static int launch_mlp_pipe(const float* packed, int F, const float* ndc, int ndc
                            const float* dirs, int dirs_stride, int64_t P, int S, float* raw, hipStream_t st, float* saved = nullptr)
 {
     const size_t lds_bytes = PIPE_LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_pipe_kernel<AO, SAVE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long lds_cap_set = 0;          // per-device bit mask (common.h)
+    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_pipe_kernel<AO, SAVE>), (int)lds_bytes, &lds_cap_set)) return rc_;
     mlp_fwd_pipe_kernel<AO, SAVE><<<mvs_cdiv(P, 128), 256, lds_bytes, st>>>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, saved, g_mlp_census);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
@@ -636,13 +631,8 @@ static int launch_mlp(const float* packed, int F, const float* ndc, int ndc_stri
                       const float* dirs, int dirs_stride, int64_t P, int S, float* raw, hipStream_t st, float* saved = nullptr)
 {
     const size_t lds_bytes = LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;   // raising the dynamic-LDS cap is idempotent; no other state
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<AO, G, WPS, SAVE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long lds_cap_set = 0;          // per-device bit mask (common.h)
+    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_kernel<AO, G, WPS, SAVE>), (int)lds_bytes, &lds_cap_set)) return rc_;
     mlp_fwd_kernel<AO, G, WPS, SAVE><<<mvs_cdiv(P, 128 * G), 256, lds_bytes, st>>>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, saved);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;

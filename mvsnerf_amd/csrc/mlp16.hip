@@ -374,13 +374,9 @@ int mvs_mlp16_fwd(const float* packed16, int F, const float* ndc, int ndc_stride
 {
     using namespace mlp16;
     const size_t lds_bytes = LDS_F * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long cap_a = 0, cap_b = 0;         // per-device bit masks (common.h)
+    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd16_kernel<false>), (int)(lds_bytes), &cap_a)) return rc_;
+    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd16_kernel<true>), (int)(lds_bytes), &cap_b)) return rc_;
     const unsigned grid = mvs_cdiv(P, 16 * WAVES);
     if (alpha_only) mlp_fwd16_kernel<true><<<grid, 64 * WAVES, lds_bytes, st>>>(packed16, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
     else mlp_fwd16_kernel<false><<<grid, 64 * WAVES, lds_bytes, st>>>(packed16, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);

@@ -732,13 +732,9 @@ int launch_split(const __bf16* wq, const float* packed_f32, int F, const float* 
                  const float* dirs, int dirs_stride, int64_t P, int S, int alpha_only, float* raw, hipStream_t st)
 {
     constexpr int LDS = (SCHED == 1 ? IL_NBUF : split_nbuf(NS)) * sp_slab_elems(NS, 4) * 2 + V_TOTAL * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_split_kernel<NS, false, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_split_kernel<NS, true, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long cap_a = 0, cap_b = 0;         // per-device bit masks (common.h)
+    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_split_kernel<NS, false, SCHED>), (int)(LDS), &cap_a)) return rc_;
+    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_split_kernel<NS, true, SCHED>), (int)(LDS), &cap_b)) return rc_;
     if (alpha_only)
         mlp_fwd_split_kernel<NS, true, SCHED><<<mvs_cdiv(P, 128), 256, LDS, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
     else
@@ -778,13 +774,9 @@ extern "C" int mvsnerf_mlp_fwd_bf16(const void* packed_bf16, const float* packed
     const int64_t P = N * S;
     if (P == 0) return MVSNERF_OK;
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long cap_a = 0, cap_b = 0;         // per-device bit masks (common.h)
+    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_bf16_kernel<false>), (int)(B_LDS_BYTES), &cap_a)) return rc_;
+    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_bf16_kernel<true>), (int)(B_LDS_BYTES), &cap_b)) return rc_;
     const __bf16* wq = reinterpret_cast<const __bf16*>(packed_bf16);
     if (alpha_only)
         mlp_fwd_bf16_kernel<true><<<mvs_cdiv(P, 128), 256, B_LDS_BYTES, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);

@@ -333,12 +333,8 @@ extern "C" int mvsnerf_mlp_bwd(const float* packed_fwd, const float* packed_bwd,
     const unsigned nwg = mvs_cdiv(P, 128);
     const int64_t n_tiles = (int64_t)nwg * 4;
     const size_t lds_bytes = LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long lds_cap_set = 0;          // per-device bit mask (common.h)
+    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_dgrad_kernel), (int)lds_bytes, &lds_cap_set)) return rc_;
     mlp_dgrad_kernel<<<nwg, 256, lds_bytes, st>>>(packed_fwd, F, packed_bwd, raw, d_raw, saved, P, gslots, d_feat8);
     MVS_LAUNCH_CHECK();
 

@@ -6,9 +6,14 @@ methods, same batch dict schema (data/dtu.py:199-211 collated with B=1), same `s
 A real `pytorch_lightning.LightningModule` can be mixed in unchanged; `_ModuleShim` provides the three attributes
 the step uses (`log`, `global_step`, `device`) when Lightning is absent.
 
-Multi-GPU: ray-sharded data parallelism - every rank encodes the same scene and draws the same
-pixel ids (same CPU-RNG state), renders its slice of the rays, and the gradients are averaged by ONE flat-buffer
-all-reduce (mvsnerf_amd.distributed.FlatGradAllReduce; RCCL over xGMI on GPUs).
+Multi-GPU (one process per GPU, gradients averaged by ONE flat-buffer all-reduce -
+mvsnerf_amd.distributed.FlatGradAllReduce, RCCL over xGMI on GPUs), two modes selected by `args.dp_mode`:
+  "ray"   every rank encodes the SAME scene sample and draws the same pixel ids / jitter (a per-step seed broadcast from rank 0),
+          renders its slice of the rays and back-propagates through its slice AND the replicated encoder: the step equals the
+          1-GPU step on the same batch, but the ~14 of 17 ms spent in the encoder are not divided (speed-up <= ~1.2x at 8 GPUs);
+  "scene" each rank takes a DIFFERENT (scan, ref view) sample and its own 1024 rays - what Lightning DDP + DistributedSampler
+          would give the reference (train_mvs_nerf_pl.py:306,313): the effective batch is `world` scenes per step and the
+          whole step is divided (speed-up ~world x; BN batch statistics are per rank, as under DDP without SyncBN).
 """
 import os
 
@@ -116,12 +121,10 @@ class MVSSystem(_ModuleShim):
         N_rays, N_samples = args.batch_size, args.N_samples
         rays_pts, rays_dir, target_s, rays_NDC, depth_candidates, rays_o, rays_depth, _ = build_rays(
             imgs, depths_h, pose_ref, pose_ref["w2cs"], pose_ref["c2ws"], pose_ref["intrinsics"], near_fars, N_rays, N_samples, pad=args.pad)  # :119
-        world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
-        if world > 1:                                                    # ray-sharded DP: same draw on all ranks, local slice
-            sl = D.shard_rays(N_rays, world, torch.distributed.get_rank())
-            rays_pts, rays_dir, target_s, rays_NDC, depth_candidates = (t[sl] for t in (rays_pts, rays_dir, target_s, rays_NDC, depth_candidates))
-            rays_o = rays_o[:, sl]
-            rays_depth = None if rays_depth is None else rays_depth[sl]
+        loss_scale = 1.0
+        if self.dp_mode() == "ray":                                      # same draw on all ranks (seeded in fit_steps), local slice
+            (rays_pts, rays_dir, target_s, rays_NDC, depth_candidates, rays_depth, rays_o), loss_scale = D.shard_ray_batch(
+                (rays_pts, rays_dir, target_s, rays_NDC, depth_candidates, rays_depth, rays_o), N_rays)     # rays_o is (3, N): sliced in dim 1
         rgb, disp, acc, depth_pred, alpha, ret = rendering(args, pose_ref, rays_pts, rays_NDC, depth_candidates, rays_o, rays_dir,
                                                            volume_feature, imgs[:, :-1], img_feat=None, **self.render_kwargs_train)   # :123
         loss = 0
@@ -136,9 +139,10 @@ class MVSSystem(_ModuleShim):
             self.log("train/loss", loss, prog_bar=True)
             self.log("train/img_mse_loss", img_loss)
             self.log("train/PSNR", mse2psnr2(float(img_loss.detach())), prog_bar=True)
-        if self.global_step % 20000 == 19999:
+        if self.global_step % 20000 == 19999 and D.world_rank()[1] == 0:  # one writer (ranks hold identical weights after the all-reduce)
             self.save_ckpt(f"{self.global_step}")
-        return {"loss": loss}
+        # ray mode with N_rays % world != 0: weight the local mean so that the rank-averaged gradient is that of the global mean
+        return {"loss": loss if loss_scale == 1.0 else loss * loss_scale}
 
     @torch.no_grad()
     def render_view(self, batch, chunk=None, whole_frame_off=False, target=None, batch_rays=4096):
@@ -212,14 +216,32 @@ class MVSSystem(_ModuleShim):
         return path
 
     # -- minimal trainer -----------------------------------------------------------------------
+    def dp_mode(self):
+        """"ray" | "scene" (module docstring); anything else is rejected loudly."""
+        mode = getattr(self.args, "dp_mode", "ray")
+        if mode not in ("ray", "scene"):
+            raise ValueError(f"args.dp_mode must be 'ray' or 'scene', got {mode!r}")
+        return mode
+
     def fit_steps(self, batches, optimizer=None):
-        """Lightning-free loop: training_step -> backward -> (flat-buffer all-reduce) -> Adam step."""
+        """Lightning-free loop: training_step -> backward -> (flat-buffer all-reduce) -> Adam step.
+        dp_mode "ray": `batches` is the same list on every rank; "scene": the list is sharded round-robin over the ranks
+        (distributed.scene_shard) and every rank seeds its own pixel-id / jitter streams."""
         if optimizer is None:
             optimizer = self.configure_optimizers()[0][0]
         if self._allreduce is None:
             self._allreduce = D.FlatGradAllReduce(self.grad_vars)
+        world, rank = D.world_rank()
+        mode = self.dp_mode()
+        if world > 1 and mode == "scene":
+            batches = D.scene_shard(list(batches))
+            if not getattr(self, "_scene_seeded", False):
+                torch.manual_seed(torch.initial_seed() + 7919 * rank)      # independent draws per rank from here on
+                self._scene_seeded = True
         losses = []
         for i, batch in enumerate(batches):
+            if world > 1 and mode == "ray":
+                torch.manual_seed(D.common_seed(self.device))                # same pixel ids (CPU RNG) and jitter (device RNG) everywhere
             optimizer.zero_grad(set_to_none=True)
             out = self.training_step(batch, i)
             out["loss"].backward()
@@ -244,7 +266,7 @@ def default_args(**over):
     d = dict(expname="exp", pad=24, batch_size=1024, num_epochs=8, pts_dim=3, dir_dim=3, net_type="v0", netdepth=6, netwidth=128,
              lrate=5e-4, chunk=1024, netchunk=1024, ckpt=None, N_samples=128, N_importance=0, perturb=1.0, use_viewdirs=True,
              i_embed=0, multires=10, multires_views=4, raw_noise_std=0.0, white_bkgd=False, img_downscale=1.0,
-             use_color_volume=False, with_depth=False, with_depth_loss=False, feat_dim=20)
+             use_color_volume=False, with_depth=False, with_depth_loss=False, feat_dim=20, dp_mode="ray")
     d.update(over)
     return types.SimpleNamespace(**d)
 
@@ -318,9 +340,20 @@ class MVSSystemFinetune(_ModuleShim):
         dev = next(self.MVSNet.parameters()).device
         self.near_far_source = near_far.to(dev)
         self.pose_source = {k: v.to(dev) for k, v in pose.items()}
-        self.MVSNet.train()                                               # :62
-        with torch.no_grad():                                             # init_volume :57-89
-            vol, _, _ = self.MVSNet(imgs.to(dev), proj_mats.to(dev), self.near_far_source, pad=args.pad, lindisp=getattr(args, "use_disp", False))
+        # init_volume :57-66: a checkpoint written by save_ckpt of THIS class carries the optimised volume - resume from it
+        # instead of re-encoding (the reference does the same); otherwise encode the scene once
+        vol = None
+        ck_path = getattr(args, "ckpt", None)
+        if ck_path and ck_path != "None" and os.path.exists(ck_path):
+            ckpts = torch.load(ck_path, map_location="cpu", weights_only=False)
+            if "volume" in ckpts:
+                vol = ckpts["volume"]["feat_volume"].to(dev, torch.float32)
+                self.volume_from_ckpt = True
+        if vol is None:
+            self.volume_from_ckpt = False
+            self.MVSNet.train()                                           # :62
+            with torch.no_grad():
+                vol, _, _ = self.MVSNet(imgs.to(dev), proj_mats.to(dev), self.near_far_source, pad=args.pad, lindisp=getattr(args, "use_disp", False))
         self.imgs = MVSSystem.unpreprocess(imgs.to(dev))
         # importance sampling from a density volume (:73-86): voxel positions + per-voxel colour features, once per scene
         self.density_volume = None
@@ -381,6 +414,7 @@ class MVSSystemFinetune(_ModuleShim):
         return path
 
     fit_steps = MVSSystem.fit_steps
+    dp_mode = MVSSystem.dp_mode
 
     def configure_optimizers(self):
         self.optimizer = torch.optim.Adam(self.grad_vars, lr=self.args.lrate, betas=(0.9, 0.999))

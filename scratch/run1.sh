@@ -1,2 +1,4 @@
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_gpu_headline_parity.py -q -s 2>&1 | tail -40 > gpurun_out/headline1.log
+timeout 900 python -m pytest tests/test_gpu_nccl.py -q -x 2>&1 | tail -25 > gpurun_out/nccl1.log
+timeout 900 python bench.py --multi-gpu-legs > gpurun_out/bench_r2_1.json 2> gpurun_out/bench_r2_1.err
+tail -5 gpurun_out/bench_r2_1.err

@@ -90,3 +90,94 @@ def test_single_process_paths():
     assert rgb2.shape == (30, 3) and depth2.shape == (30,)
     t = torch.ones(4, 2)
     assert D.all_gather_rows(t, 4) is t
+
+
+# ------------------------------------------------------------------ data-parallel training modes (train.MVSSystem.fit_steps)
+class _ToySystem:
+    """A stand-in with the attributes MVSSystem.fit_steps uses; the 'renderer' is a Linear so the step runs on CPU.
+    The sharding / seeding / all-reduce code under test is the real one (mvsnerf_amd.train, mvsnerf_amd.distributed)."""
+
+    def __new__(cls, mode):
+        import types
+        from mvsnerf_amd import train as T
+
+        class Toy(T._ModuleShim):
+            fit_steps = T.MVSSystem.fit_steps
+            dp_mode = T.MVSSystem.dp_mode
+
+            def __init__(self):
+                super().__init__()
+                torch.manual_seed(5)
+                self.lin = torch.nn.Linear(3, 2)
+                self.args = types.SimpleNamespace(dp_mode=mode)
+                self.grad_vars = list(self.lin.parameters())
+                self._allreduce = None
+                self.draws = []
+
+            def training_step(self, batch, nb):
+                x, y = batch["x"], batch["y"]                                  # (N,3), (N,2): N "rays"
+                n = x.shape[0]
+                self.draws.append(torch.rand(4))                               # stands for pixel ids / jitter
+                scale = 1.0
+                if self.dp_mode() == "ray":
+                    (x, y), scale = D.shard_ray_batch((x, y), n)
+                return {"loss": ((self.lin(x) - y) ** 2).mean() * scale}
+        return Toy()
+
+
+def _toy_batches(k):
+    g = torch.Generator().manual_seed(11)
+    return [{"x": torch.randn(7, 3, generator=g), "y": torch.randn(7, 2, generator=g)} for _ in range(k)]
+
+
+def _dp_worker(rank, world, port, mode, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    D.init_from_env(device="cpu")
+    torch.manual_seed(100 + rank)                  # deliberately DIFFERENT RNG states: ray mode must still draw alike
+    sys_ = _ToySystem(mode)
+    opt = torch.optim.SGD(sys_.grad_vars, lr=1.0)
+    w0 = sys_.lin.weight.detach().clone()
+    sys_.fit_steps(_toy_batches(2), opt)
+    q.put((rank, (sys_.lin.weight.detach() - w0).tolist(), sys_.lin.bias.detach().tolist(), torch.stack(sys_.draws).tolist()))   # plain lists: no fd passing
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["ray", "scene"])
+def test_dp_modes_world2(mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (_, dw0, b0, draws0), (_, dw1, b1, draws1) = [(r, *(torch.tensor(t) for t in rest)) for r, *rest in res]
+    assert torch.equal(dw0, dw1) and torch.equal(b0, b1)            # ranks stay in lock step
+    batches = _toy_batches(2)
+    if mode == "ray":
+        # 7 rays over 2 ranks (4 + 3): the all-reduced step must equal the single-process step on the full batches
+        assert torch.equal(draws0, draws1)                           # same "pixel ids" on both ranks (broadcast seed)
+        ref = _ToySystem("ray")
+        opt = torch.optim.SGD(ref.grad_vars, lr=1.0)
+        w0 = ref.lin.weight.detach().clone()
+        ref.fit_steps(batches, opt)
+        assert torch.allclose(ref.lin.weight.detach() - w0, dw0, atol=1e-6)
+        assert torch.allclose(ref.lin.bias.detach(), b0, atol=1e-6)
+    else:
+        # one step, two scenes: the N-rank step is the average of the two single-rank steps (SGD lr 1: delta = -mean grad)
+        assert not torch.equal(draws0, draws1)                       # independent draws per rank
+        deltas = []
+        for r in range(2):
+            ref = _ToySystem("scene")
+            w0 = ref.lin.weight.detach().clone()
+            ref.fit_steps([batches[r]], torch.optim.SGD(ref.grad_vars, lr=1.0))
+            deltas.append(ref.lin.weight.detach() - w0)
+        assert torch.allclose(0.5 * (deltas[0] + deltas[1]), dw0, atol=1e-6)
+
+
+def test_scene_shard_and_loss_scale_single_process():
+    assert D.scene_shard([1, 2, 3]) == [1, 2, 3]
+    (a,), scale = D.shard_ray_batch((torch.arange(5),), 5)
+    assert scale == 1.0 and a.numel() == 5
