@@ -72,6 +72,14 @@ int mvsnerf_planesweep_costvar_fwd(const float* feats_cl, const float* imgs_cl, 
                                    int V, int C, int H, int W, int D, int pad, float* cost, int CP, float* masks,
                                    int with_img, void* stream);
 
+/* The same sweep writing the cost volume in channel blocks of 8: cost_blocked[(CP+7)/8][D*Hp*Wp][8] (block b holds channels
+ * 8b..8b+7 of every voxel; the unused tail of the last block is not written).  This is the layout the matrix-core conv0
+ * (mvsnerf_conv3d_c8_blocked_fwd) stages from: it multiplies eight input channels at a time, and with the channel-last
+ * layout every such pass touches all of a voxel's 176-byte row again (measured: 5.4x the algorithmic HBM reads). */
+int mvsnerf_planesweep_costvar_blocked_fwd(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,
+                                           int V, int C, int H, int W, int D, int pad, float* cost_blocked, int CP, float* masks,
+                                           int with_img, void* stream);
+
 /* Stand-alone homo_warp (utils.py:580-630) for one source view: src[C][H][W] (NCHW), proj[3][4], depth[D]
  * -> warped[C][D][Hp][Wp], grid_out[D*Hp*Wp][2] (either may reuse a given grid_in, as models.py:872 does). */
 int mvsnerf_homo_warp_fwd(const float* src_nchw, const float* proj, const float* depth, const float* grid_in,
@@ -94,6 +102,9 @@ int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const float* shift1
                        const float* x2, const float* scale2, const float* shift2,
                        int Cin, int cin_ld, int D, int H, int W, const float* wpacked, int Cout, int stride,
                        float* out, void* stream);
+/* conv0 of CostRegNet (models.py:756; k3, stride 1, Cout = 8, raw input) on v_mfma_f32_4x4x1_16B_f32, input in channel
+ * blocks of 8 (see mvsnerf_planesweep_costvar_blocked_fwd), Cin = 4*ceil((32+3V)/4); weights as for conv3d_fwd. */
+int mvsnerf_conv3d_c8_blocked_fwd(const float* x_blocked, int Cin, int D, int H, int W, const float* wpacked, float* out, void* stream);
 int mvsnerf_conv_transpose3d_fwd(const float* x1, const float* scale1, const float* shift1,
                                  const float* x2, const float* scale2, const float* shift2,
                                  int Cin, int D, int H, int W, const float* wpacked, int Cout, float* out, void* stream);

@@ -58,6 +58,8 @@ SIGNATURES = {
     "mvsnerf_nchw_to_nhwc": (_c_i, [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp]),
     "mvsnerf_resize_bilinear": (_c_i, [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp]),
     "mvsnerf_planesweep_costvar_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp]),
+    "mvsnerf_planesweep_costvar_blocked_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp]),
+    "mvsnerf_conv3d_c8_blocked_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_homo_warp_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_conv3d_pack_weights": (_c_i, [_c_fp] + [_c_i] * 7 + [_c_fp, _c_fp]),
     "mvsnerf_conv3d_fwd": (_c_i, [_c_fp] * 6 + [_c_i] * 5 + [_c_fp, _c_i, _c_i, _c_fp, _c_fp]),

@@ -1,0 +1,276 @@
+// 3x3x3 stride-1 convolution with 8 output channels on the matrix cores (conv0 of CostRegNet, models.py:756: 74.5 % of the
+// encoder's FLOPs; fp32 in, fp32 accumulate, exact fp32 products).
+//
+// Why v_mfma_f32_4x4x1_16B_f32.  With Cout = 8 the 32- and 16-wide MFMA shapes leave 75 % / 50 % of their columns empty.  The
+// 16-block 4x4x1 form multiplies, per block, 4 rows x 1 k x 4 columns; 16 blocks = 8 groups of four voxels x 2 groups of four
+// output channels, i.e. 32 voxels x 8 channels per instruction with no padding, at the same 64 FLOP/clk/SIMD as every other
+// fp32 MFMA (scratch/r2/mfma4x4.hip: 125-137 TFLOP/s sustained, with or without one ds_read_b128 per four MFMAs).  Against the
+// VALU kernel it replaces (one v_pk_fma per 2 MACs, weights through the scalar cache, 62 % of the wave cycles in s_waitcnt) the
+// matrix instruction retires 256 MACs per issue slot, so the instruction stream stops being the bound.
+//
+// Mapping.  A workgroup owns 4 x 16 x 16 output voxels (z, y, x); wave w owns plane z0+w: eight M-tiles, M-tile t = rows (t, t+8) x 16 x.
+//   lane l: block = l>>2 (mb = block>>1: voxel quad, nb = block&1: channel quad), i = l&3
+//   A operand (k = one input channel of one tap): lane holds the input of voxel m = 4 mb + i      (both nb copies: LDS broadcast)
+//   B operand: lane holds w[tap][ci][4 nb + i]
+//   D: register r of lane l = output (voxel 4 mb + r, channel 4 nb + i)
+// The (6 x 18 x 18)-voxel input halo is staged through LDS eight channels at a time, channel-last ([voxel][8], 32 B per voxel)
+// with the two 16-byte halves of a voxel swapped on every other group of eight voxels: a ds_read_b128 of 16 consecutive voxels
+// then touches every bank once (un-swizzled, voxels v and v+8 would collide: 2-way conflict on every operand read).
+// One ds_read_b128 feeds four MFMAs (k = 4 channels); per (tap, 4 channels): 8 A reads + 4 B loads (global, L1-resident: the
+// packed weights are 38 KB and every wave walks them in the same order) + 32 MFMAs.  Two workgroups per CU (62 KB LDS each):
+// one stages its next channel chunk while the other one computes.
+#include "common.h"
+#include "act.h"
+
+#ifdef MVS_CONV_DBG
+__device__ int g_dbg;            // scratch/r2/conv_bench.hip only: bit 0 = no staging, bit 1 = no operand reads, bit 2 = no weight loads
+#define MVS_DBG(bit) (g_dbg & (bit))
+#else
+#define MVS_DBG(bit) false
+#endif
+
+namespace {
+
+constexpr int TX = 16, TY = 16, TZ = 4;             // output tile
+constexpr int PX = TX + 2, PY = TY + 2, PZ = TZ + 2; // staged input tile
+constexpr int NVOX = PZ * PY * PX;                   // 1944
+constexpr int CK = 8;                                // channels per staged chunk (LDS row = 32 B)
+
+// float offset of (voxel v at x position vx, 16-byte half c4) in the staged tile: the halves are swapped for vx in [8, 16)
+__device__ __forceinline__ int swz_off(int v, int vx, int c4) { return v * CK + ((c4 ^ ((vx >> 3) & 1)) << 2); }
+
+constexpr int NSLOT = (NVOX + 127) / 128;            // staging slots per thread: thread t owns half (t&1) of voxels (t>>1) + 128 j
+
+// Staging is split in two so that the global loads of chunk c+1 are in flight while chunk c is multiplied:
+//   stage_load   16 independent 16-byte loads per thread into registers (addresses precomputed once per workgroup)
+//   stage_store  (pending InPlaceABN of the producer, if any, applied here) -> ds_write_b128
+template <int CIN, int C0, int CKC, bool BLOCKED>
+__device__ __forceinline__ void stage_load(const float* __restrict__ x, int64_t block_stride, const int (&goff)[NSLOT], int c4t, f32x4 (&st)[NSLOT])
+{
+    if (CKC == 4 && c4t) return;                       // a 4-channel chunk has no second half
+    // channel-last: channel C0 + 4 c4t of voxel row goff; blocked: channel block C0/8 is its own [voxel][8] array
+    const float* base = BLOCKED ? x + (int64_t)(C0 / 8) * block_stride + c4t * 4 : x + C0 + c4t * 4;
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+        st[j] = f32x4{0, 0, 0, 0};
+        if (goff[j] >= 0) st[j] = *reinterpret_cast<const f32x4*>(base + (int64_t)goff[j]);
+    }
+}
+
+template <int C0, int CKC>
+__device__ __forceinline__ void stage_store(const ActSrc& a, float* __restrict__ tile, const int (&goff)[NSLOT], unsigned swz_bits,
+                                            int tid, f32x4 (&st)[NSLOT])
+{
+    const int c4t = tid & 1;
+    if (CKC == 4 && c4t) return;
+    f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
+    if (a.scale) { sc = *reinterpret_cast<const f32x4*>(a.scale + C0 + c4t * 4); sh = *reinterpret_cast<const f32x4*>(a.shift + C0 + c4t * 4); }
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+        const int v = (tid >> 1) + 128 * j;
+        if (v >= NVOX) continue;
+        f32x4 val = st[j];
+        if (a.scale && goff[j] >= 0) {                  // zero padding is the padding of the ACTIVATED tensor
+#pragma unroll
+            for (int k = 0; k < 4; ++k) val[k] = act_apply(val[k], sc[k], sh[k]);
+        }
+        *reinterpret_cast<f32x4*>(tile + v * CK + ((c4t ^ (int)((swz_bits >> j) & 1u)) << 2)) = val;
+    }
+}
+
+// The chunk's weights ride along: w[tap][C0 + ci][co] (global, the layout of mvsnerf_conv3d_pack_weights) -> LDS wt[tap][co][8 ci], so
+// that a lane's four k-values are one ds_read_b128.  (Loading them from global inside the multiply loop cost 0.19 of 1.12 ms:
+// the loop runs one group of 32 MFMAs = 256-512 cycles ahead of its operands, which covers an LDS round trip but not a vector-memory one.)
+constexpr int WT_FLOATS = 27 * 8 * CK;               // 1728
+constexpr int WSLOT = (27 * 8 * 2 + 255) / 256;      // 16-byte pieces (tap, co, half) per thread: 2
+
+template <int CIN, int C0, int CKC>
+__device__ __forceinline__ void wstage_load(const float* __restrict__ wp, int tid, f32x4 (&wr)[WSLOT])
+{
+#pragma unroll
+    for (int j = 0; j < WSLOT; ++j) {
+        const int idx = tid + 256 * j;
+        const int tap = idx >> 4, co = (idx >> 1) & 7, c4 = idx & 1;
+        wr[j] = f32x4{0, 0, 0, 0};
+        if (idx < 27 * 16 && c4 * 4 < CKC) {
+            const float* g = wp + ((int64_t)tap * CIN + C0 + c4 * 4) * 8 + co;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wr[j][k] = g[k * 8];
+        }
+    }
+}
+
+__device__ __forceinline__ void wstage_store(float* __restrict__ wt, int tid, const f32x4 (&wr)[WSLOT])
+{
+#pragma unroll
+    for (int j = 0; j < WSLOT; ++j) {
+        const int idx = tid + 256 * j;
+        if (idx < 27 * 16) *reinterpret_cast<f32x4*>(wt + idx * 4) = wr[j];      // idx = (tap*8 + co)*2 + half
+    }
+}
+
+template <int CIN, int C0, int CKC>
+__device__ __forceinline__ void mfma_chunk(const float* __restrict__ wtile, const float* __restrict__ tile, int wave, int lane, f32x4 (&acc)[8])
+{
+    constexpr int K4 = CKC / 4;
+    const int blk = lane >> 2, i = lane & 3, mb = blk >> 1, nb = blk & 1;
+    const int m = mb * 4 + i;                          // A row of this lane: M-tile t = output rows (t, t+8): row t + 8 (m>>4), x = m&15
+    const int xx = m & 15;
+    // per-lane part of the operand address for each (dx, c4); the tile row j and the tap plane dz are wave-uniform offsets
+    const float* alane[3][K4];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int c4 = 0; c4 < K4; ++c4)
+            alane[dx][c4] = tile + swz_off((wave * PY + (m >> 4) * 8) * PX + xx + dx, xx + dx, c4);
+    const float* wl = wtile + (nb * 4 + i) * CK;           // staged weights [tap][co][8 ci]
+    // One group = (dz, dx, c4): the ten row pairs P_j = (row j | row j+8), j = 0..9, of plane z+dz at x+dx serve all three dy taps
+    // of all eight M-tiles (M-tile t at tap dy reads P_{t+dy}): 10 operand reads + 3 weight reads per 96 MFMAs.  (With M-tiles of
+    // two ADJACENT rows every tap needed its own eight reads: 24 per 96 MFMAs, and the LDS pipe ran at > 50 %.)
+    // The MFMAs of a group run in j order; as soon as P_j has been used, its registers are refilled with P_j of the NEXT group, which
+    // is needed ~700 cycles later: one register set, no LDS round trip on the critical path.  The scheduling fences pin that order.
+    f32x4 av[10], bw[2][3];
+    auto fetch_b = [&](int dz, int dx, int c4, f32x4 (&bd)[3]) {
+        if (MVS_DBG(4)) return;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) bd[dy] = *reinterpret_cast<const f32x4*>(wl + ((dz * 3 + dy) * 3 + dx) * 8 * CK + c4 * 4);
+    };
+    auto fetch_a = [&](int dz, int dx, int c4, int j) {
+        if (MVS_DBG(2)) return;
+        av[j] = *reinterpret_cast<const f32x4*>(alane[dx][c4] + (dz * PY + j) * PX * CK);
+    };
+    // group (dz, dx, c4) with its operands in av / bd; (ndz, ndx, nc4) = the group to refill for (has_next)
+    auto group = [&](f32x4 (&bd)[3], bool has_next, int ndz, int ndx, int nc4) {
+        // rows j and j+5 together: P_j feeds M-tiles j, j-1, j-2 and P_{j+5} feeds j+5, j+4, j+3 - six different accumulators, so that
+        // consecutive MFMAs never wait for each other's result (three accumulators in turn ran the loop 12 % slower)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int jj = j + 5 * h, t = jj - dy;
+                        if (t >= 0 && t < 8) acc[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[jj][k], bd[dy][k], acc[t], 0, 0, 0);
+                    }
+            if (has_next) { fetch_a(ndz, ndx, nc4, j); fetch_a(ndz, ndx, nc4, j + 5); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    constexpr int NG = 3 * K4;                         // groups per plane dz
+    fetch_b(0, 0, 0, bw[0]);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) fetch_a(0, 0, 0, j);
+    if constexpr ((NG & 1) == 0) {                     // weight-register parity is static per plane: roll the dz loop
+#pragma unroll 1
+        for (int dz = 0; dz < 3; ++dz) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const bool last = g + 1 == NG;
+                const int ndz = last ? dz + 1 : dz, ndx = last ? 0 : (g + 1) / K4, nc4 = last ? 0 : (g + 1) % K4;
+                const bool has_next = !last || dz < 2;
+                if (has_next) fetch_b(ndz, ndx, nc4, bw[(g + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                group(bw[g & 1], has_next, ndz, ndx, nc4);
+            }
+        }
+    } else {                                           // 4-channel tail chunk: nine groups, straight line
+#pragma unroll
+        for (int g = 0; g < 3 * NG; ++g) {
+            const bool has_next = g + 1 < 3 * NG;
+            const int n = g + 1, ndz = n / NG, ndx = (n % NG) / K4, nc4 = n % K4;
+            if (has_next) fetch_b(ndz, ndx, nc4, bw[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            group(bw[g & 1], has_next, ndz, ndx, nc4);
+        }
+    }
+}
+
+template <int CIN, bool BLOCKED>
+__global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_mfma_kernel(ActSrc a, int ld, int D, int H, int W,
+                                                                    const float* __restrict__ wp, float* __restrict__ out, int swz)
+{
+    static_assert(CIN % 4 == 0 && CIN <= 64, "channel chunks of 8 (+ one of 4)");
+    __shared__ __attribute__((aligned(16))) float tile[NVOX * CK];
+    __shared__ __attribute__((aligned(16))) float wtile[WT_FLOATS];
+    const int nbx = (W + TX - 1) / TX, nby = (H + TY - 1) / TY;
+    const int tile_id = swz ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int bx = tile_id % nbx, by = (tile_id / nbx) % nby, bz = tile_id / (nbx * nby);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0 = bx * TX - 1, y0 = by * TY - 1, z0 = bz * TZ - 1;
+    // staging slots of this thread (the same for every channel chunk): element offset in the input (-1: outside the volume -> 0)
+    // and float offset in the LDS tile (-1: no such voxel)
+    const int c4t = tid & 1;
+    int goff[NSLOT];
+    unsigned swz_bits = 0;                            // bit j: the 16-byte halves of voxel slot j are swapped (vx in [8, 16))
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+        const int v = (tid >> 1) + 128 * j;
+        const int vx = v % PX, vy = (v / PX) % PY, vz = v / (PX * PY);
+        const int gx = x0 + vx, gy = y0 + vy, gz = z0 + vz;
+        const bool in = v < NVOX && gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
+        goff[j] = in ? (((gz * H + gy) * W + gx) * (BLOCKED ? 8 : ld)) : -1;
+        swz_bits |= (unsigned)((vx >> 3) & 1) << j;
+    }
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0, 0, 0, 0};
+    f32x4 st[NSLOT];
+    constexpr int NCH = (CIN + 7) / 8;
+    const int64_t block_stride = (int64_t)D * H * W * 8;
+    f32x4 wr[WSLOT];
+    stage_load<CIN, 0, (CIN >= 8 ? 8 : 4), BLOCKED>(a.x, block_stride, goff, c4t, st);
+    wstage_load<CIN, 0, (CIN >= 8 ? 8 : 4)>(wp, tid, wr);
+#define MVS_CH(IDX)                                                                                                   \
+    if constexpr ((IDX) < NCH) {                                                                                      \
+        constexpr int C0_ = (IDX) * 8, CKC_ = (CIN - C0_ >= 8) ? 8 : 4;                                             \
+        if (!MVS_DBG(1)) {                                                                                            \
+        __syncthreads();                                   /* everybody finished reading the previous chunk */        \
+        stage_store<C0_, CKC_>(a, tile, goff, swz_bits, tid, st);                                                         \
+        wstage_store(wtile, tid, wr);                                                                                 \
+        __syncthreads();                                                                                              \
+        if constexpr ((IDX) + 1 < NCH) {                                                                              \
+            stage_load<CIN, C0_ + 8, (CIN - C0_ - 8 >= 8) ? 8 : 4, BLOCKED>(a.x, block_stride, goff, c4t, st);       \
+            wstage_load<CIN, C0_ + 8, (CIN - C0_ - 8 >= 8) ? 8 : 4>(wp, tid, wr);                                    \
+        }                                                                                                             \
+        }                                                                                                             \
+        mfma_chunk<CIN, C0_, CKC_>(wtile, tile, wave, lane, acc);                                                        \
+    }
+    MVS_CH(0) MVS_CH(1) MVS_CH(2) MVS_CH(3) MVS_CH(4) MVS_CH(5) MVS_CH(6) MVS_CH(7)
+#undef MVS_CH
+    // D: register r = voxel 4 mb + r of the M-tile, this lane's channel 4 nb + i
+    const int blk = lane >> 2, i = lane & 3, mb = blk >> 1, nb = blk & 1;
+    const int oz = bz * TZ + wave;
+    if (oz >= D) return;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mb * 4 + r;
+            const int ox = bx * TX + (m & 15), oy = by * TY + t + 8 * (m >> 4);
+            if (ox < W && oy < H) out[(((int64_t)oz * H + oy) * W + ox) * 8 + nb * 4 + i] = acc[t][r];
+        }
+}
+
+}  // namespace
+
+// Called by mvsnerf_conv3d_fwd (encoder.hip) for stride-1 layers with 8 output channels.  Returns MVSNERF_EUNSUPPORTED for a
+// channel count it is not instantiated for (the caller then takes the VALU kernel).
+int mvs_conv3d_c8_mfma(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int D, int H, int W, const float* wpacked, float* out,
+                       int xcd, hipStream_t st)
+{
+    if (b.x) return MVSNERF_EUNSUPPORTED;                         // one lazily-activated source only (conv0's input is the raw cost volume)
+    const bool blocked = cin_ld == -8;                            // input in channel blocks of 8: x[(Cin+7)/8][D*H*W][8]
+    if ((int64_t)D * H * W * (blocked ? 8 : cin_ld) >= (int64_t)1 << 31) return MVSNERF_EUNSUPPORTED;      // 32-bit element offsets in the staging slots
+    const unsigned grid = (unsigned)(((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ));
+#define MVS_L(CIN) case CIN: if (blocked) conv3d_k3s1_c8_mfma_kernel<CIN, true><<<grid, 256, 0, st>>>(a, cin_ld, D, H, W, wpacked, out, xcd); \
+                             else conv3d_k3s1_c8_mfma_kernel<CIN, false><<<grid, 256, 0, st>>>(a, cin_ld, D, H, W, wpacked, out, xcd); break
+    switch (Cin) {
+        MVS_L(32); MVS_L(36); MVS_L(40); MVS_L(44); MVS_L(48); MVS_L(52); MVS_L(56);
+        default: return MVSNERF_EUNSUPPORTED;
+    }
+#undef MVS_L
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}

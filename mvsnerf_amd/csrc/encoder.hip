@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
     int V, int H, int W, int D, int pad,
     float* __restrict__ cost, int CP,   // [D][Hp][Wp][CP]
     float* __restrict__ masks,          // with img: [V][D][Hp][Wp] per-view; else [D][Hp][Wp] count
-    int with_img)
+    int with_img, int blocked)          // blocked: cost[(CP+7)/8][D*Hp*Wp][8] (channel blocks of 8, see mvsnerf_planesweep_costvar_blocked_fwd)
 {
     static_assert(C == 32, "lane q owns float4 numbers q and q + 4 of a 32-channel pixel");
     constexpr int VPB = 256, VPP = 64;                           // voxels per block / per pass
@@ -208,19 +208,49 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
             const int64_t p0 = v0 + pass * VPP;
             const int64_t nv = nvox - p0 < VPP ? (nvox - p0 > 0 ? nvox - p0 : 0) : VPP;
             const int n4 = (int)(nv * CP / 4);
-            f32x4* dst = reinterpret_cast<f32x4*>(cost + p0 * CP);
-            for (int k = threadIdx.x; k < n4; k += 256) {
-                const int vox = (k * 4) / CP, c = (k * 4) - vox * CP;
-                dst[k] = *reinterpret_cast<const f32x4*>(stage + vox * (CP + 4) + c);
+            if (!blocked) {
+                f32x4* dst = reinterpret_cast<f32x4*>(cost + p0 * CP);
+                for (int k = threadIdx.x; k < n4; k += 256) {
+                    const int vox = (k * 4) / CP, c = (k * 4) - vox * CP;
+                    dst[k] = *reinterpret_cast<const f32x4*>(stage + vox * (CP + 4) + c);
+                }
+            } else {
+                // channel block cb of these nv voxels is one contiguous run of nv*32 bytes: k -> (cb, voxel, half), half fastest,
+                // so that a wave's 16-byte stores are consecutive (a 4-channel tail block keeps only its first half)
+                const int nfull = CP >> 3, n_k = (int)nv * 2 * (nfull + ((CP & 4) ? 1 : 0));
+                for (int k = threadIdx.x; k < n_k; k += 256) {
+                    const int cb = k / ((int)nv * 2), r = k - cb * (int)nv * 2, vox = r >> 1, half = r & 1;
+                    if (cb < nfull || half == 0)
+                        *reinterpret_cast<f32x4*>(cost + (((int64_t)cb * nvox + p0 + vox) << 3) + (half << 2)) =
+                            *reinterpret_cast<const f32x4*>(stage + vox * (CP + 4) + cb * 8 + half * 4);
+                }
             }
         }
         __syncthreads();                                         // the staging rows are rewritten by the next pass
     }
 }
 
+static int planesweep_launch(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,
+                             int V, int C, int H, int W, int D, int pad, float* cost, int CP, float* masks,
+                             int with_img, int blocked, void* stream);
+
 extern "C" int mvsnerf_planesweep_costvar_fwd(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,
                                               int V, int C, int H, int W, int D, int pad, float* cost, int CP, float* masks,
                                               int with_img, void* stream)
+{
+    return planesweep_launch(feats_cl, imgs_cl, proj, depth, V, C, H, W, D, pad, cost, CP, masks, with_img, 0, stream);
+}
+
+extern "C" int mvsnerf_planesweep_costvar_blocked_fwd(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,
+                                                      int V, int C, int H, int W, int D, int pad, float* cost_blocked, int CP, float* masks,
+                                                      int with_img, void* stream)
+{
+    return planesweep_launch(feats_cl, imgs_cl, proj, depth, V, C, H, W, D, pad, cost_blocked, CP, masks, with_img, 1, stream);
+}
+
+static int planesweep_launch(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,
+                             int V, int C, int H, int W, int D, int pad, float* cost, int CP, float* masks,
+                             int with_img, int blocked, void* stream)
 {
     if (!feats_cl || !proj || !depth || !cost || !masks || V < 1 || H < 2 || W < 2 || D < 1 || pad < 0) return MVSNERF_EINVAL;
     if (with_img && !imgs_cl) return MVSNERF_EINVAL;
@@ -234,7 +264,7 @@ extern "C" int mvsnerf_planesweep_costvar_fwd(const float* feats_cl, const float
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(planesweep_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    planesweep_kernel<32><<<mvs_cdiv(nvox, 256), 256, lds, (hipStream_t)stream>>>(feats_cl, imgs_cl, proj, depth, V, H, W, D, pad, cost, CP, masks, with_img);
+    planesweep_kernel<32><<<mvs_cdiv(nvox, 256), 256, lds, (hipStream_t)stream>>>(feats_cl, imgs_cl, proj, depth, V, H, W, D, pad, cost, CP, masks, with_img, blocked);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
@@ -506,6 +536,9 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_kernel(ActSrc a, ActSrc b, i
     for (int k = 0; k < CT; k += 4) *reinterpret_cast<f32x4*>(o + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
 }
 
+int g_conv_mfma = 1;    // stride-1 layers with 8 output channels on v_mfma_f32_4x4x1_16B_f32 (conv_mfma.hip); 0 = the VALU kernels (A/B knob)
+int mvs_conv3d_c8_mfma(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int D, int H, int W, const float* wpacked, float* out,
+                       int xcd, hipStream_t st);
 int g_conv_tiled = 1;   // A/B knob (mvsnerf_tune "conv_tiled")
 int g_conv_xcd = 1;     // tiles renumbered so that an XCD owns a contiguous range (mvsnerf_tune "conv_xcd")
 static bool act_ok(const float* x, const float* sc, const float* sh) { return x && ((sc == nullptr) == (sh == nullptr)) && mvs_aligned16(x); }
@@ -527,6 +560,10 @@ extern "C" int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const fl
     conv3d_k3_kernel<CIN, CT, S, COUT><<<dim3(mvs_cdiv(nvox, 256), COUT / CT), 256, 0, st>>>(a, b, cin_ld, D, H, W, wpacked, out, Do, Ho, Wo, g_conv_xcd)
 #define MVS_CONV_TILED(CIN, CT, COUT)                                                                 \
     conv3d_k3s1_tiled_kernel<CIN, CT, COUT><<<dim3(((W + 7) / 8) * ((H + 7) / 8) * ((D + 3) / 4), COUT / CT), 256, 0, st>>>(a, b, cin_ld, D, H, W, wpacked, out, g_conv_xcd)
+    if (Cout == 8 && stride == 1 && g_conv_mfma) {
+        const int rc = mvs_conv3d_c8_mfma(a, b, Cin, cin_ld, D, H, W, wpacked, out, g_conv_xcd, st);
+        if (rc != MVSNERF_EUNSUPPORTED) return rc;
+    }
     // (Cin rounded up to a multiple of 4 by the caller's channel padding; Cout in {8,16,32,64})
     const int key = Cin * 1000 + Cout * 10 + stride;
     switch (key) {
@@ -551,6 +588,14 @@ extern "C" int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const fl
 #undef MVS_CONV_TILED
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
+}
+
+extern "C" int mvsnerf_conv3d_c8_blocked_fwd(const float* x_blocked, int Cin, int D, int H, int W, const float* wpacked, float* out, void* stream)
+{
+    if (!x_blocked || !wpacked || !out || D < 1 || H < 1 || W < 1 || Cin < 4 || (Cin & 3)) return MVSNERF_EINVAL;
+    if (!mvs_aligned16(x_blocked) || !mvs_aligned16(out)) return MVSNERF_EALIGN;
+    const ActSrc a{x_blocked, nullptr, nullptr}, b{nullptr, nullptr, nullptr};
+    return mvs_conv3d_c8_mfma(a, b, Cin, -8, D, H, W, wpacked, out, g_conv_xcd, (hipStream_t)stream);    // ld = -8: channel blocks of 8
 }
 
 extern "C" int mvsnerf_conv_transpose3d_fwd(const float* x1, const float* scale1, const float* shift1,

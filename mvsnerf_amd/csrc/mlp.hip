@@ -614,6 +614,7 @@ static int launch_mlp_pipe(const float* packed, int F, const float* ndc, int ndc
 static int g_mlp_variant = 3;
 extern int g_conv_tiled;
 extern int g_conv_xcd;
+extern int g_conv_mfma;
 extern int g_split_sched;     // mlp_bf16.hip
 
 extern "C" int mvsnerf_tune(const char* key, int value)
@@ -621,6 +622,7 @@ extern "C" int mvsnerf_tune(const char* key, int value)
     if (!key) return MVSNERF_EINVAL;
     if (__builtin_strcmp(key, "conv_tiled") == 0) { g_conv_tiled = value ? 1 : 0; return MVSNERF_OK; }
     if (__builtin_strcmp(key, "conv_xcd") == 0) { g_conv_xcd = value ? 1 : 0; return MVSNERF_OK; }
+    if (__builtin_strcmp(key, "conv_mfma") == 0) { g_conv_mfma = value ? 1 : 0; return MVSNERF_OK; }
     if (__builtin_strcmp(key, "mlp_variant") == 0) { if (value < 0 || value > 4) return MVSNERF_EINVAL; g_mlp_variant = value; return MVSNERF_OK; }
     if (__builtin_strcmp(key, "split_sched") == 0) { if (value < 0 || value > 1) return MVSNERF_EINVAL; g_split_sched = value; return MVSNERF_OK; }
     return MVSNERF_EINVAL;

@@ -3,7 +3,7 @@
 // ATen launches).
 #include "common.h"
 
-extern "C" int mvsnerf_abi_version(void) { return 5; }
+extern "C" int mvsnerf_abi_version(void) { return 6; }
 
 extern "C" int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream)
 {

@@ -405,6 +405,8 @@ class ConvBnReLU3D(nn.Module):
 
 
 MATERIALIZE_UP_INPUT = True     # A/B switch (scratch/enc_time.py)
+BLOCKED_COST = True             # A/B switch: MVSNet.forward hands conv0 a channel-blocked cost volume on the no-grad path
+_BLOCKED_CIN = (32, 36, 40, 44, 48, 52, 56)   # conv0 input widths the matrix-core kernel is instantiated for
 
 
 class _UpBlock(nn.Sequential):
@@ -456,11 +458,25 @@ class CostRegNet(nn.Module):
 
     def _run(self, x):
         """The lazily-activated U-Net; returns the 10 _Lazy layer outputs and the channel-last input."""
-        _, C, D, H, W = x.shape
+        if isinstance(x, _BlockedCost):
+            D, H, W = x.dims
+        else:
+            _, C, D, H, W = x.shape
         if D % 8 or H % 8 or W % 8:
             raise RuntimeError(f"CostRegNet needs D,h,w divisible by 8 (three stride-2 stages), got {(D, H, W)}")
-        buf, ld = _as_channel_last(x, self.conv0._packed_cin_pad())
-        c0 = self.conv0.lazy(buf, (D, H, W, ld), ld)
+        if isinstance(x, _BlockedCost):
+            pk = self.conv0._packed
+            if x.cin_pad != pk.cin_pad:
+                raise RuntimeError(f"CostRegNet: blocked cost volume has {x.cin_pad} channels, conv0 expects {pk.cin_pad}")
+            raw = torch.empty((D, H, W, pk.cout), device=x.buf.device, dtype=torch.float32)
+            check(_lib.lib().mvsnerf_conv3d_c8_blocked_fwd(x.buf.data_ptr(), pk.cin_pad, D, H, W, pk.get().data_ptr(), raw.data_ptr(), stream_ptr()),
+                  "conv3d_c8_blocked_fwd")
+            scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self.conv0.bn, update_running=self.conv0.bn.training)
+            c0 = _Lazy(raw, scale, shift, (D, H, W, pk.cout), mean, invstd)
+            buf, ld = None, 0
+        else:
+            buf, ld = _as_channel_last(x, self.conv0._packed_cin_pad())
+            c0 = self.conv0.lazy(buf, (D, H, W, ld), ld)
         c1 = self.conv1.lazy(c0, c0.dims, 8)
         c2 = self.conv2.lazy(c1, c1.dims, 16)
         c3 = self.conv3.lazy(c2, c2.dims, 16)
@@ -475,6 +491,9 @@ class CostRegNet(nn.Module):
 
     def forward(self, x):
         """x: logical (1,Cin,D,h,w) cost volume (D,h,w divisible by 8).  Returns (1,8,D,h,w), channel-last memory."""
+        if isinstance(x, _BlockedCost):          # internal no-grad hand-off from MVSNet.forward
+            _, lz = self._run(x)
+            return _cl_view_to_ncdhw(_apply_add(lz[0], lz[9]))
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             params = []
             for l in self._layers():
@@ -601,8 +620,18 @@ def homo_warp(src_feat, proj_mat, depth_values, src_grid=None, pad=0):
     return warped, grid_out
 
 
-def _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img):
-    """One-pass plane sweep (homo_warp + cost variance [+ warped thumbnails]).  Returns (cost view, masks, saved)."""
+class _BlockedCost:
+    """Cost volume in channel blocks of 8, buf[(CP+7)//8][D*H*W][8] (mvsnerf_planesweep_costvar_blocked_fwd): the internal hand-off
+    between the plane sweep and the matrix-core conv0 on the no-grad path.  Never handed to callers."""
+    __slots__ = ("buf", "n_ch", "cin_pad", "dims")
+
+    def __init__(self, buf, n_ch, cin_pad, dims):
+        self.buf, self.n_ch, self.cin_pad, self.dims = buf, n_ch, cin_pad, dims
+
+
+def _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img, blocked=False):
+    """One-pass plane sweep (homo_warp + cost variance [+ warped thumbnails]).  Returns (cost view, masks, saved);
+    blocked=True: the cost volume comes back as a _BlockedCost instead of a logical NCDHW view."""
     B, V, C, H, W = feats.shape
     dev = feats.device
     lib = _lib.lib()
@@ -621,10 +650,16 @@ def _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img):
         imgs_cl_p = imgs_cl.data_ptr()
     n_ch = (3 * V if with_img else 0) + C
     CP = (n_ch + 3) // 4 * 4
-    cost = torch.empty((D, Hp, Wp, CP), device=dev, dtype=torch.float32)
     masks = torch.empty((V, D, Hp, Wp) if with_img else (1, D, Hp, Wp), device=dev, dtype=torch.float32)
     proj = proj_mats[0].detach().contiguous()
     depth = depth_values[0].detach().contiguous()
+    if blocked:
+        cost = torch.empty(((CP + 7) // 8, D * Hp * Wp, 8), device=dev, dtype=torch.float32)
+        check(lib.mvsnerf_planesweep_costvar_blocked_fwd(feats_cl.data_ptr(), imgs_cl_p, dev_f32(proj, "proj_mats"), dev_f32(depth, "depth_values"),
+                                                         V, C, H, W, D, pad, cost.data_ptr(), CP, masks.data_ptr(), int(with_img), stream_ptr()),
+              "planesweep_costvar_blocked_fwd")
+        return _BlockedCost(cost, n_ch, CP, (D, Hp, Wp)), masks.unsqueeze(0), None
+    cost = torch.empty((D, Hp, Wp, CP), device=dev, dtype=torch.float32)
     check(lib.mvsnerf_planesweep_costvar_fwd(feats_cl.data_ptr(), imgs_cl_p, dev_f32(proj, "proj_mats"), dev_f32(depth, "depth_values"),
                                              V, C, H, W, D, pad, cost.data_ptr(), CP, masks.data_ptr(), int(with_img), stream_ptr()),
           "planesweep_costvar_fwd")
@@ -667,12 +702,12 @@ class MVSNet(nn.Module):
         self.cost_reg_2 = CostRegNet(32 + 3 * n_views, norm_act)
         self.D = 128          # number of depth planes (hard-coded `D = 128` at models.py:914; settable here for config 1)
 
-    def _sweep(self, imgs, feats, proj_mats, depth_values, pad, with_img):
+    def _sweep(self, imgs, feats, proj_mats, depth_values, pad, with_img, blocked=False):
         if feats.shape[0] != 1:
             raise RuntimeError("MVSNet: batch size must be 1 (the reference assumes it, models.py:916)")
         if torch.is_grad_enabled() and feats.requires_grad:
             return _PlaneSweepFunction.apply(feats, imgs, proj_mats, depth_values, pad, with_img)
-        cost, masks, _ = _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img)
+        cost, masks, _ = _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img, blocked=blocked)
         return cost, masks
 
     def build_volume_costvar(self, feats, proj_mats, depth_values, pad=0):
@@ -693,6 +728,13 @@ class MVSNet(nn.Module):
         near, far = near_far
         depth_values = (near * (1.0 - t_vals) + far * t_vals) if not lindisp else 1.0 / (1.0 / near * (1.0 - t_vals) + 1.0 / far * t_vals)
         depth_values = depth_values.unsqueeze(0)
+        # inference (no gradient anywhere): the cost volume goes to conv0 in channel blocks of 8 and never takes its NCDHW form
+        fast = (BLOCKED_COST and not return_color and not feats_l.requires_grad
+                and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.cost_reg_2.parameters()))
+                and (32 + 3 * V + 3) // 4 * 4 in _BLOCKED_CIN)
+        if fast:
+            cost, _ = self._sweep(imgs, feats_l, proj_mats, depth_values, pad, True, blocked=True)
+            return self.cost_reg_2(cost), feats_l, depth_values
         volume_feat, in_masks = self.build_volume_costvar_img(imgs, feats_l, proj_mats, depth_values, pad=pad)
         if return_color:
             feats_l = torch.cat((volume_feat[:, :V * 3].reshape(B, V, 3, *volume_feat.shape[2:]), in_masks.unsqueeze(2)), dim=2)
@@ -722,7 +764,10 @@ def bench_encode(rig, dev, pad, iters=6):
             torch.cuda.synchronize(); t1 = time.perf_counter()
             t_vals = torch.linspace(0.0, 1.0, steps=net.D, device=dev)
             dv = (nf[0] * (1.0 - t_vals) + nf[1] * t_vals).unsqueeze(0)
-            cost, _ = net.build_volume_costvar_img(imgs, feats_l, proj, dv, pad=pad)
+            if BLOCKED_COST:
+                cost, _ = net._sweep(imgs, feats_l, proj, dv, pad, True, blocked=True)      # what MVSNet.forward does without gradients
+            else:
+                cost, _ = net.build_volume_costvar_img(imgs, feats_l, proj, dv, pad=pad)
             torch.cuda.synchronize(); t2 = time.perf_counter()
             vol = net.cost_reg_2(cost)
             torch.cuda.synchronize(); t3 = time.perf_counter()

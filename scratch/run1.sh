@@ -1,4 +1,3 @@
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_nccl.py -q -x 2>&1 | tail -25 > gpurun_out/nccl1.log
-timeout 900 python bench.py --multi-gpu-legs > gpurun_out/bench_r2_1.json 2> gpurun_out/bench_r2_1.err
-tail -5 gpurun_out/bench_r2_1.err
+timeout 1200 python -m pytest tests/test_gpu_encoder.py tests/test_gpu_headline_parity.py tests/test_gpu_views.py -q -x 2>&1 | tail -5 > gpurun_out/enc1.log
+timeout 600 python scratch/enc_layers.py > gpurun_out/enc_time.log 2>&1
