@@ -8,7 +8,9 @@
  * Conventions
  *   - plain pointers + sizes, no torch types.  Every pointer is a DEVICE pointer (fp32 unless noted)
  *     owned by the caller; outputs are caller-allocated and fully written.  The library allocates
- *     nothing and keeps no state.
+ *     nothing.  Its only process-global state: (1) the A/B switches of mvsnerf_tune and the census pointer of
+ *     mvsnerf_debug_set_census - diagnostics for the tests and bench.py, whose defaults ARE the product behaviour and which
+ *     no product code path touches; (2) per-device "dynamic-LDS cap already raised" bits (idempotent).
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls only enqueue work.
  *   - return 0 on success, a negative MVSNERF_E* for rejected arguments (nothing was launched),
  *     or a positive hipError_t from the launch.
@@ -36,7 +38,7 @@ int mvsnerf_abi_version(void);
 
 /* A/B benchmarking knob, not part of the reference surface.  Keys: "mlp_variant" = 3 (default: 32 points/wave,
  * 2 waves/SIMD, weights double-buffered through LDS by LDS-DMA), 0 (same, register-staged weights), 1 (64 points/wave,
- * 1 wave/SIMD), 2 (32 points/wave, 1 wave/SIMD), 4 (16 points/wave on v_mfma_f32_16x16x4_f32, inference only); "conv_tiled" = 1|0; "conv_xcd" = 1|0 (tiles of the tiled convolutions renumbered per XCD, default 1); "split_sched" = 0 (default: bf16x6 kernel at two waves
+ * 1 wave/SIMD), 2 (32 points/wave, 1 wave/SIMD), 4 (16 points/wave on v_mfma_f32_16x16x4_f32, inference only); "conv_tiled" = 1|0; "conv_mfma" = 1|0 (stride-1 convolutions with 8 output channels on v_mfma_f32_4x4x1_16B_f32, default 1); "conv_xcd" = 1|0 (tiles of the tiled convolutions renumbered per XCD, default 1); "split_sched" = 0 (default: bf16x6 kernel at two waves
  * per SIMD, lean registers) | 1 (one wave per SIMD, operand splitting hand-interleaved between the MFMAs).  Results are
  * identical up to summation order. */
 int mvsnerf_tune(const char* key, int value);
@@ -253,7 +255,8 @@ int mvsnerf_mlp_fwd_bf16(const void* packed_bf16, const float* packed_f32, int F
  * mvsnerf_mlp_fwd_train = mvsnerf_mlp_fwd + an activation store `saved` (mvsnerf_mlp_saved_floats(N*S) floats).
  * mvsnerf_mlp_pack_bwd re-lays W^T fragments for the gradient chain (mvsnerf_mlp_packed_bwd_floats() floats).
  * mvsnerf_mlp_bwd: given d_raw[P][4] (grad wrt (r,g,b,sigma)) writes
- *     d_feat8[P][8]   grad wrt the first 8 feature columns (the trilinear volume features)
+ *     d_feat[P][n_feat_out]  grad wrt the first n_feat_out feature columns: 8 = the trilinear volume features; F = every
+ *                     input feature (the colour volume of --use_color_volume fine-tuning is a parameter too)
  *     gw[i], gb[i]    grads of the 11 nn.Linear weight/bias tensors (order of mvsnerf_mlp_pack), OVERWRITTEN
  *   gslots: scratch of mvsnerf_mlp_gradslot_floats(N*S) floats; workspace: mvsnerf_mlp_bwd_workspace_floats();
  *   maps: device int table built by the host side (fragment row -> nn.Linear row/column, mvsnerf_amd/ops.py).
@@ -268,7 +271,7 @@ int mvsnerf_mlp_fwd_train(const float* packed, int F, const float* ndc, int ndc_
                           const float* dirs, int dirs_stride, int64_t N, int S, float* raw, float* saved, void* stream);
 int mvsnerf_mlp_bwd(const float* packed_fwd, const float* packed_bwd, int F,
                     const float* raw, const float* d_raw, const float* saved, int64_t N, int S,
-                    float* gslots, float* d_feat8, float* const gw[11], float* const gb[11],
+                    float* gslots, float* d_feat, int n_feat_out, float* const gw[11], float* const gb[11],
                     const int* maps, float* workspace, void* stream);
 
 /* Backward of the compositing w.r.t. raw (autograd of renderer.py:18-26,65-92).  Upstream grads g_rgb[N][3],
@@ -277,7 +280,8 @@ int mvsnerf_composite_bwd(const float* raw, const float* z, int64_t N, int S, in
                           const float* g_rgb, const float* g_depth, const float* g_acc,
                           const float* g_weights, const float* g_alpha, float* d_raw, void* stream);
 
-/* Backward of the trilinear lookup w.r.t. the volume: gvol[D][H][W][8] += scatter of g[p*g_stride + c]
+/* Backward of the trilinear lookup w.r.t. the volume: gvol[D][H][W][C] += scatter of g[p*g_stride + c], C a multiple of 4
+ * (8: the neural volume; 8+4V: the colour volume of --use_color_volume, train_mvs_nerf_finetuning_pl.py:72-82)
  * (float atomics; gvol must be zero-initialised by the caller).  Needed by RefVolume fine-tuning
  * (train_mvs_nerf_finetuning_pl.py:54) and, through the encoder, by generalizable training. */
 int mvsnerf_volume_sample_bwd(int D, int H, int W, int C, const float* ndc, int64_t P,

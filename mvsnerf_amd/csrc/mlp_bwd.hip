@@ -112,7 +112,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NBLK])
 __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
     const float* __restrict__ packed_fwd, int F, const float* __restrict__ packed_bwd,
     const float* __restrict__ raw, const float* __restrict__ d_raw, const float* __restrict__ saved,
-    int64_t P, float* __restrict__ gslots, float* __restrict__ d_feat8)
+    int64_t P, float* __restrict__ gslots, float* __restrict__ d_feat, int n_feat_out)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* buf0 = lds;
@@ -217,8 +217,15 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
         f32x16 acc[1];
         zero_acc<1>(acc);
         gemm_t<16, 1>(buf1, acc, lane, [&](int t) { return gbm[t]; });
-        // C/D rows (r&3)+8*(r>>2)+4*half: r = 0..3 are feature columns 4*half + r
-        if (live) *reinterpret_cast<f32x4*>(d_feat8 + p_raw * 8 + half * 4) = f32x4{acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
+        // C/D rows (r&3)+8*(r>>2)+4*half: registers 4q..4q+3 are feature columns 8q + 4*half + (0..3); the first n_feat_out
+        // columns are stored (8: the trilinear volume features; F: every input feature, for a colour volume that is trained too)
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (8 * q + 4 * half < n_feat_out)
+                    *reinterpret_cast<f32x4*>(d_feat + p_raw * n_feat_out + 8 * q + 4 * half) =
+                        f32x4{acc[0][4 * q], acc[0][4 * q + 1], acc[0][4 * q + 2], acc[0][4 * q + 3]};
+        }
     }
 }
 
@@ -322,10 +329,11 @@ extern "C" size_t mvsnerf_mlp_bwd_workspace_floats(void) { return (size_t)(256 +
 //   [6] dir (32): r -> 128 + {0,1,2} or -1                 [7] g4_rgb (32): 0,1,2 -> rgb row, else -1   [8] g4_alpha (32): 3 -> 0
 extern "C" int mvsnerf_mlp_bwd(const float* packed_fwd, const float* packed_bwd, int F,
                                const float* raw, const float* d_raw, const float* saved, int64_t N, int S,
-                               float* gslots, float* d_feat8, float* const gw[11], float* const gb[11],
+                               float* gslots, float* d_feat, int n_feat_out, float* const gw[11], float* const gb[11],
                                const int* maps, float* workspace, void* stream)
 {
-    if (!packed_fwd || !packed_bwd || !raw || !d_raw || !saved || !gslots || !d_feat8 || !gw || !gb || !maps || !workspace) return MVSNERF_EINVAL;
+    if (!packed_fwd || !packed_bwd || !raw || !d_raw || !saved || !gslots || !d_feat || !gw || !gb || !maps || !workspace) return MVSNERF_EINVAL;
+    if (n_feat_out < 4 || n_feat_out > F || (n_feat_out & 3) || !mvs_aligned16(d_feat)) return MVSNERF_EINVAL;
     if (F < 2 || F > 32 || (F & 1) || N < 0 || S < 1) return MVSNERF_EUNSUPPORTED;
     const int64_t P = N * S;
     if (P == 0) return MVSNERF_OK;
@@ -335,7 +343,7 @@ extern "C" int mvsnerf_mlp_bwd(const float* packed_fwd, const float* packed_bwd,
     const size_t lds_bytes = LDS_FLOATS * sizeof(float);
     static unsigned long long lds_cap_set = 0;          // per-device bit mask (common.h)
     if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_dgrad_kernel), (int)lds_bytes, &lds_cap_set)) return rc_;
-    mlp_dgrad_kernel<<<nwg, 256, lds_bytes, st>>>(packed_fwd, F, packed_bwd, raw, d_raw, saved, P, gslots, d_feat8);
+    mlp_dgrad_kernel<<<nwg, 256, lds_bytes, st>>>(packed_fwd, F, packed_bwd, raw, d_raw, saved, P, gslots, d_feat, n_feat_out);
     MVS_LAUNCH_CHECK();
 
     const int* M_ACT128 = maps, *M_ACT64 = maps + 128, *M_PE = maps + 192, *M_FEAT = maps + 320, *M_HL5 = maps + 352,

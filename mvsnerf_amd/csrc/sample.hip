@@ -445,14 +445,41 @@ __global__ __launch_bounds__(256) void volume_sample_c8_bwd_kernel(
     }
 }
 
+// Any channel count that is a multiple of 4 (the 8 + 4V-channel colour volume of --use_color_volume fine-tuning,
+// train_mvs_nerf_finetuning_pl.py:72-82): one thread per (point, channel quad), eight corners each.
+__global__ __launch_bounds__(256) void volume_sample_bwd_kernel(
+    int D, int H, int W, int C, const float* __restrict__ ndc, int64_t P, const float* __restrict__ g, int g_stride, float* __restrict__ gvol)
+{
+    const int Q = C >> 2;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = tid / Q;
+    const int ch = (int)(tid - p * Q) * 4;
+    if (p >= P) return;
+    const float gx = ndc[p * 3 + 0] * 2.0f - 1.0f, gy = ndc[p * 3 + 1] * 2.0f - 1.0f, gz = ndc[p * 3 + 2] * 2.0f - 1.0f;
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1), iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1), iz = ((gz + 1.0f) / 2.0f) * (float)(D - 1);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + p * g_stride + ch);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int zc = k >> 2, yc = (k >> 1) & 1, xc = k & 1;
+        const float cxf = fx + (float)xc, cyf = fy + (float)yc, czf = fz + (float)zc;
+        if (!((cxf >= 0.0f) && (cxf <= (float)(W - 1)) && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1)))) continue;
+        const float w = (xc ? (ix - fx) : ((fx + 1.0f) - ix)) * (yc ? (iy - fy) : ((fy + 1.0f) - iy)) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
+        float* dst = gvol + ((((int64_t)czf * H + (int)cyf) * W + (int)cxf) * C + ch);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) atomicAdd(dst + c, gv[c] * w);
+    }
+}
+
 extern "C" int mvsnerf_volume_sample_bwd(int D, int H, int W, int C, const float* ndc, int64_t P,
                                          const float* g, int g_stride, float* gvol, void* stream)
 {
     if (!ndc || !g || !gvol || D < 1 || H < 1 || W < 1 || P < 0 || g_stride < C) return MVSNERF_EINVAL;
-    if (C != 8) return MVSNERF_EUNSUPPORTED;
+    if (C < 4 || (C & 3)) return MVSNERF_EUNSUPPORTED;
     if ((g_stride & 3) || !mvs_aligned16(g)) return MVSNERF_EALIGN;
     if (P == 0) return MVSNERF_OK;
-    volume_sample_c8_bwd_kernel<<<mvs_cdiv(P * 4, 256), 256, 0, (hipStream_t)stream>>>(D, H, W, ndc, P, g, g_stride, gvol);
+    if (C == 8) volume_sample_c8_bwd_kernel<<<mvs_cdiv(P * 4, 256), 256, 0, (hipStream_t)stream>>>(D, H, W, ndc, P, g, g_stride, gvol);
+    else volume_sample_bwd_kernel<<<mvs_cdiv(P * (C >> 2), 256), 256, 0, (hipStream_t)stream>>>(D, H, W, C, ndc, P, g, g_stride, gvol);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }

@@ -12,7 +12,6 @@ import time
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib, ops
 from ._lib import check, dev_f32, stream_ptr
@@ -22,9 +21,10 @@ ABN_EPS, ABN_MOMENTUM, ABN_SLOPE = 1e-5, 0.1, 0.01
 
 # ------------------------------------------------------------------ InPlaceABN stand-in
 class InPlaceABN(nn.Module):
-    """Parameter container + 2-D forward for mapillary InPlaceABN (third-party, not in the reference tree;
-    semantics restated: y = leaky_relu(batch_norm(x, gamma=|w|+eps), 0.01)).
-    3-D use goes through the HIP kernels (abn_stats / lazy activation), never through this forward."""
+    """Parameter container for mapillary InPlaceABN (third-party, not in the reference tree; semantics restated:
+    y = leaky_relu(batch_norm(x, gamma=|w|+eps), 0.01)).  Inside FeatureNet / CostRegNet the normalisation is applied
+    lazily by the consuming convolution (abn_stats -> per-channel scale/shift); `forward` is the stand-alone form on the same HIP
+    kernels (statistics + apply) for callers that use the layer on its own."""
 
     def __init__(self, num_features, eps=ABN_EPS, momentum=ABN_MOMENTUM, affine=True, activation="leaky_relu", activation_param=ABN_SLOPE):
         super().__init__()
@@ -35,10 +35,26 @@ class InPlaceABN(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x):   # 2-D FeatureNet path (PyTorch-ROCm)
-        y = F.batch_norm(x, self.running_mean, self.running_var, self.weight.abs() + self.eps, self.bias,
-                         self.training, self.momentum, self.eps)
-        return F.leaky_relu(y, self.activation_param)
+    def forward(self, x):
+        """(N,C,H,W) or (1,C,D,H,W) -> same logical shape (channel-last memory).  No autograd (inside the networks the backward
+        goes through _abn_bwd); C must be a multiple of 4 (all the reference uses: 8, 16, 32, 64)."""
+        ops._need_no_grad(x, self.weight, self.bias, op="InPlaceABN")
+        C = self.num_features
+        if x.dim() not in (4, 5) or x.shape[1] != C or C % 4 or self.activation_param != ABN_SLOPE:
+            raise NotImplementedError(f"InPlaceABN.forward: expected (N,{C},H,W) or (1,{C},D,H,W) with C % 4 == 0 and slope {ABN_SLOPE}")
+        if x.dim() == 4:
+            buf, ld = _images_channel_last(x, C)
+            dims = (x.shape[0], x.shape[2], x.shape[3], C)
+        else:
+            buf, ld = _as_channel_last(x, C)
+            dims = (x.shape[2], x.shape[3], x.shape[4], C)
+        if ld != C:
+            buf = buf[..., :C].contiguous()
+        n = dims[0] * dims[1] * dims[2]
+        scale, shift, mean, invstd = _abn_stats(buf, n, self, update_running=self.training)
+        out = _apply_add(_Lazy(buf, scale, shift, dims, mean, invstd))
+        _flush_nbt()
+        return out.permute(0, 3, 1, 2) if x.dim() == 4 else _cl_view_to_ncdhw(out)
 
 
 class _PackedConv2d:
@@ -586,8 +602,6 @@ class _CostRegFunction(torch.autograd.Function):
         g_c0 = conv_block(1, L[1], c1, c0, c0.dims, 8, g_c1)
         D, H, W = c0.dims[:3]
         g_cost = conv_block(0, L[0], c0, buf, (D, H, W, ctx.ld), ctx.ld, g, g_c0, need_dgrad=ctx.needs_input_grad[0])   # A(c0) feeds conv1 and the output sum
-        # conv0's weight gradient covers the padded input channels too: keep the real ones
-        gw0 = grads[0][0]
         out = [None if g_cost is None else _cl_view_to_ncdhw(g_cost, ctx.xshape[1]), None]
         for i in range(10):
             gw, gbw, gbb = grads[i]
@@ -701,6 +715,16 @@ class MVSNet(nn.Module):
         # BASELINE config 4 (5 views => 47 input channels, no shipped checkpoint fits)
         self.cost_reg_2 = CostRegNet(32 + 3 * n_views, norm_act)
         self.D = 128          # number of depth planes (hard-coded `D = 128` at models.py:914; settable here for config 1)
+
+    def invalidate_packed(self):
+        """Drop every re-packed convolution weight (see MVSNeRF.invalidate_packed: needed after writes through `.data`)."""
+        for m in self.modules():
+            pk = getattr(m, "_packed", None)
+            if pk is not None and hasattr(pk, "cache"):
+                pk.cache.clear()
+        tp = getattr(self.feature, "_top_packed", None)
+        if tp is not None:
+            tp.cache.clear()
 
     def _sweep(self, imgs, feats, proj_mats, depth_values, pad, with_img, blocked=False):
         if feats.shape[0] != 1:

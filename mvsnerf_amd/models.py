@@ -101,6 +101,13 @@ class Renderer_ours(nn.Module):
             self._packed_key = key
         return self._packed
 
+    def invalidate_packed(self):
+        """Drop the packed-weight caches.  The caches key on (data_ptr, tensor._version); writes through `.data` (`p.data.copy_()`,
+        EMA updates on `.data`) do not bump `_version`, so code that updates weights that way must call this afterwards
+        (MVSNet.invalidate_packed does the same for the encoder's convolution weights)."""
+        self._packed = self._packed_key = None
+        self._packed_b = self._packed_s = None
+
     def packed_bf16(self, feat_dim=None):
         """bf16 fragment-ordered weights for the opt-in bf16-MFMA kernel (same cache policy as packed())."""
         F = self.in_ch_feat if feat_dim is None else feat_dim
@@ -187,6 +194,9 @@ class MVSNeRF(nn.Module):
 
     def packed_alt(self, feat_dim=None):
         return self.nerf.packed_alt(feat_dim)
+
+    def invalidate_packed(self):
+        self.nerf.invalidate_packed()
 
     def query(self, pts, feat, viewdirs, N, S):
         return self.nerf.query(pts, feat, viewdirs, N, S)

@@ -441,18 +441,26 @@ class RayMarchFunction(torch.autograd.Function):
         dev = rays_pts.device
         f32 = dict(device=dev, dtype=torch.float32)
         st = stream_ptr()
-        dirs = torch.empty((N, 3), **f32)
         feat = torch.empty((N, S, F), **f32)
         raw = torch.empty((N, S, 4), **f32)
         saved = torch.empty(lib.mvsnerf_mlp_saved_floats(N * S), **f32)
-        check(lib.mvsnerf_gather_fwd(dev_f32(vol_cl, "volume"), D, H, W, channels_last_images(imgs).data_ptr(), V, imgs.shape[2], imgs.shape[3],
-                                     dev_f32(w2cs, "w2cs"), dev_f32(intrinsics, "intrinsics"), dev_f32(rays_pts, "rays_pts"), dev_f32(rays_ndc, "rays_ndc"),
-                                     N, S, dev_f32(rays_dir, "rays_dir"), feat.data_ptr(), F, dirs.data_ptr(), st), "gather_fwd")
+        if C == F and C != 8:
+            # --use_color_volume (renderer.py:134-135): the volume already carries the projected colours; one F-channel lookup
+            dirs = dir_feature(rays_dir, w2cs[0].contiguous(), normalize=True)
+            check(lib.mvsnerf_volume_sample_fwd(dev_f32(vol_cl, "volume"), D, H, W, C, dev_f32(rays_ndc, "rays_ndc"), N * S, feat.data_ptr(), F, st),
+                  "volume_sample_fwd")
+        elif C == 8:
+            dirs = torch.empty((N, 3), **f32)
+            check(lib.mvsnerf_gather_fwd(dev_f32(vol_cl, "volume"), D, H, W, channels_last_images(imgs).data_ptr(), V, imgs.shape[2], imgs.shape[3],
+                                         dev_f32(w2cs, "w2cs"), dev_f32(intrinsics, "intrinsics"), dev_f32(rays_pts, "rays_pts"), dev_f32(rays_ndc, "rays_ndc"),
+                                         N, S, dev_f32(rays_dir, "rays_dir"), feat.data_ptr(), F, dirs.data_ptr(), st), "gather_fwd")
+        else:
+            raise RuntimeError(f"ray march: the volume has {C} channels; expected 8 or 8 + 4V = {F}")
         check(lib.mvsnerf_mlp_fwd_train(packed.data_ptr(), F, rays_ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3, N, S,
                                         raw.data_ptr(), saved.data_ptr(), st), "mlp_fwd_train")
         rgb, disp, acc, weights, depth, alpha = composite(raw, z_vals, white_bkgd)
         ctx.save_for_backward(rays_ndc, z_vals, raw, saved, packed, *mlp_params)
-        ctx.meta = (tuple(volume.shape), (D, H, W), N, S, F, bool(white_bkgd))
+        ctx.meta = (tuple(volume.shape), (D, H, W, C), N, S, F, bool(white_bkgd))
         ctx.mark_non_differentiable(feat, raw)
         return rgb, feat, weights, depth, alpha, raw
 
@@ -460,7 +468,7 @@ class RayMarchFunction(torch.autograd.Function):
     def backward(ctx, g_rgb, g_feat, g_weights, g_depth, g_alpha, g_raw):
         lib = _lib.lib()
         rays_ndc, z_vals, raw, saved, packed, *mlp_params = ctx.saved_tensors
-        vshape, (D, H, W), N, S, F, white = ctx.meta
+        vshape, (D, H, W, C), N, S, F, white = ctx.meta
         dev = raw.device
         f32 = dict(device=dev, dtype=torch.float32)
         st = stream_ptr()
@@ -474,18 +482,18 @@ class RayMarchFunction(torch.autograd.Function):
         packed_bwd = mlp_pack_bwd(weights, F)
         gslots = torch.empty(lib.mvsnerf_mlp_gradslot_floats(N * S), **f32)
         ws = torch.empty(lib.mvsnerf_mlp_bwd_workspace_floats(), **f32)
-        d_feat8 = torch.empty((N * S, 8), **f32)
+        d_feat = torch.empty((N * S, C), **f32)         # C = 8: the volume features only; C = F: the colour volume is a parameter too
         gws = [torch.zeros_like(p) for p in mlp_params[0::2]]
         gbs = [torch.zeros_like(p) for p in mlp_params[1::2]]
         gwp = (ctypes.c_void_p * 11)(*[g.data_ptr() for g in gws])
         gbp = (ctypes.c_void_p * 11)(*[g.data_ptr() for g in gbs])
         maps = _mlp_bwd_maps(F, dev)
         check(lib.mvsnerf_mlp_bwd(packed.data_ptr(), packed_bwd.data_ptr(), F, raw.data_ptr(), d_raw.data_ptr(), saved.data_ptr(), N, S,
-                                  gslots.data_ptr(), d_feat8.data_ptr(), gwp, gbp, maps.data_ptr(), ws.data_ptr(), st), "mlp_bwd")
+                                  gslots.data_ptr(), d_feat.data_ptr(), C, gwp, gbp, maps.data_ptr(), ws.data_ptr(), st), "mlp_bwd")
         g_vol = None
         if ctx.needs_input_grad[0]:
-            gvol_cl = torch.zeros((D, H, W, 8), **f32)
-            check(lib.mvsnerf_volume_sample_bwd(D, H, W, 8, rays_ndc.data_ptr(), N * S, d_feat8.data_ptr(), 8, gvol_cl.data_ptr(), st), "volume_sample_bwd")
+            gvol_cl = torch.zeros((D, H, W, C), **f32)
+            check(lib.mvsnerf_volume_sample_bwd(D, H, W, C, rays_ndc.data_ptr(), N * S, d_feat.data_ptr(), C, gvol_cl.data_ptr(), st), "volume_sample_bwd")
             g_vol = gvol_cl.permute(3, 0, 1, 2)
             if len(vshape) == 5:
                 g_vol = g_vol.unsqueeze(0)

@@ -19,8 +19,9 @@ def depth2dist(z_vals, cos_angle):
 
 def raw2alpha(sigma, dist=None, net_type="v0"):
     """renderer.py:18-26 -> (alpha, weights, alpha_softmax).  `dist` is ignored, as in the reference.
-    The softmax the reference also returns is never consumed; it is computed lazily with torch only if
-    a caller actually unpacks and uses it."""
+    The third return value (softmax of sigma over the samples, renderer.py:24) is consumed by nobody in the reference; it is
+    computed here eagerly with one torch call so that the 3-tuple is complete.  Not on the hot path: rendering() composites
+    inside the fused kernel and never calls this function."""
     raw = torch.zeros((*sigma.shape, 4), device=sigma.device, dtype=torch.float32)
     raw[..., 3] = sigma
     _, _, _, weights, _, alpha = ops.composite(raw, torch.zeros_like(sigma), False)
@@ -95,14 +96,18 @@ def rendering(args, pose_ref, rays_pts, rays_ndc, depth_candidates, rays_o, rays
     """renderer.py:138-165.  Returns (rgb_map, input_feat, weights, depth_map, alpha, {}) - note that the
     reference's callers name the 2nd/3rd entries `disp`/`acc` (train_mvs_nerf_pl.py:123)."""
     from .models import MVSNeRF, RefVolume
-    fused = (pose_ref is not None and isinstance(network_fn, MVSNeRF) and img_feat is None
-             and not getattr(args, "use_color_volume", False) and getattr(network_query_fn, "_mvsnerf_fused", False))
+    color_vol = bool(getattr(args, "use_color_volume", False))
+    fusable = (pose_ref is not None and isinstance(network_fn, MVSNeRF) and img_feat is None and getattr(network_query_fn, "_mvsnerf_fused", False))
+    vol = volume_feature.feat_volume if isinstance(volume_feature, RefVolume) else volume_feature
+    fusable = fusable and vol is not None
+    needs_grad = fusable and torch.is_grad_enabled() and (vol.requires_grad or any(p.requires_grad for p in network_fn.parameters()))
+    fused = fusable and (not color_vol or needs_grad)     # a colour volume is rendered piecewise below, trained through raymarch_train
     if fused:
-        vol = volume_feature.feat_volume if isinstance(volume_feature, RefVolume) else volume_feature
         V = imgs.shape[1]
         if args.feat_dim != 8 + 4 * V:
             raise RuntimeError(f"args.feat_dim {args.feat_dim} != 8 + 4*V ({V} views)")
-        needs_grad = torch.is_grad_enabled() and (vol.requires_grad or any(p.requires_grad for p in network_fn.parameters()))
+        if color_vol and vol.shape[-4] != args.feat_dim:
+            raise RuntimeError(f"use_color_volume: the volume has {vol.shape[-4]} channels, feat_dim is {args.feat_dim}")
         if needs_grad:      # training: same kernels + activation store, gradients to the volume and the MLP
             out = ops.raymarch_train(vol, imgs[0].contiguous(), pose_ref["w2cs"][:V].contiguous(),
                                      pose_ref["intrinsics"][:V].contiguous(), network_fn, rays_pts.contiguous(),

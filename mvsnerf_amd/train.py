@@ -322,13 +322,11 @@ class MVSSystemFinetune(_ModuleShim):
         what `dataset.read_source_views()` returns in the reference."""
         super().__init__()
         from .models import RefVolume
-        if getattr(args, "use_color_volume", False):
-            # :79-80 concatenates the projected colours to the learnable volume (20 channels).  renderer.gen_pts_feats renders such
-            # a volume; training it needs the C != 8 scatter (backward of the lookup), which this path does not have.
-            raise NotImplementedError("MVSSystemFinetune: --use_color_volume fine-tuning is not built (rendering a colour volume is: "
-                                      "renderer.gen_pts_feats(use_color_volume=True))")
         self.args = args
         self.args.feat_dim = 8 + 3 * 4
+        if getattr(args, "use_color_volume", False) and getattr(args, "use_density_volume", False):
+            raise NotImplementedError("--use_color_volume together with --use_density_volume: update_density_volume would concatenate the "
+                                      "colours to a volume that already holds them (train_mvs_nerf_finetuning_pl.py:96); not supported")
         kw_train, _, _, self.grad_vars = create_nerf_mvs(args, use_mvs=True, dir_embedder=False, pts_embedder=True)
         for k in ("N_samples", "ndc", "lindisp"):
             kw_train.pop(k, None)
@@ -357,14 +355,22 @@ class MVSSystemFinetune(_ModuleShim):
         self.imgs = MVSSystem.unpreprocess(imgs.to(dev))
         # importance sampling from a density volume (:73-86): voxel positions + per-voxel colour features, once per scene
         self.density_volume = None
-        if getattr(args, "use_density_volume", False):
+        use_cv, use_dv = bool(getattr(args, "use_color_volume", False)), bool(getattr(args, "use_density_volume", False))
+        if use_cv or use_dv:
             from .utils import get_ptsvolume, build_color_volume
             Dv, Hv, Wv = vol.shape[-3:]
             intrinsic, c2w = self.pose_source["intrinsics"][0].clone(), self.pose_source["c2ws"][0]
             intrinsic[:2] /= 4
-            self.vox_pts = get_ptsvolume(Hv - 2 * args.pad, Wv - 2 * args.pad, Dv, args.pad, self.near_far_source, intrinsic, c2w).contiguous()
+            vox_pts = get_ptsvolume(Hv - 2 * args.pad, Wv - 2 * args.pad, Dv, args.pad, self.near_far_source, intrinsic, c2w).contiguous()
             with torch.no_grad():
-                self.color_feature = build_color_volume(self.vox_pts, self.pose_source, self.imgs, with_mask=True)   # (D*H, W, 4V)
+                self.color_feature = build_color_volume(vox_pts, self.pose_source, self.imgs, with_mask=True)   # (D*H, W, 4V)
+            if use_cv and vol.shape[1] == 8:
+                # :79-80: the projected colours become 4V extra channels of the learnable volume (a checkpoint written by this class
+                # already holds all 8+4V channels; the reference would concatenate a second copy there, :66 + :80)
+                cf = self.color_feature.reshape(Dv, Hv, Wv, -1).permute(3, 0, 1, 2).unsqueeze(0)
+                vol = torch.cat((vol, cf), dim=1)
+            if use_dv:
+                self.vox_pts = vox_pts
         self.volume = RefVolume(vol.detach())
         self.grad_vars = [p for p in self.network_fn.parameters()] + list(self.volume.parameters())    # MVSNet stays frozen here
         self._allreduce = None

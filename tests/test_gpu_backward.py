@@ -126,3 +126,52 @@ def test_encoder_backward_vs_autograd():
         errs[name] = rel(p.grad, sd["cost_reg_2." + name].grad)
     bad = {k: v for k, v in errs.items() if not v < 5e-3}
     assert not bad, f"encoder gradient mismatches: {bad}\nall: {errs}"
+
+
+def test_color_volume_backward_vs_autograd():
+    """--use_color_volume fine-tuning (reference train_mvs_nerf_finetuning_pl.py:72-82, renderer.py:134-135): the learnable volume has
+    8 + 4V = 20 channels and ALL 20 per-sample features come from it, so the MLP backward must return every feature gradient and the
+    trilinear scatter runs on 20 channels.  Gradients vs autograd through the oracle (the same lookup + MLP + compositing)."""
+    import types
+    from mvsnerf_amd import models, renderer
+    from oracle import mvsnerf_oracle as O
+    n_rays, n_samples = 48, 24
+    rig, pose, vol8, pts, dirs, ndc, z, ro, mlp_sd, (R, Q, Wt, A) = _setup(n_rays, n_samples, 77)
+    g = torch.Generator().manual_seed(9)
+    vol = torch.cat([vol8, torch.rand((1, 12, *vol8.shape[2:]), generator=g)], 1)          # 20 channels
+
+    sd = {k: v.clone().requires_grad_(True) for k, v in mlp_sd.items()}
+    vol_ref = vol.clone().requires_grad_(True)
+    feat = O.index_point_feature(vol_ref, ndc)                                              # (N,S,20): one lookup, no colour projection
+    cos = torch.norm(dirs, dim=-1)
+    angle = O.gen_dir_feature(pose["w2cs"][0], dirs / cos.unsqueeze(-1))
+    raw = O.run_network_mvs(ndc, angle, feat, sd)
+    rgb_r, _, _, w_r, depth_r, alpha_r = O.raw2outputs(raw, z, False)
+    loss_ref = (rgb_r * R).sum() + (depth_r * Q).sum() + (w_r * Wt).sum() + (alpha_r * A).sum()
+    loss_ref.backward()
+
+    args = types.SimpleNamespace(feat_dim=20, img_downscale=1.0, use_color_volume=True, net_type="v0", multires=10, i_embed=0,
+                                 pts_dim=3, multires_views=4, dir_dim=3, netdepth=6, netwidth=128, N_importance=0, netchunk=1024,
+                                 ckpt=None, perturb=1.0, N_samples=n_samples, use_viewdirs=True, white_bkgd=False, raw_noise_std=0.0)
+    kw, _, _, _ = models.create_nerf_mvs(args, use_mvs=False, dir_embedder=False, pts_embedder=True)
+    net = kw["network_fn"]
+    net.load_state_dict(mlp_sd)
+    vol_g = models.RefVolume(vol.to(DEV))
+    pose_d = {k: v.to(DEV) for k, v in pose.items()}
+    rgb, feat_g, w, depth, alpha, _ = renderer.rendering(args, pose_d, pts.to(DEV), ndc.to(DEV), z.to(DEV), ro.to(DEV), dirs.to(DEV),
+                                                         vol_g, rig["images_raw"][:, :3].to(DEV), network_fn=net,
+                                                         network_query_fn=kw["network_query_fn"])
+    assert float((feat_g.detach().cpu() - feat.detach()).abs().max()) < 1e-5
+    loss = (rgb * R.to(DEV)).sum() + (depth * Q.to(DEV)).sum() + (w * Wt.to(DEV)).sum() + (alpha * A.to(DEV)).sum()
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-3 * max(1.0, abs(float(loss_ref.detach())))
+    loss.backward()
+
+    def rel(a, b):
+        return float((a.cpu() - b).abs().max() / (b.abs().max() + 1e-12))
+    gv, gr = vol_g.feat_volume.grad.cpu(), vol_ref.grad
+    errs = {"volume[0:8]": rel(gv[:, :8], gr[:, :8]), "volume[8:20]": rel(gv[:, 8:], gr[:, 8:])}
+    assert float(gr[:, 8:].abs().max()) > 0                                                # the colour channels do receive gradient
+    for name, p in net.named_parameters():
+        errs[name] = rel(p.grad, sd[name].grad)
+    bad = {k: v for k, v in errs.items() if not v < 2e-3}
+    assert not bad, f"gradient mismatches: {bad}\nall: {errs}"

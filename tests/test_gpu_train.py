@@ -176,6 +176,51 @@ def test_finetune_step_trains_volume_and_mlp():
     assert "feat_volume" in ft.volume.state_dict()
 
 
+def _ft_batch(rig, pose, n=256, seed=0):
+    from oracle import mvsnerf_oracle as O
+    g = torch.Generator().manual_seed(seed)
+    ro, rd, pix = O.get_rays_mvs(64, 96, pose["intrinsics"][3], pose["c2ws"][3], n, generator=g)
+    rays = torch.cat([ro.expand(n, 3), rd, torch.full((n, 1), 2.125), torch.full((n, 1), 4.525)], 1)
+    tgt = rig["images_raw"][0, 3][:, pix[0].long(), pix[1].long()].permute(1, 0)
+    return {"rays": rays[None], "rgbs": tgt[None]}
+
+
+def test_finetune_color_volume_and_checkpoint_resume(tmp_path, monkeypatch):
+    """--use_color_volume fine-tuning (train_mvs_nerf_finetuning_pl.py:72-82): the learnable volume has 8 + 4V channels, all of
+    them trained; and a checkpoint written by save_ckpt is resumed with its optimised volume (init_volume :58-66) instead of a
+    fresh encode."""
+    from mvsnerf_amd import train
+    from mvsnerf_amd.synth import make_rig, pose_ref_of
+    monkeypatch.chdir(tmp_path)
+    rig = make_rig(64, 96, seed=8, smooth=True)
+    pose = pose_ref_of(rig)
+    src = (rig["images"][:, :3], rig["proj_mats"][:, :3], rig["near_fars"][0, 0], {k: v[:3] for k, v in pose.items()})
+    mlp_sd, mvs_sd = load_weights()
+    args = train.default_args(pad=4, batch_size=256, N_samples=32, use_color_volume=True, expname="cv")
+    ft = train.MVSSystemFinetune(args, src, n_depth_planes=16).to(DEV)
+    ft.network_fn.load_state_dict(mlp_sd)
+    assert ft.volume.feat_volume.shape == (1, 20, 16, 24, 32) and not ft.volume_from_ckpt
+    v0 = ft.volume.feat_volume.detach().clone()
+    torch.manual_seed(0)
+    losses = ft.fit_steps([_ft_batch(rig, pose)] * 10)
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    dv = (ft.volume.feat_volume.detach() - v0).abs()
+    assert float(dv[:, :8].max()) > 0 and float(dv[:, 8:].max()) > 0          # neural AND colour channels are optimised
+    path = ft.save_ckpt("latest")
+    # resume: the checkpoint's volume is used as is (no re-encode), the MLP weights come back too
+    args2 = train.default_args(pad=4, batch_size=256, N_samples=32, use_color_volume=True, expname="cv", ckpt=path)
+    ft2 = train.MVSSystemFinetune(args2, src, n_depth_planes=16).to(DEV)
+    assert ft2.volume_from_ckpt
+    assert torch.equal(ft2.volume.feat_volume.detach().cpu(), ft.volume.feat_volume.detach().cpu())
+    for (n1, p1), (n2, p2) in zip(ft.network_fn.named_parameters(), ft2.network_fn.named_parameters()):
+        assert n1 == n2 and torch.equal(p1.detach().cpu(), p2.detach().cpu())
+    with torch.no_grad():                                                       # both render the same pixels
+        b = _ft_batch(rig, pose, seed=3)
+        torch.manual_seed(1); l1 = float(ft.training_step(b, 0)["loss"])
+        torch.manual_seed(1); l2 = float(ft2.training_step(b, 0)["loss"])
+    assert l1 == l2
+
+
 def test_render_view_target_grid_differs_from_sources():
     """BASELINE config 5 shape of the problem (1008x756 rays over 960x640 sources), small: a target camera whose pixel
     grid and intrinsics differ from the source views', rendered by one mvsnerf_render_pixels_fwd call, vs. the oracle."""
