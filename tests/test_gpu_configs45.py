@@ -1,0 +1,128 @@
+"""Parity at the shapes of BASELINE configs 4 and 5 (not only their code paths at toy sizes):
+
+  config 4  "Blender lego fine-tune, 5 source views, 800x800, 192 planes" (README.md:90 uses --pad 0 for Blender): cost volume
+            47 x 192x200x200, feat_dim 28.  No shipped checkpoint has these shapes: seeded random weights on both sides.
+  config 5  "LLFF horns full-frame render, 1008x756" over 960x640 sources (data/llff.py:168), pad 24, 128 planes: volume
+            8 x 128x208x288, target rays on a pixel grid that differs from the sources'.
+
+The CPU oracle encodes each scene once (tens of seconds on the GPU box's host cores); the HIP encode is compared on the whole
+volume, the ray march on 4096 rays (4 ranges of 1024 consecutive pixels spread over the frame for config 5).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import load_weights, maxabs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _args(feat_dim, n_samples):
+    import types
+    return types.SimpleNamespace(feat_dim=feat_dim, img_downscale=1.0, use_color_volume=False, net_type="v0", multires=10, i_embed=0, pts_dim=3,
+                                 multires_views=4, dir_dim=3, netdepth=6, netwidth=128, N_importance=0, netchunk=1024, ckpt=None, perturb=1.0,
+                                 N_samples=n_samples, use_viewdirs=True, white_bkgd=False, raw_noise_std=0.0)
+
+
+def test_config4_shape_five_views_800x800_192_planes():
+    from mvsnerf_amd import models, ops, renderer as R
+    from mvsnerf_amd.synth import make_rig, pose_ref_of
+    from oracle import mvsnerf_oracle as O
+    V, H, W, pad, D, n_rays, n_samples = 5, 800, 800, 0, 192, 4096, 128
+    base = (0.0, 0.25, -0.25, 0.12, -0.12, 0.1)
+    rig = make_rig(H, W, n_views=V + 1, seed=404, baselines=base, smooth=True)
+    pose = pose_ref_of(rig)
+    torch.manual_seed(44)
+    mvs = models.MVSNet(n_views=V)
+    mlp = models.MVSNeRF(D=6, W=128, input_ch_pts=63, input_ch_views=3, input_ch_feat=8 + 4 * V, skips=[4], net_type="v0")
+    with torch.no_grad():
+        for m in mvs.modules():
+            if isinstance(m, models.InPlaceABN):
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+    mvs_sd = {k: v.clone() for k, v in mvs.state_dict().items()}
+    mlp_sd = {k: v.clone() for k, v in mlp.state_dict().items()}
+    imgs_n, proj, nf = rig["images"][:, :V], rig["proj_mats"][:, :V], rig["near_fars"][0, 0]
+    with torch.no_grad():
+        vol_ref, feats_ref, dv, cost_ref, masks_ref = O.mvsnet_forward(imgs_n, proj, nf, mvs_sd, pad=pad, D=D)
+        del cost_ref
+        g = torch.Generator().manual_seed(5)
+        pts, dirs, _, ndc, z, ro, _ = O.build_rays(rig["images_raw"], pose, rig["near_fars"], n_rays, n_samples, pad=pad,
+                                                   t_rand=torch.rand((n_rays, n_samples), generator=g), generator=g)
+        ref = O.rendering(pose, pts, ndc, z, dirs, vol_ref, rig["images_raw"][:, :V], mlp_sd)
+    assert vol_ref.shape == (1, 8, 192, 200, 200)
+
+    mvs = mvs.to(DEV).train(); mvs.D = D
+    mlp = mlp.to(DEV)
+    emb, _ = models.get_embedder(10, 0, 3)
+    qfn = lambda p, vd, f, fn: R.run_network_mvs(p, vd, f, fn, emb, None)
+    qfn._mvsnerf_fused = True
+    pose_d = {k: v.to(DEV) for k, v in pose.items()}
+    with torch.no_grad():
+        vol, feats, dv_g = mvs(imgs_n.to(DEV), proj.to(DEV), nf.to(DEV), pad=pad)
+        assert vol.shape == vol_ref.shape
+        e_feat = maxabs(feats.cpu(), feats_ref)
+        verr = (vol.cpu() - vol_ref).abs()
+        e_vol, rms_vol, vmax = float(verr.max()), float((verr.double() ** 2).mean().sqrt()), float(vol_ref.abs().max())
+        src = rig["images_raw"][:, :V].to(DEV)
+        rays = [t.to(DEV) for t in (pts, ndc, z, ro, dirs)]
+        rgb, feat, wts, depth, alpha, _ = R.rendering(_args(8 + 4 * V, n_samples), pose_d, *rays, vol, src, network_fn=mlp, network_query_fn=qfn)
+        # config 4 names the bf16-MFMA MLP: the same batch through it (not a 1e-4 path: bf16 keeps 8 mantissa bits)
+        ops.set_mlp_precision("bf16")
+        try:
+            rgb_b, *_ = R.rendering(_args(8 + 4 * V, n_samples), pose_d, *rays, vol, src, network_fn=mlp, network_query_fn=qfn)
+        finally:
+            ops.set_mlp_precision("fp32")
+    # (per-sample alpha is not compared: with random weights sigma = relu(.) reaches 1e3+, and a sample hidden behind an opaque one
+    # can flip 0 <-> 1 at relative error 1e-6 without touching a pixel; the composited weights carry what is visible)
+    e_rgb, e_alpha = maxabs(rgb.cpu(), ref[0]), maxabs(wts.cpu(), ref[2])
+    psnr_b = 10 * np.log10(1.0 / max(float(((rgb_b.cpu() - ref[0]) ** 2).mean()), 1e-20))
+    print(f"[config 4 shape] feats err {e_feat:.2e}; volume err max {e_vol:.2e} rms {rms_vol:.2e} (|vol| max {vmax:.2f}); "
+          f"rgb err {e_rgb:.2e}, weights err {e_alpha:.2e}, depth err {maxabs(depth.cpu(), ref[3]):.2e}; bf16-MLP PSNR vs fp32 oracle {psnr_b:.1f} dB")
+    assert e_feat < 1e-4 * max(1.0, float(feats_ref.abs().max()))
+    assert e_vol < 5e-4 * max(1.0, vmax) and rms_vol < 2e-5 * max(1.0, vmax)
+    assert e_rgb < 1e-4
+    assert e_alpha < 2e-4 and maxabs(depth.cpu(), ref[3]) < 1e-3
+    assert psnr_b > 40.0
+
+
+def test_config5_shape_1008x756_target_over_960x640_sources():
+    from mvsnerf_amd import train
+    from oracle import mvsnerf_oracle as O
+    Hs, Ws, Ht, Wt, pad, D, S = 640, 960, 756, 1008, 24, 128, 128
+    mlp_sd, mvs_sd = load_weights()
+    args = train.default_args(pad=pad, batch_size=1024, N_samples=S, chunk=1024)
+    sys_ = train.MVSSystem(args, n_depth_planes=D)
+    sys_.render_kwargs_train["network_fn"].load_state_dict(mlp_sd)
+    sys_.MVSNet.load_state_dict(mvs_sd)
+    sys_ = sys_.to(DEV)
+    batch = train.synthetic_batch(Hs, Ws, seed=505, smooth=True)
+    K_src = batch["intrinsics"][0, 0]
+    K_t = K_src.clone()
+    K_t[0] *= Wt / float(Ws)
+    K_t[1] *= Ht / float(Hs)
+    c2w_t = batch["c2ws"][0, -1].clone()
+    c2w_t[0, 3] += 0.03
+    target = {"hw": (Ht, Wt), "intrinsic": K_t, "c2w": c2w_t, "near_far": batch["near_fars"][0, -1]}
+    rgb, depth = sys_.render_view(batch, chunk=1024, target=target)
+    assert rgb.shape == (Ht, Wt, 3) and depth.shape == (Ht, Wt) and bool(torch.isfinite(rgb).all())
+    rgb, depth = rgb.cpu().reshape(-1, 3), depth.cpu().reshape(-1)
+
+    imgs_n = batch["images"]
+    pose = {k: batch[k][0] for k in ("w2cs", "c2ws", "intrinsics", "near_fars")}
+    with torch.no_grad():
+        vol, *_ = O.mvsnet_forward(imgs_n[:, :3], batch["proj_mats"][:, :3], batch["near_fars"][0, 0], mvs_sd, pad=pad, D=D)
+        assert vol.shape == (1, 8, 128, 208, 288)
+        raw_imgs = train.MVSSystem.unpreprocess(imgs_n)
+        worst_rgb = worst_depth = 0.0
+        n_chunks = (Ht * Wt + 1023) // 1024
+        for idx in (0, n_chunks // 3, n_chunks // 2 + 7, n_chunks - 2):         # 4 x 1024 consecutive pixels spread over the frame
+            pts, dirs, ndc, z, _ = O.build_rays_test(Ht, Wt, c2w_t, pose["w2cs"][0], K_t, pose["near_fars"], pose["near_fars"][-1], S, pad=pad,
+                                                     ref_intrinsic=pose["intrinsics"][0], ref_hw=(Hs, Ws), chunk=1024, idx=idx)
+            ref = O.rendering(pose, pts, ndc, z, dirs, vol, raw_imgs[:, :3], mlp_sd)
+            sl = slice(idx * 1024, idx * 1024 + pts.shape[0])
+            worst_rgb = max(worst_rgb, maxabs(rgb[sl], ref[0]))
+            worst_depth = max(worst_depth, maxabs(depth[sl], ref[3]))
+    print(f"[config 5 shape] 4 x 1024 pixels of the 1008x756 frame: rgb err {worst_rgb:.2e}, depth err {worst_depth:.2e}")
+    assert worst_rgb < 1e-4
+    assert worst_depth < 1e-3
