@@ -251,8 +251,8 @@ def multi_gpu_legs(dev, rank, world, train_steps=5):
                                           "sub-batches per rank, one all_gather of (rgb, depth); strong scaling of the ray part only"}
     del system
     # ---- (ii) data-parallel training step, both modes
-    for mode in ("ray", "scene"):
-        system = load_system(dev, dp_mode=mode)
+    for mode, amp in (("ray", False), ("scene", False), ("ray", True)):      # the last one = BASELINE config 3: bf16 MLP, ray-sharded DP
+        system = load_system(dev, dp_mode=mode, use_amp=amp)
         opt = system.configure_optimizers()[0][0]
         torch.manual_seed(0)
         n_warm = 2
@@ -272,7 +272,7 @@ def multi_gpu_legs(dev, rank, world, train_steps=5):
         if not in_sync:
             raise SystemExit(f"rank {rank}: parameters diverged across ranks after {mode}-sharded steps")
         rays = N_RAYS * (world if mode == "scene" else 1)
-        out[f"train_step_dp_{mode}"] = {"ms": round(dt / train_steps * 1e3, 2), "rays_per_s": round(rays * train_steps / dt, 1), "n_ranks": world,
+        out[f"train_step_dp_{mode}" + ("_bf16" if amp else "")] = {"ms": round(dt / train_steps * 1e3, 2), "mlp_arithmetic": "bf16 MFMA, fp32 accumulate / master weights / gradients" if amp else "fp32 MFMA", "rays_per_s": round(rays * train_steps / dt, 1), "n_ranks": world,
                                         "global_rays_per_step": rays, "params_in_sync": in_sync, "loss_last_rank0": round(losses[-1], 5),
                                         "scaling": "strong (same 1024-ray step, encoder replicated)" if mode == "ray" else "weak (one scene + 1024 rays per rank)",
                                         "note": "fit_steps: training_step fwd+bwd (HIP) + one flat fp32 all-reduce of all gradients (RCCL) + Adam"}
@@ -516,6 +516,16 @@ def main():
             torch.cuda.synchronize(); tdt = (time.perf_counter() - t0) / 5
             extras["train_step"] = {"ms": round(tdt * 1e3, 2), "rays_per_s": round(N_RAYS / tdt, 1), "loss_last": round(losses[-1], 5),
                                     "note": "MVSSystem.training_step fwd+bwd (HIP) + Adam (torch), encoder incl. FeatureNet on HIP, 1024x128, fp32"}
+            # (ii-b) the same step with args.use_amp (BASELINE config 3 "bf16"): MLP forward/backward GEMMs on bf16 MFMA
+            system.args.use_amp = True
+            system.fit_steps([batch] * 2, opt)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            losses_b = system.fit_steps([batch] * 5, opt)
+            torch.cuda.synchronize(); bdt_t = (time.perf_counter() - t0) / 5
+            system.args.use_amp = False
+            extras["train_step_bf16"] = {"ms": round(bdt_t * 1e3, 2), "rays_per_s": round(N_RAYS / bdt_t, 1), "loss_last": round(losses_b[-1], 5),
+                                         "note": "args.use_amp: ray-march MLP on v_mfma_f32_32x32x16_bf16 (forward with activation store, dgrad, wgrad), fp32 "
+                                                 "accumulation / master weights / gradients; encoder kernels fp32"}
         if not a.no_extras and world == 1:
             # (iii) opt-in bf16-MFMA MLP (BASELINE configs 3/4); NOT the headline: results differ from fp32 at the 1e-2 level
             ops.set_mlp_precision("bf16")

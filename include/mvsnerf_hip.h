@@ -251,6 +251,22 @@ int mvsnerf_mlp_fwd_bf16(const void* packed_bf16, const float* packed_f32, int F
                          const float* feat, int feat_stride, const float* dirs, int dirs_stride,
                          int64_t N, int S, int alpha_only, float* raw, void* stream);
 
+/* bf16 TRAINING (the reference's AMP switch, train_mvs_nerf_pl.py:317-318 `precision=16 if args.use_amp`; BASELINE config 3):
+ *   mlp_fwd_bf16_train  = mlp_fwd_bf16 + the activation store of mvsnerf_mlp_fwd_train (fp32 slots: what THIS forward computed)
+ *   mlp_pack_bwd_bf16   W^T fragments for v_mfma_f32_32x32x16_bf16 (mvsnerf_mlp_packed_bwd_bf16_elems() 16-bit elements)
+ *   mlp_bwd_bf16        mvsnerf_mlp_bwd with every GEMM of the backward pass (data gradient W^T products, weight-gradient point
+ *                       contractions) on the bf16 matrix cores: operands rounded to bf16, fp32 accumulate; activation derivatives,
+ *                       bias gradients and reductions fp32; gradients are returned in fp32 (fp32 master weights, fp32 all-reduce). */
+int mvsnerf_mlp_fwd_bf16_train(const void* packed_bf16, const float* packed_f32, int F, const float* ndc, int ndc_stride,
+                               const float* feat, int feat_stride, const float* dirs, int dirs_stride,
+                               int64_t N, int S, float* raw, float* saved, void* stream);
+size_t mvsnerf_mlp_packed_bwd_bf16_elems(void);
+int mvsnerf_mlp_pack_bwd_bf16(const float* const w[11], int F, void* packed_bwd_bf16, void* stream);
+int mvsnerf_mlp_bwd_bf16(const float* packed_fwd, const void* packed_bwd_bf16, int F,
+                         const float* raw, const float* d_raw, const float* saved, int64_t N, int S,
+                         float* gslots, float* d_feat, int n_feat_out, float* const gw[11], float* const gb[11],
+                         const int* maps, float* workspace, void* stream);
+
 /* ---- training path of the MLP (autograd of models.py:194-222) ----
  * mvsnerf_mlp_fwd_train = mvsnerf_mlp_fwd + an activation store `saved` (mvsnerf_mlp_saved_floats(N*S) floats).
  * mvsnerf_mlp_pack_bwd re-lays W^T fragments for the gradient chain (mvsnerf_mlp_packed_bwd_floats() floats).

@@ -104,6 +104,10 @@ SIGNATURES = {
     "mvsnerf_mlp_bwd_workspace_floats": (ctypes.c_size_t, []),
     "mvsnerf_mlp_pack_bwd": (_c_i, [ctypes.POINTER(_c_fp), _c_i, _c_fp, _c_fp]),
     "mvsnerf_mlp_fwd_train": (_c_i, [_c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_i, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_mlp_fwd_bf16_train": (_c_i, [_c_fp, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_i, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_mlp_packed_bwd_bf16_elems": (ctypes.c_size_t, []),
+    "mvsnerf_mlp_pack_bwd_bf16": (_c_i, [ctypes.POINTER(_c_fp), _c_i, _c_fp, _c_fp]),
+    "mvsnerf_mlp_bwd_bf16": (_c_i, [_c_fp, _c_fp, _c_i, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp, _c_i, ctypes.POINTER(_c_fp), ctypes.POINTER(_c_fp), _c_fp, _c_fp, _c_fp]),
     "mvsnerf_mlp_bwd": (_c_i, [_c_fp, _c_fp, _c_i, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp, _c_i, ctypes.POINTER(_c_fp), ctypes.POINTER(_c_fp), _c_fp, _c_fp, _c_fp]),
     "mvsnerf_composite_bwd": (_c_i, [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_volume_sample_bwd": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_fp, _c_l, _c_fp, _c_i, _c_fp, _c_fp]),

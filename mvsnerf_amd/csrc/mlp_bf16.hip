@@ -159,12 +159,16 @@ __device__ __forceinline__ bf16x8 pack8(const float* v)
     return r;
 }
 
-template <bool ALPHA_ONLY>
+// SAVE (bf16 training forward, train_mvs_nerf_pl.py:317-318 `precision=16`): the operands the backward pass consumes are written in
+// the slot format of mlp_layout.h, in fp32 - exactly what the fp32 training forward stores, so that the weight-gradient kernels read
+// the same buffers in either precision.  What is stored is what this forward computed (bf16-rounded operands, fp32 accumulators).
+template <bool ALPHA_ONLY, bool SAVE = false>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_bf16_kernel(
     const __bf16* __restrict__ wq, const float* __restrict__ packed_f32, int F, const float* __restrict__ ndc, int ndc_stride,
     const float* __restrict__ feat, int feat_stride, const float* __restrict__ dirs, int dirs_stride,
-    int64_t P, int S, float* __restrict__ raw)
+    int64_t P, int S, float* __restrict__ raw, float* __restrict__ saved = nullptr)
 {
+    static_assert(!(SAVE && ALPHA_ONLY), "the training forward computes colours too");
     extern __shared__ __attribute__((aligned(16))) char lds_b[];
     char* buf0 = lds_b;
     char* buf1 = lds_b + SLABB_BYTES;
@@ -177,12 +181,15 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_bf16_kernel(
     const int64_t p_raw = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
     const bool live = p_raw < P;
     const int64_t p = live ? p_raw : P - 1;
+    float* sv = nullptr;
+    if (SAVE) sv = saved + ((int64_t)blockIdx.x * 4 + wave) * (SLOTS_SAVED * 64) + lane;
+    auto save = [&](int slot, float v) { if (SAVE) sv[slot * 64] = v; };
 
     // slab 0 = pts_bias weights + layer 0 (contiguous in the packed buffer)
     slabb_dma(buf0, wq + L.featw, L.l1 - L.featw, wave, lane);
     for (int i = tid; i < V_TOTAL; i += 256) vec[i] = packed_f32[LF.vec + i];
     const float px = ndc[p * ndc_stride + 0], py = ndc[p * ndc_stride + 1], pz = ndc[p * ndc_stride + 2];
-    float fv[24];
+    float fv[24];                                 // F/2 <= 20 feature operands of this lane half (the store keeps the first 16: F <= 32 when training)
     {
         const float* fp = feat + p * feat_stride + half * (F / 2);
 #pragma unroll
@@ -214,14 +221,20 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_bf16_kernel(
         else if (L.fsteps == 2) gemm_b<2, 4>(buf0, acc, lane, fb);
         else gemm_b<3, 4>(buf0, acc, lane, fb);
 #pragma unroll
-        for (int q = 0; q < 64; ++q) bias[q] = acc[q >> 4][q & 15];
+        for (int q = 0; q < 64; ++q) { bias[q] = acc[q >> 4][q & 15]; save(S_BM + q, bias[q]); }
+        if (SAVE) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) save(S_FV + t, fv[t]);
+#pragma unroll
+            for (int t = 0; t < PE_STEPS; ++t) save(S_E + t, pe_op(t, half, px, py, pz));
+        }
     }
     {   // layer 0
         f32x16 acc[4];
         init_acc_b<4>(acc, vec + V_L0 + half * 64);
         gemm_b<B_PE_STEPS, 4>(buf0 + b_seg(L.fsteps, 4) * 2, acc, lane, [&](int s) { return pe8[s]; });
 #pragma unroll
-        for (int q = 0; q < 64; ++q) hf[q] = fmaxf(acc[q >> 4][q & 15] * bias[q], 0.0f);
+        for (int q = 0; q < 64; ++q) { hf[q] = fmaxf(acc[q >> 4][q & 15] * bias[q], 0.0f); save(S_H + q, hf[q]); }
         to_b();
     }
     // layers 1..4: slabs alternate buf1, buf0, buf1, buf0
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_bf16_kernel(
         init_acc_b<4>(acc, vec + V_L0 + 128 * layer + half * 64);
         gemm_b<B_ACT_STEPS, 4>(cur, acc, lane, [&](int s) { return hb[s]; });
 #pragma unroll
-        for (int q = 0; q < 64; ++q) hf[q] = fmaxf(acc[q >> 4][q & 15] * bias[q], 0.0f);
+        for (int q = 0; q < 64; ++q) { hf[q] = fmaxf(acc[q >> 4][q & 15] * bias[q], 0.0f); save(S_H + layer * 64 + q, hf[q]); }
         to_b();
     }
     float sigma;
@@ -250,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_bf16_kernel(
         if (!ALPHA_ONLY) slabb_dma(buf1, wq + L.feat, b_seg(B_ACT_STEPS, 4), wave, lane);
         gemm_b<B_ACT_STEPS, 4>(buf0, acc, lane, [&](int s) { return hb[s]; });
 #pragma unroll
-        for (int q = 0; q < 64; ++q) hf[q] = fmaxf(acc[q >> 4][q & 15] * bias[q], 0.0f);
+        for (int q = 0; q < 64; ++q) { hf[q] = fmaxf(acc[q >> 4][q & 15] * bias[q], 0.0f); save(S_H + 5 * 64 + q, hf[q]); }
         const float* wa = vec + V_WA + half * 64;
         float part = 0.0f;
 #pragma unroll
@@ -270,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_bf16_kernel(
         init_acc_b<4>(acc, vec + V_FEAT + half * 64);
         gemm_b<B_ACT_STEPS, 4>(buf1, acc, lane, [&](int s) { return hb[s]; });
 #pragma unroll
-        for (int q = 0; q < 64; ++q) hf[q] = acc[q >> 4][q & 15];
+        for (int q = 0; q < 64; ++q) { hf[q] = acc[q >> 4][q & 15]; save(S_FE + q, hf[q]); }
         to_b();
     }
     {   // views_linears[0] + rgb head
@@ -283,6 +296,12 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_bf16_kernel(
         slabb_sync();
         init_acc_b<2>(acc, vec + V_VIEWS + half * 32);
         gemm_b<B_VIEW_STEPS, 2>(buf0, acc, lane, [&](int s) { return s < 8 ? hb[s < 8 ? s : 0] : d8; });
+        if (SAVE) {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) save(S_HV + q, fmaxf(acc[q >> 4][q & 15], 0.0f));
+            save(S_DR + 0, dl[0]);
+            save(S_DR + 1, dl[1]);
+        }
         float rgb[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -782,6 +801,24 @@ extern "C" int mvsnerf_mlp_fwd_bf16(const void* packed_bf16, const float* packed
         mlp_fwd_bf16_kernel<true><<<mvs_cdiv(P, 128), 256, B_LDS_BYTES, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
     else
         mlp_fwd_bf16_kernel<false><<<mvs_cdiv(P, 128), 256, B_LDS_BYTES, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// bf16 training forward: mvsnerf_mlp_fwd_bf16 + the activation store of mvsnerf_mlp_fwd_train (same slot format, fp32)
+extern "C" int mvsnerf_mlp_fwd_bf16_train(const void* packed_bf16, const float* packed_f32, int F, const float* ndc, int ndc_stride,
+                                          const float* feat, int feat_stride, const float* dirs, int dirs_stride,
+                                          int64_t N, int S, float* raw, float* saved, void* stream)
+{
+    if (!packed_bf16 || !packed_f32 || !ndc || !feat || !dirs || !raw || !saved || N < 0 || S < 1 || feat_stride < F || ndc_stride < 3 || dirs_stride < 3) return MVSNERF_EINVAL;
+    if (F < 2 || F > 32 || (F & 1)) return MVSNERF_EUNSUPPORTED;
+    if (!mvs_aligned16(packed_bf16) || !mvs_aligned16(raw) || !mvs_aligned16(saved)) return MVSNERF_EALIGN;
+    const int64_t P = N * S;
+    if (P == 0) return MVSNERF_OK;
+    static unsigned long long cap = 0;
+    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_bf16_kernel<false, true>), (int)(B_LDS_BYTES), &cap)) return rc_;
+    mlp_fwd_bf16_kernel<false, true><<<mvs_cdiv(P, 128), 256, B_LDS_BYTES, (hipStream_t)stream>>>(
+        reinterpret_cast<const __bf16*>(packed_bf16), packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, saved);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }

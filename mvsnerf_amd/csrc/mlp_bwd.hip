@@ -60,6 +60,68 @@ extern "C" int mvsnerf_mlp_pack_bwd(const float* const w[11], int F, float* pack
     return MVSNERF_OK;
 }
 
+// ---- bf16 variant of the transposed segments (v_mfma_f32_32x32x16_bf16: a k-step spans 16 contraction indices, 8 per lane half;
+// element j of lane (i, h) of step s, block kb = W[n(8s + j, h)][col_off + 32 kb + i]); offsets in bf16 elements
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct LayoutBwdB { size_t views, feat, l5, l4, l3, l2, l1, bias, total; };
+__host__ __device__ inline size_t segb(int steps, int nb) { return (size_t)steps * nb * 64 * 8; }
+__host__ __device__ inline LayoutBwdB layout_bwd_b()
+{
+    LayoutBwdB L;
+    size_t o = 0;
+    L.views = o; o += segb(4, 4);
+    L.feat = o;  o += segb(8, 4);
+    L.l5 = o;    o += segb(8, 4);
+    L.l4 = o;    o += segb(8, 4);
+    L.l3 = o;    o += segb(8, 4);
+    L.l2 = o;    o += segb(8, 4);
+    L.l1 = o;    o += segb(8, 4);
+    L.bias = o;  o += segb(8, 1);
+    L.total = o;
+    return L;
+}
+
+__device__ inline void pack_tb_segment(__bf16* __restrict__ dst, const float* __restrict__ W, int ld, int col_off, int n_cols,
+                                       int steps, int nb, int tid, int nthreads)
+{
+    const int total = steps * nb * 64 * 8;
+    for (int i = tid; i < total; i += nthreads) {
+        const int j = i & 7, lane = (i >> 3) & 63, rest = i >> 9;
+        const int kb = rest % nb, s = rest / nb;
+        const int n = act_n(8 * s + j, lane >> 5);
+        const int k = kb * 32 + (lane & 31);
+        dst[i] = (__bf16)(k < n_cols ? W[(size_t)n * ld + col_off + k] : 0.0f);
+    }
+}
+
+__global__ __launch_bounds__(256) void mlp_pack_bwd_bf16_kernel(PackBwdArgs a, __bf16* __restrict__ packed)
+{
+    const LayoutBwdB L = layout_bwd_b();
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    pack_tb_segment(packed + L.views, a.w[9], WIDTH + 3, 0, WIDTH, 4, 4, tid, nt);
+    pack_tb_segment(packed + L.feat, a.w[7], WIDTH, 0, WIDTH, 8, 4, tid, nt);
+    pack_tb_segment(packed + L.l5, a.w[5], WIDTH + PE_DIM, PE_DIM, WIDTH, 8, 4, tid, nt);
+    pack_tb_segment(packed + L.l4, a.w[4], WIDTH, 0, WIDTH, 8, 4, tid, nt);
+    pack_tb_segment(packed + L.l3, a.w[3], WIDTH, 0, WIDTH, 8, 4, tid, nt);
+    pack_tb_segment(packed + L.l2, a.w[2], WIDTH, 0, WIDTH, 8, 4, tid, nt);
+    pack_tb_segment(packed + L.l1, a.w[1], WIDTH, 0, WIDTH, 8, 4, tid, nt);
+    pack_tb_segment(packed + L.bias, a.w[6], a.F, 0, a.F, 8, 1, tid, nt);
+}
+
+extern "C" size_t mvsnerf_mlp_packed_bwd_bf16_elems(void) { return layout_bwd_b().total; }
+
+extern "C" int mvsnerf_mlp_pack_bwd_bf16(const float* const w[11], int F, void* packed_bwd_bf16, void* stream)
+{
+    if (!w || !packed_bwd_bf16) return MVSNERF_EINVAL;
+    if (F < 2 || F > 32 || (F & 1)) return MVSNERF_EUNSUPPORTED;
+    PackBwdArgs a;
+    for (int i = 0; i < 11; ++i) { if (!w[i]) return MVSNERF_EINVAL; a.w[i] = w[i]; }
+    a.F = F;
+    mlp_pack_bwd_bf16_kernel<<<64, 256, 0, (hipStream_t)stream>>>(a, reinterpret_cast<__bf16*>(packed_bwd_bf16));
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
 extern "C" size_t mvsnerf_mlp_saved_floats(int64_t n_points) { return (size_t)((n_points + 127) / 128) * 4 * SLOTS_SAVED * 64; }
 extern "C" size_t mvsnerf_mlp_gradslot_floats(int64_t n_points) { return (size_t)((n_points + 127) / 128) * 4 * SLOTS_GRAD * 64; }
 
@@ -100,6 +162,24 @@ __device__ __forceinline__ void gemm_t(const float* __restrict__ w, f32x16 (&acc
     }
 }
 
+// bf16 form: STEPS k-steps of 16 (8 per lane half); B operand = this lane's gradient registers 8s..8s+7 rounded to bf16
+template <int STEPS, int NBLK>
+__device__ __forceinline__ void gemm_tb(const float* __restrict__ w, f32x16 (&acc)[NBLK], int lane, const float* __restrict__ g)
+{
+    const char* wb = reinterpret_cast<const char*>(w);
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        bf16x8 bv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[j] = (__bf16)g[8 * s + j];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(wb + ((s * NBLK + b) * 64 + lane) * 16);
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc[b], 0, 0, 0);
+        }
+    }
+}
+
 template <int NBLK>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NBLK])
 {
@@ -109,6 +189,9 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NBLK])
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
 }
 
+// BF: the transposed weights are bf16 fragments (mvsnerf_mlp_pack_bwd_bf16) and every W^T product runs on
+// v_mfma_f32_32x32x16_bf16 with the gradient operand rounded to bf16 (fp32 accumulate); everything else is unchanged fp32.
+template <bool BF>
 __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
     const float* __restrict__ packed_fwd, int F, const float* __restrict__ packed_bwd,
     const float* __restrict__ raw, const float* __restrict__ d_raw, const float* __restrict__ saved,
@@ -119,7 +202,15 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
     float* buf1 = lds + WBUF_FLOATS;
     float* vec = lds + 2 * WBUF_FLOATS;
     const Layout LF = layout(F);
-    const LayoutBwd L = layout_bwd();
+    // segment offsets and sizes in FLOAT units of the packed buffer (a bf16 segment of n elements occupies n/2 floats)
+    struct Seg { size_t views, feat, l5, bias; int n_views, n_act, n_bias; } L;
+    if (BF) {
+        const LayoutBwdB B = layout_bwd_b();
+        L = Seg{B.views / 2, B.feat / 2, B.l5 / 2, B.bias / 2, (int)(segb(4, 4) / 2), (int)(segb(8, 4) / 2), (int)(segb(8, 1) / 2)};
+    } else {
+        const LayoutBwd B = layout_bwd();
+        L = Seg{B.views, B.feat, B.l5, B.bias, (int)seg_floats(32, 4), (int)seg_floats(ACT_STEPS, 4), (int)seg_floats(ACT_STEPS, 1)};
+    }
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
@@ -128,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
     const float* sv = saved + tile * (SLOTS_SAVED * 64) + lane;
     float* gs = gslots + tile * (SLOTS_GRAD * 64) + lane;
 
-    wdma(buf0, packed_bwd + L.views, (int)seg_floats(32, 4), wave, lane);            // segment 0 -> buf0
+    wdma(buf0, packed_bwd + L.views, L.n_views, wave, lane);                         // segment 0 -> buf0
     for (int i = tid; i < V_TOTAL; i += 256) vec[i] = packed_fwd[LF.vec + i];
 
     // heads: rgb = sigmoid(z), sigma = relu(s)   (models.py:209,217)
@@ -140,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
 #pragma unroll
     for (int q = 0; q < 32; ++q) hv[q] = sv[(S_HV + q) * 64];
     wsync();                                                                           // vec + segment 0 visible
-    wdma(buf1, packed_bwd + L.feat, WBUF_FLOATS, wave, lane);                        // segment 1 -> buf1
+    wdma(buf1, packed_bwd + L.feat, L.n_act, wave, lane);                            // segment 1 -> buf1
     gs[(G_G4 + 0) * 64] = half ? gz1 : gz0;
     gs[(G_G4 + 1) * 64] = half ? gsg : gz2;
 
@@ -159,7 +250,8 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
     {
         f32x16 acc[4];
         zero_acc<4>(acc);
-        gemm_t<8, 4>(buf0, acc, lane, [&](int t) { return gh[t]; });
+        if (BF) gemm_tb<4, 4>(buf0, acc, lane, gh);
+        else gemm_t<8, 4>(buf0, acc, lane, [&](int t) { return gh[t]; });
 #pragma unroll
         for (int q = 0; q < 64; ++q) gh[q] = acc[q >> 4][q & 15];
     }
@@ -168,13 +260,14 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
     {
         f32x16 acc[4];
         wsync();                                                                       // segment 1 landed; buf0 free
-        wdma(buf0, packed_bwd + L.l5, WBUF_FLOATS, wave, lane);                      // segment 2 -> buf0
+        wdma(buf0, packed_bwd + L.l5, L.n_act, wave, lane);                          // segment 2 -> buf0
 #pragma unroll
         for (int q = 0; q < 64; ++q) gs[(G_GF + q) * 64] = gh[q];
 #pragma unroll
         for (int q = 0; q < 64; ++q) hq[q] = sv[(S_H + 5 * 64 + q) * 64];
         zero_acc<4>(acc);
-        gemm_t<16, 4>(buf1, acc, lane, [&](int t) { return gh[t]; });
+        if (BF) gemm_tb<8, 4>(buf1, acc, lane, gh);
+        else gemm_t<16, 4>(buf1, acc, lane, [&](int t) { return gh[t]; });
         const float* wa = vec + V_WA + half * 64;
 #pragma unroll
         for (int q = 0; q < 64; ++q) gh[q] = fmaf(wa[q], gsg, acc[q >> 4][q & 15]);
@@ -196,8 +289,8 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
         float* cur = (layer & 1) ? buf0 : buf1;
         float* nxt = (layer & 1) ? buf1 : buf0;
         wsync();                                                                       // this layer's segment landed; the other buffer is free
-        if (layer >= 2) wdma(nxt, packed_bwd + L.l5 + (size_t)(6 - layer) * seg_floats(ACT_STEPS, 4), WBUF_FLOATS, wave, lane);
-        else if (layer == 1) wdma(nxt, packed_bwd + L.bias, (int)seg_floats(ACT_STEPS, 1), wave, lane);
+        if (layer >= 2) wdma(nxt, packed_bwd + L.l5 + (size_t)(6 - layer) * L.n_act, L.n_act, wave, lane);
+        else if (layer == 1) wdma(nxt, packed_bwd + L.bias, L.n_bias, wave, lane);
 #pragma unroll
         for (int q = 0; q < 64; ++q) gs[(G_GP + layer * 64 + q) * 64] = gh[q];
         if (layer == 0) break;
@@ -205,7 +298,8 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
         for (int q = 0; q < 64; ++q) hq[q] = sv[(S_H + (layer - 1) * 64 + q) * 64];
         f32x16 acc[4];
         zero_acc<4>(acc);
-        gemm_t<16, 4>(cur, acc, lane, [&](int t) { return gh[t]; });
+        if (BF) gemm_tb<8, 4>(cur, acc, lane, gh);
+        else gemm_t<16, 4>(cur, acc, lane, [&](int t) { return gh[t]; });
 #pragma unroll
         for (int q = 0; q < 64; ++q) gh[q] = acc[q >> 4][q & 15];
     }
@@ -216,7 +310,8 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
     {
         f32x16 acc[1];
         zero_acc<1>(acc);
-        gemm_t<16, 1>(buf1, acc, lane, [&](int t) { return gbm[t]; });
+        if (BF) gemm_tb<8, 1>(buf1, acc, lane, gbm);
+        else gemm_t<16, 1>(buf1, acc, lane, [&](int t) { return gbm[t]; });
         // C/D rows (r&3)+8*(r>>2)+4*half: registers 4q..4q+3 are feature columns 8q + 4*half + (0..3); the first n_feat_out
         // columns are stored (8: the trilinear volume features; F: every input feature, for a colour volume that is trained too)
         if (live) {
@@ -238,7 +333,9 @@ struct WgradArgs {
     float* partial;      // [gridDim.x][RA][RB + 1]  (last column = row sums)
 };
 
-template <int RA_BLOCKS, int NBB>
+// BF: both operand rows are rounded to bf16 on load and the 32 points of a tile are contracted by two v_mfma_f32_32x32x16_bf16
+// (lane (i, kkh) holds points [16 kkh, 16 kkh + 16): MFMA m takes its points 8m..8m+7 - the same assignment for A and B).
+template <int RA_BLOCKS, int NBB, bool BF>
 __global__ __launch_bounds__(64 * RA_BLOCKS) void mlp_wgrad_kernel(WgradArgs w)
 {
     const int lane = threadIdx.x & 63, ablk = threadIdx.x >> 6;
@@ -263,12 +360,30 @@ __global__ __launch_bounds__(64 * RA_BLOCKS) void mlp_wgrad_kernel(WgradArgs w)
 #pragma unroll
             for (int k = 0; k < 4; ++k) b4[bb][k] = *reinterpret_cast<const f32x4*>(bp + k * 4);
         }
+        if constexpr (BF) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float av = a4[s >> 2][s & 3];
-            rsum += av;
+            for (int s = 0; s < 16; ++s) rsum += a4[s >> 2][s & 3];                    // bias gradient: fp32 row sums
 #pragma unroll
-            for (int bb = 0; bb < NBB; ++bb) acc[bb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b4[bb][s >> 2][s & 3], acc[bb], 0, 0, 0);
+            for (int m = 0; m < 2; ++m) {
+                bf16x8 av;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) av[j] = (__bf16)a4[2 * m + (j >> 2)][j & 3];
+#pragma unroll
+                for (int bb = 0; bb < NBB; ++bb) {
+                    bf16x8 bv;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bv[j] = (__bf16)b4[bb][2 * m + (j >> 2)][j & 3];
+                    acc[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[bb], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float av = a4[s >> 2][s & 3];
+                rsum += av;
+#pragma unroll
+                for (int bb = 0; bb < NBB; ++bb) acc[bb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b4[bb][s >> 2][s & 3], acc[bb], 0, 0, 0);
+            }
         }
     }
     constexpr int RA = RA_BLOCKS * 32;
@@ -303,9 +418,9 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------ host orchestration
-static int launch_wgrad(int ra_blocks, int nbb, const WgradArgs& w, int grid, hipStream_t st)
+static int launch_wgrad(int ra_blocks, int nbb, const WgradArgs& w, int grid, hipStream_t st, bool bf)
 {
-#define MVS_WG(RAB, NB) mlp_wgrad_kernel<RAB, NB><<<grid, 64 * RAB, 0, st>>>(w)
+#define MVS_WG(RAB, NB) do { if (bf) mlp_wgrad_kernel<RAB, NB, true><<<grid, 64 * RAB, 0, st>>>(w); else mlp_wgrad_kernel<RAB, NB, false><<<grid, 64 * RAB, 0, st>>>(w); } while (0)
     switch (ra_blocks * 10 + nbb) {
         case 42: MVS_WG(4, 2); break;
         case 44: MVS_WG(4, 4); break;
@@ -327,10 +442,36 @@ extern "C" size_t mvsnerf_mlp_bwd_workspace_floats(void) { return (size_t)(256 +
 //   [2] pe (64): r=2t+h -> embedding column or -1          [3] pe_l5 (64): same (columns 0..62 of the 191-wide layer 5)
 //   [4] feat (32): r=2t+h -> feature column or -1          [5] h_l5 (128): 63 + n(q,h)
 //   [6] dir (32): r -> 128 + {0,1,2} or -1                 [7] g4_rgb (32): 0,1,2 -> rgb row, else -1   [8] g4_alpha (32): 3 -> 0
+static int mlp_bwd_impl(bool bf, const float* packed_fwd, const float* packed_bwd, int F,
+                        const float* raw, const float* d_raw, const float* saved, int64_t N, int S,
+                        float* gslots, float* d_feat, int n_feat_out, float* const gw[11], float* const gb[11],
+                        const int* maps, float* workspace, void* stream);
+
 extern "C" int mvsnerf_mlp_bwd(const float* packed_fwd, const float* packed_bwd, int F,
                                const float* raw, const float* d_raw, const float* saved, int64_t N, int S,
                                float* gslots, float* d_feat, int n_feat_out, float* const gw[11], float* const gb[11],
                                const int* maps, float* workspace, void* stream)
+{
+    return mlp_bwd_impl(false, packed_fwd, packed_bwd, F, raw, d_raw, saved, N, S, gslots, d_feat, n_feat_out, gw, gb, maps, workspace, stream);
+}
+
+// bf16 backward (AMP-style): every GEMM of the backward pass - W^T products of the data gradient and the point contractions of
+// the weight gradients - on v_mfma_f32_32x32x16_bf16 with operands rounded to bf16 and fp32 accumulation; activation-function
+// derivatives, the multiplicative bias modulation, the bias gradients and the reductions stay fp32; the gradients come back fp32
+// (fp32 master weights, fp32 all-reduce).  packed_bwd_bf16: mvsnerf_mlp_pack_bwd_bf16.  `saved` may come from either training forward.
+extern "C" int mvsnerf_mlp_bwd_bf16(const float* packed_fwd, const void* packed_bwd_bf16, int F,
+                                    const float* raw, const float* d_raw, const float* saved, int64_t N, int S,
+                                    float* gslots, float* d_feat, int n_feat_out, float* const gw[11], float* const gb[11],
+                                    const int* maps, float* workspace, void* stream)
+{
+    return mlp_bwd_impl(true, packed_fwd, reinterpret_cast<const float*>(packed_bwd_bf16), F, raw, d_raw, saved, N, S, gslots, d_feat, n_feat_out,
+                        gw, gb, maps, workspace, stream);
+}
+
+static int mlp_bwd_impl(bool bf, const float* packed_fwd, const float* packed_bwd, int F,
+                        const float* raw, const float* d_raw, const float* saved, int64_t N, int S,
+                        float* gslots, float* d_feat, int n_feat_out, float* const gw[11], float* const gb[11],
+                        const int* maps, float* workspace, void* stream)
 {
     if (!packed_fwd || !packed_bwd || !raw || !d_raw || !saved || !gslots || !d_feat || !gw || !gb || !maps || !workspace) return MVSNERF_EINVAL;
     if (n_feat_out < 4 || n_feat_out > F || (n_feat_out & 3) || !mvs_aligned16(d_feat)) return MVSNERF_EINVAL;
@@ -341,9 +482,11 @@ extern "C" int mvsnerf_mlp_bwd(const float* packed_fwd, const float* packed_bwd,
     const unsigned nwg = mvs_cdiv(P, 128);
     const int64_t n_tiles = (int64_t)nwg * 4;
     const size_t lds_bytes = LDS_FLOATS * sizeof(float);
-    static unsigned long long lds_cap_set = 0;          // per-device bit mask (common.h)
-    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_dgrad_kernel), (int)lds_bytes, &lds_cap_set)) return rc_;
-    mlp_dgrad_kernel<<<nwg, 256, lds_bytes, st>>>(packed_fwd, F, packed_bwd, raw, d_raw, saved, P, gslots, d_feat, n_feat_out);
+    static unsigned long long lds_cap_set = 0, lds_cap_set_b = 0;          // per-device bit masks (common.h)
+    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_dgrad_kernel<false>), (int)lds_bytes, &lds_cap_set)) return rc_;
+    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_dgrad_kernel<true>), (int)lds_bytes, &lds_cap_set_b)) return rc_;
+    if (bf) mlp_dgrad_kernel<true><<<nwg, 256, lds_bytes, st>>>(packed_fwd, F, packed_bwd, raw, d_raw, saved, P, gslots, d_feat, n_feat_out);
+    else mlp_dgrad_kernel<false><<<nwg, 256, lds_bytes, st>>>(packed_fwd, F, packed_bwd, raw, d_raw, saved, P, gslots, d_feat, n_feat_out);
     MVS_LAUNCH_CHECK();
 
     const int* M_ACT128 = maps, *M_ACT64 = maps + 128, *M_PE = maps + 192, *M_FEAT = maps + 320, *M_HL5 = maps + 352,
@@ -353,7 +496,7 @@ extern "C" int mvsnerf_mlp_bwd(const float* packed_fwd, const float* packed_bwd,
     int rc;
     auto gemm = [&](int a_slot, int ra_blocks, int b_slot0, int nblk0, int b_slot1, int nbb) -> int {
         WgradArgs w{gslots, ts_g, a_slot, saved, ts_s, b_slot0, nblk0, b_slot1, n_tiles, workspace};
-        return launch_wgrad(ra_blocks, nbb, w, grid, st);
+        return launch_wgrad(ra_blocks, nbb, w, grid, st, bf);
     };
     // partials [grid][RA*(RB+1)] -> one slice (two-stage sum over the workgroups: a single pass walks `grid` strided values per
     // thread on a few dozen workgroups and cost 61 us per call), then the fragment-order -> nn.Linear scatter

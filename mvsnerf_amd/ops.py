@@ -245,15 +245,32 @@ N_SPLIT = {"bf16x3": 2, "bf16x6": 3}
 
 
 def set_mlp_precision(mode):
-    """Select the matrix-core arithmetic of the inference MLP:
-      "fp32"    v_mfma_f32_32x32x2_f32 (default; the headline / parity path)
-      "bf16"    v_mfma_f32_32x32x16_bf16, operands rounded to bf16 (BASELINE configs 3/4; ~1e-2 errors)
+    """Select the matrix-core arithmetic of the MLP:
+      "fp32"    v_mfma_f32_32x32x2_f32 (default; the headline / parity path; inference and training)
+      "bf16"    v_mfma_f32_32x32x16_bf16, operands rounded to bf16 (BASELINE configs 3/4; ~1e-2 errors); in training this is the
+                reference's AMP switch (train_mvs_nerf_pl.py:317-318): forward, data- and weight-gradient GEMMs on bf16 operands
+                with fp32 accumulation, fp32 master weights and fp32 gradients
+      (the split modes below are inference-only)
       "bf16x6"  split-bf16 fp32 emulation: operands as 3 bf16 pieces, 6 bf16 MFMAs per product (fp32-grade results)
       "bf16x3"  2 pieces, 3 MFMAs (~1e-5 relative)"""
     global MLP_PRECISION
     if mode not in ("fp32", "bf16", "bf16x3", "bf16x6"):
         raise ValueError("mlp precision must be 'fp32', 'bf16', 'bf16x3' or 'bf16x6'")
     MLP_PRECISION = mode
+
+
+class mlp_precision:
+    """`with ops.mlp_precision("bf16"): ...` - set_mlp_precision for the duration of a block (the previous mode is restored)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = MLP_PRECISION
+        set_mlp_precision(self.mode)
+
+    def __exit__(self, *exc):
+        set_mlp_precision(self.prev)
 
 
 def mlp_pack_split(weights, F, n_split):
@@ -418,6 +435,14 @@ def _mlp_bwd_maps(F, device):
     return out
 
 
+def mlp_pack_bwd_bf16(weights, F):
+    n = _lib.lib().mvsnerf_mlp_packed_bwd_bf16_elems()
+    packed = torch.empty(n, device=weights[0].device, dtype=torch.bfloat16)
+    wp = (ctypes.c_void_p * 11)(*[dev_f32(w, "weight") for w in weights])
+    check(_lib.lib().mvsnerf_mlp_pack_bwd_bf16(wp, F, packed.data_ptr(), stream_ptr()), "mlp_pack_bwd_bf16")
+    return packed
+
+
 def mlp_pack_bwd(weights, F):
     n = _lib.lib().mvsnerf_mlp_packed_bwd_floats()
     packed = torch.empty(n, device=weights[0].device, dtype=torch.float32)
@@ -456,11 +481,19 @@ class RayMarchFunction(torch.autograd.Function):
                                          N, S, dev_f32(rays_dir, "rays_dir"), feat.data_ptr(), F, dirs.data_ptr(), st), "gather_fwd")
         else:
             raise RuntimeError(f"ray march: the volume has {C} channels; expected 8 or 8 + 4V = {F}")
-        check(lib.mvsnerf_mlp_fwd_train(packed.data_ptr(), F, rays_ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3, N, S,
-                                        raw.data_ptr(), saved.data_ptr(), st), "mlp_fwd_train")
+        bf16 = MLP_PRECISION == "bf16"
+        if MLP_PRECISION not in ("fp32", "bf16"):
+            raise RuntimeError(f"training runs the MLP in 'fp32' or 'bf16' (ops.set_mlp_precision), not {MLP_PRECISION!r}")
+        if bf16:
+            packed_b = mlp_pack_bf16([p.detach() for p in mlp_params[0::2]], F)
+            check(lib.mvsnerf_mlp_fwd_bf16_train(packed_b.data_ptr(), packed.data_ptr(), F, rays_ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3,
+                                                 N, S, raw.data_ptr(), saved.data_ptr(), st), "mlp_fwd_bf16_train")
+        else:
+            check(lib.mvsnerf_mlp_fwd_train(packed.data_ptr(), F, rays_ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3, N, S,
+                                            raw.data_ptr(), saved.data_ptr(), st), "mlp_fwd_train")
         rgb, disp, acc, weights, depth, alpha = composite(raw, z_vals, white_bkgd)
         ctx.save_for_backward(rays_ndc, z_vals, raw, saved, packed, *mlp_params)
-        ctx.meta = (tuple(volume.shape), (D, H, W, C), N, S, F, bool(white_bkgd))
+        ctx.meta = (tuple(volume.shape), (D, H, W, C), N, S, F, bool(white_bkgd), bf16)
         ctx.mark_non_differentiable(feat, raw)
         return rgb, feat, weights, depth, alpha, raw
 
@@ -468,7 +501,7 @@ class RayMarchFunction(torch.autograd.Function):
     def backward(ctx, g_rgb, g_feat, g_weights, g_depth, g_alpha, g_raw):
         lib = _lib.lib()
         rays_ndc, z_vals, raw, saved, packed, *mlp_params = ctx.saved_tensors
-        vshape, (D, H, W, C), N, S, F, white = ctx.meta
+        vshape, (D, H, W, C), N, S, F, white, bf16 = ctx.meta
         dev = raw.device
         f32 = dict(device=dev, dtype=torch.float32)
         st = stream_ptr()
@@ -479,7 +512,7 @@ class RayMarchFunction(torch.autograd.Function):
         check(lib.mvsnerf_composite_bwd(raw.data_ptr(), z_vals.data_ptr(), N, S, int(white), ptr(g_rgb_c), ptr(g_depth_c), 0,
                                         ptr(g_w_c), ptr(g_a_c), d_raw.data_ptr(), st), "composite_bwd")
         weights = [p.detach() for p in mlp_params[0::2]]
-        packed_bwd = mlp_pack_bwd(weights, F)
+        packed_bwd = mlp_pack_bwd_bf16(weights, F) if bf16 else mlp_pack_bwd(weights, F)
         gslots = torch.empty(lib.mvsnerf_mlp_gradslot_floats(N * S), **f32)
         ws = torch.empty(lib.mvsnerf_mlp_bwd_workspace_floats(), **f32)
         d_feat = torch.empty((N * S, C), **f32)         # C = 8: the volume features only; C = F: the colour volume is a parameter too
@@ -488,7 +521,7 @@ class RayMarchFunction(torch.autograd.Function):
         gwp = (ctypes.c_void_p * 11)(*[g.data_ptr() for g in gws])
         gbp = (ctypes.c_void_p * 11)(*[g.data_ptr() for g in gbs])
         maps = _mlp_bwd_maps(F, dev)
-        check(lib.mvsnerf_mlp_bwd(packed.data_ptr(), packed_bwd.data_ptr(), F, raw.data_ptr(), d_raw.data_ptr(), saved.data_ptr(), N, S,
+        check((lib.mvsnerf_mlp_bwd_bf16 if bf16 else lib.mvsnerf_mlp_bwd)(packed.data_ptr(), packed_bwd.data_ptr(), F, raw.data_ptr(), d_raw.data_ptr(), saved.data_ptr(), N, S,
                                   gslots.data_ptr(), d_feat.data_ptr(), C, gwp, gbp, maps.data_ptr(), ws.data_ptr(), st), "mlp_bwd")
         g_vol = None
         if ctx.needs_input_grad[0]:

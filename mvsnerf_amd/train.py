@@ -14,6 +14,10 @@ mvsnerf_amd.distributed.FlatGradAllReduce, RCCL over xGMI on GPUs), two modes se
   "scene" each rank takes a DIFFERENT (scan, ref view) sample and its own 1024 rays - what Lightning DDP + DistributedSampler
           would give the reference (train_mvs_nerf_pl.py:306,313): the effective batch is `world` scenes per step and the
           whole step is divided (speed-up ~world x; BN batch statistics are per rank, as under DDP without SyncBN).
+
+`args.use_amp` (the reference's `precision=16 if args.use_amp`, train_mvs_nerf_pl.py:317-318; BASELINE config 3 "bf16"): the ray-march MLP
+trains on v_mfma_f32_32x32x16_bf16 - forward with activation store, data- and weight-gradient GEMMs - with fp32 accumulation, fp32
+master weights and an fp32 gradient all-reduce.  The encoder (FeatureNet, plane sweep, CostRegNet) has fp32 kernels only.
 """
 import os
 
@@ -125,8 +129,11 @@ class MVSSystem(_ModuleShim):
         if self.dp_mode() == "ray":                                      # same draw on all ranks (seeded in fit_steps), local slice
             (rays_pts, rays_dir, target_s, rays_NDC, depth_candidates, rays_depth, rays_o), loss_scale = D.shard_ray_batch(
                 (rays_pts, rays_dir, target_s, rays_NDC, depth_candidates, rays_depth, rays_o), N_rays)     # rays_o is (3, N): sliced in dim 1
-        rgb, disp, acc, depth_pred, alpha, ret = rendering(args, pose_ref, rays_pts, rays_NDC, depth_candidates, rays_o, rays_dir,
-                                                           volume_feature, imgs[:, :-1], img_feat=None, **self.render_kwargs_train)   # :123
+        # --use_amp (train_mvs_nerf_pl.py:317-318 `precision=16`): the MLP's forward / backward GEMMs on the bf16 matrix cores with
+        # fp32 accumulation, master weights and gradients; the encoder kernels stay fp32 (module docstring)
+        with ops.mlp_precision("bf16" if getattr(args, "use_amp", False) else ops.MLP_PRECISION):
+            rgb, disp, acc, depth_pred, alpha, ret = rendering(args, pose_ref, rays_pts, rays_NDC, depth_candidates, rays_o, rays_dir,
+                                                               volume_feature, imgs[:, :-1], img_feat=None, **self.render_kwargs_train)   # :123
         loss = 0
         if getattr(args, "with_depth", False):
             mask = rays_depth > 0
@@ -266,7 +273,7 @@ def default_args(**over):
     d = dict(expname="exp", pad=24, batch_size=1024, num_epochs=8, pts_dim=3, dir_dim=3, net_type="v0", netdepth=6, netwidth=128,
              lrate=5e-4, chunk=1024, netchunk=1024, ckpt=None, N_samples=128, N_importance=0, perturb=1.0, use_viewdirs=True,
              i_embed=0, multires=10, multires_views=4, raw_noise_std=0.0, white_bkgd=False, img_downscale=1.0,
-             use_color_volume=False, with_depth=False, with_depth_loss=False, feat_dim=20, dp_mode="ray")
+             use_color_volume=False, with_depth=False, with_depth_loss=False, feat_dim=20, dp_mode="ray", use_amp=False)
     d.update(over)
     return types.SimpleNamespace(**d)
 
@@ -402,8 +409,9 @@ class MVSSystemFinetune(_ModuleShim):
         if self.density_volume is not None and getattr(args, "N_importance", 0) > 0:                # :158-163
             pts, rays_o, rays_d, z_vals = ray_marcher_fine(rays, self.density_volume, z_vals, ndc, N_importance=args.N_importance)
             pts, ndc = to_ndc(z_vals)
-        rgbs, _, _, depth_pred, _, _ = rendering(args, self.pose_source, pts, ndc, z_vals, rays_o, rays_d, self.volume, self.imgs,
-                                                 **self.render_kwargs_train)
+        with ops.mlp_precision("bf16" if getattr(args, "use_amp", False) else ops.MLP_PRECISION):
+            rgbs, _, _, depth_pred, _, _ = rendering(args, self.pose_source, pts, ndc, z_vals, rays_o, rays_d, self.volume, self.imgs,
+                                                     **self.render_kwargs_train)
         img_loss = img2mse(rgbs, target)
         with torch.no_grad():
             self.log("train/loss", img_loss, prog_bar=True)
