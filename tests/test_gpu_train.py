@@ -68,20 +68,19 @@ def test_training_step_matches_oracle_autograd():
     def rel(a, b):
         return float((a.cpu() - b).abs().max() / (b.abs().max() + 1e-12))
     net, mvs = sys_.render_kwargs_train["network_fn"], sys_.MVSNet
-    checks = {
-        "mlp.pts_linears.0.weight": (net.nerf.pts_linears[0].weight.grad, sd_mlp["nerf.pts_linears.0.weight"].grad),
-        "mlp.pts_bias.weight": (net.nerf.pts_bias.weight.grad, sd_mlp["nerf.pts_bias.weight"].grad),
-        "mlp.rgb_linear.weight": (net.nerf.rgb_linear.weight.grad, sd_mlp["nerf.rgb_linear.weight"].grad),
-        "mlp.alpha_linear.bias": (net.nerf.alpha_linear.bias.grad, sd_mlp["nerf.alpha_linear.bias"].grad),
-        "cost_reg_2.conv0.conv.weight": (mvs.cost_reg_2.conv0.conv.weight.grad, sd_mvs["cost_reg_2.conv0.conv.weight"].grad),
-        "cost_reg_2.conv6.bn.weight": (mvs.cost_reg_2.conv6.bn.weight.grad, sd_mvs["cost_reg_2.conv6.bn.weight"].grad),
-        "cost_reg_2.conv11.0.weight": (mvs.cost_reg_2.conv11[0].weight.grad, sd_mvs["cost_reg_2.conv11.0.weight"].grad),
-        "feature.toplayer.weight": (mvs.feature.toplayer.weight.grad, sd_mvs["feature.toplayer.weight"].grad),
-        "feature.conv0.0.conv.weight": (mvs.feature.conv0[0].conv.weight.grad, sd_mvs["feature.conv0.0.conv.weight"].grad),
-    }
-    errs = {k: rel(a, b) for k, (a, b) in checks.items()}
-    bad = {k: v for k, v in errs.items() if not v < 2e-2}
-    assert not bad, f"end-to-end gradient mismatches: {bad}\nall: {errs}"
+    # EVERY trainable tensor of the three networks: 22 MLP + 30 CostRegNet + 26 FeatureNet
+    errs, scale = {}, {}
+    for name, p in net.named_parameters():
+        errs["mlp." + name] = rel(p.grad, sd_mlp[name].grad)
+    for name, p in mvs.named_parameters():
+        assert p.grad is not None, name
+        errs[name] = rel(p.grad, sd_mvs[name].grad)
+        scale[name] = float(sd_mvs[name].grad.abs().max())
+    assert len(errs) == 22 + 30 + 26, len(errs)
+    worst = max(errs, key=errs.get)
+    print("training step: %d gradient tensors, worst relative error %.2e (%s)" % (len(errs), errs[worst], worst))
+    bad = {k: v for k, v in errs.items() if not v < 1e-3}              # measured: worst 1.3e-5
+    assert not bad, f"end-to-end gradient mismatches (rel. to max |ref|, bound 1e-3): {bad}"
 
 
 def test_fit_steps_reduces_loss_and_checkpoint_roundtrip(tmp_path):
