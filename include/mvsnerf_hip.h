@@ -38,7 +38,7 @@ int mvsnerf_abi_version(void);
 
 /* A/B benchmarking knob, not part of the reference surface.  Keys: "mlp_variant" = 3 (default: 32 points/wave,
  * 2 waves/SIMD, weights double-buffered through LDS by LDS-DMA), 0 (same, register-staged weights), 1 (64 points/wave,
- * 1 wave/SIMD), 2 (32 points/wave, 1 wave/SIMD), 4 (16 points/wave on v_mfma_f32_16x16x4_f32, inference only); "conv_tiled" = 1|0; "conv_mfma" = 1|0 (stride-1 convolutions with 8 output channels on v_mfma_f32_4x4x1_16B_f32, default 1); "conv_xcd" = 1|0 (tiles of the tiled convolutions renumbered per XCD, default 1); "split_sched" = 0 (default: bf16x6 kernel at two waves
+ * 1 wave/SIMD), 2 (32 points/wave, 1 wave/SIMD), 4 (16 points/wave on v_mfma_f32_16x16x4_f32, inference only); "conv_tiled" = 1|0; "conv_mfma" = 1|0 (stride-1 convolutions with 8 output channels on v_mfma_f32_4x4x1_16B_f32, default 1); "mlp_gather" = 0|1 (default 0: rendering() with 3 views does its lookups in the MLP kernel's prologue - one launch less, measured 1 % slower); "conv_xcd" = 1|0 (tiles of the tiled convolutions renumbered per XCD, default 1); "split_sched" = 0 (default: bf16x6 kernel at two waves
  * per SIMD, lean registers) | 1 (one wave per SIMD, operand splitting hand-interleaved between the MFMAs).  Results are
  * identical up to summation order. */
 int mvsnerf_tune(const char* key, int value);

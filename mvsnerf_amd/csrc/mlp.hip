@@ -8,6 +8,7 @@
 // memory.  MFMA-bound: 251 392 FLOP per point against 12 B + 4*F B read and 16 B written.
 #include "common.h"
 #include "mlp_layout.h"
+#include "sample_dev.h"
 #include "lds_dma.h"
 
 using namespace mlp;
@@ -418,12 +419,26 @@ __device__ __forceinline__ void slab_sync()
     __syncthreads();                                      // ... everybody's have, and everybody left the other buffer
 }
 
-template <bool ALPHA_ONLY, bool SAVE>
+// GATHER (opt-in, see g_mlp_gather; three source views, rendering() of a whole batch): gen_dir_feature + gen_pts_feats
+// (renderer.py:111-136) run in this kernel's prologue instead of a launch of their own - every lane computes the 20-float feature row of its point with the device
+// functions the gather kernels use (sample_dev.h: same bits), keeps the half it feeds to pts_bias in registers and stores it to the
+// `input_feat` output; the lookup's memory latency hides behind the co-resident workgroup's matrix work.  Removes a 11 us launch
+// (+ the launch boundary) per 1024 x 128 batch.
+struct GatherIn {
+    const float* vol; int D, H, W;          // channel-last neural volume [D][H][W][8]
+    const float* img; int IH, IW;           // channel-last source images [3][IH][IW][4]
+    const float* w2c; const float* Kmat;    // [3][4][4], [3][3][3]
+    const float* pts; const float* rays_dir;
+    float* feat_out;                        // [P][20]
+};
+
+template <bool ALPHA_ONLY, bool SAVE, bool GATHER = false>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
     const float* __restrict__ packed, int F, const float* __restrict__ ndc, int ndc_stride,
     const float* __restrict__ feat, int feat_stride, const float* __restrict__ dirs, int dirs_stride,
-    int64_t P, int S, float* __restrict__ raw, float* __restrict__ saved, long long* __restrict__ census)
+    int64_t P, int S, float* __restrict__ raw, float* __restrict__ saved, long long* __restrict__ census, GatherIn gi = GatherIn{})
 {
+    static_assert(!GATHER || !ALPHA_ONLY, "the fused gather serves rendering(): colours are wanted");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     long long t_start = 0, c_start = 0;
     if (census) { t_start = wall_clock64(); c_start = __builtin_amdgcn_s_memtime(); }
@@ -450,7 +465,44 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
     for (int i = tid; i < V_TOTAL; i += 256) vec[i] = packed[L.vec + i];
     const float px = ndc[p * ndc_stride + 0], py = ndc[p * ndc_stride + 1], pz = ndc[p * ndc_stride + 2];
     float fv[MAX_F / 2];
-    {
+    float gd0 = 0.0f, gd1 = 0.0f, gd2 = 0.0f;             // GATHER: view-direction feature of this point's ray
+    if constexpr (GATHER) {
+        // [0:8] trilinear volume features | [8+4v : 12+4v] (r, g, b, in-frustum mask) of source view v = 0, 1, 2      (F = 20)
+        f32x4 row[5];
+        {
+            f32x4 v8[2];
+            trilinear8_of<true>(gi.vol, gi.D, gi.H, gi.W, px, py, pz, v8);
+            row[0] = v8[0]; row[1] = v8[1];
+        }
+        const float wx = gi.pts[p * 3 + 0], wy = gi.pts[p * 3 + 1], wz = gi.pts[p * 3 + 2];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const ColorTap t = color_project(wx, wy, wz, gi.w2c + v * 16, gi.Kmat + v * 9, gi.IW, gi.IH);
+            const float* pl = gi.img + (int64_t)((__umul24(v * gi.IH + t.y0, gi.IW) + t.x0) << 2);
+            const float* zt = reinterpret_cast<const float*>(&g_zero_tap);
+            const f32x4 t_nw = *reinterpret_cast<const f32x4*>(pl);
+            const f32x4 t_ne = *reinterpret_cast<const f32x4*>(t.x1in ? pl + 4 : zt);
+            const f32x4 t_sw = *reinterpret_cast<const f32x4*>(t.y1in ? pl + (int64_t)gi.IW * 4 : zt);
+            const f32x4 t_se = *reinterpret_cast<const f32x4*>((t.x1in && t.y1in) ? pl + (int64_t)gi.IW * 4 + 4 : zt);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) row[2 + v][c] = color_blend(t, t_nw[c], t_ne[c], t_sw[c], t_se[c]);
+            row[2 + v][3] = color_mask(t);
+        }
+        // this lane's operands: features [10 half, 10 half + 10)
+#pragma unroll
+        for (int i = 0; i < MAX_F / 2; ++i) {
+            const int lo = i, hi = 10 + i;
+            fv[i] = i < 10 ? (half ? row[hi >> 2][hi & 3] : row[lo >> 2][lo & 3]) : 0.0f;
+        }
+        if (live) {      // the `input_feat` output of rendering(): each half-lane stores the ten floats it holds
+            float* frow = gi.feat_out + p * 20 + half * 10;
+#pragma unroll
+            for (int i = 0; i < 10; i += 2) *reinterpret_cast<f32x2*>(frow + i) = f32x2{fv[i], fv[i + 1]};
+        }
+        float d3[3];
+        dir_feature_of(gi.rays_dir + (p / S) * 3, gi.w2c, 1, d3);       // reference view = view 0 (renderer.py:142-147)
+        gd0 = d3[0]; gd1 = d3[1]; gd2 = d3[2];
+    } else {
         const float* fp = feat + p * feat_stride + half * (F / 2);
 #pragma unroll
         for (int i = 0; i < MAX_F / 2; ++i) fv[i] = i < F / 2 ? fp[i] : 0.0f;
@@ -561,8 +613,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
     stamp();                                                                                // [12] feature_linear done
     // ---- views_linears[0] + rgb head: slab 15 (buf1)
     {
-        const int64_t ray = p / S;
-        const float d0 = dirs[ray * dirs_stride + 0], d1 = dirs[ray * dirs_stride + 1], d2 = dirs[ray * dirs_stride + 2];
+        float d0, d1, d2;
+        if constexpr (GATHER) { d0 = gd0; d1 = gd1; d2 = gd2; }
+        else { const int64_t ray = p / S; d0 = dirs[ray * dirs_stride + 0]; d1 = dirs[ray * dirs_stride + 1]; d2 = dirs[ray * dirs_stride + 2]; }
         f32x16 acc[G][2];
         slab_sync();
         init_acc<2, G>(acc, vec + V_VIEWS + half * 32);
@@ -609,6 +662,18 @@ static int launch_mlp_pipe(const float* packed, int F, const float* ndc, int ndc
     return MVSNERF_OK;
 }
 
+// A/B knob (mvsnerf_tune "mlp_gather"), default OFF: rendering() with three source views runs the lookups in the MLP kernel's prologue.
+// Measured at config 2 (scratch/ab_gather.py): 0.2574 ms/step fused vs 0.2551 ms with the separate 11 us gather launch - the lookup's
+// memory latency sits in front of every workgroup's first GEMM (the pts_bias product needs the features), and the 512 workgroups of
+// the first round all pay it at once; the stand-alone gather kernel hides the same latency behind 2048 waves of its own.
+int g_mlp_gather = 0;
+
+// Used by mvsnerf_raymarch_fwd / mvsnerf_render_pixels_fwd (raymarch.hip): gather + MLP in one launch.  Returns MVSNERF_EUNSUPPORTED
+// when the shape is outside what the fused prologue is built for (the caller then launches the gather kernel and the plain MLP kernel).
+int mvs_mlp_fwd_gather(const float* packed, const float* vol, int D, int H, int W, const float* imgs_nhwc4, int V, int IH, int IW,
+                       const float* w2c, const float* K, const float* pts, const float* ndc, const float* rays_dir,
+                       int64_t N, int S, float* feat, float* raw, hipStream_t st);
+
 // tuning knob (A/B benchmarking only): 0 = 32 pts/wave, 2 waves/SIMD, register-staged weights; 1 = 64 pts/wave, 1 wave/SIMD;
 // 2 = 32 pts/wave, 1 wave/SIMD; 3 = 32 pts/wave, 2 waves/SIMD, double-buffered LDS-DMA weight slabs (default)
 static int g_mlp_variant = 3;
@@ -623,6 +688,7 @@ extern "C" int mvsnerf_tune(const char* key, int value)
     if (__builtin_strcmp(key, "conv_tiled") == 0) { g_conv_tiled = value ? 1 : 0; return MVSNERF_OK; }
     if (__builtin_strcmp(key, "conv_xcd") == 0) { g_conv_xcd = value ? 1 : 0; return MVSNERF_OK; }
     if (__builtin_strcmp(key, "conv_mfma") == 0) { g_conv_mfma = value ? 1 : 0; return MVSNERF_OK; }
+    if (__builtin_strcmp(key, "mlp_gather") == 0) { g_mlp_gather = value ? 1 : 0; return MVSNERF_OK; }
     if (__builtin_strcmp(key, "mlp_variant") == 0) { if (value < 0 || value > 4) return MVSNERF_EINVAL; g_mlp_variant = value; return MVSNERF_OK; }
     if (__builtin_strcmp(key, "split_sched") == 0) { if (value < 0 || value > 1) return MVSNERF_EINVAL; g_split_sched = value; return MVSNERF_OK; }
     return MVSNERF_EINVAL;
@@ -636,6 +702,24 @@ static int launch_mlp(const float* packed, int F, const float* ndc, int ndc_stri
     static unsigned long long lds_cap_set = 0;          // per-device bit mask (common.h)
     if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_kernel<AO, G, WPS, SAVE>), (int)lds_bytes, &lds_cap_set)) return rc_;
     mlp_fwd_kernel<AO, G, WPS, SAVE><<<mvs_cdiv(P, 128 * G), 256, lds_bytes, st>>>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, saved);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+int mvs_mlp_fwd_gather(const float* packed, const float* vol, int D, int H, int W, const float* imgs_nhwc4, int V, int IH, int IW,
+                       const float* w2c, const float* K, const float* pts, const float* ndc, const float* rays_dir,
+                       int64_t N, int S, float* feat, float* raw, hipStream_t st)
+{
+    const int64_t P = N * S;
+    const bool small = (int64_t)D * H < (1 << 24) && W < (1 << 24) && (int64_t)D * H * W * 8 < ((int64_t)1 << 31) &&
+                       (int64_t)V * IH < (1 << 24) && IW < (1 << 24) && (int64_t)V * IH * IW * 4 < ((int64_t)1 << 31);
+    if (!g_mlp_gather || g_mlp_variant != 3 || g_mlp_census || V != 3 || !small || P < 1) return MVSNERF_EUNSUPPORTED;
+    if (!mvs_aligned16(packed) || !mvs_aligned16(raw) || !mvs_aligned16(vol) || !mvs_aligned16(imgs_nhwc4) || (reinterpret_cast<uintptr_t>(feat) & 7u)) return MVSNERF_EUNSUPPORTED;
+    const size_t lds_bytes = PIPE_LDS_FLOATS * sizeof(float);
+    static unsigned long long lds_cap_set = 0;
+    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_pipe_kernel<false, false, true>), (int)lds_bytes, &lds_cap_set)) return rc_;
+    const GatherIn gi{vol, D, H, W, imgs_nhwc4, IH, IW, w2c, K, pts, rays_dir, feat};
+    mlp_fwd_pipe_kernel<false, false, true><<<mvs_cdiv(P, 128), 256, lds_bytes, st>>>(packed, 20, ndc, 3, nullptr, 20, nullptr, 3, P, S, raw, nullptr, nullptr, gi);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }

@@ -4,26 +4,8 @@
 // Layout: volume is channel-last vol[d][y][x][8] so that one trilinear corner = one 32-byte sector
 // and the two x-neighbours of a corner pair are one 64-byte contiguous read.
 #include "common.h"
+#include "sample_dev.h"
 #include <type_traits>
-
-// A 16-byte block of zeros: out-of-volume taps read it instead of branching around the load (zeros padding, exactly).
-__device__ const f32x4 g_zero_tap = {0.0f, 0.0f, 0.0f, 0.0f};
-
-// float offset of voxel (z,y,x)'s 8-channel vector.  SMALL: 32-bit arithmetic on full-rate 24-bit multiplies (the launcher
-// checks D*H < 2^24, W < 2^24, D*H*W*8 < 2^31); v_mul_lo_u32 / v_mad_u64_u32 are quarter-rate and were 40 % of the lookup's
-// instruction slots.
-template <bool SMALL>
-__device__ __forceinline__ int64_t vox_off8(int z, int y, int x, int H, int W)
-{
-    if constexpr (SMALL) return (int64_t)((__umul24(__umul24(z, H) + y, W) + x) << 3);
-    else return (((int64_t)z * H + y) * W + x) << 3;
-}
-
-// swap with the lane two places away inside the quad (lanes 0<->2, 1<->3): what __shfl_xor(v, 2) returns, as one DPP move
-__device__ __forceinline__ float quad_swap2(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4e, 0xf, 0xf, false));   // quad_perm:[2,3,0,1]
-}
 
 // ---------------------------------------------------------------------------------------------
 // Trilinear lookup (reference: F.grid_sample 5-D, zeros padding, align_corners=True;
@@ -131,66 +113,6 @@ extern "C" int mvsnerf_volume_sample_fwd(const float* vol, int D, int H, int W, 
 // contraction OFF so that the stand-alone kernels and the fused gather kernel produce the same bits whatever the
 // surrounding code looks like to the optimiser.
 // ---------------------------------------------------------------------------------------------
-struct ColorTap { float gx, gy, wnw, wne, wsw, wse; int x0, y0; bool x1in, y1in; };
-
-__device__ __forceinline__ ColorTap color_project(float x, float y, float z, const float* __restrict__ M, const float* __restrict__ K, int W, int H)
-{
-#pragma clang fp contract(off)
-    ColorTap t;
-    // get_ndc_coordinate utils.py:124: p_cam = pts @ R^T + T   (k-ordered fma chain like sgemm)
-    const float cx = fmaf(z, M[2],  fmaf(y, M[1], x * M[0]))  + M[3];
-    const float cy = fmaf(z, M[6],  fmaf(y, M[5], x * M[4]))  + M[7];
-    const float cz = fmaf(z, M[10], fmaf(y, M[9], x * M[8]))  + M[11];
-    // :128  q = p_cam @ K^T
-    const float qx = fmaf(cz, K[2], fmaf(cy, K[1], cx * K[0]));
-    const float qy = fmaf(cz, K[5], fmaf(cy, K[4], cx * K[3]));
-    const float qz = fmaf(cz, K[8], fmaf(cy, K[7], cx * K[6]));
-    // :129  /z, / inv_scale ; utils.py:317  grid = xy*2-1
-    t.gx = ((qx / qz + 0.0f) / (float)(W - 1)) * 2.0f - 1.0f;
-    t.gy = ((qy / qz + 0.0f) / (float)(H - 1)) * 2.0f - 1.0f;
-    // grid_sample bilinear, border padding, align_corners=True
-    float ix = ((t.gx + 1.0f) / 2.0f) * (float)(W - 1);
-    float iy = ((t.gy + 1.0f) / 2.0f) * (float)(H - 1);
-    ix = fminf(fmaxf(ix, 0.0f), (float)(W - 1));   // clip_coordinates (NaN -> 0 like ATen's min/max order)
-    iy = fminf(fmaxf(iy, 0.0f), (float)(H - 1));
-    if (!(ix == ix)) ix = 0.0f;
-    if (!(iy == iy)) iy = 0.0f;
-    const float fx = floorf(ix), fy = floorf(iy);
-    t.x0 = (int)fx; t.y0 = (int)fy;
-    const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
-    t.x1in = t.x0 + 1 <= W - 1; t.y1in = t.y0 + 1 <= H - 1;
-    t.wnw = wx0 * wy0; t.wne = wx1 * wy0; t.wsw = wx0 * wy1; t.wse = wx1 * wy1;
-    return t;
-}
-
-__device__ __forceinline__ float color_blend(const ColorTap& t, float nw, float ne, float sw, float se)
-{
-#pragma clang fp contract(off)
-    float acc = nw * t.wnw;
-    if (t.x1in) acc = fmaf(ne, t.wne, acc);
-    if (t.y1in) acc = fmaf(sw, t.wsw, acc);
-    if (t.x1in && t.y1in) acc = fmaf(se, t.wse, acc);
-    return acc;
-}
-
-__device__ __forceinline__ float color_mask(const ColorTap& t) { return (t.gx > -1.0f && t.gx < 1.0f && t.gy > -1.0f && t.gy < 1.0f) ? 1.0f : 0.0f; }
-
-// dirs = normalise(d) @ R^T  (renderer.py:142-147, 111-122); R == null: no rotation
-__device__ __forceinline__ void dir_feature_of(const float* __restrict__ d3, const float* __restrict__ R, int normalize, float* __restrict__ o3)
-{
-#pragma clang fp contract(off)
-    const float dx = d3[0], dy = d3[1], dz = d3[2];
-    const float nrm = normalize ? sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx))) : 1.0f;   // torch.norm
-    const float ux = dx / nrm, uy = dy / nrm, uz = dz / nrm;
-    if (R) {
-        o3[0] = fmaf(uz, R[2],  fmaf(uy, R[1], ux * R[0]));
-        o3[1] = fmaf(uz, R[6],  fmaf(uy, R[5], ux * R[4]));
-        o3[2] = fmaf(uz, R[10], fmaf(uy, R[9], ux * R[8]));
-    } else {
-        o3[0] = ux; o3[1] = uy; o3[2] = uz;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Per-view colour lookup (utils.py:300-332).  One thread per (sample, view).  Camera matrices are
 // wave-uniform per view only if V divides the wave, so they are read through the vector path from a

@@ -1,0 +1,125 @@
+// Device functions shared by the gather kernels (sample.hip) and the fused gather prologue of the MLP kernel (mlp.hip): the arithmetic
+// of the trilinear volume lookup, the per-view colour lookup and the view-direction feature lives here ONCE, so that every kernel that
+// produces `input_feat` produces the same bits.
+#pragma once
+#include "common.h"
+
+// A 16-byte block of zeros: out-of-volume taps read it instead of branching around the load (zeros padding, exactly).
+static __device__ const f32x4 g_zero_tap = {0.0f, 0.0f, 0.0f, 0.0f};
+
+// float offset of voxel (z,y,x)'s 8-channel vector.  SMALL: 32-bit arithmetic on full-rate 24-bit multiplies (the launcher
+// checks D*H < 2^24, W < 2^24, D*H*W*8 < 2^31); v_mul_lo_u32 / v_mad_u64_u32 are quarter-rate and were 40 % of the lookup's
+// instruction slots.
+template <bool SMALL>
+__device__ __forceinline__ int64_t vox_off8(int z, int y, int x, int H, int W)
+{
+    if constexpr (SMALL) return (int64_t)((__umul24(__umul24(z, H) + y, W) + x) << 3);
+    else return (((int64_t)z * H + y) * W + x) << 3;
+}
+
+// swap with the lane two places away inside the quad (lanes 0<->2, 1<->3): what __shfl_xor(v, 2) returns, as one DPP move
+__device__ __forceinline__ float quad_swap2(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4e, 0xf, 0xf, false));   // quad_perm:[2,3,0,1]
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shared arithmetic of the colour lookup and the direction feature.  Written with explicit fmaf/mul/add and fp
+// contraction OFF so that the stand-alone kernels and the fused gather kernel produce the same bits whatever the
+// surrounding code looks like to the optimiser.
+// ---------------------------------------------------------------------------------------------
+struct ColorTap { float gx, gy, wnw, wne, wsw, wse; int x0, y0; bool x1in, y1in; };
+
+__device__ __forceinline__ ColorTap color_project(float x, float y, float z, const float* __restrict__ M, const float* __restrict__ K, int W, int H)
+{
+#pragma clang fp contract(off)
+    ColorTap t;
+    // get_ndc_coordinate utils.py:124: p_cam = pts @ R^T + T   (k-ordered fma chain like sgemm)
+    const float cx = fmaf(z, M[2],  fmaf(y, M[1], x * M[0]))  + M[3];
+    const float cy = fmaf(z, M[6],  fmaf(y, M[5], x * M[4]))  + M[7];
+    const float cz = fmaf(z, M[10], fmaf(y, M[9], x * M[8]))  + M[11];
+    // :128  q = p_cam @ K^T
+    const float qx = fmaf(cz, K[2], fmaf(cy, K[1], cx * K[0]));
+    const float qy = fmaf(cz, K[5], fmaf(cy, K[4], cx * K[3]));
+    const float qz = fmaf(cz, K[8], fmaf(cy, K[7], cx * K[6]));
+    // :129  /z, / inv_scale ; utils.py:317  grid = xy*2-1
+    t.gx = ((qx / qz + 0.0f) / (float)(W - 1)) * 2.0f - 1.0f;
+    t.gy = ((qy / qz + 0.0f) / (float)(H - 1)) * 2.0f - 1.0f;
+    // grid_sample bilinear, border padding, align_corners=True
+    float ix = ((t.gx + 1.0f) / 2.0f) * (float)(W - 1);
+    float iy = ((t.gy + 1.0f) / 2.0f) * (float)(H - 1);
+    ix = fminf(fmaxf(ix, 0.0f), (float)(W - 1));   // clip_coordinates (NaN -> 0 like ATen's min/max order)
+    iy = fminf(fmaxf(iy, 0.0f), (float)(H - 1));
+    if (!(ix == ix)) ix = 0.0f;
+    if (!(iy == iy)) iy = 0.0f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    t.x0 = (int)fx; t.y0 = (int)fy;
+    const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
+    t.x1in = t.x0 + 1 <= W - 1; t.y1in = t.y0 + 1 <= H - 1;
+    t.wnw = wx0 * wy0; t.wne = wx1 * wy0; t.wsw = wx0 * wy1; t.wse = wx1 * wy1;
+    return t;
+}
+
+__device__ __forceinline__ float color_blend(const ColorTap& t, float nw, float ne, float sw, float se)
+{
+#pragma clang fp contract(off)
+    float acc = nw * t.wnw;
+    if (t.x1in) acc = fmaf(ne, t.wne, acc);
+    if (t.y1in) acc = fmaf(sw, t.wsw, acc);
+    if (t.x1in && t.y1in) acc = fmaf(se, t.wse, acc);
+    return acc;
+}
+
+__device__ __forceinline__ float color_mask(const ColorTap& t) { return (t.gx > -1.0f && t.gx < 1.0f && t.gy > -1.0f && t.gy < 1.0f) ? 1.0f : 0.0f; }
+
+// dirs = normalise(d) @ R^T  (renderer.py:142-147, 111-122); R == null: no rotation
+__device__ __forceinline__ void dir_feature_of(const float* __restrict__ d3, const float* __restrict__ R, int normalize, float* __restrict__ o3)
+{
+#pragma clang fp contract(off)
+    const float dx = d3[0], dy = d3[1], dz = d3[2];
+    const float nrm = normalize ? sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx))) : 1.0f;   // torch.norm
+    const float ux = dx / nrm, uy = dy / nrm, uz = dz / nrm;
+    if (R) {
+        o3[0] = fmaf(uz, R[2],  fmaf(uy, R[1], ux * R[0]));
+        o3[1] = fmaf(uz, R[6],  fmaf(uy, R[5], ux * R[4]));
+        o3[2] = fmaf(uz, R[10], fmaf(uy, R[9], ux * R[8]));
+    } else {
+        o3[0] = ux; o3[1] = uy; o3[2] = uz;
+    }
+}
+
+
+// The 8-channel trilinear lookup of ONE sample by ONE lane, in the arithmetic of volume_sample_c8_kernel / gather_fused_kernel (where
+// four lanes share a sample): per x corner and channel half, the four (z, y) taps are folded in the order k = 0..3, then the two x
+// corners are added (low corner + high corner).  out[0..3] = channels 0-3, out[4..7] = channels 4-7.
+template <bool SMALL>
+__device__ __forceinline__ void trilinear8_of(const float* __restrict__ vol, int D, int H, int W, float nx, float ny, float nz, f32x4 (&out)[2])
+{
+    const float gx = nx * 2.0f - 1.0f, gy = ny * 2.0f - 1.0f, gz = nz * 2.0f - 1.0f;
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+    const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+    const float iz = ((gz + 1.0f) / 2.0f) * (float)(D - 1);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    f32x4 acc[2][2];                                  // [x corner][channel half]
+#pragma unroll
+    for (int xc = 0; xc < 2; ++xc) {
+        const float wx = xc ? (ix - fx) : ((fx + 1.0f) - ix);
+        const float cxf = fx + (float)xc;
+        const bool x_in = (cxf >= 0.0f) && (cxf <= (float)(W - 1));
+        acc[xc][0] = f32x4{0, 0, 0, 0}; acc[xc][1] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int zc = k >> 1, yc = k & 1;
+            const float cyf = fy + (float)yc, czf = fz + (float)zc;
+            const bool in = x_in && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
+            const float w = wx * (yc ? (iy - fy) : ((fy + 1.0f) - iy)) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
+            const float* src = in ? vol + vox_off8<SMALL>((int)czf, (int)cyf, (int)cxf, H, W) : reinterpret_cast<const float*>(&g_zero_tap);
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(in ? src + 4 : src);
+            acc[xc][0] += v0 * w;
+            acc[xc][1] += v1 * w;
+        }
+    }
+    out[0] = acc[0][0] + acc[1][0];
+    out[1] = acc[0][1] + acc[1][1];
+}
