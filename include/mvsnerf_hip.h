@@ -389,6 +389,42 @@ typedef struct {
 size_t mvsnerf_render_workspace_floats(int batch_rays, int S, int V);
 int mvsnerf_render_pixels_fwd(const mvsnerf_render_args* a, void* stream);
 
+/* ---- the differentiable ray march as TWO host calls (raymarch_fused_{fwd,bwd}) ----
+ * rendering() (renderer.py:138-165) inside train_mvs_nerf_pl.py:123 / train_mvs_nerf_finetuning_pl.py:166:
+ *   raymarch_train_fwd  gather (or, for an (8+4V)-channel colour volume, one lookup) -> MLP training forward with the activation
+ *                       store -> compositing; everything the backward call needs stays in caller-owned buffers
+ *   raymarch_bwd        compositing backward -> MLP backward (data + weight gradients) -> trilinear scatter into the volume gradient
+ * bf16 != 0 selects the bf16-MFMA MLP kernels (packed_mlp_bf16 / packed_bwd = the bf16 packs), else fp32.
+ * Gradient inputs g_* may be NULL (= zero).  gvol == NULL skips the volume gradient (frozen volume); it must be zero-initialised. */
+typedef struct {
+    const float* vol; int D, H, W, C;       /* [D][H][W][C], C = 8 or 8+4V (--use_color_volume) */
+    const float* imgs_nhwc4; int V, IH, IW; /* [V][IH][IW][4]; unused when C == 8+4V */
+    const float* w2c; const float* K;       /* [V][4][4], [V][3][3] */
+    const float* packed_mlp; const void* packed_mlp_bf16; int bf16;
+    const float* rays_pts; const float* rays_ndc; const float* z_vals; const float* rays_dir;
+    int64_t N; int S; int white_bkgd;
+    float* dirs_tmp;                        /* [N][3] */
+    float* input_feat;                      /* [N][S][8+4V] (output of rendering() too) */
+    float* raw;                             /* [N][S][4] */
+    float* saved;                           /* mvsnerf_mlp_saved_floats(N*S) */
+    float* rgb_map; float* disp; float* acc; float* weights; float* depth; float* alpha;
+} mvsnerf_raymarch_train_args;
+int mvsnerf_raymarch_train_fwd(const mvsnerf_raymarch_train_args* a, void* stream);
+
+typedef struct {
+    const float* packed_mlp; const void* packed_bwd; int bf16; int F;
+    const float* raw; const float* saved; const float* z_vals; const float* rays_ndc;
+    int64_t N; int S; int white_bkgd;
+    const float* g_rgb; const float* g_depth; const float* g_weights; const float* g_alpha;
+    float* d_raw;                           /* scratch [N][S][4] */
+    float* gslots;                          /* scratch mvsnerf_mlp_gradslot_floats(N*S) */
+    float* d_feat; int n_feat_out;          /* scratch [N*S][n_feat_out]; 8, or F for a colour volume */
+    float* const* gw; float* const* gb;     /* 11 weight / bias gradient tensors (nn.Linear layout) */
+    const int* maps; float* workspace;      /* as mvsnerf_mlp_bwd */
+    float* gvol; int D, H, W, C;            /* NULL or [D][H][W][C] zero-initialised, C == n_feat_out */
+} mvsnerf_raymarch_bwd_args;
+int mvsnerf_raymarch_bwd(const mvsnerf_raymarch_bwd_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,32 @@ class RaymarchArgs(ctypes.Structure):
     ]
 
 
+class RaymarchTrainArgs(ctypes.Structure):
+    """mvsnerf_raymarch_train_args (include/mvsnerf_hip.h)."""
+    _fields_ = [
+        ("vol", _c_fp), ("D", _c_i), ("H", _c_i), ("W", _c_i), ("C", _c_i),
+        ("imgs_nhwc4", _c_fp), ("V", _c_i), ("IH", _c_i), ("IW", _c_i),
+        ("w2c", _c_fp), ("K", _c_fp), ("packed_mlp", _c_fp), ("packed_mlp_bf16", _c_fp), ("bf16", _c_i),
+        ("rays_pts", _c_fp), ("rays_ndc", _c_fp), ("z_vals", _c_fp), ("rays_dir", _c_fp),
+        ("N", _c_l), ("S", _c_i), ("white_bkgd", _c_i),
+        ("dirs_tmp", _c_fp), ("input_feat", _c_fp), ("raw", _c_fp), ("saved", _c_fp),
+        ("rgb_map", _c_fp), ("disp", _c_fp), ("acc", _c_fp), ("weights", _c_fp), ("depth", _c_fp), ("alpha", _c_fp),
+    ]
+
+
+class RaymarchBwdArgs(ctypes.Structure):
+    """mvsnerf_raymarch_bwd_args (include/mvsnerf_hip.h)."""
+    _fields_ = [
+        ("packed_mlp", _c_fp), ("packed_bwd", _c_fp), ("bf16", _c_i), ("F", _c_i),
+        ("raw", _c_fp), ("saved", _c_fp), ("z_vals", _c_fp), ("rays_ndc", _c_fp),
+        ("N", _c_l), ("S", _c_i), ("white_bkgd", _c_i),
+        ("g_rgb", _c_fp), ("g_depth", _c_fp), ("g_weights", _c_fp), ("g_alpha", _c_fp),
+        ("d_raw", _c_fp), ("gslots", _c_fp), ("d_feat", _c_fp), ("n_feat_out", _c_i),
+        ("gw", ctypes.POINTER(_c_fp)), ("gb", ctypes.POINTER(_c_fp)), ("maps", _c_fp), ("workspace", _c_fp),
+        ("gvol", _c_fp), ("D", _c_i), ("H", _c_i), ("W", _c_i), ("C", _c_i),
+    ]
+
+
 class RenderArgs(ctypes.Structure):
     """mvsnerf_render_args (include/mvsnerf_hip.h)."""
     _fields_ = [
@@ -113,6 +139,8 @@ SIGNATURES = {
     "mvsnerf_volume_sample_bwd": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_fp, _c_l, _c_fp, _c_i, _c_fp, _c_fp]),
     "mvsnerf_composite_fwd": (_c_i, [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_raymarch_fwd": (_c_i, [ctypes.POINTER(RaymarchArgs), _c_fp]),
+    "mvsnerf_raymarch_train_fwd": (_c_i, [ctypes.POINTER(RaymarchTrainArgs), _c_fp]),
+    "mvsnerf_raymarch_bwd": (_c_i, [ctypes.POINTER(RaymarchBwdArgs), _c_fp]),
 }
 
 _lib = None

@@ -124,3 +124,54 @@ extern "C" int mvsnerf_render_pixels_fwd(const mvsnerf_render_args* a, void* str
     }
     return MVSNERF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The differentiable ray march as two host calls: forward with activation store, backward to the MLP
+// parameters and the volume.
+// ---------------------------------------------------------------------------------------------
+extern "C" int mvsnerf_raymarch_train_fwd(const mvsnerf_raymarch_train_args* a, void* stream)
+{
+    if (!a) return MVSNERF_EINVAL;
+    if (!a->vol || !a->w2c || !a->packed_mlp || !a->rays_ndc || !a->z_vals || !a->rays_dir || !a->dirs_tmp || !a->input_feat || !a->raw || !a->saved)
+        return MVSNERF_EINVAL;
+    if (a->N < 0 || a->S < 1 || a->V < 1 || (a->bf16 && !a->packed_mlp_bf16)) return MVSNERF_EINVAL;
+    const int F = 8 + 4 * a->V;
+    const int64_t P = a->N * a->S;
+    int rc;
+    if (a->C == F && a->C != 8) {
+        // --use_color_volume (renderer.py:134-135): the volume already holds the projected colours
+        if ((rc = mvsnerf_dir_feature_fwd(a->rays_dir, a->w2c, a->N, 1, a->dirs_tmp, stream))) return rc;
+        if ((rc = mvsnerf_volume_sample_fwd(a->vol, a->D, a->H, a->W, a->C, a->rays_ndc, P, a->input_feat, F, stream))) return rc;
+    } else if (a->C == 8) {
+        if (!a->imgs_nhwc4 || !a->K || !a->rays_pts) return MVSNERF_EINVAL;
+        if ((rc = mvsnerf_gather_fwd(a->vol, a->D, a->H, a->W, a->imgs_nhwc4, a->V, a->IH, a->IW, a->w2c, a->K, a->rays_pts, a->rays_ndc,
+                                     a->N, a->S, a->rays_dir, a->input_feat, F, a->dirs_tmp, stream))) return rc;
+    } else {
+        return MVSNERF_EUNSUPPORTED;
+    }
+    if (a->bf16) rc = mvsnerf_mlp_fwd_bf16_train(a->packed_mlp_bf16, a->packed_mlp, F, a->rays_ndc, 3, a->input_feat, F, a->dirs_tmp, 3, a->N, a->S, a->raw, a->saved, stream);
+    else rc = mvsnerf_mlp_fwd_train(a->packed_mlp, F, a->rays_ndc, 3, a->input_feat, F, a->dirs_tmp, 3, a->N, a->S, a->raw, a->saved, stream);
+    if (rc) return rc;
+    return mvsnerf_composite_fwd(a->raw, a->z_vals, a->N, a->S, a->white_bkgd, a->rgb_map, a->disp, a->acc, a->weights, a->depth, a->alpha, stream);
+}
+
+extern "C" int mvsnerf_raymarch_bwd(const mvsnerf_raymarch_bwd_args* a, void* stream)
+{
+    if (!a) return MVSNERF_EINVAL;
+    if (!a->packed_mlp || !a->packed_bwd || !a->raw || !a->saved || !a->z_vals || !a->rays_ndc || !a->d_raw || !a->gslots || !a->d_feat || !a->gw ||
+        !a->gb || !a->maps || !a->workspace)
+        return MVSNERF_EINVAL;
+    if (a->N < 0 || a->S < 1) return MVSNERF_EINVAL;
+    if (a->gvol && a->C != a->n_feat_out) return MVSNERF_EINVAL;
+    int rc;
+    if ((rc = mvsnerf_composite_bwd(a->raw, a->z_vals, a->N, a->S, a->white_bkgd, a->g_rgb, a->g_depth, nullptr, a->g_weights, a->g_alpha, a->d_raw, stream)))
+        return rc;
+    if (a->bf16) rc = mvsnerf_mlp_bwd_bf16(a->packed_mlp, a->packed_bwd, a->F, a->raw, a->d_raw, a->saved, a->N, a->S, a->gslots, a->d_feat, a->n_feat_out,
+                                          a->gw, a->gb, a->maps, a->workspace, stream);
+    else rc = mvsnerf_mlp_bwd(a->packed_mlp, reinterpret_cast<const float*>(a->packed_bwd), a->F, a->raw, a->d_raw, a->saved, a->N, a->S, a->gslots, a->d_feat,
+                              a->n_feat_out, a->gw, a->gb, a->maps, a->workspace, stream);
+    if (rc) return rc;
+    if (a->gvol)
+        return mvsnerf_volume_sample_bwd(a->D, a->H, a->W, a->C, a->rays_ndc, a->N * a->S, a->d_feat, a->n_feat_out, a->gvol, stream);
+    return MVSNERF_OK;
+}

@@ -457,41 +457,38 @@ class RayMarchFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, volume, imgs, w2cs, intrinsics, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd, packed, *mlp_params):
+        """ONE FFI call (mvsnerf_raymarch_train_fwd): lookups -> MLP training forward with activation store -> compositing."""
         lib = _lib.lib()
         vol_cl = channels_last_volume(volume)
         D, H, W, C = vol_cl.shape
         N, S = z_vals.shape
         V = imgs.shape[0]
         F = 8 + 4 * V
+        if C not in (8, F):
+            raise RuntimeError(f"ray march: the volume has {C} channels; expected 8 or 8 + 4V = {F}")
+        if MLP_PRECISION not in ("fp32", "bf16"):
+            raise RuntimeError(f"training runs the MLP in 'fp32' or 'bf16' (ops.set_mlp_precision), not {MLP_PRECISION!r}")
+        bf16 = MLP_PRECISION == "bf16"
         dev = rays_pts.device
         f32 = dict(device=dev, dtype=torch.float32)
-        st = stream_ptr()
         feat = torch.empty((N, S, F), **f32)
         raw = torch.empty((N, S, 4), **f32)
         saved = torch.empty(lib.mvsnerf_mlp_saved_floats(N * S), **f32)
-        if C == F and C != 8:
-            # --use_color_volume (renderer.py:134-135): the volume already carries the projected colours; one F-channel lookup
-            dirs = dir_feature(rays_dir, w2cs[0].contiguous(), normalize=True)
-            check(lib.mvsnerf_volume_sample_fwd(dev_f32(vol_cl, "volume"), D, H, W, C, dev_f32(rays_ndc, "rays_ndc"), N * S, feat.data_ptr(), F, st),
-                  "volume_sample_fwd")
-        elif C == 8:
-            dirs = torch.empty((N, 3), **f32)
-            check(lib.mvsnerf_gather_fwd(dev_f32(vol_cl, "volume"), D, H, W, channels_last_images(imgs).data_ptr(), V, imgs.shape[2], imgs.shape[3],
-                                         dev_f32(w2cs, "w2cs"), dev_f32(intrinsics, "intrinsics"), dev_f32(rays_pts, "rays_pts"), dev_f32(rays_ndc, "rays_ndc"),
-                                         N, S, dev_f32(rays_dir, "rays_dir"), feat.data_ptr(), F, dirs.data_ptr(), st), "gather_fwd")
-        else:
-            raise RuntimeError(f"ray march: the volume has {C} channels; expected 8 or 8 + 4V = {F}")
-        bf16 = MLP_PRECISION == "bf16"
-        if MLP_PRECISION not in ("fp32", "bf16"):
-            raise RuntimeError(f"training runs the MLP in 'fp32' or 'bf16' (ops.set_mlp_precision), not {MLP_PRECISION!r}")
-        if bf16:
-            packed_b = mlp_pack_bf16([p.detach() for p in mlp_params[0::2]], F)
-            check(lib.mvsnerf_mlp_fwd_bf16_train(packed_b.data_ptr(), packed.data_ptr(), F, rays_ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3,
-                                                 N, S, raw.data_ptr(), saved.data_ptr(), st), "mlp_fwd_bf16_train")
-        else:
-            check(lib.mvsnerf_mlp_fwd_train(packed.data_ptr(), F, rays_ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3, N, S,
-                                            raw.data_ptr(), saved.data_ptr(), st), "mlp_fwd_train")
-        rgb, disp, acc, weights, depth, alpha = composite(raw, z_vals, white_bkgd)
+        dirs = torch.empty((N, 3), **f32)
+        rgb, disp, acc, depth = (torch.empty(sh, **f32) for sh in ((N, 3), (N,), (N,), (N,)))
+        weights, alpha = torch.empty((N, S), **f32), torch.empty((N, S), **f32)
+        packed_b = mlp_pack_bf16([p.detach() for p in mlp_params[0::2]], F) if bf16 else None
+        icl = channels_last_images(imgs) if C == 8 else None
+        a = _lib.RaymarchTrainArgs(
+            vol=dev_f32(vol_cl, "volume"), D=D, H=H, W=W, C=C,
+            imgs_nhwc4=0 if icl is None else icl.data_ptr(), V=V, IH=imgs.shape[2], IW=imgs.shape[3],
+            w2c=dev_f32(w2cs, "w2cs"), K=dev_f32(intrinsics, "intrinsics"), packed_mlp=packed.data_ptr(),
+            packed_mlp_bf16=0 if packed_b is None else packed_b.data_ptr(), bf16=int(bf16),
+            rays_pts=dev_f32(rays_pts, "rays_pts"), rays_ndc=dev_f32(rays_ndc, "rays_ndc"), z_vals=dev_f32(z_vals, "z_vals"),
+            rays_dir=dev_f32(rays_dir, "rays_dir"), N=N, S=S, white_bkgd=int(bool(white_bkgd)),
+            dirs_tmp=dirs.data_ptr(), input_feat=feat.data_ptr(), raw=raw.data_ptr(), saved=saved.data_ptr(),
+            rgb_map=rgb.data_ptr(), disp=disp.data_ptr(), acc=acc.data_ptr(), weights=weights.data_ptr(), depth=depth.data_ptr(), alpha=alpha.data_ptr())
+        check(lib.mvsnerf_raymarch_train_fwd(ctypes.byref(a), stream_ptr()), "raymarch_train_fwd")
         ctx.save_for_backward(rays_ndc, z_vals, raw, saved, packed, *mlp_params)
         ctx.meta = (tuple(volume.shape), (D, H, W, C), N, S, F, bool(white_bkgd), bf16)
         ctx.mark_non_differentiable(feat, raw)
@@ -499,20 +496,18 @@ class RayMarchFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_feat, g_weights, g_depth, g_alpha, g_raw):
+        """The weight re-pack for the transposed products + ONE FFI call (mvsnerf_raymarch_bwd): compositing backward -> MLP data and
+        weight gradients -> trilinear scatter into the volume gradient."""
         lib = _lib.lib()
         rays_ndc, z_vals, raw, saved, packed, *mlp_params = ctx.saved_tensors
         vshape, (D, H, W, C), N, S, F, white, bf16 = ctx.meta
         dev = raw.device
         f32 = dict(device=dev, dtype=torch.float32)
-        st = stream_ptr()
-        ptr = lambda t: 0 if t is None else dev_f32(t.contiguous(), "grad")
-        d_raw = torch.empty((N, S, 4), **f32)
-        g_rgb_c, g_depth_c = (None if g is None else g.contiguous() for g in (g_rgb, g_depth))
-        g_w_c, g_a_c = (None if g is None else g.contiguous() for g in (g_weights, g_alpha))
-        check(lib.mvsnerf_composite_bwd(raw.data_ptr(), z_vals.data_ptr(), N, S, int(white), ptr(g_rgb_c), ptr(g_depth_c), 0,
-                                        ptr(g_w_c), ptr(g_a_c), d_raw.data_ptr(), st), "composite_bwd")
+        grads_in = [None if g is None else g.contiguous() for g in (g_rgb, g_depth, g_weights, g_alpha)]       # kept alive until the launch
+        ptr = lambda t: 0 if t is None else dev_f32(t, "grad")
         weights = [p.detach() for p in mlp_params[0::2]]
         packed_bwd = mlp_pack_bwd_bf16(weights, F) if bf16 else mlp_pack_bwd(weights, F)
+        d_raw = torch.empty((N, S, 4), **f32)
         gslots = torch.empty(lib.mvsnerf_mlp_gradslot_floats(N * S), **f32)
         ws = torch.empty(lib.mvsnerf_mlp_bwd_workspace_floats(), **f32)
         d_feat = torch.empty((N * S, C), **f32)         # C = 8: the volume features only; C = F: the colour volume is a parameter too
@@ -521,12 +516,18 @@ class RayMarchFunction(torch.autograd.Function):
         gwp = (ctypes.c_void_p * 11)(*[g.data_ptr() for g in gws])
         gbp = (ctypes.c_void_p * 11)(*[g.data_ptr() for g in gbs])
         maps = _mlp_bwd_maps(F, dev)
-        check((lib.mvsnerf_mlp_bwd_bf16 if bf16 else lib.mvsnerf_mlp_bwd)(packed.data_ptr(), packed_bwd.data_ptr(), F, raw.data_ptr(), d_raw.data_ptr(), saved.data_ptr(), N, S,
-                                  gslots.data_ptr(), d_feat.data_ptr(), C, gwp, gbp, maps.data_ptr(), ws.data_ptr(), st), "mlp_bwd")
+        gvol_cl = torch.zeros((D, H, W, C), **f32) if ctx.needs_input_grad[0] else None
+        a = _lib.RaymarchBwdArgs(
+            packed_mlp=packed.data_ptr(), packed_bwd=packed_bwd.data_ptr(), bf16=int(bf16), F=F,
+            raw=raw.data_ptr(), saved=saved.data_ptr(), z_vals=z_vals.data_ptr(), rays_ndc=rays_ndc.data_ptr(), N=N, S=S, white_bkgd=int(white),
+            g_rgb=ptr(grads_in[0]), g_depth=ptr(grads_in[1]), g_weights=ptr(grads_in[2]), g_alpha=ptr(grads_in[3]),
+            d_raw=d_raw.data_ptr(), gslots=gslots.data_ptr(), d_feat=d_feat.data_ptr(), n_feat_out=C,
+            gw=ctypes.cast(gwp, ctypes.POINTER(ctypes.c_void_p)), gb=ctypes.cast(gbp, ctypes.POINTER(ctypes.c_void_p)),
+            maps=maps.data_ptr(), workspace=ws.data_ptr(),
+            gvol=0 if gvol_cl is None else gvol_cl.data_ptr(), D=D, H=H, W=W, C=C)
+        check(lib.mvsnerf_raymarch_bwd(ctypes.byref(a), stream_ptr()), "raymarch_bwd")
         g_vol = None
-        if ctx.needs_input_grad[0]:
-            gvol_cl = torch.zeros((D, H, W, C), **f32)
-            check(lib.mvsnerf_volume_sample_bwd(D, H, W, C, rays_ndc.data_ptr(), N * S, d_feat.data_ptr(), C, gvol_cl.data_ptr(), st), "volume_sample_bwd")
+        if gvol_cl is not None:
             g_vol = gvol_cl.permute(3, 0, 1, 2)
             if len(vshape) == 5:
                 g_vol = g_vol.unsqueeze(0)
