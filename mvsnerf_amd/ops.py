@@ -456,7 +456,7 @@ class RayMarchFunction(torch.autograd.Function):
     Inputs that never carry gradients in the reference's losses (rays, source images, cameras) are not differentiated."""
 
     @staticmethod
-    def forward(ctx, volume, imgs, w2cs, intrinsics, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd, packed, *mlp_params):
+    def forward(ctx, volume, imgs, w2cs, intrinsics, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd, packed, dp_samples, *mlp_params):
         """ONE FFI call (mvsnerf_raymarch_train_fwd): lookups -> MLP training forward with activation store -> compositing."""
         lib = _lib.lib()
         vol_cl = channels_last_volume(volume)
@@ -490,7 +490,7 @@ class RayMarchFunction(torch.autograd.Function):
             rgb_map=rgb.data_ptr(), disp=disp.data_ptr(), acc=acc.data_ptr(), weights=weights.data_ptr(), depth=depth.data_ptr(), alpha=alpha.data_ptr())
         check(lib.mvsnerf_raymarch_train_fwd(ctypes.byref(a), stream_ptr()), "raymarch_train_fwd")
         ctx.save_for_backward(rays_ndc, z_vals, raw, saved, packed, *mlp_params)
-        ctx.meta = (tuple(volume.shape), (D, H, W, C), N, S, F, bool(white_bkgd), bf16)
+        ctx.meta = (tuple(volume.shape), (D, H, W, C), N, S, F, bool(white_bkgd), bf16, bool(dp_samples))
         ctx.mark_non_differentiable(feat, raw)
         return rgb, feat, weights, depth, alpha, raw
 
@@ -500,7 +500,7 @@ class RayMarchFunction(torch.autograd.Function):
         weight gradients -> trilinear scatter into the volume gradient."""
         lib = _lib.lib()
         rays_ndc, z_vals, raw, saved, packed, *mlp_params = ctx.saved_tensors
-        vshape, (D, H, W, C), N, S, F, white, bf16 = ctx.meta
+        vshape, (D, H, W, C), N, S, F, white, bf16, dp_samples = ctx.meta
         dev = raw.device
         f32 = dict(device=dev, dtype=torch.float32)
         grads_in = [None if g is None else g.contiguous() for g in (g_rgb, g_depth, g_weights, g_alpha)]       # kept alive until the launch
@@ -517,6 +517,10 @@ class RayMarchFunction(torch.autograd.Function):
         gbp = (ctypes.c_void_p * 11)(*[g.data_ptr() for g in gbs])
         maps = _mlp_bwd_maps(F, dev)
         gvol_cl = torch.zeros((D, H, W, C), **f32) if ctx.needs_input_grad[0] else None
+        from . import distributed as DD
+        # data-parallel fine-tuning of the volume: see volume_grad_from_all_ranks below (the scatter then runs after the call)
+        exchange = dp_samples and gvol_cl is not None and DD._collective_needed()
+        gvol_arg = None if exchange else gvol_cl
         a = _lib.RaymarchBwdArgs(
             packed_mlp=packed.data_ptr(), packed_bwd=packed_bwd.data_ptr(), bf16=int(bf16), F=F,
             raw=raw.data_ptr(), saved=saved.data_ptr(), z_vals=z_vals.data_ptr(), rays_ndc=rays_ndc.data_ptr(), N=N, S=S, white_bkgd=int(white),
@@ -524,8 +528,10 @@ class RayMarchFunction(torch.autograd.Function):
             d_raw=d_raw.data_ptr(), gslots=gslots.data_ptr(), d_feat=d_feat.data_ptr(), n_feat_out=C,
             gw=ctypes.cast(gwp, ctypes.POINTER(ctypes.c_void_p)), gb=ctypes.cast(gbp, ctypes.POINTER(ctypes.c_void_p)),
             maps=maps.data_ptr(), workspace=ws.data_ptr(),
-            gvol=0 if gvol_cl is None else gvol_cl.data_ptr(), D=D, H=H, W=W, C=C)
+            gvol=0 if gvol_arg is None else gvol_arg.data_ptr(), D=D, H=H, W=W, C=C)
         check(lib.mvsnerf_raymarch_bwd(ctypes.byref(a), stream_ptr()), "raymarch_bwd")
+        if exchange:
+            volume_grad_from_all_ranks(d_feat, rays_ndc.reshape(-1, 3), gvol_cl)
         g_vol = None
         if gvol_cl is not None:
             g_vol = gvol_cl.permute(3, 0, 1, 2)
@@ -534,11 +540,52 @@ class RayMarchFunction(torch.autograd.Function):
         param_grads = []
         for gw, gb in zip(gws, gbs):
             param_grads += [gw, gb]
-        return (g_vol, None, None, None, None, None, None, None, None, None, *param_grads)
+        return (g_vol, None, None, None, None, None, None, None, None, None, None, *param_grads)
 
 
-def raymarch_train(volume, imgs, w2cs, intrinsics, net, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd=False):
-    """Differentiable rendering(): `net` is a models.MVSNeRF; returns the dict of ops.raymarch."""
+def _scatter_hip(gvol_cl, ndc, g):
+    D, H, W, C = gvol_cl.shape
+    check(_lib.lib().mvsnerf_volume_sample_bwd(D, H, W, C, ndc.data_ptr(), ndc.shape[0], g.data_ptr(), C, gvol_cl.data_ptr(), stream_ptr()), "volume_sample_bwd")
+
+
+def volume_grad_from_all_ranks(d_feat, ndc, gvol_cl, group=None, scatter=_scatter_hip):
+    """Data-parallel gradient of a learnable RefVolume WITHOUT reducing the volume-sized tensor (SURVEY.md 5 / 8e "Fine-tune").
+
+    The volume gradient is the trilinear scatter of the per-sample feature gradients d_feat (P_local x C).  A dense all-reduce of it moves
+    2 x (world-1)/world x 150-246 MB per rank and step over xGMI; the SAMPLE gradients of all ranks are 36 B + 12 B (NDC) per sample -
+    6 MB for 1024 x 128 samples in total.  So: ONE all_gather of [d_feat | ndc] rows, then every rank scatters the samples of ALL ranks
+    into its own gradient volume (0.16 ms for 131 072 samples) and scales by 1/world - the same mean-over-ranks FlatGradAllReduce gives
+    the other parameters.  Every rank ends with the full gradient; the volume parameter takes no part in the flat all-reduce.
+    (The scatter uses float atomics, so replicas can differ in the last bits; MVSSystemFinetune re-broadcasts the volume from rank 0 every
+    `args.dp_volume_resync` steps.)"""
+    import torch.distributed as dist
+    from . import distributed as DD
+    C = d_feat.shape[1]
+    P = d_feat.shape[0]
+    world = dist.get_world_size(group)
+    # shards may differ by one ray: gather the counts, pad to the largest
+    cnt = torch.tensor([P], device=d_feat.device, dtype=torch.int64)
+    cnts = torch.empty(world, device=d_feat.device, dtype=torch.int64)
+    dist.all_gather_into_tensor(cnts, cnt, group=group)
+    cnts = [int(c) for c in cnts.tolist()]
+    width = max(cnts)
+    row = torch.zeros((width, C + 4), device=d_feat.device, dtype=torch.float32)          # [d_feat (C) | ndc (3) | pad] -> 16-byte rows
+    row[:P, :C] = d_feat
+    row[:P, C:C + 3] = ndc
+    allrows = torch.empty((world * width, C + 4), device=d_feat.device, dtype=torch.float32)
+    dist.all_gather_into_tensor(allrows, row, group=group)
+    for r, n in enumerate(cnts):
+        if n == 0:
+            continue
+        blk = allrows[r * width:r * width + n]
+        scatter(gvol_cl, blk[:, C:C + 3].contiguous(), blk[:, :C].contiguous())     # `scatter` is replaceable so that the CPU (gloo) tests can drive this exchange
+    gvol_cl.div_(world)
+    return gvol_cl
+
+
+def raymarch_train(volume, imgs, w2cs, intrinsics, net, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd=False, dp_samples=False):
+    """Differentiable rendering(): `net` is a models.MVSNeRF; returns the dict of ops.raymarch.
+    dp_samples: data-parallel volume gradient by exchanging sample gradients (volume_grad_from_all_ranks)."""
     V = imgs.shape[0]
     lins = net.nerf._linears()
     params = []
@@ -546,5 +593,5 @@ def raymarch_train(volume, imgs, w2cs, intrinsics, net, rays_pts, rays_ndc, z_va
         params += [l.weight, l.bias]
     packed = net.packed(8 + 4 * V)
     rgb, feat, weights, depth, alpha, raw = RayMarchFunction.apply(
-        volume, imgs, w2cs, intrinsics, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd, packed, *params)
+        volume, imgs, w2cs, intrinsics, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd, packed, dp_samples, *params)
     return {"rgb_map": rgb, "input_feat": feat, "weights": weights, "depth": depth, "alpha": alpha, "raw": raw}

@@ -111,7 +111,8 @@ def rendering(args, pose_ref, rays_pts, rays_ndc, depth_candidates, rays_o, rays
         if needs_grad:      # training: same kernels + activation store, gradients to the volume and the MLP
             out = ops.raymarch_train(vol, imgs[0].contiguous(), pose_ref["w2cs"][:V].contiguous(),
                                      pose_ref["intrinsics"][:V].contiguous(), network_fn, rays_pts.contiguous(),
-                                     rays_ndc.contiguous(), depth_candidates.contiguous(), rays_dir.contiguous(), white_bkgd)
+                                     rays_ndc.contiguous(), depth_candidates.contiguous(), rays_dir.contiguous(), white_bkgd,
+                                     dp_samples=getattr(args, "dp_volume_grad", "allreduce") == "samples" and vol.requires_grad)
         else:
             out = ops.raymarch(ops.channels_last_volume(vol), imgs[0].contiguous(),
                                pose_ref["w2cs"][:V].contiguous(), pose_ref["intrinsics"][:V].contiguous(),

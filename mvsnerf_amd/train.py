@@ -381,6 +381,16 @@ class MVSSystemFinetune(_ModuleShim):
         self.volume = RefVolume(vol.detach())
         self.grad_vars = [p for p in self.network_fn.parameters()] + list(self.volume.parameters())    # MVSNet stays frozen here
         self._allreduce = None
+        # Data parallelism (rays of the scene's all-rays buffer sharded over the ranks): args.dp_volume_grad selects how the gradient of
+        # the 150-246 MB volume is combined - "samples" (default): all_gather of the per-sample feature gradients + a local scatter on
+        # every rank (ops.volume_grad_from_all_ranks: 6 MB per step instead of a volume-sized all-reduce); "allreduce": the volume joins
+        # the flat all-reduce of the MLP gradients.
+        if not hasattr(args, "dp_volume_grad"):
+            args.dp_volume_grad = "samples"
+        if args.dp_volume_grad not in ("samples", "allreduce"):
+            raise ValueError("args.dp_volume_grad must be 'samples' or 'allreduce'")
+        if args.dp_volume_grad == "samples":
+            self._allreduce = D.FlatGradAllReduce([p for p in self.network_fn.parameters()])           # the volume gradient arrives complete
 
     def update_density_volume(self):
         """:91-99: sigma of every voxel centre from the current volume + MLP (forward_alpha queries), -> (D,H,W)."""
@@ -427,8 +437,29 @@ class MVSSystemFinetune(_ModuleShim):
                     "volume": self.volume.state_dict(), "network_mvs_state_dict": self.MVSNet.state_dict()}, path)
         return path
 
-    fit_steps = MVSSystem.fit_steps
-    dp_mode = MVSSystem.dp_mode
+    def dp_mode(self):
+        return "data"          # every rank feeds its own slice of the all-rays buffer; nothing to slice or re-seed in the step
+
+    def fit_steps(self, batches, optimizer=None):
+        """training_step -> backward -> gradient exchange -> Adam; with args.dp_volume_grad == "samples" the volume is re-broadcast from
+        rank 0 every args.dp_volume_resync steps (default 200) so that last-bit differences of the atomics-ordered scatters cannot add up."""
+        if optimizer is None:
+            optimizer = self.configure_optimizers()[0][0]
+        if self._allreduce is None:
+            self._allreduce = D.FlatGradAllReduce(self.grad_vars)
+        resync = int(getattr(self.args, "dp_volume_resync", 200))
+        losses = []
+        for i, batch in enumerate(batches):
+            optimizer.zero_grad(set_to_none=True)
+            out = self.training_step(batch, i)
+            out["loss"].backward()
+            self._allreduce()
+            optimizer.step()
+            self.global_step += 1
+            if self.args.dp_volume_grad == "samples" and resync > 0 and self.global_step % resync == 0 and D._collective_needed():
+                torch.distributed.broadcast(ops.channels_last_volume(self.volume.feat_volume.data), src=0)     # the (D,H,W,C) view of the same memory
+            losses.append(float(out["loss"].detach()))
+        return losses
 
     def configure_optimizers(self):
         self.optimizer = torch.optim.Adam(self.grad_vars, lr=self.args.lrate, betas=(0.9, 0.999))

@@ -181,3 +181,46 @@ def test_scene_shard_and_loss_scale_single_process():
     assert D.scene_shard([1, 2, 3]) == [1, 2, 3]
     (a,), scale = D.shard_ray_batch((torch.arange(5),), 5)
     assert scale == 1.0 and a.numel() == 5
+
+
+# ------------------------------------------------------------------ fine-tune DP: volume gradient from exchanged sample gradients
+def _cpu_scatter(gvol_cl, ndc, g):
+    """Nearest-voxel stand-in for the trilinear scatter kernel (the exchange logic under test does not care which scatter runs)."""
+    D, H, W, C = gvol_cl.shape
+    idx = ((ndc[:, 2] * (D - 1)).round().long().clamp(0, D - 1) * H + (ndc[:, 1] * (H - 1)).round().long().clamp(0, H - 1)) * W \
+        + (ndc[:, 0] * (W - 1)).round().long().clamp(0, W - 1)
+    gvol_cl.view(-1, C).index_add_(0, idx, g)
+
+
+def _volgrad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    D.init_from_env(device="cpu")
+    from mvsnerf_amd import ops
+    g = torch.Generator().manual_seed(50 + rank)
+    n = 37 if rank == 0 else 29                               # uneven shards
+    d_feat, ndc = torch.randn(n, 8, generator=g), torch.rand(n, 3, generator=g)
+    gvol = torch.zeros(4, 5, 6, 8)
+    ops.volume_grad_from_all_ranks(d_feat, ndc, gvol, scatter=_cpu_scatter)
+    q.put((rank, gvol.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_volume_grad_from_all_ranks_world2():
+    """Every rank ends with (1/world) * scatter of ALL ranks' sample gradients - without a volume-sized collective."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_volgrad_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    expect = torch.zeros(4, 5, 6, 8)
+    for rank, n in ((0, 37), (1, 29)):
+        g = torch.Generator().manual_seed(50 + rank)
+        d_feat, ndc = torch.randn(n, 8, generator=g), torch.rand(n, 3, generator=g)
+        _cpu_scatter(expect, ndc, d_feat)
+    expect /= 2
+    for rank, gv in res:
+        assert torch.allclose(torch.tensor(gv), expect, atol=1e-6), f"rank {rank}"

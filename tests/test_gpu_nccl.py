@@ -123,3 +123,61 @@ def test_bench_rejects_world_size_mismatch():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+def test_finetune_volume_grad_by_sample_exchange_world1():
+    """Fine-tune DP (args.dp_volume_grad = "samples"): the volume gradient is rebuilt on every rank from the all_gathered per-sample
+    feature gradients instead of all-reducing the 150-246 MB tensor.  World size 1 with the collectives forced through RCCL: the
+    gradients must equal the plain (no process group) ones up to the atomics' summation order, and the periodic re-broadcast of the
+    volume must run."""
+    import torch.distributed as dist
+    from mvsnerf_amd import distributed as D, train
+    from mvsnerf_amd.synth import make_rig, pose_ref_of
+    from oracle import mvsnerf_oracle as O
+    from tests.util import load_weights
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    rig = make_rig(64, 96, seed=8, smooth=True)
+    pose = pose_ref_of(rig)
+    src = (rig["images"][:, :3], rig["proj_mats"][:, :3], rig["near_fars"][0, 0], {k: v[:3] for k, v in pose.items()})
+    mlp_sd, mvs_sd = load_weights()
+    g = torch.Generator().manual_seed(0)
+    ro, rd, pix = O.get_rays_mvs(64, 96, pose["intrinsics"][3], pose["c2ws"][3], 256, generator=g)
+    rays = torch.cat([ro.expand(256, 3), rd, torch.full((256, 1), 2.125), torch.full((256, 1), 4.525)], 1)
+    tgt = rig["images_raw"][0, 3][:, pix[0].long(), pix[1].long()].permute(1, 0)
+    batch = {"rays": rays[None], "rgbs": tgt[None]}
+
+    def grads(mode, forced):
+        args = train.default_args(pad=4, batch_size=256, N_samples=32, dp_volume_grad=mode, dp_volume_resync=2)
+        ft = train.MVSSystemFinetune(args, src, n_depth_planes=16).to(dev)
+        ft.network_fn.load_state_dict(mlp_sd)
+        ft.MVSNet.load_state_dict(mvs_sd)
+        with torch.no_grad():                                   # same starting volume in every run
+            ft.volume.feat_volume.copy_(torch.randn(ft.volume.feat_volume.shape, generator=torch.Generator().manual_seed(1)).to(dev))
+        torch.manual_seed(4)
+        if forced:
+            with D.force_collectives():
+                out = ft.training_step(batch, 0)
+                out["loss"].backward()
+                ft._allreduce()
+                gv = ft.volume.feat_volume.grad.clone()
+                ft.zero_grad(set_to_none=True)
+                torch.manual_seed(4)
+                losses = ft.fit_steps([batch] * 4)               # includes two re-broadcasts of the volume (resync = 2)
+        else:
+            out = ft.training_step(batch, 0)
+            out["loss"].backward()
+            gv = ft.volume.feat_volume.grad.clone()
+            losses = None
+        return gv, losses
+
+    ref, _ = grads("allreduce", False)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+    try:
+        got, losses = grads("samples", True)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+    assert float(ref.abs().max()) > 0
+    assert float((got - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    assert losses is not None and all(l == l for l in losses) and losses[-1] < losses[0]
