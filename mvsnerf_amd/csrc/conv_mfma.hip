@@ -253,7 +253,130 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_mfma_kernel(ActSrc a, i
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The deep layers of CostRegNet (32 / 64 output channels, 9 152 .. 73 216 output voxels; models.py:758-761) on
+// v_mfma_f32_32x32x2_f32: implicit GEMM, M = 32 consecutive output voxels, N = output channels, K = 27 taps x Cin.
+// The VALU kernels they replace gave one thread one voxel x 16 channels, i.e. 144 workgroups for conv5/conv6: 10 TFLOP/s, bound by
+// the length of a single thread's FMA chain.  Here a workgroup owns one M-tile and its four waves split the 27 taps (7/7/7/6); the
+// partial accumulators meet in LDS and wave 0 adds them in a fixed order (deterministic) and stores.
+//   lane (m = lane & 31, kh = lane >> 5):  A operand = 4 consecutive input channels of voxel m (one 16-byte load, channel-last input,
+//   pending InPlaceABN applied on the fly), channels 8 cb + 4 kh + j; MFMA j of the quartet contracts channels (8cb + j, 8cb + 4 + j);
+//   B operand = w[tap][ci][32 nb + m] (the layout of mvsnerf_conv3d_pack_weights: consecutive lanes -> consecutive floats).
+// These volumes fit the L2 (conv6 input 2.3 MB), so the 27-fold re-read of the input comes from cache and needs no LDS tile.
+template <int CIN, int COUT, int S>
+__global__ __launch_bounds__(512) void conv3d_k3_mfma32_kernel(ActSrc a, int ld, int Di, int Hi, int Wi, const float* __restrict__ w32,
+                                                              float* __restrict__ out, int Do, int Ho, int Wo)
+{
+    constexpr int NB = COUT / 32, CB = CIN / 8;
+    constexpr int WAVES = 8, NR = WAVES / NB;                    // wave w: output block w % NB, tap range w / NB of NR
+    static_assert(COUT % 32 == 0 && CIN % 8 == 0 && WAVES % NB == 0, "32-wide output blocks, 8-channel k groups");
+    __shared__ __attribute__((aligned(16))) float red[(NR - 1) * NB * 16 * 64];
+    __shared__ __attribute__((aligned(16))) float act_sc[CIN], act_sh[CIN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, kh = lane >> 5;
+    const int nb = wave % NB, rg = wave / NB;
+    const bool lazy = a.scale != nullptr;
+    if (lazy) {
+        for (int c = tid; c < CIN; c += 512) { act_sc[c] = a.scale[c]; act_sh[c] = a.shift[c]; }
+        __syncthreads();
+    }
+    const int64_t nvox = (int64_t)Do * Ho * Wo;
+    const int64_t vox = (int64_t)blockIdx.x * 32 + m;
+    const bool live = vox < nvox;
+    const int64_t vc = live ? vox : nvox - 1;
+    const int x = (int)(vc % Wo), y = (int)((vc / Wo) % Ho), z = (int)(vc / ((int64_t)Wo * Ho));
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int t0 = (27 * rg) / NR, t1 = (27 * (rg + 1)) / NR;    // 27 taps dealt to NR ranges (3 or 4 each for NR = 8)
+#pragma unroll 1
+    for (int tap = t0; tap < t1; ++tap) {
+        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+        const int zi = z * S - 1 + dz, yi = y * S - 1 + dy, xi = x * S - 1 + dx;
+        const bool in = live && zi >= 0 && zi < Di && yi >= 0 && yi < Hi && xi >= 0 && xi < Wi;
+        const float* src = a.x + (in ? ((int64_t)zi * Hi + yi) * Wi + xi : 0) * ld + kh * 4;
+        const float* wt = w32 + ((int64_t)tap * CB * COUT + nb * 32 + m) * 8 + kh * 4;      // w32[tap][cb][co][8]
+        f32x4 av[CB], bw[CB];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {                        // all loads of the tap first: 2 CB independent 16-byte requests in flight
+            av[cb] = *reinterpret_cast<const f32x4*>(src + cb * 8);
+            bw[cb] = *reinterpret_cast<const f32x4*>(wt + (int64_t)cb * COUT * 8);
+        }
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            f32x4 v = av[cb];
+            if (lazy) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(act_sc + cb * 8 + kh * 4), sh = *reinterpret_cast<const f32x4*>(act_sh + cb * 8 + kh * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], sc[j], sh[j]);
+            }
+            if (!in) v = f32x4{0, 0, 0, 0};                      // zero padding of the ACTIVATED input
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], bw[cb][j], acc, 0, 0, 0);
+        }
+    }
+    // combine the tap ranges: ranges 1.. park their accumulators in LDS, range 0 adds them in order (deterministic) and stores
+    if (rg > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(((rg - 1) * NB + nb) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (rg == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[r];
+#pragma unroll
+            for (int w = 0; w < NR - 1; ++w) v += red[((w * NB + nb) * 16 + r) * 64 + lane];
+            // D: register r of lane (n = m, half = kh) = output voxel (r&3) + 8 (r>>2) + 4 half of the tile, channel 32 nb + n
+            const int64_t ov = (int64_t)blockIdx.x * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (ov < nvox) out[ov * COUT + nb * 32 + m] = v;
+        }
+    }
+}
+
+// weights [tap][ci][co] (mvsnerf_conv3d_pack_weights) -> [tap][ci/8][co][8]: a lane's four k-values become one 16-byte load
+__global__ __launch_bounds__(256) void conv_w32_repack_kernel(const float* __restrict__ wp, float* __restrict__ w32, int CIN, int COUT)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 27 * CIN * COUT) return;
+    const int c8 = i & 7, co = (i >> 3) % COUT, cb = (i / (8 * COUT)) % (CIN / 8), tap = i / (CIN * COUT);
+    w32[i] = wp[((int64_t)tap * CIN + cb * 8 + c8) * COUT + co];
+}
+
 }  // namespace
+
+// Called by mvsnerf_conv3d_fwd (encoder.hip) for the layers with 32 / 64 output channels; MVSNERF_EUNSUPPORTED = not instantiated.
+int mvs_conv3d_mfma32(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int D, int H, int W, const float* w32, int Cout, int stride,
+                      float* out, hipStream_t st)
+{
+    if (b.x || (cin_ld & 3)) return MVSNERF_EUNSUPPORTED;
+    const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const unsigned grid = mvs_cdiv((int64_t)Do * Ho * Wo, 32);
+#define MVS_M32(CIN, COUT, S) conv3d_k3_mfma32_kernel<CIN, COUT, S><<<grid, 512, 0, st>>>(a, cin_ld, D, H, W, w32, out, Do, Ho, Wo)
+    switch (Cin * 1000 + Cout * 10 + stride) {
+        case 16 * 1000 + 32 * 10 + 2: MVS_M32(16, 32, 2); break;     // conv3 (and the data gradient of conv9)
+        case 32 * 1000 + 32 * 10 + 1: MVS_M32(32, 32, 1); break;     // conv4 (and its data gradient)
+        case 32 * 1000 + 64 * 10 + 2: MVS_M32(32, 64, 2); break;     // conv5 (and the data gradient of conv7)
+        case 64 * 1000 + 64 * 10 + 1: MVS_M32(64, 64, 1); break;     // conv6 (and its data gradient)
+        default: return MVSNERF_EUNSUPPORTED;
+    }
+#undef MVS_M32
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+bool mvs_conv3d_mfma32_supported(int Cin, int Cout, int stride)
+{
+    const int k = Cin * 1000 + Cout * 10 + stride;
+    return k == 16322 || k == 32321 || k == 32642 || k == 64641;
+}
+
+int mvs_conv_w32_repack(const float* wpacked, float* w32, int Cin, int Cout, hipStream_t st)
+{
+    conv_w32_repack_kernel<<<mvs_cdiv((int64_t)27 * Cin * Cout, 256), 256, 0, st>>>(wpacked, w32, Cin, Cout);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
 
 // Called by mvsnerf_conv3d_fwd (encoder.hip) for stride-1 layers with 8 output channels.  Returns MVSNERF_EUNSUPPORTED for a
 // channel count it is not instantiated for (the caller then takes the VALU kernel).

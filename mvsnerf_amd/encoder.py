@@ -316,6 +316,18 @@ class _PackedConv:
         self.cache[mode] = (key, buf)
         return buf
 
+    def get_mfma(self, mode="fwd"):
+        """[tap][ci/8][co][8] re-layout of get(mode) for the matrix-core kernel of the 32/64-channel layers (same cache policy)."""
+        base = self.get(mode)
+        hit = self.cache.get(mode + "_m32")
+        if hit is not None and hit[0] is base:
+            return hit[1]
+        ci_k, co_k = (self.cin_pad, self.cout) if mode == "fwd" else (self.cout, self.cin_pad)
+        buf = torch.empty_like(base)
+        check(_lib.lib().mvsnerf_conv3d_pack_weights_mfma(base.data_ptr(), ci_k, co_k, buf.data_ptr(), stream_ptr()), "conv3d_pack_weights_mfma")
+        self.cache[mode + "_m32"] = (base, buf)
+        return buf
+
 
 def _abn_stats(raw, n_vox, bn, update_running=True):
     C = bn.num_features
@@ -361,11 +373,17 @@ def _ptrs(src):
     return src.data_ptr(), 0, 0
 
 
-def _conv(src1, src2, dims_in, cin_ld, wbuf, cin_k, cout_k, stride):
-    """k3 p1 convolution kernel launch: input (D,H,W) with channel stride cin_ld -> raw (Do,Ho,Wo,cout_k)."""
+def _conv(src1, src2, dims_in, cin_ld, wbuf, cin_k, cout_k, stride, packed=None, mode="fwd"):
+    """k3 p1 convolution kernel launch: input (D,H,W) with channel stride cin_ld -> raw (Do,Ho,Wo,cout_k).
+    packed (+ mode): the layer's _PackedConv - lets the 32/64-channel layers take the matrix-core kernel with its own weight layout."""
     D, H, W, _ = dims_in
     Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
     out = torch.empty((Do, Ho, Wo, cout_k), device=wbuf.device, dtype=torch.float32)
+    if packed is not None and src2 is None and _lib.lib().mvsnerf_conv3d_mfma_supported(cin_k, cout_k, stride):
+        x, sc, sh = _ptrs(src1)
+        check(_lib.lib().mvsnerf_conv3d_mfma_fwd(x, sc, sh, cin_k, cin_ld, D, H, W, packed.get_mfma(mode).data_ptr(), cout_k, stride,
+                                                 out.data_ptr(), stream_ptr()), "conv3d_mfma_fwd")
+        return out
     check(_lib.lib().mvsnerf_conv3d_fwd(*_ptrs(src1), *_ptrs(src2), cin_k, cin_ld, D, H, W, wbuf.data_ptr(), cout_k, stride,
                                         out.data_ptr(), stream_ptr()), "conv3d_fwd")
     return out
@@ -402,7 +420,7 @@ class ConvBnReLU3D(nn.Module):
 
     def lazy(self, src1, dims_in, cin_ld, src2=None):
         pk = self._packed
-        raw = _conv(src1, src2, dims_in, cin_ld, pk.get(), pk.cin_pad, pk.cout, self.stride)
+        raw = _conv(src1, src2, dims_in, cin_ld, pk.get(), pk.cin_pad, pk.cout, self.stride, packed=pk)
         D, H, W, C = raw.shape
         scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self.bn, update_running=self.bn.training)
         return _Lazy(raw, scale, shift, (D, H, W, C), mean, invstd)
@@ -576,7 +594,7 @@ class _CostRegFunction(torch.autograd.Function):
             gx, gbw, gbb = _abn_bwd(out_lz, lay[1], g_act1, g_act2)
             pk = lay._packed
             gw = _wgrad(in1, in2, pk.cin, gx, None, pk.cout, pk.cout, in1.dims[:3], out_lz.dims[:3], 2, tuple(lay[0].weight.shape))
-            g_in = _conv(gx, None, out_lz.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin, 2)       # data grad = stride-2 conv
+            g_in = _conv(gx, None, out_lz.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin, 2, packed=pk, mode="dgrad")       # data grad = stride-2 conv
             grads[i] = (gw, gbw, gbb)
             return g_in
 
@@ -588,7 +606,7 @@ class _CostRegFunction(torch.autograd.Function):
             if not need_dgrad:
                 return None
             if lay.stride == 1:
-                return _conv(gx, None, out_lz.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin_pad, 1)
+                return _conv(gx, None, out_lz.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin_pad, 1, packed=pk, mode="dgrad")
             return _conv_t(gx, None, out_lz.dims, pk.get("dgrad"), pk.cout, pk.cin_pad)
 
         g_u9c2 = up_block(9, L[9], u11, c2, u9, g)               # conv11: grad w.r.t. A(c2)+A(u9)

@@ -1,5 +1,4 @@
-"""Scene-encode stage times (config 2) with the A/B switches of the encoder: blocked cost volume + matrix-core conv0 (default),
-channel-last cost volume + matrix-core conv0, channel-last + VALU conv0."""
+"""Scene-encode stage times (config 2) with the A/B switches of the encoder."""
 import sys, torch
 sys.path.insert(0, '.')
 from mvsnerf_amd import _lib, encoder
@@ -7,10 +6,12 @@ from mvsnerf_amd.synth import make_rig
 rig = make_rig(512, 640, seed=1234)
 dev = torch.device('cuda')
 ref = None
+L = _lib.lib()
 for blocked, mfma in ((True, 1), (False, 1), (False, 0), (True, 1)):
     encoder.BLOCKED_COST = blocked
-    _lib.lib().mvsnerf_tune(b"conv_mfma", mfma)
+    L.mvsnerf_tune(b"conv_mfma", mfma)
     vol, t = encoder.bench_encode(rig, dev, 24, iters=6)
     if ref is None:
         ref = vol.clone()
     print("blocked", blocked, "conv_mfma", mfma, t, "max |vol - first|", float((vol - ref).abs().max()))
+L.mvsnerf_tune(b"conv_mfma", 1)
