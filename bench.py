@@ -419,7 +419,11 @@ def main():
                 "traffic_source": PMC_FILE + " (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)",
                 "avg_launch_ms": round(t_mlp, 4),
                 "mfma_pipe_busy_frac_pmc": pmc_mfma_busy_frac("mlp_fwd_pipe_kernel"),
-                "s_memtime_ghz": round(clock, 3)}
+                "s_memtime_ghz": round(clock, 3),
+                # the datasheet peak assumes 2.4 GHz; under this kernel the chip sustains s_memtime_ghz (power-limited DVFS): the fp32-MFMA
+                # rate at THAT clock is 64 FLOP/clk/SIMD x 1024 SIMDs x clock - what the matrix pipes could deliver in this launch at most
+                "peak_at_sustained_clock": round(64 * 1024 * clock / 1e3, 1),
+                "frac_of_sustained_clock_peak": round(tf / (64 * 1024 * clock / 1e3), 4)}
         for name, t, bps in (("gather_fused_kernel", t_gat, VOL_BYTES_PER_SAMPLE + COL_BYTES_PER_SAMPLE),
                              ("volume_sample_c8_kernel", t_vol, VOL_BYTES_PER_SAMPLE), ("color_sample_kernel", t_col, COL_BYTES_PER_SAMPLE),
                              ("composite_kernel", t_cmp, 28)):

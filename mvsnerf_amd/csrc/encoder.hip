@@ -676,19 +676,28 @@ __global__ __launch_bounds__(256) void abn_partial_kernel(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(64) void abn_finalize_kernel(const float* __restrict__ part, int nblocks, int C, int64_t n,
+__global__ __launch_bounds__(256) void abn_finalize_kernel(const float* __restrict__ part, int nblocks, int C, int64_t n,
                                     const float* __restrict__ weight, const float* __restrict__ bias,
                                     float* __restrict__ running_mean, float* __restrict__ running_var,
                                     float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift,
                                     float* __restrict__ mean_out, float* __restrict__ invstd_out)
 {
-    // one wavefront per channel: lanes stride over the per-block partials (fixed order => deterministic), fp64 combine
-    const int c = blockIdx.x, lane = threadIdx.x;
+    // one workgroup of 256 threads per channel: thread t adds the partials of workgroups t, t+256, ... (<= 4 independent loads; a single
+    // wavefront walking 1024 partials in 16 dependent steps made this a 8.5 us kernel, 10-18 of them per scene encode), then a
+    // fixed-order tree in LDS (deterministic), fp64 throughout
+    const int c = blockIdx.x, t = threadIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = lane; b < nblocks; b += 64) { s += (double)part[((int64_t)b * 2) * C + c]; q += (double)part[((int64_t)b * 2 + 1) * C + c]; }
+    for (int b = t; b < nblocks; b += 256) { s += (double)part[((int64_t)b * 2) * C + c]; q += (double)part[((int64_t)b * 2 + 1) * C + c]; }
+    __shared__ double rs[256], rq[256];
+    rs[t] = s; rq[t] = q;
+    __syncthreads();
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { s += __shfl_xor(s, d); q += __shfl_xor(q, d); }
-    if (lane != 0) return;
+    for (int d = 128; d >= 1; d >>= 1) {
+        if (t < d) { rs[t] += rs[t + d]; rq[t] += rq[t + d]; }
+        __syncthreads();
+    }
+    if (t != 0) return;
+    s = rs[0]; q = rq[0];
     const double mean = s / (double)n;
     double var = q / (double)n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -705,6 +714,10 @@ __global__ __launch_bounds__(64) void abn_finalize_kernel(const float* __restric
     }
 }
 
+// (Measured and dropped: folding this kernel into abn_partial_kernel through a "last workgroup finalizes" ticket.  With an agent-scope
+// release fence per workgroup the 5 us partial kernel took 60 us (one L2 write-back per workgroup); with write-through partial stores and
+// a parallel read by the last workgroup 20 us - the last workgroup reads nb x 2C partials that no cache holds, alone, after everybody
+// else has left.  Two small launches, 5 + 5.5 us, are faster.)
 extern "C" size_t mvsnerf_abn_workspace_floats(int C) { return (size_t)1024 * 2 * C + 2 * C; }
 
 extern "C" int mvsnerf_abn_stats(const float* x, int64_t n_vox, int C, const float* weight, const float* bias,
@@ -725,7 +738,7 @@ extern "C" int mvsnerf_abn_stats(const float* x, int64_t n_vox, int C, const flo
         default: return MVSNERF_EUNSUPPORTED;
     }
     MVS_LAUNCH_CHECK();
-    abn_finalize_kernel<<<C, 64, 0, st>>>(workspace, nb, C, n_vox, weight, bias, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out);
+    abn_finalize_kernel<<<C, 256, 0, st>>>(workspace, nb, C, n_vox, weight, bias, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
