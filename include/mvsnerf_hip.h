@@ -105,8 +105,9 @@ int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const float* shift1
                        int Cin, int cin_ld, int D, int H, int W, const float* wpacked, int Cout, int stride,
                        float* out, void* stream);
 /* conv0 of CostRegNet (models.py:756; k3, stride 1, Cout = 8, raw input) on v_mfma_f32_4x4x1_16B_f32, input in channel
- * blocks of 8 (see mvsnerf_planesweep_costvar_blocked_fwd), Cin = 4*ceil((32+3V)/4); weights as for conv3d_fwd. */
-int mvsnerf_conv3d_c8_blocked_fwd(const float* x_blocked, int Cin, int D, int H, int W, const float* wpacked, float* out, void* stream);
+ * blocks of 8 (see mvsnerf_planesweep_costvar_blocked_fwd), Cin = 4*ceil((32+3V)/4) channels of which the first Cin_real = 32+3V exist
+ * (products with the zero padding are skipped); weights as for conv3d_fwd. */
+int mvsnerf_conv3d_c8_blocked_fwd(const float* x_blocked, int Cin, int Cin_real, int D, int H, int W, const float* wpacked, float* out, void* stream);
 /* The same convolution for the deep layers (Cout = 32 | 64; models.py:758-761: conv3..conv6, and the data gradients that have these
  * shapes) on v_mfma_f32_32x32x2_f32.  conv3d_mfma_supported: 1 when (Cin, Cout, stride) is built (and the "conv_mfma" switch is on);
  * conv3d_pack_weights_mfma: packed[tap][ci][co] (mvsnerf_conv3d_pack_weights) -> w32[tap][ci/8][co][8]; one lazily-activated source. */
@@ -114,6 +115,10 @@ int mvsnerf_conv3d_mfma_supported(int Cin, int Cout, int stride);
 int mvsnerf_conv3d_pack_weights_mfma(const float* wpacked, int Cin, int Cout, float* w32, void* stream);
 int mvsnerf_conv3d_mfma_fwd(const float* x1, const float* scale1, const float* shift1, int Cin, int cin_ld, int D, int H, int W,
                             const float* w32, int Cout, int stride, float* out, void* stream);
+/* The transposed convolutions (conv7/9/11) on v_mfma_f32_32x32x2_f32: plain (already activated) input x[D][H][W][Cin], weights from
+ * mvsnerf_conv3d_pack_weights_mfma; raw out[2D][2H][2W][Cout]. */
+int mvsnerf_conv_transpose3d_mfma_supported(int Cin, int Cout);
+int mvsnerf_conv_transpose3d_mfma_fwd(const float* x, int Cin, int D, int H, int W, const float* w32, int Cout, float* out, void* stream);
 int mvsnerf_conv_transpose3d_fwd(const float* x1, const float* scale1, const float* shift1,
                                  const float* x2, const float* scale2, const float* shift2,
                                  int Cin, int D, int H, int W, const float* wpacked, int Cout, float* out, void* stream);

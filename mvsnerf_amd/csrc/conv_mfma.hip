@@ -109,7 +109,7 @@ __device__ __forceinline__ void wstage_store(float* __restrict__ wt, int tid, co
     }
 }
 
-template <int CIN, int C0, int CKC>
+template <int CIN, int C0, int CKC, int CREAL>          // CREAL: real input channels (<= CIN): k-values beyond them are zero padding and skipped
 __device__ __forceinline__ void mfma_chunk(const float* __restrict__ wtile, const float* __restrict__ tile, int wave, int lane, f32x4 (&acc)[8])
 {
     constexpr int K4 = CKC / 4;
@@ -140,7 +140,7 @@ __device__ __forceinline__ void mfma_chunk(const float* __restrict__ wtile, cons
         av[j] = *reinterpret_cast<const f32x4*>(alane[dx][c4] + (dz * PY + j) * PX * CK);
     };
     // group (dz, dx, c4) with its operands in av / bd; (ndz, ndx, nc4) = the group to refill for (has_next)
-    auto group = [&](f32x4 (&bd)[3], bool has_next, int ndz, int ndx, int nc4) {
+    auto group = [&](f32x4 (&bd)[3], int c4, bool has_next, int ndz, int ndx, int nc4) {
         // rows j and j+5 together: P_j feeds M-tiles j, j-1, j-2 and P_{j+5} feeds j+5, j+4, j+3 - six different accumulators, so that
         // consecutive MFMAs never wait for each other's result (three accumulators in turn ran the loop 12 % slower)
 #pragma unroll
@@ -152,7 +152,8 @@ __device__ __forceinline__ void mfma_chunk(const float* __restrict__ wtile, cons
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int jj = j + 5 * h, t = jj - dy;
-                        if (t >= 0 && t < 8) acc[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[jj][k], bd[dy][k], acc[t], 0, 0, 0);
+                        if (t >= 0 && t < 8 && C0 + c4 * 4 + k < CREAL)        // (c4 is a constant at every call site: folded)
+                            acc[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[jj][k], bd[dy][k], acc[t], 0, 0, 0);
                     }
             if (has_next) { fetch_a(ndz, ndx, nc4, j); fetch_a(ndz, ndx, nc4, j + 5); }
             __builtin_amdgcn_sched_barrier(0);
@@ -172,7 +173,7 @@ __device__ __forceinline__ void mfma_chunk(const float* __restrict__ wtile, cons
                 const bool has_next = !last || dz < 2;
                 if (has_next) fetch_b(ndz, ndx, nc4, bw[(g + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                group(bw[g & 1], has_next, ndz, ndx, nc4);
+                group(bw[g & 1], g % K4, has_next, ndz, ndx, nc4);
             }
         }
     } else {                                           // 4-channel tail chunk: nine groups, straight line
@@ -182,12 +183,12 @@ __device__ __forceinline__ void mfma_chunk(const float* __restrict__ wtile, cons
             const int n = g + 1, ndz = n / NG, ndx = (n % NG) / K4, nc4 = n % K4;
             if (has_next) fetch_b(ndz, ndx, nc4, bw[(g + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
-            group(bw[g & 1], has_next, ndz, ndx, nc4);
+            group(bw[g & 1], g % K4, has_next, ndz, ndx, nc4);
         }
     }
 }
 
-template <int CIN, bool BLOCKED>
+template <int CIN, int CREAL, bool BLOCKED>
 __global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_mfma_kernel(ActSrc a, int ld, int D, int H, int W,
                                                                     const float* __restrict__ wp, float* __restrict__ out, int swz)
 {
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_mfma_kernel(ActSrc a, i
             wstage_load<CIN, C0_ + 8, (CIN - C0_ - 8 >= 8) ? 8 : 4>(wp, tid, wr);                                    \
         }                                                                                                             \
         }                                                                                                             \
-        mfma_chunk<CIN, C0_, CKC_>(wtile, tile, wave, lane, acc);                                                        \
+        mfma_chunk<CIN, C0_, CKC_, CREAL>(wtile, tile, wave, lane, acc);                                                        \
     }
     MVS_CH(0) MVS_CH(1) MVS_CH(2) MVS_CH(3) MVS_CH(4) MVS_CH(5) MVS_CH(6) MVS_CH(7)
 #undef MVS_CH
@@ -334,6 +335,99 @@ __global__ __launch_bounds__(512) void conv3d_k3_mfma32_kernel(ActSrc a, int ld,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Transposed 3x3x3 convolution, stride 2, padding 1, output_padding 1 (models.py:739-752: conv7 64->32, conv9 32->16, conv11 16->8) on
+// v_mfma_f32_32x32x2_f32.  out[o] = sum over taps k with o = 2 i - 1 + k.  Per dimension an output of parity 0 (o = 2i) has one tap
+// (k = 1, input i) and one of parity 1 (o = 2i + 1) two (k = 0 from input i + 1, k = 2 from input i), so the eight parity classes of
+// o are eight small gather-form convolutions over the SAME input positions i.  M = 32 consecutive input positions.  The 32 columns of
+// the MFMA are COUT output channels x NCLS = 32 / COUT parity classes of the innermost dimensions (COUT = 32: one class; 16: the two x
+// parities; 8: the four (y, x) parities), so that no column is padding; the remaining ("outer") parity bits come from blockIdx.y.  The
+// contraction enumerates, for merged dimensions, both input offsets {0, 1} (a column whose parity has no tap at an offset gets a zero
+// weight: 25 % / 44 % of the products for COUT = 16 / 8), for outer dimensions the one or two taps of the parity, times Cin.
+// Workgroup = (M-tile, outer class); its 8 waves deal the (offset combination, 8-channel group) units round-robin and meet in LDS.
+// WAVES waves share an M-tile (they deal the contraction units and meet in LDS); TPW M-tiles per workgroup.  conv7 has 8..64 units per
+// tile (8 waves); conv11 has 8 or 16 - with 8 waves the LDS reduction cost more than the products (281 us against 199 us for the VALU
+// kernel), one wave per tile and no reduction at all is the right shape there.
+template <int CIN, int COUT, int WAVES, int TPW>
+__global__ __launch_bounds__(64 * WAVES * TPW) void convT3d_k3s2_mfma32_kernel(const float* __restrict__ x, int Di, int Hi, int Wi,
+                                                                              const float* __restrict__ w32, float* __restrict__ out)
+{
+    constexpr int NCLS = 32 / COUT, MD = NCLS == 1 ? 0 : NCLS == 2 ? 1 : 2;      // merged dimensions: none | x | y and x
+    constexpr int CB = CIN / 8;
+    static_assert(COUT == 8 || COUT == 16 || COUT == 32, "32 columns = COUT channels x 32/COUT parity classes");
+    __shared__ __attribute__((aligned(16))) float red_all[TPW * (WAVES > 1 ? WAVES - 1 : 1) * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wv % WAVES, tsel = wv / WAVES;                // wave within its tile, tile within the workgroup
+    float* red = red_all + tsel * (WAVES > 1 ? WAVES - 1 : 1) * 16 * 64;
+    const int64_t tile = (int64_t)blockIdx.x * TPW + tsel;
+    const int m = lane & 31, kh = lane >> 5;
+    const int oc = blockIdx.y;                                     // outer parity bits: MD = 0: (pz,py,px); 1: (pz,py); 2: (pz)
+    const int pz = MD == 0 ? (oc >> 2) & 1 : MD == 1 ? (oc >> 1) & 1 : oc & 1;
+    const int py_o = MD == 0 ? (oc >> 1) & 1 : oc & 1;             // used when y is an outer dimension (MD <= 1)
+    const int px_o = oc & 1;                                       // used when x is an outer dimension (MD == 0)
+    // this lane as a B/D column: channel and merged-dimension parities
+    const int co = m % COUT, icls = m / COUT;
+    const int py_c = MD == 2 ? (icls >> 1) & 1 : py_o, px_c = MD >= 1 ? icls & 1 : px_o;
+    // this lane as an A row: input position of the M-tile
+    const int64_t nin = (int64_t)Di * Hi * Wi;
+    const int64_t pos = tile * 32 + m;
+    const bool live = pos < nin;
+    const int64_t pc = live ? pos : nin - 1;
+    const int ix = (int)(pc % Wi), iy = (int)((pc / Wi) % Hi), iz = (int)(pc / ((int64_t)Wi * Hi));
+    // contraction entries per dimension: (input offset, kernel tap or -1) - uniform per workgroup for outer dims, per column for merged
+    const int nz = pz ? 2 : 1;
+    const int ny = MD == 2 ? 2 : (py_o ? 2 : 1);
+    const int nx = MD >= 1 ? 2 : (px_o ? 2 : 1);
+    auto tap_of = [](int parity, int off, bool merged, int entry) -> int {          // kernel index along one dimension, -1 = no tap
+        if (merged) return parity ? (off ? 0 : 2) : (off ? -1 : 1);
+        return parity ? (entry ? 2 : 0) : 1;
+    };
+    auto off_of = [](int parity, bool merged, int entry) -> int { return merged ? entry : (parity ? (entry ? 0 : 1) : 0); };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int n_units = nz * ny * nx * CB;
+#pragma unroll 1
+    for (int u = wave; u < n_units; u += WAVES) {
+        const int cb = u % CB, e = u / CB;
+        const int ex = e % nx, ey = (e / nx) % ny, ez = e / (nx * ny);
+        const int oz = off_of(pz, false, ez), oy = off_of(py_o, MD == 2, ey), ox = off_of(px_o, MD >= 1, ex);     // input offsets (uniform)
+        const int kz = tap_of(pz, oz, false, ez), ky = tap_of(py_c, oy, MD == 2, ey), kx = tap_of(px_c, ox, MD >= 1, ex);   // taps (per column)
+        const int zi = iz + oz, yi = iy + oy, xi = ix + ox;
+        const bool in = live && zi < Di && yi < Hi && xi < Wi;
+        f32x4 av = {0, 0, 0, 0}, bw = {0, 0, 0, 0};
+        if (in) av = *reinterpret_cast<const f32x4*>(x + (((int64_t)zi * Hi + yi) * Wi + xi) * CIN + cb * 8 + kh * 4);
+        if (ky >= 0 && kx >= 0)
+            bw = *reinterpret_cast<const f32x4*>(w32 + ((int64_t)(((kz * 3 + ky) * 3 + kx) * CB + cb) * COUT + co) * 8 + kh * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bw[j], acc, 0, 0, 0);
+    }
+    if constexpr (WAVES > 1) {
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        const int Ho = 2 * Hi, Wo = 2 * Wi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[r];
+            if constexpr (WAVES > 1) {
+#pragma unroll
+                for (int w = 0; w < WAVES - 1; ++w) v += red[(w * 16 + r) * 64 + lane];
+            }
+            // D: register r of lane (column m, half kh) = input position (r&3) + 8 (r>>2) + 4 kh of the tile
+            const int64_t ip = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (ip < nin) {
+                const int jx = (int)(ip % Wi), jy = (int)((ip / Wi) % Hi), jz = (int)(ip / ((int64_t)Wi * Hi));
+                out[((((int64_t)(2 * jz + pz)) * Ho + 2 * jy + py_c) * Wo + 2 * jx + px_c) * COUT + co] = v;
+            }
+        }
+    }
+}
+
 // weights [tap][ci][co] (mvsnerf_conv3d_pack_weights) -> [tap][ci/8][co][8]: a lane's four k-values become one 16-byte load
 __global__ __launch_bounds__(256) void conv_w32_repack_kernel(const float* __restrict__ wp, float* __restrict__ w32, int CIN, int COUT)
 {
@@ -365,6 +459,22 @@ int mvs_conv3d_mfma32(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int
     return MVSNERF_OK;
 }
 
+// transposed convolution; plain (materialised) input x[D][H][W][Cin]
+int mvs_convT3d_mfma32(const float* x, int Cin, int D, int H, int W, const float* w32, int Cout, float* out, hipStream_t st)
+{
+    const int64_t tiles = ((int64_t)D * H * W + 31) / 32;
+#define MVS_T32(CIN, COUT, WV, TPW) convT3d_k3s2_mfma32_kernel<CIN, COUT, WV, TPW><<<dim3(mvs_cdiv(tiles, TPW), 8 / (32 / COUT)), 64 * WV * TPW, 0, st>>>(x, D, H, W, w32, out)
+    switch (Cin * 100 + Cout) {
+        case 64 * 100 + 32: MVS_T32(64, 32, 8, 1); break;      // conv7:  8..64 units per tile
+        case 32 * 100 + 16: MVS_T32(32, 16, 2, 2); break;      // conv9:  8..32
+        case 16 * 100 + 8:  MVS_T32(16, 8, 1, 4); break;       // conv11: 8 | 16 -> one wave per tile, no reduction
+        default: return MVSNERF_EUNSUPPORTED;
+    }
+#undef MVS_T32
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
 bool mvs_conv3d_mfma32_supported(int Cin, int Cout, int stride)
 {
     const int k = Cin * 1000 + Cout * 10 + stride;
@@ -378,19 +488,25 @@ int mvs_conv_w32_repack(const float* wpacked, float* w32, int Cin, int Cout, hip
     return MVSNERF_OK;
 }
 
-// Called by mvsnerf_conv3d_fwd (encoder.hip) for stride-1 layers with 8 output channels.  Returns MVSNERF_EUNSUPPORTED for a
-// channel count it is not instantiated for (the caller then takes the VALU kernel).
-int mvs_conv3d_c8_mfma(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int D, int H, int W, const float* wpacked, float* out,
+// Called by mvsnerf_conv3d_fwd / mvsnerf_conv3d_c8_blocked_fwd (encoder.hip) for stride-1 layers with 8 output channels.  Cin: padded
+// channel count (multiple of 4), cin_real: how many of them exist (products with the zero padding are skipped).  Returns
+// MVSNERF_EUNSUPPORTED for a channel count it is not instantiated for (the caller then takes the VALU kernel).
+int mvs_conv3d_c8_mfma(const ActSrc& a, const ActSrc& b, int Cin, int cin_real, int cin_ld, int D, int H, int W, const float* wpacked, float* out,
                        int xcd, hipStream_t st)
 {
     if (b.x) return MVSNERF_EUNSUPPORTED;                         // one lazily-activated source only (conv0's input is the raw cost volume)
     const bool blocked = cin_ld == -8;                            // input in channel blocks of 8: x[(Cin+7)/8][D*H*W][8]
     if ((int64_t)D * H * W * (blocked ? 8 : cin_ld) >= (int64_t)1 << 31) return MVSNERF_EUNSUPPORTED;      // 32-bit element offsets in the staging slots
     const unsigned grid = (unsigned)(((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ));
-#define MVS_L(CIN) case CIN: if (blocked) conv3d_k3s1_c8_mfma_kernel<CIN, true><<<grid, 256, 0, st>>>(a, cin_ld, D, H, W, wpacked, out, xcd); \
-                             else conv3d_k3s1_c8_mfma_kernel<CIN, false><<<grid, 256, 0, st>>>(a, cin_ld, D, H, W, wpacked, out, xcd); break
-    switch (Cin) {
-        MVS_L(32); MVS_L(36); MVS_L(40); MVS_L(44); MVS_L(48); MVS_L(52); MVS_L(56);
+#define MVS_L(CIN, CREAL) case CIN * 100 + CREAL:                                                                                             \
+        if (blocked) conv3d_k3s1_c8_mfma_kernel<CIN, CREAL, true><<<grid, 256, 0, st>>>(a, cin_ld, D, H, W, wpacked, out, xcd);                \
+        else conv3d_k3s1_c8_mfma_kernel<CIN, CREAL, false><<<grid, 256, 0, st>>>(a, cin_ld, D, H, W, wpacked, out, xcd);                       \
+        break
+    if (cin_real <= 0 || cin_real > Cin) cin_real = Cin;
+    switch (Cin * 100 + cin_real) {
+        // 32 + 3V real channels for V = 0..8 source views (padded to a multiple of 4), and the padded counts themselves
+        MVS_L(32, 32); MVS_L(36, 35); MVS_L(36, 36); MVS_L(40, 38); MVS_L(40, 40); MVS_L(44, 41); MVS_L(44, 44);
+        MVS_L(48, 47); MVS_L(48, 48); MVS_L(52, 50); MVS_L(52, 52); MVS_L(56, 53); MVS_L(56, 56);
         default: return MVSNERF_EUNSUPPORTED;
     }
 #undef MVS_L

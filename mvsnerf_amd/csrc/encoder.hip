@@ -537,12 +537,13 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_kernel(ActSrc a, ActSrc b, i
 }
 
 int g_conv_mfma = 1;    // stride-1 layers with 8 output channels on v_mfma_f32_4x4x1_16B_f32 (conv_mfma.hip); 0 = the VALU kernels (A/B knob)
-int mvs_conv3d_c8_mfma(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int D, int H, int W, const float* wpacked, float* out,
+int mvs_conv3d_c8_mfma(const ActSrc& a, const ActSrc& b, int Cin, int cin_real, int cin_ld, int D, int H, int W, const float* wpacked, float* out,
                        int xcd, hipStream_t st);
 int mvs_conv3d_mfma32(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int D, int H, int W, const float* w32, int Cout, int stride,
                       float* out, hipStream_t st);
 bool mvs_conv3d_mfma32_supported(int Cin, int Cout, int stride);
 int mvs_conv_w32_repack(const float* wpacked, float* w32, int Cin, int Cout, hipStream_t st);
+int mvs_convT3d_mfma32(const float* x, int Cin, int D, int H, int W, const float* w32, int Cout, float* out, hipStream_t st);
 int g_conv_tiled = 1;   // A/B knob (mvsnerf_tune "conv_tiled")
 int g_conv_xcd = 1;     // tiles renumbered so that an XCD owns a contiguous range (mvsnerf_tune "conv_xcd")
 static bool act_ok(const float* x, const float* sc, const float* sh) { return x && ((sc == nullptr) == (sh == nullptr)) && mvs_aligned16(x); }
@@ -565,7 +566,7 @@ extern "C" int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const fl
 #define MVS_CONV_TILED(CIN, CT, COUT)                                                                 \
     conv3d_k3s1_tiled_kernel<CIN, CT, COUT><<<dim3(((W + 7) / 8) * ((H + 7) / 8) * ((D + 3) / 4), COUT / CT), 256, 0, st>>>(a, b, cin_ld, D, H, W, wpacked, out, g_conv_xcd)
     if (Cout == 8 && stride == 1 && g_conv_mfma) {
-        const int rc = mvs_conv3d_c8_mfma(a, b, Cin, cin_ld, D, H, W, wpacked, out, g_conv_xcd, st);
+        const int rc = mvs_conv3d_c8_mfma(a, b, Cin, Cin, cin_ld, D, H, W, wpacked, out, g_conv_xcd, st);
         if (rc != MVSNERF_EUNSUPPORTED) return rc;
     }
     // (Cin rounded up to a multiple of 4 by the caller's channel padding; Cout in {8,16,32,64})
@@ -594,12 +595,12 @@ extern "C" int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const fl
     return MVSNERF_OK;
 }
 
-extern "C" int mvsnerf_conv3d_c8_blocked_fwd(const float* x_blocked, int Cin, int D, int H, int W, const float* wpacked, float* out, void* stream)
+extern "C" int mvsnerf_conv3d_c8_blocked_fwd(const float* x_blocked, int Cin, int Cin_real, int D, int H, int W, const float* wpacked, float* out, void* stream)
 {
-    if (!x_blocked || !wpacked || !out || D < 1 || H < 1 || W < 1 || Cin < 4 || (Cin & 3)) return MVSNERF_EINVAL;
+    if (!x_blocked || !wpacked || !out || D < 1 || H < 1 || W < 1 || Cin < 4 || (Cin & 3) || Cin_real < 1 || Cin_real > Cin) return MVSNERF_EINVAL;
     if (!mvs_aligned16(x_blocked) || !mvs_aligned16(out)) return MVSNERF_EALIGN;
     const ActSrc a{x_blocked, nullptr, nullptr}, b{nullptr, nullptr, nullptr};
-    return mvs_conv3d_c8_mfma(a, b, Cin, -8, D, H, W, wpacked, out, g_conv_xcd, (hipStream_t)stream);    // ld = -8: channel blocks of 8
+    return mvs_conv3d_c8_mfma(a, b, Cin, Cin_real, -8, D, H, W, wpacked, out, g_conv_xcd, (hipStream_t)stream);    // ld = -8: channel blocks of 8
 }
 
 // ---- the deep layers (32 / 64 output channels) on v_mfma_f32_32x32x2_f32 (conv_mfma.hip)
@@ -607,7 +608,7 @@ extern "C" int mvsnerf_conv3d_mfma_supported(int Cin, int Cout, int stride) { re
 
 extern "C" int mvsnerf_conv3d_pack_weights_mfma(const float* wpacked, int Cin, int Cout, float* w32, void* stream)
 {
-    if (!wpacked || !w32 || Cin < 8 || (Cin & 7) || Cout < 32 || (Cout & 31)) return MVSNERF_EINVAL;
+    if (!wpacked || !w32 || Cin < 8 || (Cin & 7) || Cout < 8 || (Cout & 7)) return MVSNERF_EINVAL;
     return mvs_conv_w32_repack(wpacked, w32, Cin, Cout, (hipStream_t)stream);
 }
 
@@ -619,6 +620,19 @@ extern "C" int mvsnerf_conv3d_mfma_fwd(const float* x1, const float* scale1, con
     if ((cin_ld & 3) || cin_ld < Cin || !mvs_aligned16(out) || !mvs_aligned16(w32)) return MVSNERF_EALIGN;
     const ActSrc a{x1, scale1, shift1}, b{nullptr, nullptr, nullptr};
     return mvs_conv3d_mfma32(a, b, Cin, cin_ld, D, H, W, w32, Cout, stride, out, (hipStream_t)stream);
+}
+
+extern "C" int mvsnerf_conv_transpose3d_mfma_supported(int Cin, int Cout)
+{
+    const int k = Cin * 100 + Cout;
+    return (g_conv_mfma && (k == 6432 || k == 3216 || k == 1608)) ? 1 : 0;
+}
+
+extern "C" int mvsnerf_conv_transpose3d_mfma_fwd(const float* x, int Cin, int D, int H, int W, const float* w32, int Cout, float* out, void* stream)
+{
+    if (!x || !w32 || !out || D < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
+    if (!mvs_aligned16(x) || !mvs_aligned16(w32) || !mvs_aligned16(out)) return MVSNERF_EALIGN;
+    return mvs_convT3d_mfma32(x, Cin, D, H, W, w32, Cout, out, (hipStream_t)stream);
 }
 
 extern "C" int mvsnerf_conv_transpose3d_fwd(const float* x1, const float* scale1, const float* shift1,

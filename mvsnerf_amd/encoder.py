@@ -389,10 +389,16 @@ def _conv(src1, src2, dims_in, cin_ld, wbuf, cin_k, cout_k, stride, packed=None,
     return out
 
 
-def _conv_t(src1, src2, dims_in, wbuf, cin_k, cout_k):
-    """k3 s2 p1 op1 transposed-convolution kernel launch: (D,H,W,cin_k) -> raw (2D,2H,2W,cout_k)."""
+def _conv_t(src1, src2, dims_in, wbuf, cin_k, cout_k, packed=None, mode="fwd"):
+    """k3 s2 p1 op1 transposed-convolution kernel launch: (D,H,W,cin_k) -> raw (2D,2H,2W,cout_k).
+    packed (+ mode): the layer's _PackedConv - a plain (materialised) input then takes the matrix-core kernel."""
     D, H, W, _ = dims_in
     out = torch.empty((2 * D, 2 * H, 2 * W, cout_k), device=wbuf.device, dtype=torch.float32)
+    if (packed is not None and src2 is None and torch.is_tensor(src1) and cin_k % 8 == 0
+            and _lib.lib().mvsnerf_conv_transpose3d_mfma_supported(cin_k, cout_k)):
+        check(_lib.lib().mvsnerf_conv_transpose3d_mfma_fwd(src1.data_ptr(), cin_k, D, H, W, packed.get_mfma(mode).data_ptr(), cout_k,
+                                                           out.data_ptr(), stream_ptr()), "conv_transpose3d_mfma_fwd")
+        return out
     check(_lib.lib().mvsnerf_conv_transpose3d_fwd(*_ptrs(src1), *_ptrs(src2), cin_k, D, H, W, wbuf.data_ptr(), cout_k,
                                                   out.data_ptr(), stream_ptr()), "conv_transpose3d_fwd")
     return out
@@ -455,7 +461,7 @@ class _UpBlock(nn.Sequential):
         if MATERIALIZE_UP_INPUT and isinstance(src1, _Lazy):
             # every input voxel feeds 27/8 output voxels on average: activate (and sum the skip) once instead of per tap
             src1, src2 = _apply_add(src1, src2), None
-        raw = _conv_t(src1, src2, dims_in, pk.get(), pk.cin_pad, pk.cout)
+        raw = _conv_t(src1, src2, dims_in, pk.get(), pk.cin_pad, pk.cout, packed=pk)
         D, H, W, C = raw.shape
         scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self[1], update_running=self[1].training)
         return _Lazy(raw, scale, shift, (D, H, W, C), mean, invstd)
@@ -503,7 +509,7 @@ class CostRegNet(nn.Module):
             if x.cin_pad != pk.cin_pad:
                 raise RuntimeError(f"CostRegNet: blocked cost volume has {x.cin_pad} channels, conv0 expects {pk.cin_pad}")
             raw = torch.empty((D, H, W, pk.cout), device=x.buf.device, dtype=torch.float32)
-            check(_lib.lib().mvsnerf_conv3d_c8_blocked_fwd(x.buf.data_ptr(), pk.cin_pad, D, H, W, pk.get().data_ptr(), raw.data_ptr(), stream_ptr()),
+            check(_lib.lib().mvsnerf_conv3d_c8_blocked_fwd(x.buf.data_ptr(), pk.cin_pad, pk.cin, D, H, W, pk.get().data_ptr(), raw.data_ptr(), stream_ptr()),
                   "conv3d_c8_blocked_fwd")
             scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self.conv0.bn, update_running=self.conv0.bn.training)
             c0 = _Lazy(raw, scale, shift, (D, H, W, pk.cout), mean, invstd)
@@ -607,7 +613,7 @@ class _CostRegFunction(torch.autograd.Function):
                 return None
             if lay.stride == 1:
                 return _conv(gx, None, out_lz.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin_pad, 1, packed=pk, mode="dgrad")
-            return _conv_t(gx, None, out_lz.dims, pk.get("dgrad"), pk.cout, pk.cin_pad)
+            return _conv_t(gx, None, out_lz.dims, pk.get("dgrad"), pk.cout, pk.cin_pad, packed=pk, mode="dgrad")
 
         g_u9c2 = up_block(9, L[9], u11, c2, u9, g)               # conv11: grad w.r.t. A(c2)+A(u9)
         g_u7c4 = up_block(8, L[8], u9, c4, u7, g_u9c2)           # conv9:  grad w.r.t. A(c4)+A(u7)

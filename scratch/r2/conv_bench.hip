@@ -17,10 +17,10 @@ int main()
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int dbg : {0, 1, 2, 4, 6, 7, 3, 0}) {
         hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &dbg, sizeof(int));
-        for (int rep = 0; rep < 3; ++rep) mvs_conv3d_c8_mfma(a, b, CIN, -8, D, H, W, w, out, 1, 0);
+        for (int rep = 0; rep < 3; ++rep) mvs_conv3d_c8_mfma(a, b, CIN, 41, -8, D, H, W, w, out, 1, 0);
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        for (int rep = 0; rep < 5; ++rep) mvs_conv3d_c8_mfma(a, b, CIN, -8, D, H, W, w, out, 1, 0);
+        for (int rep = 0; rep < 5; ++rep) mvs_conv3d_c8_mfma(a, b, CIN, 41, -8, D, H, W, w, out, 1, 0);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("dbg %d (1 = no staging, 2 = no operand reads, 4 = no weight loads): %.3f ms  -> %.1f TFLOP/s issued\n", dbg, ms / 5,
