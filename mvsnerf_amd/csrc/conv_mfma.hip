@@ -16,9 +16,10 @@
 // The (6 x 18 x 18)-voxel input halo is staged through LDS eight channels at a time, channel-last ([voxel][8], 32 B per voxel)
 // with the two 16-byte halves of a voxel swapped on every other group of eight voxels: a ds_read_b128 of 16 consecutive voxels
 // then touches every bank once (un-swizzled, voxels v and v+8 would collide: 2-way conflict on every operand read).
-// One ds_read_b128 feeds four MFMAs (k = 4 channels); per (tap, 4 channels): 8 A reads + 4 B loads (global, L1-resident: the
-// packed weights are 38 KB and every wave walks them in the same order) + 32 MFMAs.  Two workgroups per CU (62 KB LDS each):
-// one stages its next channel chunk while the other one computes.
+// One ds_read_b128 feeds four MFMAs (k = 4 channels).  Two workgroups per CU (69 KB LDS each): one stages its next channel chunk
+// while the other one multiplies.  (Measured and dropped: ONE workgroup per CU with two LDS tiles, the next chunk written into the
+// other tile in the middle of the multiply, one barrier per chunk: 1.69 ms against 0.94 - a single wave per SIMD issues this
+// dependent-accumulator MFMA stream at 53 TFLOP/s; it takes the second wave to fill the matrix pipe.)
 #include "common.h"
 #include "act.h"
 
