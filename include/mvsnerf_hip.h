@@ -74,10 +74,10 @@ int mvsnerf_planesweep_costvar_fwd(const float* feats_cl, const float* imgs_cl, 
                                    int V, int C, int H, int W, int D, int pad, float* cost, int CP, float* masks,
                                    int with_img, void* stream);
 
-/* The same sweep writing the cost volume in channel blocks of 8: cost_blocked[(CP+7)/8][D*Hp*Wp][8] (block b holds channels
- * 8b..8b+7 of every voxel; the unused tail of the last block is not written).  This is the layout the matrix-core conv0
- * (mvsnerf_conv3d_c8_blocked_fwd) stages from: it multiplies eight input channels at a time, and with the channel-last
- * layout every such pass touches all of a voxel's 176-byte row again (measured: 5.4x the algorithmic HBM reads). */
+/* The same sweep writing the cost volume in channel blocks of FOUR: cost_blocked[CP/4][D*Hp*Wp][4] (block b holds channels 4b..4b+3
+ * of every voxel).  This is the layout the matrix-core conv0 (mvsnerf_conv3d_c8_blocked_fwd) stages from by LDS-DMA: it multiplies four
+ * input channels at a time, and with the channel-last layout every such pass touched all of a voxel's 176-byte row again
+ * (measured: 5.4x the algorithmic HBM reads); in blocks, 64 consecutive voxels of a pass are 1 KB of contiguous, fully used bytes. */
 int mvsnerf_planesweep_costvar_blocked_fwd(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,
                                            int V, int C, int H, int W, int D, int pad, float* cost_blocked, int CP, float* masks,
                                            int with_img, void* stream);
@@ -105,9 +105,11 @@ int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const float* shift1
                        int Cin, int cin_ld, int D, int H, int W, const float* wpacked, int Cout, int stride,
                        float* out, void* stream);
 /* conv0 of CostRegNet (models.py:756; k3, stride 1, Cout = 8, raw input) on v_mfma_f32_4x4x1_16B_f32, input in channel
- * blocks of 8 (see mvsnerf_planesweep_costvar_blocked_fwd), Cin = 4*ceil((32+3V)/4) channels of which the first Cin_real = 32+3V exist
- * (products with the zero padding are skipped); weights as for conv3d_fwd. */
-int mvsnerf_conv3d_c8_blocked_fwd(const float* x_blocked, int Cin, int Cin_real, int D, int H, int W, const float* wpacked, float* out, void* stream);
+ * blocks of four (see mvsnerf_planesweep_costvar_blocked_fwd), Cin = 4*ceil((32+3V)/4) channels of which the first Cin_real = 32+3V exist
+ * (products with the zero padding are skipped).  Weights: wq[ci/4][tap][co][4] = mvsnerf_conv3d_pack_weights_c8 of the
+ * packed[tap][ci][8] layout of mvsnerf_conv3d_pack_weights (27*Cin*8 floats either way). */
+int mvsnerf_conv3d_pack_weights_c8(const float* wpacked, int Cin, float* wq, void* stream);
+int mvsnerf_conv3d_c8_blocked_fwd(const float* x_blocked, int Cin, int Cin_real, int D, int H, int W, const float* wq, float* out, void* stream);
 /* The same convolution for the deep layers (Cout = 32 | 64; models.py:758-761: conv3..conv6, and the data gradients that have these
  * shapes) on v_mfma_f32_32x32x2_f32.  conv3d_mfma_supported: 1 when (Cin, Cout, stride) is built (and the "conv_mfma" switch is on);
  * conv3d_pack_weights_mfma: packed[tap][ci][co] (mvsnerf_conv3d_pack_weights) -> w32[tap][ci/8][co][8]; one lazily-activated source. */

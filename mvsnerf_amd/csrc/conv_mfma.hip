@@ -22,6 +22,7 @@
 // dependent-accumulator MFMA stream at 53 TFLOP/s; it takes the second wave to fill the matrix pipe.)
 #include "common.h"
 #include "act.h"
+#include "lds_dma.h"
 
 #ifdef MVS_CONV_DBG
 __device__ int g_dbg;            // scratch/r2/conv_bench.hip only: bit 0 = no staging, bit 1 = no operand reads, bit 2 = no weight loads
@@ -31,6 +32,8 @@ __device__ int g_dbg;            // scratch/r2/conv_bench.hip only: bit 0 = no s
 #endif
 
 namespace {
+
+__device__ const f32x4 g_zero16 = {0.0f, 0.0f, 0.0f, 0.0f};   // what a DMA lane reads for a voxel outside the volume (zero padding)
 
 constexpr int TX = 16, TY = 16, TZ = 4;             // output tile
 constexpr int PX = TX + 2, PY = TY + 2, PZ = TZ + 2; // staged input tile
@@ -253,6 +256,140 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_mfma_kernel(ActSrc a, i
             const int ox = bx * TX + (m & 15), oy = by * TY + t + 8 * (m >> 4);
             if (ox < W && oy < H) out[(((int64_t)oz * H + oy) * W + ox) * 8 + nb * 4 + i] = acc[t][r];
         }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// conv0, inference form: input in channel blocks of FOUR (x4[Cin/4][D*H*W][4], written by the plane sweep), staged by LDS-DMA.
+// Same mapping and MFMA stream as above with four channels per chunk; what changes is how a chunk reaches LDS:
+//   * one `global_load_lds_dwordx4` moves 64 consecutive tile voxels x 16 bytes (1 KB) from global memory straight into the tile - no
+//     staging registers, no ds_write pass; a lane whose voxel lies outside the volume reads a 16-byte block of zeros instead;
+//   * two tiles (+ two weight tiles): the DMA of chunk c+1 is issued when chunk c starts and lands during its 864 MFMAs per wave, so
+//     a chunk costs ONE barrier and the matrix pipes never wait for staging (in the register-staged kernel above staging was
+//     0.10 of 0.94 ms).  Two workgroups per CU (70 KB each).
+// Weights: wq[chunk][tap][co][4] (mvsnerf_conv3d_pack_weights_c8), one 3.4 KB slab per chunk by the same DMA.
+constexpr int T4_FLOATS = ((NVOX * 4 + 255) / 256) * 256;       // tile of 4-channel voxels, rounded up to whole 1 KB DMA pieces (31)
+constexpr int T4_PIECES = T4_FLOATS / 256;
+constexpr int W4_FLOATS = 1024;                                 // 27 x 8 x 4 = 864 weights, four DMA pieces
+constexpr int T4_SLOTS = (T4_PIECES + 3) / 4;                   // DMA pieces per wave: 8
+
+__device__ __forceinline__ void dma16_gather(const void* lane_ptr, unsigned lds_byte_uniform)
+{
+    // lanes read 16 B each at their own address; LDS receives them at lds_byte_uniform + lane * 16 (M0 carries the LDS base)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(lane_ptr), "s"(lds_byte_uniform) : "memory");
+}
+
+template <int KREAL>      // k-values (input channels) of this chunk that exist; the rest is zero padding and skipped
+__device__ __forceinline__ void mfma_chunk4(const float* __restrict__ wtile, const float* __restrict__ tile, int wave, int lane, f32x4 (&acc)[8])
+{
+    const int blk = lane >> 2, i = lane & 3, mb = blk >> 1, nb = blk & 1;
+    const int m = mb * 4 + i, xx = m & 15;
+    const float* alane = tile + ((wave * PY + (m >> 4) * 8) * PX + xx) * 4;      // 16 consecutive x = 256 contiguous bytes: conflict-free
+    const float* wl = wtile + (nb * 4 + i) * 4;
+    f32x4 av[10], bw[2][3];
+    auto fetch_b = [&](int g, f32x4 (&bd)[3]) {                  // group g = (dz, dx)
+        const int dz = g / 3, dx = g - dz * 3;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) bd[dy] = *reinterpret_cast<const f32x4*>(wl + ((dz * 3 + dy) * 3 + dx) * 32);
+    };
+    auto fetch_a = [&](int g, int j) {
+        const int dz = g / 3, dx = g - dz * 3;
+        av[j] = *reinterpret_cast<const f32x4*>(alane + ((dz * PY + j) * PX + dx) * 4);
+    };
+    fetch_b(0, bw[0]);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) fetch_a(0, j);
+#pragma unroll
+    for (int g = 0; g < 9; ++g) {
+        if (g + 1 < 9) fetch_b(g + 1, bw[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+#pragma unroll
+            for (int k = 0; k < KREAL; ++k)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int jj = j + 5 * h, t = jj - dy;
+                        if (t >= 0 && t < 8) acc[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[jj][k], bw[g & 1][dy][k], acc[t], 0, 0, 0);
+                    }
+            if (g + 1 < 9) { fetch_a(g + 1, j); fetch_a(g + 1, j + 5); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int CIN, int CREAL>
+__global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_mfma4_kernel(const float* __restrict__ x4, int D, int H, int W, const float* __restrict__ wq,
+                                                                     float* __restrict__ out, int swz)
+{
+    static_assert(CIN % 4 == 0 && CREAL <= CIN && CREAL > CIN - 4, "chunks of four channels; only the last one may be partly padding");
+    constexpr int NCH = CIN / 4;
+    __shared__ __attribute__((aligned(1024))) float lds4[2 * (T4_FLOATS + W4_FLOATS)];
+    constexpr int BUF = T4_FLOATS + W4_FLOATS;                    // one (tile, weights) buffer; the two alternate
+    const int nbx = (W + TX - 1) / TX, nby = (H + TY - 1) / TY;
+    const int tile_id = swz ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int bx = tile_id % nbx, by = (tile_id / nbx) % nby, bz = tile_id / (nbx * nby);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0 = bx * TX - 1, y0 = by * TY - 1, z0 = bz * TZ - 1;
+    // this lane's DMA slots: piece p = wave + 4 j covers tile voxels 64 p .. 64 p + 63; element offset of the voxel in a channel block, -1 = zeros
+    int goff[T4_SLOTS];
+#pragma unroll
+    for (int j = 0; j < T4_SLOTS; ++j) {
+        const int v = (wave + 4 * j) * 64 + lane;
+        const int vx = v % PX, vy = (v / PX) % PY, vz = v / (PX * PY);
+        const int gx = x0 + vx, gy = y0 + vy, gz = z0 + vz;
+        const bool in = v < NVOX && gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
+        goff[j] = in ? ((gz * H + gy) * W + gx) * 4 : -1;
+    }
+    const int64_t block_stride = (int64_t)D * H * W * 4;
+    const float* zero16 = reinterpret_cast<const float*>(&g_zero16);
+    auto issue = [&](int c, float* dst) {                         // DMA of chunk c (input tile + weight slab) into `dst`
+        const float* xb = x4 + (int64_t)c * block_stride;
+        const unsigned base = lds_byte_addr(dst);
+#pragma unroll
+        for (int j = 0; j < T4_SLOTS; ++j) {
+            const int p = wave + 4 * j;
+            if (p < T4_PIECES) dma16_gather(goff[j] >= 0 ? xb + goff[j] : zero16, base + p * 1024);
+        }
+        const int wi = wave * 64 + lane;                          // weight slab: 216 x 16 bytes, one piece per wave
+        dma16_gather(wi < 216 ? wq + ((int64_t)c * 216 + wi) * 4 : zero16, base + T4_FLOATS * 4 + wave * 1024);
+    };
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0, 0, 0, 0};
+    issue(0, lds4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        float* cur = lds4 + (c & 1) * BUF;
+        if (c + 1 < NCH) issue(c + 1, lds4 + ((c + 1) & 1) * BUF);       // lands while this chunk is multiplied (the other tile is free: barrier below)
+        if (c + 1 < NCH || CREAL == CIN) mfma_chunk4<4>(cur + T4_FLOATS, cur, wave, lane, acc);
+        else mfma_chunk4<CREAL - (CIN - 4)>(cur + T4_FLOATS, cur, wave, lane, acc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMA pieces have landed ...
+        __syncthreads();                                          // ... everybody's have, and everybody is done reading `cur`
+    }
+    const int blk = lane >> 2, i = lane & 3, mb = blk >> 1, nb = blk & 1;
+    const int oz = bz * TZ + wave;
+    if (oz >= D) return;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mb * 4 + r;
+            const int ox = bx * TX + (m & 15), oy = by * TY + t + 8 * (m >> 4);
+            if (ox < W && oy < H) out[(((int64_t)oz * H + oy) * W + ox) * 8 + nb * 4 + i] = acc[t][r];
+        }
+}
+
+// packed[tap][ci][8] (mvsnerf_conv3d_pack_weights, Cout = 8) -> wq[ci/4][tap][co][4]
+__global__ __launch_bounds__(256) void conv_w4_repack_kernel(const float* __restrict__ wp, float* __restrict__ wq, int CIN)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 27 * CIN * 8) return;
+    const int c4 = i & 3, co = (i >> 2) & 7, tap = (i >> 5) % 27, ch = i / (27 * 32);
+    wq[i] = wp[((int64_t)tap * CIN + ch * 4 + c4) * 8 + co];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -489,7 +626,29 @@ int mvs_conv_w32_repack(const float* wpacked, float* w32, int Cin, int Cout, hip
     return MVSNERF_OK;
 }
 
-// Called by mvsnerf_conv3d_fwd / mvsnerf_conv3d_c8_blocked_fwd (encoder.hip) for stride-1 layers with 8 output channels.  Cin: padded
+// conv0 on a cost volume in channel blocks of four (mvsnerf_conv3d_c8_blocked_fwd)
+int mvs_conv3d_c8_mfma4(const float* x4, int Cin, int cin_real, int D, int H, int W, const float* wq, float* out, int xcd, hipStream_t st)
+{
+    if ((int64_t)D * H * W * 4 >= (int64_t)1 << 31) return MVSNERF_EUNSUPPORTED;
+    const unsigned grid = (unsigned)(((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ));
+#define MVS_L4(CIN, CREAL) case CIN * 100 + CREAL: conv3d_k3s1_c8_mfma4_kernel<CIN, CREAL><<<grid, 256, 0, st>>>(x4, D, H, W, wq, out, xcd); break
+    switch (Cin * 100 + cin_real) {
+        MVS_L4(32, 32); MVS_L4(36, 35); MVS_L4(40, 38); MVS_L4(44, 41); MVS_L4(44, 44); MVS_L4(48, 47); MVS_L4(52, 50); MVS_L4(56, 53); MVS_L4(56, 56);
+        default: return MVSNERF_EUNSUPPORTED;
+    }
+#undef MVS_L4
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+int mvs_conv_w4_repack(const float* wpacked, float* wq, int Cin, hipStream_t st)
+{
+    conv_w4_repack_kernel<<<mvs_cdiv((int64_t)27 * Cin * 8, 256), 256, 0, st>>>(wpacked, wq, Cin);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// Called by mvsnerf_conv3d_fwd (encoder.hip) for stride-1 layers with 8 output channels and a channel-last input.  Cin: padded
 // channel count (multiple of 4), cin_real: how many of them exist (products with the zero padding are skipped).  Returns
 // MVSNERF_EUNSUPPORTED for a channel count it is not instantiated for (the caller then takes the VALU kernel).
 int mvs_conv3d_c8_mfma(const ActSrc& a, const ActSrc& b, int Cin, int cin_real, int cin_ld, int D, int H, int W, const float* wpacked, float* out,

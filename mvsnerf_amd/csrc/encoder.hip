@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
     int V, int H, int W, int D, int pad,
     float* __restrict__ cost, int CP,   // [D][Hp][Wp][CP]
     float* __restrict__ masks,          // with img: [V][D][Hp][Wp] per-view; else [D][Hp][Wp] count
-    int with_img, int blocked)          // blocked: cost[(CP+7)/8][D*Hp*Wp][8] (channel blocks of 8, see mvsnerf_planesweep_costvar_blocked_fwd)
+    int with_img, int blocked)          // blocked: cost[CP/4][D*Hp*Wp][4] (channel blocks of four, see mvsnerf_planesweep_costvar_blocked_fwd)
 {
     static_assert(C == 32, "lane q owns float4 numbers q and q + 4 of a 32-channel pixel");
     constexpr int VPB = 256, VPP = 64;                           // voxels per block / per pass
@@ -215,14 +215,12 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
                     dst[k] = *reinterpret_cast<const f32x4*>(stage + vox * (CP + 4) + c);
                 }
             } else {
-                // channel block cb of these nv voxels is one contiguous run of nv*32 bytes: k -> (cb, voxel, half), half fastest,
-                // so that a wave's 16-byte stores are consecutive (a 4-channel tail block keeps only its first half)
-                const int nfull = CP >> 3, n_k = (int)nv * 2 * (nfull + ((CP & 4) ? 1 : 0));
+                // channel block cb (four channels) of these nv voxels is one contiguous run of nv * 16 bytes: k -> (cb, voxel)
+                const int nblk = CP >> 2, n_k = (int)nv * nblk;
                 for (int k = threadIdx.x; k < n_k; k += 256) {
-                    const int cb = k / ((int)nv * 2), r = k - cb * (int)nv * 2, vox = r >> 1, half = r & 1;
-                    if (cb < nfull || half == 0)
-                        *reinterpret_cast<f32x4*>(cost + (((int64_t)cb * nvox + p0 + vox) << 3) + (half << 2)) =
-                            *reinterpret_cast<const f32x4*>(stage + vox * (CP + 4) + cb * 8 + half * 4);
+                    const int cb = k / (int)nv, vox = k - cb * (int)nv;
+                    *reinterpret_cast<f32x4*>(cost + (((int64_t)cb * nvox + p0 + vox) << 2)) =
+                        *reinterpret_cast<const f32x4*>(stage + vox * (CP + 4) + cb * 4);
                 }
             }
         }
@@ -595,12 +593,20 @@ extern "C" int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const fl
     return MVSNERF_OK;
 }
 
-extern "C" int mvsnerf_conv3d_c8_blocked_fwd(const float* x_blocked, int Cin, int Cin_real, int D, int H, int W, const float* wpacked, float* out, void* stream)
+int mvs_conv3d_c8_mfma4(const float* x4, int Cin, int cin_real, int D, int H, int W, const float* wq, float* out, int xcd, hipStream_t st);
+int mvs_conv_w4_repack(const float* wpacked, float* wq, int Cin, hipStream_t st);
+
+extern "C" int mvsnerf_conv3d_pack_weights_c8(const float* wpacked, int Cin, float* wq, void* stream)
 {
-    if (!x_blocked || !wpacked || !out || D < 1 || H < 1 || W < 1 || Cin < 4 || (Cin & 3) || Cin_real < 1 || Cin_real > Cin) return MVSNERF_EINVAL;
-    if (!mvs_aligned16(x_blocked) || !mvs_aligned16(out)) return MVSNERF_EALIGN;
-    const ActSrc a{x_blocked, nullptr, nullptr}, b{nullptr, nullptr, nullptr};
-    return mvs_conv3d_c8_mfma(a, b, Cin, Cin_real, -8, D, H, W, wpacked, out, g_conv_xcd, (hipStream_t)stream);    // ld = -8: channel blocks of 8
+    if (!wpacked || !wq || Cin < 4 || (Cin & 3)) return MVSNERF_EINVAL;
+    return mvs_conv_w4_repack(wpacked, wq, Cin, (hipStream_t)stream);
+}
+
+extern "C" int mvsnerf_conv3d_c8_blocked_fwd(const float* x_blocked, int Cin, int Cin_real, int D, int H, int W, const float* wq, float* out, void* stream)
+{
+    if (!x_blocked || !wq || !out || D < 1 || H < 1 || W < 1 || Cin < 4 || (Cin & 3) || Cin_real < 1 || Cin_real > Cin) return MVSNERF_EINVAL;
+    if (!mvs_aligned16(x_blocked) || !mvs_aligned16(out) || !mvs_aligned16(wq)) return MVSNERF_EALIGN;
+    return mvs_conv3d_c8_mfma4(x_blocked, Cin, Cin_real, D, H, W, wq, out, g_conv_xcd, (hipStream_t)stream);
 }
 
 // ---- the deep layers (32 / 64 output channels) on v_mfma_f32_32x32x2_f32 (conv_mfma.hip)

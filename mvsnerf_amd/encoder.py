@@ -316,6 +316,17 @@ class _PackedConv:
         self.cache[mode] = (key, buf)
         return buf
 
+    def get_c8(self):
+        """[ci/4][tap][co][4] re-layout of get("fwd") for the DMA-staged matrix-core conv0 (8 output channels; same cache policy)."""
+        base = self.get("fwd")
+        hit = self.cache.get("fwd_c8")
+        if hit is not None and hit[0] is base:
+            return hit[1]
+        buf = torch.empty_like(base)
+        check(_lib.lib().mvsnerf_conv3d_pack_weights_c8(base.data_ptr(), self.cin_pad, buf.data_ptr(), stream_ptr()), "conv3d_pack_weights_c8")
+        self.cache["fwd_c8"] = (base, buf)
+        return buf
+
     def get_mfma(self, mode="fwd"):
         """[tap][ci/8][co][8] re-layout of get(mode) for the matrix-core kernel of the 32/64-channel layers (same cache policy)."""
         base = self.get(mode)
@@ -509,7 +520,7 @@ class CostRegNet(nn.Module):
             if x.cin_pad != pk.cin_pad:
                 raise RuntimeError(f"CostRegNet: blocked cost volume has {x.cin_pad} channels, conv0 expects {pk.cin_pad}")
             raw = torch.empty((D, H, W, pk.cout), device=x.buf.device, dtype=torch.float32)
-            check(_lib.lib().mvsnerf_conv3d_c8_blocked_fwd(x.buf.data_ptr(), pk.cin_pad, pk.cin, D, H, W, pk.get().data_ptr(), raw.data_ptr(), stream_ptr()),
+            check(_lib.lib().mvsnerf_conv3d_c8_blocked_fwd(x.buf.data_ptr(), pk.cin_pad, pk.cin, D, H, W, pk.get_c8().data_ptr(), raw.data_ptr(), stream_ptr()),
                   "conv3d_c8_blocked_fwd")
             scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self.conv0.bn, update_running=self.conv0.bn.training)
             c0 = _Lazy(raw, scale, shift, (D, H, W, pk.cout), mean, invstd)
@@ -659,7 +670,7 @@ def homo_warp(src_feat, proj_mat, depth_values, src_grid=None, pad=0):
 
 
 class _BlockedCost:
-    """Cost volume in channel blocks of 8, buf[(CP+7)//8][D*H*W][8] (mvsnerf_planesweep_costvar_blocked_fwd): the internal hand-off
+    """Cost volume in channel blocks of four, buf[CP//4][D*H*W][4] (mvsnerf_planesweep_costvar_blocked_fwd): the internal hand-off
     between the plane sweep and the matrix-core conv0 on the no-grad path.  Never handed to callers."""
     __slots__ = ("buf", "n_ch", "cin_pad", "dims")
 
@@ -692,7 +703,7 @@ def _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img, blocked=Fa
     proj = proj_mats[0].detach().contiguous()
     depth = depth_values[0].detach().contiguous()
     if blocked:
-        cost = torch.empty(((CP + 7) // 8, D * Hp * Wp, 8), device=dev, dtype=torch.float32)
+        cost = torch.empty((CP // 4, D * Hp * Wp, 4), device=dev, dtype=torch.float32)
         check(lib.mvsnerf_planesweep_costvar_blocked_fwd(feats_cl.data_ptr(), imgs_cl_p, dev_f32(proj, "proj_mats"), dev_f32(depth, "depth_values"),
                                                          V, C, H, W, D, pad, cost.data_ptr(), CP, masks.data_ptr(), int(with_img), stream_ptr()),
               "planesweep_costvar_blocked_fwd")

@@ -1,4 +1,5 @@
-// Stand-alone timing harness for the matrix-core conv0 (mvsnerf_amd/csrc/conv_mfma.hip) with parts switched off.
+// Stand-alone timing harness for the matrix-core conv0 kernels (mvsnerf_amd/csrc/conv_mfma.hip): the register-staged kernel (channel-last
+// or 8-channel-chunk input) with parts switched off, and the DMA-staged kernel on a cost volume in channel blocks of four.
 #define MVS_CONV_DBG 1
 #include "../../mvsnerf_amd/csrc/conv_mfma.hip"
 #include <cstdio>
@@ -25,6 +26,18 @@ int main()
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("dbg %d (1 = no staging, 2 = no operand reads, 4 = no weight loads): %.3f ms  -> %.1f TFLOP/s issued\n", dbg, ms / 5,
                (double)nvox * 27 * CIN * 8 * 2 / (ms / 5 * 1e-3) / 1e12);
+    }
+    {   // DMA-staged kernel (blocks of four): x holds enough floats for [11][nvox][4]
+        float* wq; hipMalloc(&wq, 27 * CIN * 8 * 4);
+        mvs_conv_w4_repack(w, wq, CIN, 0);
+        for (int rep = 0; rep < 3; ++rep) mvs_conv3d_c8_mfma4(x, CIN, 41, D, H, W, wq, out, 1, 0);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int rep = 0; rep < 5; ++rep) mvs_conv3d_c8_mfma4(x, CIN, 41, D, H, W, wq, out, 1, 0);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("DMA-staged kernel (cost volume in channel blocks of four): %.3f ms -> %.1f TFLOP/s algorithmic (41 channels)\n", ms / 5,
+               (double)nvox * 27 * 41 * 8 * 2 / (ms / 5 * 1e-3) / 1e12);
     }
     return 0;
 }
