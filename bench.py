@@ -37,7 +37,7 @@ VOL_BYTES_PER_SAMPLE = 300        # 8 corners x 32 B + 12 B coord + 32 B out
 COL_BYTES_PER_SAMPLE = 204        # 3 views x 48 B + 12 B + 48 B out
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = "profiles/r01_pmc_summary.json"
+PMC_FILE = "profiles/r02_pmc_summary.json"
 
 
 def _load_pmc_traffic():

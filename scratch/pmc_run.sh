@@ -2,7 +2,7 @@
 # separate rocprofv3 PMC passes over the bench workload (kernel-trace only, as the guide prescribes)
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc
-for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM"; do
   tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
   rm -rf gpurun_out/pmc/$tag
   rocprofv3 --pmc $pass --kernel-trace --output-format csv -d gpurun_out/pmc/$tag -o p -- python bench.py --steps 20 --warmup 3 --cpu-batches 0 --no-extras > gpurun_out/pmc/$tag.log 2>&1
@@ -14,7 +14,7 @@ out = {}
 for f in glob.glob('gpurun_out/pmc/*/p_counter_collection.csv'):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].split('(')[0].replace('void ', '')[:40]
+        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')[:48]
         acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, cs in acc.items():
         for c, v in cs.items():
