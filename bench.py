@@ -591,6 +591,7 @@ def main():
             "roofline": roof, "rooflines": roofs, "cpu_baseline": cpu, "multi_gpu": multi, "extras": extras,
         }))
     if world > 1:
+        dist.barrier()                    # rank 0 was alone in the per-kernel section above: nobody tears the group down before it is back
         dist.destroy_process_group()
 
 
