@@ -110,6 +110,12 @@ int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const float* shift1
  * packed[tap][ci][8] layout of mvsnerf_conv3d_pack_weights (27*Cin*8 floats either way). */
 int mvsnerf_conv3d_pack_weights_c8(const float* wpacked, int Cin, float* wq, void* stream);
 int mvsnerf_conv3d_c8_blocked_fwd(const float* x_blocked, int Cin, int Cin_real, int D, int H, int W, const float* wq, float* out, void* stream);
+/* Weight gradient of that convolution from the same blocked input (the training path keeps the cost volume blocked; autograd of
+ * models.py:756 through nn.Conv3d): gw[co][ci][tap] = sum_o g[o][co] * x[o + tap - 1][ci] on v_mfma_f32_4x4x1 with the voxels as the k
+ * dimension.  g: gradient of the raw conv0 output, channel-last [D][H][W][8]; gw: (8, Cin_real, 3,3,3) floats; workspace:
+ * mvsnerf_conv3d_wgrad_workspace_floats(8, Cin_real).  Deterministic. */
+int mvsnerf_conv3d_c8_blocked_wgrad(const float* x_blocked, int Cin, int Cin_real, int D, int H, int W, const float* g, float* gw,
+                                    float* workspace, void* stream);
 /* The same convolution for the deep layers (Cout = 32 | 64; models.py:758-761: conv3..conv6, and the data gradients that have these
  * shapes) on v_mfma_f32_32x32x2_f32.  conv3d_mfma_supported: 1 when (Cin, Cout, stride) is built (and the "conv_mfma" switch is on);
  * conv3d_pack_weights_mfma: packed[tap][ci][co] (mvsnerf_conv3d_pack_weights) -> w32[tap][ci/8][co][8]; one lazily-activated source. */

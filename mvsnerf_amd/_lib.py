@@ -92,6 +92,7 @@ SIGNATURES = {
     "mvsnerf_conv_transpose3d_mfma_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_fp]),
     "mvsnerf_conv3d_pack_weights_c8": (_c_i, [_c_fp, _c_i, _c_fp, _c_fp]),
     "mvsnerf_conv3d_c8_blocked_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_conv3d_c8_blocked_wgrad": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_homo_warp_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_conv3d_pack_weights": (_c_i, [_c_fp] + [_c_i] * 7 + [_c_fp, _c_fp]),
     "mvsnerf_conv3d_fwd": (_c_i, [_c_fp] * 6 + [_c_i] * 5 + [_c_fp, _c_i, _c_i, _c_fp, _c_fp]),

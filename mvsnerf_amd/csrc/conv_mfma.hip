@@ -25,7 +25,7 @@
 #include "lds_dma.h"
 
 #ifdef MVS_CONV_DBG
-__device__ int g_dbg;            // scratch/r2/conv_bench.hip only: bit 0 = no staging, bit 1 = no operand reads, bit 2 = no weight loads
+__device__ int g_dbg;            // scratch/r2/conv_bench.hip only: bit 0 = no staging, bit 1 = no operand reads, bit 2 = no weight loads; wgrad: bit 3 = no DMA, bit 4 = no MFMA phase
 #define MVS_DBG(bit) (g_dbg & (bit))
 #else
 #define MVS_DBG(bit) false
@@ -575,6 +575,162 @@ __global__ __launch_bounds__(256) void conv_w32_repack_kernel(const float* __res
     w32[i] = wp[((int64_t)tap * CIN + cb * 8 + c8) * COUT + co];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// conv0's weight gradient (8 x Cin x 27 sums over all voxels; 41 % of the CostRegNet backward's FLOPs) on v_mfma_f32_4x4x1_16B_f32:
+//   gW[co][ci][tap] = sum_u X[u][ci] * G[u - (tap - 1)][co]      X: cost volume in channel blocks of four, G: gradient of conv0's raw output
+// Here the voxels are the k dimension.  One instruction takes eight voxels (block pair mb) and multiplies, per voxel, four input
+// channels (A operand, the wave's channel block) by the eight output channels (B operand, nb = which four): the 4 x 4 results of
+// the 16 blocks are (voxel slot mb, co quad nb) partial sums of one tap, so 27 accumulators (108 registers) hold every tap of a
+// channel block and nothing is padded.  A wave owns one channel block; the four waves of a workgroup share the G halo tile.
+//   A: lane (mb, nb, i) = X[u0 + mb][4 cg + i]          32 contiguous floats of the blocked tile (both nb read the same: broadcast)
+//   B: lane (mb, nb, j) = G[u0 + mb - tap + 1][4 nb + j] 64 contiguous floats of the channel-last halo tile: conflict-free
+// Marching along y, the three dy taps slide over the same G rows: a step reads one new halo row (9 operands: 3 dz x 3 dx) and one
+// A operand for 27 MFMAs.  The accumulators stay in registers across all tiles a workgroup visits (grid-stride over 2 x 16 x 16
+// tiles); at the end the eight voxel slots are folded across lanes and the workgroup leaves ONE partial result (deterministic; the
+// partials are summed by mvs_partial_sum).  grid.y splits the channel blocks four at a time (G is re-read per split: it is the
+// small operand, 32 B per voxel against 16 B per voxel and channel block).
+constexpr int GW_X = 16, GW_Y = 16, GW_Z = 2;                        // X tile
+constexpr int GH_X = GW_X + 2, GH_Y = GW_Y + 2, GH_Z = GW_Z + 2;     // G halo tile
+constexpr int GW_NV = GW_X * GW_Y * GW_Z;                            // 512 voxels: 8 DMA pieces per channel block
+constexpr int GH_NV = GH_X * GH_Y * GH_Z;                            // 1296 voxels of 32 B: 40.5 DMA pieces
+constexpr int GW_XF = 4 * GW_NV * 4;                                 // floats of the X tile: [4 channel blocks][512][4]
+constexpr int GW_GP = (GH_NV * 2 + 63) / 64;                         // 41
+constexpr int GW_GF = GW_GP * 256;
+constexpr int GW_GSLOTS = (GW_GP + 3) / 4;                           // G pieces per wave: 11
+
+__device__ __forceinline__ void wgrad4_tile(const float* __restrict__ xw, const float* __restrict__ gt, int lane, f32x4 (&acc)[27])
+{
+    const int mb = lane >> 3, i = lane & 3;
+    const float* xl = xw + mb * 4 + i;
+    const float* gl = gt + (mb + 2) * 8 + (lane & 7);
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        const int tz = q >> 1, xg = q & 1;
+        const float* xa = xl + (tz * (GW_X * GW_Y) + xg * 8) * 4;
+        const float* gb = gl + xg * 64 + tz * (GH_Y * GH_X * 8);
+        float win[4][3][3];                                           // [halo row % 4][dz][dx]: the row of the NEXT step is in flight
+        auto load_row = [&](int hy) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) win[hy % 4][a][c] = gb[(((2 - a) * GH_Y + hy) * GH_X - c) * 8];
+        };
+        load_row(0);
+        load_row(1);
+        load_row(2);
+        float a_cur = xa[0];
+#pragma unroll
+        for (int y = 0; y < GW_Y; ++y) {
+            if (y + 3 < GH_Y) load_row(y + 3);                        // consumed by the dy = 0 taps of the next step
+            const float a_nxt = y + 1 < GW_Y ? xa[(y + 1) * GW_X * 4] : 0.0f;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 2; b >= 0; --b) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        acc[(a * 3 + b) * 3 + c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur, win[(y + 2 - b) % 4][a][c], acc[(a * 3 + b) * 3 + c], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            a_cur = a_nxt;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_wgrad4_kernel(const float* __restrict__ x4, const float* __restrict__ g, int D, int H, int W,
+                                                                      int NCG, int B, float* __restrict__ partial)
+{
+    __shared__ __attribute__((aligned(1024))) float lds[GW_XF + GW_GF];
+    float* xt = lds;
+    float* gt = lds + GW_XF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.y, cg = split * 4 + wave;
+    const bool active = cg < NCG;
+    const int nbx = (W + GW_X - 1) / GW_X, nby = (H + GW_Y - 1) / GW_Y, nbz = (D + GW_Z - 1) / GW_Z;
+    const int ntiles = nbx * nby * nbz;
+    const int64_t nvox = (int64_t)D * H * W;
+    // halo voxel of this lane in its G pieces (piece = wave + 4 jj covers 32 voxels, two lanes per voxel) and its byte offset from the
+    // halo's first voxel: tile-invariant, so a tile inside the volume costs one scalar base address and one DMA instruction per piece
+    int hpk[GW_GSLOTS];
+    unsigned grel[GW_GSLOTS];
+#pragma unroll
+    for (int jj = 0; jj < GW_GSLOTS; ++jj) {
+        const int gp = wave + 4 * jj, hv = gp * 32 + (lane >> 1);
+        const int hx = hv % GH_X, hy = (hv / GH_X) % GH_Y, hz = hv / (GH_X * GH_Y);
+        const bool in = gp < GW_GP && hv < GH_NV;
+        hpk[jj] = in ? (hx | (hy << 8) | (hz << 16)) : -1;
+        grel[jj] = in ? (unsigned)(((hz * H + hy) * W + hx) * 8 + (lane & 1) * 4) * 4u : 0u;
+    }
+    const int tx = lane & 15, ty = wave * 4 + (lane >> 4);           // this lane's voxel in an X piece (plane tz = piece parity)
+    const unsigned xbase = lds_byte_addr(xt), gbase = lds_byte_addr(gt);
+    const unsigned xrel[2] = {(unsigned)(ty * W + tx) * 16u, (unsigned)((H + ty) * W + tx) * 16u};
+    f32x4 acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = f32x4{0, 0, 0, 0};
+    // Tile order: XCD x (= blockIdx.x & 7; gridDim.x is a multiple of 8, so the channel splits of a tile sequence share the XCD) walks
+    // its own contiguous eighth of the tiles, its workgroups side by side: neighbouring halos and the other splits' reads of the same
+    // G tile come out of that XCD's L2 instead of HBM.
+    const int per_xcd = (ntiles + 7) >> 3, wg_per_xcd = gridDim.x >> 3;
+    const int t_end = min(((int)(blockIdx.x & 7) + 1) * per_xcd, ntiles);
+#pragma unroll 1
+    for (int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3); tile < t_end; tile += wg_per_xcd) {
+        const int bx = tile % nbx, by = (tile / nbx) % nby, bz = tile / (nbx * nby);
+        const int x0 = bx * GW_X, y0 = by * GW_Y, z0 = bz * GW_Z;
+        __syncthreads();                                              // everybody finished reading the previous tile
+        // wave-uniform bases: first voxel of the X tile in channel block 0, first voxel of the G halo (outside the array for a border
+        // tile: only lanes whose own voxel is inside dereference it)
+        const char* xorg = reinterpret_cast<const char*>(x4) + (((int64_t)z0 * H + y0) * W + x0) * 16;
+        const char* gorg = reinterpret_cast<const char*>(g) + ((((int64_t)z0 - 1) * H + (y0 - 1)) * W + (x0 - 1)) * 32;
+        const bool interior = x0 >= 1 && x0 + GW_X + 1 <= W && y0 >= 1 && y0 + GW_Y + 1 <= H && z0 >= 1 && z0 + GW_Z + 1 <= D;
+        if (MVS_DBG(8)) {
+        } else if (interior) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)                               // X pieces: channel block j >> 1 of the split, plane j & 1
+                if (split * 4 + (j >> 1) < NCG) lds_dma_1k(xorg + (int64_t)(split * 4 + (j >> 1)) * nvox * 16, xbase + (wave + 4 * j) * 1024, xrel[j & 1]);
+#pragma unroll
+            for (int jj = 0; jj < GW_GSLOTS; ++jj)
+                if (wave + 4 * jj < GW_GP) lds_dma_1k(gorg, gbase + (wave + 4 * jj) * 1024, grel[jj]);
+        } else {
+            // border tile: a lane whose voxel is outside the volume writes the zero padding itself (the DMA skips inactive lanes)
+            const bool xy_ok = x0 + tx < W && y0 + ty < H;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (split * 4 + (j >> 1) >= NCG) continue;
+                float* dst = xt + (wave + 4 * j) * 256 + lane * 4;
+                if (xy_ok && z0 + (j & 1) < D) lds_dma_1k(xorg + (int64_t)(split * 4 + (j >> 1)) * nvox * 16, xbase + (wave + 4 * j) * 1024, xrel[j & 1]);
+                else *reinterpret_cast<f32x4*>(dst) = f32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int jj = 0; jj < GW_GSLOTS; ++jj) {
+                const int gp = wave + 4 * jj;
+                if (gp >= GW_GP) continue;
+                const int gx = x0 - 1 + (hpk[jj] & 255), gy = y0 - 1 + ((hpk[jj] >> 8) & 255), gz = z0 - 1 + (hpk[jj] >> 16);
+                float* dst = gt + gp * 256 + lane * 4;
+                if (hpk[jj] >= 0 && gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D) lds_dma_1k(gorg, gbase + gp * 1024, grel[jj]);
+                else *reinterpret_cast<f32x4*>(dst) = f32x4{0, 0, 0, 0};
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (active && !MVS_DBG(16)) wgrad4_tile(xt + wave * (GW_NV * 4), gt, lane, acc);
+    }
+    if (!active) return;
+    // fold the eight voxel slots (lane bits 3..5); lanes 0..7 then hold gW[co = lane][ci = 4 cg + r][tap]
+    const int co = lane & 7;
+    float* po = partial + ((int64_t)blockIdx.x * 8 + co) * B * 27;
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[t][r];
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 8 && cg * 4 + r < B) po[(int64_t)(cg * 4 + r) * 27 + t] = v;
+        }
+}
+
 }  // namespace
 
 // Called by mvsnerf_conv3d_fwd (encoder.hip) for the layers with 32 / 64 output channels; MVSNERF_EUNSUPPORTED = not instantiated.
@@ -622,6 +778,25 @@ bool mvs_conv3d_mfma32_supported(int Cin, int Cout, int stride)
 int mvs_conv_w32_repack(const float* wpacked, float* w32, int Cin, int Cout, hipStream_t st)
 {
     conv_w32_repack_kernel<<<mvs_cdiv((int64_t)27 * Cin * Cout, 256), 256, 0, st>>>(wpacked, w32, Cin, Cout);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// conv0's weight gradient from the blocked cost volume (mvsnerf_conv3d_c8_blocked_wgrad).  workspace: cap_parts + MVS_RED_SLICES rows
+// of 8 * cin_real * 27 floats.
+int mvs_conv3d_c8_wgrad4(const float* x4, int Cin, int cin_real, int D, int H, int W, const float* g, float* gw, float* workspace, int cap_parts,
+                         hipStream_t st)
+{
+    if ((Cin & 3) || cin_real > Cin || cin_real <= Cin - 4) return MVSNERF_EINVAL;
+    const int ncg = Cin / 4, nsplit = (ncg + 3) / 4;
+    const int ntiles = ((W + GW_X - 1) / GW_X) * ((H + GW_Y - 1) / GW_Y) * ((D + GW_Z - 1) / GW_Z);
+    int nx = (512 / nsplit) & ~7;                                     // two workgroups per CU; a multiple of 8 (see the kernel's tile order)
+    while (nx > 8 && (nx > cap_parts || nx / 8 > (ntiles + 7) / 8)) nx -= 8;
+    if (nx > cap_parts) return MVSNERF_EINVAL;
+    conv3d_k3s1_c8_wgrad4_kernel<<<dim3(nx, nsplit), 256, 0, st>>>(x4, g, D, H, W, ncg, cin_real, workspace);
+    MVS_LAUNCH_CHECK();
+    const int64_t n_out = (int64_t)8 * cin_real * 27;
+    mvs_partial_sum(workspace, nx, n_out, workspace + (size_t)cap_parts * n_out, gw, st);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }

@@ -1084,6 +1084,22 @@ extern "C" int mvsnerf_conv3d_wgrad(const float* g1, const float* g1_scale, cons
     return MVSNERF_OK;
 }
 
+// conv0's weight gradient with the cost volume in channel blocks of four (what mvsnerf_planesweep_costvar_blocked_fwd writes): matrix
+// cores, conv_mfma.hip.  g: gradient of conv0's raw output, channel-last [D][H][W][8].  gw: (8, Cin_real, 3,3,3).  workspace:
+// mvsnerf_conv3d_wgrad_workspace_floats(8, Cin_real) floats.  Deterministic (fixed partial-sum order).
+int mvs_conv3d_c8_wgrad4(const float* x4, int Cin, int cin_real, int D, int H, int W, const float* g, float* gw, float* workspace, int cap_parts,
+                         hipStream_t st);
+
+extern "C" int mvsnerf_conv3d_c8_blocked_wgrad(const float* x_blocked, int Cin, int Cin_real, int D, int H, int W, const float* g, float* gw,
+                                               float* workspace, void* stream)
+{
+    if (!x_blocked || !g || !gw || !workspace || D < 1 || H < 1 || W < 1 || Cin < 4 || (Cin & 3) || Cin_real < 1 || Cin_real > Cin || Cin_real <= Cin - 4)
+        return MVSNERF_EINVAL;
+    if (!mvs_aligned16(x_blocked) || !mvs_aligned16(g)) return MVSNERF_EALIGN;
+    if ((int64_t)D * H * W * 8 >= (int64_t)1 << 31) return MVSNERF_EUNSUPPORTED;
+    return mvs_conv3d_c8_wgrad4(x_blocked, Cin, Cin_real, D, H, W, g, gw, workspace, wgrad3d_part_cap(8, Cin_real), (hipStream_t)stream);
+}
+
 // ---- plane-sweep backward: d cost[...variance channels] -> d feats (channel-last [V][H][W][32]).
 // var_c = s2*inv - (s*inv)^2 with s = sum of warped values, so for every contributing value w:
 //   d w = g_var * 2*inv*(w - s*inv).   Warped values are bilinear gathers => their gradient is a bilinear scatter

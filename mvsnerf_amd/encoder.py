@@ -327,6 +327,23 @@ class _PackedConv:
         self.cache["fwd_c8"] = (base, buf)
         return buf
 
+    def get_dgrad_slice(self, c0, n):
+        """get("dgrad") restricted to the layer inputs c0 .. c0+n-1 (stride-1 Conv3d): [27][cout][n], mirrored taps.  The plane sweep's
+        backward needs the gradient of the variance channels only (the warped thumbnails carry no parameters)."""
+        w = self.conv.weight
+        key = (w.data_ptr(), w._version, c0, n)
+        hit = self.cache.get("dgrad_slice")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        if self.transposed or self.conv.stride[0] != 1 or n % 4 or c0 < 0 or c0 + n > self.cin:
+            raise RuntimeError("get_dgrad_slice: stride-1 Conv3d and a channel range inside the layer's inputs (multiple of 4 wide)")
+        wc = dev_f32(w.detach().contiguous(), "conv weight")
+        buf = torch.empty(27 * self.cout * n, device=w.device, dtype=torch.float32)
+        check(_lib.lib().mvsnerf_conv3d_pack_weights(wc + c0 * 27 * 4, self.cout, n, self.cout, n, self.cin * 27, 27, 1, buf.data_ptr(), stream_ptr()),
+              "conv3d_pack_weights")
+        self.cache["dgrad_slice"] = (key, buf)
+        return buf
+
     def get_mfma(self, mode="fwd"):
         """[tap][ci/8][co][8] re-layout of get(mode) for the matrix-core kernel of the 32/64-channel layers (same cache policy)."""
         base = self.get(mode)
@@ -546,11 +563,7 @@ class CostRegNet(nn.Module):
             _, lz = self._run(x)
             return _cl_view_to_ncdhw(_apply_add(lz[0], lz[9]))
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            params = []
-            for l in self._layers():
-                conv, bn = (l.conv, l.bn) if isinstance(l, ConvBnReLU3D) else (l[0], l[1])
-                params += [conv.weight, bn.weight, bn.bias]
-            return _CostRegFunction.apply(x, self, *params)
+            return _CostRegFunction.apply(x, self, *_costreg_params(self))
         _, lz = self._run(x)
         return _cl_view_to_ncdhw(_apply_add(lz[0], lz[9]))
 
@@ -589,6 +602,59 @@ def _wgrad(G1, G2, A, X1, X2, B, ldx, g_dims, x_dims, stride, shape):
     return gw
 
 
+def _costreg_backward(net, lz, g_out, conv0_grads):
+    """Backward of CostRegNet._run + the output sum.  g_out: gradient of the (1,8,D,h,w) result.  conv0_grads(gx) -> (gw, g_input):
+    conv0's weight gradient and whatever the caller needs upstream of it, from the gradient gx of conv0's raw output.
+    Returns (g_input, [gw, g bn.weight, g bn.bias] x 10 in _layers() order)."""
+    c0, c1, c2, c3, c4, c5, c6, u7, u9, u11 = lz
+    L = net._layers()
+    g = _grad_cl(g_out, 8)                                  # grad w.r.t. A(c0) + A(u11)
+    grads = {}
+
+    def up_block(i, lay, out_lz, in1, in2, g_act1, g_act2=None):
+        """ConvTranspose3d+ABN `lay` (output out_lz, input A(in1)+A(in2)): returns grad w.r.t. its activated input."""
+        gx, gbw, gbb = _abn_bwd(out_lz, lay[1], g_act1, g_act2)
+        pk = lay._packed
+        gw = _wgrad(in1, in2, pk.cin, gx, None, pk.cout, pk.cout, in1.dims[:3], out_lz.dims[:3], 2, tuple(lay[0].weight.shape))
+        g_in = _conv(gx, None, out_lz.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin, 2, packed=pk, mode="dgrad")       # data grad = stride-2 conv
+        grads[i] = (gw, gbw, gbb)
+        return g_in
+
+    def conv_block(i, lay, out_lz, in1, in_dims, in_ld, g_act1, g_act2=None):
+        gx, gbw, gbb = _abn_bwd(out_lz, lay.bn, g_act1, g_act2)
+        pk = lay._packed
+        gw = _wgrad(gx, None, pk.cout, in1, None, pk.cin, in_ld, out_lz.dims[:3], in_dims[:3], lay.stride, tuple(lay.conv.weight.shape))
+        grads[i] = (gw, gbw, gbb)
+        if lay.stride == 1:
+            return _conv(gx, None, out_lz.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin_pad, 1, packed=pk, mode="dgrad")
+        return _conv_t(gx, None, out_lz.dims, pk.get("dgrad"), pk.cout, pk.cin_pad, packed=pk, mode="dgrad")
+
+    g_u9c2 = up_block(9, L[9], u11, c2, u9, g)               # conv11: grad w.r.t. A(c2)+A(u9)
+    g_u7c4 = up_block(8, L[8], u9, c4, u7, g_u9c2)           # conv9:  grad w.r.t. A(c4)+A(u7)
+    g_c6 = up_block(7, L[7], u7, c6, None, g_u7c4)           # conv7:  grad w.r.t. A(c6)
+    g_c5 = conv_block(6, L[6], c6, c5, c5.dims, 64, g_c6)
+    g_c4 = conv_block(5, L[5], c5, c4, c4.dims, 32, g_c5)
+    g_c3 = conv_block(4, L[4], c4, c3, c3.dims, 32, g_u7c4, g_c4)     # A(c4) feeds conv5 and the conv9 skip
+    g_c2 = conv_block(3, L[3], c3, c2, c2.dims, 16, g_c3)
+    g_c1 = conv_block(2, L[2], c2, c1, c1.dims, 16, g_u9c2, g_c2)     # A(c2) feeds conv3 and the conv11 skip
+    g_c0 = conv_block(1, L[1], c1, c0, c0.dims, 8, g_c1)
+    gx0, gbw0, gbb0 = _abn_bwd(c0, L[0].bn, g, g_c0)                   # A(c0) feeds conv1 and the output sum
+    gw0, g_in = conv0_grads(gx0)
+    grads[0] = (gw0, gbw0, gbb0)
+    flat = []
+    for i in range(10):
+        flat += list(grads[i])
+    return g_in, flat
+
+
+def _costreg_params(net):
+    params = []
+    for l in net._layers():
+        conv, bn = (l.conv, l.bn) if isinstance(l, ConvBnReLU3D) else (l[0], l[1])
+        params += [conv.weight, bn.weight, bn.bias]
+    return params
+
+
 class _CostRegFunction(torch.autograd.Function):
     """CostRegNet with gradients to the cost volume, the 10 conv weights and the 10 ABN weight/bias pairs."""
 
@@ -601,47 +667,18 @@ class _CostRegFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         net, lz, buf, ld = ctx.net, ctx.lz, ctx.buf, ctx.ld
-        c0, c1, c2, c3, c4, c5, c6, u7, u9, u11 = lz
-        L = net._layers()
-        g = _grad_cl(g_out, 8)                                  # grad w.r.t. A(c0) + A(u11)
-        grads = {}
-
-        def up_block(i, lay, out_lz, in1, in2, g_act1, g_act2=None):
-            """ConvTranspose3d+ABN `lay` (output out_lz, input A(in1)+A(in2)): returns grad w.r.t. its activated input."""
-            gx, gbw, gbb = _abn_bwd(out_lz, lay[1], g_act1, g_act2)
-            pk = lay._packed
-            gw = _wgrad(in1, in2, pk.cin, gx, None, pk.cout, pk.cout, in1.dims[:3], out_lz.dims[:3], 2, tuple(lay[0].weight.shape))
-            g_in = _conv(gx, None, out_lz.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin, 2, packed=pk, mode="dgrad")       # data grad = stride-2 conv
-            grads[i] = (gw, gbw, gbb)
-            return g_in
-
-        def conv_block(i, lay, out_lz, in1, in_dims, in_ld, g_act1, g_act2=None, need_dgrad=True):
-            gx, gbw, gbb = _abn_bwd(out_lz, lay.bn, g_act1, g_act2)
-            pk = lay._packed
-            gw = _wgrad(gx, None, pk.cout, in1, None, pk.cin, in_ld, out_lz.dims[:3], in_dims[:3], lay.stride, tuple(lay.conv.weight.shape))
-            grads[i] = (gw, gbw, gbb)
-            if not need_dgrad:
-                return None
-            if lay.stride == 1:
-                return _conv(gx, None, out_lz.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin_pad, 1, packed=pk, mode="dgrad")
-            return _conv_t(gx, None, out_lz.dims, pk.get("dgrad"), pk.cout, pk.cin_pad, packed=pk, mode="dgrad")
-
-        g_u9c2 = up_block(9, L[9], u11, c2, u9, g)               # conv11: grad w.r.t. A(c2)+A(u9)
-        g_u7c4 = up_block(8, L[8], u9, c4, u7, g_u9c2)           # conv9:  grad w.r.t. A(c4)+A(u7)
-        g_c6 = up_block(7, L[7], u7, c6, None, g_u7c4)           # conv7:  grad w.r.t. A(c6)
-        g_c5 = conv_block(6, L[6], c6, c5, c5.dims, 64, g_c6)
-        g_c4 = conv_block(5, L[5], c5, c4, c4.dims, 32, g_c5)
-        g_c3 = conv_block(4, L[4], c4, c3, c3.dims, 32, g_u7c4, g_c4)     # A(c4) feeds conv5 and the conv9 skip
-        g_c2 = conv_block(3, L[3], c3, c2, c2.dims, 16, g_c3)
-        g_c1 = conv_block(2, L[2], c2, c1, c1.dims, 16, g_u9c2, g_c2)     # A(c2) feeds conv3 and the conv11 skip
-        g_c0 = conv_block(1, L[1], c1, c0, c0.dims, 8, g_c1)
+        lay, c0 = net.conv0, lz[0]
+        pk = lay._packed
         D, H, W = c0.dims[:3]
-        g_cost = conv_block(0, L[0], c0, buf, (D, H, W, ctx.ld), ctx.ld, g, g_c0, need_dgrad=ctx.needs_input_grad[0])   # A(c0) feeds conv1 and the output sum
-        out = [None if g_cost is None else _cl_view_to_ncdhw(g_cost, ctx.xshape[1]), None]
-        for i in range(10):
-            gw, gbw, gbb = grads[i]
-            out += [gw, gbw, gbb]
-        return tuple(out)
+
+        def conv0_grads(gx):
+            gw = _wgrad(gx, None, pk.cout, buf, None, pk.cin, ld, (D, H, W), (D, H, W), 1, tuple(lay.conv.weight.shape))
+            if not ctx.needs_input_grad[0]:
+                return gw, None
+            return gw, _conv(gx, None, c0.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin_pad, 1, packed=pk, mode="dgrad")
+
+        g_cost, flat = _costreg_backward(net, lz, g_out, conv0_grads)
+        return (None if g_cost is None else _cl_view_to_ncdhw(g_cost, ctx.xshape[1]), None, *flat)
 
 
 # ------------------------------------------------------------------ MVSNet
@@ -707,7 +744,7 @@ def _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img, blocked=Fa
         check(lib.mvsnerf_planesweep_costvar_blocked_fwd(feats_cl.data_ptr(), imgs_cl_p, dev_f32(proj, "proj_mats"), dev_f32(depth, "depth_values"),
                                                          V, C, H, W, D, pad, cost.data_ptr(), CP, masks.data_ptr(), int(with_img), stream_ptr()),
               "planesweep_costvar_blocked_fwd")
-        return _BlockedCost(cost, n_ch, CP, (D, Hp, Wp)), masks.unsqueeze(0), None
+        return _BlockedCost(cost, n_ch, CP, (D, Hp, Wp)), masks.unsqueeze(0), (feats_cl, proj, depth, (V, C, H, W, D, pad, CP, n_ch))
     cost = torch.empty((D, Hp, Wp, CP), device=dev, dtype=torch.float32)
     check(lib.mvsnerf_planesweep_costvar_fwd(feats_cl.data_ptr(), imgs_cl_p, dev_f32(proj, "proj_mats"), dev_f32(depth, "depth_values"),
                                              V, C, H, W, D, pad, cost.data_ptr(), CP, masks.data_ptr(), int(with_img), stream_ptr()),
@@ -733,6 +770,47 @@ class _PlaneSweepFunction(torch.autograd.Function):
         check(_lib.lib().mvsnerf_planesweep_costvar_bwd(feats_cl.data_ptr(), proj.data_ptr(), depth.data_ptr(), V, C, H, W, D, pad,
                                                         buf.data_ptr(), ld, int(ctx.with_img), g_feats.data_ptr(), stream_ptr()), "planesweep_costvar_bwd")
         return g_feats.permute(0, 3, 1, 2).unsqueeze(0), None, None, None, None, None
+
+
+class _SweepRegFunction(torch.autograd.Function):
+    """Training form of MVSNet.forward's volume branch (models.py:922-930): plane sweep -> CostRegNet as ONE autograd node, with the
+    cost volume in channel blocks of four between them (never in NCDHW / channel-last form).  conv0 and its weight gradient run on the
+    matrix cores from the blocked volume; its data gradient is computed for the 32 variance channels only - the warped thumbnails
+    (channels 0..3V-1) have no parameters upstream."""
+
+    @staticmethod
+    def forward(ctx, feats, imgs, proj_mats, depth_values, pad, net, *params):
+        cost, _, saved = _plane_sweep(imgs, feats, proj_mats, depth_values, pad, True, blocked=True)
+        _, lz = net._run(cost)
+        ctx.net, ctx.cost, ctx.lz, ctx.saved = net, cost, lz, saved
+        return _cl_view_to_ncdhw(_apply_add(lz[0], lz[9]))
+
+    @staticmethod
+    def backward(ctx, g_out):
+        net, cost, lz = ctx.net, ctx.cost, ctx.lz
+        feats_cl, proj, depth, (V, C, H, W, D, pad, CP, n_ch) = ctx.saved
+        lay, c0 = net.conv0, lz[0]
+        pk = lay._packed
+        Dv, Hv, Wv = cost.dims
+        lib = _lib.lib()
+
+        def conv0_grads(gx):
+            gw = torch.empty(tuple(lay.conv.weight.shape), device=gx.device, dtype=torch.float32)
+            ws = torch.empty(lib.mvsnerf_conv3d_wgrad_workspace_floats(8, pk.cin), device=gx.device, dtype=torch.float32)
+            check(lib.mvsnerf_conv3d_c8_blocked_wgrad(cost.buf.data_ptr(), pk.cin_pad, pk.cin, Dv, Hv, Wv, gx.data_ptr(), gw.data_ptr(),
+                                                      ws.data_ptr(), stream_ptr()), "conv3d_c8_blocked_wgrad")
+            if not ctx.needs_input_grad[0]:
+                return gw, None
+            return gw, _conv(gx, None, c0.dims, pk.cout, pk.get_dgrad_slice(3 * V, C), pk.cout, C, 1)     # d cost[variance channels]
+
+        g_var, flat = _costreg_backward(net, lz, g_out, conv0_grads)
+        g_feats = None
+        if g_var is not None:
+            g_feats_cl = torch.zeros((V, H, W, C), device=feats_cl.device, dtype=torch.float32)
+            check(lib.mvsnerf_planesweep_costvar_bwd(feats_cl.data_ptr(), proj.data_ptr(), depth.data_ptr(), V, C, H, W, D, pad,
+                                                     g_var.data_ptr(), C, 0, g_feats_cl.data_ptr(), stream_ptr()), "planesweep_costvar_bwd")
+            g_feats = g_feats_cl.permute(0, 3, 1, 2).unsqueeze(0)
+        return (g_feats, None, None, None, None, None, *flat)
 
 
 class MVSNet(nn.Module):
@@ -794,6 +872,10 @@ class MVSNet(nn.Module):
         if fast:
             cost, _ = self._sweep(imgs, feats_l, proj_mats, depth_values, pad, True, blocked=True)
             return self.cost_reg_2(cost), feats_l, depth_values
+        if BLOCKED_COST and not return_color and torch.is_grad_enabled() and (32 + 3 * V + 3) // 4 * 4 in _BLOCKED_CIN and B == 1:
+            # training: the same blocked hand-off inside one autograd node
+            vol = _SweepRegFunction.apply(feats_l, imgs, proj_mats, depth_values, pad, self.cost_reg_2, *_costreg_params(self.cost_reg_2))
+            return vol, feats_l, depth_values
         volume_feat, in_masks = self.build_volume_costvar_img(imgs, feats_l, proj_mats, depth_values, pad=pad)
         if return_color:
             feats_l = torch.cat((volume_feat[:, :V * 3].reshape(B, V, 3, *volume_feat.shape[2:]), in_masks.unsqueeze(2)), dim=2)

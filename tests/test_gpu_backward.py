@@ -88,10 +88,13 @@ def test_composite_backward_alone():
         assert err < 1e-4 * max(1.0, float(raw.grad.abs().max())), (S, err)
 
 
-def test_encoder_backward_vs_autograd():
+@pytest.mark.parametrize("fused", [False, True])
+def test_encoder_backward_vs_autograd(fused):
     """Plane sweep + CostRegNet backward (grads of all conv / ABN parameters and of the source features) against
-    PyTorch autograd through the CPU oracle.  Small shapes: features 16x24, pad 4, D=16."""
-    from mvsnerf_amd import models
+    PyTorch autograd through the CPU oracle.  Small shapes: features 16x24, pad 4, D=16.
+    fused: the single autograd node MVSNet.forward uses in training (cost volume in channel blocks of four, conv0's weight gradient
+    on the matrix cores, data gradient of the variance channels only) instead of the two public modules."""
+    from mvsnerf_amd import encoder as E, models
     from mvsnerf_amd.synth import make_rig
     from oracle import mvsnerf_oracle as O
     _, sd0 = load_weights()
@@ -114,8 +117,11 @@ def test_encoder_backward_vs_autograd():
     net.load_state_dict(sd0)
     net = net.to(DEV).train()
     f = feats0.clone().to(DEV).requires_grad_(True)
-    cost, _ = net.build_volume_costvar_img(imgs.to(DEV), f, proj.to(DEV), dv.to(DEV), pad=pad)
-    vol = net.cost_reg_2(cost)
+    if fused:
+        vol = E._SweepRegFunction.apply(f, imgs.to(DEV), proj.to(DEV), dv.to(DEV), pad, net.cost_reg_2, *E._costreg_params(net.cost_reg_2))
+    else:
+        cost, _ = net.build_volume_costvar_img(imgs.to(DEV), f, proj.to(DEV), dv.to(DEV), pad=pad)
+        vol = net.cost_reg_2(cost)
     assert float((vol.detach().cpu() - vol_ref.detach()).abs().max()) < 2e-3
     (vol * Rw.to(DEV)).sum().backward()
 

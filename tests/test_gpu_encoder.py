@@ -153,3 +153,71 @@ def test_xcd_tile_numbering_does_not_change_results(dims, mvs):
             _lib.lib().mvsnerf_tune(b"conv_xcd", 1)
     assert torch.equal(outs[0], outs[1])
     assert torch.isfinite(outs[0]).all()
+
+
+def _blocked(x_cl, cp):
+    """(D,H,W,C) channel-last -> [cp/4][D*H*W][4] (zero padding channels)."""
+    D, H, W, C = x_cl.shape
+    xp = torch.zeros((D * H * W, cp), device=x_cl.device)
+    xp[:, :C] = x_cl.reshape(-1, C)
+    return xp.view(-1, cp // 4, 4).permute(1, 0, 2).contiguous()
+
+
+@pytest.mark.parametrize("dims,cin", [((6, 20, 37), 41), ((3, 16, 16), 32), ((8, 33, 18), 47)])
+def test_conv0_blocked_wgrad_vs_float64(dims, cin):
+    """conv0's weight gradient on the matrix cores (blocked cost volume, voxels as the k dimension) against the float64 definition
+    gw[co][ci][tap] = sum_o g[o][co] x[o+tap-1][ci] (torch.nn.grad.conv3d_weight on the CPU)."""
+    from mvsnerf_amd import _lib
+    from mvsnerf_amd.ops import stream_ptr
+    D, H, W = dims
+    gen = torch.Generator().manual_seed(D * 1000 + cin)
+    x = torch.randn((D, H, W, cin), generator=gen)
+    g = torch.randn((D, H, W, 8), generator=gen)
+    cp = (cin + 3) // 4 * 4
+    ref = torch.nn.grad.conv3d_weight(x.permute(3, 0, 1, 2)[None].double(), (8, cin, 3, 3, 3), g.permute(3, 0, 1, 2)[None].double(), padding=1)
+    L = _lib.lib()
+    xb, gd = _blocked(x.to(DEV), cp), g.to(DEV)
+    gw = torch.full((8, cin, 3, 3, 3), float("nan"), device=DEV)
+    ws = torch.empty(L.mvsnerf_conv3d_wgrad_workspace_floats(8, cin), device=DEV)
+    rc = L.mvsnerf_conv3d_c8_blocked_wgrad(xb.data_ptr(), cp, cin, D, H, W, gd.data_ptr(), gw.data_ptr(), ws.data_ptr(), stream_ptr())
+    assert rc == 0
+    err = float((gw.cpu().double() - ref).abs().max())
+    assert err < 2e-6 * (D * H * W) ** 0.5 * 4, f"max err {err:.3e}"          # fp32 sums of D*H*W unit-variance products
+    gw2 = torch.empty_like(gw)
+    assert L.mvsnerf_conv3d_c8_blocked_wgrad(xb.data_ptr(), cp, cin, D, H, W, gd.data_ptr(), gw2.data_ptr(), ws.data_ptr(), stream_ptr()) == 0
+    assert torch.equal(gw, gw2)                                                 # deterministic
+
+
+def test_conv0_blocked_wgrad_full_size_vs_rows_kernel():
+    """Config-2 size: the matrix-core weight gradient against the VALU kernel it replaces (different summation orders)."""
+    from mvsnerf_amd import _lib
+    from mvsnerf_amd.ops import stream_ptr
+    D, H, W, cin, cp = 128, 176, 208, 41, 44
+    x = torch.randn((D, H, W, cp), device=DEV, generator=torch.Generator(DEV).manual_seed(1))
+    x[..., cin:] = 0
+    g = torch.randn((D, H, W, 8), device=DEV, generator=torch.Generator(DEV).manual_seed(2)) * 0.1
+    L = _lib.lib()
+    ws = torch.empty(L.mvsnerf_conv3d_wgrad_workspace_floats(8, cin), device=DEV)
+    old, new = torch.empty((8, cin, 3, 3, 3), device=DEV), torch.empty((8, cin, 3, 3, 3), device=DEV)
+    xb = _blocked(x[..., :cin], cp)
+
+    def run_old():
+        assert L.mvsnerf_conv3d_wgrad(g.data_ptr(), 0, 0, 0, 0, 0, 8, x.data_ptr(), 0, 0, 0, 0, 0, cin, cp, D, H, W, D, H, W, 1,
+                                      old.data_ptr(), ws.data_ptr(), stream_ptr()) == 0
+
+    def run_new():
+        assert L.mvsnerf_conv3d_c8_blocked_wgrad(xb.data_ptr(), cp, cin, D, H, W, g.data_ptr(), new.data_ptr(), ws.data_ptr(), stream_ptr()) == 0
+
+    ms = {}
+    for name, fn in (("rows", run_old), ("mfma", run_new)):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ms[name] = e0.elapsed_time(e1) / 5
+    scale = float(old.abs().max())
+    err = float((old - new).abs().max())
+    print(f"[conv0 wgrad 128x176x208x{cin}] rows kernel {ms['rows']:.3f} ms, matrix cores {ms['mfma']:.3f} ms; max diff {err:.2e} (|gw| max {scale:.1f})")
+    assert err < 1e-4 * scale
