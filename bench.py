@@ -237,7 +237,7 @@ def multi_gpu_legs(dev, rank, world, train_steps=5):
     out = {}
     # ---- (i) tile-parallel frame
     system = load_system(dev)
-    batch = train.synthetic_batch(H_IMG, W_IMG, seed=1234)
+    batch = train.batch_to_device(train.synthetic_batch(H_IMG, W_IMG, seed=1234), dev)      # inputs resident in HBM before any timed region
     system.render_view(batch, batch_rays=N_RAYS)
     dt, (rgb, depth) = timed_collective(lambda: system.render_view(batch, batch_rays=N_RAYS), dev, world)
     with D.single_rank():                                   # the whole frame on this rank alone: must be the same pixels, bit for bit
@@ -260,7 +260,7 @@ def multi_gpu_legs(dev, rank, world, train_steps=5):
             bl = [batch] * (n_warm + train_steps)
             take = lambda lst, a, b: lst[a:b]
         else:      # scene j goes to rank j % world (distributed.scene_shard): build only this rank's scenes
-            bl = [train.synthetic_batch(H_IMG, W_IMG, seed=1234 + j) if j % world == rank else None for j in range(world * (n_warm + train_steps))]
+            bl = [train.batch_to_device(train.synthetic_batch(H_IMG, W_IMG, seed=1234 + j), dev) if j % world == rank else None for j in range(world * (n_warm + train_steps))]
             take = lambda lst, a, b: lst[a * world:b * world]
         system.fit_steps(take(bl, 0, n_warm), opt)
         dt, losses = timed_collective(lambda: system.fit_steps(take(bl, n_warm, n_warm + train_steps), opt), dev, world)
@@ -500,7 +500,7 @@ def main():
             from mvsnerf_amd import train
             # (i) end-to-end frame: encode + 320 batches of 1024 rays (one 512x640 target view), validation_step's loop
             system = load_system(dev)
-            batch = train.synthetic_batch(H_IMG, W_IMG, seed=1234)
+            batch = train.batch_to_device(train.synthetic_batch(H_IMG, W_IMG, seed=1234), dev)
             # sub-batches of 1024 rays = the reference's chunk (and the headline batch): every launch of the MLP kernel in this
             # process then has the same size, so its rocprofv3 average is comparable with roofline.avg_launch_ms
             system.render_view(batch, batch_rays=N_RAYS)

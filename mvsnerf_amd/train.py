@@ -31,8 +31,14 @@ from .renderer import rendering
 from .utils import build_rays, build_rays_test, img2mse
 
 
+_UNPRE = {}
+
+
 def mse2psnr2(x):
+    """utils.py:28-30.  A device tensor stays on the device (no host synchronisation inside the training step)."""
     import math
+    if torch.is_tensor(x):
+        return -10.0 * torch.log(x.detach().clamp_min(1e-20)) / math.log(10.0)
     return -10.0 * math.log(max(x, 1e-20)) / math.log(10.0)
 
 
@@ -58,7 +64,12 @@ class _ModuleShim(nn.Module):
         self.logged = {}
 
     def log(self, key, value, prog_bar=False, **kw):
-        self.logged[key] = float(value.detach()) if torch.is_tensor(value) else float(value)
+        # tensors are kept as (detached) device tensors: reading one is the only host synchronisation, and it is the reader's
+        self.logged[key] = value.detach() if torch.is_tensor(value) else float(value)
+
+    def logged_values(self):
+        """The last logged metrics as Python floats (synchronises with the device)."""
+        return {k: float(v) for k, v in self.logged.items()}
 
     @property
     def device(self):
@@ -91,7 +102,7 @@ class MVSSystem(_ModuleShim):
     def decode_batch(self, batch):
         """:56-62 - move to device, squeeze the B=1 dim of the pose tensors."""
         dev = self.device
-        data = {k: (v.float().to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        data = {k: (v.to(dev, torch.float32, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
         pose_ref = {k: data[k].squeeze(0) if data[k].dim() > 3 or k == "near_fars" else data[k]
                     for k in ("w2cs", "intrinsics", "c2ws", "near_fars")}
         return data, pose_ref
@@ -99,9 +110,12 @@ class MVSSystem(_ModuleShim):
     @staticmethod
     def unpreprocess(data, shape=(1, 1, 3, 1, 1)):
         """:64-71 - undo the ImageNet normalisation (colour lookups use raw [0,1] images)."""
-        mean = torch.tensor([-0.485 / 0.229, -0.456 / 0.224, -0.406 / 0.225], device=data.device).view(*shape)
-        std = torch.tensor([1 / 0.229, 1 / 0.224, 1 / 0.225], device=data.device).view(*shape)
-        return (data - mean) / std
+        key = (data.device, data.dtype)
+        if key not in _UNPRE:                     # built once per device: a torch.tensor(list, device=...) is a synchronous upload
+            _UNPRE[key] = (torch.tensor([-0.485 / 0.229, -0.456 / 0.224, -0.406 / 0.225], device=data.device, dtype=data.dtype),
+                           torch.tensor([1 / 0.229, 1 / 0.224, 1 / 0.225], device=data.device, dtype=data.dtype))
+        mean, std = _UNPRE[key]
+        return (data - mean.view(*shape)) / std.view(*shape)
 
     def configure_optimizers(self):
         """:84-88."""
@@ -145,7 +159,7 @@ class MVSSystem(_ModuleShim):
         with torch.no_grad():
             self.log("train/loss", loss, prog_bar=True)
             self.log("train/img_mse_loss", img_loss)
-            self.log("train/PSNR", mse2psnr2(float(img_loss.detach())), prog_bar=True)
+            self.log("train/PSNR", mse2psnr2(img_loss), prog_bar=True)
         if self.global_step % 20000 == 19999 and D.world_rank()[1] == 0:  # one writer (ranks hold identical weights after the all-reduce)
             self.save_ckpt(f"{self.global_step}")
         # ray mode with N_rays % world != 0: weight the local mean so that the rank-averaged gradient is that of the global mean
@@ -255,8 +269,8 @@ class MVSSystem(_ModuleShim):
             self._allreduce()
             optimizer.step()
             self.global_step += 1
-            losses.append(float(out["loss"].detach()))
-        return losses
+            losses.append(out["loss"].detach())
+        return [float(l) for l in losses]                                   # one host synchronisation, after the last step is enqueued
 
 
 def synthetic_batch(H=512, W=640, seed=1234, **rig_kw):
@@ -265,6 +279,12 @@ def synthetic_batch(H=512, W=640, seed=1234, **rig_kw):
     rig = make_rig(H, W, seed=seed, **rig_kw)
     return {"images": rig["images"], "proj_mats": rig["proj_mats"], "w2cs": rig["w2cs"], "c2ws": rig["c2ws"],
             "intrinsics": rig["intrinsics"], "near_fars": rig["near_fars"], "depths_h": torch.zeros(1, 4, 1, 1)}
+
+
+def batch_to_device(batch, device):
+    """The collated batch with its tensors on `device` (what a pinned-memory DataLoader + prefetcher hands the step): training_step then
+    issues no host-to-device copy of its own."""
+    return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
 
 def default_args(**over):
@@ -425,7 +445,7 @@ class MVSSystemFinetune(_ModuleShim):
         img_loss = img2mse(rgbs, target)
         with torch.no_grad():
             self.log("train/loss", img_loss, prog_bar=True)
-            self.log("train/PSNR", mse2psnr2(float(img_loss.detach())), prog_bar=True)
+            self.log("train/PSNR", mse2psnr2(img_loss), prog_bar=True)
         return {"loss": img_loss}
 
     def save_ckpt(self, name="latest"):
@@ -458,8 +478,8 @@ class MVSSystemFinetune(_ModuleShim):
             self.global_step += 1
             if self.args.dp_volume_grad == "samples" and resync > 0 and self.global_step % resync == 0 and D._collective_needed():
                 torch.distributed.broadcast(ops.channels_last_volume(self.volume.feat_volume.data), src=0)     # the (D,H,W,C) view of the same memory
-            losses.append(float(out["loss"].detach()))
-        return losses
+            losses.append(out["loss"].detach())
+        return [float(l) for l in losses]                                   # one host synchronisation, after the last step is enqueued
 
     def configure_optimizers(self):
         self.optimizer = torch.optim.Adam(self.grad_vars, lr=self.args.lrate, betas=(0.9, 0.999))

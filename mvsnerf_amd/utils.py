@@ -76,6 +76,17 @@ def _stratified(near, far, n_rays, n_samples, device, jitter):
     return lower + (upper - lower) * torch.rand(z.shape, device=device)       # device RNG, as utils.py:220
 
 
+_INV_SCALE = {}
+
+
+def _inv_scale(W, H, dev):
+    """tensor([W-1, H-1]) on `dev`, uploaded once (a torch.tensor(list).to(dev) per step is a synchronous copy)."""
+    key = (W, H, str(dev))
+    if key not in _INV_SCALE:
+        _INV_SCALE[key] = torch.tensor([W - 1, H - 1]).to(dev)
+    return _INV_SCALE[key]
+
+
 def _nf_pair(near_fars_row):
     return near_fars_row.reshape(-1)[:2].to(torch.float32).contiguous()
 
@@ -89,18 +100,21 @@ def build_rays(imgs, depths, pose_ref, w2cs, c2ws, intrinsics, near_fars, N_rays
     dev = imgs.device
     _, V, _, H, W = imgs.shape
     w2c_ref, k_ref = pose_ref["w2cs"][ref_idx], pose_ref["intrinsics"][ref_idx]
-    inv_scale = torch.tensor([W - 1, H - 1]).to(dev)
+    inv_scale = _inv_scale(W, H, dev)
     near_ref, far_ref = pose_ref["near_fars"][ref_idx, 0], pose_ref["near_fars"][ref_idx, 1]
     i = V - 1
     if with_depth or importanceSampling or not imgs.is_cuda:
         return _build_rays_torch(imgs, depths, pose_ref, w2cs, c2ws, intrinsics, near_fars, N_rays, N_samples, pad,
                                  is_precrop_iters, ref_idx, importanceSampling, with_depth)
     if is_precrop_iters and torch.rand((1,)) > 0.3:                                  # utils.py:90-93
-        xs = torch.randint(W // 6, W - W // 6, (N_rays,)).float().to(dev)
-        ys = torch.randint(H // 6, H - H // 6, (N_rays,)).float().to(dev)
+        xs = torch.randint(W // 6, W - W // 6, (N_rays,))
+        ys = torch.randint(H // 6, H - H // 6, (N_rays,))
     else:
-        xs = torch.randint(0, W, (N_rays,)).float().to(dev)
-        ys = torch.randint(0, H, (N_rays,)).float().to(dev)
+        xs = torch.randint(0, W, (N_rays,))
+        ys = torch.randint(0, H, (N_rays,))
+    # one asynchronous copy from pinned memory (a pageable .to(dev) makes the host wait for everything already enqueued)
+    xy = torch.stack((xs, ys)).float().pin_memory().to(dev, non_blocking=True)
+    xs, ys = xy[0], xy[1]
     t_rand = torch.rand((N_rays, N_samples), device=dev)                             # utils.py:220
     pts, rays_d, ndc, z, pix = ops.raygen(H, W, intrinsics[i], c2ws[i], k_ref, w2c_ref, _nf_pair(near_fars[0, i]),
                                           _nf_pair(pose_ref["near_fars"][ref_idx]), N_samples, pad=pad, xs=xs, ys=ys, t_rand=t_rand)

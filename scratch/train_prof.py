@@ -8,7 +8,7 @@ system = train.MVSSystem(args).to(dev)
 z = np.load('tests/golden/mvsnerf_v0_weights.npz')
 system.render_kwargs_train["network_fn"].load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("mlp/")})
 system.MVSNet.load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("mvs/")})
-batch = train.synthetic_batch(512, 640, seed=1234)
+batch = train.batch_to_device(train.synthetic_batch(512, 640, seed=1234), dev)
 opt = system.configure_optimizers()[0][0]
 torch.manual_seed(0)
 system.fit_steps([batch]*2, opt)
