@@ -1186,12 +1186,247 @@ __global__ __launch_bounds__(256) void planesweep_bwd_kernel(const float* __rest
     }
 }
 
+// ---- plane-sweep backward, tile form.  The scatter above is bound by the atomics themselves: float atomics of one XCD cannot stay in its
+// L2 when seven other XCDs add to the same feature maps, so each of the 9 x 4.7 M 128-byte updates crosses the fabric (3.6 TB/s of atomic
+// traffic at 1.5 ms).  Here a workgroup owns an 8 x 8 column of voxels (CL = 16 of the 32 channels) over DCH consecutive depth planes and
+// merges before it sends:
+//   * reference view: voxel (d, y, x) always lands on pixel (y - pad, x - pad) - the sum over the depth planes is kept in a register and
+//     leaves as ONE atomic per pixel, channel and depth chunk (D / DCH instead of D);
+//   * source views: the 256 taps of a plane's tile fall on ~10 x 10 pixels, and consecutive planes move that footprint by a fraction of
+//     a pixel (the disparity step).  They are added into a PW x PW-pixel LDS patch per view, centred on where the tile's middle lands in
+//     the first of DSUB planes; after DSUB planes the touched pixels are flushed with one global atomic each.  A tap outside the patch
+//     (strongly magnifying view pairs) goes straight to memory, so the result never depends on the patch size.
+// The LDS sums are 64-bit FIXED POINT.  Measured on gfx950 (scratch/r2/lds_atomic_rate.hip): ds_add_f32 retires one wave-instruction
+// per ~170 clocks per CU (the 64 lanes serialise), ds_add_u64 one per ~9; with float LDS atomics this kernel ran 2x SLOWER than the plain
+// scatter.  Per group of DSUB planes the scale is 2^45 / (a power-of-two bound of 128 max|g| over the tile's first plane): a term is
+// exact to 2^-45 of that bound (fp32 keeps 2^-24 of the running sum), the sums cannot overflow (terms < 2^50, int64 accumulators), and
+// the patch sum no longer depends on the order of the additions.  float -> fixed point is one v_fma_f64 (add 1.5 * 2^52, read the mantissa).
+template <int C, int CL, int NSRC, int PW>
+__global__ __launch_bounds__(256) void planesweep_bwd_tiles_kernel(const float* __restrict__ feat, const float* __restrict__ proj,
+                                                                  const float* __restrict__ depth, int H, int W, int D, int pad,
+                                                                  const float* __restrict__ g_cost, int CP, int c_var, float* __restrict__ g_feat, int DCH)
+{
+    static_assert(C % CL == 0 && 256 % CL == 0 && CL >= 4, "channel split");
+    constexpr int TS = 8, NVX = TS * TS, PP = PW * PW, DSUB = 4, GS = NSRC * 16;
+    constexpr int VPP = 256 / CL;                                     // voxels per pass of the workgroup
+    constexpr int KV = NVX / VPP;                                     // voxels per thread and plane
+    constexpr int KB = (NSRC <= 4 || KV < 4) ? KV : KV / 2;           // voxels whose gathers are in flight together
+    typedef unsigned long long u64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // per (voxel, source view), written by ONE thread in phase 1 so that the channel lanes of phase 2 only multiply and add:
+    //   {w_nw,w_ne,w_sw,w_se | byte offset of the 4 tap pixels in a feature map | index of the 4 taps in `patch` (-1: outside) |
+    //    view counts this voxel (0/1), all four taps inside the patch (0/1), -, -}
+    float* geo = smem;                                                // [NVX][NSRC][16]
+    int* org = reinterpret_cast<int*>(geo + NVX * GS);                // [NSRC]{x, y} of the patch's first pixel (16 ints)
+    float* wmax = reinterpret_cast<float*>(org + 16);                 // [4] per-wave max |g| of the group's first plane, then 4 spare
+    double* fx = reinterpret_cast<double*>(wmax + 8);                 // {scale, 1 / scale} of the current group, then float limit in fx[2]
+    u64* patch = reinterpret_cast<u64*>(fx + 4);                      // [NSRC][PP][CL]
+    const int tid = threadIdx.x;
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const int ntx = (Wp + TS - 1) / TS, nty = (Hp + TS - 1) / TS;
+    const int tile = blockIdx.x % (ntx * nty), chunk = blockIdx.x / (ntx * nty);
+    const int x0 = (tile % ntx) * TS, y0 = (tile / ntx) * TS;
+    const int d_begin = chunk * DCH, d_end = min(D, d_begin + DCH);
+    const float sx = (float)(W - 1) / 2.0f, sy = (float)(H - 1) / 2.0f;
+    // phase-1 role: voxel pv of the tile, source views tid>>6, +4, ...
+    const int pv = tid & 63, vx = x0 + (pv & 7), vy = y0 + (pv >> 3);
+    const bool pvalid = vx < Wp && vy < Hp;
+    const float u = (float)(vx - pad), v = (float)(vy - pad);
+    // phase-2 role: channel c of voxels vl0 + VPP k
+    const int cl = tid & (CL - 1), c = blockIdx.y * CL + cl, vl0 = tid / CL;
+    float ref[KV], racc[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        const int vl = vl0 + VPP * k, x2 = x0 + (vl & 7), y2 = y0 + (vl >> 3);
+        const bool interior = x2 >= pad && x2 < W + pad && y2 >= pad && y2 < H + pad;
+        ref[k] = interior ? feat[(int64_t)((y2 - pad) * W + (x2 - pad)) * C + c] : 0.f;
+        racc[k] = 0.f;
+    }
+    for (int i = tid; i < NSRC * PP * CL; i += 256) patch[i] = 0;
+    auto flush = [&]() {                                              // caller guarantees every ds_add has been issued and synchronised
+        const double inv = fx[1];
+        for (int i = tid; i < NSRC * PP * CL; i += 256) {             // i % CL == cl: CL lanes send one contiguous piece of a pixel's line
+            const long long q = (long long)patch[i];
+            if (q != 0) {
+                patch[i] = 0;
+                const int slot = i / CL, vs = slot / PP, sp = slot - vs * PP;
+                const int px = org[vs * 2] + sp % PW, py = org[vs * 2 + 1] + sp / PW;
+                atomicAdd(g_feat + ((int64_t)(vs + 1) * H * W + (int64_t)py * W + px) * C + c, (float)((double)q * inv));
+            }
+        }
+    };
+    const float* lane_feat = feat + c;
+    u64* lane_patch = patch + cl;
+    for (int d = d_begin; d < d_end; ++d) {
+        const float dep = depth[d];
+        if (((d - d_begin) % DSUB) == 0) {
+            if (d != d_begin) { flush(); }
+            // fixed-point scale of this group from max |g| over the tile's first plane
+            float m = 0.f;
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                const int vl = vl0 + VPP * k, x2 = x0 + (vl & 7), y2 = y0 + (vl >> 3);
+                if (x2 < Wp && y2 < Hp) m = fmaxf(m, fabsf(g_cost[(((int64_t)d * Hp + y2) * Wp + x2) * CP + c_var + c]));
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            if ((tid & 63) == 0) wmax[tid >> 6] = m;
+            if (tid < NSRC) {                                         // centre the patch on where the tile's middle lands in this plane
+                const float* P = proj + (tid + 1) * 12;
+                const float uc = (float)(x0 - pad) + 3.5f, vc = (float)(y0 - pad) + 3.5f;
+                const float p0 = fmaf(P[1], vc, P[0] * uc) + P[2] + P[3] / dep, p1 = fmaf(P[5], vc, P[4] * uc) + P[6] + P[7] / dep;
+                const float p2 = fmaf(P[9], vc, P[8] * uc) + P[10] + P[11] / dep;
+                const float cx = fminf(fmaxf(p0 / p2, -4096.f), 1e6f), cy = fminf(fmaxf(p1 / p2, -4096.f), 1e6f);
+                org[tid * 2] = (int)floorf(cx) - PW / 2 + 1;
+                org[tid * 2 + 1] = (int)floorf(cy) - PW / 2 + 1;
+            }
+            __syncthreads();                                          // (also: the flush above is complete before anybody adds again)
+            if (tid == 0) {
+                const float mm = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+                int e = 0;
+                frexpf(fmaxf(mm, 1e-30f) * 128.0f, &e);               // bound < 2^e
+                const int se = min(45 - e, 120);
+                fx[0] = ldexp(1.0, se);
+                fx[1] = ldexp(1.0, -se);
+                reinterpret_cast<float*>(fx + 2)[0] = ldexpf(1.0f, 50 - se);      // |term| below this stays under 2^50 after scaling
+            }
+        }
+        for (int vs = tid >> 6; vs < NSRC; vs += 4) {
+            const float* P = proj + (vs + 1) * 12;
+            const float p0 = fmaf(P[2], 1.0f, fmaf(P[1], v, P[0] * u)) + P[3] / dep;
+            const float p1 = fmaf(P[6], 1.0f, fmaf(P[5], v, P[4] * u)) + P[7] / dep;
+            const float p2 = fmaf(P[10], 1.0f, fmaf(P[9], v, P[8] * u)) + P[11] / dep;
+            const float gx = (p0 / p2) / sx - 1.0f, gy = (p1 / p2) / sy - 1.0f;
+            const bool inside = gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f;
+            const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1), iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+            const float fxx = floorf(ix), fyy = floorf(iy);
+            const float wx1 = ix - fxx, wx0 = (fxx + 1.0f) - ix, wy1 = iy - fyy, wy0 = (fyy + 1.0f) - iy;
+            const bool x0in = fxx >= 0.f && fxx <= (float)(W - 1), x1in = fxx + 1.f >= 0.f && fxx + 1.f <= (float)(W - 1);
+            const bool y0in = fyy >= 0.f && fyy <= (float)(H - 1), y1in = fyy + 1.f >= 0.f && fyy + 1.f <= (float)(H - 1);
+            const bool any = pvalid && (x0in || x1in) && (y0in || y1in);
+            const int xa = any ? min(max((int)fxx, 0), W - 1) : 0, xb = any ? min(max((int)fxx + 1, 0), W - 1) : 0;
+            const int ya = any ? min(max((int)fyy, 0), H - 1) : 0, yb = any ? min(max((int)fyy + 1, 0), H - 1) : 0;
+            const f32x4 wq = {(any && x0in && y0in) ? wx0 * wy0 : 0.f, (any && x1in && y0in) ? wx1 * wy0 : 0.f,
+                              (any && x0in && y1in) ? wx0 * wy1 : 0.f, (any && x1in && y1in) ? wx1 * wy1 : 0.f};
+            const int ox = org[vs * 2], oy = org[vs * 2 + 1];
+            const unsigned rxa = (unsigned)(xa - ox), rxb = (unsigned)(xb - ox), rya = (unsigned)(ya - oy), ryb = (unsigned)(yb - oy);
+            const bool xai = rxa < (unsigned)PW, xbi = rxb < (unsigned)PW, yai = rya < (unsigned)PW, ybi = ryb < (unsigned)PW;
+            const int pb = vs * PP;
+            const int4 po = {(xai && yai) ? (int)((pb + rya * PW + rxa) * CL) : -1, (xbi && yai) ? (int)((pb + rya * PW + rxb) * CL) : -1,
+                             (xai && ybi) ? (int)((pb + ryb * PW + rxa) * CL) : -1, (xbi && ybi) ? (int)((pb + ryb * PW + rxb) * CL) : -1};
+            const int4 gb = {(ya * W + xa) * C * 4, (ya * W + xb) * C * 4, (yb * W + xa) * C * 4, (yb * W + xb) * C * 4};
+            float* ov = geo + (pv * NSRC + vs) * 16;
+            *reinterpret_cast<f32x4*>(ov) = wq;
+            *reinterpret_cast<int4*>(ov + 4) = gb;
+            *reinterpret_cast<int4*>(ov + 8) = po;
+            *reinterpret_cast<f32x4*>(ov + 12) = f32x4{(pvalid && inside) ? 1.0f : 0.0f, (xai && xbi && yai && ybi) ? 1.0f : 0.0f, 0.f, 0.f};
+        }
+        __syncthreads();
+        const double scale = fx[0];
+        const float lim = reinterpret_cast<const float*>(fx + 2)[0];
+        auto to_fixed = [&](float val) -> u64 {                       // round(val * scale) for |val * scale| < 2^51
+            const double t = fma((double)val, scale, 6755399441055744.0);
+            return (u64)(__double_as_longlong(t) - 0x4338000000000000LL);
+        };
+#pragma unroll 1
+        for (int k0 = 0; k0 < KV; k0 += KB) {
+            float gv[KB], tap[KB][NSRC][4];
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                const int vl = vl0 + VPP * (k0 + kk), x2 = x0 + (vl & 7), y2 = y0 + (vl >> 3);
+                gv[kk] = (x2 < Wp && y2 < Hp) ? g_cost[(((int64_t)d * Hp + y2) * Wp + x2) * CP + c_var + c] : 0.f;
+                const float* o = geo + (vl * NSRC) * 16;
+#pragma unroll
+                for (int vs = 0; vs < NSRC; ++vs) {
+                    const char* fb = reinterpret_cast<const char*>(lane_feat + (int64_t)(vs + 1) * H * W * C);
+                    const int4 gb = *reinterpret_cast<const int4*>(o + vs * 16 + 4);
+                    tap[kk][vs][0] = *reinterpret_cast<const float*>(fb + gb.x); tap[kk][vs][1] = *reinterpret_cast<const float*>(fb + gb.y);
+                    tap[kk][vs][2] = *reinterpret_cast<const float*>(fb + gb.z); tap[kk][vs][3] = *reinterpret_cast<const float*>(fb + gb.w);
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                const int k = k0 + kk, vl = vl0 + VPP * k;
+                const float* o = geo + (vl * NSRC) * 16;
+                float cnt = 1.0f, s = ref[k], wv[NSRC];
+                f32x4 wq[NSRC];
+#pragma unroll
+                for (int vs = 0; vs < NSRC; ++vs) {
+                    wq[vs] = *reinterpret_cast<const f32x4*>(o + vs * 16);
+                    cnt += o[vs * 16 + 12];
+                    wv[vs] = ((tap[kk][vs][0] * wq[vs][0] + tap[kk][vs][1] * wq[vs][1]) + tap[kk][vs][2] * wq[vs][2]) + tap[kk][vs][3] * wq[vs][3];
+                    s += wv[vs];
+                }
+                const float inv = 1.0f / cnt;
+                const float k2 = gv[kk] * 2.0f * inv, mean = s * inv;
+                racc[k] += k2 * (ref[k] - mean);
+#pragma unroll
+                for (int vs = 0; vs < NSRC; ++vs) {
+                    const float gw_ = k2 * (wv[vs] - mean);
+                    const int4 po = *reinterpret_cast<const int4*>(o + vs * 16 + 8);
+                    if (o[vs * 16 + 13] != 0.f && fabsf(gw_) < lim) { // all four taps inside the patch (a zero-weight tap adds 0), in range
+                        atomicAdd(lane_patch + po.x, to_fixed(gw_ * wq[vs][0])); atomicAdd(lane_patch + po.y, to_fixed(gw_ * wq[vs][1]));
+                        atomicAdd(lane_patch + po.z, to_fixed(gw_ * wq[vs][2])); atomicAdd(lane_patch + po.w, to_fixed(gw_ * wq[vs][3]));
+                    } else {
+                        const int4 gb = *reinterpret_cast<const int4*>(o + vs * 16 + 4);
+                        const int pos[4] = {po.x, po.y, po.z, po.w}, gbs[4] = {gb.x, gb.y, gb.z, gb.w};
+                        float* gview = g_feat + (int64_t)(vs + 1) * H * W * C + c;
+#pragma unroll 1
+                        for (int t = 0; t < 4; ++t) {
+                            const float val = gw_ * wq[vs][t];
+                            if (wq[vs][t] == 0.f) continue;
+                            if (pos[t] >= 0 && fabsf(val) < lim) atomicAdd(lane_patch + pos[t], to_fixed(val));
+                            else atomicAdd(gview + (gbs[t] >> 2), val);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    flush();
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        const int vl = vl0 + VPP * k, x2 = x0 + (vl & 7), y2 = y0 + (vl >> 3);
+        if (x2 >= pad && x2 < W + pad && y2 >= pad && y2 < H + pad) atomicAdd(g_feat + (int64_t)((y2 - pad) * W + (x2 - pad)) * C + c, racc[k]);
+    }
+}
+
+int g_psw_bwd_tiles = 1;   // A/B knob (mvsnerf_tune "psw_bwd_tiles"): 0 = the per-voxel scatter kernel
+
+template <int NSRC>
+static int planesweep_bwd_tiles_launch(const float* feat, const float* proj, const float* depth, int H, int W, int D, int pad, const float* g_cost, int CP,
+                                       int c_var, float* g_feat, hipStream_t st)
+{
+    constexpr int PW = 12, DCH = 16, CL = 16;
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const size_t lds = (size_t)(64 * NSRC * 16 + 16 + 8 + 8) * sizeof(float) + (size_t)NSRC * PW * PW * CL * 8;
+    static unsigned long long cap_mask = 0;
+    if (lds > 64 * 1024) {
+        const int rc = mvs_raise_lds_cap((const void*)planesweep_bwd_tiles_kernel<32, CL, NSRC, PW>, (int)lds, &cap_mask);
+        if (rc != MVSNERF_OK) return rc;
+    }
+    const dim3 grid((unsigned)(((Wp + 7) / 8) * ((Hp + 7) / 8) * ((D + DCH - 1) / DCH)), 32 / CL);
+    planesweep_bwd_tiles_kernel<32, CL, NSRC, PW><<<grid, 256, lds, st>>>(feat, proj, depth, H, W, D, pad, g_cost, CP, c_var, g_feat, DCH);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
 extern "C" int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float* proj, const float* depth, int V, int C, int H, int W, int D, int pad,
                                               const float* g_cost, int CP, int with_img, float* g_feats_cl, void* stream)
 {
     if (!feats_cl || !proj || !depth || !g_cost || !g_feats_cl || V < 1 || V > 8 || H < 2 || W < 2 || D < 1 || pad < 0) return MVSNERF_EINVAL;
     if (C != 32) return MVSNERF_EUNSUPPORTED;
     const int64_t nvox = (int64_t)D * (H + 2 * pad) * (W + 2 * pad);
+    if (g_psw_bwd_tiles && V >= 2) {
+        hipStream_t st = (hipStream_t)stream;
+        const int cv = with_img ? 3 * V : 0;
+        switch (V - 1) {
+#define MVS_PBT(N) case N: return planesweep_bwd_tiles_launch<N>(feats_cl, proj, depth, H, W, D, pad, g_cost, CP, cv, g_feats_cl, st)
+            MVS_PBT(1); MVS_PBT(2); MVS_PBT(3); MVS_PBT(4); MVS_PBT(5); MVS_PBT(6); MVS_PBT(7);
+#undef MVS_PBT
+        }
+    }
     const size_t lds = (size_t)256 * ((V - 1) * 8 + 2) * sizeof(float);
     planesweep_bwd_kernel<32><<<mvs_cdiv(nvox, 256), 256, lds, (hipStream_t)stream>>>(feats_cl, proj, depth, V, H, W, D, pad, g_cost, CP,
                                                                                     with_img ? 3 * V : 0, g_feats_cl);

@@ -678,6 +678,7 @@ int mvs_mlp_fwd_gather(const float* packed, const float* vol, int D, int H, int 
 // 2 = 32 pts/wave, 1 wave/SIMD; 3 = 32 pts/wave, 2 waves/SIMD, double-buffered LDS-DMA weight slabs (default)
 static int g_mlp_variant = 3;
 extern int g_conv_tiled;
+extern int g_psw_bwd_tiles;
 extern int g_conv_xcd;
 extern int g_conv_mfma;
 extern int g_split_sched;     // mlp_bf16.hip
@@ -686,6 +687,7 @@ extern "C" int mvsnerf_tune(const char* key, int value)
 {
     if (!key) return MVSNERF_EINVAL;
     if (__builtin_strcmp(key, "conv_tiled") == 0) { g_conv_tiled = value ? 1 : 0; return MVSNERF_OK; }
+    if (__builtin_strcmp(key, "psw_bwd_tiles") == 0) { g_psw_bwd_tiles = value ? 1 : 0; return MVSNERF_OK; }
     if (__builtin_strcmp(key, "conv_xcd") == 0) { g_conv_xcd = value ? 1 : 0; return MVSNERF_OK; }
     if (__builtin_strcmp(key, "conv_mfma") == 0) { g_conv_mfma = value ? 1 : 0; return MVSNERF_OK; }
     if (__builtin_strcmp(key, "mlp_gather") == 0) { g_mlp_gather = value ? 1 : 0; return MVSNERF_OK; }

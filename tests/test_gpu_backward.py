@@ -284,3 +284,43 @@ def test_bf16_training_vs_torch_emulation():
     assert not bad, f"vs bf16 emulation: {bad}\nall: {errs_e}"
     bad = {k: v for k, v in errs_f.items() if not v < 0.15}          # measured 6.8e-2: the price of bf16 operands
     assert not bad, f"vs fp32 oracle: {bad}\nall: {errs_f}"
+
+
+@pytest.mark.parametrize("V,H,W,pad,D,with_img", [(3, 30, 41, 3, 10, True), (5, 16, 24, 4, 19, True), (2, 32, 32, 0, 8, False), (3, 128, 160, 24, 128, False)])
+def test_planesweep_bwd_tiles_vs_scatter(V, H, W, pad, D, with_img):
+    """The tile form of the plane-sweep backward (register sum over depth for the reference view, LDS patches for the source views)
+    against the per-voxel scatter kernel: same terms, different float summation order.  The last case is the training shape (timed)."""
+    from mvsnerf_amd import _lib
+    from mvsnerf_amd.ops import stream_ptr
+    from mvsnerf_amd.synth import make_rig
+    base = (0.0, 0.25, -0.25, 0.12, -0.12, 0.1)
+    rig = make_rig(H * 4, W * 4, n_views=V + 1, seed=77, baselines=base[:V + 1], rot_deg=2.0, smooth=True)
+    proj = rig["proj_mats"][0, :V].contiguous().to(DEV)
+    nf = rig["near_fars"][0, 0]
+    depth = torch.linspace(float(nf[0]), float(nf[1]), D).to(DEV)
+    g = torch.Generator(DEV).manual_seed(V * 100 + D)
+    feats = torch.randn((V, H, W, 32), device=DEV, generator=g)
+    CP = (32 + 3 * V + 3) // 4 * 4 if with_img else 32
+    Hp, Wp = H + 2 * pad, W + 2 * pad
+    g_cost = torch.randn((D, Hp, Wp, CP), device=DEV, generator=g)
+    L = _lib.lib()
+    out, ms = {}, {}
+    for mode in (0, 1):
+        assert L.mvsnerf_tune(b"psw_bwd_tiles", mode) == 0
+        try:
+            for rep in range(3):
+                gf = torch.zeros((V, H, W, 32), device=DEV)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = L.mvsnerf_planesweep_costvar_bwd(feats.data_ptr(), proj.data_ptr(), depth.data_ptr(), V, 32, H, W, D, pad, g_cost.data_ptr(), CP,
+                                                      int(with_img), gf.data_ptr(), stream_ptr())
+                e1.record(); torch.cuda.synchronize()
+                assert rc == 0
+            out[mode], ms[mode] = gf, e0.elapsed_time(e1)
+        finally:
+            L.mvsnerf_tune(b"psw_bwd_tiles", 1)
+    scale = float(out[0].abs().max())
+    err = float((out[0] - out[1]).abs().max())
+    print(f"[planesweep bwd V={V} {D}x{Hp}x{Wp}] scatter {ms[0]:.3f} ms, tiles {ms[1]:.3f} ms; max diff {err:.2e} (|g| max {scale:.1f})")
+    assert scale > 0 and err < 2e-5 * scale
