@@ -38,7 +38,7 @@ int mvsnerf_abi_version(void);
 
 /* A/B benchmarking knob, not part of the reference surface.  Keys: "mlp_variant" = 3 (default: 32 points/wave,
  * 2 waves/SIMD, weights double-buffered through LDS by LDS-DMA), 0 (same, register-staged weights), 1 (64 points/wave,
- * 1 wave/SIMD), 2 (32 points/wave, 1 wave/SIMD), 4 (16 points/wave on v_mfma_f32_16x16x4_f32, inference only); "conv_tiled" = 1|0; "conv_mfma" = 1|0 (stride-1 convolutions with 8 output channels on v_mfma_f32_4x4x1_16B_f32, default 1); "mlp_gather" = 0|1 (default 0: rendering() with 3 views does its lookups in the MLP kernel's prologue - one launch less, measured 1 % slower); "conv_xcd" = 1|0 (tiles of the tiled convolutions renumbered per XCD, default 1); "split_sched" = 0 (default: bf16x6 kernel at two waves
+ * 1 wave/SIMD), 2 (32 points/wave, 1 wave/SIMD), 4 (16 points/wave on v_mfma_f32_16x16x4_f32, inference only); "conv_tiled" = 1|0; "conv_mfma" = 1|0 (stride-1 convolutions with 8 output channels on v_mfma_f32_4x4x1_16B_f32, default 1); "mlp_gather" = 0|1 (default 0: rendering() with 3 views does its lookups in the MLP kernel's prologue - one launch less, measured 1 % slower); "conv_xcd" = 1|0 (tiles of the tiled convolutions renumbered per XCD, default 1); "psw_bwd_tiles" = 1|0 (plane-sweep backward merging its scatter in LDS tiles, default 1; 0 = one float atomic per tap); "split_sched" = 0 (default: bf16x6 kernel at two waves
  * per SIMD, lean registers) | 1 (one wave per SIMD, operand splitting hand-interleaved between the MFMAs).  Results are
  * identical up to summation order. */
 int mvsnerf_tune(const char* key, int value);
@@ -160,6 +160,17 @@ int mvsnerf_conv3d_wgrad(const float* g1, const float* g1_scale, const float* g1
                          float* gw, float* workspace, void* stream);
 int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float* proj, const float* depth, int V, int C, int H, int W, int D, int pad,
                                    const float* g_cost, int CP, int with_img, float* g_feats_cl, void* stream);
+/* Every weight-gradient entry (conv3d_wgrad, conv3d_c8_blocked_wgrad, conv2d_wgrad) leaves per-workgroup partial results at the start of
+ * its workspace and then reduces them (two small launches).  With gw == NULL the reduction is skipped: the caller collects the
+ * (workspace, *_wgrad_parts(...) rows, A*B*taps floats per row, gw) of all layers of a backward pass and finishes them together with
+ * ONE call of partial_sum_multi (<= 32 jobs; host arrays; two launches in total; a training step has ~30 weight gradients).
+ * scratch: mvsnerf_partial_sum_multi_scratch_floats(sum of the jobs' n_out) floats.  Same fixed summation order either way. */
+int mvsnerf_conv3d_wgrad_parts(int A, int B, int Do, int Ho);
+int mvsnerf_conv3d_c8_blocked_wgrad_parts(int Cin, int Cin_real, int D, int H, int W);
+int mvsnerf_conv2d_wgrad_parts(int A, int N, int Ho, int Wo);
+size_t mvsnerf_partial_sum_multi_scratch_floats(int64_t total_n_out);
+int mvsnerf_partial_sum_multi(int n_jobs, const float* const* partial, const int* n_part, const int64_t* n_out, float* const* dst,
+                              float* scratch, void* stream);
 
 /* ---- FeatureNet (models.py:688-722; ConvBnReLU :661-672): 2-D convolutions over N images, channel-last
  * act[n][y][x][C], same lazy-InPlaceABN convention as the 3-D blocks (statistics via mvsnerf_abn_stats / mvsnerf_abn_bwd

@@ -60,3 +60,41 @@ static inline void mvs_partial_sum(const float* partial, int n_part, int64_t n_o
     mvs_partial_sum_kernel<<<dim3(gx, slices), 256, 0, st>>>(partial, n_part, n_out, chunk, scratch);
     mvs_partial_sum_kernel<<<dim3(gx, 1), 256, 0, st>>>(scratch, slices, n_out, slices, dst);
 }
+
+// The same reduction for up to MVS_PSUM_JOBS independent (partial, dst) pairs in TWO launches in total: a training step has ~30 weight
+// gradients, each of which used to pay its own two launches (60 x 9 us).  The jobs travel in the kernel arguments.
+constexpr int MVS_PSUM_JOBS = 32;
+struct PsumJobs {
+    const float* partial[MVS_PSUM_JOBS];
+    float* dst[MVS_PSUM_JOBS];
+    float* scratch[MVS_PSUM_JOBS];     // [slices][n_out] (unused when slices == 1)
+    long long n_out[MVS_PSUM_JOBS];
+    int n_part[MVS_PSUM_JOBS], chunk[MVS_PSUM_JOBS], slices[MVS_PSUM_JOBS];
+    int blk1[MVS_PSUM_JOBS + 1], blk2[MVS_PSUM_JOBS + 1];     // first workgroup of each job in stage 1 / stage 2
+    int n;
+};
+
+template <int STAGE>
+static __global__ __launch_bounds__(256) void mvs_partial_sum_multi_kernel(PsumJobs J)
+{
+    const int* blk = STAGE == 1 ? J.blk1 : J.blk2;
+    int j = 0;
+    while (j + 1 < J.n && (int)blockIdx.x >= blk[j + 1]) ++j;
+    const int local = blockIdx.x - blk[j];
+    const long long n_out = J.n_out[j];
+    const int gx = (int)((n_out + 255) / 256);
+    const int slice = local / gx;
+    const long long i = (long long)(local - slice * gx) * 256 + threadIdx.x;
+    if (i >= n_out) return;
+    const float* src = STAGE == 1 ? J.partial[j] : J.scratch[j];
+    const int n_src = STAGE == 1 ? J.n_part[j] : J.slices[j];
+    const int chunk = STAGE == 1 ? J.chunk[j] : n_src;
+    const int p0 = slice * chunk, p1 = p0 + chunk < n_src ? p0 + chunk : n_src;
+    float s0 = 0.f, s1 = 0.f;
+    int p = p0;
+    for (; p + 1 < p1; p += 2) { s0 += src[(long long)p * n_out + i]; s1 += src[(long long)(p + 1) * n_out + i]; }
+    if (p < p1) s0 += src[(long long)p * n_out + i];
+    float* out = (STAGE == 1 && J.slices[j] > 1) ? J.scratch[j] + (long long)slice * n_out : J.dst[j];
+    out[i] = s0 + s1;
+}
+

@@ -784,17 +784,27 @@ int mvs_conv_w32_repack(const float* wpacked, float* w32, int Cin, int Cout, hip
 
 // conv0's weight gradient from the blocked cost volume (mvsnerf_conv3d_c8_blocked_wgrad).  workspace: cap_parts + MVS_RED_SLICES rows
 // of 8 * cin_real * 27 floats.
+static int wgrad4_nx(int Cin, int D, int H, int W, int cap_parts)
+{
+    const int ncg = Cin / 4, nsplit = (ncg + 3) / 4;
+    const int ntiles = ((W + GW_X - 1) / GW_X) * ((H + GW_Y - 1) / GW_Y) * ((D + GW_Z - 1) / GW_Z);
+    int nx = (512 / nsplit) & ~7;                                     // two workgroups per CU; a multiple of 8 (see the kernel's tile order)
+    while (nx > 8 && (nx > cap_parts || nx / 8 > (ntiles + 7) / 8)) nx -= 8;
+    return nx;
+}
+
+int mvs_conv3d_c8_wgrad4_parts(int Cin, int D, int H, int W, int cap_parts) { return wgrad4_nx(Cin, D, H, W, cap_parts); }
+
 int mvs_conv3d_c8_wgrad4(const float* x4, int Cin, int cin_real, int D, int H, int W, const float* g, float* gw, float* workspace, int cap_parts,
                          hipStream_t st)
 {
     if ((Cin & 3) || cin_real > Cin || cin_real <= Cin - 4) return MVSNERF_EINVAL;
     const int ncg = Cin / 4, nsplit = (ncg + 3) / 4;
-    const int ntiles = ((W + GW_X - 1) / GW_X) * ((H + GW_Y - 1) / GW_Y) * ((D + GW_Z - 1) / GW_Z);
-    int nx = (512 / nsplit) & ~7;                                     // two workgroups per CU; a multiple of 8 (see the kernel's tile order)
-    while (nx > 8 && (nx > cap_parts || nx / 8 > (ntiles + 7) / 8)) nx -= 8;
+    const int nx = wgrad4_nx(Cin, D, H, W, cap_parts);
     if (nx > cap_parts) return MVSNERF_EINVAL;
     conv3d_k3s1_c8_wgrad4_kernel<<<dim3(nx, nsplit), 256, 0, st>>>(x4, g, D, H, W, ncg, cin_real, workspace);
     MVS_LAUNCH_CHECK();
+    if (!gw) return MVSNERF_OK;                                       // partials left for mvsnerf_partial_sum_multi
     const int64_t n_out = (int64_t)8 * cin_real * 27;
     mvs_partial_sum(workspace, nx, n_out, workspace + (size_t)cap_parts * n_out, gw, st);
     MVS_LAUNCH_CHECK();

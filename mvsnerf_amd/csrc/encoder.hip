@@ -1063,7 +1063,7 @@ extern "C" int mvsnerf_conv3d_wgrad(const float* g1, const float* g1_scale, cons
                                     int Do, int Ho, int Wo, int Di, int Hi, int Wi, int stride,
                                     float* gw, float* workspace, void* stream)
 {
-    if (!g1 || !x1 || !gw || !workspace || A < 8 || (A & 7) || B < 1 || ldx < B || (ldx & 3)) return MVSNERF_EINVAL;
+    if (!g1 || !x1 || !workspace || A < 8 || (A & 7) || B < 1 || ldx < B || (ldx & 3)) return MVSNERF_EINVAL;
     if (stride != 1 && stride != 2) return MVSNERF_EUNSUPPORTED;
     if (!mvs_aligned16(g1) || !mvs_aligned16(x1) || (g2 && !mvs_aligned16(g2)) || (x2 && !mvs_aligned16(x2))) return MVSNERF_EALIGN;
     const int nb4 = (B + 3) / 4, npr = nb4 * 9;
@@ -1078,9 +1078,56 @@ extern "C" int mvsnerf_conv3d_wgrad(const float* g1, const float* g1_scale, cons
     if (stride == 1) conv3d_wgrad_rows_kernel<1><<<grid, 256, 0, st>>>(G1, G2, A, X1, X2, B, ldx, Do, Ho, Wo, Di, Hi, Wi, nb4, R, workspace);
     else             conv3d_wgrad_rows_kernel<2><<<grid, 256, 0, st>>>(G1, G2, A, X1, X2, B, ldx, Do, Ho, Wo, Di, Hi, Wi, nb4, R, workspace);
     MVS_LAUNCH_CHECK();
+    if (!gw) return MVSNERF_OK;                            // partials left in `workspace` for mvsnerf_partial_sum_multi
     const int64_t n_out = (int64_t)A * B * 27;
     mvs_partial_sum(workspace, nwg * R, n_out, workspace + (size_t)wgrad3d_part_cap(A, B) * n_out, gw, st);
     MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// number of partial results mvsnerf_conv3d_wgrad leaves at the start of its workspace (rows of A*B*27 floats)
+extern "C" int mvsnerf_conv3d_wgrad_parts(int A, int B, int Do, int Ho)
+{
+    if (A < 8 || B < 1) return 0;
+    const int npr = ((B + 3) / 4) * 9;
+    if (npr > 256) return 0;
+    const int R = 256 / npr, ngroups = (Do * Ho + R - 1) / R, cap = wgrad3d_part_cap(A, B) / R;
+    return (ngroups < cap ? ngroups : cap) * R;
+}
+
+// dst_j[i] = sum_p partial_j[p][i] for n_jobs independent reductions in two launches (host arrays, copied into the kernel arguments).
+// scratch: mvsnerf_partial_sum_multi_scratch_floats(sum of n_out) floats.
+extern "C" size_t mvsnerf_partial_sum_multi_scratch_floats(int64_t total_n_out) { return (size_t)MVS_RED_SLICES * (size_t)total_n_out; }
+
+extern "C" int mvsnerf_partial_sum_multi(int n_jobs, const float* const* partial, const int* n_part, const int64_t* n_out, float* const* dst,
+                                         float* scratch, void* stream)
+{
+    if (n_jobs < 1 || n_jobs > MVS_PSUM_JOBS || !partial || !n_part || !n_out || !dst || !scratch) return MVSNERF_EINVAL;
+    PsumJobs J;
+    J.n = n_jobs;
+    int b1 = 0, b2 = 0;
+    size_t off = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        if (!partial[j] || !dst[j] || n_part[j] < 1 || n_out[j] < 1) return MVSNERF_EINVAL;
+        const int gx = (int)((n_out[j] + 255) / 256);
+        const int chunk = n_part[j] <= MVS_RED_SLICES ? n_part[j] : (n_part[j] + MVS_RED_SLICES - 1) / MVS_RED_SLICES;
+        const int slices = (n_part[j] + chunk - 1) / chunk;
+        J.partial[j] = partial[j]; J.dst[j] = dst[j]; J.scratch[j] = scratch + off; J.n_out[j] = n_out[j];
+        J.n_part[j] = n_part[j]; J.chunk[j] = chunk; J.slices[j] = slices;
+        J.blk1[j] = b1; J.blk2[j] = b2;
+        b1 += gx * slices;
+        b2 += slices > 1 ? gx : 0;
+        off += (size_t)slices * (size_t)n_out[j];
+    }
+    J.blk1[n_jobs] = b1; J.blk2[n_jobs] = b2;
+    hipStream_t st = (hipStream_t)stream;
+    mvs_partial_sum_multi_kernel<1><<<b1, 256, 0, st>>>(J);
+    MVS_LAUNCH_CHECK();
+    if (b2 > 0) {
+        // stage 2 walks only the jobs that have slices: give the others an empty block range
+        mvs_partial_sum_multi_kernel<2><<<b2, 256, 0, st>>>(J);
+        MVS_LAUNCH_CHECK();
+    }
     return MVSNERF_OK;
 }
 
@@ -1090,10 +1137,16 @@ extern "C" int mvsnerf_conv3d_wgrad(const float* g1, const float* g1_scale, cons
 int mvs_conv3d_c8_wgrad4(const float* x4, int Cin, int cin_real, int D, int H, int W, const float* g, float* gw, float* workspace, int cap_parts,
                          hipStream_t st);
 
+int mvs_conv3d_c8_wgrad4_parts(int Cin, int D, int H, int W, int cap_parts);
+extern "C" int mvsnerf_conv3d_c8_blocked_wgrad_parts(int Cin, int Cin_real, int D, int H, int W)
+{
+    return mvs_conv3d_c8_wgrad4_parts(Cin, D, H, W, wgrad3d_part_cap(8, Cin_real));
+}
+
 extern "C" int mvsnerf_conv3d_c8_blocked_wgrad(const float* x_blocked, int Cin, int Cin_real, int D, int H, int W, const float* g, float* gw,
                                                float* workspace, void* stream)
 {
-    if (!x_blocked || !g || !gw || !workspace || D < 1 || H < 1 || W < 1 || Cin < 4 || (Cin & 3) || Cin_real < 1 || Cin_real > Cin || Cin_real <= Cin - 4)
+    if (!x_blocked || !g || !workspace || D < 1 || H < 1 || W < 1 || Cin < 4 || (Cin & 3) || Cin_real < 1 || Cin_real > Cin || Cin_real <= Cin - 4)
         return MVSNERF_EINVAL;
     if (!mvs_aligned16(x_blocked) || !mvs_aligned16(g)) return MVSNERF_EALIGN;
     if ((int64_t)D * H * W * 8 >= (int64_t)1 << 31) return MVSNERF_EUNSUPPORTED;

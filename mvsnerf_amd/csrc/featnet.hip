@@ -258,7 +258,7 @@ extern "C" int mvsnerf_conv2d_wgrad(const float* g, int A, const float* x, const
                                     int N, int Ho, int Wo, int Hi, int Wi, int ksize, int stride,
                                     float* gw, float* workspace, void* stream)
 {
-    if (!g || !x || !gw || !workspace || A < 8 || (A & 7) || B < 1 || ldx < B || N < 1) return MVSNERF_EINVAL;
+    if (!g || !x || !workspace || A < 8 || (A & 7) || B < 1 || ldx < B || N < 1) return MVSNERF_EINVAL;
     if (((x_scale == nullptr) != (x_shift == nullptr))) return MVSNERF_EINVAL;
     const ActSrc X1{x, x_scale, x_shift};
     const int64_t npix = (int64_t)N * Ho * Wo;
@@ -280,10 +280,18 @@ extern "C" int mvsnerf_conv2d_wgrad(const float* g, int A, const float* x, const
     }
 #undef MVS_WG2
     MVS_LAUNCH_CHECK();
+    if (!gw) return MVSNERF_OK;                            // partials left in `workspace` for mvsnerf_partial_sum_multi
     const int64_t n_out = (int64_t)A * B * ksize * ksize;
     mvs_partial_sum(workspace, nwg, n_out, workspace + (size_t)(4096 / (A / 8)) * n_out, gw, st);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
+}
+
+// number of partial results mvsnerf_conv2d_wgrad leaves at the start of its workspace (rows of A*B*k*k floats)
+extern "C" int mvsnerf_conv2d_wgrad_parts(int A, int N, int Ho, int Wo)
+{
+    if (A < 8) return 0;
+    return wgrad2d_nwg((int64_t)N * Ho * Wo, A);
 }
 
 // per-channel sum over n rows of a dense [n][C] tensor (C <= 64, 256 % C == 0): the bias gradient of `toplayer`

@@ -188,13 +188,40 @@ def dev_f32_tensor(t):
     return t
 
 
-def _wgrad2d(gx, A, X, B, ldx, g_dims, x_dims, ksize, stride, shape):
-    """gW[a][b][tap] = sum_o G[o][a] X[o*stride - k//2 + tap][b]  (mvsnerf_conv2d_wgrad)."""
+class _PartialSums:
+    """The per-workgroup partial results of the weight-gradient kernels of one backward pass, reduced together at its end
+    (mvsnerf_partial_sum_multi: two launches for all of them instead of two per layer)."""
+
+    def __init__(self):
+        self.jobs = []
+
+    def add(self, ws, n_part, gw):
+        self.jobs.append((ws, int(n_part), gw))
+
+    def flush(self):
+        import ctypes
+        lib = _lib.lib()
+        for i in range(0, len(self.jobs), 32):
+            jobs = self.jobs[i:i + 32]
+            n = len(jobs)
+            n_out = [gw.numel() for _, _, gw in jobs]
+            scratch = torch.empty(lib.mvsnerf_partial_sum_multi_scratch_floats(sum(n_out)), device=jobs[0][2].device, dtype=torch.float32)
+            check(lib.mvsnerf_partial_sum_multi(n, (ctypes.c_void_p * n)(*[ws.data_ptr() for ws, _, _ in jobs]),
+                                                (ctypes.c_int * n)(*[p for _, p, _ in jobs]), (ctypes.c_int64 * n)(*n_out),
+                                                (ctypes.c_void_p * n)(*[gw.data_ptr() for _, _, gw in jobs]), scratch.data_ptr(), stream_ptr()),
+                  "partial_sum_multi")
+        self.jobs = []
+
+
+def _wgrad2d(gx, A, X, B, ldx, g_dims, x_dims, ksize, stride, shape, sums=None):
+    """gW[a][b][tap] = sum_o G[o][a] X[o*stride - k//2 + tap][b]  (mvsnerf_conv2d_wgrad).  sums: a _PartialSums that finishes gw later."""
     lib = _lib.lib()
     gw = torch.empty(shape, device=gx.device, dtype=torch.float32)
     ws = torch.empty(lib.mvsnerf_conv2d_wgrad_workspace_floats(A, B, ksize), device=gx.device, dtype=torch.float32)
     check(lib.mvsnerf_conv2d_wgrad(gx.data_ptr(), A, *_ptrs(X), B, ldx, g_dims[0], g_dims[1], g_dims[2], x_dims[1], x_dims[2], ksize, stride,
-                                   gw.data_ptr(), ws.data_ptr(), stream_ptr()), "conv2d_wgrad")
+                                   0 if sums is not None else gw.data_ptr(), ws.data_ptr(), stream_ptr()), "conv2d_wgrad")
+    if sums is not None:
+        sums.add(ws, lib.mvsnerf_conv2d_wgrad_parts(A, g_dims[0], g_dims[1], g_dims[2]), gw)
     return gw
 
 
@@ -220,7 +247,8 @@ class _FeatureNetFunction(torch.autograd.Function):
         gb = torch.empty(32, device=g.device, dtype=torch.float32)
         ws = torch.empty(lib.mvsnerf_channel_sum_workspace_floats(32), device=g.device, dtype=torch.float32)
         check(lib.mvsnerf_channel_sum(g.data_ptr(), N * h * w, 32, gb.data_ptr(), ws.data_ptr(), stream_ptr()), "channel_sum")
-        gw_top = _wgrad2d(g, 32, last, 32, 32, (N, h, w), last.dims, 1, 1, tuple(net.toplayer.weight.shape))
+        sums = _PartialSums()
+        gw_top = _wgrad2d(g, 32, last, 32, 32, (N, h, w), last.dims, 1, 1, tuple(net.toplayer.weight.shape), sums)
         g_act = _conv2d(g, (N, h, w, 32), 32, net._top_packed.get("dgrad"), 32, 32, 1, 1)
         grads = [None] * len(L)
         for i in range(len(L) - 1, -1, -1):
@@ -231,7 +259,7 @@ class _FeatureNetFunction(torch.autograd.Function):
                 xin, x_dims, x_ld = lz[i - 1], lz[i - 1].dims, lz[i - 1].dims[3]
             else:
                 xin, x_dims, x_ld = ctx.img, tuple(ctx.img.shape), ctx.ld
-            gw = _wgrad2d(gx, pk.cout, xin, pk.cin, x_ld, out_lz.dims[:3], x_dims, lay.k, lay.stride, tuple(lay.conv.weight.shape))
+            gw = _wgrad2d(gx, pk.cout, xin, pk.cin, x_ld, out_lz.dims[:3], x_dims, lay.k, lay.stride, tuple(lay.conv.weight.shape), sums)
             grads[i] = (gw, gbw, gbb)
             if i == 0:
                 break
@@ -243,6 +271,7 @@ class _FeatureNetFunction(torch.autograd.Function):
                 g_act = torch.empty((Nn, Hi, Wi, pk.cin), device=g.device, dtype=torch.float32)
                 check(lib.mvsnerf_conv2d_dgrad_k5s2(gx.data_ptr(), pk.cout, Nn, Ho, Wo, pk.get("dgrad").data_ptr(), pk.cin, Hi, Wi,
                                                     g_act.data_ptr(), stream_ptr()), "conv2d_dgrad_k5s2")
+        sums.flush()
         out = [None, None]
         for gw, gbw, gbb in grads:
             out += [gw, gbw, gbb]
@@ -591,18 +620,21 @@ def _abn_bwd(lz, bn, g1, g2=None):
     return gx, gwb[0], gwb[1]
 
 
-def _wgrad(G1, G2, A, X1, X2, B, ldx, g_dims, x_dims, stride, shape):
-    """gW[a][b][tap] = sum_o G[o][a] X[o*stride-1+tap][b]  (see mvsnerf_conv3d_wgrad)."""
+def _wgrad(G1, G2, A, X1, X2, B, ldx, g_dims, x_dims, stride, shape, sums=None):
+    """gW[a][b][tap] = sum_o G[o][a] X[o*stride-1+tap][b]  (see mvsnerf_conv3d_wgrad).  sums: a _PartialSums that finishes gw later."""
     lib = _lib.lib()
     dev = (G1.x if isinstance(G1, _Lazy) else G1).device
     gw = torch.empty(shape, device=dev, dtype=torch.float32)
     ws = torch.empty(lib.mvsnerf_conv3d_wgrad_workspace_floats(A, B), device=dev, dtype=torch.float32)
     check(lib.mvsnerf_conv3d_wgrad(*_ptrs(G1), *_ptrs(G2), A, *_ptrs(X1), *_ptrs(X2), B, ldx, g_dims[0], g_dims[1], g_dims[2],
-                                   x_dims[0], x_dims[1], x_dims[2], stride, gw.data_ptr(), ws.data_ptr(), stream_ptr()), "conv3d_wgrad")
+                                   x_dims[0], x_dims[1], x_dims[2], stride, 0 if sums is not None else gw.data_ptr(), ws.data_ptr(), stream_ptr()),
+          "conv3d_wgrad")
+    if sums is not None:
+        sums.add(ws, lib.mvsnerf_conv3d_wgrad_parts(A, B, g_dims[0], g_dims[1]), gw)
     return gw
 
 
-def _costreg_backward(net, lz, g_out, conv0_grads):
+def _costreg_backward(net, lz, g_out, conv0_grads, sums=None):
     """Backward of CostRegNet._run + the output sum.  g_out: gradient of the (1,8,D,h,w) result.  conv0_grads(gx) -> (gw, g_input):
     conv0's weight gradient and whatever the caller needs upstream of it, from the gradient gx of conv0's raw output.
     Returns (g_input, [gw, g bn.weight, g bn.bias] x 10 in _layers() order)."""
@@ -615,7 +647,7 @@ def _costreg_backward(net, lz, g_out, conv0_grads):
         """ConvTranspose3d+ABN `lay` (output out_lz, input A(in1)+A(in2)): returns grad w.r.t. its activated input."""
         gx, gbw, gbb = _abn_bwd(out_lz, lay[1], g_act1, g_act2)
         pk = lay._packed
-        gw = _wgrad(in1, in2, pk.cin, gx, None, pk.cout, pk.cout, in1.dims[:3], out_lz.dims[:3], 2, tuple(lay[0].weight.shape))
+        gw = _wgrad(in1, in2, pk.cin, gx, None, pk.cout, pk.cout, in1.dims[:3], out_lz.dims[:3], 2, tuple(lay[0].weight.shape), sums)
         g_in = _conv(gx, None, out_lz.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin, 2, packed=pk, mode="dgrad")       # data grad = stride-2 conv
         grads[i] = (gw, gbw, gbb)
         return g_in
@@ -623,7 +655,7 @@ def _costreg_backward(net, lz, g_out, conv0_grads):
     def conv_block(i, lay, out_lz, in1, in_dims, in_ld, g_act1, g_act2=None):
         gx, gbw, gbb = _abn_bwd(out_lz, lay.bn, g_act1, g_act2)
         pk = lay._packed
-        gw = _wgrad(gx, None, pk.cout, in1, None, pk.cin, in_ld, out_lz.dims[:3], in_dims[:3], lay.stride, tuple(lay.conv.weight.shape))
+        gw = _wgrad(gx, None, pk.cout, in1, None, pk.cin, in_ld, out_lz.dims[:3], in_dims[:3], lay.stride, tuple(lay.conv.weight.shape), sums)
         grads[i] = (gw, gbw, gbb)
         if lay.stride == 1:
             return _conv(gx, None, out_lz.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin_pad, 1, packed=pk, mode="dgrad")
@@ -641,6 +673,8 @@ def _costreg_backward(net, lz, g_out, conv0_grads):
     gx0, gbw0, gbb0 = _abn_bwd(c0, L[0].bn, g, g_c0)                   # A(c0) feeds conv1 and the output sum
     gw0, g_in = conv0_grads(gx0)
     grads[0] = (gw0, gbw0, gbb0)
+    if sums is not None:
+        sums.flush()
     flat = []
     for i in range(10):
         flat += list(grads[i])
@@ -671,13 +705,15 @@ class _CostRegFunction(torch.autograd.Function):
         pk = lay._packed
         D, H, W = c0.dims[:3]
 
+        sums = _PartialSums()
+
         def conv0_grads(gx):
-            gw = _wgrad(gx, None, pk.cout, buf, None, pk.cin, ld, (D, H, W), (D, H, W), 1, tuple(lay.conv.weight.shape))
+            gw = _wgrad(gx, None, pk.cout, buf, None, pk.cin, ld, (D, H, W), (D, H, W), 1, tuple(lay.conv.weight.shape), sums)
             if not ctx.needs_input_grad[0]:
                 return gw, None
             return gw, _conv(gx, None, c0.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin_pad, 1, packed=pk, mode="dgrad")
 
-        g_cost, flat = _costreg_backward(net, lz, g_out, conv0_grads)
+        g_cost, flat = _costreg_backward(net, lz, g_out, conv0_grads, sums)
         return (None if g_cost is None else _cl_view_to_ncdhw(g_cost, ctx.xshape[1]), None, *flat)
 
 
@@ -794,16 +830,19 @@ class _SweepRegFunction(torch.autograd.Function):
         Dv, Hv, Wv = cost.dims
         lib = _lib.lib()
 
+        sums = _PartialSums()
+
         def conv0_grads(gx):
             gw = torch.empty(tuple(lay.conv.weight.shape), device=gx.device, dtype=torch.float32)
             ws = torch.empty(lib.mvsnerf_conv3d_wgrad_workspace_floats(8, pk.cin), device=gx.device, dtype=torch.float32)
-            check(lib.mvsnerf_conv3d_c8_blocked_wgrad(cost.buf.data_ptr(), pk.cin_pad, pk.cin, Dv, Hv, Wv, gx.data_ptr(), gw.data_ptr(),
+            check(lib.mvsnerf_conv3d_c8_blocked_wgrad(cost.buf.data_ptr(), pk.cin_pad, pk.cin, Dv, Hv, Wv, gx.data_ptr(), 0,
                                                       ws.data_ptr(), stream_ptr()), "conv3d_c8_blocked_wgrad")
+            sums.add(ws, lib.mvsnerf_conv3d_c8_blocked_wgrad_parts(pk.cin_pad, pk.cin, Dv, Hv, Wv), gw)
             if not ctx.needs_input_grad[0]:
                 return gw, None
             return gw, _conv(gx, None, c0.dims, pk.cout, pk.get_dgrad_slice(3 * V, C), pk.cout, C, 1)     # d cost[variance channels]
 
-        g_var, flat = _costreg_backward(net, lz, g_out, conv0_grads)
+        g_var, flat = _costreg_backward(net, lz, g_out, conv0_grads, sums)
         g_feats = None
         if g_var is not None:
             g_feats_cl = torch.zeros((V, H, W, C), device=feats_cl.device, dtype=torch.float32)

@@ -25,7 +25,7 @@ def test_library_builds_and_exports_header_symbols():
     missing = [n for n in names if not hasattr(l, n)]
     assert not missing, f"declared in the header but not exported: {missing}"
     assert sorted(_lib.SIGNATURES) == names, (set(names) ^ set(_lib.SIGNATURES))
-    assert _lib.lib().mvsnerf_abi_version() == 6
+    assert _lib.lib().mvsnerf_abi_version() == 7
     # pure host-side queries work without a GPU
     # 32-point layout (12 feature k-steps x 4 blocks x 64 lanes, ...) followed by the 16-point layout of the same weights
     n32 = 12 * 256 + 8192 * 2 + 16384 * 6 + 68 * 128 + 1416
