@@ -90,11 +90,19 @@ static __global__ __launch_bounds__(256) void mvs_partial_sum_multi_kernel(PsumJ
     const int n_src = STAGE == 1 ? J.n_part[j] : J.slices[j];
     const int chunk = STAGE == 1 ? J.chunk[j] : n_src;
     const int p0 = slice * chunk, p1 = p0 + chunk < n_src ? p0 + chunk : n_src;
-    float s0 = 0.f, s1 = 0.f;
+    // eight independent running sums: the loads of one round are in flight together (a chunk is up to 128 rows, each a latency-bound
+    // strided read); the order of the additions is fixed
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int p = p0;
-    for (; p + 1 < p1; p += 2) { s0 += src[(long long)p * n_out + i]; s1 += src[(long long)(p + 1) * n_out + i]; }
-    if (p < p1) s0 += src[(long long)p * n_out + i];
+    for (; p + 7 < p1; p += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[(long long)(p + k) * n_out + i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += v[k];
+    }
+    for (int k = 0; p < p1; ++p, ++k) s[k] += src[(long long)p * n_out + i];
     float* out = (STAGE == 1 && J.slices[j] > 1) ? J.scratch[j] + (long long)slice * n_out : J.dst[j];
-    out[i] = s0 + s1;
+    out[i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
