@@ -165,7 +165,7 @@ int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float* proj, con
  * (workspace, *_wgrad_parts(...) rows, A*B*taps floats per row, gw) of all layers of a backward pass and finishes them together with
  * ONE call of partial_sum_multi (<= 32 jobs; host arrays; two launches in total; a training step has ~30 weight gradients).
  * scratch: mvsnerf_partial_sum_multi_scratch_floats(sum of the jobs' n_out) floats.  Same fixed summation order either way. */
-int mvsnerf_conv3d_wgrad_parts(int A, int B, int Do, int Ho);
+int mvsnerf_conv3d_wgrad_parts(int A, int B, int Do, int Ho, int Wo, int stride, int two_x_sources);
 int mvsnerf_conv3d_c8_blocked_wgrad_parts(int Cin, int Cin_real, int D, int H, int W);
 int mvsnerf_conv2d_wgrad_parts(int A, int N, int Ho, int Wo);
 size_t mvsnerf_partial_sum_multi_scratch_floats(int64_t total_n_out);

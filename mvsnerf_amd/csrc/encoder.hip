@@ -1047,6 +1047,10 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_rows_kernel(ActSrc g1, ActSr
     }
 }
 
+int mvs_conv3d_wgrad_mfma4_parts(int A, int B, int Do, int Ho, int Wo, int stride, int cap_parts);
+int mvs_conv3d_wgrad_mfma4(const ActSrc& g1, const ActSrc& g2, int A, const ActSrc& x1, const ActSrc& x2, int B, int ldx, int Do, int Ho, int Wo,
+                           int Di, int Hi, int Wi, int stride, float* partial, int cap_parts, hipStream_t st);
+
 // number of partial results the workspace is sized for
 static int wgrad3d_part_cap(int A, int B)
 {
@@ -1069,6 +1073,18 @@ extern "C" int mvsnerf_conv3d_wgrad(const float* g1, const float* g1_scale, cons
     const int nb4 = (B + 3) / 4, npr = nb4 * 9;
     if (npr > 256 || (nb4 * 4 > ldx)) return MVSNERF_EUNSUPPORTED;
     const ActSrc G1{g1, g1_scale, g1_shift}, G2{g2, g2_scale, g2_shift}, X1{x1, x1_scale, x1_shift}, X2{x2, x2_scale, x2_shift};
+    if (g_conv_mfma && !x2) {                              // 16 / 32 / 64 `a` channels: matrix cores (wgrad_mfma.hip)
+        const int cap = wgrad3d_part_cap(A, B);
+        const int rc = mvs_conv3d_wgrad_mfma4(G1, G2, A, X1, X2, B, ldx, Do, Ho, Wo, Di, Hi, Wi, stride, workspace, cap, (hipStream_t)stream);
+        if (rc != MVSNERF_EUNSUPPORTED) {
+            if (rc != MVSNERF_OK || !gw) return rc;
+            const int64_t n_out = (int64_t)A * B * 27;
+            mvs_partial_sum(workspace, mvs_conv3d_wgrad_mfma4_parts(A, B, Do, Ho, Wo, stride, cap), n_out, workspace + (size_t)cap * n_out, gw,
+                            (hipStream_t)stream);
+            MVS_LAUNCH_CHECK();
+            return MVSNERF_OK;
+        }
+    }
     const int R = 256 / npr;
     const int nrows = Do * Ho, ngroups = (nrows + R - 1) / R;
     const int cap = wgrad3d_part_cap(A, B) / R;
@@ -1086,9 +1102,13 @@ extern "C" int mvsnerf_conv3d_wgrad(const float* g1, const float* g1_scale, cons
 }
 
 // number of partial results mvsnerf_conv3d_wgrad leaves at the start of its workspace (rows of A*B*27 floats)
-extern "C" int mvsnerf_conv3d_wgrad_parts(int A, int B, int Do, int Ho)
+extern "C" int mvsnerf_conv3d_wgrad_parts(int A, int B, int Do, int Ho, int Wo, int stride, int two_x_sources)
 {
     if (A < 8 || B < 1) return 0;
+    if (g_conv_mfma && !two_x_sources) {
+        const int n = mvs_conv3d_wgrad_mfma4_parts(A, B, Do, Ho, Wo, stride, wgrad3d_part_cap(A, B));
+        if (n > 0) return n;
+    }
     const int npr = ((B + 3) / 4) * 9;
     if (npr > 256) return 0;
     const int R = 256 / npr, ngroups = (Do * Ho + R - 1) / R, cap = wgrad3d_part_cap(A, B) / R;

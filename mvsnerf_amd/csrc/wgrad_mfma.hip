@@ -1,0 +1,170 @@
+// Weight gradients of CostRegNet's 3x3x3 convolutions with 16 / 32 / 64 "a" channels on v_mfma_f32_4x4x1_16B_f32 (fp32 in, fp32
+// accumulate, exact fp32 products):
+//   gW[a][b][tap] = sum_o G[o][a] * X[o * S - 1 + tap][b]          (mvsnerf_conv3d_wgrad; S = 1 | 2)
+// The output voxels o are the k dimension.  The 16 blocks of one instruction are (voxel slot mb) x (quad of `a` channels nb): 64 / A
+// voxels x A channels, so the B operand is 64 contiguous floats of the channel-last G tile and nothing is padded for any A in
+// {16, 32, 64}; the A operand is X[.][4 cg .. 4 cg + 3] of the same voxels shifted by the tap (broadcast over nb).  D[r][j] of block
+// (mb, nb) is the partial gW[a = 4 nb + j][b = 4 cg + r][tap] of voxel slot mb: 27 accumulators (108 registers) hold every tap of one
+// block of four `b` channels.  A wave owns one such block; a workgroup (NW waves) shares the staged tiles; grid.y covers B / (4 NW).
+// Marching along y the taps slide over the same X rows: a step reads one G operand and one (S = 1) or two (S = 2) new X rows of
+// 3 x 3 operands for 27 MFMAs.  Accumulators stay in registers across all tiles a workgroup visits; one partial result per
+// workgroup (deterministic; summed by mvs_partial_sum / mvsnerf_partial_sum_multi).
+// The VALU kernel this replaces (conv3d_wgrad_rows_kernel) ran the six half- and quarter-resolution layers at 13 - 25 TFLOP/s and
+// wrote one partial result per 1 - 14 output rows (up to 150 MB per layer).
+#include "common.h"
+#include "act.h"
+
+namespace {
+
+constexpr int WTX = 8, WTY = 8;                                       // output-voxel tile (x, y); z extent is a template parameter
+
+template <int A, int NW, int S, int TOZ>
+__global__ __launch_bounds__(NW * 64) void conv3d_wgrad_mfma4_kernel(ActSrc g1, ActSrc g2, ActSrc x1, int ldx, int B,
+                                                                    int Do, int Ho, int Wo, int Di, int Hi, int Wi, float* __restrict__ partial)
+{
+    constexpr int VM = 64 / A;                                        // voxels per MFMA
+    constexpr int NXG = WTX / VM;                                     // x groups per tile row
+    constexpr int HX = (WTX - 1) * S + 3, HY = (WTY - 1) * S + 3, HZ = (TOZ - 1) * S + 3;
+    constexpr int NVH = HX * HY * HZ, NVO = WTX * WTY * TOZ;
+    constexpr int NT = NW * 64;
+    __shared__ __attribute__((aligned(16))) float gt[NVO * A];         // [o voxel][A]
+    __shared__ __attribute__((aligned(16))) float xt[NW * NVH * 4];    // [cg local][halo voxel][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg0 = blockIdx.y * NW;
+    const int nbx = (Wo + WTX - 1) / WTX, nby = (Ho + WTY - 1) / WTY, nbz = (Do + TOZ - 1) / TOZ;
+    const int ntiles = nbx * nby * nbz;
+    f32x4 acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = f32x4{0, 0, 0, 0};
+    const float* gl = gt + lane;                                      // B operand: 64 contiguous floats per voxel group
+    const float* xl = xt + (wave * NVH + (lane / A) * S) * 4 + (lane & 3);      // A operand: voxel slot mb = lane / A, channel i = lane & 3
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int bx = tile % nbx, by = (tile / nbx) % nby, bz = tile / (nbx * nby);
+        const int ox0 = bx * WTX, oy0 = by * WTY, oz0 = bz * TOZ;
+        __syncthreads();                                              // everybody finished reading the previous tile
+        // ---- stage G (activation / skip sum applied here) and the X halo (activation applied here)
+        for (int it = tid; it < NVO * (A / 4); it += NT) {
+            const int v = it / (A / 4), c4 = (it - v * (A / 4)) * 4;
+            const int ox = ox0 + v % WTX, oy = oy0 + (v / WTX) % WTY, oz = oz0 + v / (WTX * WTY);
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (ox < Wo && oy < Ho && oz < Do) load_act4<A>(g1, g2, ((int64_t)oz * Ho + oy) * Wo + ox, A, c4, val);
+            *reinterpret_cast<f32x4*>(gt + v * A + c4) = val;
+        }
+        for (int it = tid; it < NW * NVH; it += NT) {
+            const int cgl = it / NVH, hv = it - cgl * NVH;
+            const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+            const int ix = ox0 * S - 1 + hx, iy = oy0 * S - 1 + hy, iz = oz0 * S - 1 + hz;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            const int cb = (cg0 + cgl) * 4;
+            if (cb < B && ix >= 0 && ix < Wi && iy >= 0 && iy < Hi && iz >= 0 && iz < Di) {
+                val = *reinterpret_cast<const f32x4*>(x1.x + (((int64_t)iz * Hi + iy) * Wi + ix) * ldx + cb);
+                if (x1.scale) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) val[k] = act_apply(val[k], x1.scale[cb + k], x1.shift[cb + k]);
+                }
+            }
+            *reinterpret_cast<f32x4*>(xt + (cgl * NVH + hv) * 4) = val;
+        }
+        __syncthreads();
+        if ((cg0 + wave) * 4 >= B) continue;
+        // ---- multiply: columns (oz, x group), marching along oy
+#pragma unroll 1
+        for (int q = 0; q < TOZ * NXG; ++q) {
+            const int oz = q / NXG, xg = q - oz * NXG;
+            const float* gb = gl + (oz * WTY * WTX + xg * VM) * A;
+            const float* xb = xl + ((oz * S * HY) * HX + xg * VM * S) * 4;
+            float win[4][3][3];                                       // [halo row % 4][dz][dx]
+            auto load_row = [&](int hy) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) win[hy % 4][a][c] = xb[((a * HY + hy) * HX + c) * 4];
+            };
+            load_row(0);
+            if (S == 1) load_row(1);
+#pragma unroll
+            for (int oy = 0; oy < WTY; ++oy) {
+                // rows S oy .. S oy + 2: the first (S = 2) / the first two (S = 1) are here already
+                if (S == 1) load_row(oy + 2); else { load_row(2 * oy + 1); load_row(2 * oy + 2); }
+                const float gcur = gb[oy * WTX * A];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            acc[(a * 3 + b) * 3 + c] = __builtin_amdgcn_mfma_f32_4x4x1f32(win[(S * oy + b) % 4][a][c], gcur, acc[(a * 3 + b) * 3 + c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if ((cg0 + wave) * 4 >= B) return;
+    // fold the voxel slots (lane bits above log2 A); lanes 0 .. A-1 then hold gW[a = lane][b = 4 cg + r][tap]
+    float* po = partial + ((int64_t)blockIdx.x * A + (lane % A)) * B * 27;
+    const int cb = (cg0 + wave) * 4;
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[t][r];
+            if (VM >= 2) v += __shfl_xor(v, 32);
+            if (VM >= 4) v += __shfl_xor(v, 16);
+            if (lane < A) po[(int64_t)(cb + r) * 27 + t] = v;
+        }
+}
+
+template <int A, int NW, int S, int TOZ>
+int launch(const ActSrc& g1, const ActSrc& g2, const ActSrc& x1, int ldx, int B, int Do, int Ho, int Wo, int Di, int Hi, int Wi, float* partial, int nx,
+           hipStream_t st)
+{
+    const dim3 grid(nx, (B / 4 + NW - 1) / NW);
+    conv3d_wgrad_mfma4_kernel<A, NW, S, TOZ><<<grid, NW * 64, 0, st>>>(g1, g2, x1, ldx, B, Do, Ho, Wo, Di, Hi, Wi, partial);
+    return MVSNERF_OK;
+}
+
+}  // namespace
+
+// number of partial results (= workgroups along x) the matrix-core weight gradient leaves for (A, B, stride) on an output grid
+// Do x Ho x Wo; 0 = this combination takes the VALU kernel
+int mvs_conv3d_wgrad_mfma4_parts(int A, int B, int Do, int Ho, int Wo, int stride, int cap_parts)
+{
+    const bool ok = (A == 16 && (B == 8 || B == 16)) || (A == 32 && (B == 16 || B == 32)) || (A == 64 && (B == 32 || B == 64));
+    if (!ok || (stride != 1 && stride != 2)) return 0;
+    const int toz = stride == 1 ? 2 : 1;
+    const int ntiles = ((Wo + WTX - 1) / WTX) * ((Ho + WTY - 1) / WTY) * ((Do + toz - 1) / toz);
+    const int nw = B == 8 ? 2 : 4, gy = (B / 4 + nw - 1) / nw;
+    int nx = 768 / gy;                                                // ~3 workgroups per CU
+    if (nx > ntiles) nx = ntiles;
+    if (nx > cap_parts) nx = cap_parts;
+    return nx;
+}
+
+int mvs_conv3d_wgrad_mfma4(const ActSrc& g1, const ActSrc& g2, int A, const ActSrc& x1, const ActSrc& x2, int B, int ldx, int Do, int Ho, int Wo,
+                           int Di, int Hi, int Wi, int stride, float* partial, int cap_parts, hipStream_t st)
+{
+    if (x2.x) return MVSNERF_EUNSUPPORTED;
+    const int nx = mvs_conv3d_wgrad_mfma4_parts(A, B, Do, Ho, Wo, stride, cap_parts);
+    if (nx <= 0) return MVSNERF_EUNSUPPORTED;
+#define MVS_WM(A_, NW_, S_, TOZ_) launch<A_, NW_, S_, TOZ_>(g1, g2, x1, ldx, B, Do, Ho, Wo, Di, Hi, Wi, partial, nx, st)
+    const int key = (A * 100 + B) * 10 + stride;
+    switch (key) {
+        case (16 * 100 + 8) * 10 + 2:  MVS_WM(16, 2, 2, 1); break;     // conv1, conv11^T
+        case (16 * 100 + 8) * 10 + 1:  MVS_WM(16, 2, 1, 2); break;
+        case (16 * 100 + 16) * 10 + 1: MVS_WM(16, 4, 1, 2); break;     // conv2
+        case (16 * 100 + 16) * 10 + 2: MVS_WM(16, 4, 2, 1); break;
+        case (32 * 100 + 16) * 10 + 2: MVS_WM(32, 4, 2, 1); break;     // conv3, conv9^T
+        case (32 * 100 + 16) * 10 + 1: MVS_WM(32, 4, 1, 2); break;
+        case (32 * 100 + 32) * 10 + 1: MVS_WM(32, 4, 1, 2); break;     // conv4
+        case (32 * 100 + 32) * 10 + 2: MVS_WM(32, 4, 2, 1); break;
+        case (64 * 100 + 32) * 10 + 2: MVS_WM(64, 4, 2, 1); break;     // conv5, conv7^T
+        case (64 * 100 + 32) * 10 + 1: MVS_WM(64, 4, 1, 2); break;
+        case (64 * 100 + 64) * 10 + 1: MVS_WM(64, 4, 1, 2); break;     // conv6
+        case (64 * 100 + 64) * 10 + 2: MVS_WM(64, 4, 2, 1); break;
+        default: return MVSNERF_EUNSUPPORTED;
+    }
+#undef MVS_WM
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}

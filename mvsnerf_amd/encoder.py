@@ -630,7 +630,7 @@ def _wgrad(G1, G2, A, X1, X2, B, ldx, g_dims, x_dims, stride, shape, sums=None):
                                    x_dims[0], x_dims[1], x_dims[2], stride, 0 if sums is not None else gw.data_ptr(), ws.data_ptr(), stream_ptr()),
           "conv3d_wgrad")
     if sums is not None:
-        sums.add(ws, lib.mvsnerf_conv3d_wgrad_parts(A, B, g_dims[0], g_dims[1]), gw)
+        sums.add(ws, lib.mvsnerf_conv3d_wgrad_parts(A, B, g_dims[0], g_dims[1], g_dims[2], stride, int(X2 is not None)), gw)
     return gw
 
 

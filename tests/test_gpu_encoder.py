@@ -221,3 +221,51 @@ def test_conv0_blocked_wgrad_full_size_vs_rows_kernel():
     err = float((old - new).abs().max())
     print(f"[conv0 wgrad 128x176x208x{cin}] rows kernel {ms['rows']:.3f} ms, matrix cores {ms['mfma']:.3f} ms; max diff {err:.2e} (|gw| max {scale:.1f})")
     assert err < 1e-4 * scale
+
+
+@pytest.mark.parametrize("A,B,stride,dims,g2,xact", [
+    (16, 8, 2, (6, 10, 12), False, True),       # conv1 (odd tile counts)
+    (16, 8, 2, (64, 88, 104), True, False),     # conv11^T at the training size: G = act(c2) + act(u9)
+    (16, 16, 1, (64, 88, 104), False, True),    # conv2 at the training size
+    (32, 16, 2, (5, 9, 7), True, False),        # conv9^T
+    (32, 32, 1, (32, 44, 52), False, True),     # conv4 at the training size
+    (64, 32, 2, (4, 6, 5), False, True),        # conv5
+    (64, 64, 1, (16, 22, 26), False, True),     # conv6 at the training size
+])
+def test_conv3d_wgrad_matrix_cores_vs_rows_kernel(A, B, stride, dims, g2, xact):
+    """The matrix-core weight gradient of the 16/32/64-channel layers (wgrad_mfma.hip) against the VALU kernel it replaces, with the
+    lazily applied activations and the skip sum of the transposed layers; different summation orders."""
+    from mvsnerf_amd import _lib
+    from mvsnerf_amd.ops import stream_ptr
+    Do, Ho, Wo = dims
+    Di, Hi, Wi = (Do, Ho, Wo) if stride == 1 else (2 * Do, 2 * Ho, 2 * Wo)
+    gen = torch.Generator(DEV).manual_seed(A * 100 + B + stride)
+    r = lambda *s: torch.randn(s, device=DEV, generator=gen)
+    G1, X1 = r(Do, Ho, Wo, A), r(Di, Hi, Wi, B)
+    G2 = r(Do, Ho, Wo, A) if g2 else None
+    gs = [(r(A).abs() + 0.5, r(A)) for _ in range(2)] if g2 else None
+    xs = (r(B).abs() + 0.5, r(B)) if xact else None
+    L = _lib.lib()
+    ws = torch.empty(L.mvsnerf_conv3d_wgrad_workspace_floats(A, B), device=DEV)
+    p = lambda t: 0 if t is None else t.data_ptr()
+    out, ms = {}, {}
+    for mode in (0, 1):
+        assert L.mvsnerf_tune(b"conv_mfma", mode) == 0
+        try:
+            gw = torch.full((A, B, 3, 3, 3), float("nan"), device=DEV)
+            for rep in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = L.mvsnerf_conv3d_wgrad(p(G1), p(gs[0][0]) if g2 else 0, p(gs[0][1]) if g2 else 0, p(G2), p(gs[1][0]) if g2 else 0, p(gs[1][1]) if g2 else 0, A,
+                                            p(X1), p(xs[0]) if xact else 0, p(xs[1]) if xact else 0, 0, 0, 0, B, B, Do, Ho, Wo, Di, Hi, Wi, stride,
+                                            gw.data_ptr(), ws.data_ptr(), stream_ptr())
+                e1.record(); torch.cuda.synchronize()
+                assert rc == 0
+            out[mode], ms[mode] = gw, e0.elapsed_time(e1)
+        finally:
+            L.mvsnerf_tune(b"conv_mfma", 1)
+    scale, err = float(out[0].abs().max()), float((out[0] - out[1]).abs().max())
+    gf = Do * Ho * Wo * A * B * 54 / 1e9
+    print(f"[conv3d wgrad A={A} B={B} s{stride} {Do}x{Ho}x{Wo}] rows {ms[0]:.3f} ms, matrix cores {ms[1]:.3f} ms ({gf / ms[1]:.1f} TFLOP/s); "
+          f"max diff {err:.2e} (|gw| max {scale:.1f})")
+    assert torch.isfinite(out[1]).all() and err < 2e-5 * scale
