@@ -18,59 +18,90 @@ namespace {
 
 constexpr int WTX = 8, WTY = 8;                                       // output-voxel tile (x, y); z extent is a template parameter
 
-template <int A, int NW, int S, int TOZ>
-__global__ __launch_bounds__(NW * 64) void conv3d_wgrad_mfma4_kernel(ActSrc g1, ActSrc g2, ActSrc x1, int ldx, int B,
-                                                                    int Do, int Ho, int Wo, int Di, int Hi, int Wi, float* __restrict__ partial)
+template <int A, int NCG, int NQ, int S, int TOZ>      // NCG blocks of four b channels x NQ column shares = 4 waves
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_mfma4_kernel(ActSrc g1, ActSrc g2, ActSrc x1, int ldx, int B,
+                                                                int Do, int Ho, int Wo, int Di, int Hi, int Wi, float* __restrict__ partial)
 {
+    static_assert(NCG * NQ == 4, "four waves");
     constexpr int VM = 64 / A;                                        // voxels per MFMA
     constexpr int NXG = WTX / VM;                                     // x groups per tile row
     constexpr int HX = (WTX - 1) * S + 3, HY = (WTY - 1) * S + 3, HZ = (TOZ - 1) * S + 3;
     constexpr int NVH = HX * HY * HZ, NVO = WTX * WTY * TOZ;
-    constexpr int NT = NW * 64;
+    constexpr int NT = 256;
+    constexpr int XIT = (NCG * NVH + NT - 1) / NT, GIT = (NVO * (A / 4) + NT - 1) / NT;      // staging slots per thread
+    constexpr int XB = A == 16 ? 8 : 4;                               // X loads in flight together (register budget: 108 accumulators + 36 window)
+    constexpr int NCOL = TOZ * NXG, CPQ = (NCOL + NQ - 1) / NQ;       // (oz, x group) columns; per column share
     __shared__ __attribute__((aligned(16))) float gt[NVO * A];         // [o voxel][A]
-    __shared__ __attribute__((aligned(16))) float xt[NW * NVH * 4];    // [cg local][halo voxel][4]
+    __shared__ __attribute__((aligned(16))) float xt[NCG * NVH * 4];   // [cg local][halo voxel][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cg0 = blockIdx.y * NW;
+    const int cgl = wave % NCG, qpart = wave / NCG;
+    const int cg0 = blockIdx.y * NCG;
     const int nbx = (Wo + WTX - 1) / WTX, nby = (Ho + WTY - 1) / WTY, nbz = (Do + TOZ - 1) / TOZ;
     const int ntiles = nbx * nby * nbz;
+    // tile-invariant staging slots of this thread.  X: item = tid + 256 j -> (cg local, halo voxel) packed hx | hy << 8 | hz << 16 | cgl << 24
+    int xpk[XIT];
+#pragma unroll
+    for (int j = 0; j < XIT; ++j) {
+        const int it = tid + NT * j, c = it / NVH, hv = it - c * NVH;
+        xpk[j] = (it < NCG * NVH && (cg0 + c) * 4 < B) ? ((hv % HX) | (((hv / HX) % HY) << 8) | ((hv / (HX * HY)) << 16) | (c << 24)) : -1;
+    }
     f32x4 acc[27];
 #pragma unroll
     for (int t = 0; t < 27; ++t) acc[t] = f32x4{0, 0, 0, 0};
     const float* gl = gt + lane;                                      // B operand: 64 contiguous floats per voxel group
-    const float* xl = xt + (wave * NVH + (lane / A) * S) * 4 + (lane & 3);      // A operand: voxel slot mb = lane / A, channel i = lane & 3
+    const float* xl = xt + (cgl * NVH + (lane / A) * S) * 4 + (lane & 3);       // A operand: voxel slot mb = lane / A, channel i = lane & 3
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int bx = tile % nbx, by = (tile / nbx) % nby, bz = tile / (nbx * nby);
         const int ox0 = bx * WTX, oy0 = by * WTY, oz0 = bz * TOZ;
+        const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1, iz0 = oz0 * S - 1;
+        const bool interior = ix0 >= 0 && ix0 + HX <= Wi && iy0 >= 0 && iy0 + HY <= Hi && iz0 >= 0 && iz0 + HZ <= Di;      // wave-uniform
         __syncthreads();                                              // everybody finished reading the previous tile
-        // ---- stage G (activation / skip sum applied here) and the X halo (activation applied here)
-        for (int it = tid; it < NVO * (A / 4); it += NT) {
+        // ---- stage the X halo: all loads of a batch in flight together, then (activation ->) LDS
+#pragma unroll
+        for (int j0 = 0; j0 < XIT; j0 += XB) {
+            f32x4 val[XB];
+#pragma unroll
+            for (int j = j0; j < j0 + XB && j < XIT; ++j) {
+                const int hx = xpk[j] & 255, hy = (xpk[j] >> 8) & 255, hz = (xpk[j] >> 16) & 255, c = (xpk[j] >> 24) & 7;
+                const int ix = ix0 + hx, iy = iy0 + hy, iz = iz0 + hz;
+                const bool ok = xpk[j] >= 0 && (interior || (ix >= 0 && ix < Wi && iy >= 0 && iy < Hi && iz >= 0 && iz < Di));
+                val[j - j0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok) val[j - j0] = *reinterpret_cast<const f32x4*>(x1.x + (((int64_t)iz * Hi + iy) * Wi + ix) * ldx + (cg0 + c) * 4);
+            }
+#pragma unroll
+            for (int j = j0; j < j0 + XB && j < XIT; ++j) {
+                const int it = tid + NT * j;
+                if (it >= NCG * NVH) continue;
+                f32x4 v = val[j - j0];
+                if (x1.scale && xpk[j] >= 0) {
+                    const int cb = (cg0 + ((xpk[j] >> 24) & 7)) * 4;
+                    const int hx = xpk[j] & 255, hy = (xpk[j] >> 8) & 255, hz = (xpk[j] >> 16) & 255;
+                    const int ix = ix0 + hx, iy = iy0 + hy, iz = iz0 + hz;
+                    if (interior || (ix >= 0 && ix < Wi && iy >= 0 && iy < Hi && iz >= 0 && iz < Di)) {       // the zero padding is not activated
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = act_apply(v[k], x1.scale[cb + k], x1.shift[cb + k]);
+                    }
+                }
+                *reinterpret_cast<f32x4*>(xt + it * 4) = v;
+            }
+        }
+        // ---- stage G (activation / skip sum applied here)
+#pragma unroll 2
+        for (int j = 0; j < GIT; ++j) {
+            const int it = tid + NT * j;
+            if (it >= NVO * (A / 4)) continue;
             const int v = it / (A / 4), c4 = (it - v * (A / 4)) * 4;
             const int ox = ox0 + v % WTX, oy = oy0 + (v / WTX) % WTY, oz = oz0 + v / (WTX * WTY);
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
             if (ox < Wo && oy < Ho && oz < Do) load_act4<A>(g1, g2, ((int64_t)oz * Ho + oy) * Wo + ox, A, c4, val);
             *reinterpret_cast<f32x4*>(gt + v * A + c4) = val;
         }
-        for (int it = tid; it < NW * NVH; it += NT) {
-            const int cgl = it / NVH, hv = it - cgl * NVH;
-            const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
-            const int ix = ox0 * S - 1 + hx, iy = oy0 * S - 1 + hy, iz = oz0 * S - 1 + hz;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            const int cb = (cg0 + cgl) * 4;
-            if (cb < B && ix >= 0 && ix < Wi && iy >= 0 && iy < Hi && iz >= 0 && iz < Di) {
-                val = *reinterpret_cast<const f32x4*>(x1.x + (((int64_t)iz * Hi + iy) * Wi + ix) * ldx + cb);
-                if (x1.scale) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) val[k] = act_apply(val[k], x1.scale[cb + k], x1.shift[cb + k]);
-                }
-            }
-            *reinterpret_cast<f32x4*>(xt + (cgl * NVH + hv) * 4) = val;
-        }
         __syncthreads();
-        if ((cg0 + wave) * 4 >= B) continue;
-        // ---- multiply: columns (oz, x group), marching along oy
+        if ((cg0 + cgl) * 4 >= B) continue;
+        // ---- multiply: this wave's share of the (oz, x group) columns, marching along oy
 #pragma unroll 1
-        for (int q = 0; q < TOZ * NXG; ++q) {
+        for (int q = qpart * CPQ; q < (qpart + 1) * CPQ && q < NCOL; ++q) {
             const int oz = q / NXG, xg = q - oz * NXG;
             const float* gb = gl + (oz * WTY * WTX + xg * VM) * A;
             const float* xb = xl + ((oz * S * HY) * HX + xg * VM * S) * 4;
@@ -100,10 +131,11 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_mfma4_kernel(ActSrc g1, 
             }
         }
     }
-    if ((cg0 + wave) * 4 >= B) return;
-    // fold the voxel slots (lane bits above log2 A); lanes 0 .. A-1 then hold gW[a = lane][b = 4 cg + r][tap]
-    float* po = partial + ((int64_t)blockIdx.x * A + (lane % A)) * B * 27;
-    const int cb = (cg0 + wave) * 4;
+    if ((cg0 + cgl) * 4 >= B) return;
+    // fold the voxel slots (lane bits above log2 A); lanes 0 .. A-1 then hold gW[a = lane][b = 4 cg + r][tap] of this wave's column share:
+    // partial row blockIdx.x * NQ + qpart
+    float* po = partial + (((int64_t)blockIdx.x * NQ + qpart) * A + (lane % A)) * B * 27;
+    const int cb = (cg0 + cgl) * 4;
 #pragma unroll
     for (int t = 0; t < 27; ++t)
 #pragma unroll
@@ -115,53 +147,59 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_mfma4_kernel(ActSrc g1, 
         }
 }
 
-template <int A, int NW, int S, int TOZ>
+template <int A, int NCG, int NQ, int S, int TOZ>
 int launch(const ActSrc& g1, const ActSrc& g2, const ActSrc& x1, int ldx, int B, int Do, int Ho, int Wo, int Di, int Hi, int Wi, float* partial, int nx,
            hipStream_t st)
 {
-    const dim3 grid(nx, (B / 4 + NW - 1) / NW);
-    conv3d_wgrad_mfma4_kernel<A, NW, S, TOZ><<<grid, NW * 64, 0, st>>>(g1, g2, x1, ldx, B, Do, Ho, Wo, Di, Hi, Wi, partial);
+    const dim3 grid(nx, (B / 4 + NCG - 1) / NCG);
+    conv3d_wgrad_mfma4_kernel<A, NCG, NQ, S, TOZ><<<grid, 256, 0, st>>>(g1, g2, x1, ldx, B, Do, Ho, Wo, Di, Hi, Wi, partial);
     return MVSNERF_OK;
 }
 
 }  // namespace
 
-// number of partial results (= workgroups along x) the matrix-core weight gradient leaves for (A, B, stride) on an output grid
-// Do x Ho x Wo; 0 = this combination takes the VALU kernel
-int mvs_conv3d_wgrad_mfma4_parts(int A, int B, int Do, int Ho, int Wo, int stride, int cap_parts)
+// number of partial results the matrix-core weight gradient leaves for (A, B, stride) on an output grid Do x Ho x Wo (workgroups along x
+// times the column shares of a workgroup); 0 = this combination takes the VALU kernel
+static int wgrad_mfma4_nx(int A, int B, int Do, int Ho, int Wo, int stride, int cap_parts)
 {
     const bool ok = (A == 16 && (B == 8 || B == 16)) || (A == 32 && (B == 16 || B == 32)) || (A == 64 && (B == 32 || B == 64));
     if (!ok || (stride != 1 && stride != 2)) return 0;
     const int toz = stride == 1 ? 2 : 1;
     const int ntiles = ((Wo + WTX - 1) / WTX) * ((Ho + WTY - 1) / WTY) * ((Do + toz - 1) / toz);
-    const int nw = B == 8 ? 2 : 4, gy = (B / 4 + nw - 1) / nw;
-    int nx = 768 / gy;                                                // ~3 workgroups per CU
-    if (nx > ntiles) nx = ntiles;
-    if (nx > cap_parts) nx = cap_parts;
-    return nx;
+    const int ncg = B == 8 ? 2 : 4, nq = 4 / ncg, gy = (B / 4 + ncg - 1) / ncg;
+    int nmax = 512 / gy;                                              // two resident workgroups per CU
+    if (nmax * nq > cap_parts) nmax = cap_parts / nq;
+    if (nmax < 1) return 0;
+    const int rounds = (ntiles + nmax - 1) / nmax;                    // every workgroup takes `rounds` tiles (the last one may take fewer)
+    return (ntiles + rounds - 1) / rounds;
+}
+
+int mvs_conv3d_wgrad_mfma4_parts(int A, int B, int Do, int Ho, int Wo, int stride, int cap_parts)
+{
+    return wgrad_mfma4_nx(A, B, Do, Ho, Wo, stride, cap_parts) * (B == 8 ? 2 : 1);
 }
 
 int mvs_conv3d_wgrad_mfma4(const ActSrc& g1, const ActSrc& g2, int A, const ActSrc& x1, const ActSrc& x2, int B, int ldx, int Do, int Ho, int Wo,
                            int Di, int Hi, int Wi, int stride, float* partial, int cap_parts, hipStream_t st)
 {
     if (x2.x) return MVSNERF_EUNSUPPORTED;
-    const int nx = mvs_conv3d_wgrad_mfma4_parts(A, B, Do, Ho, Wo, stride, cap_parts);
+    const int nx = wgrad_mfma4_nx(A, B, Do, Ho, Wo, stride, cap_parts);
     if (nx <= 0) return MVSNERF_EUNSUPPORTED;
-#define MVS_WM(A_, NW_, S_, TOZ_) launch<A_, NW_, S_, TOZ_>(g1, g2, x1, ldx, B, Do, Ho, Wo, Di, Hi, Wi, partial, nx, st)
+#define MVS_WM(A_, NCG_, NQ_, S_, TOZ_) launch<A_, NCG_, NQ_, S_, TOZ_>(g1, g2, x1, ldx, B, Do, Ho, Wo, Di, Hi, Wi, partial, nx, st)
     const int key = (A * 100 + B) * 10 + stride;
     switch (key) {
-        case (16 * 100 + 8) * 10 + 2:  MVS_WM(16, 2, 2, 1); break;     // conv1, conv11^T
-        case (16 * 100 + 8) * 10 + 1:  MVS_WM(16, 2, 1, 2); break;
-        case (16 * 100 + 16) * 10 + 1: MVS_WM(16, 4, 1, 2); break;     // conv2
-        case (16 * 100 + 16) * 10 + 2: MVS_WM(16, 4, 2, 1); break;
-        case (32 * 100 + 16) * 10 + 2: MVS_WM(32, 4, 2, 1); break;     // conv3, conv9^T
-        case (32 * 100 + 16) * 10 + 1: MVS_WM(32, 4, 1, 2); break;
-        case (32 * 100 + 32) * 10 + 1: MVS_WM(32, 4, 1, 2); break;     // conv4
-        case (32 * 100 + 32) * 10 + 2: MVS_WM(32, 4, 2, 1); break;
-        case (64 * 100 + 32) * 10 + 2: MVS_WM(64, 4, 2, 1); break;     // conv5, conv7^T
-        case (64 * 100 + 32) * 10 + 1: MVS_WM(64, 4, 1, 2); break;
-        case (64 * 100 + 64) * 10 + 1: MVS_WM(64, 4, 1, 2); break;     // conv6
-        case (64 * 100 + 64) * 10 + 2: MVS_WM(64, 4, 2, 1); break;
+        case (16 * 100 + 8) * 10 + 2:  MVS_WM(16, 2, 2, 2, 1); break;     // conv1, conv11^T
+        case (16 * 100 + 8) * 10 + 1:  MVS_WM(16, 2, 2, 1, 2); break;
+        case (16 * 100 + 16) * 10 + 1: MVS_WM(16, 4, 1, 1, 2); break;     // conv2
+        case (16 * 100 + 16) * 10 + 2: MVS_WM(16, 4, 1, 2, 1); break;
+        case (32 * 100 + 16) * 10 + 2: MVS_WM(32, 4, 1, 2, 1); break;     // conv3, conv9^T
+        case (32 * 100 + 16) * 10 + 1: MVS_WM(32, 4, 1, 1, 2); break;
+        case (32 * 100 + 32) * 10 + 1: MVS_WM(32, 4, 1, 1, 2); break;     // conv4
+        case (32 * 100 + 32) * 10 + 2: MVS_WM(32, 4, 1, 2, 1); break;
+        case (64 * 100 + 32) * 10 + 2: MVS_WM(64, 4, 1, 2, 1); break;     // conv5, conv7^T
+        case (64 * 100 + 32) * 10 + 1: MVS_WM(64, 4, 1, 1, 2); break;
+        case (64 * 100 + 64) * 10 + 1: MVS_WM(64, 4, 1, 1, 2); break;     // conv6
+        case (64 * 100 + 64) * 10 + 2: MVS_WM(64, 4, 1, 2, 1); break;
         default: return MVSNERF_EUNSUPPORTED;
     }
 #undef MVS_WM
