@@ -167,7 +167,7 @@ int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float* proj, con
  * scratch: mvsnerf_partial_sum_multi_scratch_floats(sum of the jobs' n_out) floats.  Same fixed summation order either way. */
 int mvsnerf_conv3d_wgrad_parts(int A, int B, int Do, int Ho, int Wo, int stride, int two_x_sources);
 int mvsnerf_conv3d_c8_blocked_wgrad_parts(int Cin, int Cin_real, int D, int H, int W);
-int mvsnerf_conv2d_wgrad_parts(int A, int N, int Ho, int Wo);
+int mvsnerf_conv2d_wgrad_parts(int A, int B, int N, int Ho, int Wo, int ksize, int stride);
 size_t mvsnerf_partial_sum_multi_scratch_floats(int64_t total_n_out);
 int mvsnerf_partial_sum_multi(int n_jobs, const float* const* partial, const int* n_part, const int64_t* n_out, float* const* dst,
                               float* scratch, void* stream);

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(const float* __restri
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const int yi = oy * S + dy[j], xi = ox * S + dx[j];
-                const bool in = valid[j] && (unsigned)yi < (unsigned)Hi && (unsigned)xi < (unsigned)Wi;
+                const bool in = live && valid[j] && (unsigned)yi < (unsigned)Hi && (unsigned)xi < (unsigned)Wi;      // (not live: `on` may be N)
                 const int64_t idx = in ? (((int64_t)on * Hi + yi) * Wi + xi) * ldx + bch[j] : 0;
                 const float t = act1(x1, idx, bch[j]);
                 xv[u_][j] = in ? t : 0.f;
@@ -242,6 +242,11 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(const float* __restri
         }
 }
 
+extern int g_conv_mfma;
+int mvs_conv2d_wgrad_mfma4_parts(int A, int B, int N, int Ho, int Wo, int ksize, int stride, int cap_parts);
+int mvs_conv2d_wgrad_mfma4(const float* g, int A, const ActSrc& x1, int B, int ldx, int N, int Ho, int Wo, int Hi, int Wi, int ksize, int stride,
+                           float* partial, int cap_parts, hipStream_t st);
+
 // >= 64 pixels per workgroup, <= 4096 workgroups over all channel groups (bounds the partials to 32768*B*k*k floats)
 static int wgrad2d_nwg(int64_t npix, int A)
 {
@@ -263,11 +268,22 @@ extern "C" int mvsnerf_conv2d_wgrad(const float* g, int A, const float* x, const
     const ActSrc X1{x, x_scale, x_shift};
     const int64_t npix = (int64_t)N * Ho * Wo;
     if (npix > 0x7fffffff) return MVSNERF_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (g_conv_mfma) {                                     // matrix cores (wgrad_mfma.hip) for FeatureNet's eight k3 / k5 layers
+        const int cap = 4096 / (A / 8);
+        const int rc = mvs_conv2d_wgrad_mfma4(g, A, X1, B, ldx, N, Ho, Wo, Hi, Wi, ksize, stride, workspace, cap, st);
+        if (rc != MVSNERF_EUNSUPPORTED) {
+            if (rc != MVSNERF_OK || !gw) return rc;
+            const int64_t n_out = (int64_t)A * B * ksize * ksize;
+            mvs_partial_sum(workspace, mvs_conv2d_wgrad_mfma4_parts(A, B, N, Ho, Wo, ksize, stride, cap), n_out, workspace + (size_t)cap * n_out, gw, st);
+            MVS_LAUNCH_CHECK();
+            return MVSNERF_OK;
+        }
+    }
     const int nwg = wgrad2d_nwg(npix, A);
     const int pairs = ksize * ksize * B;
     const int threads = pairs >= 256 ? 256 : (pairs + 63) / 64 * 64;      // waves without any (tap,b) pair are not launched
     const int np = (pairs + threads - 1) / threads;
-    hipStream_t st = (hipStream_t)stream;
     const dim3 grid(nwg, A / 8);
 #define MVS_WG2(NP_, S_, K_) conv2d_wgrad_kernel<NP_, S_, K_><<<grid, threads, 0, st>>>(g, A, X1, B, ldx, N, Ho, Wo, Hi, Wi, workspace)
     switch ((np * 10 + stride) * 10 + ksize) {
@@ -288,9 +304,13 @@ extern "C" int mvsnerf_conv2d_wgrad(const float* g, int A, const float* x, const
 }
 
 // number of partial results mvsnerf_conv2d_wgrad leaves at the start of its workspace (rows of A*B*k*k floats)
-extern "C" int mvsnerf_conv2d_wgrad_parts(int A, int N, int Ho, int Wo)
+extern "C" int mvsnerf_conv2d_wgrad_parts(int A, int B, int N, int Ho, int Wo, int ksize, int stride)
 {
     if (A < 8) return 0;
+    if (g_conv_mfma) {
+        const int n = mvs_conv2d_wgrad_mfma4_parts(A, B, N, Ho, Wo, ksize, stride, 4096 / (A / 8));
+        if (n > 0) return n;
+    }
     return wgrad2d_nwg((int64_t)N * Ho * Wo, A);
 }
 

@@ -221,7 +221,7 @@ def _wgrad2d(gx, A, X, B, ldx, g_dims, x_dims, ksize, stride, shape, sums=None):
     check(lib.mvsnerf_conv2d_wgrad(gx.data_ptr(), A, *_ptrs(X), B, ldx, g_dims[0], g_dims[1], g_dims[2], x_dims[1], x_dims[2], ksize, stride,
                                    0 if sums is not None else gw.data_ptr(), ws.data_ptr(), stream_ptr()), "conv2d_wgrad")
     if sums is not None:
-        sums.add(ws, lib.mvsnerf_conv2d_wgrad_parts(A, g_dims[0], g_dims[1], g_dims[2]), gw)
+        sums.add(ws, lib.mvsnerf_conv2d_wgrad_parts(A, B, g_dims[0], g_dims[1], g_dims[2], ksize, stride), gw)
     return gw
 
 

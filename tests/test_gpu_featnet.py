@@ -78,3 +78,54 @@ def test_convbnrelu_standalone():
         y = F.conv2d(x, lay.conv.weight, None, stride=2, padding=2)
         ref = F.leaky_relu(F.batch_norm(y, None, None, lay.bn.weight.abs() + lay.bn.eps, lay.bn.bias, True, 0.1, lay.bn.eps), 0.01)
     assert float((out - ref).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("A,B,k,stride,hw,ldx", [
+    (8, 3, 3, 1, (40, 56), 4),       # conv0.0: image input, 3 of 4 channels real
+    (8, 8, 3, 1, (512, 640), 8),     # conv0.1 at the training size
+    (16, 8, 5, 2, (128, 160), 8),    # conv1.0 (output grid given)
+    (16, 16, 3, 1, (37, 45), 16),    # conv1.1 (odd sizes)
+    (32, 16, 5, 2, (128, 160), 16),  # conv2.0 at the training size
+    (32, 32, 3, 1, (128, 160), 32),  # conv2.1 at the training size
+])
+def test_conv2d_wgrad_matrix_cores_vs_valu_kernel(A, B, k, stride, hw, ldx):
+    """FeatureNet's weight gradients on the matrix cores (wgrad_mfma.hip, the images as the z axis) against the VALU kernel, with the
+    lazily applied InPlaceABN of the input layer; different summation orders."""
+    from mvsnerf_amd import _lib
+    from mvsnerf_amd.ops import stream_ptr
+    N, (Ho, Wo) = 3, hw
+    Hi, Wi = (Ho, Wo) if stride == 1 else (2 * Ho, 2 * Wo)
+    gen = torch.Generator(DEV).manual_seed(A * 100 + B + k)
+    r = lambda *s: torch.randn(s, device=DEV, generator=gen)
+    G, X = r(N, Ho, Wo, A), r(N, Hi, Wi, ldx)
+    if B < ldx:
+        X[..., B:] = 0
+    sc, sh = (r(B).abs() + 0.5, r(B)) if B > 3 else (None, None)
+    L = _lib.lib()
+    ws = torch.empty(L.mvsnerf_conv2d_wgrad_workspace_floats(A, B, k), device=DEV)
+    out, ms = {}, {}
+    for mode in (0, 1):
+        assert L.mvsnerf_tune(b"conv_mfma", mode) == 0
+        try:
+            gw = torch.full((A, B, k, k), float("nan"), device=DEV)
+            for rep in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = L.mvsnerf_conv2d_wgrad(G.data_ptr(), A, X.data_ptr(), 0 if sc is None else sc.data_ptr(), 0 if sh is None else sh.data_ptr(), B, ldx,
+                                            N, Ho, Wo, Hi, Wi, k, stride, gw.data_ptr(), ws.data_ptr(), stream_ptr())
+                e1.record(); torch.cuda.synchronize()
+                assert rc == 0
+            out[mode], ms[mode] = gw, e0.elapsed_time(e1)
+        finally:
+            L.mvsnerf_tune(b"conv_mfma", 1)
+    # float64 definition: gw = d/dW sum(conv2d(act(X), W) * G)
+    xa = X[..., :B].double()
+    if sc is not None:
+        xa = torch.nn.functional.leaky_relu(xa * sc.double() + sh.double(), 0.01)
+    ref = torch.nn.grad.conv2d_weight(xa.permute(0, 3, 1, 2), (A, B, k, k), G.double().permute(0, 3, 1, 2), stride=stride, padding=k // 2)
+    scale = float(ref.abs().max())
+    e_valu, e_mfma = float((out[0].double() - ref).abs().max()), float((out[1].double() - ref).abs().max())
+    print(f"[conv2d wgrad A={A} B={B} k{k} s{stride} {N}x{Ho}x{Wo}] VALU {ms[0]:.3f} ms (err {e_valu:.2e}), matrix cores {ms[1]:.3f} ms (err {e_mfma:.2e}); "
+          f"|gw| max {scale:.1f}")
+    assert torch.isfinite(out[1]).all() and e_mfma < 1e-5 * scale
+    assert e_valu < 1e-5 * scale
