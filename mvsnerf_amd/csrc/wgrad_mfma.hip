@@ -35,11 +35,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma4_kernel(ActSrc g1, Act
     constexpr int XB = A == 16 ? 8 : 4;                               // X loads in flight together (register budget: accumulators + window)
     constexpr int YSEG = (TOZ * NXG >= NQ) ? TOY : TOY / 4;           // a work item = (oz, x group) column x YSEG output rows
     constexpr int NSEG = TOY / YSEG, NITEM = TOZ * NXG * NSEG;
-    __shared__ __attribute__((aligned(16))) float gt[NVO * A];         // [o voxel][A]
-    __shared__ __attribute__((aligned(16))) float xt[NCG * NVH * 4];   // [cg local][halo voxel][4]
+    __shared__ __attribute__((aligned(16))) float lds[NVO * A + NCG * NVH * 4];
+    float* gt = lds;                                                  // [o voxel][A]
+    float* xt = lds + NVO * A;                                        // [cg local][halo voxel][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cgl = wave % NCG, qpart = wave / NCG;
     const int cg0 = blockIdx.y * NCG;
+    const bool active = (cg0 + cgl) * 4 < B;                          // (B = 8 with four blocks per workgroup: two waves only stage)
     const int nbx = (Wo + WTX - 1) / WTX, nby = (Ho + TOY - 1) / TOY, nbz = (Do + TOZ - 1) / TOZ;
     const int ntiles = nbx * nby * nbz;
     // tile-invariant staging slots of this thread.  X: item = tid + 256 j -> (cg local, halo voxel) packed hx | hy << 8 | hz << 16 | cgl << 24
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma4_kernel(ActSrc g1, Act
             *reinterpret_cast<f32x4*>(gt + v * A + c4) = val;
         }
         __syncthreads();
-        if ((cg0 + cgl) * 4 >= B) continue;
+        if (!active) continue;
         // ---- multiply: this wave's work items, each marching along oy
 #pragma unroll 1
         for (int item = qpart; item < NITEM; item += NQ) {
@@ -138,11 +140,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma4_kernel(ActSrc g1, Act
             }
         }
     }
-    if ((cg0 + cgl) * 4 >= B) return;
-    // fold the voxel slots (lane bits above log2 A); lanes 0 .. A-1 then hold gW[a = lane][b = 4 cg + r][tap] of this wave's work share:
-    // partial row blockIdx.x * NQ + qpart
-    float* po = partial + (((int64_t)blockIdx.x * NQ + qpart) * A + (lane % A)) * B * NTAP;
-    const int cb = (cg0 + cgl) * 4;
+    // ---- one partial result per wave share: row blockIdx.x * NQ + qpart of partial[.][A][B][NTAP].  After folding the voxel slots (lane
+    // bits above log2 A) lane a < A holds gW[a][4 cg + r][tap]: per `a` that is 4 NTAP CONTIGUOUS floats of the row, but the lanes are
+    // B * NTAP floats apart - stored directly, every instruction would be 64 separate 4-byte writes (6912 of them per wave for A = 64:
+    // the deep layers spent more time here than multiplying).  So: through LDS, RC `a` rows at a time, and out as whole rows.
+    __syncthreads();                                                  // nobody reads the tiles any more
+    constexpr int ROWF = 4 * NTAP;                                    // floats per (a, channel block)
+    constexpr int WBUD = (NVO * A + NCG * NVH * 4) / 4;               // LDS floats per wave
+    constexpr int RC0 = WBUD / ROWF < A ? WBUD / ROWF : A;
+    constexpr int RC = RC0 >= 64 ? 64 : RC0 >= 32 ? 32 : RC0 >= 16 ? 16 : RC0 >= 8 ? 8 : RC0 >= 4 ? 4 : RC0 >= 2 ? 2 : 1;
+    static_assert(RC0 >= 1, "LDS too small for the epilogue");
+    if (!active) return;
 #pragma unroll
     for (int t = 0; t < NTAP; ++t)
 #pragma unroll
@@ -151,8 +159,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma4_kernel(ActSrc g1, Act
             if (VM >= 2) v += __shfl_xor(v, 32);
             if (VM >= 4) v += __shfl_xor(v, 16);
             if (VM >= 8) v += __shfl_xor(v, 8);
-            if (lane < A && cb + r < B) po[(int64_t)(cb + r) * NTAP + t] = v;
+            acc[t][r] = v;
         }
+    float* tw = lds + wave * WBUD;
+    const int cb = (cg0 + cgl) * 4;
+    float* prow = partial + ((int64_t)blockIdx.x * NQ + qpart) * A * B * NTAP + (int64_t)cb * NTAP;
+    const int ncol = (B - cb >= 4 ? 4 : B - cb) * NTAP;               // columns of the block that exist (B = 3: three of four)
+#pragma unroll 1
+    for (int a0 = 0; a0 < A; a0 += RC) {
+        if (lane >= a0 && lane < a0 + RC) {
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tw[(lane - a0) * ROWF + r * NTAP + t] = acc[t][r];
+        }
+        // (same wave: the LDS writes above are complete before the reads below are served)
+        for (int e = lane; e < RC * ROWF; e += 64) {
+            const int row = e / ROWF, colx = e - row * ROWF;
+            if (colx < ncol) prow[(int64_t)(a0 + row) * B * NTAP + colx] = tw[e];
+        }
+    }
 }
 
 template <int A, int NCG, int NQ, int S, int TOZ, int TOY, int KZ, int K>
