@@ -1274,8 +1274,11 @@ __global__ __launch_bounds__(256) void planesweep_bwd_kernel(const float* __rest
 // scatter.  Per group of DSUB planes the scale is 2^45 / (a power-of-two bound of 128 max|g| over the tile's first plane): a term is
 // exact to 2^-45 of that bound (fp32 keeps 2^-24 of the running sum), the sums cannot overflow (terms < 2^50, int64 accumulators), and
 // the patch sum no longer depends on the order of the additions.  float -> fixed point is one v_fma_f64 (add 1.5 * 2^52, read the mantissa).
+// Occupancy decides the rest: the plane loop is a chain of latencies (geometry -> barrier -> 36 gathers per thread -> adds -> barrier), so
+// PW = 10 (34 KB of LDS) with the registers capped at 128 - four workgroups per CU - runs at 1.16 ms where PW = 12 (45 KB, three per CU)
+// took 1.45; a window in unclamped coordinates with the features staged in LDS as well (two workgroups per CU) was slower than either.
 template <int C, int CL, int NSRC, int PW>
-__global__ __launch_bounds__(256) void planesweep_bwd_tiles_kernel(const float* __restrict__ feat, const float* __restrict__ proj,
+__global__ __launch_bounds__(256, NSRC <= 2 ? 4 : 2) void planesweep_bwd_tiles_kernel(const float* __restrict__ feat, const float* __restrict__ proj,
                                                                   const float* __restrict__ depth, int H, int W, int D, int pad,
                                                                   const float* __restrict__ g_cost, int CP, int c_var, float* __restrict__ g_feat, int DCH)
 {
@@ -1471,7 +1474,7 @@ template <int NSRC>
 static int planesweep_bwd_tiles_launch(const float* feat, const float* proj, const float* depth, int H, int W, int D, int pad, const float* g_cost, int CP,
                                        int c_var, float* g_feat, hipStream_t st)
 {
-    constexpr int PW = 12, DCH = 16, CL = 16;
+    constexpr int PW = 10, DCH = 16, CL = 16;
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const size_t lds = (size_t)(64 * NSRC * 16 + 16 + 8 + 8) * sizeof(float) + (size_t)NSRC * PW * PW * CL * 8;
     static unsigned long long cap_mask = 0;
