@@ -119,6 +119,11 @@ int mvsnerf_conv3d_c8_blocked_wgrad(const float* x_blocked, int Cin, int Cin_rea
 /* The same convolution for the deep layers (Cout = 32 | 64; models.py:758-761: conv3..conv6, and the data gradients that have these
  * shapes) on v_mfma_f32_32x32x2_f32.  conv3d_mfma_supported: 1 when (Cin, Cout, stride) is built (and the "conv_mfma" switch is on);
  * conv3d_pack_weights_mfma: packed[tap][ci][co] (mvsnerf_conv3d_pack_weights) -> w32[tap][ci/8][co][8]; one lazily-activated source. */
+/* All weight re-layouts of a step in one launch (<= 64 jobs, host arrays): job j gathers from the layer's own weight tensor w[j] with
+ * params[9 j ..] = {kind, ntaps, ci_real, co_real, ci_pad, co_pad, s_ci, s_co, flip}; kind 0 = conv3d/conv2d_pack_weights' [tap][ci][co],
+ * 1 = conv3d_pack_weights_c8's [ci/4][tap][co][4], 2 = conv3d_pack_weights_mfma's [tap][ci/8][co][8] (both straight from w, not from a packed
+ * copy).  The weights change with every optimizer step; separately these are ~50 launches of a few microseconds each. */
+int mvsnerf_pack_weights_multi(int n_jobs, const float* const* w, float* const* dst, const int* params, void* stream);
 int mvsnerf_conv3d_mfma_supported(int Cin, int Cout, int stride);
 int mvsnerf_conv3d_pack_weights_mfma(const float* wpacked, int Cin, int Cout, float* w32, void* stream);
 int mvsnerf_conv3d_mfma_fwd(const float* x1, const float* scale1, const float* shift1, int Cin, int cin_ld, int D, int H, int W,

@@ -98,6 +98,7 @@ SIGNATURES = {
     "mvsnerf_conv2d_wgrad_parts": (_c_i, [_c_i] * 7),
     "mvsnerf_partial_sum_multi_scratch_floats": (ctypes.c_size_t, [_c_l]),
     "mvsnerf_partial_sum_multi": (_c_i, [_c_i, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_pack_weights_multi": (_c_i, [_c_i, _c_fp, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_homo_warp_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_conv3d_pack_weights": (_c_i, [_c_fp] + [_c_i] * 7 + [_c_fp, _c_fp]),
     "mvsnerf_conv3d_fwd": (_c_i, [_c_fp] * 6 + [_c_i] * 5 + [_c_fp, _c_i, _c_i, _c_fp, _c_fp]),

@@ -342,6 +342,60 @@ extern "C" int mvsnerf_conv3d_pack_weights(const float* w, int ci_real, int co_r
     return MVSNERF_OK;
 }
 
+// Every re-layout a training step needs (the weights change with every optimizer step: ~50 of them, each a 5-us launch of its own) in ONE
+// launch.  A job gathers straight from the nn.Conv / nn.ConvTranspose weight tensor:
+//   value(tap, ci, co) = (ci < ci_real && co < co_real) ? w[ci * s_ci + co * s_co + (flip ? ntaps - 1 - tap : tap)] : 0
+// into layout kind 0: dst[tap][ci][co] (conv3d_pack_weights / conv2d_pack_weights), 1: dst[ci/4][tap][co][ci%4] (conv3d_pack_weights_c8),
+// 2: dst[tap][ci/8][co][ci%8] (conv3d_pack_weights_mfma).
+constexpr int MVS_PACK_JOBS = 64;
+struct PackJobs {
+    const float* w[MVS_PACK_JOBS];
+    float* dst[MVS_PACK_JOBS];
+    int ci_real[MVS_PACK_JOBS], co_real[MVS_PACK_JOBS], ci_pad[MVS_PACK_JOBS], co_pad[MVS_PACK_JOBS], s_ci[MVS_PACK_JOBS], s_co[MVS_PACK_JOBS];
+    short ntaps[MVS_PACK_JOBS];
+    signed char flip[MVS_PACK_JOBS], kind[MVS_PACK_JOBS];
+    int blk[MVS_PACK_JOBS + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(PackJobs J)
+{
+    int j = 0;
+    while (j + 1 < J.n && (int)blockIdx.x >= J.blk[j + 1]) ++j;
+    const int i = (blockIdx.x - J.blk[j]) * 256 + threadIdx.x;
+    const int ntaps = J.ntaps[j], cip = J.ci_pad[j], cop = J.co_pad[j];
+    if (i >= ntaps * cip * cop) return;
+    int tap, ci, co;
+    if (J.kind[j] == 0) { co = i % cop; ci = (i / cop) % cip; tap = i / (cop * cip); }
+    else if (J.kind[j] == 1) { co = (i >> 2) % cop; tap = (i / (4 * cop)) % ntaps; ci = (i / (4 * cop * ntaps)) * 4 + (i & 3); }
+    else { co = (i >> 3) % cop; ci = ((i / (8 * cop)) % (cip / 8)) * 8 + (i & 7); tap = i / (cip * cop); }
+    if (J.flip[j]) tap = ntaps - 1 - tap;
+    J.dst[j][i] = (ci < J.ci_real[j] && co < J.co_real[j]) ? J.w[j][(int64_t)ci * J.s_ci[j] + (int64_t)co * J.s_co[j] + tap] : 0.f;
+}
+
+// params[j] = {kind, ntaps, ci_real, co_real, ci_pad, co_pad, s_ci, s_co, flip}; host arrays
+extern "C" int mvsnerf_pack_weights_multi(int n_jobs, const float* const* w, float* const* dst, const int* params, void* stream)
+{
+    if (n_jobs < 1 || n_jobs > MVS_PACK_JOBS || !w || !dst || !params) return MVSNERF_EINVAL;
+    PackJobs J;
+    J.n = n_jobs;
+    int b = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const int* q = params + 9 * j;
+        if (!w[j] || !dst[j] || q[0] < 0 || q[0] > 2 || q[1] < 1 || q[1] > 27 || q[2] < 1 || q[3] < 1 || q[4] < q[2] || q[5] < q[3]) return MVSNERF_EINVAL;
+        if ((q[0] == 1 && (q[4] & 3)) || (q[0] == 2 && (q[4] & 7))) return MVSNERF_EINVAL;
+        J.w[j] = w[j]; J.dst[j] = dst[j];
+        J.kind[j] = (signed char)q[0]; J.ntaps[j] = (short)q[1]; J.ci_real[j] = q[2]; J.co_real[j] = q[3]; J.ci_pad[j] = q[4]; J.co_pad[j] = q[5];
+        J.s_ci[j] = q[6]; J.s_co[j] = q[7]; J.flip[j] = (signed char)(q[8] ? 1 : 0);
+        J.blk[j] = b;
+        b += (q[1] * q[4] * q[5] + 255) / 256;
+    }
+    J.blk[n_jobs] = b;
+    pack_weights_multi_kernel<<<b, 256, 0, (hipStream_t)stream>>>(J);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
 // Direct 3x3x3 convolution, padding 1, stride S.  One thread = one output voxel x CT output channels.
 // Neighbouring threads re-read each other's input voxels through L1/L2 (27-fold reuse).
 template <int CIN, int CT, int S, int COUT>      // COUT a template constant: weight offsets become s_load immediates

@@ -57,6 +57,57 @@ class InPlaceABN(nn.Module):
         return out.permute(0, 3, 1, 2) if x.dim() == 4 else _cl_view_to_ncdhw(out)
 
 
+class _PackBatch:
+    """Weight re-layouts collected while `active` and issued as ONE launch on exit (mvsnerf_pack_weights_multi).  Outside a batch a
+    re-layout is its own launch of the same kernel.  MVSNet.forward replays the re-layouts the previous step asked for (`log`, filled by
+    the getters on their cache misses) inside a batch, so a training step packs its ~50 weight layouts in one launch up front."""
+    active = None
+
+    def __init__(self):
+        self.jobs = []
+
+    def __enter__(self):
+        _PackBatch.active = self
+        return self
+
+    def __exit__(self, *exc):
+        _PackBatch.active = None
+        if exc[0] is None:
+            _PackBatch.launch(self.jobs)
+        self.jobs = []
+        return False
+
+    @staticmethod
+    def launch(jobs):
+        import ctypes
+        lib = _lib.lib()
+        for i in range(0, len(jobs), 64):
+            part = jobs[i:i + 64]
+            n = len(part)
+            flat = [v for _, _, q in part for v in q]
+            check(lib.mvsnerf_pack_weights_multi(n, (ctypes.c_void_p * n)(*[w for w, _, _ in part]), (ctypes.c_void_p * n)(*[d.data_ptr() for _, d, _ in part]),
+                                                 (ctypes.c_int * (9 * n))(*flat), stream_ptr()), "pack_weights_multi")
+
+
+def _pack(w_ptr, dst, kind, ntaps, ci_real, co_real, ci_pad, co_pad, s_ci, s_co, flip):
+    """dst <- layout `kind` of the weights at device address w_ptr (see mvsnerf_pack_weights_multi)."""
+    job = (w_ptr, dst, (kind, ntaps, ci_real, co_real, ci_pad, co_pad, s_ci, s_co, flip))
+    if _PackBatch.active is not None:
+        _PackBatch.active.jobs.append(job)
+    else:
+        _PackBatch.launch([job])
+    return dst
+
+
+def _log_pack(pk, method, *args):
+    """Remember that `pk.method(*args)` had to pack (replayed in a batch at the start of the next MVSNet.forward)."""
+    log = getattr(pk, "log", None)
+    if log is not None and _PackBatch.active is None:
+        entry = (pk, method, args)
+        if entry not in log:
+            log.append(entry)
+
+
 class _PackedConv2d:
     """Caches the [k*k][cin_pad][cout] re-layouts of a Conv2d weight (re-packed when it changes).
     mode 'fwd': the layer itself; mode 'dgrad': the convolution computing its data gradient (channel roles swapped,
@@ -79,8 +130,9 @@ class _PackedConv2d:
         else:
             args = (self.cout, self.cin, self.cout, self.cin_pad, self.cin * kk, kk, self.k, 1 if self.conv.stride[0] == 1 else 0)
         buf = torch.empty(kk * args[2] * args[3], device=w.device, dtype=torch.float32)
-        check(_lib.lib().mvsnerf_conv2d_pack_weights(dev_f32(w.detach().contiguous(), "conv weight"), *args, buf.data_ptr(), stream_ptr()),
-              "conv2d_pack_weights")
+        ci_real, co_real, ci_pad, co_pad, s_ci, s_co, _, flip = args
+        _pack(dev_f32(w.detach().contiguous(), "conv weight"), buf, 0, kk, ci_real, co_real, ci_pad, co_pad, s_ci, s_co, flip)
+        _log_pack(self, "get", mode)
         self.cache[mode] = (key, buf)
         return buf
 
@@ -324,37 +376,35 @@ class _PackedConv:
         self.cin, self.cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
         self.cin_pad = (self.cin + 3) // 4 * 4
 
-    def get(self, mode="fwd"):
-        w = self.conv.weight
-        key = (w.data_ptr(), w._version)
-        hit = self.cache.get(mode)
-        if hit is not None and hit[0] == key:
-            return hit[1]
+    def _params(self, mode):
+        """(ci_real, co_real, ci_pad, co_pad, s_ci, s_co, flip) of the convolution kernel that runs this layer (mode "fwd") or its data
+        gradient ("dgrad": kernel input channels = the layer's outputs)."""
         cin, cout = self.cin, self.cout
         if mode == "fwd":
-            ci_real, co_real, ci_pad, co_pad = cin, cout, self.cin_pad, cout
             s_ci, s_co = (cout * 27, 27) if self.transposed else (27, cin * 27)
-            flip = 0
-        else:   # kernel channels: ci_k = this layer's outputs, co_k = this layer's inputs
-            ci_real, co_real, ci_pad, co_pad = cout, cin, cout, self.cin_pad
-            s_ci, s_co = (27, cout * 27) if self.transposed else (cin * 27, 27)
-            flip = 1 if (not self.transposed and self.conv.stride[0] == 1) else 0
+            return cin, cout, self.cin_pad, cout, s_ci, s_co, 0
+        s_ci, s_co = (27, cout * 27) if self.transposed else (cin * 27, 27)
+        return cout, cin, cout, self.cin_pad, s_ci, s_co, (1 if (not self.transposed and self.conv.stride[0] == 1) else 0)
+
+    def _cached(self, name, kind, mode, method, *args):
+        w = self.conv.weight
+        key = (w.data_ptr(), w._version)
+        hit = self.cache.get(name)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        ci_real, co_real, ci_pad, co_pad, s_ci, s_co, flip = self._params(mode)
         buf = torch.empty(27 * ci_pad * co_pad, device=w.device, dtype=torch.float32)
-        check(_lib.lib().mvsnerf_conv3d_pack_weights(dev_f32(w.detach().contiguous(), "conv weight"), ci_real, co_real, ci_pad, co_pad,
-                                                     s_ci, s_co, flip, buf.data_ptr(), stream_ptr()), "conv3d_pack_weights")
-        self.cache[mode] = (key, buf)
+        _pack(dev_f32(w.detach().contiguous(), "conv weight"), buf, kind, 27, ci_real, co_real, ci_pad, co_pad, s_ci, s_co, flip)
+        _log_pack(self, method, *args)
+        self.cache[name] = (key, buf)
         return buf
 
+    def get(self, mode="fwd"):
+        return self._cached(mode, 0, mode, "get", mode)
+
     def get_c8(self):
-        """[ci/4][tap][co][4] re-layout of get("fwd") for the DMA-staged matrix-core conv0 (8 output channels; same cache policy)."""
-        base = self.get("fwd")
-        hit = self.cache.get("fwd_c8")
-        if hit is not None and hit[0] is base:
-            return hit[1]
-        buf = torch.empty_like(base)
-        check(_lib.lib().mvsnerf_conv3d_pack_weights_c8(base.data_ptr(), self.cin_pad, buf.data_ptr(), stream_ptr()), "conv3d_pack_weights_c8")
-        self.cache["fwd_c8"] = (base, buf)
-        return buf
+        """[ci/4][tap][co][4] layout of the forward weights for the DMA-staged matrix-core conv0 (8 output channels)."""
+        return self._cached("fwd_c8", 1, "fwd", "get_c8")
 
     def get_dgrad_slice(self, c0, n):
         """get("dgrad") restricted to the layer inputs c0 .. c0+n-1 (stride-1 Conv3d): [27][cout][n], mirrored taps.  The plane sweep's
@@ -368,22 +418,14 @@ class _PackedConv:
             raise RuntimeError("get_dgrad_slice: stride-1 Conv3d and a channel range inside the layer's inputs (multiple of 4 wide)")
         wc = dev_f32(w.detach().contiguous(), "conv weight")
         buf = torch.empty(27 * self.cout * n, device=w.device, dtype=torch.float32)
-        check(_lib.lib().mvsnerf_conv3d_pack_weights(wc + c0 * 27 * 4, self.cout, n, self.cout, n, self.cin * 27, 27, 1, buf.data_ptr(), stream_ptr()),
-              "conv3d_pack_weights")
+        _pack(wc + c0 * 27 * 4, buf, 0, 27, self.cout, n, self.cout, n, self.cin * 27, 27, 1)
+        _log_pack(self, "get_dgrad_slice", c0, n)
         self.cache["dgrad_slice"] = (key, buf)
         return buf
 
     def get_mfma(self, mode="fwd"):
-        """[tap][ci/8][co][8] re-layout of get(mode) for the matrix-core kernel of the 32/64-channel layers (same cache policy)."""
-        base = self.get(mode)
-        hit = self.cache.get(mode + "_m32")
-        if hit is not None and hit[0] is base:
-            return hit[1]
-        ci_k, co_k = (self.cin_pad, self.cout) if mode == "fwd" else (self.cout, self.cin_pad)
-        buf = torch.empty_like(base)
-        check(_lib.lib().mvsnerf_conv3d_pack_weights_mfma(base.data_ptr(), ci_k, co_k, buf.data_ptr(), stream_ptr()), "conv3d_pack_weights_mfma")
-        self.cache[mode + "_m32"] = (base, buf)
-        return buf
+        """[tap][ci/8][co][8] layout of get(mode)'s weights for the matrix-core kernels of the 32/64-channel layers."""
+        return self._cached(mode + "_m32", 2, mode, "get_mfma", mode)
 
 
 def _abn_stats(raw, n_vox, bn, update_running=True):
@@ -867,6 +909,19 @@ class MVSNet(nn.Module):
         # BASELINE config 4 (5 views => 47 input channels, no shipped checkpoint fits)
         self.cost_reg_2 = CostRegNet(32 + 3 * n_views, norm_act)
         self.D = 128          # number of depth planes (hard-coded `D = 128` at models.py:914; settable here for config 1)
+        self._pack_log = []   # weight re-layouts the last forward/backward asked for (see _PackBatch)
+        for m in self.modules():
+            for name in ("_packed", "_top_packed"):
+                pk = getattr(m, name, None)
+                if pk is not None:
+                    pk.log = self._pack_log
+
+    def prepack(self):
+        """Issue every weight re-layout the previous step needed (and that is stale now) in one launch."""
+        if self._pack_log:
+            with _PackBatch():
+                for pk, method, args in list(self._pack_log):
+                    getattr(pk, method)(*args)
 
     def invalidate_packed(self):
         """Drop every re-packed convolution weight (see MVSNeRF.invalidate_packed: needed after writes through `.data`)."""
@@ -898,6 +953,7 @@ class MVSNet(nn.Module):
     def forward(self, imgs, proj_mats, near_far, pad=0, return_color=False, lindisp=False):
         """reference models.py:895-932.  imgs (B,V,3,H,W) normalised; proj_mats (B,V,3,4); near_far (2,)."""
         B, V, _, H, W = imgs.shape
+        self.prepack()
         feats = self.feature(imgs.reshape(B * V, 3, H, W))
         feats_l = feats.view(B, V, *feats.shape[1:])
         t_vals = torch.linspace(0.0, 1.0, steps=self.D, device=imgs.device, dtype=imgs.dtype)
