@@ -106,6 +106,7 @@ class FlatGradAllReduce:
         self.group = group
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
+        self.views = None
 
     def __call__(self):
         if not _collective_needed(self.group) or not self.params:
@@ -113,24 +114,24 @@ class FlatGradAllReduce:
         dev = self.params[0].device
         if self.flat is None or self.flat.device != dev:
             self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:
-            n = p.numel()
+            self.views, off = [], 0
+            for p in self.params:
+                self.views.append(self.flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        # gather / scatter with one multi-tensor copy each (78 parameters: 156 single-tensor copies of a few microseconds otherwise)
+        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
+        for v, p in zip(self.views, self.params):
             if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
+                v.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.div_(dist.get_world_size(self.group))
-        off = 0
-        for p in self.params:
-            n = p.numel()
+        for v, p in zip(self.views, self.params):
             if p.grad is None:
-                p.grad = self.flat[off:off + n].view_as(p).clone()
-            else:
-                p.grad.copy_(self.flat[off:off + n].view_as(p))
-            off += n
+                p.grad = v.clone()
+        if have:
+            torch._foreach_copy_([g for _, g in have], [v for v, _ in have])
 
 
 def render_frame(render_chunk, H, W, chunk, group=None):
