@@ -132,6 +132,10 @@ int mvsnerf_conv3d_mfma_fwd(const float* x1, const float* scale1, const float* s
  * mvsnerf_conv3d_pack_weights_mfma; raw out[2D][2H][2W][Cout]. */
 int mvsnerf_conv_transpose3d_mfma_supported(int Cin, int Cout);
 int mvsnerf_conv_transpose3d_mfma_fwd(const float* x, int Cin, int D, int H, int W, const float* w32, int Cout, float* out, void* stream);
+/* The 16 -> 8 layer (conv11, and conv1's data gradient) without padded products on v_mfma_f32_4x4x1 (the parity-class form above spends
+ * 44 % of its products on zero weights at 8 output channels).  wq: [ci/4][tap][co][4] = mvsnerf_pack_weights_multi kind 1 of the layer. */
+int mvsnerf_conv_transpose3d_c8_supported(int Cin, int Cout);
+int mvsnerf_conv_transpose3d_c8_fwd(const float* x, int Cin, int D, int H, int W, const float* wq, float* out, void* stream);
 int mvsnerf_conv_transpose3d_fwd(const float* x1, const float* scale1, const float* shift1,
                                  const float* x2, const float* scale2, const float* shift2,
                                  int Cin, int D, int H, int W, const float* wpacked, int Cout, float* out, void* stream);

@@ -90,6 +90,8 @@ SIGNATURES = {
     "mvsnerf_conv3d_mfma_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_fp, _c_fp]),
     "mvsnerf_conv_transpose3d_mfma_supported": (_c_i, [_c_i, _c_i]),
     "mvsnerf_conv_transpose3d_mfma_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_conv_transpose3d_c8_supported": (_c_i, [_c_i, _c_i]),
+    "mvsnerf_conv_transpose3d_c8_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_conv3d_pack_weights_c8": (_c_i, [_c_fp, _c_i, _c_fp, _c_fp]),
     "mvsnerf_conv3d_c8_blocked_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_conv3d_c8_blocked_wgrad": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_fp]),

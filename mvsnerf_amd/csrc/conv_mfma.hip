@@ -731,6 +731,98 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_wgrad4_kernel(const flo
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Transposed 3x3x3 convolution, stride 2, 16 -> 8 channels (conv11, models.py:751; the data gradient of conv1 has the same shape) on
+// v_mfma_f32_4x4x1_16B_f32.  The parity-class kernel above spends 44 % of its products on zero weights at 8 output channels (170 us for
+// 4 GFLOP and 188 MB).  Here the 16 blocks are 8 input-voxel quads x 2 output-channel quads and a class's taps are enumerated exactly:
+// an output of parity p in one dimension takes (k = 1, input j) for p = 0 and (k = 0, input j + 1), (k = 2, input j) for p = 1, so input
+// offset (dz, dy, dx) in {0,1}^3 serves 2^(number of zeros) (class, tap) pairs, 27 in all.  A wave owns two M-tiles (two input rows x 16 x
+// each) and all 8 classes (64 accumulator registers); per (offset, channel quad) it reads the A operands once (one ds_read_b128 per
+// M-tile: four k-steps) and, per pair, one b128 of weights for 8 MFMAs.  Input tile [ci/4][voxel][4] (conflict-free operand reads),
+// weights [ci/4][tap][co][4] (mvsnerf_pack_weights_multi kind 1 / mvsnerf_conv3d_pack_weights_c8 of the layer's packed weights).
+constexpr int CT8_TX = 16, CT8_TY = 8, CT8_TZ = 2;
+constexpr int CT8_PX = CT8_TX + 1, CT8_PY = CT8_TY + 1, CT8_PZ = CT8_TZ + 1;
+constexpr int CT8_NVH = CT8_PX * CT8_PY * CT8_PZ;                     // 459
+
+__global__ __launch_bounds__(256) void convT3d_k3s2_c16to8_mfma4_kernel(const float* __restrict__ x, int Di, int Hi, int Wi,
+                                                                       const float* __restrict__ wq, float* __restrict__ out, int swz)
+{
+    __shared__ __attribute__((aligned(16))) float xt[4 * CT8_NVH * 4];      // [ci quad][halo voxel][4]
+    __shared__ __attribute__((aligned(16))) float wt[4 * 27 * 8 * 4];       // [ci quad][tap][co][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nbx = (Wi + CT8_TX - 1) / CT8_TX, nby = (Hi + CT8_TY - 1) / CT8_TY;
+    const int tile_id = swz ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int bx = tile_id % nbx, by = (tile_id / nbx) % nby, bz = tile_id / (nbx * nby);
+    const int x0 = bx * CT8_TX, y0 = by * CT8_TY, z0 = bz * CT8_TZ;
+    for (int i = tid; i < 4 * 27 * 8; i += 256) *reinterpret_cast<f32x4*>(wt + i * 4) = *reinterpret_cast<const f32x4*>(wq + i * 4);
+    for (int it = tid; it < 4 * CT8_NVH; it += 256) {
+        const int cq = it & 3, v = it >> 2;
+        const int vx = v % CT8_PX, vy = (v / CT8_PX) % CT8_PY, vz = v / (CT8_PX * CT8_PY);
+        const int gx = x0 + vx, gy = y0 + vy, gz = z0 + vz;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (gx < Wi && gy < Hi && gz < Di) val = *reinterpret_cast<const f32x4*>(x + (((int64_t)gz * Hi + gy) * Wi + gx) * 16 + cq * 4);
+        *reinterpret_cast<f32x4*>(xt + (cq * CT8_NVH + v) * 4) = val;
+    }
+    __syncthreads();
+    const int mb = lane >> 3, nb = (lane >> 2) & 1, li = lane & 3;
+    const int m = mb * 4 + li;                                        // A operand: this lane's voxel of the M-tile (row m >> 4, x m & 15)
+    // the wave's two M-tiles: tile rows (2 r2, 2 r2 + 1) of plane tz, M-tile index mt = wave * 2 + r -> tz = mt >> 2, r2 = mt & 3
+    f32x4 acc[8][2];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { acc[c][0] = f32x4{0, 0, 0, 0}; acc[c][1] = f32x4{0, 0, 0, 0}; }
+    int abase[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int mt = wave * 2 + r, tz = mt >> 2, r2 = mt & 3;
+        abase[r] = ((tz * CT8_PY + r2 * 2 + (m >> 4)) * CT8_PX + (m & 15)) * 4;
+    }
+    const float* wl = wt + (nb * 4 + li) * 4;                         // B operand: this lane's output channel 4 nb + li
+#pragma unroll
+    for (int off = 0; off < 8; ++off) {
+        const int dz = off >> 2, dy = (off >> 1) & 1, dx = off & 1;
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) {
+            f32x4 a[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) a[r] = *reinterpret_cast<const f32x4*>(xt + cq * (CT8_NVH * 4) + abase[r] + ((dz * CT8_PY + dy) * CT8_PX + dx) * 4);
+            // the (class, tap) pairs of this offset: per dimension d = 0 -> (p, k) in {(0, 1), (1, 2)}, d = 1 -> (1, 0)
+#pragma unroll
+            for (int sz = 0; sz < (dz ? 1 : 2); ++sz)
+#pragma unroll
+                for (int sy = 0; sy < (dy ? 1 : 2); ++sy)
+#pragma unroll
+                    for (int sx = 0; sx < (dx ? 1 : 2); ++sx) {
+                        const int pz = dz ? 1 : sz, kz = dz ? 0 : 1 + sz;
+                        const int py = dy ? 1 : sy, ky = dy ? 0 : 1 + sy;
+                        const int px = dx ? 1 : sx, kx = dx ? 0 : 1 + sx;
+                        const int cls = pz * 4 + py * 2 + px, tap = (kz * 3 + ky) * 3 + kx;
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(wl + ((cq * 27 + tap) * 8) * 4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            acc[cls][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0][k], b[k], acc[cls][0], 0, 0, 0);
+                            acc[cls][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1][k], b[k], acc[cls][1], 0, 0, 0);
+                        }
+                    }
+        }
+    }
+    // D: register q of lane (mb, nb, li) = (voxel 4 mb + q of the M-tile, channel 4 nb + li)
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int mt = wave * 2 + r, jz = z0 + (mt >> 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int mm = mb * 4 + q, jy = y0 + (mt & 3) * 2 + (mm >> 4), jx = x0 + (mm & 15);
+            if (jz >= Di || jy >= Hi || jx >= Wi) continue;
+#pragma unroll
+            for (int cls = 0; cls < 8; ++cls) {
+                const int oz = 2 * jz + (cls >> 2), oy = 2 * jy + ((cls >> 1) & 1), ox = 2 * jx + (cls & 1);
+                out[(((int64_t)oz * Ho + oy) * Wo + ox) * 8 + nb * 4 + li] = acc[cls][r][q];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // Called by mvsnerf_conv3d_fwd (encoder.hip) for the layers with 32 / 64 output channels; MVSNERF_EUNSUPPORTED = not instantiated.
@@ -749,6 +841,15 @@ int mvs_conv3d_mfma32(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int
         default: return MVSNERF_EUNSUPPORTED;
     }
 #undef MVS_M32
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// conv11-shaped transposed convolution (16 -> 8) without padded products (mvsnerf_conv_transpose3d_c8_fwd); wq: [ci/4][tap][co][4]
+int mvs_convT3d_c16to8_mfma4(const float* x, int D, int H, int W, const float* wq, float* out, int xcd, hipStream_t st)
+{
+    const unsigned grid = (unsigned)(((W + CT8_TX - 1) / CT8_TX) * ((H + CT8_TY - 1) / CT8_TY) * ((D + CT8_TZ - 1) / CT8_TZ));
+    convT3d_k3s2_c16to8_mfma4_kernel<<<grid, 256, 0, st>>>(x, D, H, W, wq, out, xcd);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }

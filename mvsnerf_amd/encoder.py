@@ -402,9 +402,9 @@ class _PackedConv:
     def get(self, mode="fwd"):
         return self._cached(mode, 0, mode, "get", mode)
 
-    def get_c8(self):
-        """[ci/4][tap][co][4] layout of the forward weights for the DMA-staged matrix-core conv0 (8 output channels)."""
-        return self._cached("fwd_c8", 1, "fwd", "get_c8")
+    def get_c8(self, mode="fwd"):
+        """[ci/4][tap][co][4] layout of get(mode)'s weights: the DMA-staged matrix-core conv0 and the 16 -> 8 transposed layer."""
+        return self._cached(mode + "_c8", 1, mode, "get_c8", mode)
 
     def get_dgrad_slice(self, c0, n):
         """get("dgrad") restricted to the layer inputs c0 .. c0+n-1 (stride-1 Conv3d): [27][cout][n], mirrored taps.  The plane sweep's
@@ -493,6 +493,10 @@ def _conv_t(src1, src2, dims_in, wbuf, cin_k, cout_k, packed=None, mode="fwd"):
     packed (+ mode): the layer's _PackedConv - a plain (materialised) input then takes the matrix-core kernel."""
     D, H, W, _ = dims_in
     out = torch.empty((2 * D, 2 * H, 2 * W, cout_k), device=wbuf.device, dtype=torch.float32)
+    if packed is not None and src2 is None and torch.is_tensor(src1) and _lib.lib().mvsnerf_conv_transpose3d_c8_supported(cin_k, cout_k):
+        check(_lib.lib().mvsnerf_conv_transpose3d_c8_fwd(src1.data_ptr(), cin_k, D, H, W, packed.get_c8(mode).data_ptr(), out.data_ptr(), stream_ptr()),
+              "conv_transpose3d_c8_fwd")
+        return out
     if (packed is not None and src2 is None and torch.is_tensor(src1) and cin_k % 8 == 0
             and _lib.lib().mvsnerf_conv_transpose3d_mfma_supported(cin_k, cout_k)):
         check(_lib.lib().mvsnerf_conv_transpose3d_mfma_fwd(src1.data_ptr(), cin_k, D, H, W, packed.get_mfma(mode).data_ptr(), cout_k,
