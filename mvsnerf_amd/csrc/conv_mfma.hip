@@ -35,6 +35,22 @@ namespace {
 
 __device__ const f32x4 g_zero16 = {0.0f, 0.0f, 0.0f, 0.0f};   // what a DMA lane reads for a voxel outside the volume (zero padding)
 
+// Per-workgroup InPlaceABN statistics of an 8-channel output tile straight from the accumulators (the layer's raw output is not read
+// again by abn_partial_kernel: 150 MB for the two full-resolution layers): lane (mb, nb, i) holds values of channel 4 nb + i only, so a
+// lane sums its own values, the 8 lanes of a channel meet by xor-shuffle over the mb bits, the 4 waves in LDS; workgroup `slot` writes
+// part[(slot * 2 + {sum, sum of squares}) * 8 + channel] - the layout abn_finalize_kernel reads.
+__device__ __forceinline__ void c8_tile_stats(float s, float q, int lane, int wave, float* red /* [4][16] */, float* __restrict__ part, int slot)
+{
+#pragma unroll
+    for (int o = 8; o <= 32; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if (lane < 8) { red[wave * 16 + lane] = s; red[wave * 16 + 8 + lane] = q; }
+    __syncthreads();
+    if (wave == 0 && lane < 16) {
+        const float v = (red[lane] + red[16 + lane]) + (red[32 + lane] + red[48 + lane]);
+        part[((int64_t)slot * 2 + (lane >> 3)) * 8 + (lane & 7)] = v;
+    }
+}
+
 constexpr int TX = 16, TY = 16, TZ = 4;             // output tile
 constexpr int PX = TX + 2, PY = TY + 2, PZ = TZ + 2; // staged input tile
 constexpr int NVOX = PZ * PY * PX;                   // 1944
@@ -321,7 +337,7 @@ __device__ __forceinline__ void mfma_chunk4(const float* __restrict__ wtile, con
 
 template <int CIN, int CREAL>
 __global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_mfma4_kernel(const float* __restrict__ x4, int D, int H, int W, const float* __restrict__ wq,
-                                                                     float* __restrict__ out, int swz)
+                                                                     float* __restrict__ out, int swz, float* __restrict__ stats)
 {
     static_assert(CIN % 4 == 0 && CREAL <= CIN && CREAL > CIN - 4, "chunks of four channels; only the last one may be partly padding");
     constexpr int NCH = CIN / 4;
@@ -372,15 +388,24 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_mfma4_kernel(const floa
     }
     const int blk = lane >> 2, i = lane & 3, mb = blk >> 1, nb = blk & 1;
     const int oz = bz * TZ + wave;
-    if (oz >= D) return;
+    float ssum = 0.f, ssq = 0.f;
+    if (oz < D) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = mb * 4 + r;
-            const int ox = bx * TX + (m & 15), oy = by * TY + t + 8 * (m >> 4);
-            if (ox < W && oy < H) out[(((int64_t)oz * H + oy) * W + ox) * 8 + nb * 4 + i] = acc[t][r];
-        }
+            for (int r = 0; r < 4; ++r) {
+                const int m = mb * 4 + r;
+                const int ox = bx * TX + (m & 15), oy = by * TY + t + 8 * (m >> 4);
+                if (ox < W && oy < H) {
+                    out[(((int64_t)oz * H + oy) * W + ox) * 8 + nb * 4 + i] = acc[t][r];
+                    ssum += acc[t][r]; ssq = fmaf(acc[t][r], acc[t][r], ssq);
+                }
+            }
+    }
+    if (stats) {
+        __syncthreads();                                          // the tiles are free: reuse their first floats
+        c8_tile_stats(ssum, ssq, lane, wave, lds4, stats, tile_id);
+    }
 }
 
 // packed[tap][ci][8] (mvsnerf_conv3d_pack_weights, Cout = 8) -> wq[ci/4][tap][co][4]
@@ -745,7 +770,8 @@ constexpr int CT8_PX = CT8_TX + 1, CT8_PY = CT8_TY + 1, CT8_PZ = CT8_TZ + 1;
 constexpr int CT8_NVH = CT8_PX * CT8_PY * CT8_PZ;                     // 459
 
 __global__ __launch_bounds__(256) void convT3d_k3s2_c16to8_mfma4_kernel(const float* __restrict__ x, int Di, int Hi, int Wi,
-                                                                       const float* __restrict__ wq, float* __restrict__ out, int swz)
+                                                                       const float* __restrict__ wq, float* __restrict__ out, int swz,
+                                                                       float* __restrict__ stats)
 {
     __shared__ __attribute__((aligned(16))) float xt[4 * CT8_NVH * 4];      // [ci quad][halo voxel][4]
     __shared__ __attribute__((aligned(16))) float wt[4 * 27 * 8 * 4];       // [ci quad][tap][co][4]
@@ -807,6 +833,7 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_c16to8_mfma4_kernel(const fl
     }
     // D: register q of lane (mb, nb, li) = (voxel 4 mb + q of the M-tile, channel 4 nb + li)
     const int Ho = 2 * Hi, Wo = 2 * Wi;
+    float ssum = 0.f, ssq = 0.f;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int mt = wave * 2 + r, jz = z0 + (mt >> 2);
@@ -818,8 +845,13 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_c16to8_mfma4_kernel(const fl
             for (int cls = 0; cls < 8; ++cls) {
                 const int oz = 2 * jz + (cls >> 2), oy = 2 * jy + ((cls >> 1) & 1), ox = 2 * jx + (cls & 1);
                 out[(((int64_t)oz * Ho + oy) * Wo + ox) * 8 + nb * 4 + li] = acc[cls][r][q];
+                ssum += acc[cls][r][q]; ssq = fmaf(acc[cls][r][q], acc[cls][r][q], ssq);
             }
         }
+    }
+    if (stats) {
+        __syncthreads();                                              // the input tile is free
+        c8_tile_stats(ssum, ssq, lane, wave, xt, stats, tile_id);
     }
 }
 
@@ -846,10 +878,12 @@ int mvs_conv3d_mfma32(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int
 }
 
 // conv11-shaped transposed convolution (16 -> 8) without padded products (mvsnerf_conv_transpose3d_c8_fwd); wq: [ci/4][tap][co][4]
-int mvs_convT3d_c16to8_mfma4(const float* x, int D, int H, int W, const float* wq, float* out, int xcd, hipStream_t st)
+int mvs_convT3d_c16to8_tiles(int D, int H, int W) { return ((W + CT8_TX - 1) / CT8_TX) * ((H + CT8_TY - 1) / CT8_TY) * ((D + CT8_TZ - 1) / CT8_TZ); }
+
+int mvs_convT3d_c16to8_mfma4(const float* x, int D, int H, int W, const float* wq, float* out, int xcd, float* stats, hipStream_t st)
 {
-    const unsigned grid = (unsigned)(((W + CT8_TX - 1) / CT8_TX) * ((H + CT8_TY - 1) / CT8_TY) * ((D + CT8_TZ - 1) / CT8_TZ));
-    convT3d_k3s2_c16to8_mfma4_kernel<<<grid, 256, 0, st>>>(x, D, H, W, wq, out, xcd);
+    const unsigned grid = (unsigned)mvs_convT3d_c16to8_tiles(D, H, W);
+    convT3d_k3s2_c16to8_mfma4_kernel<<<grid, 256, 0, st>>>(x, D, H, W, wq, out, xcd, stats);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
@@ -913,11 +947,13 @@ int mvs_conv3d_c8_wgrad4(const float* x4, int Cin, int cin_real, int D, int H, i
 }
 
 // conv0 on a cost volume in channel blocks of four (mvsnerf_conv3d_c8_blocked_fwd)
-int mvs_conv3d_c8_mfma4(const float* x4, int Cin, int cin_real, int D, int H, int W, const float* wq, float* out, int xcd, hipStream_t st)
+int mvs_conv3d_c8_mfma4_tiles(int D, int H, int W) { return ((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ); }
+
+int mvs_conv3d_c8_mfma4(const float* x4, int Cin, int cin_real, int D, int H, int W, const float* wq, float* out, int xcd, float* stats, hipStream_t st)
 {
     if ((int64_t)D * H * W * 4 >= (int64_t)1 << 31) return MVSNERF_EUNSUPPORTED;
     const unsigned grid = (unsigned)(((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ));
-#define MVS_L4(CIN, CREAL) case CIN * 100 + CREAL: conv3d_k3s1_c8_mfma4_kernel<CIN, CREAL><<<grid, 256, 0, st>>>(x4, D, H, W, wq, out, xcd); break
+#define MVS_L4(CIN, CREAL) case CIN * 100 + CREAL: conv3d_k3s1_c8_mfma4_kernel<CIN, CREAL><<<grid, 256, 0, st>>>(x4, D, H, W, wq, out, xcd, stats); break
     switch (Cin * 100 + cin_real) {
         MVS_L4(32, 32); MVS_L4(36, 35); MVS_L4(40, 38); MVS_L4(44, 41); MVS_L4(44, 44); MVS_L4(48, 47); MVS_L4(52, 50); MVS_L4(56, 53); MVS_L4(56, 56);
         default: return MVSNERF_EUNSUPPORTED;

@@ -647,7 +647,8 @@ extern "C" int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const fl
     return MVSNERF_OK;
 }
 
-int mvs_conv3d_c8_mfma4(const float* x4, int Cin, int cin_real, int D, int H, int W, const float* wq, float* out, int xcd, hipStream_t st);
+int mvs_conv3d_c8_mfma4(const float* x4, int Cin, int cin_real, int D, int H, int W, const float* wq, float* out, int xcd, float* stats, hipStream_t st);
+int mvs_conv3d_c8_mfma4_tiles(int D, int H, int W);
 int mvs_conv_w4_repack(const float* wpacked, float* wq, int Cin, hipStream_t st);
 
 extern "C" int mvsnerf_conv3d_pack_weights_c8(const float* wpacked, int Cin, float* wq, void* stream)
@@ -660,7 +661,19 @@ extern "C" int mvsnerf_conv3d_c8_blocked_fwd(const float* x_blocked, int Cin, in
 {
     if (!x_blocked || !wq || !out || D < 1 || H < 1 || W < 1 || Cin < 4 || (Cin & 3) || Cin_real < 1 || Cin_real > Cin) return MVSNERF_EINVAL;
     if (!mvs_aligned16(x_blocked) || !mvs_aligned16(out) || !mvs_aligned16(wq)) return MVSNERF_EALIGN;
-    return mvs_conv3d_c8_mfma4(x_blocked, Cin, Cin_real, D, H, W, wq, out, g_conv_xcd, (hipStream_t)stream);
+    return mvs_conv3d_c8_mfma4(x_blocked, Cin, Cin_real, D, H, W, wq, out, g_conv_xcd, nullptr, (hipStream_t)stream);
+}
+
+// The same convolution leaving the InPlaceABN statistics of its output as per-workgroup partial sums (stats_part: 2 * 8 floats per
+// workgroup, mvsnerf_conv3d_c8_blocked_tiles(D, H, W) workgroups; finish with mvsnerf_abn_finalize): the 150 MB output is not read again.
+extern "C" int mvsnerf_conv3d_c8_blocked_tiles(int D, int H, int W) { return mvs_conv3d_c8_mfma4_tiles(D, H, W); }
+
+extern "C" int mvsnerf_conv3d_c8_blocked_fwd_stats(const float* x_blocked, int Cin, int Cin_real, int D, int H, int W, const float* wq, float* out,
+                                                   float* stats_part, void* stream)
+{
+    if (!x_blocked || !wq || !out || !stats_part || D < 1 || H < 1 || W < 1 || Cin < 4 || (Cin & 3) || Cin_real < 1 || Cin_real > Cin) return MVSNERF_EINVAL;
+    if (!mvs_aligned16(x_blocked) || !mvs_aligned16(out) || !mvs_aligned16(wq)) return MVSNERF_EALIGN;
+    return mvs_conv3d_c8_mfma4(x_blocked, Cin, Cin_real, D, H, W, wq, out, g_conv_xcd, stats_part, (hipStream_t)stream);
 }
 
 // ---- the deep layers (32 / 64 output channels) on v_mfma_f32_32x32x2_f32 (conv_mfma.hip)
@@ -695,7 +708,8 @@ extern "C" int mvsnerf_conv_transpose3d_mfma_fwd(const float* x, int Cin, int D,
     return mvs_convT3d_mfma32(x, Cin, D, H, W, w32, Cout, out, (hipStream_t)stream);
 }
 
-int mvs_convT3d_c16to8_mfma4(const float* x, int D, int H, int W, const float* wq, float* out, int xcd, hipStream_t st);
+int mvs_convT3d_c16to8_mfma4(const float* x, int D, int H, int W, const float* wq, float* out, int xcd, float* stats, hipStream_t st);
+int mvs_convT3d_c16to8_tiles(int D, int H, int W);
 
 // ConvTranspose3d(16, 8, 3, stride 2, padding 1, output_padding 1) of a plain tensor x[D][H][W][16] -> out[2D][2H][2W][8] on
 // v_mfma_f32_4x4x1 without padded products; wq: the layer's weights as [ci/4][tap][co][4].  1 when the "conv_mfma" switch is on.
@@ -706,7 +720,17 @@ extern "C" int mvsnerf_conv_transpose3d_c8_fwd(const float* x, int Cin, int D, i
     if (!x || !wq || !out || D < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
     if (Cin != 16) return MVSNERF_EUNSUPPORTED;
     if (!mvs_aligned16(x) || !mvs_aligned16(wq) || !mvs_aligned16(out)) return MVSNERF_EALIGN;
-    return mvs_convT3d_c16to8_mfma4(x, D, H, W, wq, out, g_conv_xcd, (hipStream_t)stream);
+    return mvs_convT3d_c16to8_mfma4(x, D, H, W, wq, out, g_conv_xcd, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int mvsnerf_conv_transpose3d_c8_tiles(int D, int H, int W) { return mvs_convT3d_c16to8_tiles(D, H, W); }
+
+extern "C" int mvsnerf_conv_transpose3d_c8_fwd_stats(const float* x, int Cin, int D, int H, int W, const float* wq, float* out, float* stats_part, void* stream)
+{
+    if (!x || !wq || !out || !stats_part || D < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
+    if (Cin != 16) return MVSNERF_EUNSUPPORTED;
+    if (!mvs_aligned16(x) || !mvs_aligned16(wq) || !mvs_aligned16(out)) return MVSNERF_EALIGN;
+    return mvs_convT3d_c16to8_mfma4(x, D, H, W, wq, out, g_conv_xcd, stats_part, (hipStream_t)stream);
 }
 
 extern "C" int mvsnerf_conv_transpose3d_fwd(const float* x1, const float* scale1, const float* shift1,
@@ -827,6 +851,19 @@ extern "C" int mvsnerf_abn_stats(const float* x, int64_t n_vox, int C, const flo
     }
     MVS_LAUNCH_CHECK();
     abn_finalize_kernel<<<C, 256, 0, st>>>(workspace, nb, C, n_vox, weight, bias, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// stage 2 alone, for producers that leave the per-workgroup sums themselves (part[(b * 2 + {sum, sum of squares}) * C + c], b < n_blocks)
+extern "C" int mvsnerf_abn_finalize(const float* part, int n_blocks, int C, int64_t n_vox, const float* weight, const float* bias,
+                                    float* running_mean, float* running_var, float momentum, float eps,
+                                    float* scale, float* shift, float* mean_out, float* invstd_out, void* stream)
+{
+    if (!part || n_blocks < 1 || C < 1 || n_vox < 1 || !weight || !bias || !scale || !shift) return MVSNERF_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return MVSNERF_EINVAL;
+    abn_finalize_kernel<<<C, 256, 0, (hipStream_t)stream>>>(part, n_blocks, C, n_vox, weight, bias, running_mean, running_var, momentum, eps, scale, shift,
+                                                            mean_out, invstd_out);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }

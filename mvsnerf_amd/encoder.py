@@ -428,7 +428,9 @@ class _PackedConv:
         return self._cached(mode + "_m32", 2, mode, "get_mfma", mode)
 
 
-def _abn_stats(raw, n_vox, bn, update_running=True):
+def _abn_stats(raw, n_vox, bn, update_running=True, partials=None):
+    """Train-mode InPlaceABN statistics of a raw layer output -> (scale, shift, mean, invstd).  partials = (buffer, n_blocks): the
+    producing kernel already left per-workgroup sums (mvsnerf_*_fwd_stats), only stage 2 runs."""
     C = bn.num_features
     dev = raw.device
     out = torch.empty((4, C), device=dev, dtype=torch.float32)        # scale, shift, mean, invstd
@@ -441,9 +443,16 @@ def _abn_stats(raw, n_vox, bn, update_running=True):
             out[0] = (bn.weight.abs() + bn.eps) * out[3]
             out[1] = bn.bias - bn.running_mean * out[0]
         return out[0], out[1], out[2], out[3]
-    ws = torch.empty(_lib.lib().mvsnerf_abn_workspace_floats(C), device=dev, dtype=torch.float32)
     rm = bn.running_mean.data_ptr() if update_running else 0
     rv = bn.running_var.data_ptr() if update_running else 0
+    if partials is not None:
+        check(_lib.lib().mvsnerf_abn_finalize(partials[0].data_ptr(), partials[1], C, n_vox, dev_f32(bn.weight.detach(), "bn.weight"),
+                                              dev_f32(bn.bias.detach(), "bn.bias"), rm, rv, bn.momentum, bn.eps, out[0].data_ptr(), out[1].data_ptr(),
+                                              out[2].data_ptr(), out[3].data_ptr(), stream_ptr()), "abn_finalize")
+        if update_running:
+            _NBT_PENDING.append(bn.num_batches_tracked)
+        return out[0], out[1], out[2], out[3]
+    ws = torch.empty(_lib.lib().mvsnerf_abn_workspace_floats(C), device=dev, dtype=torch.float32)
     check(_lib.lib().mvsnerf_abn_stats(raw.data_ptr(), n_vox, C, dev_f32(bn.weight.detach(), "bn.weight"), dev_f32(bn.bias.detach(), "bn.bias"),
                                        rm, rv, bn.momentum, bn.eps, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
                                        ws.data_ptr(), stream_ptr()), "abn_stats")
@@ -488,23 +497,32 @@ def _conv(src1, src2, dims_in, cin_ld, wbuf, cin_k, cout_k, stride, packed=None,
     return out
 
 
-def _conv_t(src1, src2, dims_in, wbuf, cin_k, cout_k, packed=None, mode="fwd"):
+def _conv_t(src1, src2, dims_in, wbuf, cin_k, cout_k, packed=None, mode="fwd", want_stats=None):
     """k3 s2 p1 op1 transposed-convolution kernel launch: (D,H,W,cin_k) -> raw (2D,2H,2W,cout_k).
-    packed (+ mode): the layer's _PackedConv - a plain (materialised) input then takes the matrix-core kernel."""
+    packed (+ mode): the layer's _PackedConv - a plain (materialised) input then takes the matrix-core kernel.
+    want_stats None: returns out; True / False: returns (out, partials) - partials = the InPlaceABN partial sums of `out` when the kernel
+    could leave them (only asked for with True), else None."""
     D, H, W, _ = dims_in
     out = torch.empty((2 * D, 2 * H, 2 * W, cout_k), device=wbuf.device, dtype=torch.float32)
     if packed is not None and src2 is None and torch.is_tensor(src1) and _lib.lib().mvsnerf_conv_transpose3d_c8_supported(cin_k, cout_k):
-        check(_lib.lib().mvsnerf_conv_transpose3d_c8_fwd(src1.data_ptr(), cin_k, D, H, W, packed.get_c8(mode).data_ptr(), out.data_ptr(), stream_ptr()),
+        lib = _lib.lib()
+        if want_stats and FUSED_ABN_STATS:       # the caller's InPlaceABN statistics come out of the same launch: returns (out, partials)
+            nblk = lib.mvsnerf_conv_transpose3d_c8_tiles(D, H, W)
+            part = torch.empty(nblk * 16, device=out.device, dtype=torch.float32)
+            check(lib.mvsnerf_conv_transpose3d_c8_fwd_stats(src1.data_ptr(), cin_k, D, H, W, packed.get_c8(mode).data_ptr(), out.data_ptr(), part.data_ptr(),
+                                                            stream_ptr()), "conv_transpose3d_c8_fwd_stats")
+            return out, (part, nblk)
+        check(lib.mvsnerf_conv_transpose3d_c8_fwd(src1.data_ptr(), cin_k, D, H, W, packed.get_c8(mode).data_ptr(), out.data_ptr(), stream_ptr()),
               "conv_transpose3d_c8_fwd")
-        return out
+        return out if want_stats is None else (out, None)
     if (packed is not None and src2 is None and torch.is_tensor(src1) and cin_k % 8 == 0
             and _lib.lib().mvsnerf_conv_transpose3d_mfma_supported(cin_k, cout_k)):
         check(_lib.lib().mvsnerf_conv_transpose3d_mfma_fwd(src1.data_ptr(), cin_k, D, H, W, packed.get_mfma(mode).data_ptr(), cout_k,
                                                            out.data_ptr(), stream_ptr()), "conv_transpose3d_mfma_fwd")
-        return out
+        return out if want_stats is None else (out, None)
     check(_lib.lib().mvsnerf_conv_transpose3d_fwd(*_ptrs(src1), *_ptrs(src2), cin_k, D, H, W, wbuf.data_ptr(), cout_k,
                                                   out.data_ptr(), stream_ptr()), "conv_transpose3d_fwd")
-    return out
+    return out if want_stats is None else (out, None)
 
 
 def _apply_add(a, b=None):
@@ -548,6 +566,7 @@ class ConvBnReLU3D(nn.Module):
 
 
 MATERIALIZE_UP_INPUT = True     # A/B switch (scratch/enc_time.py)
+FUSED_ABN_STATS = True          # A/B switch: the 8-channel producers (conv0, conv11) leave their InPlaceABN partial sums themselves
 BLOCKED_COST = True             # A/B switch: MVSNet.forward hands conv0 a channel-blocked cost volume on the no-grad path
 _BLOCKED_CIN = (32, 36, 40, 44, 48, 52, 56)   # conv0 input widths the matrix-core kernel is instantiated for
 
@@ -564,9 +583,9 @@ class _UpBlock(nn.Sequential):
         if MATERIALIZE_UP_INPUT and isinstance(src1, _Lazy):
             # every input voxel feeds 27/8 output voxels on average: activate (and sum the skip) once instead of per tap
             src1, src2 = _apply_add(src1, src2), None
-        raw = _conv_t(src1, src2, dims_in, pk.get(), pk.cin_pad, pk.cout, packed=pk)
+        raw, partials = _conv_t(src1, src2, dims_in, pk.get(), pk.cin_pad, pk.cout, packed=pk, want_stats=self[1].training)
         D, H, W, C = raw.shape
-        scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self[1], update_running=self[1].training)
+        scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self[1], update_running=self[1].training, partials=partials)
         return _Lazy(raw, scale, shift, (D, H, W, C), mean, invstd)
 
     def forward(self, x):
@@ -612,9 +631,18 @@ class CostRegNet(nn.Module):
             if x.cin_pad != pk.cin_pad:
                 raise RuntimeError(f"CostRegNet: blocked cost volume has {x.cin_pad} channels, conv0 expects {pk.cin_pad}")
             raw = torch.empty((D, H, W, pk.cout), device=x.buf.device, dtype=torch.float32)
-            check(_lib.lib().mvsnerf_conv3d_c8_blocked_fwd(x.buf.data_ptr(), pk.cin_pad, pk.cin, D, H, W, pk.get_c8().data_ptr(), raw.data_ptr(), stream_ptr()),
-                  "conv3d_c8_blocked_fwd")
-            scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self.conv0.bn, update_running=self.conv0.bn.training)
+            lib = _lib.lib()
+            if self.conv0.bn.training and FUSED_ABN_STATS:
+                nblk = lib.mvsnerf_conv3d_c8_blocked_tiles(D, H, W)
+                part = torch.empty(nblk * 16, device=raw.device, dtype=torch.float32)
+                check(lib.mvsnerf_conv3d_c8_blocked_fwd_stats(x.buf.data_ptr(), pk.cin_pad, pk.cin, D, H, W, pk.get_c8().data_ptr(), raw.data_ptr(),
+                                                              part.data_ptr(), stream_ptr()), "conv3d_c8_blocked_fwd_stats")
+                partials = (part, nblk)
+            else:
+                check(lib.mvsnerf_conv3d_c8_blocked_fwd(x.buf.data_ptr(), pk.cin_pad, pk.cin, D, H, W, pk.get_c8().data_ptr(), raw.data_ptr(), stream_ptr()),
+                      "conv3d_c8_blocked_fwd")
+                partials = None
+            scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self.conv0.bn, update_running=self.conv0.bn.training, partials=partials)
             c0 = _Lazy(raw, scale, shift, (D, H, W, pk.cout), mean, invstd)
             buf, ld = None, 0
         else:

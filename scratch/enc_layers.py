@@ -7,11 +7,12 @@ rig = make_rig(512, 640, seed=1234)
 dev = torch.device('cuda')
 ref = None
 L = _lib.lib()
-for blocked, mfma in ((True, 1), (False, 1), (False, 0), (True, 1)):
+for blocked, mfma, fused in ((True, 1, True), (True, 1, False), (False, 1, True), (False, 0, True), (True, 1, False), (True, 1, True)):
     encoder.BLOCKED_COST = blocked
+    encoder.FUSED_ABN_STATS = fused
     L.mvsnerf_tune(b"conv_mfma", mfma)
     vol, t = encoder.bench_encode(rig, dev, 24, iters=6)
     if ref is None:
         ref = vol.clone()
-    print("blocked", blocked, "conv_mfma", mfma, t, "max |vol - first|", float((vol - ref).abs().max()))
+    print("blocked", blocked, "conv_mfma", mfma, "fused_abn_stats", fused, t, "max |vol - first|", float((vol - ref).abs().max()))
 L.mvsnerf_tune(b"conv_mfma", 1)
