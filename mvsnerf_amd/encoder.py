@@ -72,9 +72,8 @@ class _PackBatch:
 
     def __exit__(self, *exc):
         _PackBatch.active = None
-        if exc[0] is None:
-            _PackBatch.launch(self.jobs)
-        self.jobs = []
+        jobs, self.jobs = self.jobs, []
+        _PackBatch.launch(jobs)        # also on an exception: the getters have already cached these buffers as packed
         return False
 
     @staticmethod
