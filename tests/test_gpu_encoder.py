@@ -269,3 +269,76 @@ def test_conv3d_wgrad_matrix_cores_vs_rows_kernel(A, B, stride, dims, g2, xact):
     print(f"[conv3d wgrad A={A} B={B} s{stride} {Do}x{Ho}x{Wo}] rows {ms[0]:.3f} ms, matrix cores {ms[1]:.3f} ms ({gf / ms[1]:.1f} TFLOP/s); "
           f"max diff {err:.2e} (|gw| max {scale:.1f})")
     assert torch.isfinite(out[1]).all() and err < 2e-5 * scale
+
+
+def test_pack_weights_multi_equals_the_single_layout_entries():
+    """mvsnerf_pack_weights_multi (all weight layouts of a step in one launch, straight from the layer's weight tensor) must give the
+    bytes of the per-layout entries it replaces: conv3d_pack_weights, + _c8 and _mfma re-layouts of that result, conv2d_pack_weights."""
+    import ctypes
+    from mvsnerf_amd import _lib
+    from mvsnerf_amd.ops import stream_ptr
+    L = _lib.lib()
+    g = torch.Generator(DEV).manual_seed(5)
+    w3 = torch.randn((16, 41, 3, 3, 3), device=DEV, generator=g)            # Conv3d(41 -> 16): fwd, cin padded to 44
+    wt = torch.randn((32, 16, 3, 3, 3), device=DEV, generator=g)            # ConvTranspose3d(32 -> 16)
+    w2 = torch.randn((16, 8, 5, 5), device=DEV, generator=g)                # Conv2d(8 -> 16, k5)
+    jobs, refs = [], []
+
+    def ref3(w, ci_real, co_real, ci_pad, co_pad, s_ci, s_co, flip):
+        buf = torch.empty(27 * ci_pad * co_pad, device=DEV)
+        assert L.mvsnerf_conv3d_pack_weights(w.data_ptr(), ci_real, co_real, ci_pad, co_pad, s_ci, s_co, flip, buf.data_ptr(), stream_ptr()) == 0
+        return buf
+
+    # kind 0: forward of the Conv3d, data gradient (flip) of it, forward of the transposed layer
+    for (w, q) in ((w3, (41, 16, 44, 16, 27, 41 * 27, 0)), (w3, (16, 41, 16, 44, 41 * 27, 27, 1)), (wt, (32, 16, 32, 16, 16 * 27, 27, 0))):
+        refs.append(ref3(w, *q)); jobs.append((w, 0, 27, q))
+    # kind 1 (c8): 8-output layer from a 44-channel input
+    w8 = torch.randn((8, 41, 3, 3, 3), device=DEV, generator=g)
+    base = ref3(w8, 41, 8, 44, 8, 27, 41 * 27, 0)
+    c8 = torch.empty_like(base)
+    assert L.mvsnerf_conv3d_pack_weights_c8(base.data_ptr(), 44, c8.data_ptr(), stream_ptr()) == 0
+    refs.append(c8); jobs.append((w8, 1, 27, (41, 8, 44, 8, 27, 41 * 27, 0)))
+    # kind 2 (w32) of the transposed layer
+    m32 = torch.empty_like(refs[2])
+    assert L.mvsnerf_conv3d_pack_weights_mfma(refs[2].data_ptr(), 32, 16, m32.data_ptr(), stream_ptr()) == 0
+    refs.append(m32); jobs.append((wt, 2, 27, (32, 16, 32, 16, 16 * 27, 27, 0)))
+    # 2-D, k5, data gradient without flip
+    r2 = torch.empty(25 * 16 * 8, device=DEV)
+    assert L.mvsnerf_conv2d_pack_weights(w2.data_ptr(), 16, 8, 16, 8, 8 * 25, 25, 5, 0, r2.data_ptr(), stream_ptr()) == 0
+    refs.append(r2); jobs.append((w2, 0, 25, (16, 8, 16, 8, 8 * 25, 25, 0)))
+    n = len(jobs)
+    outs = [torch.full_like(r, float("nan")) for r in refs]
+    params = []
+    for (_, kind, ntaps, q) in jobs:
+        params += [kind, ntaps, *q]
+    rc = L.mvsnerf_pack_weights_multi(n, (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in jobs]), (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs]),
+                                      (ctypes.c_int * (9 * n))(*params), stream_ptr())
+    assert rc == 0
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert torch.equal(o, r), f"job {i}"
+
+
+def test_partial_sum_multi_matches_float64_sums():
+    import ctypes
+    from mvsnerf_amd import _lib
+    from mvsnerf_amd.ops import stream_ptr
+    L = _lib.lib()
+    g = torch.Generator(DEV).manual_seed(6)
+    shapes = [(1, 7), (31, 300), (32, 1000), (33, 64), (700, 5000), (2048, 513)]       # (partials, outputs): one slice / exactly 32 / several
+    parts = [torch.randn(s, device=DEV, generator=g) for s in shapes]
+    dsts = [torch.full((s[1],), float("nan"), device=DEV) for s in shapes]
+    n = len(shapes)
+    scratch = torch.empty(L.mvsnerf_partial_sum_multi_scratch_floats(sum(s[1] for s in shapes)), device=DEV)
+    rc = L.mvsnerf_partial_sum_multi(n, (ctypes.c_void_p * n)(*[p.data_ptr() for p in parts]), (ctypes.c_int * n)(*[s[0] for s in shapes]),
+                                     (ctypes.c_int64 * n)(*[s[1] for s in shapes]), (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts]),
+                                     scratch.data_ptr(), stream_ptr())
+    assert rc == 0
+    for p, d in zip(parts, dsts):
+        ref = p.double().sum(0)
+        assert float((d.double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+    # deterministic
+    d2 = [torch.empty_like(d) for d in dsts]
+    assert L.mvsnerf_partial_sum_multi(n, (ctypes.c_void_p * n)(*[p.data_ptr() for p in parts]), (ctypes.c_int * n)(*[s[0] for s in shapes]),
+                                       (ctypes.c_int64 * n)(*[s[1] for s in shapes]), (ctypes.c_void_p * n)(*[d.data_ptr() for d in d2]),
+                                       scratch.data_ptr(), stream_ptr()) == 0
+    assert all(torch.equal(a, b) for a, b in zip(dsts, d2))
