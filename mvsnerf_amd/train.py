@@ -350,7 +350,7 @@ class MVSSystemFinetune(_ModuleShim):
         super().__init__()
         from .models import RefVolume
         self.args = args
-        self.args.feat_dim = 8 + 3 * 4
+        self.args.feat_dim = 8 + 4 * int(getattr(args, "n_views", 3))       # :39 hard-wires 3 source views (8 + 3*4); n_views is the config-4 extension
         if getattr(args, "use_color_volume", False) and getattr(args, "use_density_volume", False):
             raise NotImplementedError("--use_color_volume together with --use_density_volume: update_density_volume would concatenate the "
                                       "colours to a volume that already holds them (train_mvs_nerf_finetuning_pl.py:96); not supported")

@@ -175,6 +175,28 @@ def test_finetune_step_trains_volume_and_mlp():
     assert "feat_volume" in ft.volume.state_dict()
 
 
+def test_finetune_five_source_views_bf16():
+    """BASELINE config 4 names 5 source views and the bf16 MLP: `args.n_views = 5` (47-channel cost volume, feat_dim 28) through
+    MVSSystemFinetune - the reference hard-wires 8 + 3*4 (train_mvs_nerf_finetuning_pl.py:39)."""
+    from mvsnerf_amd import train
+    from mvsnerf_amd.synth import make_rig, pose_ref_of
+    V = 5
+    base = (0.0, 0.25, -0.25, 0.12, -0.12, 0.1)
+    rig = make_rig(64, 96, n_views=V + 1, seed=9, baselines=base, smooth=True)
+    pose = pose_ref_of(rig)
+    src = (rig["images"][:, :V], rig["proj_mats"][:, :V], rig["near_fars"][0, 0], {k: v[:V] for k, v in pose.items()})
+    args = train.default_args(pad=4, batch_size=256, N_samples=32, n_views=V, use_amp=True)
+    ft = train.MVSSystemFinetune(args, src, n_depth_planes=16).to(DEV)
+    assert args.feat_dim == 28 and ft.volume.feat_volume.shape == (1, 8, 16, 24, 32)
+    g = torch.Generator().manual_seed(1)
+    rays = torch.cat([torch.zeros(256, 3), torch.nn.functional.normalize(torch.randn(256, 3, generator=g) * 0.05 + torch.tensor([0., 0., 1.]), dim=1),
+                      torch.full((256, 1), 2.125), torch.full((256, 1), 4.525)], 1)
+    batch = {"rays": rays[None], "rgbs": torch.rand(1, 256, 3, generator=g)}
+    torch.manual_seed(0)
+    losses = ft.fit_steps([batch] * 8)
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+
+
 def test_use_amp_training_step_runs_bf16_and_learns():
     """args.use_amp (train_mvs_nerf_pl.py:317-318): the training step runs the MLP on the bf16 matrix cores; the loss stays close to
     the fp32 step's on the same draw and decreases over steps; parameters and gradients stay fp32."""
