@@ -213,3 +213,27 @@ def dev_f32(t, name):
         raise RuntimeError(f"{name}: tensor is on {t.device} but the current device is cuda:{torch.cuda.current_device()} "
                            "(call torch.cuda.set_device / use `with torch.cuda.device(...)` around the call)")
     return t.data_ptr()
+
+
+# ---- weight-cache epoch.  The packed-weight caches (models.MVSNeRF.packed*, encoder._PackedConv*) key on (data_ptr, tensor._version),
+# but a FUSED optimizer (`torch.optim.Adam(..., fused=True)`) updates the parameters without bumping `_version` (checked on torch 2.10:
+# version 0 -> 0), and a training loop would silently keep running on the first step's packed weights.  Every optimizer step anywhere
+# in the process therefore advances this counter, and it is part of every cache key.  (Writes through `.data` are still invisible:
+# invalidate_packed().)
+_WEIGHTS_EPOCH = [0]
+
+
+def _bump_weights_epoch(*_a, **_k):
+    _WEIGHTS_EPOCH[0] += 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_hook
+    _reg_hook(_bump_weights_epoch)
+except Exception:                                   # very old torch: no global hook; fused optimizers then need invalidate_packed()
+    pass
+
+
+def weights_epoch():
+    return _WEIGHTS_EPOCH[0]
+

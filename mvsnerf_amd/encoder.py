@@ -119,7 +119,7 @@ class _PackedConv2d:
 
     def get(self, mode="fwd"):
         w = self.conv.weight
-        key = (w.data_ptr(), w._version)
+        key = (w.data_ptr(), w._version, _lib.weights_epoch())
         hit = self.cache.get(mode)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -387,7 +387,7 @@ class _PackedConv:
 
     def _cached(self, name, kind, mode, method, *args):
         w = self.conv.weight
-        key = (w.data_ptr(), w._version)
+        key = (w.data_ptr(), w._version, _lib.weights_epoch())
         hit = self.cache.get(name)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -409,7 +409,7 @@ class _PackedConv:
         """get("dgrad") restricted to the layer inputs c0 .. c0+n-1 (stride-1 Conv3d): [27][cout][n], mirrored taps.  The plane sweep's
         backward needs the gradient of the variance channels only (the warped thumbnails carry no parameters)."""
         w = self.conv.weight
-        key = (w.data_ptr(), w._version, c0, n)
+        key = (w.data_ptr(), w._version, _lib.weights_epoch(), c0, n)
         hit = self.cache.get("dgrad_slice")
         if hit is not None and hit[0] == key:
             return hit[1]

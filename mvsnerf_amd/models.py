@@ -8,7 +8,7 @@ hand raw device pointers to the C ABI.
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from .renderer import run_network_mvs
 
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")   # reference models.py:657
@@ -95,14 +95,14 @@ class Renderer_ours(nn.Module):
                 "the HIP MLP kernel is specialised for netdepth=6, netwidth=128, skips=[4], multires=10, raw view dirs "
                 f"(got D={self.D}, W={self.W}, skips={self.skips}, in_ch_pts={self.in_ch_pts}, in_ch_views={self.in_ch_views})")
         lins = self._linears()
-        key = tuple((l.weight.data_ptr(), l.weight._version, l.bias.data_ptr(), l.bias._version) for l in lins)
+        key = (_lib.weights_epoch(),) + tuple((l.weight.data_ptr(), l.weight._version, l.bias.data_ptr(), l.bias._version) for l in lins)
         if self._packed is None or key != self._packed_key:
             self._packed = ops.mlp_pack([l.weight.detach() for l in lins], [l.bias.detach() for l in lins], F)
             self._packed_key = key
         return self._packed
 
     def invalidate_packed(self):
-        """Drop the packed-weight caches.  The caches key on (data_ptr, tensor._version); writes through `.data` (`p.data.copy_()`,
+        """Drop the packed-weight caches.  The caches key on (data_ptr, tensor._version, optimizer-step epoch - _lib.weights_epoch); writes through `.data` (`p.data.copy_()`,
         EMA updates on `.data`) do not bump `_version`, so code that updates weights that way must call this afterwards
         (MVSNet.invalidate_packed does the same for the encoder's convolution weights)."""
         self._packed = self._packed_key = None

@@ -53,7 +53,7 @@ def channels_last_volume(volume_feature):
     # cache key: storage identity + version.  The entry keeps the source storage alive, so the caching
     # allocator cannot hand the same address to a different tensor while the entry exists.
     st = v.untyped_storage()
-    key = (st.data_ptr(), v.storage_offset(), v._version, tuple(v.shape), tuple(v.stride()))
+    key = (st.data_ptr(), v.storage_offset(), v._version, _lib.weights_epoch(), tuple(v.shape), tuple(v.stride()))
     hit = _cl_cache.get("k")
     if hit is not None and hit[0] == key:
         return hit[2]

@@ -34,6 +34,13 @@ from .utils import build_rays, build_rays_test, img2mse
 _UNPRE = {}
 
 
+def _adam_kw(params):
+    """torch's single-kernel Adam when every parameter lives on the GPU (same update rule as the reference's torch.optim.Adam; the default
+    multi-tensor path makes ~8 passes over the parameters - 0.6 ms per fine-tuning step for the 150 MB learnable volume)."""
+    ps = list(params)
+    return {"fused": True} if ps and all(p.is_cuda and p.dtype == torch.float32 for p in ps) else {}
+
+
 def mse2psnr2(x):
     """utils.py:28-30.  A device tensor stays on the device (no host synchronisation inside the training step)."""
     import math
@@ -119,7 +126,7 @@ class MVSSystem(_ModuleShim):
 
     def configure_optimizers(self):
         """:84-88."""
-        self.optimizer = torch.optim.Adam(self.grad_vars, lr=self.learning_rate, betas=(0.9, 0.999))
+        self.optimizer = torch.optim.Adam(self.grad_vars, lr=self.learning_rate, betas=(0.9, 0.999), **_adam_kw(self.grad_vars))
         sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=self.args.num_epochs, eta_min=1e-7)
         return [self.optimizer], [sched]
 
@@ -482,5 +489,5 @@ class MVSSystemFinetune(_ModuleShim):
         return [float(l) for l in losses]                                   # one host synchronisation, after the last step is enqueued
 
     def configure_optimizers(self):
-        self.optimizer = torch.optim.Adam(self.grad_vars, lr=self.args.lrate, betas=(0.9, 0.999))
+        self.optimizer = torch.optim.Adam(self.grad_vars, lr=self.args.lrate, betas=(0.9, 0.999), **_adam_kw(self.grad_vars))
         return [self.optimizer], []

@@ -175,6 +175,23 @@ def test_finetune_step_trains_volume_and_mlp():
     assert "feat_volume" in ft.volume.state_dict()
 
 
+def test_fused_optimizer_updates_are_seen_by_the_packed_weight_caches():
+    """torch.optim.Adam(fused=True) writes the parameters without bumping tensor._version (the packed-weight caches' key): the caches
+    also key on an optimizer-step epoch (_lib.weights_epoch, a global optimizer post-step hook), so the next forward re-packs."""
+    from mvsnerf_amd import models
+    mlp = models.MVSNeRF(D=6, W=128, input_ch_pts=63, input_ch_views=3, input_ch_feat=20, skips=[4], net_type="v0").to(DEV)
+    conv = models.ConvBnReLU3D(16, 16).to(DEV)
+    params = list(mlp.parameters()) + list(conv.parameters())
+    opt = torch.optim.Adam(params, lr=1e-2, fused=True)
+    p0, c0 = mlp.packed(20).clone(), conv._packed.get().clone()
+    for p in params:
+        p.grad = torch.ones_like(p)
+    opt.step()
+    # (torch 2.10: params[0]._version == v0 here - the fused kernel does not bump it)
+    p1, c1 = mlp.packed(20), conv._packed.get()
+    assert not torch.equal(p0, p1) and not torch.equal(c0, c1)
+
+
 def test_finetune_five_source_views_bf16():
     """BASELINE config 4 names 5 source views and the bf16 MLP: `args.n_views = 5` (47-channel cost volume, feat_dim 28) through
     MVSSystemFinetune - the reference hard-wires 8 + 3*4 (train_mvs_nerf_finetuning_pl.py:39)."""
