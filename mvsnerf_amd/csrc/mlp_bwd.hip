@@ -399,23 +399,38 @@ __global__ __launch_bounds__(64 * RA_BLOCKS) void mlp_wgrad_kernel(WgradArgs w)
     if (kkh == 0) out[(int64_t)arow * (RB + 1) + RB] = rsum;
 }
 
-// combine the per-workgroup partials and scatter (ra, rb) -> nn.Linear layout via the maps (-1 = drop)
-__global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(const float* __restrict__ partial, int n_part, int RA, int RB,
-                                                              const int* __restrict__ rowmap, const int* __restrict__ colmap,
-                                                              float* __restrict__ gw, int ld, float* __restrict__ gb)
+// scatter (ra, rb) of the summed partials -> nn.Linear layout via the maps (-1 = drop), for all eleven weight/bias pairs in one launch
+// (jobs in the kernel arguments); red[j]: the summed partials of GEMM j
+constexpr int WG_JOBS = 12;
+struct ScatterJobs {
+    const float* red[WG_JOBS];
+    const int* rowmap[WG_JOBS];
+    const int* colmap[WG_JOBS];
+    float* gw[WG_JOBS];
+    float* gb[WG_JOBS];
+    int RA[WG_JOBS], RB[WG_JOBS], ld[WG_JOBS], blk[WG_JOBS + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void mlp_wgrad_scatter_multi_kernel(ScatterJobs J)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = 0;
+    while (j + 1 < J.n && (int)blockIdx.x >= J.blk[j + 1]) ++j;
+    const int idx = (blockIdx.x - J.blk[j]) * 256 + threadIdx.x;
+    const int RA = J.RA[j], RB = J.RB[j];
     if (idx >= RA * (RB + 1)) return;
     const int ra = idx / (RB + 1), rb = idx - ra * (RB + 1);
-    const int n = rowmap[ra];
+    const int n = J.rowmap[j][ra];
     if (n < 0) return;
     const bool is_bias = rb == RB;
-    const int k = is_bias ? 0 : colmap[rb];
-    if (k < 0 || (is_bias && !gb)) return;
-    float s = 0.0f;
-    for (int pw = 0; pw < n_part; ++pw) s += partial[(int64_t)pw * RA * (RB + 1) + idx];      // fixed order: deterministic
-    if (is_bias) gb[n] = s; else gw[(int64_t)n * ld + k] = s;
+    const int k = is_bias ? 0 : J.colmap[j][rb];
+    if (k < 0 || (is_bias && !J.gb[j])) return;
+    const float v = J.red[j][idx];
+    if (is_bias) J.gb[j][n] = v; else J.gw[j][(int64_t)n * J.ld[j] + k] = v;
 }
+
+extern "C" int mvsnerf_partial_sum_multi(int n_jobs, const float* const* partial, const int* n_part, const int64_t* n_out, float* const* dst,
+                                         float* scratch, void* stream);
 
 // ------------------------------------------------------------------------------------------ host orchestration
 static int launch_wgrad(int ra_blocks, int nbb, const WgradArgs& w, int grid, hipStream_t st, bool bf)
@@ -435,7 +450,10 @@ static int launch_wgrad(int ra_blocks, int nbb, const WgradArgs& w, int grid, hi
     return MVSNERF_OK;
 }
 
-extern "C" size_t mvsnerf_mlp_bwd_workspace_floats(void) { return (size_t)(256 + MVS_RED_SLICES + 1) * 128 * (192 + 1); }
+// ten weight-gradient GEMMs, each leaving `grid` <= 256 partial results of RA * (RB + 1) floats, reduced together at the end:
+// sum of RA * (RB + 1) = 128*65 + 4*128*129 + 128*193 + 128*33 + 128*129 + 64*161 + 32*193
+constexpr size_t WG_NOUT_SUM = 128 * 65 + 4 * 128 * 129 + 128 * 193 + 128 * 33 + 128 * 129 + 64 * 161 + 32 * 193;
+extern "C" size_t mvsnerf_mlp_bwd_workspace_floats(void) { return (size_t)(256 + MVS_RED_SLICES + 1) * WG_NOUT_SUM + 1024; }
 
 // maps: device int array of 8 consecutive tables (see mvsnerf_amd/ops.py:_mlp_bwd_maps):
 //   [0] act128 (128): slot-row r=2q+h -> n(q,h)            [1] act64 (64): same for q<32
@@ -494,57 +512,60 @@ static int mlp_bwd_impl(bool bf, const float* packed_fwd, const float* packed_bw
     const int64_t ts_s = (int64_t)SLOTS_SAVED * 64, ts_g = (int64_t)SLOTS_GRAD * 64;
     const int grid = (int)(n_tiles < 256 ? n_tiles : 256);
     int rc;
-    auto gemm = [&](int a_slot, int ra_blocks, int b_slot0, int nblk0, int b_slot1, int nbb) -> int {
-        WgradArgs w{gslots, ts_g, a_slot, saved, ts_s, b_slot0, nblk0, b_slot1, n_tiles, workspace};
+    // every GEMM leaves its partials [grid][RA*(RB+1)] in its own piece of the workspace; ONE multi-job two-stage sum over the workgroups
+    // (fixed order) and ONE scatter launch finish all of them (fragment order -> nn.Linear layout): 5 launches instead of 33
+    float* part_next = workspace;
+    float* red_all = workspace + (size_t)256 * WG_NOUT_SUM;
+    float* red_scratch = red_all + WG_NOUT_SUM;
+    float* red_next = red_all;
+    const float* ps_part[WG_JOBS]; int ps_np[WG_JOBS]; int64_t ps_no[WG_JOBS]; float* ps_dst[WG_JOBS];
+    int n_gemm = 0;
+    ScatterJobs SJ;
+    SJ.n = 0;
+    int sblk = 0;
+    auto gemm = [&](int a_slot, int ra_blocks, int b_slot0, int nblk0, int b_slot1, int nbb, int RA, int RB) -> int {
+        WgradArgs w{gslots, ts_g, a_slot, saved, ts_s, b_slot0, nblk0, b_slot1, n_tiles, part_next};
+        const int64_t n_out = (int64_t)RA * (RB + 1);
+        ps_part[n_gemm] = part_next; ps_np[n_gemm] = grid; ps_no[n_gemm] = n_out; ps_dst[n_gemm] = red_next;
+        ++n_gemm;
+        part_next += (size_t)grid * n_out;
+        red_next += n_out;
         return launch_wgrad(ra_blocks, nbb, w, grid, st, bf);
     };
-    // partials [grid][RA*(RB+1)] -> one slice (two-stage sum over the workgroups: a single pass walks `grid` strided values per
-    // thread on a few dozen workgroups and cost 61 us per call), then the fragment-order -> nn.Linear scatter
-    float* red_scratch = workspace + (size_t)256 * 128 * (192 + 1);
-    float* red_out = red_scratch + (size_t)MVS_RED_SLICES * 128 * (192 + 1);
-    auto reduce = [&](int RA, int RB, const int* rowmap, const int* colmap, float* w_out, int ld, float* b_out, bool fresh = true) -> int {
-        const int64_t n_out = (int64_t)RA * (RB + 1);
-        if (fresh) mvs_partial_sum(workspace, grid, n_out, red_scratch, red_out, st);
-        mlp_wgrad_reduce_kernel<<<mvs_cdiv(n_out, 256), 256, 0, st>>>(red_out, 1, RA, RB, rowmap, colmap, w_out, ld, b_out);
-        hipError_t e = hipGetLastError();
-        return e == hipSuccess ? 0 : (int)e;
+    auto scatter = [&](int RA, int RB, const int* rowmap, const int* colmap, float* w_out, int ld, float* b_out) {     // of the LAST gemm's sums
+        const int j = SJ.n++;
+        SJ.red[j] = ps_dst[n_gemm - 1]; SJ.rowmap[j] = rowmap; SJ.colmap[j] = colmap; SJ.gw[j] = w_out; SJ.gb[j] = b_out;
+        SJ.RA[j] = RA; SJ.RB[j] = RB; SJ.ld[j] = ld; SJ.blk[j] = sblk;
+        sblk += (RA * (RB + 1) + 255) / 256;
     };
     // pts_linears.0: dW0 = GP0 x E^T
-    if ((rc = gemm(G_GP, 4, S_E, 2, 0, 2))) return rc;
-    if ((rc = reduce(128, 64, M_ACT128, M_PE, gw[0], PE_DIM, gb[0]))) return rc;
+    if ((rc = gemm(G_GP, 4, S_E, 2, 0, 2, 128, 64))) return rc;
+    scatter(128, 64, M_ACT128, M_PE, gw[0], PE_DIM, gb[0]);
     // pts_linears.1..4: dWi = GPi x H(i-1)^T
     for (int l = 1; l <= 4; ++l) {
-        if ((rc = gemm(G_GP + l * 64, 4, S_H + (l - 1) * 64, 4, 0, 4))) return rc;
-        if ((rc = reduce(128, 128, M_ACT128, M_ACT128, gw[l], WIDTH, gb[l]))) return rc;
+        if ((rc = gemm(G_GP + l * 64, 4, S_H + (l - 1) * 64, 4, 0, 4, 128, 128))) return rc;
+        scatter(128, 128, M_ACT128, M_ACT128, gw[l], WIDTH, gb[l]);
     }
-    // pts_linears.5 on cat([pts, h4]): B = [E | H4]; two scatters (columns 0..62 and 63..190)
-    if ((rc = gemm(G_GP + 5 * 64, 4, S_E, 2, S_H + 4 * 64, 6))) return rc;
-    {
-        // colmap for the 192 B rows = [pe (64) | 63 + act (128)] is stored contiguously as M_PE followed by M_HL5? no: build on the fly
-        // (two reduce calls would need masks); the Python side provides a 192-entry table right after the 9 tables:
-        const int* M_L5 = maps + 576;
-        if ((rc = reduce(128, 192, M_ACT128, M_L5, gw[5], WIDTH + PE_DIM, gb[5]))) return rc;
-    }
+    // pts_linears.5 on cat([pts, h4]): B = [E | H4]; the 192-entry column table [pe (64) | 63 + act (128)] follows the 9 tables
+    if ((rc = gemm(G_GP + 5 * 64, 4, S_E, 2, S_H + 4 * 64, 6, 128, 192))) return rc;
+    scatter(128, 192, M_ACT128, maps + 576, gw[5], WIDTH + PE_DIM, gb[5]);
     // pts_bias: dWb = GBM x Fv^T
-    if ((rc = gemm(G_GBM, 4, S_FV, 1, 0, 1))) return rc;
-    if ((rc = reduce(128, 32, M_ACT128, M_FEAT, gw[6], F, gb[6]))) return rc;
+    if ((rc = gemm(G_GBM, 4, S_FV, 1, 0, 1, 128, 32))) return rc;
+    scatter(128, 32, M_ACT128, M_FEAT, gw[6], F, gb[6]);
     // feature_linear: dWf = GF x H5^T
-    if ((rc = gemm(G_GF, 4, S_H + 5 * 64, 4, 0, 4))) return rc;
-    if ((rc = reduce(128, 128, M_ACT128, M_ACT128, gw[7], WIDTH, gb[7]))) return rc;
-    // views_linears.0: dWv = GPV x [Fe | dir]^T
-    if ((rc = gemm(G_GPV, 2, S_FE, 4, S_DR, 5))) return rc;
-    {
-        const int* M_V = maps + 768;     // 160 entries: [act128 | 128 + dir]
-        if ((rc = reduce(64, 160, M_ACT64, M_V, gw[9], WIDTH + 3, gb[9]))) return rc;
-    }
-    // heads: rows (gz_r, gz_g, gz_b, gsigma) x [HV (64) | H5 (128)]
-    if ((rc = gemm(G_G4, 1, S_HV, 2, S_H + 5 * 64, 6))) return rc;
-    {
-        const int* M_HEAD_RGB = maps + 928;     // 192 entries: [act64 | -1 x128]
-        const int* M_HEAD_A = maps + 1120;      // 192 entries: [-1 x64 | act128]
-        if ((rc = reduce(32, 192, M_G4RGB, M_HEAD_RGB, gw[10], 64, gb[10]))) return rc;
-        if ((rc = reduce(32, 192, M_G4A, M_HEAD_A, gw[8], WIDTH, gb[8], false))) return rc;      // same partials, second scatter
-    }
+    if ((rc = gemm(G_GF, 4, S_H + 5 * 64, 4, 0, 4, 128, 128))) return rc;
+    scatter(128, 128, M_ACT128, M_ACT128, gw[7], WIDTH, gb[7]);
+    // views_linears.0: dWv = GPV x [Fe | dir]^T; 160-entry column table [act128 | 128 + dir]
+    if ((rc = gemm(G_GPV, 2, S_FE, 4, S_DR, 5, 64, 160))) return rc;
+    scatter(64, 160, M_ACT64, maps + 768, gw[9], WIDTH + 3, gb[9]);
+    // heads: rows (gz_r, gz_g, gz_b, gsigma) x [HV (64) | H5 (128)]; two scatters of the same sums
+    if ((rc = gemm(G_G4, 1, S_HV, 2, S_H + 5 * 64, 6, 32, 192))) return rc;
+    scatter(32, 192, M_G4RGB, maps + 928, gw[10], 64, gb[10]);          // 192 entries: [act64 | -1 x128]
+    scatter(32, 192, M_G4A, maps + 1120, gw[8], WIDTH, gb[8]);          // 192 entries: [-1 x64 | act128]
+    SJ.blk[SJ.n] = sblk;
+    if ((rc = mvsnerf_partial_sum_multi(n_gemm, ps_part, ps_np, ps_no, ps_dst, red_scratch, stream))) return rc;
+    mlp_wgrad_scatter_multi_kernel<<<sblk, 256, 0, st>>>(SJ);
+    MVS_LAUNCH_CHECK();
     (void)M_HL5; (void)M_DIR;
     return MVSNERF_OK;
 }
