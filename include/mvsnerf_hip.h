@@ -135,18 +135,20 @@ int mvsnerf_conv_transpose3d_mfma_fwd(const float* x, int Cin, int D, int H, int
 /* The 16 -> 8 layer (conv11, and conv1's data gradient) without padded products on v_mfma_f32_4x4x1 (the parity-class form above spends
  * 44 % of its products on zero weights at 8 output channels).  wq: [ci/4][tap][co][4] = mvsnerf_pack_weights_multi kind 1 of the layer. */
 int mvsnerf_conv_transpose3d_c8_supported(int Cin, int Cout);
-/* Both 8-channel producers can leave the InPlaceABN statistics of their output as per-workgroup partial sums (2 * 8 floats per workgroup,
- * *_tiles(...) workgroups) so that the full-resolution output is not read again; mvsnerf_abn_finalize is stage 2 of mvsnerf_abn_stats on
- * such partials (part[(b * 2 + {sum, sum of squares}) * C + c]). */
+/* The input is leaky(x1*scale1+shift1) [+ leaky(x2*scale2+shift2)] like mvsnerf_conv_transpose3d_fwd's (scale NULL: plain tensor): the
+ * pending InPlaceABN of the producers and the U-Net skip sum are applied while staging, no materialised input.
+ * Both 8-channel producers can leave the InPlaceABN statistics of their output as per-workgroup partial sums (stats_part: 2 * 8 floats per
+ * workgroup, *_tiles(...) workgroups; NULL = not wanted) so that the full-resolution output is not read again; mvsnerf_abn_finalize is
+ * stage 2 of mvsnerf_abn_stats on such partials (part[(b * 2 + {sum, sum of squares}) * C + c]). */
+int mvsnerf_conv_transpose3d_c8_fwd(const float* x1, const float* scale1, const float* shift1, const float* x2, const float* scale2, const float* shift2,
+                                    int Cin, int D, int H, int W, const float* wq, float* out, float* stats_part, void* stream);
+int mvsnerf_conv_transpose3d_c8_tiles(int D, int H, int W);
 int mvsnerf_conv3d_c8_blocked_tiles(int D, int H, int W);
 int mvsnerf_conv3d_c8_blocked_fwd_stats(const float* x_blocked, int Cin, int Cin_real, int D, int H, int W, const float* wq, float* out,
                                         float* stats_part, void* stream);
-int mvsnerf_conv_transpose3d_c8_tiles(int D, int H, int W);
-int mvsnerf_conv_transpose3d_c8_fwd_stats(const float* x, int Cin, int D, int H, int W, const float* wq, float* out, float* stats_part, void* stream);
 int mvsnerf_abn_finalize(const float* part, int n_blocks, int C, int64_t n_vox, const float* weight, const float* bias,
                          float* running_mean, float* running_var, float momentum, float eps,
                          float* scale, float* shift, float* mean_out, float* invstd_out, void* stream);
-int mvsnerf_conv_transpose3d_c8_fwd(const float* x, int Cin, int D, int H, int W, const float* wq, float* out, void* stream);
 int mvsnerf_conv_transpose3d_fwd(const float* x1, const float* scale1, const float* shift1,
                                  const float* x2, const float* scale2, const float* shift2,
                                  int Cin, int D, int H, int W, const float* wpacked, int Cout, float* out, void* stream);

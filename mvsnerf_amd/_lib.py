@@ -94,9 +94,8 @@ SIGNATURES = {
     "mvsnerf_conv3d_c8_blocked_tiles": (_c_i, [_c_i] * 3),
     "mvsnerf_conv3d_c8_blocked_fwd_stats": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_conv_transpose3d_c8_tiles": (_c_i, [_c_i] * 3),
-    "mvsnerf_conv_transpose3d_c8_fwd_stats": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_abn_finalize": (_c_i, [_c_fp, _c_i, _c_i, _c_l, _c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_float, ctypes.c_float, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp]),
-    "mvsnerf_conv_transpose3d_c8_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_conv_transpose3d_c8_fwd": (_c_i, [_c_fp] * 6 + [_c_i] * 4 + [_c_fp, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_conv3d_pack_weights_c8": (_c_i, [_c_fp, _c_i, _c_fp, _c_fp]),
     "mvsnerf_conv3d_c8_blocked_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_conv3d_c8_blocked_wgrad": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_fp]),

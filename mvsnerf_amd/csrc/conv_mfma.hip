@@ -769,7 +769,7 @@ constexpr int CT8_TX = 16, CT8_TY = 8, CT8_TZ = 2;
 constexpr int CT8_PX = CT8_TX + 1, CT8_PY = CT8_TY + 1, CT8_PZ = CT8_TZ + 1;
 constexpr int CT8_NVH = CT8_PX * CT8_PY * CT8_PZ;                     // 459
 
-__global__ __launch_bounds__(256) void convT3d_k3s2_c16to8_mfma4_kernel(const float* __restrict__ x, int Di, int Hi, int Wi,
+__global__ __launch_bounds__(256) void convT3d_k3s2_c16to8_mfma4_kernel(ActSrc xa, ActSrc xb, int Di, int Hi, int Wi,
                                                                        const float* __restrict__ wq, float* __restrict__ out, int swz,
                                                                        float* __restrict__ stats)
 {
@@ -786,7 +786,9 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_c16to8_mfma4_kernel(const fl
         const int vx = v % CT8_PX, vy = (v / CT8_PX) % CT8_PY, vz = v / (CT8_PX * CT8_PY);
         const int gx = x0 + vx, gy = y0 + vy, gz = z0 + vz;
         f32x4 val = {0.f, 0.f, 0.f, 0.f};
-        if (gx < Wi && gy < Hi && gz < Di) val = *reinterpret_cast<const f32x4*>(x + (((int64_t)gz * Hi + gy) * Wi + gx) * 16 + cq * 4);
+        // the pending InPlaceABN of the producer(s) and the U-Net skip sum are applied here, once per staged element (the input used to
+        // be materialised by a separate abn_apply_add pass: 113 MB of traffic for conv11)
+        if (gx < Wi && gy < Hi && gz < Di) load_act4<16>(xa, xb, ((int64_t)gz * Hi + gy) * Wi + gx, 16, cq * 4, val);
         *reinterpret_cast<f32x4*>(xt + (cq * CT8_NVH + v) * 4) = val;
     }
     __syncthreads();
@@ -880,10 +882,10 @@ int mvs_conv3d_mfma32(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int
 // conv11-shaped transposed convolution (16 -> 8) without padded products (mvsnerf_conv_transpose3d_c8_fwd); wq: [ci/4][tap][co][4]
 int mvs_convT3d_c16to8_tiles(int D, int H, int W) { return ((W + CT8_TX - 1) / CT8_TX) * ((H + CT8_TY - 1) / CT8_TY) * ((D + CT8_TZ - 1) / CT8_TZ); }
 
-int mvs_convT3d_c16to8_mfma4(const float* x, int D, int H, int W, const float* wq, float* out, int xcd, float* stats, hipStream_t st)
+int mvs_convT3d_c16to8_mfma4(const ActSrc& xa, const ActSrc& xb, int D, int H, int W, const float* wq, float* out, int xcd, float* stats, hipStream_t st)
 {
     const unsigned grid = (unsigned)mvs_convT3d_c16to8_tiles(D, H, W);
-    convT3d_k3s2_c16to8_mfma4_kernel<<<grid, 256, 0, st>>>(x, D, H, W, wq, out, xcd, stats);
+    convT3d_k3s2_c16to8_mfma4_kernel<<<grid, 256, 0, st>>>(xa, xb, D, H, W, wq, out, xcd, stats);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }

@@ -708,30 +708,26 @@ extern "C" int mvsnerf_conv_transpose3d_mfma_fwd(const float* x, int Cin, int D,
     return mvs_convT3d_mfma32(x, Cin, D, H, W, w32, Cout, out, (hipStream_t)stream);
 }
 
-int mvs_convT3d_c16to8_mfma4(const float* x, int D, int H, int W, const float* wq, float* out, int xcd, float* stats, hipStream_t st);
+int mvs_convT3d_c16to8_mfma4(const ActSrc& xa, const ActSrc& xb, int D, int H, int W, const float* wq, float* out, int xcd, float* stats, hipStream_t st);
 int mvs_convT3d_c16to8_tiles(int D, int H, int W);
 
 // ConvTranspose3d(16, 8, 3, stride 2, padding 1, output_padding 1) of a plain tensor x[D][H][W][16] -> out[2D][2H][2W][8] on
 // v_mfma_f32_4x4x1 without padded products; wq: the layer's weights as [ci/4][tap][co][4].  1 when the "conv_mfma" switch is on.
 extern "C" int mvsnerf_conv_transpose3d_c8_supported(int Cin, int Cout) { return (g_conv_mfma && Cin == 16 && Cout == 8) ? 1 : 0; }
 
-extern "C" int mvsnerf_conv_transpose3d_c8_fwd(const float* x, int Cin, int D, int H, int W, const float* wq, float* out, void* stream)
+extern "C" int mvsnerf_conv_transpose3d_c8_fwd(const float* x1, const float* scale1, const float* shift1,
+                                               const float* x2, const float* scale2, const float* shift2,
+                                               int Cin, int D, int H, int W, const float* wq, float* out, float* stats_part, void* stream)
 {
-    if (!x || !wq || !out || D < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
+    if (!act_ok(x1, scale1, shift1) || !wq || !out || D < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
+    if (x2 && (!act_ok(x2, scale2, shift2) || !scale2)) return MVSNERF_EINVAL;
     if (Cin != 16) return MVSNERF_EUNSUPPORTED;
-    if (!mvs_aligned16(x) || !mvs_aligned16(wq) || !mvs_aligned16(out)) return MVSNERF_EALIGN;
-    return mvs_convT3d_c16to8_mfma4(x, D, H, W, wq, out, g_conv_xcd, nullptr, (hipStream_t)stream);
+    if (!mvs_aligned16(wq) || !mvs_aligned16(out)) return MVSNERF_EALIGN;
+    const ActSrc a{x1, scale1, shift1}, b{x2, scale2, shift2};
+    return mvs_convT3d_c16to8_mfma4(a, b, D, H, W, wq, out, g_conv_xcd, stats_part, (hipStream_t)stream);
 }
 
 extern "C" int mvsnerf_conv_transpose3d_c8_tiles(int D, int H, int W) { return mvs_convT3d_c16to8_tiles(D, H, W); }
-
-extern "C" int mvsnerf_conv_transpose3d_c8_fwd_stats(const float* x, int Cin, int D, int H, int W, const float* wq, float* out, float* stats_part, void* stream)
-{
-    if (!x || !wq || !out || !stats_part || D < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
-    if (Cin != 16) return MVSNERF_EUNSUPPORTED;
-    if (!mvs_aligned16(x) || !mvs_aligned16(wq) || !mvs_aligned16(out)) return MVSNERF_EALIGN;
-    return mvs_convT3d_c16to8_mfma4(x, D, H, W, wq, out, g_conv_xcd, stats_part, (hipStream_t)stream);
-}
 
 extern "C" int mvsnerf_conv_transpose3d_fwd(const float* x1, const float* scale1, const float* shift1,
                                             const float* x2, const float* scale2, const float* shift2,

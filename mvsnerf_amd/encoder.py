@@ -503,17 +503,15 @@ def _conv_t(src1, src2, dims_in, wbuf, cin_k, cout_k, packed=None, mode="fwd", w
     could leave them (only asked for with True), else None."""
     D, H, W, _ = dims_in
     out = torch.empty((2 * D, 2 * H, 2 * W, cout_k), device=wbuf.device, dtype=torch.float32)
-    if packed is not None and src2 is None and torch.is_tensor(src1) and _lib.lib().mvsnerf_conv_transpose3d_c8_supported(cin_k, cout_k):
-        lib = _lib.lib()
-        if want_stats and FUSED_ABN_STATS:       # the caller's InPlaceABN statistics come out of the same launch: returns (out, partials)
+    if packed is not None and _lib.lib().mvsnerf_conv_transpose3d_c8_supported(cin_k, cout_k):
+        lib = _lib.lib()            # lazily-activated sources and the skip sum are applied while staging; statistics from the same launch
+        part, nblk = None, 0
+        if want_stats and FUSED_ABN_STATS:
             nblk = lib.mvsnerf_conv_transpose3d_c8_tiles(D, H, W)
             part = torch.empty(nblk * 16, device=out.device, dtype=torch.float32)
-            check(lib.mvsnerf_conv_transpose3d_c8_fwd_stats(src1.data_ptr(), cin_k, D, H, W, packed.get_c8(mode).data_ptr(), out.data_ptr(), part.data_ptr(),
-                                                            stream_ptr()), "conv_transpose3d_c8_fwd_stats")
-            return out, (part, nblk)
-        check(lib.mvsnerf_conv_transpose3d_c8_fwd(src1.data_ptr(), cin_k, D, H, W, packed.get_c8(mode).data_ptr(), out.data_ptr(), stream_ptr()),
-              "conv_transpose3d_c8_fwd")
-        return out if want_stats is None else (out, None)
+        check(lib.mvsnerf_conv_transpose3d_c8_fwd(*_ptrs(src1), *_ptrs(src2), cin_k, D, H, W, packed.get_c8(mode).data_ptr(), out.data_ptr(),
+                                                  0 if part is None else part.data_ptr(), stream_ptr()), "conv_transpose3d_c8_fwd")
+        return out if want_stats is None else (out, None if part is None else (part, nblk))
     if (packed is not None and src2 is None and torch.is_tensor(src1) and cin_k % 8 == 0
             and _lib.lib().mvsnerf_conv_transpose3d_mfma_supported(cin_k, cout_k)):
         check(_lib.lib().mvsnerf_conv_transpose3d_mfma_fwd(src1.data_ptr(), cin_k, D, H, W, packed.get_mfma(mode).data_ptr(), cout_k,
@@ -579,7 +577,8 @@ class _UpBlock(nn.Sequential):
 
     def lazy(self, src1, dims_in, src2=None):
         pk = self._packed
-        if MATERIALIZE_UP_INPUT and isinstance(src1, _Lazy):
+        if (MATERIALIZE_UP_INPUT and isinstance(src1, _Lazy)
+                and not _lib.lib().mvsnerf_conv_transpose3d_c8_supported(pk.cin_pad, pk.cout)):      # (that kernel activates while staging)
             # every input voxel feeds 27/8 output voxels on average: activate (and sum the skip) once instead of per tap
             src1, src2 = _apply_add(src1, src2), None
         raw, partials = _conv_t(src1, src2, dims_in, pk.get(), pk.cin_pad, pk.cout, packed=pk, want_stats=self[1].training)
