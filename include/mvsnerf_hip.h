@@ -127,7 +127,10 @@ int mvsnerf_pack_weights_multi(int n_jobs, const float* const* w, float* const* 
 int mvsnerf_conv3d_mfma_supported(int Cin, int Cout, int stride);
 int mvsnerf_conv3d_pack_weights_mfma(const float* wpacked, int Cin, int Cout, float* w32, void* stream);
 int mvsnerf_conv3d_mfma_fwd(const float* x1, const float* scale1, const float* shift1, int Cin, int cin_ld, int D, int H, int W,
-                            const float* w32, int Cout, int stride, float* out, void* stream);
+                            const float* w32, int Cout, int stride, float* out, float* stats_part, void* stream);
+/* stats_part (NULL = not wanted): per-workgroup InPlaceABN partial sums of the output, 2 * Cout floats per workgroup,
+ * mvsnerf_conv3d_mfma_tiles(D, H, W, stride) workgroups, finished by mvsnerf_abn_finalize. */
+int mvsnerf_conv3d_mfma_tiles(int D, int H, int W, int stride);
 /* The transposed convolutions (conv7/9/11) on v_mfma_f32_32x32x2_f32: plain (already activated) input x[D][H][W][Cin], weights from
  * mvsnerf_conv3d_pack_weights_mfma; raw out[2D][2H][2W][Cout]. */
 int mvsnerf_conv_transpose3d_mfma_supported(int Cin, int Cout);

@@ -87,7 +87,8 @@ SIGNATURES = {
     "mvsnerf_planesweep_costvar_blocked_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp]),
     "mvsnerf_conv3d_mfma_supported": (_c_i, [_c_i, _c_i, _c_i]),
     "mvsnerf_conv3d_pack_weights_mfma": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_fp]),
-    "mvsnerf_conv3d_mfma_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_conv3d_mfma_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_conv3d_mfma_tiles": (_c_i, [_c_i] * 4),
     "mvsnerf_conv_transpose3d_mfma_supported": (_c_i, [_c_i, _c_i]),
     "mvsnerf_conv_transpose3d_mfma_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_fp]),
     "mvsnerf_conv_transpose3d_c8_supported": (_c_i, [_c_i, _c_i]),

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void conv_w4_repack_kernel(const float* __rest
 // These volumes fit the L2 (conv6 input 2.3 MB), so the 27-fold re-read of the input comes from cache and needs no LDS tile.
 template <int CIN, int COUT, int S>
 __global__ __launch_bounds__(512) void conv3d_k3_mfma32_kernel(ActSrc a, int ld, int Di, int Hi, int Wi, const float* __restrict__ w32,
-                                                              float* __restrict__ out, int Do, int Ho, int Wo)
+                                                              float* __restrict__ out, int Do, int Ho, int Wo, float* __restrict__ stats)
 {
     constexpr int NB = COUT / 32, CB = CIN / 8;
     constexpr int WAVES = 8, NR = WAVES / NB;                    // wave w: output block w % NB, tap range w / NB of NR
@@ -486,6 +486,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_mfma32_kernel(ActSrc a, int ld,
     }
     __syncthreads();
     if (rg == 0) {
+        float ssum = 0.f, ssq = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = acc[r];
@@ -493,7 +494,14 @@ __global__ __launch_bounds__(512) void conv3d_k3_mfma32_kernel(ActSrc a, int ld,
             for (int w = 0; w < NR - 1; ++w) v += red[((w * NB + nb) * 16 + r) * 64 + lane];
             // D: register r of lane (n = m, half = kh) = output voxel (r&3) + 8 (r>>2) + 4 half of the tile, channel 32 nb + n
             const int64_t ov = (int64_t)blockIdx.x * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (ov < nvox) out[ov * COUT + nb * 32 + m] = v;
+            if (ov < nvox) { out[ov * COUT + nb * 32 + m] = v; ssum += v; ssq = fmaf(v, v, ssq); }
+        }
+        if (stats) {                                              // InPlaceABN partial sums of this M-tile (abn_finalize_kernel's layout)
+            ssum += __shfl_xor(ssum, 32); ssq += __shfl_xor(ssq, 32);
+            if (kh == 0) {
+                stats[((int64_t)blockIdx.x * 2) * COUT + nb * 32 + m] = ssum;
+                stats[((int64_t)blockIdx.x * 2 + 1) * COUT + nb * 32 + m] = ssq;
+            }
         }
     }
 }
@@ -860,13 +868,19 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_c16to8_mfma4_kernel(ActSrc x
 }  // namespace
 
 // Called by mvsnerf_conv3d_fwd (encoder.hip) for the layers with 32 / 64 output channels; MVSNERF_EUNSUPPORTED = not instantiated.
+int mvs_conv3d_mfma32_tiles(int D, int H, int W, int stride)
+{
+    const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    return (int)mvs_cdiv((int64_t)Do * Ho * Wo, 32);
+}
+
 int mvs_conv3d_mfma32(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int D, int H, int W, const float* w32, int Cout, int stride,
-                      float* out, hipStream_t st)
+                      float* out, float* stats, hipStream_t st)
 {
     if (b.x || (cin_ld & 3)) return MVSNERF_EUNSUPPORTED;
     const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const unsigned grid = mvs_cdiv((int64_t)Do * Ho * Wo, 32);
-#define MVS_M32(CIN, COUT, S) conv3d_k3_mfma32_kernel<CIN, COUT, S><<<grid, 512, 0, st>>>(a, cin_ld, D, H, W, w32, out, Do, Ho, Wo)
+#define MVS_M32(CIN, COUT, S) conv3d_k3_mfma32_kernel<CIN, COUT, S><<<grid, 512, 0, st>>>(a, cin_ld, D, H, W, w32, out, Do, Ho, Wo, stats)
     switch (Cin * 1000 + Cout * 10 + stride) {
         case 16 * 1000 + 32 * 10 + 2: MVS_M32(16, 32, 2); break;     // conv3 (and the data gradient of conv9)
         case 32 * 1000 + 32 * 10 + 1: MVS_M32(32, 32, 1); break;     // conv4 (and its data gradient)

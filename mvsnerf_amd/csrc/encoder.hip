@@ -592,7 +592,8 @@ int g_conv_mfma = 1;    // stride-1 layers with 8 output channels on v_mfma_f32_
 int mvs_conv3d_c8_mfma(const ActSrc& a, const ActSrc& b, int Cin, int cin_real, int cin_ld, int D, int H, int W, const float* wpacked, float* out,
                        int xcd, hipStream_t st);
 int mvs_conv3d_mfma32(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int D, int H, int W, const float* w32, int Cout, int stride,
-                      float* out, hipStream_t st);
+                      float* out, float* stats, hipStream_t st);
+int mvs_conv3d_mfma32_tiles(int D, int H, int W, int stride);
 bool mvs_conv3d_mfma32_supported(int Cin, int Cout, int stride);
 int mvs_conv_w32_repack(const float* wpacked, float* w32, int Cin, int Cout, hipStream_t st);
 int mvs_convT3d_mfma32(const float* x, int Cin, int D, int H, int W, const float* w32, int Cout, float* out, hipStream_t st);
@@ -685,14 +686,16 @@ extern "C" int mvsnerf_conv3d_pack_weights_mfma(const float* wpacked, int Cin, i
     return mvs_conv_w32_repack(wpacked, w32, Cin, Cout, (hipStream_t)stream);
 }
 
+extern "C" int mvsnerf_conv3d_mfma_tiles(int D, int H, int W, int stride) { return (stride == 1 || stride == 2) ? mvs_conv3d_mfma32_tiles(D, H, W, stride) : 0; }
+
 extern "C" int mvsnerf_conv3d_mfma_fwd(const float* x1, const float* scale1, const float* shift1, int Cin, int cin_ld, int D, int H, int W,
-                                       const float* w32, int Cout, int stride, float* out, void* stream)
+                                       const float* w32, int Cout, int stride, float* out, float* stats_part, void* stream)
 {
     if (!act_ok(x1, scale1, shift1) || !w32 || !out || D < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
     if (stride != 1 && stride != 2) return MVSNERF_EUNSUPPORTED;
     if ((cin_ld & 3) || cin_ld < Cin || !mvs_aligned16(out) || !mvs_aligned16(w32)) return MVSNERF_EALIGN;
     const ActSrc a{x1, scale1, shift1}, b{nullptr, nullptr, nullptr};
-    return mvs_conv3d_mfma32(a, b, Cin, cin_ld, D, H, W, w32, Cout, stride, out, (hipStream_t)stream);
+    return mvs_conv3d_mfma32(a, b, Cin, cin_ld, D, H, W, w32, Cout, stride, out, stats_part, (hipStream_t)stream);
 }
 
 extern "C" int mvsnerf_conv_transpose3d_mfma_supported(int Cin, int Cout)

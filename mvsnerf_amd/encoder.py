@@ -480,20 +480,26 @@ def _ptrs(src):
     return src.data_ptr(), 0, 0
 
 
-def _conv(src1, src2, dims_in, cin_ld, wbuf, cin_k, cout_k, stride, packed=None, mode="fwd"):
+def _conv(src1, src2, dims_in, cin_ld, wbuf, cin_k, cout_k, stride, packed=None, mode="fwd", want_stats=None):
     """k3 p1 convolution kernel launch: input (D,H,W) with channel stride cin_ld -> raw (Do,Ho,Wo,cout_k).
-    packed (+ mode): the layer's _PackedConv - lets the 32/64-channel layers take the matrix-core kernel with its own weight layout."""
+    packed (+ mode): the layer's _PackedConv - lets the 32/64-channel layers take the matrix-core kernel with its own weight layout.
+    want_stats: as in _conv_t (None: returns out; True / False: (out, InPlaceABN partial sums | None))."""
     D, H, W, _ = dims_in
     Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
     out = torch.empty((Do, Ho, Wo, cout_k), device=wbuf.device, dtype=torch.float32)
     if packed is not None and src2 is None and _lib.lib().mvsnerf_conv3d_mfma_supported(cin_k, cout_k, stride):
+        lib = _lib.lib()
         x, sc, sh = _ptrs(src1)
-        check(_lib.lib().mvsnerf_conv3d_mfma_fwd(x, sc, sh, cin_k, cin_ld, D, H, W, packed.get_mfma(mode).data_ptr(), cout_k, stride,
-                                                 out.data_ptr(), stream_ptr()), "conv3d_mfma_fwd")
-        return out
+        part, nblk = None, 0
+        if want_stats and FUSED_ABN_STATS:
+            nblk = lib.mvsnerf_conv3d_mfma_tiles(D, H, W, stride)
+            part = torch.empty(nblk * 2 * cout_k, device=out.device, dtype=torch.float32)
+        check(lib.mvsnerf_conv3d_mfma_fwd(x, sc, sh, cin_k, cin_ld, D, H, W, packed.get_mfma(mode).data_ptr(), cout_k, stride,
+                                          out.data_ptr(), 0 if part is None else part.data_ptr(), stream_ptr()), "conv3d_mfma_fwd")
+        return out if want_stats is None else (out, None if part is None else (part, nblk))
     check(_lib.lib().mvsnerf_conv3d_fwd(*_ptrs(src1), *_ptrs(src2), cin_k, cin_ld, D, H, W, wbuf.data_ptr(), cout_k, stride,
                                         out.data_ptr(), stream_ptr()), "conv3d_fwd")
-    return out
+    return out if want_stats is None else (out, None)
 
 
 def _conv_t(src1, src2, dims_in, wbuf, cin_k, cout_k, packed=None, mode="fwd", want_stats=None):
@@ -544,9 +550,9 @@ class ConvBnReLU3D(nn.Module):
 
     def lazy(self, src1, dims_in, cin_ld, src2=None):
         pk = self._packed
-        raw = _conv(src1, src2, dims_in, cin_ld, pk.get(), pk.cin_pad, pk.cout, self.stride, packed=pk)
+        raw, partials = _conv(src1, src2, dims_in, cin_ld, pk.get(), pk.cin_pad, pk.cout, self.stride, packed=pk, want_stats=self.bn.training)
         D, H, W, C = raw.shape
-        scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self.bn, update_running=self.bn.training)
+        scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self.bn, update_running=self.bn.training, partials=partials)
         return _Lazy(raw, scale, shift, (D, H, W, C), mean, invstd)
 
     def forward(self, x):
