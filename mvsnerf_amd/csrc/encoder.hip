@@ -1440,7 +1440,10 @@ __global__ __launch_bounds__(256, NSRC <= 2 ? 4 : 2) void planesweep_bwd_tiles_k
     for (int d = d_begin; d < d_end; ++d) {
         const float dep = depth[d];
         if (((d - d_begin) % DSUB) == 0) {
-            if (d != d_begin) { flush(); }
+            if (d != d_begin) {
+                flush();
+                __syncthreads();                                      // flush() reads org[]: nobody may move the patch origin (below) before every wave has flushed
+            }
             // fixed-point scale of this group from max |g| over the tile's first plane
             float m = 0.f;
 #pragma unroll

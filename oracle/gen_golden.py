@@ -21,9 +21,23 @@ OUT = os.path.join(ROOT, "tests", "golden")
 np_ = lambda t: t.detach().cpu().numpy()
 
 
+CHECK = [False]      # --check: compare what the reference produces NOW with the committed fixtures instead of writing them
+MISMATCH = []
+
+
 def save(name, **arrs):
     path = os.path.join(OUT, name)
-    np.savez_compressed(path, **{k: (np_(v) if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    arrs = {k: (np_(v) if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()}
+    if CHECK[0]:
+        z = np.load(path)
+        missing = sorted(set(arrs) ^ set(z.files))
+        bad = [k for k in arrs if k in z.files and not (arrs[k].shape == z[k].shape and arrs[k].dtype == z[k].dtype
+                                                        and np.array_equal(arrs[k], z[k], equal_nan=arrs[k].dtype.kind == "f"))]
+        print(f"{name}: {len(arrs) - len(bad)} of {len(arrs)} arrays reproduce bit for bit" + (f"; DIFFER: {bad}" if bad else "")
+              + (f"; key sets differ: {missing}" if missing else ""))
+        MISMATCH.extend(f"{name}:{k}" for k in bad + missing)
+        return
+    np.savez_compressed(path, **arrs)
     print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB, {len(arrs)} arrays")
 
 
@@ -54,7 +68,8 @@ def main():
             feats = mvs.feature(imgs_n[0, :3])[None]                                    # models.py:904
             dv = torch.linspace(float(near_far[0]), float(near_far[1]), D_direct)[None]
             warped, grid = ref_utils.homo_warp(feats[:, 1], proj[:, 1], dv, pad=pad)      # utils.py:580
-            cost_img, in_masks = mvs.build_volume_costvar_img(imgs_n[:, :3], feats, proj[:, :3], dv, pad=pad)
+            with ref_shim.zero_filled_empty():
+                cost_img, in_masks = mvs.build_volume_costvar_img(imgs_n[:, :3], feats, proj[:, :3], dv, pad=pad)
             if pad > 0:  # convention: uninitialised border of channels 0:3 := 0
                 m = torch.zeros_like(cost_img[:, :3])
                 m[..., pad:-pad, pad:-pad] = 1
@@ -64,7 +79,11 @@ def main():
             vol_small = mvs.cost_reg_2(cost_img)                                        # models.py:756
             mvs.load_state_dict(rm)  # undo running-stat update
             # --- full forward (D hard-coded 128, models.py:914)
-            vol128, _, dv128 = mvs(imgs_n[:, :3], proj[:, :3], near_far, pad=pad)
+            # models.py:858 allocates the cost volume with torch.empty and never writes the border of channels 0:3 (pad > 0): inside
+            # mvs(...) that garbage reaches CostRegNet.  Convention of the fixtures (SURVEY 7/8b "outputs fully written"): border := 0,
+            # made explicit here so that the fixture does not depend on what the allocator happens to return.
+            with ref_shim.zero_filled_empty():
+                vol128, _, dv128 = mvs(imgs_n[:, :3], proj[:, :3], near_far, pad=pad)
             mvs.load_state_dict(rm)
 
             # --- rays: reference build_rays with the global CPU RNG seeded (ids: utils.py:93, jitter: :220)
@@ -112,5 +131,23 @@ def main():
              ref_disp=ro[1], ref_acc=ro[2])
 
 
+def check():
+    """Re-run the reference and compare with the committed fixtures bit for bit -> list of arrays that differ."""
+    CHECK[0] = True
+    del MISMATCH[:]
+    try:
+        main()
+        from oracle import gen_golden_importance
+        gen_golden_importance.main()
+    finally:
+        CHECK[0] = False
+    return list(MISMATCH)
+
+
 if __name__ == "__main__":
+    if "--check" in sys.argv[1:]:
+        from oracle import gen_golden as _self     # the module instance gen_golden_importance imports `save` from
+        bad = _self.check()
+        print("gen_golden --check:", "OK" if not bad else f"{len(bad)} arrays differ")
+        sys.exit(1 if bad else 0)
     main()

@@ -105,3 +105,18 @@ def test_rendering_end_to_end(name, weights):
     outw = O.rendering(pose, c["ref_test_pts"], c["ref_test_ndc"], c["ref_test_z"], c["ref_test_dir"],
                        c["ref_vol_small"], c["images_raw"][:, :3], mlp, white_bkgd=True)
     assert maxabs(outw[0], c["ref_rgb_white"]) < 1e-5
+
+
+def test_fixtures_reproduce_from_the_reference():
+    """`python -m oracle.gen_golden --check`: the committed fixtures are what the imported reference produces NOW, bit for bit
+    (authoring container only: /root/reference does not exist on the GPU box)."""
+    import os
+    from oracle import ref_shim
+    if not os.path.isdir(ref_shim.REF_ROOT):
+        pytest.skip("reference not present (GPU box)")
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "oracle.gen_golden", "--check"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "gen_golden --check: OK" in r.stdout
