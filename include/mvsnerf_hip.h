@@ -8,9 +8,8 @@
  * Conventions
  *   - plain pointers + sizes, no torch types.  Every pointer is a DEVICE pointer (fp32 unless noted)
  *     owned by the caller; outputs are caller-allocated and fully written.  The library allocates
- *     nothing.  Its only process-global state: (1) the A/B switches of mvsnerf_tune and the census pointer of
- *     mvsnerf_debug_set_census - diagnostics for the tests and bench.py, whose defaults ARE the product behaviour and which
- *     no product code path touches; (2) per-device "dynamic-LDS cap already raised" bits (idempotent).
+ *     nothing and has no behavioural state: its only process-global data are per-device "dynamic-LDS cap already
+ *     raised" bits (idempotent).  (The A/B switches between kernel variants exist only in the dev build, csrc/knobs.h.)
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls only enqueue work.
  *   - return 0 on success, a negative MVSNERF_E* for rejected arguments (nothing was launched),
  *     or a positive hipError_t from the launch.
@@ -35,17 +34,6 @@ extern "C" {
 
 /* ABI version; bumped on any signature change. */
 int mvsnerf_abi_version(void);
-
-/* A/B benchmarking knob, not part of the reference surface.  Keys: "mlp_variant" = 3 (default: 32 points/wave,
- * 2 waves/SIMD, weights double-buffered through LDS by LDS-DMA), 0 (same, register-staged weights), 1 (64 points/wave,
- * 1 wave/SIMD), 2 (32 points/wave, 1 wave/SIMD), 4 (16 points/wave on v_mfma_f32_16x16x4_f32, inference only); "conv_tiled" = 1|0; "conv_mfma" = 1|0 (stride-1 convolutions with 8 output channels on v_mfma_f32_4x4x1_16B_f32, default 1); "mlp_gather" = 0|1 (default 0: rendering() with 3 views does its lookups in the MLP kernel's prologue - one launch less, measured 1 % slower); "conv_xcd" = 1|0 (tiles of the tiled convolutions renumbered per XCD, default 1); "psw_bwd_tiles" = 1|0 (plane-sweep backward merging its scatter in LDS tiles, default 1; 0 = one float atomic per tap); "split_sched" = 0 (default: bf16x6 kernel at two waves
- * per SIMD, lean registers) | 1 (one wave per SIMD, operand splitting hand-interleaved between the MFMAs).  Results are
- * identical up to summation order. */
-int mvsnerf_tune(const char* key, int value);
-/* Diagnostics: resident workgroups per CU the runtime grants the MLP kernel variant (occupancy query). */
-int mvsnerf_debug_mlp_occupancy(int variant);
-/* Diagnostics: when non-NULL, every workgroup of the pipelined MLP kernel records {start, end (100 MHz clock), HW_ID, XCC_ID}. */
-int mvsnerf_debug_set_census(long long* buf);
 
 /* ---------------------------------------------------------------- layout helpers */
 
@@ -296,6 +284,13 @@ int mvsnerf_mlp_fwd(const float* packed, int F,
                     const float* ndc, int ndc_stride, const float* feat, int feat_stride,
                     const float* dirs, int dirs_stride, int64_t N, int S, int alpha_only,
                     float* raw, void* stream);
+/* The same launch, additionally filling a caller-owned timing record (stateless; bench.py derives the shader clock the chip sustains
+ * under this kernel from it): census[(N*S + 127) / 128][16] int64 = {start, end (100 MHz wall clock), HW_ID, XCC_ID,
+ * phase stamps [4..12], shader-clock ticks of the workgroup [13], -, -}. */
+int mvsnerf_mlp_fwd_census(const float* packed, int F,
+                           const float* ndc, int ndc_stride, const float* feat, int feat_stride,
+                           const float* dirs, int dirs_stride, int64_t N, int S, int alpha_only,
+                           float* raw, long long* census, void* stream);
 
 /* bf16-MFMA variant of the MLP forward (BASELINE configs 3/4: "bf16", "MFMA-bf16 MLP"): weights and layer inputs are
  * rounded to bf16, products accumulate in fp32; biases, modulation, ReLU, positional encoding and the heads stay fp32.

@@ -76,9 +76,6 @@ class RenderArgs(ctypes.Structure):
 # name -> (restype, argtypes); must list every symbol of include/mvsnerf_hip.h (tests check this)
 SIGNATURES = {
     "mvsnerf_abi_version": (_c_i, []),
-    "mvsnerf_tune": (_c_i, [ctypes.c_char_p, _c_i]),
-    "mvsnerf_debug_mlp_occupancy": (_c_i, [_c_i]),
-    "mvsnerf_debug_set_census": (_c_i, [_c_fp]),
     "mvsnerf_ncdhw_to_ndhwc": (_c_i, [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp]),
     "mvsnerf_ndhwc_to_ncdhw": (_c_i, [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp]),
     "mvsnerf_nchw_to_nhwc": (_c_i, [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp]),
@@ -138,6 +135,7 @@ SIGNATURES = {
     "mvsnerf_mlp_packed_floats": (ctypes.c_size_t, [_c_i]),
     "mvsnerf_mlp_pack": (_c_i, [ctypes.POINTER(_c_fp), ctypes.POINTER(_c_fp), _c_i, _c_fp, _c_fp]),
     "mvsnerf_mlp_fwd": (_c_i, [_c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_mlp_fwd_census": (_c_i, [_c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_mlp_packed_split_elems": (ctypes.c_size_t, [_c_i, _c_i]),
     "mvsnerf_mlp_pack_split": (_c_i, [ctypes.POINTER(_c_fp), _c_i, _c_i, _c_fp, _c_fp]),
     "mvsnerf_mlp_fwd_split": (_c_i, [_c_fp, _c_fp, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp]),

@@ -11,6 +11,7 @@
 // Skip additions (models.py:762-766) are the sum of two such lazily-activated tensors.
 #include "common.h"
 #include "act.h"
+#include "knobs.h"
 
 // =============================================================================================
 // small layout / resize helpers
@@ -86,6 +87,11 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
     float* __restrict__ masks,          // with img: [V][D][Hp][Wp] per-view; else [D][Hp][Wp] count
     int with_img, int blocked)          // blocked: cost[CP/4][D*Hp*Wp][4] (channel blocks of four, see mvsnerf_planesweep_costvar_blocked_fwd)
 {
+    // fp32 arithmetic of the CPU reference path, operation for operation (scratch/r3/cpu_arith_probe.py, cpu_var_probe.py compare candidate
+    // formulas with reference-generated fixtures BIT FOR BIT): the projection is a k-ordered fma chain (sgemm), grid_sample's blend is
+    // fma(se, w_se, fma(sw, w_sw, fma(ne, w_ne, nw * w_nw))), and everything in models.py:879-890 is one ATen op per rounding
+    // (x**2, +, *count, -): no contraction anywhere else.
+#pragma clang fp contract(off)
     static_assert(C == 32, "lane q owns float4 numbers q and q + 4 of a 32-channel pixel");
     constexpr int VPB = 256, VPP = 64;                           // voxels per block / per pass
     extern __shared__ __attribute__((aligned(16))) float lds_[];
@@ -179,9 +185,9 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
                 const f32x4 a = t_nw[q + 4 * hh], b = t_ne[q + 4 * hh], c_ = t_sw[q + 4 * hh], e = t_se[q + 4 * hh];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float wv = ((a[k] * w_nw + b[k] * w_ne) + c_[k] * w_sw) + e[k] * w_se;   // ATen's nw,ne,sw,se order
+                    const float wv = fmaf(e[k], w_se, fmaf(c_[k], w_sw, fmaf(b[k], w_ne, a[k] * w_nw)));   // ATen's nw,ne,sw,se chain
                     s[hh * 4 + k] += wv;                             // models.py:880
-                    s2[hh * 4 + k] += wv * wv;                       // :881
+                    s2[hh * 4 + k] += wv * wv;                       // :881 (the square is rounded before it is added)
                 }
             }
             if (with_img && q == (vv & 3)) {                         // warped thumbnail with the same grid (models.py:872), one lane per view
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
                 const f32x4 c_ = *reinterpret_cast<const f32x4*>(ib + (int64_t)a_sw * 4);
                 const f32x4 e = *reinterpret_cast<const f32x4*>(ib + (int64_t)a_se * 4);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) o[3 * vv + k] = ((a[k] * w_nw + b[k] * w_ne) + c_[k] * w_sw) + e[k] * w_se;
+                for (int k = 0; k < 3; ++k) o[3 * vv + k] = fmaf(e[k], w_se, fmaf(c_[k], w_sw, fmaf(b[k], w_ne, a[k] * w_nw)));
             }
         }
 #pragma unroll
@@ -272,6 +278,7 @@ __global__ __launch_bounds__(256) void homo_warp_kernel(const float* __restrict_
                                                         const float* __restrict__ grid_in, int C, int H, int W, int D, int pad,
                                                         float* __restrict__ out, float* __restrict__ grid_out)
 {
+#pragma clang fp contract(off)
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const int64_t nvox = (int64_t)D * Hp * Wp;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -296,12 +303,10 @@ __global__ __launch_bounds__(256) void homo_warp_kernel(const float* __restrict_
     const int x0 = (int)fx, y0 = (int)fy;
     for (int c = 0; c < C; ++c) {
         const float* pl = src + (int64_t)c * H * W;
-        float acc = 0.f;
-        if (x0in && y0in) acc += pl[(int64_t)y0 * W + x0] * (wx0 * wy0);
-        if (x1in && y0in) acc += pl[(int64_t)y0 * W + x0 + 1] * (wx1 * wy0);
-        if (x0in && y1in) acc += pl[(int64_t)(y0 + 1) * W + x0] * (wx0 * wy1);
-        if (x1in && y1in) acc += pl[(int64_t)(y0 + 1) * W + x0 + 1] * (wx1 * wy1);
-        out[(int64_t)c * nvox + i] = acc;
+        // the CPU reference's chain fma(se, w_se, fma(sw, w_sw, fma(ne, w_ne, nw * w_nw))) with 0 for a tap outside the image
+        const float nw = (x0in && y0in) ? pl[(int64_t)y0 * W + x0] : 0.f, ne = (x1in && y0in) ? pl[(int64_t)y0 * W + x0 + 1] : 0.f;
+        const float sw = (x0in && y1in) ? pl[(int64_t)(y0 + 1) * W + x0] : 0.f, se = (x1in && y1in) ? pl[(int64_t)(y0 + 1) * W + x0 + 1] : 0.f;
+        out[(int64_t)c * nvox + i] = fmaf(se, wx1 * wy1, fmaf(sw, wx0 * wy1, fmaf(ne, wx1 * wy0, nw * (wx0 * wy0))));
     }
 }
 
@@ -588,7 +593,7 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_kernel(ActSrc a, ActSrc b, i
     for (int k = 0; k < CT; k += 4) *reinterpret_cast<f32x4*>(o + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
 }
 
-int g_conv_mfma = 1;    // stride-1 layers with 8 output channels on v_mfma_f32_4x4x1_16B_f32 (conv_mfma.hip); 0 = the VALU kernels (A/B knob)
+MVS_KNOB_DEF(g_conv_mfma, 1)    // knobs.h: constants in the product build
 int mvs_conv3d_c8_mfma(const ActSrc& a, const ActSrc& b, int Cin, int cin_real, int cin_ld, int D, int H, int W, const float* wpacked, float* out,
                        int xcd, hipStream_t st);
 int mvs_conv3d_mfma32(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int D, int H, int W, const float* w32, int Cout, int stride,
@@ -597,8 +602,8 @@ int mvs_conv3d_mfma32_tiles(int D, int H, int W, int stride);
 bool mvs_conv3d_mfma32_supported(int Cin, int Cout, int stride);
 int mvs_conv_w32_repack(const float* wpacked, float* w32, int Cin, int Cout, hipStream_t st);
 int mvs_convT3d_mfma32(const float* x, int Cin, int D, int H, int W, const float* w32, int Cout, float* out, hipStream_t st);
-int g_conv_tiled = 1;   // A/B knob (mvsnerf_tune "conv_tiled")
-int g_conv_xcd = 1;     // tiles renumbered so that an XCD owns a contiguous range (mvsnerf_tune "conv_xcd")
+MVS_KNOB_DEF(g_conv_tiled, 1)
+MVS_KNOB_DEF(g_conv_xcd, 1)
 static bool act_ok(const float* x, const float* sc, const float* sh) { return x && ((sc == nullptr) == (sh == nullptr)) && mvs_aligned16(x); }
 
 extern "C" int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const float* shift1,
@@ -1346,8 +1351,8 @@ __global__ __launch_bounds__(256) void planesweep_bwd_kernel(const float* __rest
         for (int vv = 1; vv < V; ++vv) {
             const float* ov = o + (vv - 1) * 8;
             const float* fb = feat + (int64_t)vv * H * W * C + c;
-            wv[vv] = ((fb[(int64_t)__float_as_int(ov[4]) * C] * ov[0] + fb[(int64_t)__float_as_int(ov[5]) * C] * ov[1]) +
-                      fb[(int64_t)__float_as_int(ov[6]) * C] * ov[2]) + fb[(int64_t)__float_as_int(ov[7]) * C] * ov[3];
+            wv[vv] = fmaf(fb[(int64_t)__float_as_int(ov[7]) * C], ov[3], fmaf(fb[(int64_t)__float_as_int(ov[6]) * C], ov[2],
+                          fmaf(fb[(int64_t)__float_as_int(ov[5]) * C], ov[1], fb[(int64_t)__float_as_int(ov[4]) * C] * ov[0])));
             s += wv[vv];
         }
         const float k2 = gv * 2.0f * inv, mean = s * inv;
@@ -1537,7 +1542,7 @@ __global__ __launch_bounds__(256, NSRC <= 2 ? 4 : 2) void planesweep_bwd_tiles_k
                 for (int vs = 0; vs < NSRC; ++vs) {
                     wq[vs] = *reinterpret_cast<const f32x4*>(o + vs * 16);
                     cnt += o[vs * 16 + 12];
-                    wv[vs] = ((tap[kk][vs][0] * wq[vs][0] + tap[kk][vs][1] * wq[vs][1]) + tap[kk][vs][2] * wq[vs][2]) + tap[kk][vs][3] * wq[vs][3];
+                    wv[vs] = fmaf(tap[kk][vs][3], wq[vs][3], fmaf(tap[kk][vs][2], wq[vs][2], fmaf(tap[kk][vs][1], wq[vs][1], tap[kk][vs][0] * wq[vs][0])));
                     s += wv[vs];
                 }
                 const float inv = 1.0f / cnt;
@@ -1575,7 +1580,7 @@ __global__ __launch_bounds__(256, NSRC <= 2 ? 4 : 2) void planesweep_bwd_tiles_k
     }
 }
 
-int g_psw_bwd_tiles = 1;   // A/B knob (mvsnerf_tune "psw_bwd_tiles"): 0 = the per-voxel scatter kernel
+MVS_KNOB_DEF(g_psw_bwd_tiles, 1)   // 0 (dev build only) = the per-voxel scatter kernel for every shape; the product uses it for V == 1
 
 template <int NSRC>
 static int planesweep_bwd_tiles_launch(const float* feat, const float* proj, const float* depth, int H, int W, int D, int pad, const float* g_cost, int CP,

@@ -12,6 +12,7 @@
 // wave-uniform, are fetched through the scalar cache.
 #include "common.h"
 #include "act.h"
+#include "knobs.h"
 
 __global__ void conv2d_pack_kernel(const float* __restrict__ w, int ci_real, int co_real, int cin_pad, int cout_pad,
                                    int s_ci, int s_co, int ntaps, int flip, float* __restrict__ packed)
@@ -242,7 +243,6 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(const float* __restri
         }
 }
 
-extern int g_conv_mfma;
 int mvs_conv2d_wgrad_mfma4_parts(int A, int B, int N, int Ho, int Wo, int ksize, int stride, int cap_parts);
 int mvs_conv2d_wgrad_mfma4(const float* g, int A, const ActSrc& x1, int B, int ldx, int N, int Ho, int Wo, int Hi, int Wi, int ksize, int stride,
                            float* partial, int cap_parts, hipStream_t st);

@@ -10,6 +10,7 @@
 #include "mlp_layout.h"
 #include "sample_dev.h"
 #include "lds_dma.h"
+#include "knobs.h"
 
 using namespace mlp;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -77,17 +78,23 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(PackArgs a, float* __rest
     }
 }
 
-// 16-point-tile variant (mlp16.hip): its own fragment order, appended to the packed buffer
+#ifdef MVSNERF_DEV_KNOBS
+// 16-point-tile variant (mlp16.hip, dev build only): its own fragment order, appended to the packed buffer
 size_t mvs_mlp16_packed_floats(int F);
 int mvs_mlp16_pack(const float* const w[11], const float* const b[11], int F, float* packed16, hipStream_t st);
 int mvs_mlp16_fwd(const float* packed16, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
                   const float* dirs, int dirs_stride, int64_t P, int S, int alpha_only, float* raw, hipStream_t st);
+#endif
 static size_t off16(int F) { return (layout(F).total + 3) & ~(size_t)3; }
 
 extern "C" size_t mvsnerf_mlp_packed_floats(int F)
 {
     if (F < 2 || F > MAX_F || (F & 1)) return 0;
+#ifdef MVSNERF_DEV_KNOBS
     return off16(F) + mvs_mlp16_packed_floats(F);
+#else
+    return off16(F);
+#endif
 }
 
 extern "C" int mvsnerf_mlp_pack(const float* const w[11], const float* const b[11], int F, float* packed, void* stream)
@@ -103,7 +110,11 @@ extern "C" int mvsnerf_mlp_pack(const float* const w[11], const float* const b[1
     a.F = F;
     mlp_pack_kernel<<<64, 256, 0, (hipStream_t)stream>>>(a, packed);
     MVS_LAUNCH_CHECK();
+#ifdef MVSNERF_DEV_KNOBS
     return mvs_mlp16_pack(w, b, F, packed + off16(F), (hipStream_t)stream);
+#else
+    return MVSNERF_OK;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ compute
@@ -199,6 +210,7 @@ __device__ __forceinline__ float pe_operand(int t, int half, float px, float py,
     return pe_sin_or_cos(x, half);
 }
 
+#ifdef MVSNERF_DEV_KNOBS   // schedules 0/1/2 (register-staged weights): measured and dropped, dev build only
 // G groups of 32 points per wave; WPS = waves per SIMD the register budget is capped for.
 // SAVE (training forward, G == 1): every operand the backward pass needs is written in slot format (mlp_layout.h);
 // the stores are fire-and-forget and hide under the MFMAs.
@@ -388,6 +400,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_fwd_kernel(
         }
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------ pipelined forward
 // Measured on MI355X: 0.237 ms per 1024x128 batch = 139 TFLOP/s = 88 % of the 157.3 TFLOP/s fp32-MFMA peak; PMC:
@@ -399,7 +412,6 @@ __global__ __launch_bounds__(256, WPS) void mlp_fwd_kernel(
 // Same arithmetic as mlp_fwd_kernel<.., G=1, ..>, different weight logistics: the packed weights are cut into 16 slabs
 // of <= 34 KB (half a 128x128 layer = 32 k-steps) that alternate between two LDS buffers.  While the MFMAs of slab i
 // run, slab i+1 arrives by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write pass); one barrier per slab.
-static long long* g_mlp_census = nullptr;     // diagnostics buffer (4 x int64 per workgroup), set by mvsnerf_debug_set_census
 constexpr int SLAB_FLOATS = 8704;                        // 34 KB = 34 k-steps x 4 blocks x 64 lanes (views: 68 x 2)
 constexpr int PIPE_LDS_FLOATS = 2 * SLAB_FLOATS + V_TOTAL;
 
@@ -652,37 +664,49 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
 
 template <bool AO, bool SAVE>
 static int launch_mlp_pipe(const float* packed, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
-                           const float* dirs, int dirs_stride, int64_t P, int S, float* raw, hipStream_t st, float* saved = nullptr)
+                           const float* dirs, int dirs_stride, int64_t P, int S, float* raw, hipStream_t st, float* saved = nullptr, long long* census = nullptr)
 {
     const size_t lds_bytes = PIPE_LDS_FLOATS * sizeof(float);
     static unsigned long long lds_cap_set = 0;          // per-device bit mask (common.h)
     if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_pipe_kernel<AO, SAVE>), (int)lds_bytes, &lds_cap_set)) return rc_;
-    mlp_fwd_pipe_kernel<AO, SAVE><<<mvs_cdiv(P, 128), 256, lds_bytes, st>>>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, saved, g_mlp_census);
+    mlp_fwd_pipe_kernel<AO, SAVE><<<mvs_cdiv(P, 128), 256, lds_bytes, st>>>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, saved, census);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
 
-// A/B knob (mvsnerf_tune "mlp_gather"), default OFF: rendering() with three source views runs the lookups in the MLP kernel's prologue.
-// Measured at config 2 (scratch/ab_gather.py): 0.2574 ms/step fused vs 0.2551 ms with the separate 11 us gather launch - the lookup's
-// memory latency sits in front of every workgroup's first GEMM (the pts_bias product needs the features), and the 512 workgroups of
-// the first round all pay it at once; the stand-alone gather kernel hides the same latency behind 2048 waves of its own.
-int g_mlp_gather = 0;
+// Gather fused into the MLP kernel's prologue (knob g_mlp_gather, dev build only): rendering() with three source views runs the lookups
+// in this kernel instead of a launch of their own.  Measured at config 2 (scratch/ab_gather.py): 0.2574 ms/step fused vs 0.2551 ms with the
+// separate 11 us gather launch - the lookup's memory latency sits in front of every workgroup's first GEMM (the pts_bias product needs the
+// features), and the 512 workgroups of the first round all pay it at once; the stand-alone gather kernel hides the same latency behind
+// 2048 waves of its own.  The product build therefore always answers MVSNERF_EUNSUPPORTED here and raymarch.hip launches the gather kernel.
+MVS_KNOB_DEF(g_mlp_gather, 0)
+MVS_KNOB_DEF(g_mlp_variant, 3)
 
-// Used by mvsnerf_raymarch_fwd / mvsnerf_render_pixels_fwd (raymarch.hip): gather + MLP in one launch.  Returns MVSNERF_EUNSUPPORTED
-// when the shape is outside what the fused prologue is built for (the caller then launches the gather kernel and the plain MLP kernel).
+// Used by mvsnerf_raymarch_fwd / mvsnerf_render_pixels_fwd (raymarch.hip): gather + MLP in one launch, or MVSNERF_EUNSUPPORTED
+// (the caller then launches the gather kernel and the plain MLP kernel).
 int mvs_mlp_fwd_gather(const float* packed, const float* vol, int D, int H, int W, const float* imgs_nhwc4, int V, int IH, int IW,
                        const float* w2c, const float* K, const float* pts, const float* ndc, const float* rays_dir,
-                       int64_t N, int S, float* feat, float* raw, hipStream_t st);
+                       int64_t N, int S, float* feat, float* raw, hipStream_t st)
+{
+#ifdef MVSNERF_DEV_KNOBS
+    const int64_t P = N * S;
+    const bool small = (int64_t)D * H < (1 << 24) && W < (1 << 24) && (int64_t)D * H * W * 8 < ((int64_t)1 << 31) &&
+                       (int64_t)V * IH < (1 << 24) && IW < (1 << 24) && (int64_t)V * IH * IW * 4 < ((int64_t)1 << 31);
+    if (!g_mlp_gather || g_mlp_variant != 3 || V != 3 || !small || P < 1) return MVSNERF_EUNSUPPORTED;
+    if (!mvs_aligned16(packed) || !mvs_aligned16(raw) || !mvs_aligned16(vol) || !mvs_aligned16(imgs_nhwc4) || (reinterpret_cast<uintptr_t>(feat) & 7u)) return MVSNERF_EUNSUPPORTED;
+    const size_t lds_bytes = PIPE_LDS_FLOATS * sizeof(float);
+    static unsigned long long lds_cap_set = 0;
+    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_pipe_kernel<false, false, true>), (int)lds_bytes, &lds_cap_set)) return rc_;
+    const GatherIn gi{vol, D, H, W, imgs_nhwc4, IH, IW, w2c, K, pts, rays_dir, feat};
+    mlp_fwd_pipe_kernel<false, false, true><<<mvs_cdiv(P, 128), 256, lds_bytes, st>>>(packed, 20, ndc, 3, nullptr, 20, nullptr, 3, P, S, raw, nullptr, nullptr, gi);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+#else
+    return MVSNERF_EUNSUPPORTED;
+#endif
+}
 
-// tuning knob (A/B benchmarking only): 0 = 32 pts/wave, 2 waves/SIMD, register-staged weights; 1 = 64 pts/wave, 1 wave/SIMD;
-// 2 = 32 pts/wave, 1 wave/SIMD; 3 = 32 pts/wave, 2 waves/SIMD, double-buffered LDS-DMA weight slabs (default)
-static int g_mlp_variant = 3;
-extern int g_conv_tiled;
-extern int g_psw_bwd_tiles;
-extern int g_conv_xcd;
-extern int g_conv_mfma;
-extern int g_split_sched;     // mlp_bf16.hip
-
+#ifdef MVSNERF_DEV_KNOBS
 extern "C" int mvsnerf_tune(const char* key, int value)
 {
     if (!key) return MVSNERF_EINVAL;
@@ -707,27 +731,10 @@ static int launch_mlp(const float* packed, int F, const float* ndc, int ndc_stri
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
+#endif
 
-int mvs_mlp_fwd_gather(const float* packed, const float* vol, int D, int H, int W, const float* imgs_nhwc4, int V, int IH, int IW,
-                       const float* w2c, const float* K, const float* pts, const float* ndc, const float* rays_dir,
-                       int64_t N, int S, float* feat, float* raw, hipStream_t st)
-{
-    const int64_t P = N * S;
-    const bool small = (int64_t)D * H < (1 << 24) && W < (1 << 24) && (int64_t)D * H * W * 8 < ((int64_t)1 << 31) &&
-                       (int64_t)V * IH < (1 << 24) && IW < (1 << 24) && (int64_t)V * IH * IW * 4 < ((int64_t)1 << 31);
-    if (!g_mlp_gather || g_mlp_variant != 3 || g_mlp_census || V != 3 || !small || P < 1) return MVSNERF_EUNSUPPORTED;
-    if (!mvs_aligned16(packed) || !mvs_aligned16(raw) || !mvs_aligned16(vol) || !mvs_aligned16(imgs_nhwc4) || (reinterpret_cast<uintptr_t>(feat) & 7u)) return MVSNERF_EUNSUPPORTED;
-    const size_t lds_bytes = PIPE_LDS_FLOATS * sizeof(float);
-    static unsigned long long lds_cap_set = 0;
-    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_pipe_kernel<false, false, true>), (int)lds_bytes, &lds_cap_set)) return rc_;
-    const GatherIn gi{vol, D, H, W, imgs_nhwc4, IH, IW, w2c, K, pts, rays_dir, feat};
-    mlp_fwd_pipe_kernel<false, false, true><<<mvs_cdiv(P, 128), 256, lds_bytes, st>>>(packed, 20, ndc, 3, nullptr, 20, nullptr, 3, P, S, raw, nullptr, nullptr, gi);
-    MVS_LAUNCH_CHECK();
-    return MVSNERF_OK;
-}
-
-extern "C" int mvsnerf_mlp_fwd(const float* packed, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
-                               const float* dirs, int dirs_stride, int64_t N, int S, int alpha_only, float* raw, void* stream)
+static int mlp_fwd_checked(const float* packed, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
+                           const float* dirs, int dirs_stride, int64_t N, int S, int alpha_only, float* raw, void* stream, long long* census)
 {
     if (!packed || !ndc || !feat || !raw || N < 0 || S < 1 || feat_stride < F || ndc_stride < 3) return MVSNERF_EINVAL;
     if (!alpha_only && dirs_stride < 3) return MVSNERF_EINVAL;
@@ -737,10 +744,9 @@ extern "C" int mvsnerf_mlp_fwd(const float* packed, int F, const float* ndc, int
     const int64_t P = N * S;
     if (P == 0) return MVSNERF_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (g_mlp_variant == 4) {                      // 16 points per wave (mlp16.hip), its weights follow the 32-point layout in `packed`
-        const int rc = mvs_mlp16_fwd(packed + off16(F), F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st);
-        return rc;
-    }
+#ifdef MVSNERF_DEV_KNOBS
+    if (g_mlp_variant == 4)                        // 16 points per wave (mlp16.hip), its weights follow the 32-point layout in `packed`
+        return mvs_mlp16_fwd(packed + off16(F), F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st);
 #define MVS_MLP(AO, G, WPS) launch_mlp<AO, G, WPS>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, st)
     switch (g_mlp_variant * 2 + (alpha_only ? 1 : 0)) {
         case 0: return MVS_MLP(false, 1, 2);
@@ -749,10 +755,27 @@ extern "C" int mvsnerf_mlp_fwd(const float* packed, int F, const float* ndc, int
         case 3: return MVS_MLP(true, 2, 1);
         case 4: return MVS_MLP(false, 1, 1);
         case 5: return MVS_MLP(true, 1, 1);
-        case 6: return launch_mlp_pipe<false, false>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, st);
-        default: return launch_mlp_pipe<true, false>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, st);
+        default: break;
     }
 #undef MVS_MLP
+#endif
+    if (alpha_only) return launch_mlp_pipe<true, false>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, st, nullptr, census);
+    return launch_mlp_pipe<false, false>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, st, nullptr, census);
+}
+
+extern "C" int mvsnerf_mlp_fwd(const float* packed, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
+                               const float* dirs, int dirs_stride, int64_t N, int S, int alpha_only, float* raw, void* stream)
+{
+    return mlp_fwd_checked(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, N, S, alpha_only, raw, stream, nullptr);
+}
+
+// The same launch with a per-workgroup timing record (stateless diagnostics for bench.py's sustained-clock figure): census =
+// (N*S + 127) / 128 rows of 16 int64 {start, end (100 MHz wall clock), HW_ID, XCC_ID, phase stamps [4..12], shader-clock ticks [13]}.
+extern "C" int mvsnerf_mlp_fwd_census(const float* packed, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
+                                      const float* dirs, int dirs_stride, int64_t N, int S, int alpha_only, float* raw, long long* census, void* stream)
+{
+    if (!census) return MVSNERF_EINVAL;
+    return mlp_fwd_checked(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, N, S, alpha_only, raw, stream, census);
 }
 
 // Training forward: identical arithmetic to mvsnerf_mlp_fwd (32 points per wave) + the activation store the
@@ -765,11 +788,14 @@ extern "C" int mvsnerf_mlp_fwd_train(const float* packed, int F, const float* nd
     if (!mvs_aligned16(packed) || !mvs_aligned16(raw) || !mvs_aligned16(saved)) return MVSNERF_EALIGN;
     const int64_t P = N * S;
     if (P == 0) return MVSNERF_OK;
-    if (g_mlp_variant == 3)
-        return launch_mlp_pipe<false, true>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, (hipStream_t)stream, saved);
-    return launch_mlp<false, 1, 2, true>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, (hipStream_t)stream, saved);
+#ifdef MVSNERF_DEV_KNOBS
+    if (g_mlp_variant != 3)
+        return launch_mlp<false, 1, 2, true>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, (hipStream_t)stream, saved);
+#endif
+    return launch_mlp_pipe<false, true>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, (hipStream_t)stream, saved);
 }
 
+#ifdef MVSNERF_DEV_KNOBS
 // diagnostics: resident workgroups per CU the runtime grants the MLP kernels (A/B tooling, not part of the reference surface)
 extern "C" int mvsnerf_debug_mlp_occupancy(int variant)
 {
@@ -784,5 +810,4 @@ extern "C" int mvsnerf_debug_mlp_occupancy(int variant)
     }
     return e == hipSuccess ? n : -(int)e;
 }
-
-extern "C" int mvsnerf_debug_set_census(long long* buf) { g_mlp_census = buf; return MVSNERF_OK; }
+#endif

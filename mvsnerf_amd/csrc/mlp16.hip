@@ -1,3 +1,5 @@
+// DEV BUILD ONLY (`make dev`, -DMVSNERF_DEV_KNOBS): a measured-and-dropped schedule, not compiled into libmvsnerf_hip.so.
+#ifdef MVSNERF_DEV_KNOBS
 // 16-point-tile variant of the fused Embedder + Renderer_ours forward (inference): same network, same fp32 MFMA arithmetic as
 // mlp.hip, on v_mfma_f32_16x16x4_f32 instead of v_mfma_f32_32x32x2_f32.
 //
@@ -383,3 +385,5 @@ int mvs_mlp16_fwd(const float* packed16, int F, const float* ndc, int ndc_stride
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
+
+#endif   // MVSNERF_DEV_KNOBS

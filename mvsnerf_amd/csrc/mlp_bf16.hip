@@ -10,6 +10,7 @@
 #include "common.h"
 #include "lds_dma.h"
 #include "mlp_layout.h"
+#include "knobs.h"
 
 using namespace mlp;
 
@@ -823,7 +824,7 @@ extern "C" int mvsnerf_mlp_fwd_bf16_train(const void* packed_bf16, const float* 
     return MVSNERF_OK;
 }
 
-int g_split_sched = 0;    // A/B knob (mvsnerf_tune "split_sched"): schedule of the 3-piece kernel
+MVS_KNOB_DEF(g_split_sched, 0)    // knobs.h
 
 extern "C" size_t mvsnerf_mlp_packed_split_elems(int F, int n_split)
 {

@@ -287,11 +287,9 @@ def test_bf16_training_vs_torch_emulation():
 
 
 @pytest.mark.parametrize("V,H,W,pad,D,with_img", [(3, 30, 41, 3, 10, True), (5, 16, 24, 4, 19, True), (2, 32, 32, 0, 8, False), (3, 128, 160, 24, 128, False)])
-def test_planesweep_bwd_vs_float64_autograd(V, H, W, pad, D, with_img):
-    """The plane-sweep backward (register sum over depth for the reference view, 64-bit fixed-point LDS patches for the source views)
-    against float64 autograd through a torch restatement of models.py:839-893 on the same GPU.  The last case is the training shape
-    (timed).  (A/B against the per-voxel scatter kernel it replaced: scratch/dev_tests.)"""
-    import torch.nn.functional as F
+def test_planesweep_bwd_tiles_vs_scatter(V, H, W, pad, D, with_img):
+    """The tile form of the plane-sweep backward (register sum over depth for the reference view, LDS patches for the source views)
+    against the per-voxel scatter kernel: same terms, different float summation order.  The last case is the training shape (timed)."""
     from mvsnerf_amd import _lib
     from mvsnerf_amd.ops import stream_ptr
     from mvsnerf_amd.synth import make_rig
@@ -303,45 +301,26 @@ def test_planesweep_bwd_vs_float64_autograd(V, H, W, pad, D, with_img):
     g = torch.Generator(DEV).manual_seed(V * 100 + D)
     feats = torch.randn((V, H, W, 32), device=DEV, generator=g)
     CP = (32 + 3 * V + 3) // 4 * 4 if with_img else 32
-    c_var = 3 * V if with_img else 0
     Hp, Wp = H + 2 * pad, W + 2 * pad
     g_cost = torch.randn((D, Hp, Wp, CP), device=DEV, generator=g)
     L = _lib.lib()
-    for rep in range(3):
-        gf = torch.zeros((V, H, W, 32), device=DEV)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        rc = L.mvsnerf_planesweep_costvar_bwd(feats.data_ptr(), proj.data_ptr(), depth.data_ptr(), V, 32, H, W, D, pad, g_cost.data_ptr(), CP,
-                                              int(with_img), gf.data_ptr(), stream_ptr())
-        e1.record(); torch.cuda.synchronize()
-        assert rc == 0
-    ms = e0.elapsed_time(e1)
-    # ---- float64 reference (grid coordinates in fp32 as the kernel computes them, everything downstream in float64)
-    f = feats.double().permute(0, 3, 1, 2).contiguous().requires_grad_()                    # (V,32,H,W)
-    ys, xs = torch.meshgrid(torch.arange(Hp, device=DEV, dtype=torch.float32) - pad, torch.arange(Wp, device=DEV, dtype=torch.float32) - pad, indexing="ij")
-    uv1 = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(Hp * Wp, device=DEV)], 0)   # (3,N)
-    ref = F.pad(f[0], (pad, pad, pad, pad))[:, None].expand(-1, D, -1, -1).reshape(32, D, Hp * Wp)
-    # the view count per voxel from the HIP forward kernel (a step function of the fp32 grid: torch's own fp32 arithmetic may round a
-    # coordinate at the frustum border the other way, and a flipped count is an O(1) difference that says nothing about the gradient)
-    cost_tmp, cnt_k = torch.empty((D, Hp, Wp, 32), device=DEV), torch.empty((D, Hp, Wp), device=DEV)
-    assert L.mvsnerf_planesweep_costvar_fwd(feats.data_ptr(), 0, proj.data_ptr(), depth.data_ptr(), V, 32, H, W, D, pad, cost_tmp.data_ptr(), 32,
-                                            cnt_k.data_ptr(), 0, stream_ptr()) == 0
-    del cost_tmp
-    cnt = cnt_k.double().reshape(D, Hp * Wp)
-    s, s2 = ref, ref ** 2
-    for v in range(1, V):
-        pr = (proj[v, :, :3] @ uv1)[None] + (proj[v, :, 3:][None] / depth[:, None, None])   # (D,3,N) fp32
-        gx = pr[:, 0] / pr[:, 2] / ((W - 1) / 2) - 1
-        gy = pr[:, 1] / pr[:, 2] / ((H - 1) / 2) - 1
-        grid = torch.stack([gx, gy], -1).double()[None]                                   # (1,D,N,2)
-        w = F.grid_sample(f[v:v + 1], grid, mode="bilinear", padding_mode="zeros", align_corners=True)[0]   # (32,D,N)
-        s, s2 = s + w, s2 + w ** 2
-    var = s2 / cnt - (s / cnt) ** 2
-    gv = g_cost[..., c_var:c_var + 32].double().permute(3, 0, 1, 2).reshape(32, D, Hp * Wp)
-    (gref,) = torch.autograd.grad((var * gv).sum(), f)
-    gref = gref.permute(0, 2, 3, 1)
-    scale = float(gref.abs().max())
-    err = float((gf.double() - gref).abs().max())
-    print(f"[planesweep bwd V={V} {D}x{Hp}x{Wp}] {ms:.3f} ms; max err vs float64 autograd {err:.2e} (|g| max {scale:.1f})")
+    out, ms = {}, {}
+    for mode in (0, 1):
+        assert L.mvsnerf_tune(b"psw_bwd_tiles", mode) == 0
+        try:
+            for rep in range(3):
+                gf = torch.zeros((V, H, W, 32), device=DEV)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = L.mvsnerf_planesweep_costvar_bwd(feats.data_ptr(), proj.data_ptr(), depth.data_ptr(), V, 32, H, W, D, pad, g_cost.data_ptr(), CP,
+                                                      int(with_img), gf.data_ptr(), stream_ptr())
+                e1.record(); torch.cuda.synchronize()
+                assert rc == 0
+            out[mode], ms[mode] = gf, e0.elapsed_time(e1)
+        finally:
+            L.mvsnerf_tune(b"psw_bwd_tiles", 1)
+    scale = float(out[0].abs().max())
+    err = float((out[0] - out[1]).abs().max())
+    print(f"[planesweep bwd V={V} {D}x{Hp}x{Wp}] scatter {ms[0]:.3f} ms, tiles {ms[1]:.3f} ms; max diff {err:.2e} (|g| max {scale:.1f})")
     assert scale > 0 and err < 2e-5 * scale

@@ -135,6 +135,26 @@ def test_abn_stats_and_conv_vs_torch_full_size():
         assert maxabs(raw.cpu(), ref.cpu()) < 2e-4
 
 
+@pytest.mark.parametrize("dims", [(8, 24, 40), (16, 24, 32), (8, 8, 8)])
+def test_xcd_tile_numbering_does_not_change_results(dims, mvs):
+    """The convolution kernels renumber their tiles so that an XCD owns a contiguous range (common.h: xcd_contiguous_tile).
+    A pure permutation of the workgroups: outputs must be bit-identical with the numbering switched off, also when the tile
+    count is not a multiple of 8 (8x24x40 -> 30 tiles of the stride-1 layers)."""
+    from mvsnerf_amd import _lib
+    D, H, W = dims
+    x = torch.randn((1, 41, D, H, W), generator=torch.Generator().manual_seed(3)).to(DEV)
+    outs = []
+    for on in (1, 0):
+        assert _lib.lib().mvsnerf_tune(b"conv_xcd", on) == 0
+        try:
+            with torch.no_grad():
+                outs.append(mvs.cost_reg_2(x).clone())
+        finally:
+            _lib.lib().mvsnerf_tune(b"conv_xcd", 1)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.isfinite(outs[0]).all()
+
+
 def _blocked(x_cl, cp):
     """(D,H,W,C) channel-last -> [cp/4][D*H*W][4] (zero padding channels)."""
     D, H, W, C = x_cl.shape
@@ -212,13 +232,11 @@ def test_conv0_blocked_wgrad_full_size_vs_rows_kernel():
     (64, 32, 2, (4, 6, 5), False, True),        # conv5
     (64, 64, 1, (16, 22, 26), False, True),     # conv6 at the training size
 ])
-def test_conv3d_wgrad_vs_float64(A, B, stride, dims, g2, xact):
-    """The matrix-core weight gradient of the 16/32/64-channel layers (wgrad_mfma.hip), with the lazily applied activations and the skip
-    sum of the transposed layers, against its float64 definition  gw[a,b,tap] = sum_vox G[vox,a] * X[vox*stride + tap - 1, b]
-    (27 float64 matrix products on the GPU).  (The A/B against the VALU kernel it replaced: scratch/dev_tests.)"""
+def test_conv3d_wgrad_matrix_cores_vs_rows_kernel(A, B, stride, dims, g2, xact):
+    """The matrix-core weight gradient of the 16/32/64-channel layers (wgrad_mfma.hip) against the VALU kernel it replaces, with the
+    lazily applied activations and the skip sum of the transposed layers; different summation orders."""
     from mvsnerf_amd import _lib
     from mvsnerf_amd.ops import stream_ptr
-    import torch.nn.functional as F
     Do, Ho, Wo = dims
     Di, Hi, Wi = (Do, Ho, Wo) if stride == 1 else (2 * Do, 2 * Ho, 2 * Wo)
     gen = torch.Generator(DEV).manual_seed(A * 100 + B + stride)
@@ -230,31 +248,27 @@ def test_conv3d_wgrad_vs_float64(A, B, stride, dims, g2, xact):
     L = _lib.lib()
     ws = torch.empty(L.mvsnerf_conv3d_wgrad_workspace_floats(A, B), device=DEV)
     p = lambda t: 0 if t is None else t.data_ptr()
-    gw = torch.full((A, B, 3, 3, 3), float("nan"), device=DEV)
-    for rep in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        rc = L.mvsnerf_conv3d_wgrad(p(G1), p(gs[0][0]) if g2 else 0, p(gs[0][1]) if g2 else 0, p(G2), p(gs[1][0]) if g2 else 0, p(gs[1][1]) if g2 else 0, A,
-                                    p(X1), p(xs[0]) if xact else 0, p(xs[1]) if xact else 0, 0, 0, 0, B, B, Do, Ho, Wo, Di, Hi, Wi, stride,
-                                    gw.data_ptr(), ws.data_ptr(), stream_ptr())
-        e1.record(); torch.cuda.synchronize()
-        assert rc == 0
-    ms = e0.elapsed_time(e1)
-    act = lambda t, sc, sh: F.leaky_relu(t.double() * sc.double() + sh.double(), 0.01)
-    G = (act(G1, *gs[0]) + act(G2, *gs[1])) if g2 else G1.double()
-    X = act(X1, *xs) if xact else X1.double()
-    Xp = F.pad(X, (0, 0, 1, 1, 1, 1, 1, 1))                                  # zero padding 1 on z, y, x
-    Gm = G.reshape(-1, A)
-    ref = torch.empty((A, B, 3, 3, 3), dtype=torch.float64, device=DEV)
-    for dz in range(3):
-        for dy in range(3):
-            for dx in range(3):
-                xt = Xp[dz:dz + stride * Do:stride, dy:dy + stride * Ho:stride, dx:dx + stride * Wo:stride].reshape(-1, B)
-                ref[:, :, dz, dy, dx] = Gm.t() @ xt
-    scale, err = float(ref.abs().max()), float((gw.double() - ref).abs().max())
+    out, ms = {}, {}
+    for mode in (0, 1):
+        assert L.mvsnerf_tune(b"conv_mfma", mode) == 0
+        try:
+            gw = torch.full((A, B, 3, 3, 3), float("nan"), device=DEV)
+            for rep in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = L.mvsnerf_conv3d_wgrad(p(G1), p(gs[0][0]) if g2 else 0, p(gs[0][1]) if g2 else 0, p(G2), p(gs[1][0]) if g2 else 0, p(gs[1][1]) if g2 else 0, A,
+                                            p(X1), p(xs[0]) if xact else 0, p(xs[1]) if xact else 0, 0, 0, 0, B, B, Do, Ho, Wo, Di, Hi, Wi, stride,
+                                            gw.data_ptr(), ws.data_ptr(), stream_ptr())
+                e1.record(); torch.cuda.synchronize()
+                assert rc == 0
+            out[mode], ms[mode] = gw, e0.elapsed_time(e1)
+        finally:
+            L.mvsnerf_tune(b"conv_mfma", 1)
+    scale, err = float(out[0].abs().max()), float((out[0] - out[1]).abs().max())
     gf = Do * Ho * Wo * A * B * 54 / 1e9
-    print(f"[conv3d wgrad A={A} B={B} s{stride} {Do}x{Ho}x{Wo}] {ms:.3f} ms ({gf / ms:.1f} TFLOP/s); max err vs float64 {err:.2e} (|gw| max {scale:.1f})")
-    assert torch.isfinite(gw).all() and err < 1e-5 * scale
+    print(f"[conv3d wgrad A={A} B={B} s{stride} {Do}x{Ho}x{Wo}] rows {ms[0]:.3f} ms, matrix cores {ms[1]:.3f} ms ({gf / ms[1]:.1f} TFLOP/s); "
+          f"max diff {err:.2e} (|gw| max {scale:.1f})")
+    assert torch.isfinite(out[1]).all() and err < 2e-5 * scale
 
 
 def test_pack_weights_multi_equals_the_single_layout_entries():

@@ -88,9 +88,9 @@ def test_convbnrelu_standalone():
     (32, 16, 5, 2, (128, 160), 16),  # conv2.0 at the training size
     (32, 32, 3, 1, (128, 160), 32),  # conv2.1 at the training size
 ])
-def test_conv2d_wgrad_vs_float64(A, B, k, stride, hw, ldx):
-    """FeatureNet's weight gradients on the matrix cores (wgrad_mfma.hip, the images as the z axis) with the lazily applied InPlaceABN
-    of the input layer, against the float64 definition.  (A/B against the VALU kernel it replaced: scratch/dev_tests.)"""
+def test_conv2d_wgrad_matrix_cores_vs_valu_kernel(A, B, k, stride, hw, ldx):
+    """FeatureNet's weight gradients on the matrix cores (wgrad_mfma.hip, the images as the z axis) against the VALU kernel, with the
+    lazily applied InPlaceABN of the input layer; different summation orders."""
     from mvsnerf_amd import _lib
     from mvsnerf_amd.ops import stream_ptr
     N, (Ho, Wo) = 3, hw
@@ -103,21 +103,29 @@ def test_conv2d_wgrad_vs_float64(A, B, k, stride, hw, ldx):
     sc, sh = (r(B).abs() + 0.5, r(B)) if B > 3 else (None, None)
     L = _lib.lib()
     ws = torch.empty(L.mvsnerf_conv2d_wgrad_workspace_floats(A, B, k), device=DEV)
-    gw = torch.full((A, B, k, k), float("nan"), device=DEV)
-    for rep in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        rc = L.mvsnerf_conv2d_wgrad(G.data_ptr(), A, X.data_ptr(), 0 if sc is None else sc.data_ptr(), 0 if sh is None else sh.data_ptr(), B, ldx,
-                                    N, Ho, Wo, Hi, Wi, k, stride, gw.data_ptr(), ws.data_ptr(), stream_ptr())
-        e1.record(); torch.cuda.synchronize()
-        assert rc == 0
-    ms = e0.elapsed_time(e1)
+    out, ms = {}, {}
+    for mode in (0, 1):
+        assert L.mvsnerf_tune(b"conv_mfma", mode) == 0
+        try:
+            gw = torch.full((A, B, k, k), float("nan"), device=DEV)
+            for rep in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = L.mvsnerf_conv2d_wgrad(G.data_ptr(), A, X.data_ptr(), 0 if sc is None else sc.data_ptr(), 0 if sh is None else sh.data_ptr(), B, ldx,
+                                            N, Ho, Wo, Hi, Wi, k, stride, gw.data_ptr(), ws.data_ptr(), stream_ptr())
+                e1.record(); torch.cuda.synchronize()
+                assert rc == 0
+            out[mode], ms[mode] = gw, e0.elapsed_time(e1)
+        finally:
+            L.mvsnerf_tune(b"conv_mfma", 1)
     # float64 definition: gw = d/dW sum(conv2d(act(X), W) * G)
     xa = X[..., :B].double()
     if sc is not None:
         xa = torch.nn.functional.leaky_relu(xa * sc.double() + sh.double(), 0.01)
     ref = torch.nn.grad.conv2d_weight(xa.permute(0, 3, 1, 2), (A, B, k, k), G.double().permute(0, 3, 1, 2), stride=stride, padding=k // 2)
     scale = float(ref.abs().max())
-    e_mfma = float((gw.double() - ref).abs().max())
-    print(f"[conv2d wgrad A={A} B={B} k{k} s{stride} {N}x{Ho}x{Wo}] {ms:.3f} ms, max err vs float64 {e_mfma:.2e}; |gw| max {scale:.1f}")
-    assert torch.isfinite(gw).all() and e_mfma < 1e-5 * scale
+    e_valu, e_mfma = float((out[0].double() - ref).abs().max()), float((out[1].double() - ref).abs().max())
+    print(f"[conv2d wgrad A={A} B={B} k{k} s{stride} {N}x{Ho}x{Wo}] VALU {ms[0]:.3f} ms (err {e_valu:.2e}), matrix cores {ms[1]:.3f} ms (err {e_mfma:.2e}); "
+          f"|gw| max {scale:.1f}")
+    assert torch.isfinite(out[1]).all() and e_mfma < 1e-5 * scale
+    assert e_valu < 1e-5 * scale

@@ -25,12 +25,14 @@ def test_library_builds_and_exports_header_symbols():
     missing = [n for n in names if not hasattr(l, n)]
     assert not missing, f"declared in the header but not exported: {missing}"
     assert sorted(_lib.SIGNATURES) == names, (set(names) ^ set(_lib.SIGNATURES))
-    assert _lib.lib().mvsnerf_abi_version() == 7
+    assert _lib.lib().mvsnerf_abi_version() == 8
+    # no A/B switches and no diagnostics state in the product library (csrc/knobs.h: dev build only)
+    exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert not re.search(r"mvsnerf_tune|mvsnerf_debug|\bg_(conv|mlp|psw|split)_", exported)
     # pure host-side queries work without a GPU
-    # 32-point layout (12 feature k-steps x 4 blocks x 64 lanes, ...) followed by the 16-point layout of the same weights
+    # 32-point layout (12 feature k-steps x 4 blocks x 64 lanes, ...)
     n32 = 12 * 256 + 8192 * 2 + 16384 * 6 + 68 * 128 + 1416
-    n16 = 8 * 512 + 8192 * 2 + 16384 * 6 + 36 * 256 + 1416
-    assert _lib.lib().mvsnerf_mlp_packed_floats(20) == n32 + n16
+    assert _lib.lib().mvsnerf_mlp_packed_floats(20) == n32
     assert _lib.lib().mvsnerf_mlp_packed_floats(21) == 0
 
 

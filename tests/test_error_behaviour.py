@@ -28,7 +28,7 @@ def test_c_abi_rejects_bad_arguments_without_launching():
     assert l.mvsnerf_planesweep_costvar_fwd(p, 0, p, p, 3, 16, 8, 8, 4, 0, p, 16, p, 0, 0) == EUNSUPPORTED   # C != 32
     assert l.mvsnerf_raymarch_fwd(None, 0) == EINVAL and l.mvsnerf_render_pixels_fwd(None, 0) == EINVAL
     assert l.mvsnerf_render_workspace_floats(0, 128, 3) == 0
-    assert l.mvsnerf_tune(b"no_such_knob", 1) != 0
+    assert not hasattr(l, "mvsnerf_tune") and not hasattr(l, "mvsnerf_debug_set_census")     # the product library has no A/B switches (csrc/knobs.h)
 
 
 def test_python_layer_raises_and_names_the_op():

@@ -105,6 +105,9 @@ def test_stage_isolated(scene, mvs):
         e_rgbch, e_var = float(err[:, :9].max()), float(err[:, 9:].max())
         _record("planesweep_rgb_channels_max_abs_err", e_rgbch)
         _record("planesweep_variance_max_abs_err", e_var)
+        # the sweep follows the CPU reference operation for operation (encoder.hip planesweep_kernel): count the values whose BITS differ
+        n_bits = int((cost.cpu().view(torch.int32) != s["cost_ref"].view(torch.int32)).masked_fill_(bad.expand_as(err), False).sum())
+        _record("planesweep_values_with_different_bits_of_%d" % cost.numel(), n_bits)
         e_var64 = float((cost.cpu()[:, 9:] - s["cvar64"]).abs().masked_fill_(bad.expand(-1, 32, -1, -1, -1), 0).max())
         _record("planesweep_variance_max_abs_err_vs_f64", e_var64)
         _record("oracle_f32_variance_max_abs_err_vs_f64", s["noise"]["cost_variance"])
@@ -156,6 +159,28 @@ def test_chained_images_to_rgb(scene, mvs):
     sig_ref = ref[6][..., 3]
     serr = sig.cpu().double() - sig_ref.double()
     e_sig_abs = float(serr.abs().max())
+    n_sig_over = int((serr.abs() > TOL_SIGMA).sum())
+    sig_p999 = float(serr.abs().flatten().kthvalue(int(0.999 * serr.numel()))[0])
+    _record("sigma_end_to_end_samples_over_1e-4_of_%d" % serr.numel(), n_sig_over)
+    _record("sigma_end_to_end_abs_err_p99.9", sig_p999)
+    # the ray march alone: HIP ray march on the ORACLE's volume against the oracle (what is left of the sigma error when the encoder's is taken out)
+    with torch.no_grad():
+        vol_o = s["vol_ref"].to(DEV).contiguous(memory_format=torch.channels_last_3d)
+        rgb_sv, feat_sv, *_ = R.rendering(args, pose_d, pts.to(DEV), ndc.to(DEV), z.to(DEV), ro.to(DEV), dirs.to(DEV), vol_o,
+                                 s["rig"]["images_raw"][:, :3].to(DEV), network_fn=net, network_query_fn=qfn)
+        sig_sv = R.rendering.last_raw.view(N_RAYS, N_SAMPLES, 4)[..., 3].cpu()
+        # ... and the network alone: the HIP MLP on the ORACLE's per-sample features (no lookup of ours in front of it)
+        from mvsnerf_amd import ops
+        angle = ops.dir_feature(dirs.to(DEV).contiguous(), pose_d["w2cs"][0].contiguous(), normalize=True)
+        raw_iso = qfn(ndc.to(DEV).contiguous(), angle, ref[1].to(DEV).contiguous(), net).cpu()
+    _record("sigma_mlp_isolated_max_abs_err", maxabs(raw_iso[..., 3], sig_ref))
+    _record("sigma_mlp_isolated_samples_over_1e-4", int(((raw_iso[..., 3].double() - sig_ref.double()).abs() > TOL_SIGMA).sum()))
+    _record("rgb_raw_mlp_isolated_max_abs_err", maxabs(raw_iso[..., :3], ref[6][..., :3]))
+    _record("input_feat_same_volume_max_abs_err", maxabs(feat_sv.cpu(), ref[1]))
+    e_sig_sv = maxabs(sig_sv, sig_ref)
+    _record("sigma_same_volume_max_abs_err", e_sig_sv)
+    _record("sigma_same_volume_samples_over_1e-4", int(((sig_sv.double() - sig_ref.double()).abs() > TOL_SIGMA).sum()))
+    _record("rgb_same_volume_max_abs_err", maxabs(rgb_sv.cpu(), ref[0]))
     mse = float(((rgb.cpu().double() - ref[0].double()) ** 2).mean())
     psnr = 10 * np.log10(1.0 / max(mse, 1e-30))
     _record("rgb_end_to_end_max_abs_err", e_rgb)
