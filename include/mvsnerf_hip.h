@@ -225,6 +225,19 @@ int mvsnerf_raygen_fwd(const float* xs, const float* ys, int64_t first_pixel, in
                        const float* t_rand, int64_t N, int S,
                        float* rays_pts, float* rays_dir, float* rays_ndc, float* z_vals, float* pix, void* stream);
 
+/* build_rays of one training step in ONE launch (utils.py:148-241 downstream of the RNG draws; train_mvs_nerf_pl.py:119): the ray
+ * generation above plus the per-pixel gathers - target colours (tgt_img [3][H_img][W_img] -> colors [N][3], utils.py:190-192), ground-truth
+ * depth (depth_map [H_img][W_img] -> rays_depth [N], :194-196; both NULL when the batch carries no depth) - and the per-pixel depth
+ * ranges: depth_mode 0 = near/far of the view; 1 = importanceSampling (near, far = depth -+ 0.1, :202-204); 2 = with_depth (the single
+ * candidate of a ray is z_map[y][x], :199-200; S must be 1). */
+int mvsnerf_raygen_train_fwd(const float* xs, const float* ys, int W_img, int H_img, int W_ref, int H_ref,
+                             const float* K_tgt, const float* c2w_tgt, const float* K_ref, const float* w2c_ref,
+                             const float* near_far_tgt, const float* near_far_ref, int pad, int lindisp,
+                             const float* t_rand, int64_t N, int S,
+                             const float* tgt_img, const float* depth_map, const float* z_map, int depth_mode,
+                             float* rays_pts, float* rays_dir, float* rays_ndc, float* z_vals, float* pix, float* colors, float* rays_depth,
+                             void* stream);
+
 /* Trilinear lookup of the channel-last volume: replaces F.grid_sample 5-D in
  * utils.py:357-383 (index_point_feature) and models.py:941-950 (RefVolume.forward).
  * vol[D][H][W][C] (C == 8); ndc[P][3] = (x->W, y->H, z->D) in [0,1]; zeros padding, align_corners=True.
@@ -242,6 +255,14 @@ int mvsnerf_color_sample_fwd(const float* imgs, int V, int H, int W,
                              const float* w2c, const float* K,
                              const float* pts, int64_t P, int with_mask,
                              float* out, int out_stride, void* stream);
+
+/* build_color_volume with per-view feature maps (utils.py:300-332, `img_feat is not None`; gen_pts_feats renderer.py:124-136 passes it
+ * through): per sample and view [r, g, b (border padding) | Cf channels of img_feat[v] (zeros padding, same normalised grid, the map's
+ * own Hf x Wf) | mask].  imgs [V][3][H][W], img_feat [V][Cf][Hf][Wf] (NCHW, the reference's layout); out rows of out_stride floats,
+ * view v at columns v*(3+Cf+mask). */
+int mvsnerf_color_feat_sample_fwd(const float* imgs, int V, int H, int W, const float* img_feat, int Cf, int Hf, int Wf,
+                                  const float* w2c, const float* K, const float* pts, int64_t P, int with_mask,
+                                  float* out, int out_stride, void* stream);
 
 /* View-direction feature: renderer.py:142-147 + gen_dir_feature renderer.py:111-122.
  * dirs_out[n] = (rays_dir[n]/|rays_dir[n]|) @ w2c_ref[:3,:3]^T ; w2c_ref may be NULL (no rotation);

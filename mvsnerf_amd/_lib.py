@@ -128,8 +128,10 @@ SIGNATURES = {
     "mvsnerf_gather_fwd": (_c_i, [_c_fp] + [_c_i] * 3 + [_c_fp] + [_c_i] * 3 + [_c_fp] * 4 + [_c_l, _c_i, _c_fp, _c_fp, _c_i, _c_fp, _c_fp]),
     "mvsnerf_abn_apply_add": (_c_i, [_c_fp] * 6 + [_c_l, _c_i, _c_fp, _c_fp]),
     "mvsnerf_raygen_fwd": (_c_i, [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i] + [_c_fp] * 6 + [_c_i, _c_i, _c_fp, _c_l, _c_i] + [_c_fp] * 6),
+    "mvsnerf_raygen_train_fwd": (_c_i, [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i] + [_c_fp] * 6 + [_c_i, _c_i, _c_fp, _c_l, _c_i] + [_c_fp] * 3 + [_c_i] + [_c_fp] * 8),
     "mvsnerf_volume_sample_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_l, _c_fp, _c_i, _c_fp]),
     "mvsnerf_color_sample_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_i, _c_fp]),
+    "mvsnerf_color_feat_sample_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_i, _c_fp]),
     "mvsnerf_dir_feature_fwd": (_c_i, [_c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp]),
     "mvsnerf_posenc_fwd": (_c_i, [_c_fp, _c_l, _c_i, _c_i, _c_fp, _c_fp]),
     "mvsnerf_mlp_packed_floats": (ctypes.c_size_t, [_c_i]),

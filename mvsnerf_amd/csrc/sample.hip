@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void volume_sample_c8_kernel(
     const float* __restrict__ vol, int D, int H, int W,
     const float* __restrict__ ndc, int64_t P, float* __restrict__ out, int out_stride)
 {
+#pragma clang fp contract(off)
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int q = (int)(tid & 3);
     const int xc = q >> 1, ch = (q & 1) * 4;
@@ -43,22 +44,21 @@ __global__ __launch_bounds__(256) void volume_sample_c8_kernel(
         const float cxf = fx + (float)xc;
         // NaN / huge coordinates: the float compares reject them before any int conversion is used
         const bool x_in = (cxf >= 0.0f) && (cxf <= (float)(W - 1));
-        acc[j] = f32x4{0, 0, 0, 0};
+        f32x4 vv[4];
+        float vw[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int zc = k >> 1, yc = k & 1;
             const float cyf = fy + (float)yc, czf = fz + (float)zc;
             const bool in = x_in && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
-            const float w = wx * (yc ? (iy - fy) : ((fy + 1.0f) - iy)) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
+            vw[k] = (wx * (yc ? (iy - fy) : ((fy + 1.0f) - iy))) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
             const float* src = in ? vol + vox_off8<SMALL>((int)czf, (int)cyf, (int)cxf, H, W) + ch : reinterpret_cast<const float*>(&g_zero_tap);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src);
-            acc[j] += v * w;
+            vv[k] = *reinterpret_cast<const f32x4*>(src);
         }
+        acc[j] = trilinear_fold_x0_lane(vv, vw);                                  // ATen's term order and roundings (sample_dev.h); valid in the x0 lanes
     }
 #pragma unroll
     for (int j = 0; j < SPQ; ++j) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[j][c] += quad_swap2(acc[j][c]);         // fold the two x corners
         if (p0 + j < P && xc == 0)                                                // lanes q=0,1 store channels 0-3 / 4-7
             *reinterpret_cast<f32x4*>(out + (p0 + j) * out_stride + ch) = acc[j];
     }
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void volume_sample_generic_kernel(
     const float* __restrict__ vol, int D, int H, int W, int C,
     const float* __restrict__ ndc, int64_t P, float* __restrict__ out, int out_stride)
 {
+#pragma clang fp contract(off)
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= P * C) return;
     const int64_t p = tid / C;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void volume_sample_generic_kernel(
     for (int k = 0; k < 8; ++k) {
         const int zc = k >> 2, yc = (k >> 1) & 1, xc = k & 1;
         const float cx = fx + xc, cy = fy + yc, cz = fz + zc;
-        const float w = (xc ? ix - fx : fx + 1.0f - ix) * (yc ? iy - fy : fy + 1.0f - iy) * (zc ? iz - fz : fz + 1.0f - iz);
+        const float w = ((xc ? ix - fx : fx + 1.0f - ix) * (yc ? iy - fy : fy + 1.0f - iy)) * (zc ? iz - fz : fz + 1.0f - iz);
         if (cx >= 0.0f && cx <= (float)(W - 1) && cy >= 0.0f && cy <= (float)(H - 1) && cz >= 0.0f && cz <= (float)(D - 1))
             acc += vol[((((int64_t)cz * H + (int)cy) * W + (int)cx)) * C + c] * w;
     }
@@ -150,6 +151,58 @@ extern "C" int mvsnerf_color_sample_fwd(const float* imgs, int V, int H, int W, 
     return MVSNERF_OK;
 }
 
+// build_color_volume(img_feat=...) (utils.py:300-332, the `img_feat is not None` branch): per view [r, g, b | Cf feature channels | mask].
+// Colours: border padding (utils.py:320); the per-view feature maps (their own resolution Hf x Wf) are read at the SAME normalised grid
+// with ZEROS padding (:322).  One thread per (sample, view); feat maps NCHW [V][Cf][Hf][Wf].  Off the hot path (training_step passes None).
+__global__ __launch_bounds__(256) void color_feat_sample_kernel(
+    const float* __restrict__ imgs, int V, int H, int W, const float* __restrict__ feats, int Cf, int Hf, int Wf,
+    const float* __restrict__ w2c, const float* __restrict__ Kmat,
+    const float* __restrict__ pts, int64_t P, int with_mask, float* __restrict__ out, int out_stride)
+{
+#pragma clang fp contract(off)
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= P * V) return;
+    const int64_t p = tid / V;
+    const int v = (int)(tid - p * V);
+    const ColorTap t = color_project(pts[p * 3 + 0], pts[p * 3 + 1], pts[p * 3 + 2], w2c + v * 16, Kmat + v * 9, W, H);
+    const int Cv = 3 + Cf + (with_mask ? 1 : 0);
+    float* o = out + p * out_stride + v * Cv;
+    const float* img = imgs + (int64_t)v * 3 * H * W;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* pl = img + (int64_t)c * H * W + (int64_t)t.y0 * W + t.x0;
+        o[c] = color_blend(t, pl[0], t.x1in ? pl[1] : 0.f, t.y1in ? pl[W] : 0.f, (t.x1in && t.y1in) ? pl[W + 1] : 0.f);
+    }
+    // zeros padding, align_corners=True, the feature map's own size (ATen grid_sampler_unnormalize + the nw,ne,sw,se fma chain)
+    const float ix = ((t.gx + 1.0f) / 2.0f) * (float)(Wf - 1), iy = ((t.gy + 1.0f) / 2.0f) * (float)(Hf - 1);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
+    const bool x0in = fx >= 0.f && fx <= (float)(Wf - 1), x1in = fx + 1.f >= 0.f && fx + 1.f <= (float)(Wf - 1);
+    const bool y0in = fy >= 0.f && fy <= (float)(Hf - 1), y1in = fy + 1.f >= 0.f && fy + 1.f <= (float)(Hf - 1);
+    const bool finite = (ix == ix) && (iy == iy) && fabsf(ix) < 1e9f && fabsf(iy) < 1e9f;
+    const int x0 = finite ? (int)fx : 0, y0 = finite ? (int)fy : 0;
+    const float* fb = feats + (int64_t)v * Cf * Hf * Wf;
+    for (int c = 0; c < Cf; ++c) {
+        const float* pl = fb + (int64_t)c * Hf * Wf;
+        const float nw = (finite && x0in && y0in) ? pl[(int64_t)y0 * Wf + x0] : 0.f, ne = (finite && x1in && y0in) ? pl[(int64_t)y0 * Wf + x0 + 1] : 0.f;
+        const float sw = (finite && x0in && y1in) ? pl[(int64_t)(y0 + 1) * Wf + x0] : 0.f, se = (finite && x1in && y1in) ? pl[(int64_t)(y0 + 1) * Wf + x0 + 1] : 0.f;
+        o[3 + c] = fmaf(se, wx1 * wy1, fmaf(sw, wx0 * wy1, fmaf(ne, wx1 * wy0, nw * (wx0 * wy0))));
+    }
+    if (with_mask) o[3 + Cf] = color_mask(t);
+}
+
+extern "C" int mvsnerf_color_feat_sample_fwd(const float* imgs, int V, int H, int W, const float* img_feat, int Cf, int Hf, int Wf,
+                                             const float* w2c, const float* K, const float* pts, int64_t P, int with_mask,
+                                             float* out, int out_stride, void* stream)
+{
+    if (!imgs || !img_feat || !w2c || !K || !pts || !out || V < 1 || H < 2 || W < 2 || Cf < 1 || Hf < 2 || Wf < 2 || P < 0) return MVSNERF_EINVAL;
+    if (out_stride < V * (3 + Cf + (with_mask ? 1 : 0))) return MVSNERF_EINVAL;
+    if (P == 0) return MVSNERF_OK;
+    color_feat_sample_kernel<<<mvs_cdiv(P * V, 256), 256, 0, (hipStream_t)stream>>>(imgs, V, H, W, img_feat, Cf, Hf, Wf, w2c, K, pts, P, with_mask, out, out_stride);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // dirs = normalise(rays_dir) @ R_ref^T     (renderer.py:142-147, 111-122)
 // ---------------------------------------------------------------------------------------------
@@ -190,6 +243,7 @@ struct GatherArgs {
 template <bool SMALL>
 __global__ __launch_bounds__(256) void gather_fused_kernel(GatherArgs a)
 {
+#pragma clang fp contract(off)
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int q = (int)(tid & 3);
     const int64_t p_raw = tid >> 2;
@@ -216,7 +270,7 @@ __global__ __launch_bounds__(256) void gather_fused_kernel(GatherArgs a)
         const int zc = k >> 1, yc = k & 1;
         const float cyf = fy + (float)yc, czf = fz + (float)zc;
         const bool in = x_in && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
-        vw[k] = wx * (yc ? (iy - fy) : ((fy + 1.0f) - iy)) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
+        vw[k] = (wx * (yc ? (iy - fy) : ((fy + 1.0f) - iy))) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
         const float* src = in ? a.vol + vox_off8<SMALL>((int)czf, (int)cyf, (int)cxf, H, W) + ch : reinterpret_cast<const float*>(&g_zero_tap);
         vv[k] = *reinterpret_cast<const f32x4*>(src);
     }
@@ -238,12 +292,8 @@ __global__ __launch_bounds__(256) void gather_fused_kernel(GatherArgs a)
         o[3] = color_mask(t);
         if (live) *reinterpret_cast<f32x4*>(frow + 8 + 4 * v) = o;
     }
-    // ---- fold the volume taps (same order as the stand-alone kernel: k = 0..3, then the x-corner shuffle)
-    f32x4 acc = {0, 0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc += vv[k] * vw[k];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] += quad_swap2(acc[c]);
+    // ---- fold the volume taps in ATen's term order and roundings (sample_dev.h: the sum is valid in the x0 lanes)
+    const f32x4 acc = trilinear_fold_x0_lane(vv, vw);
     if (live && xc == 0) *reinterpret_cast<f32x4*>(frow + ch) = acc;
     // ---- view-direction feature: lane 3 of quad number n < N handles ray n (no p / S: a 64-bit division costs every lane of
     // the wave dozens of instruction slots)
@@ -427,6 +477,12 @@ struct RayGenArgs {
     const float* t_rand;                    // [N][S] or null
     int64_t N; int S;
     float* rays_pts; float* rays_dir; float* rays_ndc; float* z_vals; float* pix;   // pix: [2][N] = (ys, xs), may be null
+    // build_rays' per-pixel extras (mvsnerf_raygen_train_fwd; all null / 0 for the plain entry)
+    const float* tgt_img;                   // [3][H_img][W_img] target view: colours gathered at the pixel ids (utils.py:190-192)
+    const float* depth_map;                 // [H_img][W_img] ground-truth depth of the target view or null (utils.py:194-196)
+    const float* z_map;                     // depth_mode 2: [H_img][W_img] map the single depth candidate is read from (utils.py:199-200)
+    int depth_mode;                         // 0: near/far of the view; 1: importanceSampling (depth -+ 0.1, :202-204); 2: with_depth (S == 1)
+    float* colors; float* rays_depth;       // [N][3], [N] (null without depth_map)
 };
 
 __device__ __forceinline__ float linspace01(int i, int steps)
@@ -446,7 +502,10 @@ __global__ __launch_bounds__(256) void raygen_kernel(RayGenArgs a)
     float x, y;
     if (a.xs) { x = a.xs[n]; y = a.ys[n]; }
     else { const int64_t p = a.first_pixel + n; y = (float)(p / a.W_img); x = (float)(p % a.W_img); }
-    const float near = a.nf_tgt[0], far = a.nf_tgt[1], near_ref = a.nf_ref[0], far_ref = a.nf_ref[1];
+    float near = a.nf_tgt[0], far = a.nf_tgt[1];
+    const float near_ref = a.nf_ref[0], far_ref = a.nf_ref[1];
+    const int64_t pix_off = (int64_t)y * a.W_img + (int64_t)x;            // pixel_coordinates.long() (:189): ids are non-negative integers
+    if (a.depth_mode == 1) { const float d = a.depth_map[pix_off]; near = d - 0.1f; far = d + 0.1f; }      // utils.py:203
     const float cxd = (x - a.Kt[2]) / a.Kt[0], cyd = (y - a.Kt[5]) / a.Kt[4];
     const float dx = fmaf(1.0f, a.c2w[2], fmaf(cyd, a.c2w[1], cxd * a.c2w[0]));
     const float dy = fmaf(1.0f, a.c2w[6], fmaf(cyd, a.c2w[5], cxd * a.c2w[4]));
@@ -455,8 +514,8 @@ __global__ __launch_bounds__(256) void raygen_kernel(RayGenArgs a)
         const float tv = linspace01(i, a.S);
         return a.lindisp ? 1.0f / (1.0f / near * (1.0f - tv) + 1.0f / far * tv) : near * (1.0f - tv) + far * tv;
     };
-    float z = zplain(s);
-    if (a.t_rand) {
+    float z = a.depth_mode == 2 ? a.z_map[pix_off] : zplain(s);           // :200: one candidate per ray, no stratification
+    if (a.t_rand && a.depth_mode != 2) {
         const float lo = s == 0 ? z : 0.5f * (z + zplain(s - 1));
         const float up = s == a.S - 1 ? z : 0.5f * (zplain(s + 1) + z);
         z = lo + (up - lo) * a.t_rand[t];
@@ -485,14 +544,54 @@ __global__ __launch_bounds__(256) void raygen_kernel(RayGenArgs a)
     if (s == 0) {
         a.rays_dir[n * 3 + 0] = dx; a.rays_dir[n * 3 + 1] = dy; a.rays_dir[n * 3 + 2] = dz;
         if (a.pix) { a.pix[n] = y; a.pix[a.N + n] = x; }
+        if (a.colors) {
+            const int64_t plane = (int64_t)a.H_img * a.W_img;
+            a.colors[n * 3 + 0] = a.tgt_img[pix_off]; a.colors[n * 3 + 1] = a.tgt_img[plane + pix_off]; a.colors[n * 3 + 2] = a.tgt_img[2 * plane + pix_off];
+        }
+        if (a.rays_depth) a.rays_depth[n] = a.depth_map[pix_off];
     }
 }
+
+static int raygen_launch(const float* xs, const float* ys, int64_t first_pixel, int W_img, int H_img, int W_ref, int H_ref,
+                         const float* K_tgt, const float* c2w_tgt, const float* K_ref, const float* w2c_ref,
+                         const float* near_far_tgt, const float* near_far_ref, int pad, int lindisp,
+                         const float* t_rand, int64_t N, int S,
+                         float* rays_pts, float* rays_dir, float* rays_ndc, float* z_vals, float* pix,
+                         const float* tgt_img, const float* depth_map, const float* z_map, int depth_mode, float* colors, float* rays_depth, void* stream);
 
 extern "C" int mvsnerf_raygen_fwd(const float* xs, const float* ys, int64_t first_pixel, int W_img, int H_img, int W_ref, int H_ref,
                                   const float* K_tgt, const float* c2w_tgt, const float* K_ref, const float* w2c_ref,
                                   const float* near_far_tgt, const float* near_far_ref, int pad, int lindisp,
                                   const float* t_rand, int64_t N, int S,
                                   float* rays_pts, float* rays_dir, float* rays_ndc, float* z_vals, float* pix, void* stream)
+{
+    return raygen_launch(xs, ys, first_pixel, W_img, H_img, W_ref, H_ref, K_tgt, c2w_tgt, K_ref, w2c_ref, near_far_tgt, near_far_ref, pad, lindisp,
+                         t_rand, N, S, rays_pts, rays_dir, rays_ndc, z_vals, pix, nullptr, nullptr, nullptr, 0, nullptr, nullptr, stream);
+}
+
+// build_rays of one training step in ONE launch (utils.py:148-241 downstream of the RNG draws): the plain ray generation plus the
+// per-pixel gathers (target colours :190-192, ground-truth depth :194-196) and the two per-pixel depth ranges
+// (depth_mode 1 = importanceSampling :202-204, 2 = with_depth :199-200 with S == 1).
+extern "C" int mvsnerf_raygen_train_fwd(const float* xs, const float* ys, int W_img, int H_img, int W_ref, int H_ref,
+                                        const float* K_tgt, const float* c2w_tgt, const float* K_ref, const float* w2c_ref,
+                                        const float* near_far_tgt, const float* near_far_ref, int pad, int lindisp,
+                                        const float* t_rand, int64_t N, int S,
+                                        const float* tgt_img, const float* depth_map, const float* z_map, int depth_mode,
+                                        float* rays_pts, float* rays_dir, float* rays_ndc, float* z_vals, float* pix, float* colors, float* rays_depth,
+                                        void* stream)
+{
+    if (!xs || !ys || !tgt_img || !colors || depth_mode < 0 || depth_mode > 2) return MVSNERF_EINVAL;
+    if ((depth_mode == 1 && !depth_map) || (depth_mode == 2 && (!z_map || S != 1)) || (rays_depth && !depth_map)) return MVSNERF_EINVAL;
+    return raygen_launch(xs, ys, 0, W_img, H_img, W_ref, H_ref, K_tgt, c2w_tgt, K_ref, w2c_ref, near_far_tgt, near_far_ref, pad, lindisp,
+                         t_rand, N, S, rays_pts, rays_dir, rays_ndc, z_vals, pix, tgt_img, depth_map, z_map, depth_mode, colors, rays_depth, stream);
+}
+
+static int raygen_launch(const float* xs, const float* ys, int64_t first_pixel, int W_img, int H_img, int W_ref, int H_ref,
+                         const float* K_tgt, const float* c2w_tgt, const float* K_ref, const float* w2c_ref,
+                         const float* near_far_tgt, const float* near_far_ref, int pad, int lindisp,
+                         const float* t_rand, int64_t N, int S,
+                         float* rays_pts, float* rays_dir, float* rays_ndc, float* z_vals, float* pix,
+                         const float* tgt_img, const float* depth_map, const float* z_map, int depth_mode, float* colors, float* rays_depth, void* stream)
 {
     if (!K_tgt || !c2w_tgt || !K_ref || !w2c_ref || !near_far_tgt || !near_far_ref || !rays_pts || !rays_dir || !rays_ndc || !z_vals || N < 0 || S < 1) return MVSNERF_EINVAL;
     if ((xs == nullptr) != (ys == nullptr) || W_img < 2 || H_img < 2) return MVSNERF_EINVAL;
@@ -505,6 +604,7 @@ extern "C" int mvsnerf_raygen_fwd(const float* xs, const float* ys, int64_t firs
     a.Kt = K_tgt; a.c2w = c2w_tgt; a.Kr = K_ref; a.w2c = w2c_ref; a.nf_tgt = near_far_tgt; a.nf_ref = near_far_ref;
     a.pad = pad; a.lindisp = lindisp; a.t_rand = t_rand; a.N = N; a.S = S;
     a.rays_pts = rays_pts; a.rays_dir = rays_dir; a.rays_ndc = rays_ndc; a.z_vals = z_vals; a.pix = pix;
+    a.tgt_img = tgt_img; a.depth_map = depth_map; a.z_map = z_map; a.depth_mode = depth_mode; a.colors = colors; a.rays_depth = rays_depth;
     raygen_kernel<<<mvs_cdiv(N * S, 256), 256, 0, (hipStream_t)stream>>>(a);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;

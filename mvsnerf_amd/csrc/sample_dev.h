@@ -89,37 +89,51 @@ __device__ __forceinline__ void dir_feature_of(const float* __restrict__ d3, con
 }
 
 
+// Fold of the eight trilinear terms in the arithmetic of ATen's 5-D grid_sample on the CPU (the reference path the oracle runs; pinned bit for
+// bit by scratch/r3/cpu_lookup_probe.py against the reference-generated fixtures): every term v * w is ROUNDED (no fma), w = (wx * wy) * wz,
+// and the terms are added one after the other in the order (z0,y0,x0), (z0,y0,x1), (z0,y1,x0), (z0,y1,x1), (z1,...) starting from 0.
+// Lane layout of the gather kernels: a lane holds the four (z, y) products of ONE x corner (k = 2 zc + yc), its partner two lanes further
+// in the quad holds the other corner's.  The x0 lane adds its own product, then the partner's (one DPP quad swap each); the x1 lane runs the
+// same instructions on swapped roles and its sum is discarded by the caller (it would be the x1-first order).
+__device__ __forceinline__ f32x4 trilinear_fold_x0_lane(const f32x4 (&v)[4], const float (&w)[4])
+{
+#pragma clang fp contract(off)
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f32x4 own = v[k] * w[k];
+        f32x4 other;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) other[c] = quad_swap2(own[c]);
+        acc = acc + own;
+        acc = acc + other;
+    }
+    return acc;
+}
+
 // The 8-channel trilinear lookup of ONE sample by ONE lane, in the arithmetic of volume_sample_c8_kernel / gather_fused_kernel (where
 // four lanes share a sample): per x corner and channel half, the four (z, y) taps are folded in the order k = 0..3, then the two x
 // corners are added (low corner + high corner).  out[0..3] = channels 0-3, out[4..7] = channels 4-7.
 template <bool SMALL>
 __device__ __forceinline__ void trilinear8_of(const float* __restrict__ vol, int D, int H, int W, float nx, float ny, float nz, f32x4 (&out)[2])
 {
+#pragma clang fp contract(off)
     const float gx = nx * 2.0f - 1.0f, gy = ny * 2.0f - 1.0f, gz = nz * 2.0f - 1.0f;
     const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
     const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
     const float iz = ((gz + 1.0f) / 2.0f) * (float)(D - 1);
     const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-    f32x4 acc[2][2];                                  // [x corner][channel half]
+    out[0] = f32x4{0, 0, 0, 0}; out[1] = f32x4{0, 0, 0, 0};
 #pragma unroll
-    for (int xc = 0; xc < 2; ++xc) {
-        const float wx = xc ? (ix - fx) : ((fx + 1.0f) - ix);
-        const float cxf = fx + (float)xc;
-        const bool x_in = (cxf >= 0.0f) && (cxf <= (float)(W - 1));
-        acc[xc][0] = f32x4{0, 0, 0, 0}; acc[xc][1] = f32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int zc = k >> 1, yc = k & 1;
-            const float cyf = fy + (float)yc, czf = fz + (float)zc;
-            const bool in = x_in && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
-            const float w = wx * (yc ? (iy - fy) : ((fy + 1.0f) - iy)) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
-            const float* src = in ? vol + vox_off8<SMALL>((int)czf, (int)cyf, (int)cxf, H, W) : reinterpret_cast<const float*>(&g_zero_tap);
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(in ? src + 4 : src);
-            acc[xc][0] += v0 * w;
-            acc[xc][1] += v1 * w;
-        }
+    for (int k = 0; k < 8; ++k) {                     // ATen's order: (z0,y0,x0), (z0,y0,x1), (z0,y1,x0), ... every term rounded, then added
+        const int zc = k >> 2, yc = (k >> 1) & 1, xc = k & 1;
+        const float cxf = fx + (float)xc, cyf = fy + (float)yc, czf = fz + (float)zc;
+        const bool in = (cxf >= 0.0f) && (cxf <= (float)(W - 1)) && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
+        const float w = ((xc ? (ix - fx) : ((fx + 1.0f) - ix)) * (yc ? (iy - fy) : ((fy + 1.0f) - iy))) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
+        const float* src = in ? vol + vox_off8<SMALL>((int)czf, (int)cyf, (int)cxf, H, W) : reinterpret_cast<const float*>(&g_zero_tap);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(in ? src + 4 : src);
+        out[0] = out[0] + v0 * w;
+        out[1] = out[1] + v1 * w;
     }
-    out[0] = acc[0][0] + acc[1][0];
-    out[1] = acc[0][1] + acc[1][1];
 }

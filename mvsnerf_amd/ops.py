@@ -138,6 +138,24 @@ def color_sample(imgs, w2cs, intrinsics, pts, with_mask=True, out=None, out_ptr=
     return out
 
 
+def color_feat_sample(imgs, img_feat, w2cs, intrinsics, pts, with_mask=True, out=None, out_ptr=None, out_stride=None):
+    """build_color_volume's img_feat branch: imgs (V,3,H,W), img_feat (V,Cf,Hf,Wf) -> (..., V*(3+Cf+mask))."""
+    _need_no_grad(imgs, img_feat, pts, op="color_feat_sample")
+    V, _, H, W = imgs.shape
+    if img_feat.dim() != 4 or img_feat.shape[0] != V:
+        raise RuntimeError(f"img_feat must be (V={V},Cf,Hf,Wf), got {tuple(img_feat.shape)}")
+    Cf, Hf, Wf = img_feat.shape[1:]
+    Cv = 3 + Cf + int(bool(with_mask))
+    P = pts.numel() // 3
+    if out is None:
+        out = torch.empty((*pts.shape[:-1], V * Cv), device=pts.device, dtype=torch.float32)
+        out_ptr, out_stride = out.data_ptr(), V * Cv
+    check(_lib.lib().mvsnerf_color_feat_sample_fwd(dev_f32(imgs, "imgs"), V, H, W, dev_f32(img_feat, "img_feat"), Cf, Hf, Wf,
+                                                   dev_f32(w2cs, "w2cs"), dev_f32(intrinsics, "intrinsics"), dev_f32(pts, "pts"), P,
+                                                   int(bool(with_mask)), out_ptr, out_stride, stream_ptr()), "color_feat_sample_fwd")
+    return out
+
+
 def dir_feature(rays_dir, w2c_ref=None, normalize=True):
     _need_no_grad(rays_dir, op="dir_feature")
     out = torch.empty_like(rays_dir)
@@ -176,6 +194,30 @@ def raygen(H, W, K_tgt, c2w_tgt, K_ref, w2c_ref, nf_tgt, nf_ref, N_samples, pad=
                                         0 if t_rand is None else c(t_rand, "t_rand"), N, N_samples,
                                         pts.data_ptr(), dirs.data_ptr(), ndc.data_ptr(), z.data_ptr(), pix.data_ptr(), stream_ptr()), "raygen_fwd")
     return pts, dirs, ndc, z, pix
+
+
+def raygen_train(H, W, K_tgt, c2w_tgt, K_ref, w2c_ref, nf_tgt, nf_ref, N_samples, xs, ys, t_rand, tgt_img, depth_map=None, z_map=None,
+                 depth_mode=0, pad=0, lindisp=False):
+    """build_rays of a training step in one launch (mvsnerf_raygen_train_fwd): ray generation + target-colour gather (+ ground-truth depth
+    gather, + the per-pixel depth ranges of importanceSampling (depth_mode 1) / with_depth (depth_mode 2, one candidate per ray)).
+    Returns rays_pts (N,S,3), rays_dir (N,3), rays_ndc (N,S,3), z_vals (N,S), pix (2,N), colors (N,3), rays_depth (N,) | None."""
+    dev = c2w_tgt.device
+    N = int(xs.shape[0])
+    S = 1 if depth_mode == 2 else int(N_samples)
+    f32 = dict(device=dev, dtype=torch.float32)
+    pts, ndc, dirs = torch.empty((N, S, 3), **f32), torch.empty((N, S, 3), **f32), torch.empty((N, 3), **f32)
+    z, pix, colors = torch.empty((N, S), **f32), torch.empty((2, N), **f32), torch.empty((N, 3), **f32)
+    rd = None if depth_map is None else torch.empty((N,), **f32)
+    c = _Keep()
+    if tuple(tgt_img.shape) != (3, H, W) or (depth_map is not None and tuple(depth_map.shape) != (H, W)) or (z_map is not None and tuple(z_map.shape) != (H, W)):
+        raise RuntimeError("raygen_train: tgt_img must be (3,H,W), depth_map / z_map (H,W)")
+    check(_lib.lib().mvsnerf_raygen_train_fwd(c(xs, "xs"), c(ys, "ys"), W, H, 0, 0, c(K_tgt, "K_tgt"), c(c2w_tgt, "c2w_tgt"), c(K_ref, "K_ref"),
+                                              c(w2c_ref, "w2c_ref"), c(nf_tgt, "near_far_tgt"), c(nf_ref, "near_far_ref"), int(pad), int(bool(lindisp)),
+                                              0 if t_rand is None else c(t_rand, "t_rand"), N, S, c(tgt_img, "tgt_img"),
+                                              0 if depth_map is None else c(depth_map, "depth_map"), 0 if z_map is None else c(z_map, "z_map"),
+                                              int(depth_mode), pts.data_ptr(), dirs.data_ptr(), ndc.data_ptr(), z.data_ptr(), pix.data_ptr(),
+                                              colors.data_ptr(), 0 if rd is None else rd.data_ptr(), stream_ptr()), "raygen_train_fwd")
+    return pts, dirs, ndc, z, pix, colors, rd
 
 
 def ray_points(rays_o, rays_d, z_vals, w2c_ref=None, K_ref=None, near_far_ref=None, ref_hw=None, pad=0, lindisp=False):

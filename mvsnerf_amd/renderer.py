@@ -69,8 +69,6 @@ def gen_dir_feature(w2c_ref, rays_dir):
 def gen_pts_feats(imgs, volume_feature, rays_pts, pose_ref, rays_ndc, feat_dim, img_feat=None, img_downscale=1.0,
                   use_color_volume=False, net_type="v0"):
     """renderer.py:124-136: [8 volume channels | V x (r,g,b,mask)] written in place into one (N,S,feat_dim) tensor."""
-    if img_feat is not None:
-        raise NotImplementedError("gen_pts_feats: img_feat is outside the shipped hot path (training_step passes None)")
     from .models import RefVolume
     vol = volume_feature.feat_volume if isinstance(volume_feature, RefVolume) else volume_feature
     vol_cl = ops.channels_last_volume(vol)
@@ -84,6 +82,14 @@ def gen_pts_feats(imgs, volume_feature, rays_pts, pose_ref, rays_ndc, feat_dim, 
     V = imgs.shape[1]
     if feat_dim != 8 + 4 * V:
         raise RuntimeError(f"feat_dim {feat_dim} != 8 + 4*V ({V} views)")
+    if img_feat is not None:          # renderer.py:126-127,133: feat_dim grows by V*Cf; columns [8 | V x (rgb, Cf feature channels, mask)]
+        feat_dim += img_feat.shape[1] * img_feat.shape[2]
+        out = torch.empty((N, S, feat_dim), device=rays_pts.device, dtype=torch.float32)
+        ops.volume_sample(vol_cl, rays_ndc.contiguous(), out=out, out_stride=feat_dim)
+        ops.color_feat_sample(imgs[0].contiguous(), img_feat[0, :V].contiguous(), pose_ref["w2cs"][:V].contiguous(),
+                              pose_ref["intrinsics"][:V].contiguous(), rays_pts.contiguous(), with_mask=True, out=out,
+                              out_ptr=out.data_ptr() + 8 * 4, out_stride=feat_dim)
+        return out
     out = torch.empty((N, S, feat_dim), device=rays_pts.device, dtype=torch.float32)
     ops.volume_sample(vol_cl, rays_ndc.contiguous(), out=out, out_stride=feat_dim)
     ops.color_sample(imgs[0].contiguous(), pose_ref["w2cs"][:V].contiguous(), pose_ref["intrinsics"][:V].contiguous(),

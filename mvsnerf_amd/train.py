@@ -160,13 +160,21 @@ class MVSSystem(_ModuleShim):
             mask = rays_depth > 0
             if getattr(args, "with_depth_loss", False):
                 loss = loss + self.loss(depth_pred, rays_depth, mask)
-            self.log("train/abs_err", (depth_pred - rays_depth)[mask].abs().mean(), prog_bar=True)
+            with torch.no_grad():                                        # :130-138
+                err = (depth_pred - rays_depth)[mask].abs()
+                for t in self.eval_metric:
+                    self.log(f"train/acc_l_{t}mm", (err < t).float().mean(), prog_bar=False)
+                self.log("train/abs_err", err.mean(), prog_bar=True)
         img_loss = img2mse(rgb, target_s)                                # :143
         loss = loss + img_loss
         with torch.no_grad():
             self.log("train/loss", loss, prog_bar=True)
             self.log("train/img_mse_loss", img_loss)
-            self.log("train/PSNR", mse2psnr2(img_loss), prog_bar=True)
+            if getattr(args, "with_depth", False):                       # :152-155: PSNR over the masked rays, PSNR_out over the rest
+                self.log("train/PSNR", mse2psnr2(img2mse(rgb[mask], target_s[mask])), prog_bar=True)
+                self.log("train/PSNR_out", mse2psnr2(img2mse(rgb[~mask], target_s[~mask])), prog_bar=True)
+            else:
+                self.log("train/PSNR", mse2psnr2(img_loss), prog_bar=True)
         if self.global_step % 20000 == 19999 and D.world_rank()[1] == 0:  # one writer (ranks hold identical weights after the all-reduce)
             self.save_ckpt(f"{self.global_step}")
         # ray mode with N_rays % world != 0: weight the local mean so that the rank-averaged gradient is that of the global mean
@@ -233,6 +241,52 @@ class MVSSystem(_ModuleShim):
             return rgb, depth_pred
         rgb, depth = D.render_frame(render_chunk, H, W, chunk)
         return rgb.reshape(H, W, 3), depth.reshape(H, W)
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_nb):
+        """:172-254.  Renders the batch's last view from the first three (render_view: encode + the chunk loop, tile-parallel over the
+        ranks) and returns the reference's per-sample log dict: 'val_psnr', 'val_depth_loss_r', 'val_abs_err', 'mask_sum',
+        'val_acc_{t}mm' for t in eval_metric (sums over the mask, as the reference - validation_epoch_end divides by mask_sum).
+        Left out: the TensorBoard image grids (`self.logger.experiment.add_images`) and the PNG dump (cv2 colour maps / imageio are
+        not in this image); `args.img_downscale = rand*0.75+0.25` (:187) is drawn like the reference but, like there, consumed by
+        nothing on the img_feat=None path."""
+        args = self.args
+        batch = dict(batch)
+        batch.pop("scan", None)
+        from .evaluate import abs_error, acc_threshold
+        from .utils import mse2psnr
+        log = {k: torch.tensor([0.0], dtype=torch.float64) for k in
+               ["val_psnr", "val_depth_loss_r", "val_abs_err", "mask_sum"] + [f"val_acc_{i}mm" for i in self.eval_metric]}      # init_log, utils.py:23-26
+        args.img_downscale = float(torch.rand((1,)) * 0.75 + 0.25)                                       # :187
+        rgb, depth_r = self.render_view(batch)                                                          # (H,W,3), (H,W)
+        rgb = torch.clamp(rgb.permute(2, 0, 1), 0, 1).cpu()                                             # :207
+        depth_r = depth_r.cpu()
+        tgt = self.unpreprocess(batch["images"].to(torch.float32).cpu())[0, -1]                            # :193 + :208
+        img_err_abs = (rgb - tgt).abs()
+        if getattr(args, "with_depth", False):
+            depth_gt = batch["depths_h"][0, -1].to(torch.float32).cpu()
+            mask = depth_gt > 0
+            log["val_psnr"] = mse2psnr(torch.mean(img_err_abs[:, mask] ** 2))                             # :213
+            log["val_depth_loss_r"] = self.loss(depth_r, depth_gt, mask)                                # :220
+            log["val_abs_err"] = abs_error(depth_r, depth_gt, mask).sum()                               # :229
+            for t in self.eval_metric:
+                log[f"val_acc_{t}mm"] = acc_threshold(depth_r, depth_gt, mask, t).sum()                 # :230-232
+            log["mask_sum"] = mask.float().sum()
+        else:
+            log["val_psnr"] = mse2psnr(torch.mean(img_err_abs ** 2))                                      # :215
+        self.idx += 1
+        self.last_val_images = {"rgb": rgb, "depth": depth_r, "err": img_err_abs}                       # what the reference's image grids show
+        return log
+
+    def validation_epoch_end(self, outputs):
+        """:256-275: the 'val/*' keys."""
+        st = lambda k: torch.stack([torch.as_tensor(x[k], dtype=torch.float64).reshape(()) for x in outputs])
+        mask_sum = st("mask_sum").sum()
+        self.log("val/d_loss_r", st("val_depth_loss_r").mean(), prog_bar=False)
+        self.log("val/PSNR", st("val_psnr").mean(), prog_bar=False)
+        self.log("val/abs_err", st("val_abs_err").sum() / mask_sum, prog_bar=False)
+        for t in self.eval_metric:
+            self.log(f"val/acc_{t}mm", st(f"val_acc_{t}mm").sum() / mask_sum, prog_bar=False)
 
     def save_ckpt(self, name="latest"):
         """:277-288 - same dict keys as the reference's .tar checkpoints."""

@@ -103,7 +103,7 @@ def build_rays(imgs, depths, pose_ref, w2cs, c2ws, intrinsics, near_fars, N_rays
     inv_scale = _inv_scale(W, H, dev)
     near_ref, far_ref = pose_ref["near_fars"][ref_idx, 0], pose_ref["near_fars"][ref_idx, 1]
     i = V - 1
-    if with_depth or importanceSampling or not imgs.is_cuda:
+    if not imgs.is_cuda:
         return _build_rays_torch(imgs, depths, pose_ref, w2cs, c2ws, intrinsics, near_fars, N_rays, N_samples, pad,
                                  is_precrop_iters, ref_idx, importanceSampling, with_depth)
     if is_precrop_iters and torch.rand((1,)) > 0.3:                                  # utils.py:90-93
@@ -115,12 +115,20 @@ def build_rays(imgs, depths, pose_ref, w2cs, c2ws, intrinsics, near_fars, N_rays
     # one asynchronous copy from pinned memory (a pageable .to(dev) makes the host wait for everything already enqueued)
     xy = torch.stack((xs, ys)).float().pin_memory().to(dev, non_blocking=True)
     xs, ys = xy[0], xy[1]
-    t_rand = torch.rand((N_rays, N_samples), device=dev)                             # utils.py:220
-    pts, rays_d, ndc, z, pix = ops.raygen(H, W, intrinsics[i], c2ws[i], k_ref, w2c_ref, _nf_pair(near_fars[0, i]),
-                                          _nf_pair(pose_ref["near_fars"][ref_idx]), N_samples, pad=pad, xs=xs, ys=ys, t_rand=t_rand)
-    pix_i = pix.long()
-    colors = imgs[0, i, :, pix_i[0], pix_i[1]].permute(1, 0)
-    rays_depth = depths[0, i, pix_i[0], pix_i[1]] if depths.shape[2] != 1 else None
+    has_depth = depths.shape[2] != 1                                                  # utils.py:194
+    if importanceSampling and not has_depth:
+        raise RuntimeError("build_rays(importanceSampling=True) needs the ground-truth depth maps (utils.py:203 reads rays_depth)")
+    # with_depth (:199-200): the reference indexes `near_fars` itself with the pixel ids, i.e. expects an (H,W) depth map there
+    z_map = near_fars.to(torch.float32) if with_depth else None
+    if with_depth and tuple(z_map.shape) != (H, W):
+        raise RuntimeError(f"build_rays(with_depth=True): near_fars must be the (H,W) = ({H},{W}) depth map (utils.py:200), got {tuple(near_fars.shape)}")
+    # utils.py:220: the jitter is drawn only on the stratified branches (not for with_depth)
+    t_rand = None if with_depth else torch.rand((N_rays, N_samples), device=dev)
+    nf_tgt = _nf_pair(pose_ref["near_fars"][ref_idx]) if with_depth else _nf_pair(near_fars[0, i])   # unused by depth modes 1 / 2
+    pts, rays_d, ndc, z, pix, colors, rays_depth = ops.raygen_train(
+        H, W, intrinsics[i], c2ws[i], k_ref, w2c_ref, nf_tgt, _nf_pair(pose_ref["near_fars"][ref_idx]), N_samples, xs, ys, t_rand,
+        imgs[0, i], depth_map=depths[0, i].to(torch.float32) if has_depth else None, z_map=z_map,
+        depth_mode=2 if with_depth else (1 if importanceSampling else 0), pad=pad)
     rays_o = c2ws[i][:3, -1].reshape(3, 1).expand(3, N_rays)
     ndc_parameters = {"w2c_ref": w2c_ref, "intrinsic_ref": k_ref, "inv_scale": inv_scale, "near": near_ref, "far": far_ref}
     return pts, rays_d, colors, ndc, z, rays_o, rays_depth, ndc_parameters
@@ -203,10 +211,12 @@ def index_point_feature(volume_feature, ray_coordinate_ref, chunk=-1):
 
 
 def build_color_volume(point_samples, pose_ref, imgs, img_feat=None, downscale=1.0, with_mask=False):
-    """utils.py:300-332: per-view projected colours (+ strict in-frustum mask) -> (N_rays,N_samples,V*C)."""
-    if img_feat is not None:
-        raise NotImplementedError("build_color_volume(img_feat=...) is outside the hot path (training_step passes None)")
+    """utils.py:300-332: per-view projected colours [+ img_feat channels] (+ strict in-frustum mask) -> (N_rays,N_samples,V*C).
+    `downscale` is accepted and unused, as in the reference (its interpolate line is commented out, utils.py:319)."""
     V = imgs.shape[1]
+    if img_feat is not None:          # (1,V,Cf,Hf,Wf): sampled at the same grid with zeros padding (:322)
+        return ops.color_feat_sample(imgs[0].contiguous(), img_feat[0, :V].contiguous(), pose_ref["w2cs"][:V].contiguous(),
+                                     pose_ref["intrinsics"][:V].contiguous(), point_samples.contiguous(), with_mask=with_mask)
     return ops.color_sample(imgs[0].contiguous(), pose_ref["w2cs"][:V].contiguous(), pose_ref["intrinsics"][:V].contiguous(),
                             point_samples.contiguous(), with_mask=with_mask)
 

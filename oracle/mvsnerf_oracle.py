@@ -98,6 +98,40 @@ def feature_net(x, sd, prefix="feature."):
     return F.conv2d(x, sd[prefix + "toplayer.weight"], sd[prefix + "toplayer.bias"])
 
 
+def _fma32(a, b, c):
+    """fl32(a*b + c) with ONE rounding: the product of two fp32 numbers is exact in float64."""
+    return (a.double() * b.double() + c.double()).to(torch.float32)
+
+
+def _sgemm_k3(R, X):
+    """R (B,3,3) @ X (B,3,N) in the arithmetic the reference's bmm (utils.py:612) has on the authoring host, the one the golden fixtures
+    pin: per output element the k-ordered chain  r0*x0 -> fma(r1, x1, .) -> fma(r2, x2, .)  (Intel MKL sgemm on the Xeon that ran
+    oracle/gen_golden.py; tests/test_oracle_golden.py compares the resulting sampling grid with the reference-generated one BIT FOR BIT).
+    The bits of `R @ X` itself depend on the host's BLAS code path - on the GPU box's AMD EPYC the same MKL rounds the two products and
+    the sums separately, 8 % of the grid values of a rotated view then differ in the last bit (scratch/r3/grid_bits_gpu.py,
+    gpurun_out/r3_grid_bits.txt) - so the oracle spells the pinned arithmetic out instead of inheriting whatever the host it runs on does.
+    float64 mode (`precision`): a plain matmul."""
+    if R.dtype != torch.float32:
+        return R @ X
+    acc = R[:, :, 0:1] * X[:, 0:1]
+    acc = _fma32(R[:, :, 1:2], X[:, 1:2], acc)
+    return _fma32(R[:, :, 2:3], X[:, 2:3], acc)
+
+
+def _rows_times_mat3_t(p, M):
+    """p (n,3) @ M(3,3).t() in the pinned arithmetic of the authoring host's sgemm (see _sgemm_k3): out[:, j] =
+    fma(p2, M[j,2], fma(p1, M[j,1], p0 * M[j,0])).  tests/test_oracle_golden.py: the reference-generated NDC coordinates
+    (utils.py:124,128 inside build_rays) are reproduced bit for bit; scratch/r3/cpu_lookup_probe.py lists the alternatives that are not."""
+    if p.dtype != torch.float32 or M.dtype != torch.float32:
+        return p @ M.t()
+    cols = []
+    for j in range(3):
+        acc = p[:, 0] * M[j, 0]
+        acc = _fma32(p[:, 1], M[j, 1], acc)
+        cols.append(_fma32(p[:, 2], M[j, 2], acc))
+    return torch.stack(cols, -1)
+
+
 def homo_warp(src_feat, proj_mat, depth_values, src_grid=None, pad=0):
     """utils.py:580-630.  src_feat (B,C,H,W); proj_mat (B,3,4); depth_values (B,D).
     Returns warped (B,C,D,H+2p,W+2p) and the sampling grid (B,D,(W+2p),(H+2p),2) [x,y in -1..1]
@@ -112,7 +146,7 @@ def homo_warp(src_feat, proj_mat, depth_values, src_grid=None, pad=0):
         uv1 = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(Hp * Wp)], 0)[None].expand(B, -1, -1)
         uv1 = uv1.repeat(1, 1, D)                                            # :611  (B,3,D*Hp*Wp) order d,y,x
         dv = depth_values[:, :, None].expand(B, D, Hp * Wp).reshape(B, 1, -1)
-        p = R @ uv1 + T / dv                                                 # :612
+        p = _sgemm_k3(R, uv1) + T / dv                                       # :612
         g = p[:, :2] / p[:, 2:]                                              # :617
         gx = g[:, 0] / ((W - 1) / 2) - 1                                     # :619 un-padded W
         gy = g[:, 1] / ((H - 1) / 2) - 1                                     # :620
@@ -235,8 +269,8 @@ def get_ndc_coordinate(w2c_ref, intrinsic_ref, pts, inv_scale, near=2, far=6, pa
     N, S = pts.shape[:2]
     p = pts.reshape(-1, 3)
     if w2c_ref is not None:
-        p = p @ w2c_ref[:3, :3].t() + w2c_ref[:3, 3].reshape(1, 3)          # :124
-    q = p @ intrinsic_ref.t()                                                # :128
+        p = _rows_times_mat3_t(p, w2c_ref[:3, :3]) + w2c_ref[:3, 3].reshape(1, 3)   # :124
+    q = _rows_times_mat3_t(p, intrinsic_ref)                                 # :128
     xy = q[:, :2] / q[:, 2:] / inv_scale.reshape(1, 2)                       # :129
     if lindisp:
         z = (1.0 / q[:, 2] - 1.0 / near) / (1.0 / far - 1.0 / near)
@@ -263,22 +297,33 @@ def stratified_depths(near, far, N_rays, N_samples, t_rand=None):
     return lower + (upper - lower) * t_rand
 
 
-def build_rays(imgs, pose_ref, near_fars, N_rays, N_samples, pad=0, t_rand=None, generator=None, tgt=-1):
-    """utils.py:148-241 restricted to the path training_step uses (with_depth=False, importanceSampling=False).
-    imgs (1,V,3,H,W) un-normalised; pose_ref dict of w2cs/c2ws/intrinsics (V,..), near_fars (1,V,2).
-    Returns rays_pts, rays_dir, target_rgb, rays_ndc, depth_candidates, rays_o (3,N) , pixel ids (2,N) long."""
+def build_rays(imgs, pose_ref, near_fars, N_rays, N_samples, pad=0, t_rand=None, generator=None, tgt=-1,
+               depths=None, importanceSampling=False, with_depth=False):
+    """utils.py:148-241.  imgs (1,V,3,H,W) un-normalised; pose_ref dict of w2cs/c2ws/intrinsics (V,..), near_fars (1,V,2)
+    (with_depth=True: the (H,W) map the reference indexes with the pixel ids, :200); depths None or (1,V,H,W).
+    Returns rays_pts, rays_dir, target_rgb, rays_ndc, depth_candidates, rays_o (3,N) , pixel ids (2,N) long
+    [, rays_depth (N,) when depths is given]."""
     _, V, _, H, W = imgs.shape
     tgt = tgt % V
     inv_scale = torch.tensor([W - 1, H - 1], dtype=_dt())
     rays_o, rays_d, pix = get_rays_mvs(H, W, pose_ref["intrinsics"][tgt], pose_ref["c2ws"][tgt], N_rays, generator=generator)
     pix_i = pix.long()
     target = imgs[0, tgt][:, pix_i[0], pix_i[1]].permute(1, 0)              # :194,233
-    near, far = near_fars[0, tgt, 0], near_fars[0, tgt, 1]                  # :209
-    z = stratified_depths(near, far, N_rays, N_samples, t_rand)
+    rays_depth = None if depths is None else depths[0, tgt, pix_i[0], pix_i[1]]        # :194-196
+    if with_depth:
+        z = near_fars[pix_i[0], pix_i[1]].reshape(-1, 1)                   # :199-200
+    else:
+        if importanceSampling:
+            near, far = (rays_depth - 0.1).view(N_rays, 1), (rays_depth + 0.1).view(N_rays, 1)   # :202-204
+        else:
+            near, far = near_fars[0, tgt, 0], near_fars[0, tgt, 1]          # :206
+        z = stratified_depths(near, far, N_rays, N_samples, t_rand)
     ro = rays_o.reshape(1, 3).expand(N_rays, -1)
     pts = ro.unsqueeze(1) + z.unsqueeze(-1) * rays_d.unsqueeze(1)           # :223
     nr, fr = pose_ref["near_fars"][0, 0], pose_ref["near_fars"][0, 1]       # :173 ref view 0
     ndc = get_ndc_coordinate(pose_ref["w2cs"][0], pose_ref["intrinsics"][0], pts, inv_scale, near=nr, far=fr, pad=pad)
+    if depths is not None:
+        return pts, rays_d, target, ndc, z, ro.permute(1, 0), pix_i, rays_depth
     return pts, rays_d, target, ndc, z, ro.permute(1, 0), pix_i
 
 
@@ -316,18 +361,20 @@ def index_point_feature(volume, ndc):
     return f[:, :, 0].permute(2, 3, 0, 1).reshape(N, S, -1)
 
 
-def build_color_volume(pts, pose_ref, imgs, with_mask=True):
-    """utils.py:300-332 (img_feat=None).  pts (N,S,3) world; imgs (1,V,3,H,W) un-normalised.
-    Per view: project (:316), bilinear with *border* padding (:320), strict in-bounds mask (:325-326).
-    -> (N,S,V*(3+mask))."""
+def build_color_volume(pts, pose_ref, imgs, with_mask=True, img_feat=None):
+    """utils.py:300-332.  pts (N,S,3) world; imgs (1,V,3,H,W) un-normalised; img_feat None or (1,V,Cf,Hf,Wf).
+    Per view: project (:316), bilinear with *border* padding (:320), [img_feat at the same grid with *zeros* padding (:322),]
+    strict in-bounds mask (:325-326).  -> (N,S,V*(3+Cf+mask))."""
     _, V, C, H, W = imgs.shape
     inv_scale = torch.tensor([W - 1, H - 1], dtype=_dt())
-    Cv = C + int(with_mask)
+    Cv = C + int(with_mask) + (0 if img_feat is None else img_feat.shape[2])
     out = torch.empty(*pts.shape[:2], V * Cv)
     for v in range(V):
         ndc = get_ndc_coordinate(pose_ref["w2cs"][v], pose_ref["intrinsics"][v], pts, inv_scale)[None]
         grid = ndc[..., :2] * 2.0 - 1.0                                      # :317
         data = F.grid_sample(imgs[:, v], grid, align_corners=True, mode="bilinear", padding_mode="border")
+        if img_feat is not None:
+            data = torch.cat((data, F.grid_sample(img_feat[:, v], grid, align_corners=True, mode="bilinear", padding_mode="zeros")), 1)
         if with_mask:
             m = ((grid > -1.0) & (grid < 1.0)).all(-1).to(_dt())
             data = torch.cat((data, m.unsqueeze(1)), 1)

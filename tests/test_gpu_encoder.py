@@ -12,6 +12,8 @@ DEV = "cuda"
 def close(a, b, atol, rtol=1e-4):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     err = (a - b).abs()
+    from tests.util import record_err, caller_tag
+    record_err(caller_tag(), float(err.max()), float(b.abs().max()), [atol, rtol])
     return bool((err <= atol + rtol * b.abs()).all()), float(err.max())
 
 

@@ -79,8 +79,10 @@ def test_training_step_matches_oracle_autograd():
     assert len(errs) == 22 + 30 + 26, len(errs)
     worst = max(errs, key=errs.get)
     print("training step: %d gradient tensors, worst relative error %.2e (%s)" % (len(errs), errs[worst], worst))
-    bad = {k: v for k, v in errs.items() if not v < 1e-3}              # measured: worst 1.3e-5
-    assert not bad, f"end-to-end gradient mismatches (rel. to max |ref|, bound 1e-3): {bad}"
+    from tests.util import record_err
+    record_err("test_gpu_train:training_step_gradients_worst_rel", errs[worst], None, 6.5e-5)
+    bad = {k: v for k, v in errs.items() if not v < 6.5e-5}            # measured: worst 1.3e-5 (bound = 5x)
+    assert not bad, f"end-to-end gradient mismatches (rel. to max |ref|, bound 6.5e-5): {bad}"
 
 
 def test_fit_steps_reduces_loss_and_checkpoint_roundtrip(tmp_path):

@@ -25,7 +25,7 @@ def test_encoder_pieces(name, weights):
     feats = c["ref_feats"]
     warped, grid = O.homo_warp(feats[:, 1], c["proj_mats"][:, 1], c["depth_values"], pad=pad)
     assert grid.shape == c["ref_grid_v1"].shape
-    assert maxabs(grid, c["ref_grid_v1"]) < 1e-5
+    assert torch.equal(grid, c["ref_grid_v1"])                  # the sampling grid of the reference, bit for bit (oracle._sgemm_k3)
     assert maxabs(warped, c["ref_warped_v1"]) < 1e-5
     cost, masks = O.build_volume_costvar_img(c["images"][:, :3], feats, c["proj_mats"][:, :3], c["depth_values"], pad)
     assert torch.equal(masks, c["ref_in_masks"])
@@ -64,7 +64,13 @@ def test_rays_bit_exact(name):
     pts, dirs, target, ndc, z, ro, pix = O.build_rays(c["images_raw"], pose, c["near_fars"], c["N_rays"], c["N_samples"],
                                                      pad=c["pad"], t_rand=c["t_rand"], generator=g)
     assert torch.equal(pix[1], c["pix_xs"])
-    assert maxabs(pts, c["ref_rays_pts"]) < TOL and maxabs(ndc, c["ref_rays_ndc"]) < TOL
+    assert maxabs(pts, c["ref_rays_pts"]) < TOL
+    assert torch.equal(ndc, c["ref_rays_ndc"]) if maxabs(pts, c["ref_rays_pts"]) == 0 else maxabs(ndc, c["ref_rays_ndc"]) < TOL
+    # the NDC coordinates of the REFERENCE's own points, bit for bit (oracle._rows_times_mat3_t pins the authoring host's sgemm arithmetic)
+    inv = torch.tensor([c["W"] - 1, c["H"] - 1], dtype=torch.float32)
+    ndc2 = O.get_ndc_coordinate(pose["w2cs"][0], pose["intrinsics"][0], c["ref_rays_pts"], inv, near=pose["near_fars"][0, 0],
+                                far=pose["near_fars"][0, 1], pad=c["pad"])
+    assert torch.equal(ndc2, c["ref_rays_ndc"])
     assert maxabs(ro, c["ref_rays_o"]) == 0
     t = O.build_rays_test(c["H"], c["W"], pose["c2ws"][-1], pose["w2cs"][0], pose["intrinsics"][-1], pose["near_fars"],
                           pose["near_fars"][-1], c["N_samples"], pad=c["pad"], chunk=c["N_rays"], idx=1)
@@ -78,8 +84,8 @@ def test_raymarch_pieces(name, weights):
     mlp, _ = weights
     pose = pose_of(c)
     vol, ndc, pts = c["ref_vol_small"], c["ref_rays_ndc"], c["ref_rays_pts"]
-    assert maxabs(O.index_point_feature(vol, ndc), c["ref_vfeat"]) < TOL
-    assert maxabs(O.build_color_volume(pts, pose, c["images_raw"][:, :3]), c["ref_colors"]) < TOL
+    assert torch.equal(O.index_point_feature(vol, ndc), c["ref_vfeat"])                       # same ATen kernel underneath: bit-identical
+    assert torch.equal(O.build_color_volume(pts, pose, c["images_raw"][:, :3]), c["ref_colors"])   # incl. the pinned projection arithmetic
     d = c["ref_rays_dir"]
     assert maxabs(O.gen_dir_feature(pose["w2cs"][0], d / d.norm(dim=-1, keepdim=True)), c["ref_dirs"]) < TOL
     assert maxabs(O.embed(ndc), c["ref_embed"]) < TOL

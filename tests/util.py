@@ -26,3 +26,23 @@ def pose_of(c):
 
 def maxabs(a, b):
     return float((a.double() - b.double()).abs().max())
+
+
+def record_err(tag, err, scale=None, tol=None):
+    """Append a measured error to gpurun_out/measured_errs.jsonl (the asserts' bounds are kept within 5x of these)."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "measured_errs.jsonl")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(json.dumps({"tag": tag, "err": err, "scale": scale, "tol": tol}) + "\n")
+    except OSError:
+        pass
+
+
+def caller_tag(depth=2):
+    import inspect
+    st = inspect.stack()
+    fr = st[depth]
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0].split("::")[-1]
+    return f"{test}:{fr.lineno}"
