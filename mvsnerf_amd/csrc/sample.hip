@@ -96,9 +96,8 @@ extern "C" int mvsnerf_volume_sample_fwd(const float* vol, int D, int H, int W, 
     if (!vol || !ndc || !out || D < 1 || H < 1 || W < 1 || C < 1 || P < 0 || out_stride < C) return MVSNERF_EINVAL;
     if (P == 0) return MVSNERF_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (C == 8) {
-        if (!mvs_aligned16(vol)) return MVSNERF_EALIGN;
-        if ((out_stride & 3) || !mvs_aligned16(out)) return MVSNERF_EALIGN;
+    if (C == 8 && !mvs_aligned16(vol)) return MVSNERF_EALIGN;
+    if (C == 8 && !(out_stride & 3) && mvs_aligned16(out)) {      // 16-byte row stores; rows of another stride take the per-channel kernel (same bits)
         const bool small = (int64_t)D * H < (1 << 24) && W < (1 << 24) && (int64_t)D * H * W * 8 < ((int64_t)1 << 31);
         if (small) volume_sample_c8_kernel<1, true><<<mvs_cdiv(P * 4, 256), 256, 0, st>>>(vol, D, H, W, ndc, P, out, out_stride);
         else volume_sample_c8_kernel<1, false><<<mvs_cdiv(P * 4, 256), 256, 0, st>>>(vol, D, H, W, ndc, P, out, out_stride);

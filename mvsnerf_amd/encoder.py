@@ -38,7 +38,12 @@ class InPlaceABN(nn.Module):
     def forward(self, x):
         """(N,C,H,W) or (1,C,D,H,W) -> same logical shape (channel-last memory).  No autograd (inside the networks the backward
         goes through _abn_bwd); C must be a multiple of 4 (all the reference uses: 8, 16, 32, 64)."""
-        ops._need_no_grad(x, self.weight, self.bias, op="InPlaceABN")
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad or self.bias.requires_grad):
+            # stand-alone differentiable use (outside FeatureNet / CostRegNet, whose backward runs on _abn_bwd): the same function through
+            # autograd-capable torch ops - plumbing for callers that build their own networks from this layer, not a hot-path route
+            import torch.nn.functional as F
+            y = F.batch_norm(x, self.running_mean, self.running_var, self.weight.abs() + self.eps, self.bias, self.training, self.momentum, self.eps)
+            return F.leaky_relu(y, self.activation_param)
         C = self.num_features
         if x.dim() not in (4, 5) or x.shape[1] != C or C % 4 or self.activation_param != ABN_SLOPE:
             raise NotImplementedError(f"InPlaceABN.forward: expected (N,{C},H,W) or (1,{C},D,H,W) with C % 4 == 0 and slope {ABN_SLOPE}")
@@ -486,7 +491,8 @@ def _conv(src1, src2, dims_in, cin_ld, wbuf, cin_k, cout_k, stride, packed=None,
     want_stats: as in _conv_t (None: returns out; True / False: (out, InPlaceABN partial sums | None))."""
     D, H, W, _ = dims_in
     Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
-    out = torch.empty((Do, Ho, Wo, cout_k), device=wbuf.device, dtype=torch.float32)
+    dev = (src1.x if isinstance(src1, _Lazy) else src1).device
+    out = torch.empty((Do, Ho, Wo, cout_k), device=dev, dtype=torch.float32)
     if packed is not None and src2 is None and _lib.lib().mvsnerf_conv3d_mfma_supported(cin_k, cout_k, stride):
         lib = _lib.lib()
         x, sc, sh = _ptrs(src1)
@@ -497,6 +503,8 @@ def _conv(src1, src2, dims_in, cin_ld, wbuf, cin_k, cout_k, stride, packed=None,
         check(lib.mvsnerf_conv3d_mfma_fwd(x, sc, sh, cin_k, cin_ld, D, H, W, packed.get_mfma(mode).data_ptr(), cout_k, stride,
                                           out.data_ptr(), 0 if part is None else part.data_ptr(), stream_ptr()), "conv3d_mfma_fwd")
         return out if want_stats is None else (out, None if part is None else (part, nblk))
+    if callable(wbuf):
+        wbuf = wbuf()               # the VALU layout is only packed when this branch runs (no eager pk.get() per step)
     check(_lib.lib().mvsnerf_conv3d_fwd(*_ptrs(src1), *_ptrs(src2), cin_k, cin_ld, D, H, W, wbuf.data_ptr(), cout_k, stride,
                                         out.data_ptr(), stream_ptr()), "conv3d_fwd")
     return out if want_stats is None else (out, None)
@@ -508,7 +516,8 @@ def _conv_t(src1, src2, dims_in, wbuf, cin_k, cout_k, packed=None, mode="fwd", w
     want_stats None: returns out; True / False: returns (out, partials) - partials = the InPlaceABN partial sums of `out` when the kernel
     could leave them (only asked for with True), else None."""
     D, H, W, _ = dims_in
-    out = torch.empty((2 * D, 2 * H, 2 * W, cout_k), device=wbuf.device, dtype=torch.float32)
+    dev = (src1.x if isinstance(src1, _Lazy) else src1).device
+    out = torch.empty((2 * D, 2 * H, 2 * W, cout_k), device=dev, dtype=torch.float32)
     if packed is not None and _lib.lib().mvsnerf_conv_transpose3d_c8_supported(cin_k, cout_k):
         lib = _lib.lib()            # lazily-activated sources and the skip sum are applied while staging; statistics from the same launch
         part, nblk = None, 0
@@ -523,6 +532,8 @@ def _conv_t(src1, src2, dims_in, wbuf, cin_k, cout_k, packed=None, mode="fwd", w
         check(_lib.lib().mvsnerf_conv_transpose3d_mfma_fwd(src1.data_ptr(), cin_k, D, H, W, packed.get_mfma(mode).data_ptr(), cout_k,
                                                            out.data_ptr(), stream_ptr()), "conv_transpose3d_mfma_fwd")
         return out if want_stats is None else (out, None)
+    if callable(wbuf):
+        wbuf = wbuf()
     check(_lib.lib().mvsnerf_conv_transpose3d_fwd(*_ptrs(src1), *_ptrs(src2), cin_k, D, H, W, wbuf.data_ptr(), cout_k,
                                                   out.data_ptr(), stream_ptr()), "conv_transpose3d_fwd")
     return out if want_stats is None else (out, None)
@@ -550,7 +561,7 @@ class ConvBnReLU3D(nn.Module):
 
     def lazy(self, src1, dims_in, cin_ld, src2=None):
         pk = self._packed
-        raw, partials = _conv(src1, src2, dims_in, cin_ld, pk.get(), pk.cin_pad, pk.cout, self.stride, packed=pk, want_stats=self.bn.training)
+        raw, partials = _conv(src1, src2, dims_in, cin_ld, pk.get, pk.cin_pad, pk.cout, self.stride, packed=pk, want_stats=self.bn.training)
         D, H, W, C = raw.shape
         scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self.bn, update_running=self.bn.training, partials=partials)
         return _Lazy(raw, scale, shift, (D, H, W, C), mean, invstd)
@@ -587,7 +598,7 @@ class _UpBlock(nn.Sequential):
                 and not _lib.lib().mvsnerf_conv_transpose3d_c8_supported(pk.cin_pad, pk.cout)):      # (that kernel activates while staging)
             # every input voxel feeds 27/8 output voxels on average: activate (and sum the skip) once instead of per tap
             src1, src2 = _apply_add(src1, src2), None
-        raw, partials = _conv_t(src1, src2, dims_in, pk.get(), pk.cin_pad, pk.cout, packed=pk, want_stats=self[1].training)
+        raw, partials = _conv_t(src1, src2, dims_in, pk.get, pk.cin_pad, pk.cout, packed=pk, want_stats=self[1].training)
         D, H, W, C = raw.shape
         scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self[1], update_running=self[1].training, partials=partials)
         return _Lazy(raw, scale, shift, (D, H, W, C), mean, invstd)
@@ -726,7 +737,7 @@ def _costreg_backward(net, lz, g_out, conv0_grads, sums=None):
         gx, gbw, gbb = _abn_bwd(out_lz, lay[1], g_act1, g_act2)
         pk = lay._packed
         gw = _wgrad(in1, in2, pk.cin, gx, None, pk.cout, pk.cout, in1.dims[:3], out_lz.dims[:3], 2, tuple(lay[0].weight.shape), sums)
-        g_in = _conv(gx, None, out_lz.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin, 2, packed=pk, mode="dgrad")       # data grad = stride-2 conv
+        g_in = _conv(gx, None, out_lz.dims, pk.cout, lambda: pk.get("dgrad"), pk.cout, pk.cin, 2, packed=pk, mode="dgrad")       # data grad = stride-2 conv
         grads[i] = (gw, gbw, gbb)
         return g_in
 
@@ -736,8 +747,8 @@ def _costreg_backward(net, lz, g_out, conv0_grads, sums=None):
         gw = _wgrad(gx, None, pk.cout, in1, None, pk.cin, in_ld, out_lz.dims[:3], in_dims[:3], lay.stride, tuple(lay.conv.weight.shape), sums)
         grads[i] = (gw, gbw, gbb)
         if lay.stride == 1:
-            return _conv(gx, None, out_lz.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin_pad, 1, packed=pk, mode="dgrad")
-        return _conv_t(gx, None, out_lz.dims, pk.get("dgrad"), pk.cout, pk.cin_pad, packed=pk, mode="dgrad")
+            return _conv(gx, None, out_lz.dims, pk.cout, lambda: pk.get("dgrad"), pk.cout, pk.cin_pad, 1, packed=pk, mode="dgrad")
+        return _conv_t(gx, None, out_lz.dims, lambda: pk.get("dgrad"), pk.cout, pk.cin_pad, packed=pk, mode="dgrad")
 
     g_u9c2 = up_block(9, L[9], u11, c2, u9, g)               # conv11: grad w.r.t. A(c2)+A(u9)
     g_u7c4 = up_block(8, L[8], u9, c4, u7, g_u9c2)           # conv9:  grad w.r.t. A(c4)+A(u7)
@@ -789,7 +800,7 @@ class _CostRegFunction(torch.autograd.Function):
             gw = _wgrad(gx, None, pk.cout, buf, None, pk.cin, ld, (D, H, W), (D, H, W), 1, tuple(lay.conv.weight.shape), sums)
             if not ctx.needs_input_grad[0]:
                 return gw, None
-            return gw, _conv(gx, None, c0.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin_pad, 1, packed=pk, mode="dgrad")
+            return gw, _conv(gx, None, c0.dims, pk.cout, lambda: pk.get("dgrad"), pk.cout, pk.cin_pad, 1, packed=pk, mode="dgrad")
 
         g_cost, flat = _costreg_backward(net, lz, g_out, conv0_grads, sums)
         return (None if g_cost is None else _cl_view_to_ncdhw(g_cost, ctx.xshape[1]), None, *flat)

@@ -8,12 +8,18 @@ the step uses (`log`, `global_step`, `device`) when Lightning is absent.
 
 Multi-GPU (one process per GPU, gradients averaged by ONE flat-buffer all-reduce -
 mvsnerf_amd.distributed.FlatGradAllReduce, RCCL over xGMI on GPUs), two modes selected by `args.dp_mode`:
-  "ray"   every rank encodes the SAME scene sample and draws the same pixel ids / jitter (a per-step seed broadcast from rank 0),
-          renders its slice of the rays and back-propagates through its slice AND the replicated encoder: the step equals the
-          1-GPU step on the same batch, but the ~14 of 17 ms spent in the encoder are not divided (speed-up <= ~1.2x at 8 GPUs);
-  "scene" each rank takes a DIFFERENT (scan, ref view) sample and its own 1024 rays - what Lightning DDP + DistributedSampler
-          would give the reference (train_mvs_nerf_pl.py:306,313): the effective batch is `world` scenes per step and the
-          whole step is divided (speed-up ~world x; BN batch statistics are per rank, as under DDP without SyncBN).
+  "scene" (DEFAULT for generalizable training; north_star's "source-view triplets" sharding) each rank takes a DIFFERENT
+          (scan, ref view) sample and its own 1024 rays - what Lightning DDP + DistributedSampler would give the reference
+          (train_mvs_nerf_pl.py:306,313): the effective batch is `world` scenes per step and the WHOLE step (encoder included) is
+          divided; the only exchange is the 1.9 MB flat all-reduce.  BN batch statistics are per rank (DDP without SyncBN); the
+          running-stat buffers are broadcast from rank 0 at the end of fit_steps and before save_ckpt (DDP's broadcast_buffers).
+  "ray"   every rank encodes the SAME scene sample and draws the same pixel ids / jitter (ONE base seed broadcast from rank 0 at
+          the start of fit_steps, step i uses base + i), renders its slice of the rays and back-propagates through its slice AND
+          the replicated encoder: the step equals the 1-GPU step on the same batch, but the encoder's ~8.5 of ~10 ms are repeated on
+          every rank (bounded speed-up, <= ~1.2x at 8 GPUs by construction).  It is the right mode where no encoder runs per step
+          (per-scene fine-tuning, MVSSystemFinetune), not for this class.
+Nothing here has run on more than one GPU (the dev boxes have one): every multi-GPU statement is by construction + world-size-2 gloo
+tests, UNMEASURED on hardware.
 
 `args.use_amp` (the reference's `precision=16 if args.use_amp`, train_mvs_nerf_pl.py:317-318; BASELINE config 3 "bf16"): the ray-march MLP
 trains on v_mfma_f32_32x32x16_bf16 - forward with activation store, data- and weight-gradient GEMMs - with fp32 accumulation, fp32
@@ -146,7 +152,8 @@ class MVSSystem(_ModuleShim):
         N_rays, N_samples = args.batch_size, args.N_samples
         rays_pts, rays_dir, target_s, rays_NDC, depth_candidates, rays_o, rays_depth, _ = build_rays(
             imgs, depths_h, pose_ref, pose_ref["w2cs"], pose_ref["c2ws"], pose_ref["intrinsics"], near_fars, N_rays, N_samples, pad=args.pad)  # :119
-        loss_scale = 1.0
+        loss_scale, depth_scale, depth_term = 1.0, None, None
+        n_masked_all = (rays_depth > 0).sum() if (rays_depth is not None and getattr(args, "with_depth", False)) else None
         if self.dp_mode() == "ray":                                      # same draw on all ranks (seeded in fit_steps), local slice
             (rays_pts, rays_dir, target_s, rays_NDC, depth_candidates, rays_depth, rays_o), loss_scale = D.shard_ray_batch(
                 (rays_pts, rays_dir, target_s, rays_NDC, depth_candidates, rays_depth, rays_o), N_rays)     # rays_o is (3, N): sliced in dim 1
@@ -159,7 +166,12 @@ class MVSSystem(_ModuleShim):
         if getattr(args, "with_depth", False):
             mask = rays_depth > 0
             if getattr(args, "with_depth_loss", False):
-                loss = loss + self.loss(depth_pred, rays_depth, mask)
+                depth_term = self.loss(depth_pred, rays_depth, mask)
+                loss = loss + depth_term
+                if self.dp_mode() == "ray" and D.world_rank()[0] > 1:
+                    # the depth term is a mean over the MASKED rays: weight by local masked count x world / global masked count (every
+                    # rank holds the full draw before slicing, so the global count is local knowledge; device tensors, no host sync)
+                    depth_scale = mask.sum() * float(D.world_rank()[0]) / n_masked_all.clamp_min(1)
             with torch.no_grad():                                        # :130-138
                 err = (depth_pred - rays_depth)[mask].abs()
                 for t in self.eval_metric:
@@ -175,10 +187,17 @@ class MVSSystem(_ModuleShim):
                 self.log("train/PSNR_out", mse2psnr2(img2mse(rgb[~mask], target_s[~mask])), prog_bar=True)
             else:
                 self.log("train/PSNR", mse2psnr2(img_loss), prog_bar=True)
-        if self.global_step % 20000 == 19999 and D.world_rank()[1] == 0:  # one writer (ranks hold identical weights after the all-reduce)
-            self.save_ckpt(f"{self.global_step}")
-        # ray mode with N_rays % world != 0: weight the local mean so that the rank-averaged gradient is that of the global mean
-        return {"loss": loss if loss_scale == 1.0 else loss * loss_scale}
+        if self.global_step % 20000 == 19999:
+            if self.dp_mode() == "scene":
+                self.sync_buffers()                                       # collective: every rank takes part, rank 0 writes
+            if D.world_rank()[1] == 0:                                    # one writer (ranks hold identical weights after the all-reduce)
+                self.save_ckpt(f"{self.global_step}")
+        # ray mode with N_rays % world != 0: the tensor that is back-propagated is weighted so that the rank-AVERAGED gradient is that of
+        # the global mean; what is reported / logged stays the plain local mean ('loss_unscaled')
+        if loss_scale == 1.0 and depth_scale is None:
+            return {"loss": loss}
+        scaled = img_loss * loss_scale + (0 if depth_term is None else depth_term * (depth_scale if depth_scale is not None else loss_scale))
+        return {"loss": scaled, "loss_unscaled": loss.detach()}
 
     @torch.no_grad()
     def render_view(self, batch, chunk=None, whole_frame_off=False, target=None, batch_rays=4096):
@@ -300,7 +319,7 @@ class MVSSystem(_ModuleShim):
     # -- minimal trainer -----------------------------------------------------------------------
     def dp_mode(self):
         """"ray" | "scene" (module docstring); anything else is rejected loudly."""
-        mode = getattr(self.args, "dp_mode", "ray")
+        mode = getattr(self.args, "dp_mode", "scene")
         if mode not in ("ray", "scene"):
             raise ValueError(f"args.dp_mode must be 'ray' or 'scene', got {mode!r}")
         return mode
@@ -321,17 +340,36 @@ class MVSSystem(_ModuleShim):
                 torch.manual_seed(torch.initial_seed() + 7919 * rank)      # independent draws per rank from here on
                 self._scene_seeded = True
         losses = []
+        base_seed = D.common_seed(self.device) if (world > 1 and mode == "ray") else None   # ONE broadcast + host read per call, not per step
         for i, batch in enumerate(batches):
-            if world > 1 and mode == "ray":
-                torch.manual_seed(D.common_seed(self.device))                # same pixel ids (CPU RNG) and jitter (device RNG) everywhere
+            if base_seed is not None:
+                torch.manual_seed(base_seed + i)                             # same pixel ids (CPU RNG) and jitter (device RNG) everywhere
             optimizer.zero_grad(set_to_none=True)
             out = self.training_step(batch, i)
             out["loss"].backward()
             self._allreduce()
             optimizer.step()
             self.global_step += 1
-            losses.append(out["loss"].detach())
+            losses.append(out.get("loss_unscaled", out["loss"]).detach())
+        if world > 1 and mode == "scene":
+            self.sync_buffers()
         return [float(l) for l in losses]                                   # one host synchronisation, after the last step is enqueued
+
+    def sync_buffers(self):
+        """Scene-sharded DP: every rank updates the InPlaceABN running statistics from its own scenes.  Like DDP's default
+        broadcast_buffers=True, rank 0's buffers become everybody's (one flat broadcast); the forward pass never reads them
+        (MVSNet runs in train mode, batch statistics), so it only matters for what save_ckpt writes."""
+        if not D._collective_needed():
+            return
+        bufs = [b for b in self.MVSNet.buffers() if b.is_floating_point()]
+        if not bufs:
+            return
+        flat = torch.cat([b.reshape(-1) for b in bufs])
+        torch.distributed.broadcast(flat, src=0)
+        off = 0
+        for b in bufs:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
 
 
 def synthetic_batch(H=512, W=640, seed=1234, **rig_kw):
@@ -354,7 +392,7 @@ def default_args(**over):
     d = dict(expname="exp", pad=24, batch_size=1024, num_epochs=8, pts_dim=3, dir_dim=3, net_type="v0", netdepth=6, netwidth=128,
              lrate=5e-4, chunk=1024, netchunk=1024, ckpt=None, N_samples=128, N_importance=0, perturb=1.0, use_viewdirs=True,
              i_embed=0, multires=10, multires_views=4, raw_noise_std=0.0, white_bkgd=False, img_downscale=1.0,
-             use_color_volume=False, with_depth=False, with_depth_loss=False, feat_dim=20, dp_mode="ray", use_amp=False)
+             use_color_volume=False, with_depth=False, with_depth_loss=False, feat_dim=20, dp_mode="scene", use_amp=False)
     d.update(over)
     return types.SimpleNamespace(**d)
 

@@ -104,11 +104,13 @@ class _ToySystem:
         class Toy(T._ModuleShim):
             fit_steps = T.MVSSystem.fit_steps
             dp_mode = T.MVSSystem.dp_mode
+            sync_buffers = T.MVSSystem.sync_buffers
 
             def __init__(self):
                 super().__init__()
                 torch.manual_seed(5)
                 self.lin = torch.nn.Linear(3, 2)
+                self.MVSNet = torch.nn.BatchNorm1d(2)                          # stands for the encoder's InPlaceABN running statistics
                 self.args = types.SimpleNamespace(dp_mode=mode)
                 self.grad_vars = list(self.lin.parameters())
                 self._allreduce = None
@@ -118,6 +120,8 @@ class _ToySystem:
                 x, y = batch["x"], batch["y"]                                  # (N,3), (N,2): N "rays"
                 n = x.shape[0]
                 self.draws.append(torch.rand(4))                               # stands for pixel ids / jitter
+                with torch.no_grad():
+                    self.MVSNet.running_mean += y.mean(0)                      # per-rank statistics of the scene this rank saw
                 scale = 1.0
                 if self.dp_mode() == "ray":
                     (x, y), scale = D.shard_ray_batch((x, y), n)
@@ -138,7 +142,8 @@ def _dp_worker(rank, world, port, mode, q):
     opt = torch.optim.SGD(sys_.grad_vars, lr=1.0)
     w0 = sys_.lin.weight.detach().clone()
     sys_.fit_steps(_toy_batches(2), opt)
-    q.put((rank, (sys_.lin.weight.detach() - w0).tolist(), sys_.lin.bias.detach().tolist(), torch.stack(sys_.draws).tolist()))   # plain lists: no fd passing
+    q.put((rank, (sys_.lin.weight.detach() - w0).tolist(), sys_.lin.bias.detach().tolist(), torch.stack(sys_.draws).tolist(),
+           sys_.MVSNet.running_mean.tolist()))   # plain lists: no fd passing
     dist.barrier()
     dist.destroy_process_group()
 
@@ -153,8 +158,9 @@ def test_dp_modes_world2(mode):
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
     [p.join(timeout=60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    (_, dw0, b0, draws0), (_, dw1, b1, draws1) = [(r, *(torch.tensor(t) for t in rest)) for r, *rest in res]
+    (_, dw0, b0, draws0, rm0), (_, dw1, b1, draws1, rm1) = [(r, *(torch.tensor(t) for t in rest)) for r, *rest in res]
     assert torch.equal(dw0, dw1) and torch.equal(b0, b1)            # ranks stay in lock step
+    assert torch.equal(rm0, rm1)                                    # ... and so do the running statistics (ray: same data; scene: rank 0's, broadcast)
     batches = _toy_batches(2)
     if mode == "ray":
         # 7 rays over 2 ranks (4 + 3): the all-reduced step must equal the single-process step on the full batches

@@ -35,23 +35,22 @@ def test_golden_sweep(name, mvs):
     with torch.no_grad():
         warped, grid = U.homo_warp(g["ref_feats"][:, 1], g["proj_mats"][:, 1], g["depth_values"], pad=pad)
         assert grid.shape == c["ref_grid_v1"].shape
-        ok, e = close(grid, c["ref_grid_v1"], 2e-5); assert ok, f"grid {e}"
-        ok, e = close(warped, c["ref_warped_v1"], 1e-4); assert ok, f"warped {e}"
+        # homo_warp / the plane sweep follow the CPU reference's fp32 arithmetic operation for operation (encoder.hip): the reference-generated
+        # fixtures are reproduced exactly (measured 0.0; equality up to the sign of zero, hence `==` on values rather than on bits)
+        assert bool((grid.cpu() == c["ref_grid_v1"]).all()), f"grid {maxabs(grid.cpu(), c['ref_grid_v1'])}"
+        assert bool((warped.cpu() == c["ref_warped_v1"]).all()), f"warped {maxabs(warped.cpu(), c['ref_warped_v1'])}"
         w2, _ = U.homo_warp(g["ref_feats"][:, 1], g["proj_mats"][:, 1], g["depth_values"], src_grid=g["ref_grid_v1"], pad=pad)
-        ok, e = close(w2, c["ref_warped_v1"], 1e-5); assert ok, f"warped(grid given) {e}"
+        assert bool((w2.cpu() == c["ref_warped_v1"]).all()), f"warped(grid given) {maxabs(w2.cpu(), c['ref_warped_v1'])}"
         cost, masks = mvs.build_volume_costvar_img(g["images"][:, :3], g["ref_feats"], g["proj_mats"][:, :3], g["depth_values"], pad=pad)
         assert cost.shape == c["ref_cost_img"].shape and masks.shape == c["ref_in_masks"].shape
-        flips = int((masks.cpu() != c["ref_in_masks"]).sum())
-        assert flips <= 2, f"{flips} in-frustum mask flips"
-        bad = (masks.cpu() != c["ref_in_masks"]).any(1, keepdim=True).expand_as(cost.cpu())
-        err = ((cost.cpu() - c["ref_cost_img"]).abs() * (~bad)).max()
-        # variance = E[x^2]-E[x]^2 cancels: its rounding error scales with the second moment, not with the result
-        tol = 1e-4 + 3e-6 * float(c["ref_feats"].abs().max()) ** 2
-        assert float(err) < tol, f"cost volume {float(err)} (tol {tol})"
+        assert torch.equal(masks.cpu(), c["ref_in_masks"])                       # no in-frustum decision differs
+        # channels 0:3 are the 4x-resized reference image (ATen's resize rounds differently at some sizes: 1e-7 level); the warped colours
+        # and the 32 variance channels - E[x^2]-E[x]^2, ill-conditioned, |x| up to 14 - are reproduced exactly
+        assert maxabs(cost.cpu()[:, :3], c["ref_cost_img"][:, :3]) < 5e-7
+        assert bool((cost.cpu()[:, 3:] == c["ref_cost_img"][:, 3:]).all()), f"cost volume {maxabs(cost.cpu(), c['ref_cost_img'])}"
         var, cnt = mvs.build_volume_costvar(g["ref_feats"], g["proj_mats"][:, :3], g["depth_values"], pad=pad)
-        assert int((cnt.cpu() != c["ref_cost_cnt"]).sum()) <= 2
-        bad = (cnt.cpu() != c["ref_cost_cnt"]).expand_as(var.cpu())
-        assert float(((var.cpu() - c["ref_cost_var"]).abs() * (~bad)).max()) < tol
+        assert torch.equal(cnt.cpu(), c["ref_cost_cnt"])
+        assert bool((var.cpu() == c["ref_cost_var"]).all()), f"variance {maxabs(var.cpu(), c['ref_cost_var'])}"
 
 
 @pytest.mark.parametrize("name", ["caseA", "caseB"])
@@ -62,7 +61,7 @@ def test_golden_costreg(name, mvs):
     with torch.no_grad():
         vol = mvs.cost_reg_2(x)                      # reference-layout NCDHW tensor in (boundary transpose inside)
     assert vol.shape == c["ref_vol_small"].shape
-    ok, e = close(vol, c["ref_vol_small"], 2e-4, 1e-3)
+    ok, e = close(vol, c["ref_vol_small"], 2e-5, 2e-6)          # measured 7.4e-6 at |vol| <= 5.5
     assert ok, f"CostRegNet {e}"
     assert vol[0].permute(1, 2, 3, 0).is_contiguous()         # channel-last memory, feeds the ray march with no transpose
     assert not torch.equal(rm_before, mvs.cost_reg_2.conv0.bn.running_mean)   # train-mode side effect reproduced
@@ -70,20 +69,20 @@ def test_golden_costreg(name, mvs):
 
 @pytest.mark.parametrize("name", ["caseA", "caseB"])
 def test_golden_mvsnet_forward(name, mvs):
-    """Full MVSNet.forward (D=128): FeatureNet runs on PyTorch-ROCm (MIOpen) here vs oneDNN in the reference run,
-    so inputs to the HIP stages already differ at the 1e-5 level; tolerance is looser than for the single stages."""
+    """Full MVSNet.forward (D=128), all three stages on HIP, against the reference's own output (fixture)."""
     c = load_case(name)
     with torch.no_grad():
         vol, feats, dv = mvs(c["images"][:, :3].to(DEV), c["proj_mats"][:, :3].to(DEV), c["near_fars"][0, 0].to(DEV), pad=c["pad"])
     assert maxabs(dv.cpu(), c["ref_dv128"]) < 1e-6
-    ok, e = close(feats, c["ref_feats"], 1e-4, 1e-4)
-    assert ok, f"FeatureNet (torch-ROCm) {e}"
+    ok, e = close(feats, c["ref_feats"], 1e-5, 1e-6)            # measured 3.6e-6 at |f| <= 11.8
+    assert ok, f"FeatureNet {e}"
     sub = vol[:, :, ::8].cpu()
     err = (sub - c["ref_vol128_sub"]).abs()
-    # in-frustum mask flips at the 1-ulp level change single voxels by O(1): allow a handful of outliers
-    frac_bad = float((err > 2e-3).float().mean())
-    assert frac_bad < 1e-4, f"{frac_bad} of voxels off; max {float(err.max())}"
-    assert abs(float(vol.double().sum()) - c["ref_vol128_sum"]) < 1e-3 * c["ref_vol128_abssum"]
+    from tests.util import record_err
+    record_err(f"test_golden_mvsnet_forward[{name}]:vol128_sub", float(err.max()), float(c["ref_vol128_sub"].abs().max()), 1e-4)
+    # FeatureNet's 1e-6-level differences move variance channels by 1e-4 (E[x^2]-E[x]^2 at |x| ~ 10) and CostRegNet's batch statistics with them
+    assert float(err.max()) < 1e-4, f"max {float(err.max())}"
+    assert abs(float(vol.double().sum()) - c["ref_vol128_sum"]) < 1e-5 * c["ref_vol128_abssum"]
 
 
 def test_midsize_vs_oracle(mvs):
@@ -100,12 +99,11 @@ def test_midsize_vs_oracle(mvs):
     vol_ref = O.cost_reg_net(cost_ref, sd)
     with torch.no_grad():
         cost, masks = mvs.build_volume_costvar_img(imgs.to(DEV), feats.to(DEV), proj.to(DEV), dv.to(DEV), pad=pad)
-        flips = (masks.cpu() != masks_ref)
-        assert int(flips.sum()) <= 4
-        bad = flips.any(1, keepdim=True).expand_as(cost_ref)
-        assert float(((cost.cpu() - cost_ref).abs() * (~bad)).max()) < 1e-4 + 3e-6 * float(feats.abs().max()) ** 2
+        assert torch.equal(masks.cpu(), masks_ref)
+        assert maxabs(cost.cpu()[:, :3], cost_ref[:, :3]) < 5e-7
+        assert bool((cost.cpu()[:, 3:] == cost_ref[:, 3:]).all()), maxabs(cost.cpu(), cost_ref)    # rotated cameras, pad 4: exact as well
         vol = mvs.cost_reg_2(cost_ref.to(DEV))
-    ok, e = close(vol, vol_ref, 2e-4, 1e-3)
+    ok, e = close(vol, vol_ref, 2e-5, 2e-6)                      # measured 6.4e-6 at |vol| <= 6.1
     assert ok, f"CostRegNet vs oracle {e}"
 
 

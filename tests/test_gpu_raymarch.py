@@ -14,10 +14,10 @@ from tests.util import load_case, load_weights, pose_of, maxabs
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-ATOL = 1e-4
+ATOL = 3e-6          # bounds of close(): atol + rtol |ref|; measured (gpurun_out/measured_errs.jsonl): 1.2e-6 on the fixtures (|raw| <= 3.9), 9.5e-6 at config 2 (sigma <= 20)
 
 
-def close(a, b, atol=ATOL, rtol=1e-4):
+def close(a, b, atol=ATOL, rtol=2e-6):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     err = (a - b).abs()
     ok = bool((err <= atol + rtol * b.abs()).all())
@@ -90,7 +90,7 @@ def test_golden_pieces(name, net):
         # compositing on the reference's raw
         outs = R.raw2outputs(g["ref_raw"], g["ref_depth_cand"], None, False, "v0")
         for a, k in zip(outs, ["ref_rgb", "ref_disp", "ref_acc", "ref_weights", "ref_depth_map", "ref_alpha"]):
-            ok, e = close(a, c[k], 1e-5, 1e-5)
+            ok, e = close(a, c[k], 2e-6, 1e-6)                  # measured 4.8e-7
             assert ok, f"raw2outputs {k} {e}"
 
 
@@ -178,7 +178,7 @@ def test_ragged_shapes_vs_oracle(n_rays, n_samples, net):
         rgb, feat, w, depth, alpha, _ = R.rendering(_args(), pose_d, pts.to(DEV), ndc.to(DEV), z.to(DEV), ro.to(DEV), dirs.to(DEV),
                                                     vol.to(DEV), rig["images_raw"][:, :3].to(DEV), network_fn=net, network_query_fn=qfn)
     for a, b, k in [(rgb, ref[0], "rgb"), (feat, ref[1], "input_feat"), (w, ref[2], "weights"), (depth, ref[3], "depth"), (alpha, ref[4], "alpha")]:
-        ok, e = close(a, b, 2e-4 if k == "input_feat" else ATOL)
+        ok, e = close(a, b, 0.0 if k == "input_feat" else ATOL, 0.0 if k == "input_feat" else 2e-6)     # the lookups are exact
         assert ok, f"{k} ({n_rays}x{n_samples}): {e}"
 
 
@@ -397,9 +397,10 @@ def test_use_color_volume_rendering_vs_oracle(net):
         rgb, feat, w, depth, alpha, _ = R.rendering(_args(use_color_volume=True), pose_d, pts.to(DEV), ndc.to(DEV), z.to(DEV), ro.to(DEV),
                                                     dirs.to(DEV), vol.to(DEV), rig["images_raw"][:, :3].to(DEV), network_fn=net, network_query_fn=qfn)
     assert feat.shape == (200, 48, 20)
-    assert maxabs(feat.cpu(), feat_ref) < 1e-5                  # trilinear summation order (generic-C kernel: one thread per channel)
+    assert maxabs(feat.cpu(), feat_ref) < 1e-6                  # generic-C kernel (one thread per channel), ATen's term order: measured 0
     for a, b, name in ((rgb, rgb_ref, "rgb"), (w, w_ref, "weights"), (depth, depth_ref, "depth"), (alpha, alpha_ref, "alpha")):
-        assert torch.allclose(a.cpu(), b, atol=1e-4, rtol=1e-4), name
+        ok, e = close(a, b)
+        assert ok, f"{name}: {e}"
     with pytest.raises(RuntimeError):                       # channel count must match feat_dim
         R.gen_pts_feats(rig["images_raw"][:, :3].to(DEV), vol8.to(DEV), pts.to(DEV), pose_d, ndc.to(DEV), 20, use_color_volume=True)
 
