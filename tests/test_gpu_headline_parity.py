@@ -21,13 +21,13 @@ DEV = "cuda"
 H, W, PAD, D, N_RAYS, N_SAMPLES = 512, 640, 24, 128, 1024, 128
 
 # Bounds asserted below (fp32; see DESIGN.md section "parity at the headline shape" for where each comes from).
-TOL_FEATS = 2e-5          # FeatureNet: 8 conv+ABN layers, |feats| <= ~3
-TOL_COST_REL = 3e-6       # variance = E[x^2]-E[x]^2: rounding scales with the second moment (|feats|max^2)
-TOL_VOL_ISOLATED = 1e-4   # CostRegNet on the oracle's own cost volume
-TOL_VOL_CHAINED = 2e-4    # images -> volume, all HIP (in-frustum flips excluded, counted separately)
-TOL_RGB = 1e-4            # north_star
-TOL_SIGMA = 1e-4          # north_star; applied to alpha = 1-exp(-sigma) and to sigma relative to max|sigma| (see the asserts)
-MAX_FLIPS = 16            # in-frustum mask decisions that differ (strict `-1 < g < 1` at 1-ulp distance), of 14 M
+# Every bound is <= 5x what was measured on MI355X (gpurun_out/headline_parity.json of round 3).
+TOL_FEATS = 2e-5          # FeatureNet: 8 conv+ABN layers, |feats| <= 28; measured 7.6e-6
+TOL_VOL_ISOLATED = 6e-5   # CostRegNet on the oracle's own cost volume, |vol| <= 12; measured 1.3e-5
+TOL_VOL_CHAINED = 7e-5    # images -> volume, all HIP; measured 1.5e-5
+TOL_RGB = 1e-5            # north_star asks 1e-4; measured 1.8e-6
+TOL_SIGMA = 1e-4          # north_star, ABSOLUTE on sigma (<= 10.6 here): every one of the 131 072 samples; measured max 8.6e-6 (bound below 4e-5)
+MAX_FLIPS = 0             # in-frustum mask decisions that differ, of 14 M: the projection is the reference's arithmetic, bit for bit
 
 
 @pytest.fixture(scope="module")
@@ -119,9 +119,8 @@ def test_stage_isolated(scene, mvs):
         _record("volume_abs_max", float(s["vol_ref"].abs().max()))
     assert e_feats < TOL_FEATS
     assert n_flips <= MAX_FLIPS
-    assert e_rgbch < 5e-5          # bilinear taps of ImageNet-normalised colours (|c| <= 2.7) at 1e-5-pixel coordinate rounding
-    assert e_var < 1e-5 + TOL_COST_REL * float(s["feats_ref"].abs().max()) ** 2
-    assert e_var64 <= 1.25 * s["noise"]["cost_variance"] + 1e-5      # no further from the exact variance than the fp32 reference path is
+    assert e_rgbch == 0.0 and e_var == 0.0      # the plane sweep IS the reference's fp32 arithmetic (what differs in bits is the sign of zeros)
+    assert e_var64 <= 1.001 * s["noise"]["cost_variance"] + 1e-7     # hence exactly as far from the float64 variance as the reference is
     assert e_vol < TOL_VOL_ISOLATED
 
 
@@ -150,7 +149,7 @@ def test_chained_images_to_rgb(scene, mvs):
         e_vol = float(verr.max())
         n_over = int((verr > TOL_VOL_CHAINED).sum())
         _record("volume_chained_max_abs_err", e_vol)
-        _record("volume_chained_voxels_over_%g" % TOL_VOL_CHAINED, n_over)
+        _record("volume_chained_voxels_over_tol", n_over)
         _record("volume_chained_rms_err", float((verr.double() ** 2).mean().sqrt()))
         rgb, feat, wts, depth, alpha, _ = R.rendering(args, pose_d, pts.to(DEV), ndc.to(DEV), z.to(DEV), ro.to(DEV), dirs.to(DEV), vol,
                                                       s["rig"]["images_raw"][:, :3].to(DEV), network_fn=net, network_query_fn=qfn)
@@ -199,12 +198,13 @@ def test_chained_images_to_rgb(scene, mvs):
     for k, v in hip64.items():
         _record(f"hip_vs_f64_{k}", v)
         _record(f"oracle_f32_vs_f64_{k}", s["noise"][k])
-    assert e_rgb < TOL_RGB, e_rgb                                   # north_star: RGB within 1e-4
-    # sigma = relu(.) is unbounded (here up to ~10): the 1e-4 bound is applied to sigma relative to its scale and to alpha = 1-exp(-sigma)
-    assert e_sig_abs < 1e-4 * max(1.0, float(sig_ref.abs().max())), e_sig_abs
-    assert maxabs(alpha.cpu(), ref[4]) < 2 * TOL_SIGMA            # measured 1.2e-4: the fp32 reference path's own alpha noise vs fp64 is larger
-    # ... and in absolute terms the HIP sigma / volume are no further from the exact values than the fp32 reference path itself
-    assert hip64["sigma"] <= 1.25 * s["noise"]["sigma"] + 2e-5, (hip64["sigma"], s["noise"]["sigma"])
-    assert hip64["volume"] <= 1.25 * s["noise"]["volume"] + 2e-5, (hip64["volume"], s["noise"]["volume"])
-    assert hip64["volume_rms"] <= 1.25 * s["noise"]["volume_rms"] + 1e-6
-    assert e_vol < 5 * TOL_VOL_CHAINED and n_over <= 64, (e_vol, n_over)
+    assert e_rgb < TOL_RGB, e_rgb                                   # north_star: RGB within 1e-4 (bound here 1e-5)
+    assert e_sig_abs < 4e-5 and n_sig_over == 0, (e_sig_abs, n_sig_over)   # north_star: sigma within 1e-4, absolute, all samples (measured 8.6e-6)
+    assert e_sig_sv < 2.5e-5 and maxabs(feat_sv.cpu(), ref[1]) == 0.0  # same volume: the lookups are exact, what is left is the MLP (4.8e-6)
+    assert maxabs(alpha.cpu(), ref[4]) < 1e-5                       # measured 1.7e-6
+    assert maxabs(depth.cpu(), ref[3]) < 1.5e-5 and maxabs(wts.cpu(), ref[2]) < 6e-6        # measured 2.9e-6 / 1.3e-6
+    # distances to the float64 evaluation: the HIP path is where the fp32 reference path is
+    assert hip64["sigma"] <= 1.01 * s["noise"]["sigma"] + 2e-5, (hip64["sigma"], s["noise"]["sigma"])
+    assert hip64["volume"] <= 1.05 * s["noise"]["volume"] + 2e-5, (hip64["volume"], s["noise"]["volume"])
+    assert hip64["volume_rms"] <= 1.05 * s["noise"]["volume_rms"] + 1e-6
+    assert e_vol < TOL_VOL_CHAINED and n_over == 0, (e_vol, n_over)
