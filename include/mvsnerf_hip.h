@@ -70,6 +70,34 @@ int mvsnerf_planesweep_costvar_blocked_fwd(const float* feats_cl, const float* i
                                            int V, int C, int H, int W, int D, int pad, float* cost_blocked, int CP, float* masks,
                                            int with_img, void* stream);
 
+/* bf16 encoder (the reference's AMP switch, train_mvs_nerf_pl.py:317-318 `precision=16 if args.use_amp`; BASELINE config 3 "bf16"):
+ * conv0 of CostRegNet (models.py:756, 74.5 % of the encoder's FLOPs) on v_mfma_f32_16x16x32_bf16 - operands rounded to bf16, fp32
+ * accumulation, fp32 master weights / statistics / gradients.
+ *   planesweep_costvar_bf16_fwd  the plane sweep above storing the cost volume as bf16 in channel blocks of sixteen:
+ *                                cost16[ceil(CP/16)][D*Hp*Wp][16] (channels >= CP zero); the sweep's arithmetic stays fp32
+ *   conv0_bf16_pack              nn.Conv3d weight w[8][Cin][3][3][3] -> the kernel's B fragments (conv0_bf16_packed_elems(Cin) bf16 values)
+ *   conv0_bf16_fwd               out[D][H][W][8] fp32 (raw, before InPlaceABN); stats_part: NULL or conv0_bf16_tiles(D,H,W) * 16 floats of
+ *                                per-tile sums / sums of squares for mvsnerf_abn_finalize */
+int mvsnerf_planesweep_costvar_bf16_fwd(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,
+                                        int V, int C, int H, int W, int D, int pad, void* cost16, int CP, float* masks,
+                                        int with_img, void* stream);
+size_t mvsnerf_conv0_bf16_packed_elems(int Cin);
+int mvsnerf_conv0_bf16_pack(const float* w, int Cin, void* packed, void* stream);
+int mvsnerf_conv0_bf16_tiles(int D, int H, int W);
+int mvsnerf_conv0_bf16_fwd(const void* x16, int Cin, int D, int H, int W, const void* packed, float* out, float* stats_part, void* stream);
+/*   conv0_bf16_dgrad_pack / conv0_bf16_dgrad   data gradient w.r.t. the n_ci (16 or 32) input channels starting at c_first (the plane sweep's
+ *                                backward needs the 32 variance channels only): g = gradient of conv0's raw output, fp32 [D][H][W][8], rounded
+ *                                to bf16 on the way into the matrix cores; gx[D][H][W][n_ci] fp32 */
+size_t mvsnerf_conv0_bf16_dgrad_packed_elems(int n_ci);
+int mvsnerf_conv0_bf16_dgrad_pack(const float* w, int Cin, int c_first, int n_ci, void* packed, void* stream);
+int mvsnerf_conv0_bf16_dgrad(const float* g, int D, int H, int W, const void* packed, int n_ci, float* gx, void* stream);
+/*   conv0_bf16_wgrad             gw[8][Cin][3][3][3] from the bf16 cost volume and g (fp32, rounded to bf16 while staged): voxels are the
+ *                                reduction dimension, both operands are transposed by the LDS read (ds_read_b64_tr_b16); deterministic.
+ *                                workspace: mvsnerf_conv3d_wgrad_workspace_floats(8, Cin) floats; gw NULL leaves conv0_bf16_wgrad_parts(D,H,W)
+ *                                partial results (rows of 8*Cin*27 floats) at its start for mvsnerf_partial_sum_multi */
+int mvsnerf_conv0_bf16_wgrad_parts(int D, int H, int W);
+int mvsnerf_conv0_bf16_wgrad(const void* x16, int Cin, int D, int H, int W, const float* g, float* gw, float* workspace, void* stream);
+
 /* Stand-alone homo_warp (utils.py:580-630) for one source view: src[C][H][W] (NCHW), proj[3][4], depth[D]
  * -> warped[C][D][Hp][Wp], grid_out[D*Hp*Wp][2] (either may reuse a given grid_in, as models.py:872 does). */
 int mvsnerf_homo_warp_fwd(const float* src_nchw, const float* proj, const float* depth, const float* grid_in,

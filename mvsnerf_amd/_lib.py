@@ -82,6 +82,16 @@ SIGNATURES = {
     "mvsnerf_resize_bilinear": (_c_i, [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp]),
     "mvsnerf_planesweep_costvar_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp]),
     "mvsnerf_planesweep_costvar_blocked_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp]),
+    "mvsnerf_planesweep_costvar_bf16_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp]),
+    "mvsnerf_conv0_bf16_packed_elems": (ctypes.c_size_t, [_c_i]),
+    "mvsnerf_conv0_bf16_pack": (_c_i, [_c_fp, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_conv0_bf16_tiles": (_c_i, [_c_i] * 3),
+    "mvsnerf_conv0_bf16_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_conv0_bf16_dgrad_packed_elems": (ctypes.c_size_t, [_c_i]),
+    "mvsnerf_conv0_bf16_dgrad_pack": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_conv0_bf16_dgrad": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_conv0_bf16_wgrad_parts": (_c_i, [_c_i] * 3),
+    "mvsnerf_conv0_bf16_wgrad": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_conv3d_mfma_supported": (_c_i, [_c_i, _c_i, _c_i]),
     "mvsnerf_conv3d_pack_weights_mfma": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_fp]),
     "mvsnerf_conv3d_mfma_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),

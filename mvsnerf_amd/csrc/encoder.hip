@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
     int V, int H, int W, int D, int pad,
     float* __restrict__ cost, int CP,   // [D][Hp][Wp][CP]
     float* __restrict__ masks,          // with img: [V][D][Hp][Wp] per-view; else [D][Hp][Wp] count
-    int with_img, int blocked)          // blocked: cost[CP/4][D*Hp*Wp][4] (channel blocks of four, see mvsnerf_planesweep_costvar_blocked_fwd)
+    int with_img, int blocked)          // blocked 1: cost[CP/4][D*Hp*Wp][4] (channel blocks of four, see mvsnerf_planesweep_costvar_blocked_fwd);
+                                        // 2: bf16 in channel blocks of sixteen, cost16[ceil(CP/16)][D*Hp*Wp][16] (mvsnerf_planesweep_costvar_bf16_fwd)
 {
     // fp32 arithmetic of the CPU reference path, operation for operation (scratch/r3/cpu_arith_probe.py, cpu_var_probe.py compare candidate
     // formulas with reference-generated fixtures BIT FOR BIT): the projection is a k-ordered fma chain (sgemm), grid_sample's blend is
@@ -220,6 +221,19 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
                     const int vox = (k * 4) / CP, c = (k * 4) - vox * CP;
                     dst[k] = *reinterpret_cast<const f32x4*>(stage + vox * (CP + 4) + c);
                 }
+            } else if (blocked == 2) {
+                // bf16 (round to nearest even), blocks of sixteen channels: the two 16-byte halves of a voxel's block, voxels consecutive
+                typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+                __bf16* cost16 = reinterpret_cast<__bf16*>(cost);
+                const int nb16 = (CP + 15) >> 4, per = (int)nv * 2, n_k = per * nb16;
+                for (int k = threadIdx.x; k < n_k; k += 256) {
+                    const int cb = k / per, rem = k - cb * per, vox = rem >> 1, c0 = cb * 16 + (rem & 1) * 8;
+                    const float* srow = stage + vox * (CP + 4);
+                    bf16x8_t h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = (__bf16)(c0 + e < CP ? srow[c0 + e] : 0.0f);
+                    *reinterpret_cast<bf16x8_t*>(cost16 + (((int64_t)cb * nvox + p0 + vox) << 4) + (rem & 1) * 8) = h;
+                }
             } else {
                 // channel block cb (four channels) of these nv voxels is one contiguous run of nv * 16 bytes: k -> (cb, voxel)
                 const int nblk = CP >> 2, n_k = (int)nv * nblk;
@@ -250,6 +264,15 @@ extern "C" int mvsnerf_planesweep_costvar_blocked_fwd(const float* feats_cl, con
                                                       int with_img, void* stream)
 {
     return planesweep_launch(feats_cl, imgs_cl, proj, depth, V, C, H, W, D, pad, cost_blocked, CP, masks, with_img, 1, stream);
+}
+
+// The cost volume rounded to bf16 in channel blocks of sixteen: cost16[ceil(CP/16)][D*Hp*Wp][16] (channels >= CP are zero) - what the bf16
+// conv0 kernels (conv_bf16.hip) stage with 1 KB DMA pieces.  The sweep's own arithmetic is the fp32 one; only the store rounds.
+extern "C" int mvsnerf_planesweep_costvar_bf16_fwd(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,
+                                                   int V, int C, int H, int W, int D, int pad, void* cost16, int CP, float* masks,
+                                                   int with_img, void* stream)
+{
+    return planesweep_launch(feats_cl, imgs_cl, proj, depth, V, C, H, W, D, pad, reinterpret_cast<float*>(cost16), CP, masks, with_img, 2, stream);
 }
 
 static int planesweep_launch(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,

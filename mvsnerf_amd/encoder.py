@@ -18,6 +18,28 @@ from ._lib import check, dev_f32, stream_ptr
 
 ABN_EPS, ABN_MOMENTUM, ABN_SLOPE = 1e-5, 0.1, 0.01
 
+ENCODER_PRECISION = "fp32"      # "fp32" | "bf16": see encoder_precision
+
+
+class encoder_precision:
+    """`with encoder.encoder_precision("bf16"): ...` - the reference's AMP switch for the scene encoder (train_mvs_nerf_pl.py:317-318
+    `precision=16 if args.use_amp`; BASELINE config 3): the plane sweep stores the cost volume as bf16 and conv0 of CostRegNet (74.5 % of the
+    encoder's FLOPs) runs forward, data gradient and weight gradient on v_mfma_f32_16x16x32_bf16 (csrc/conv_bf16.hip) - operands rounded to
+    bf16, fp32 accumulation, fp32 statistics / master weights / gradients.  The other layers keep their fp32 kernels.  Default "fp32"."""
+
+    def __init__(self, mode):
+        if mode not in ("fp32", "bf16"):
+            raise ValueError("encoder precision must be 'fp32' or 'bf16'")
+        self.mode = mode
+
+    def __enter__(self):
+        global ENCODER_PRECISION
+        self.prev, ENCODER_PRECISION = ENCODER_PRECISION, self.mode
+
+    def __exit__(self, *exc):
+        global ENCODER_PRECISION
+        ENCODER_PRECISION = self.prev
+
 
 # ------------------------------------------------------------------ InPlaceABN stand-in
 class InPlaceABN(nn.Module):
@@ -431,6 +453,28 @@ class _PackedConv:
         """[tap][ci/8][co][8] layout of get(mode)'s weights for the matrix-core kernels of the 32/64-channel layers."""
         return self._cached(mode + "_m32", 2, mode, "get_mfma", mode)
 
+    def get_bf16_conv0(self, dgrad=None):
+        """bf16 B fragments of the 8-output-channel stride-1 layer (csrc/conv_bf16.hip): dgrad None -> forward; (c_first, n_ci) -> the
+        data gradient w.r.t. input channels c_first .. c_first + n_ci - 1."""
+        w = self.conv.weight
+        key = (w.data_ptr(), w._version, _lib.weights_epoch(), dgrad)
+        name = "bf16_fwd" if dgrad is None else "bf16_dgrad"
+        hit = self.cache.get(name)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        if self.transposed or self.conv.stride[0] != 1 or self.cout != 8:
+            raise RuntimeError("get_bf16_conv0: stride-1 Conv3d with 8 output channels (conv0)")
+        lib = _lib.lib()
+        wc = dev_f32(w.detach().contiguous(), "conv weight")
+        if dgrad is None:
+            buf = torch.empty(lib.mvsnerf_conv0_bf16_packed_elems(self.cin), device=w.device, dtype=torch.bfloat16)
+            check(lib.mvsnerf_conv0_bf16_pack(wc, self.cin, buf.data_ptr(), stream_ptr()), "conv0_bf16_pack")
+        else:
+            buf = torch.empty(lib.mvsnerf_conv0_bf16_dgrad_packed_elems(dgrad[1]), device=w.device, dtype=torch.bfloat16)
+            check(lib.mvsnerf_conv0_bf16_dgrad_pack(wc, self.cin, dgrad[0], dgrad[1], buf.data_ptr(), stream_ptr()), "conv0_bf16_dgrad_pack")
+        self.cache[name] = (key, buf)
+        return buf
+
 
 def _abn_stats(raw, n_vox, bn, update_running=True, partials=None):
     """Train-mode InPlaceABN statistics of a raw layer output -> (scale, shift, mean, invstd).  partials = (buffer, n_blocks): the
@@ -641,7 +685,22 @@ class CostRegNet(nn.Module):
             _, C, D, H, W = x.shape
         if D % 8 or H % 8 or W % 8:
             raise RuntimeError(f"CostRegNet needs D,h,w divisible by 8 (three stride-2 stages), got {(D, H, W)}")
-        if isinstance(x, _BlockedCost):
+        if isinstance(x, _BlockedCost16):
+            pk = self.conv0._packed
+            if x.n_ch != pk.cin:
+                raise RuntimeError(f"CostRegNet: bf16 cost volume has {x.n_ch} channels, conv0 expects {pk.cin}")
+            raw = torch.empty((D, H, W, pk.cout), device=x.buf.device, dtype=torch.float32)
+            lib = _lib.lib()
+            want = self.conv0.bn.training and FUSED_ABN_STATS
+            nblk = lib.mvsnerf_conv0_bf16_tiles(D, H, W)
+            part = torch.empty(nblk * 16, device=raw.device, dtype=torch.float32) if want else None
+            check(lib.mvsnerf_conv0_bf16_fwd(x.buf.data_ptr(), pk.cin, D, H, W, pk.get_bf16_conv0().data_ptr(), raw.data_ptr(),
+                                             0 if part is None else part.data_ptr(), stream_ptr()), "conv0_bf16_fwd")
+            scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self.conv0.bn, update_running=self.conv0.bn.training,
+                                                    partials=None if part is None else (part, nblk))
+            c0 = _Lazy(raw, scale, shift, (D, H, W, pk.cout), mean, invstd)
+            buf, ld = None, 0
+        elif isinstance(x, _BlockedCost):
             pk = self.conv0._packed
             if x.cin_pad != pk.cin_pad:
                 raise RuntimeError(f"CostRegNet: blocked cost volume has {x.cin_pad} channels, conv0 expects {pk.cin_pad}")
@@ -840,6 +899,12 @@ class _BlockedCost:
         self.buf, self.n_ch, self.cin_pad, self.dims = buf, n_ch, cin_pad, dims
 
 
+class _BlockedCost16(_BlockedCost):
+    """The same hand-off rounded to bf16, in channel blocks of sixteen: buf[ceil(n_ch/16)][D*H*W][16] torch.bfloat16
+    (mvsnerf_planesweep_costvar_bf16_fwd -> the bf16 conv0 kernels of csrc/conv_bf16.hip; `use_amp` training)."""
+    __slots__ = ()
+
+
 def _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img, blocked=False):
     """One-pass plane sweep (homo_warp + cost variance [+ warped thumbnails]).  Returns (cost view, masks, saved);
     blocked=True: the cost volume comes back as a _BlockedCost instead of a logical NCDHW view."""
@@ -864,6 +929,13 @@ def _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img, blocked=Fa
     masks = torch.empty((V, D, Hp, Wp) if with_img else (1, D, Hp, Wp), device=dev, dtype=torch.float32)
     proj = proj_mats[0].detach().contiguous()
     depth = depth_values[0].detach().contiguous()
+    if blocked == "bf16":
+        nb16 = (n_ch + 15) // 16
+        cost = torch.empty((nb16, D * Hp * Wp, 16), device=dev, dtype=torch.bfloat16)
+        check(lib.mvsnerf_planesweep_costvar_bf16_fwd(feats_cl.data_ptr(), imgs_cl_p, dev_f32(proj, "proj_mats"), dev_f32(depth, "depth_values"),
+                                                      V, C, H, W, D, pad, cost.data_ptr(), CP, masks.data_ptr(), int(with_img), stream_ptr()),
+              "planesweep_costvar_bf16_fwd")
+        return _BlockedCost16(cost, n_ch, nb16 * 16, (D, Hp, Wp)), masks.unsqueeze(0), (feats_cl, proj, depth, (V, C, H, W, D, pad, CP, n_ch))
     if blocked:
         cost = torch.empty((CP // 4, D * Hp * Wp, 4), device=dev, dtype=torch.float32)
         check(lib.mvsnerf_planesweep_costvar_blocked_fwd(feats_cl.data_ptr(), imgs_cl_p, dev_f32(proj, "proj_mats"), dev_f32(depth, "depth_values"),
@@ -905,7 +977,7 @@ class _SweepRegFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feats, imgs, proj_mats, depth_values, pad, net, *params):
-        cost, _, saved = _plane_sweep(imgs, feats, proj_mats, depth_values, pad, True, blocked=True)
+        cost, _, saved = _plane_sweep(imgs, feats, proj_mats, depth_values, pad, True, blocked="bf16" if ENCODER_PRECISION == "bf16" else True)
         _, lz = net._run(cost)
         ctx.net, ctx.cost, ctx.lz, ctx.saved = net, cost, lz, saved
         return _cl_view_to_ncdhw(_apply_add(lz[0], lz[9]))
@@ -924,6 +996,15 @@ class _SweepRegFunction(torch.autograd.Function):
         def conv0_grads(gx):
             gw = torch.empty(tuple(lay.conv.weight.shape), device=gx.device, dtype=torch.float32)
             ws = torch.empty(lib.mvsnerf_conv3d_wgrad_workspace_floats(8, pk.cin), device=gx.device, dtype=torch.float32)
+            if isinstance(cost, _BlockedCost16):          # use_amp: both conv0 gradients on the bf16 matrix cores (gx is rounded on the way in)
+                check(lib.mvsnerf_conv0_bf16_wgrad(cost.buf.data_ptr(), pk.cin, Dv, Hv, Wv, gx.data_ptr(), 0, ws.data_ptr(), stream_ptr()), "conv0_bf16_wgrad")
+                sums.add(ws, lib.mvsnerf_conv0_bf16_wgrad_parts(Dv, Hv, Wv), gw)
+                if not ctx.needs_input_grad[0]:
+                    return gw, None
+                g_var = torch.empty((Dv, Hv, Wv, C), device=gx.device, dtype=torch.float32)
+                check(lib.mvsnerf_conv0_bf16_dgrad(gx.data_ptr(), Dv, Hv, Wv, pk.get_bf16_conv0(dgrad=(3 * V, C)).data_ptr(), C, g_var.data_ptr(),
+                                                   stream_ptr()), "conv0_bf16_dgrad")
+                return gw, g_var
             check(lib.mvsnerf_conv3d_c8_blocked_wgrad(cost.buf.data_ptr(), pk.cin_pad, pk.cin, Dv, Hv, Wv, gx.data_ptr(), 0,
                                                       ws.data_ptr(), stream_ptr()), "conv3d_c8_blocked_wgrad")
             sums.add(ws, lib.mvsnerf_conv3d_c8_blocked_wgrad_parts(pk.cin_pad, pk.cin, Dv, Hv, Wv), gw)
@@ -1012,7 +1093,7 @@ class MVSNet(nn.Module):
                 and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.cost_reg_2.parameters()))
                 and (32 + 3 * V + 3) // 4 * 4 in _BLOCKED_CIN)
         if fast:
-            cost, _ = self._sweep(imgs, feats_l, proj_mats, depth_values, pad, True, blocked=True)
+            cost, _ = self._sweep(imgs, feats_l, proj_mats, depth_values, pad, True, blocked="bf16" if ENCODER_PRECISION == "bf16" else True)
             return self.cost_reg_2(cost), feats_l, depth_values
         if BLOCKED_COST and not return_color and torch.is_grad_enabled() and (32 + 3 * V + 3) // 4 * 4 in _BLOCKED_CIN and B == 1:
             # training: the same blocked hand-off inside one autograd node

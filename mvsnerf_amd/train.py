@@ -22,8 +22,10 @@ Nothing here has run on more than one GPU (the dev boxes have one): every multi-
 tests, UNMEASURED on hardware.
 
 `args.use_amp` (the reference's `precision=16 if args.use_amp`, train_mvs_nerf_pl.py:317-318; BASELINE config 3 "bf16"): the ray-march MLP
-trains on v_mfma_f32_32x32x16_bf16 - forward with activation store, data- and weight-gradient GEMMs - with fp32 accumulation, fp32
-master weights and an fp32 gradient all-reduce.  The encoder (FeatureNet, plane sweep, CostRegNet) has fp32 kernels only.
+trains on v_mfma_f32_32x32x16_bf16 - forward with activation store, data- and weight-gradient GEMMs - and conv0 of CostRegNet (74.5 % of
+the encoder's FLOPs) on v_mfma_f32_16x16x32_bf16 from a bf16 cost volume (forward, data and weight gradient: csrc/conv_bf16.hip), with fp32
+accumulation, fp32 master weights and an fp32 gradient all-reduce.  FeatureNet, the plane sweep's arithmetic, InPlaceABN and the other
+nine 3-D layers keep their fp32 kernels.
 """
 import os
 
@@ -147,7 +149,9 @@ class MVSSystem(_ModuleShim):
         near_fars, depths_h = data_mvs["near_fars"], data_mvs["depths_h"]
 
         nv = self.n_views
-        volume_feature, _, _ = self.MVSNet(imgs[:, :nv], proj_mats[:, :nv], near_fars[0, 0], pad=args.pad)      # :113
+        from . import encoder as _enc
+        with _enc.encoder_precision("bf16" if getattr(args, "use_amp", False) else _enc.ENCODER_PRECISION):   # :317-318 precision=16: conv0 on bf16
+            volume_feature, _, _ = self.MVSNet(imgs[:, :nv], proj_mats[:, :nv], near_fars[0, 0], pad=args.pad)      # :113
         imgs = self.unpreprocess(imgs)
         N_rays, N_samples = args.batch_size, args.N_samples
         rays_pts, rays_dir, target_s, rays_NDC, depth_candidates, rays_o, rays_depth, _ = build_rays(

@@ -1,0 +1,165 @@
+"""bf16 encoder kernels (csrc/conv_bf16.hip; the reference's `precision=16 if args.use_amp`, train_mvs_nerf_pl.py:317-318): each kernel
+against a torch emulation of exactly its rounding - operands rounded to bf16 (round to nearest even), products and sums in fp32/float64."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _sweep_inputs(V, H, W, D, pad, seed):
+    from mvsnerf_amd.synth import make_rig
+    base = (0.0, 0.25, -0.25, 0.12, -0.12, 0.1)
+    rig = make_rig(H * 4, W * 4, n_views=V + 1, seed=seed, baselines=base[:V + 1], rot_deg=2.0, smooth=True)
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn((1, V, 32, H, W), generator=g) * 2
+    return rig["images"][:, :V].to(DEV), feats.to(DEV), rig["proj_mats"][:, :V].to(DEV), torch.linspace(2.1, 4.5, D)[None].to(DEV)
+
+
+@pytest.mark.parametrize("V,H,W,D,pad", [(3, 16, 24, 8, 4), (5, 12, 20, 16, 2), (3, 128, 160, 128, 24)])
+def test_planesweep_bf16_store_is_the_rounded_fp32_volume(V, H, W, D, pad):
+    """mvsnerf_planesweep_costvar_bf16_fwd = the fp32 sweep, each value rounded to bf16 (RNE), in channel blocks of sixteen."""
+    from mvsnerf_amd import encoder as E
+    imgs, feats, proj, dv = _sweep_inputs(V, H, W, D, pad, seed=V * 10 + D)
+    with torch.no_grad():
+        cost32, masks32, _ = E._plane_sweep(imgs, feats, proj, dv, pad, True)
+        cost16, masks16, _ = E._plane_sweep(imgs, feats, proj, dv, pad, True, blocked="bf16")
+    assert torch.equal(masks32, masks16)
+    n_ch = 3 * V + 32
+    nb = (n_ch + 15) // 16
+    Dp, Hp, Wp = cost16.dims
+    assert cost16.buf.dtype == torch.bfloat16 and tuple(cost16.buf.shape) == (nb, Dp * Hp * Wp, 16)
+    ref = torch.zeros((nb * 16, Dp * Hp * Wp), device=DEV)
+    ref[:n_ch] = cost32[0].reshape(n_ch, -1)
+    ref = ref.reshape(nb, 16, -1).permute(0, 2, 1).to(torch.bfloat16)
+    assert torch.equal(cost16.buf, ref)
+
+
+@pytest.mark.parametrize("cin,dims", [(41, (8, 16, 32)), (47, (5, 9, 17)), (32, (4, 8, 16)), (41, (128, 176, 208))])
+def test_conv0_bf16_forward_and_dgrad_vs_emulation(cin, dims):
+    """conv0 on v_mfma_f32_16x16x32_bf16 (forward with its InPlaceABN partial sums; data gradient of the 32 variance channels) against
+    float64 convolutions of the bf16-rounded operands.  The last case is the training shape (timed)."""
+    import torch.nn.functional as F
+    from mvsnerf_amd import _lib
+    from mvsnerf_amd.ops import stream_ptr
+    L = _lib.lib()
+    D, H, W = dims
+    g = torch.Generator(DEV).manual_seed(cin + D)
+    nb = (cin + 15) // 16
+    x = torch.randn((nb * 16, D, H, W), device=DEV, generator=g)
+    x[cin:] = 0
+    w = torch.randn((8, cin, 3, 3, 3), device=DEV, generator=g) * 0.1
+    x16 = x.reshape(nb, 16, -1).permute(0, 2, 1).contiguous().to(torch.bfloat16)
+    pk = torch.empty(L.mvsnerf_conv0_bf16_packed_elems(cin), device=DEV, dtype=torch.bfloat16)
+    assert L.mvsnerf_conv0_bf16_pack(w.data_ptr(), cin, pk.data_ptr(), stream_ptr()) == 0
+    out = torch.full((D, H, W, 8), float("nan"), device=DEV)
+    ntile = L.mvsnerf_conv0_bf16_tiles(D, H, W)
+    part = torch.empty(ntile * 16, device=DEV)
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        assert L.mvsnerf_conv0_bf16_fwd(x16.data_ptr(), cin, D, H, W, pk.data_ptr(), out.data_ptr(), part.data_ptr(), stream_ptr()) == 0
+        e1.record(); torch.cuda.synchronize()
+    ms_f = e0.elapsed_time(e1)
+    big = D * H * W > 1_000_000
+    xr, wr = _bf(x[:cin]), _bf(w)
+    dt = torch.float32 if big else torch.float64            # the full-size reference in fp32 (MIOpen), the small ones in float64
+    ref = F.conv3d(xr[None].to(dt), wr.to(dt), padding=1)[0].permute(1, 2, 3, 0)
+    scale = float(ref.abs().max())
+    err = float((out.double() - ref.double()).abs().max())
+    print(f"[conv0 bf16 fwd cin={cin} {D}x{H}x{W}] {ms_f:.3f} ms; max err vs emulation {err:.2e} (|out| max {scale:.1f})")
+    assert torch.isfinite(out).all() and err < (2e-5 if big else 3e-6) * scale
+    # InPlaceABN partial sums of the tiles
+    s = part.view(ntile, 2, 8).double().sum(0)
+    assert float((s[0] - out.double().sum((0, 1, 2))).abs().max()) < 1e-6 * float(out.double().abs().sum((0, 1, 2)).max())
+    assert float((s[1] - (out.double() ** 2).sum((0, 1, 2))).abs().max()) < 1e-6 * float((out.double() ** 2).sum((0, 1, 2)).max())
+    # ---- data gradient of the last 32 input channels (the variance channels)
+    if cin >= 32:
+        c_first = cin - 32
+        gout = torch.randn((D, H, W, 8), device=DEV, generator=g)
+        pd = torch.empty(L.mvsnerf_conv0_bf16_dgrad_packed_elems(32), device=DEV, dtype=torch.bfloat16)
+        assert L.mvsnerf_conv0_bf16_dgrad_pack(w.data_ptr(), cin, c_first, 32, pd.data_ptr(), stream_ptr()) == 0
+        gx = torch.full((D, H, W, 32), float("nan"), device=DEV)
+        for rep in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            assert L.mvsnerf_conv0_bf16_dgrad(gout.data_ptr(), D, H, W, pd.data_ptr(), 32, gx.data_ptr(), stream_ptr()) == 0
+            e1.record(); torch.cuda.synchronize()
+        ms_d = e0.elapsed_time(e1)
+        gr = _bf(gout).permute(3, 0, 1, 2)[None].to(dt)
+        refg = F.conv_transpose3d(gr, wr[:, c_first:].to(dt), padding=1)[0].permute(1, 2, 3, 0)
+        scale = float(refg.abs().max())
+        err = float((gx.double() - refg.double()).abs().max())
+        print(f"[conv0 bf16 dgrad cin={cin} {D}x{H}x{W}] {ms_d:.3f} ms; max err vs emulation {err:.2e} (|gx| max {scale:.1f})")
+        assert torch.isfinite(gx).all() and err < (2e-5 if big else 3e-6) * scale
+
+
+@pytest.mark.parametrize("cin,dims", [(41, (8, 12, 64)), (47, (5, 7, 33)), (32, (4, 6, 32)), (41, (3, 5, 9)), (41, (128, 176, 208))])
+def test_conv0_bf16_wgrad_vs_emulation(cin, dims):
+    """conv0's weight gradient on v_mfma_f32_16x16x32_bf16 with both operands transposed by the LDS read (ds_read_b64_tr_b16) against the
+    float64 definition on the bf16-rounded operands: gw[co][ci][tap] = sum_v g[v][co] x[v + tap - 1][ci].  Deterministic (run twice)."""
+    import torch.nn.functional as F
+    from mvsnerf_amd import _lib
+    from mvsnerf_amd.ops import stream_ptr
+    L = _lib.lib()
+    D, H, W = dims
+    gen = torch.Generator(DEV).manual_seed(cin * 7 + D)
+    nb = (cin + 15) // 16
+    x = torch.randn((nb * 16, D, H, W), device=DEV, generator=gen)
+    x[cin:] = 0
+    g = torch.randn((D, H, W, 8), device=DEV, generator=gen) * 0.1
+    x16 = x.reshape(nb, 16, -1).permute(0, 2, 1).contiguous().to(torch.bfloat16)
+    ws = torch.empty(L.mvsnerf_conv3d_wgrad_workspace_floats(8, cin), device=DEV)
+    outs = []
+    for rep in range(3):
+        gw = torch.full((8, cin, 3, 3, 3), float("nan"), device=DEV)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        assert L.mvsnerf_conv0_bf16_wgrad(x16.data_ptr(), cin, D, H, W, g.data_ptr(), gw.data_ptr(), ws.data_ptr(), stream_ptr()) == 0
+        e1.record(); torch.cuda.synchronize()
+        outs.append(gw)
+    ms = e0.elapsed_time(e1)
+    assert torch.equal(outs[1], outs[2])
+    xr = _bf(x[:cin]).double().permute(1, 2, 3, 0)                    # (D,H,W,cin)
+    gr = _bf(g).double().reshape(-1, 8)
+    xp = F.pad(xr, (0, 0, 1, 1, 1, 1, 1, 1))
+    ref = torch.empty((8, cin, 3, 3, 3), dtype=torch.float64, device=DEV)
+    for dz in range(3):
+        for dy in range(3):
+            for dx in range(3):
+                ref[:, :, dz, dy, dx] = gr.t() @ xp[dz:dz + D, dy:dy + H, dx:dx + W].reshape(-1, cin)
+    scale, err = float(ref.abs().max()), float((outs[2].double() - ref).abs().max())
+    print(f"[conv0 bf16 wgrad cin={cin} {D}x{H}x{W}] {ms:.3f} ms; max err vs emulation {err:.2e} (|gw| max {scale:.1f})")
+    assert torch.isfinite(outs[2]).all() and err < 1e-5 * scale
+
+
+def test_training_node_bf16_vs_fp32_gradients():
+    """The plane sweep -> CostRegNet autograd node with encoder_precision('bf16') (conv0 forward / dgrad / wgrad on bf16 operands) against
+    the fp32 node on the same inputs: same structure, results within bf16 operand rounding; parameters and gradients stay fp32."""
+    from mvsnerf_amd import encoder as E, models
+    from tests.util import load_weights
+    _, mvs_sd = load_weights()
+    V, H, W, D, pad = 3, 16, 24, 16, 4
+    imgs, feats, proj, dv = _sweep_inputs(V, H, W, D, pad, seed=9)
+    res = {}
+    for prec in ("fp32", "bf16"):
+        net = models.MVSNet()
+        net.load_state_dict(mvs_sd)
+        net = net.to(DEV).train()
+        f = feats.clone().requires_grad_(True)
+        with E.encoder_precision(prec):
+            vol = E._SweepRegFunction.apply(f, imgs, proj, dv, pad, net.cost_reg_2, *E._costreg_params(net.cost_reg_2))
+            gen = torch.Generator(DEV).manual_seed(1)
+            (vol * torch.randn(vol.shape, device=DEV, generator=gen)).sum().backward()
+        assert all(p.grad is None or p.grad.dtype == torch.float32 for p in net.parameters())
+        res[prec] = (vol.detach(), f.grad.detach(), {n: p.grad.detach() for n, p in net.cost_reg_2.named_parameters()})
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-12))
+    e_vol, e_gf = rel(res["bf16"][0], res["fp32"][0]), rel(res["bf16"][1], res["fp32"][1])
+    e_gw = {n: rel(res["bf16"][2][n], res["fp32"][2][n]) for n in res["fp32"][2]}
+    worst = max(e_gw, key=e_gw.get)
+    print(f"bf16 training node vs fp32: volume {e_vol:.2e}, d feats {e_gf:.2e}, worst weight gradient {e_gw[worst]:.2e} ({worst})")
+    assert 0 < e_vol < 5e-2 and e_gf < 0.15 and e_gw[worst] < 0.15

@@ -152,7 +152,7 @@ def test_config2_vs_oracle(net):
     errs = {}
     for a, b, k in [(rgb, ref[0], "rgb"), (feat, ref[1], "input_feat"), (w, ref[2], "weights"), (depth, ref[3], "depth"),
                     (alpha, ref[4], "alpha"), (raw[..., :3], ref[6][..., :3], "raw_rgb"), (raw[..., 3], ref[6][..., 3], "sigma")]:
-        ok, e = close(a, b)
+        ok, e = close(a, b, 0.0 if k == "input_feat" else 3e-5, 0.0 if k == "input_feat" else 2e-6)   # random volume (|v| <= 5, sigma <= 20): measured 9.5e-6 on raw rgb / sigma
         errs[k] = e
         assert ok, f"{k}: max abs err {e}"
     mse = float(((rgb.cpu() - ref[0]) ** 2).mean())
