@@ -37,20 +37,39 @@ VOL_BYTES_PER_SAMPLE = 300        # 8 corners x 32 B + 12 B coord + 32 B out
 COL_BYTES_PER_SAMPLE = 204        # 3 views x 48 B + 12 B + 48 B out
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = "profiles/r02_pmc_summary.json"
+PMC_FILE = "profiles/r03_pmc_summary.json"
+
+
+def csrc_sha16():
+    """Hash of the kernel sources: the committed PMC summary carries the hash of the tree it was measured on (`_csrc_sha16`), and
+    `traffic` is reported only while it still matches - a kernel change can no longer keep an old traffic number alive silently."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mvsnerf_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _pmc_summary():
+    try:
+        d = json.load(open(os.path.join(ROOT, PMC_FILE)))
+    except Exception:
+        return {}, "no PMC summary committed"
+    if d.get("_csrc_sha16") != csrc_sha16():
+        return {}, f"{PMC_FILE} was measured on other kernel sources (csrc hash {d.get('_csrc_sha16')} != {csrc_sha16()}): traffic withheld as stale"
+    return d, PMC_FILE + " (rocprofv3 --pmc passes of this command on these kernel sources, committed; not re-measured in this run)"
 
 
 def _load_pmc_traffic():
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE collected in
     separate --pmc passes over this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950's
     16-B/lane reads; counters are in KiB).  bench.py cannot run rocprof on itself, so `traffic` cites that measurement."""
-    try:
-        d = json.load(open(os.path.join(ROOT, PMC_FILE)))
-    except Exception:
-        return {}
+    d, _ = _pmc_summary()
     out = {}
     for k, v in d.items():
-        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        if isinstance(v, dict) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             out[k] = int((2 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * 1024)
     return out
 
@@ -58,12 +77,9 @@ def _load_pmc_traffic():
 def pmc_mfma_busy_frac(kernel_prefix):
     """Fraction of the kernel's duration the matrix pipes were busy, from the committed PMC passes:
     (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs)."""
-    try:
-        d = json.load(open(os.path.join(ROOT, PMC_FILE)))
-    except Exception:
-        return None
+    d, _ = _pmc_summary()
     for k, v in d.items():
-        if k.startswith(kernel_prefix) and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
+        if isinstance(v, dict) and k.startswith(kernel_prefix) and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
             return round((v["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / 1024.0) / (v["GRBM_GUI_ACTIVE"]["mean"] / 8.0), 4)
     return None
 
@@ -232,7 +248,27 @@ def multi_gpu_legs(dev, rank, world, train_steps=5):
        train_step_dp        MVSSystem.fit_steps: training_step + backward + ONE flat-buffer all-reduce + Adam, in both DP modes."""
     import torch.distributed as dist
     from mvsnerf_amd import distributed as D, train
-    out = {}
+    out = {"world_size": world, "backend": (dist.get_backend() if world > 1 else None),
+           "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+           "gpus_visible": torch.cuda.device_count(), "device": torch.cuda.get_device_name(dev),
+           "measured_on_hardware": world > 1,
+           "note": "every number in this object is measured in THIS run; with world_size 1 the collectives are skipped (identity) and nothing here "
+                   "says anything about multi-GPU scaling"}
+    # ---- (o) the gradient exchange alone: the flat fp32 all-reduce of all 78 gradient tensors (what every DP step adds)
+    if world > 1:
+        system = load_system(dev)
+        n_flat = sum(p.numel() for p in system.grad_vars)
+        flat = torch.zeros(n_flat, device=dev)
+        for _ in range(5):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize()
+        out["grad_allreduce"] = {"bytes": n_flat * 4, "us_per_allreduce": round((time.perf_counter() - t0) / 50 * 1e6, 1), "n_ranks": world,
+                                 "note": "dist.all_reduce of one flat fp32 buffer (RCCL over xGMI), 50 back-to-back calls"}
+        del system, flat
     # ---- (i) tile-parallel frame
     system = load_system(dev)
     batch = train.batch_to_device(train.synthetic_batch(H_IMG, W_IMG, seed=1234), dev)      # inputs resident in HBM before any timed region
@@ -249,7 +285,7 @@ def multi_gpu_legs(dev, rank, world, train_steps=5):
                                           "sub-batches per rank, one all_gather of (rgb, depth); strong scaling of the ray part only"}
     del system
     # ---- (ii) data-parallel training step, both modes
-    for mode, amp in (("ray", False), ("scene", False), ("ray", True)):      # the last one = BASELINE config 3: bf16 MLP, ray-sharded DP
+    for mode, amp in (("scene", False), ("scene", True), ("ray", False), ("ray", True)):      # scene = the default DP mode; ("ray", True) = BASELINE config 3 as worded
         system = load_system(dev, dp_mode=mode, use_amp=amp)
         opt = system.configure_optimizers()[0][0]
         torch.manual_seed(0)
@@ -270,7 +306,7 @@ def multi_gpu_legs(dev, rank, world, train_steps=5):
         if not in_sync:
             raise SystemExit(f"rank {rank}: parameters diverged across ranks after {mode}-sharded steps")
         rays = N_RAYS * (world if mode == "scene" else 1)
-        out[f"train_step_dp_{mode}" + ("_bf16" if amp else "")] = {"ms": round(dt / train_steps * 1e3, 2), "mlp_arithmetic": "bf16 MFMA, fp32 accumulate / master weights / gradients" if amp else "fp32 MFMA", "rays_per_s": round(rays * train_steps / dt, 1), "n_ranks": world,
+        out[f"train_step_dp_{mode}" + ("_bf16" if amp else "")] = {"ms": round(dt / train_steps * 1e3, 2), "arithmetic": "use_amp: MLP and conv0 on bf16 MFMA, fp32 accumulate / master weights / gradients" if amp else "fp32 MFMA", "rays_per_s": round(rays * train_steps / dt, 1), "n_ranks": world,
                                         "global_rays_per_step": rays, "params_in_sync": in_sync, "loss_last_rank0": round(losses[-1], 5),
                                         "scaling": "strong (same 1024-ray step, encoder replicated)" if mode == "ray" else "weak (one scene + 1024 rays per rank)",
                                         "note": "fit_steps: training_step fwd+bwd (HIP) + one flat fp32 all-reduce of all gradients (RCCL) + Adam"}
@@ -416,7 +452,7 @@ def main():
         tf = FLOP_PER_SAMPLE * P / (t_mlp * 1e-3) / 1e12
         roof = {"kernel": "mlp_fwd_pipe_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic("mlp_fwd_pipe_kernel"),
-                "traffic_source": PMC_FILE + " (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)",
+                "traffic_source": _pmc_summary()[1],
                 "avg_launch_ms": round(t_mlp, 4),
                 "mfma_pipe_busy_frac_pmc": pmc_mfma_busy_frac("mlp_fwd_pipe_kernel"),
                 "s_memtime_ghz": round(clock, 3),

@@ -27,8 +27,11 @@ __device__ __forceinline__ void dma16_gather_b(const void* lane_ptr, unsigned ld
 
 // ------------------------------------------------------------------------------------------------------------------ forward
 // Workgroup = 4 waves = 4 x 8 x 16 output voxels (z, y, x); wave w owns plane z0 + w, M-tile t = row y0 + t (16 x).
-// Per 16-channel block (chunk) the (6 x 10 x 18)-voxel halo is DMA'd into LDS as [voxel][32 B] (34 pieces of 1 KB; two buffers: chunk
-// c+1 lands while chunk c is multiplied).  K = 32 of one MFMA = two (dz, dx) taps x 16 channels: fragment f = 0..4 pairs the (dz, dx)
+// Per 16-channel block (chunk) the (6 x 10 x 18)-voxel halo is DMA'd into LDS as [voxel][32 B] (34 pieces of 1 KB) together with the
+// chunk's 7.5 KB of weight fragments.  ONE 43 KB buffer per workgroup and three workgroups per CU: a chunk is issue -> wait -> barrier ->
+// 120 MFMAs per wave -> barrier, and it is the other two workgroups' MFMAs that cover the DMA round trip.  (First version: two buffers per
+// workgroup with chunk c+1 in flight during chunk c - 86 KB, i.e. ONE workgroup of four waves per CU: 0.42 ms, every chunk waiting ~4 us for
+// its DMA with nothing else resident to run.)  K = 32 of one MFMA = two (dz, dx) taps x 16 channels: fragment f = 0..4 pairs the (dz, dx)
 // combinations p = 2f, 2f+1 (p = 3 dz + dx; p = 9 does not exist: zero weights).  For a fixed f the A fragment of INPUT row j serves
 // the three dy taps of the M-tiles t = j - dy: 10 operand reads + 3 weight reads per 24 MFMAs.
 constexpr int BTX = 16, BTY = 8, BTZ = 4;
@@ -39,9 +42,9 @@ constexpr int BT_BYTES = BT_PIECES * 1024;
 constexpr int BT_SLOTS = (BT_PIECES + 3) / 4;                   // 9 per wave
 constexpr int BW_BYTES = 5 * 3 * 4 * 8 * 16;                    // weights of a chunk: [f][dy][kg][co 8][8 ci] bf16 = 7680 B
 constexpr int BW_PIECES = (BW_BYTES + 1023) / 1024;             // 8
-constexpr int BBUF = BT_BYTES + BW_PIECES * 1024;               // 43008 B per buffer, two of them
+constexpr int BBUF = BT_BYTES + BW_PIECES * 1024;               // 43008 B
 
-__global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_bf16_kernel(const __bf16* __restrict__ x16, int nblk16, int D, int H, int W,
+__global__ __launch_bounds__(256, 3) void conv3d_k3s1_c8_bf16_kernel(const __bf16* __restrict__ x16, int nblk16, int D, int H, int W,
                                                                     const __bf16* __restrict__ wq, float* __restrict__ out,
                                                                     float* __restrict__ stats)
 {
@@ -82,13 +85,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_bf16_kernel(const __bf1
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = f32x4{0, 0, 0, 0};
     const int m = lane & 15, kg = lane >> 4;
-    issue(0, lds);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 #pragma unroll 1
     for (int c = 0; c < nblk16; ++c) {
-        char* cur = lds + (c & 1) * BBUF;
-        if (c + 1 < nblk16) issue(c + 1, lds + ((c + 1) & 1) * BBUF);
+        char* cur = lds;
+        issue(c, cur);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMA pieces have landed ...
+        __syncthreads();                                          // ... everybody's have
         const char* wt = cur + BT_BYTES + (kg * 8 + (m & 7)) * 16;          // columns 8..15 repeat 0..7 (their results are never stored)
 #pragma unroll
         for (int f = 0; f < 5; ++f) {
@@ -108,8 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_bf16_kernel(const __bf1
                     if (t >= 0 && t < 8) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[j], bw[dy], acc[t], 0, 0, 0);
                 }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMA pieces have landed ...
-        __syncthreads();                                          // ... everybody's have, and everybody is done reading `cur`
+        __syncthreads();                                          // everybody is done reading the buffer
     }
     // D: lane (col n = lane & 15 = output channel when < 8, g = lane >> 4): register r = voxel x 4 g + r of the M-tile
     const int n = lane & 15, g4 = lane >> 4;
@@ -185,8 +186,8 @@ extern "C" int mvsnerf_conv0_bf16_fwd(const void* x16, int Cin, int D, int H, in
     if (!mvs_aligned16(x16) || !mvs_aligned16(packed)) return MVSNERF_EALIGN;
     if ((int64_t)D * H * W * 32 >= ((int64_t)1 << 31)) return MVSNERF_EUNSUPPORTED;
     static unsigned long long cap_mask = 0;
-    if (int rc = mvs_raise_lds_cap(reinterpret_cast<const void*>(conv3d_k3s1_c8_bf16_kernel), 2 * BBUF, &cap_mask)) return rc;
-    conv3d_k3s1_c8_bf16_kernel<<<mvsnerf_conv0_bf16_tiles(D, H, W), 256, 2 * BBUF, (hipStream_t)stream>>>(
+    if (int rc = mvs_raise_lds_cap(reinterpret_cast<const void*>(conv3d_k3s1_c8_bf16_kernel), BBUF, &cap_mask)) return rc;
+    conv3d_k3s1_c8_bf16_kernel<<<mvsnerf_conv0_bf16_tiles(D, H, W), 256, BBUF, (hipStream_t)stream>>>(
         reinterpret_cast<const __bf16*>(x16), (Cin + 15) / 16, D, H, W, reinterpret_cast<const __bf16*>(packed), out, stats_part);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;

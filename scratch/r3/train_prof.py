@@ -1,0 +1,20 @@
+"""One generalizable-training run at config-3 shapes for rocprofv3 (2 warm-up + N timed steps).  usage: train_prof.py [amp] [steps]"""
+import sys, time, torch, os
+sys.path.insert(0, '.')
+import numpy as np
+from mvsnerf_amd import train
+amp = len(sys.argv) > 1 and sys.argv[1] == "amp"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = 'cuda'
+args = train.default_args(pad=24, batch_size=1024, N_samples=128, chunk=1024, use_amp=amp)
+system = train.MVSSystem(args).to(dev)
+z = np.load('tests/golden/mvsnerf_v0_weights.npz')
+system.render_kwargs_train["network_fn"].load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("mlp/")})
+system.MVSNet.load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("mvs/")})
+batch = train.batch_to_device(train.synthetic_batch(512, 640, seed=1234), dev)
+opt = system.configure_optimizers()[0][0]
+torch.manual_seed(0)
+system.fit_steps([batch] * 2, opt)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+system.fit_steps([batch] * steps, opt)
+torch.cuda.synchronize(); print("train step ms (%s)" % ("use_amp" if amp else "fp32"), (time.perf_counter() - t0) / steps * 1e3)
