@@ -360,9 +360,17 @@ def main():
         enc_ready = True
     except ImportError:
         enc_ready = False
+    encode_ms_bf16 = None
     if enc_ready:
         vol, encode_ms = encoder.bench_encode(rig, dev, PAD)
         volume_src = "mvsnet-encode"
+        if not a.no_extras:
+            # opt-in (NOT the headline volume, which stays fp32): the encoder with conv0 on the bf16 matrix cores from a bf16 cost volume
+            with encoder.encoder_precision("bf16"):
+                vol_b, encode_ms_bf16 = encoder.bench_encode(rig, dev, PAD)
+            encode_ms_bf16["max_abs_volume_diff_vs_fp32_encode"] = float((vol_b - vol).abs().max())
+            encode_ms_bf16["volume_abs_max"] = float(vol.abs().max())
+            del vol_b
     else:
         vol = torch.randn((1, 8, D_PLANES, h, w), generator=torch.Generator().manual_seed(5)).to(dev)
         vol = vol.contiguous(memory_format=torch.channels_last_3d)
@@ -638,7 +646,7 @@ def main():
                        "weights": "mvsnerf-v0 checkpoint", "volume": volume_src, "rays_per_step_per_gpu": N_RAYS,
                        "parallelism": f"ray-sharded x{world}, no data-path collective",
                        "clock_settle_ms": a.settle_ms},
-            "encode_ms": encode_ms,
+            "encode_ms": encode_ms, "encode_ms_bf16_conv0": encode_ms_bf16,
             "roofline": roof, "rooflines": roofs, "cpu_baseline": cpu, "multi_gpu": multi, "extras": extras,
         }))
     if world > 1:

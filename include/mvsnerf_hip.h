@@ -228,6 +228,12 @@ int mvsnerf_conv2d_pack_weights(const float* w, int ci_real, int co_real, int ci
 int mvsnerf_conv2d_fwd(const float* x, const float* scale, const float* shift, int Cin, int cin_ld,
                        int N, int H, int W, const float* wpacked, const float* bias, int Cout,
                        int ksize, int stride, float* out, void* stream);
+/* The 16- / 32-output-channel layers (conv1.x, conv2.x, and the stride-1 data gradients) run on the fp32 matrix cores inside
+ * mvsnerf_conv2d_fwd.  conv2d_fwd_stats is that launch + the InPlaceABN partial sums of the raw output (stats_part[tiles][2][Cout] for
+ * mvsnerf_abn_finalize; conv2d_mfma_tiles(...) rows, 0 = the layer has no matrix-core kernel -> MVSNERF_EUNSUPPORTED). */
+int mvsnerf_conv2d_mfma_tiles(int Cin, int Cout, int N, int H, int W, int ksize, int stride);
+int mvsnerf_conv2d_fwd_stats(const float* x, const float* scale, const float* shift, int Cin, int cin_ld, int N, int H, int W,
+                             const float* wpacked, int Cout, int ksize, int stride, float* out, float* stats_part, void* stream);
 int mvsnerf_conv2d_dgrad_k5s2(const float* g, int Cin, int N, int Ho, int Wo, const float* wpacked, int Cout,
                               int Hi, int Wi, float* out, void* stream);
 size_t mvsnerf_conv2d_wgrad_workspace_floats(int A, int B, int ksize);

@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
     extern __shared__ __attribute__((aligned(16))) float lds_[];
     const int GS = (V - 1) * 8 + 2;                              // per voxel: per source view {w_nw,w_ne,w_sw,w_se, t_nw,t_ne,t_sw,t_se}; then {1/count, ref pixel}
     float* geo = lds_;                                           // [VPB][GS]
-    float* stage = lds_ + ((VPB * GS + 3) & ~3);                 // [VPP][CP+4]: +4 floats per row breaks the bank stride
+    const int RS = blocked == 2 ? ((CP + 15) & ~15) + 4 : CP + 4;  // staging row: +4 floats break the bank stride; bf16 mode stages whole 16-channel blocks
+    float* stage = lds_ + ((VPB * GS + 3) & ~3);                 // [VPP][RS]
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const int64_t nvox = (int64_t)D * Hp * Wp;
     const int64_t v0 = (int64_t)blockIdx.x * VPB;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
     // ---- phase 2
     const int q = threadIdx.x & 3, vloc = threadIdx.x >> 2;
     const int c_var = with_img ? 3 * V : 0;
-    float* o = stage + vloc * (CP + 4);
+    float* o = stage + vloc * RS;
     for (int pass = 0; pass < VPB / VPP; ++pass) {
         const int vb = pass * VPP + vloc;
         const int64_t i_raw = v0 + vb;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
             o[c_var + c] = s2[j] * inv - mean * mean;                // :890
         }
         if (q == 0)
-            for (int c = c_var + C; c < CP; ++c) o[c] = 0.0f;
+            for (int c = c_var + C; c < RS - 4; ++c) o[c] = 0.0f;
         // flush this pass's 64 consecutive voxels (one contiguous CP*64*4-byte span of the cost volume) with coalesced 16-byte stores
         __syncthreads();
         {
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
                 f32x4* dst = reinterpret_cast<f32x4*>(cost + p0 * CP);
                 for (int k = threadIdx.x; k < n4; k += 256) {
                     const int vox = (k * 4) / CP, c = (k * 4) - vox * CP;
-                    dst[k] = *reinterpret_cast<const f32x4*>(stage + vox * (CP + 4) + c);
+                    dst[k] = *reinterpret_cast<const f32x4*>(stage + vox * RS + c);
                 }
             } else if (blocked == 2) {
                 // bf16 (round to nearest even), blocks of sixteen channels: the two 16-byte halves of a voxel's block, voxels consecutive
@@ -228,10 +229,10 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
                 const int nb16 = (CP + 15) >> 4, per = (int)nv * 2, n_k = per * nb16;
                 for (int k = threadIdx.x; k < n_k; k += 256) {
                     const int cb = k / per, rem = k - cb * per, vox = rem >> 1, c0 = cb * 16 + (rem & 1) * 8;
-                    const float* srow = stage + vox * (CP + 4);
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + vox * RS + c0), hi = *reinterpret_cast<const f32x4*>(stage + vox * RS + c0 + 4);
                     bf16x8_t h;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) h[e] = (__bf16)(c0 + e < CP ? srow[c0 + e] : 0.0f);
+                    for (int e = 0; e < 4; ++e) { h[e] = (__bf16)lo[e]; h[4 + e] = (__bf16)hi[e]; }
                     *reinterpret_cast<bf16x8_t*>(cost16 + (((int64_t)cb * nvox + p0 + vox) << 4) + (rem & 1) * 8) = h;
                 }
             } else {
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
                 for (int k = threadIdx.x; k < n_k; k += 256) {
                     const int cb = k / (int)nv, vox = k - cb * (int)nv;
                     *reinterpret_cast<f32x4*>(cost + (((int64_t)cb * nvox + p0 + vox) << 2)) =
-                        *reinterpret_cast<const f32x4*>(stage + vox * (CP + 4) + cb * 4);
+                        *reinterpret_cast<const f32x4*>(stage + vox * RS + cb * 4);
                 }
             }
         }
@@ -286,7 +287,7 @@ static int planesweep_launch(const float* feats_cl, const float* imgs_cl, const 
     if (!mvs_aligned16(feats_cl) || (imgs_cl && !mvs_aligned16(imgs_cl))) return MVSNERF_EALIGN;
     const int64_t nvox = (int64_t)D * (H + 2 * pad) * (W + 2 * pad);
     if ((CP & 3) || !mvs_aligned16(cost)) return MVSNERF_EALIGN;
-    const size_t lds = ((((size_t)256 * ((V - 1) * 8 + 2) + 3) & ~(size_t)3) + (size_t)64 * (CP + 4)) * sizeof(float);
+    const size_t lds = ((((size_t)256 * ((V - 1) * 8 + 2) + 3) & ~(size_t)3) + (size_t)64 * ((blocked == 2 ? ((CP + 15) & ~15) : CP) + 4)) * sizeof(float);
     if (lds > 48 * 1024) {      // many source views: raise the dynamic-LDS cap (idempotent)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(planesweep_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;

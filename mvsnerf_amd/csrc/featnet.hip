@@ -88,6 +88,143 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ActSrc a, int ld, int Hi, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The 16- and 32-output-channel layers (conv1.x, conv2.x and the data gradients of the stride-1 ones: 83 % of FeatureNet's multiply-adds)
+// on the fp32 matrix cores.  (the VALU kernel above ran FeatureNet at 10.7 % of the fp32 peak.)  Implicit GEMM, one WAVE
+// per M-tile of MT consecutive output pixels (linear index over n, y, x - a tile may wrap around a row end), no LDS:
+//   COUT = 32: v_mfma_f32_32x32x2_f32, MT = 32, lane (m = lane & 31, kh = lane >> 5)
+//   COUT = 16: v_mfma_f32_16x16x4_f32, MT = 16, lane (m = lane & 15, kh = lane >> 4)
+// A operand: CPL consecutive input channels of pixel m at the tap (one 8- or 16-byte load, pending InPlaceABN applied on the fly, zero
+// padding of the ACTIVATED input); MFMA j contracts the channels c0 + CPL kh + j of all kh.  B operand: w[tap][ci][co] (the VALU kernel's
+// layout: a row of COUT consecutive floats per (tap, ci), lanes of one kh read one row).  The inputs stay in L1/L2 across the K x K taps.
+// Optionally leaves the InPlaceABN partial sums of its M-tiles (abn_finalize_kernel's layout) so that no statistics pass re-reads the output.
+template <int CIN, int COUT, int K, int S>
+__global__ __launch_bounds__(256) void conv2d_mfma_kernel(ActSrc a, int ld, int N, int Hi, int Wi, const float* __restrict__ wp,
+                                                          float* __restrict__ out, int Ho, int Wo, float* __restrict__ stats)
+{
+    constexpr int MT = COUT == 32 ? 32 : 16, KL = 64 / MT, P = K / 2;
+    constexpr int CPL = CIN / KL >= 4 ? 4 : CIN / KL;               // channels per lane and load
+    constexpr int NG = CIN / (KL * CPL);                            // load groups per tap
+    static_assert((COUT == 32 || COUT == 16) && CPL >= 2 && NG * KL * CPL == CIN, "channel split");
+    typedef float fcpl __attribute__((ext_vector_type(CPL)));
+    typedef float facc __attribute__((ext_vector_type(COUT == 32 ? 16 : 4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & (MT - 1), kh = lane / MT;
+    const int64_t npix = (int64_t)N * Ho * Wo;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile * MT >= npix) return;
+    const int64_t pix = tile * MT + m;
+    const bool live = pix < npix;
+    const int64_t pc = live ? pix : npix - 1;
+    const int x = (int)(pc % Wo), y = (int)((pc / Wo) % Ho), n = (int)(pc / ((int64_t)Wo * Ho));
+    const bool lazy = a.scale != nullptr;
+    facc acc;
+#pragma unroll
+    for (int r = 0; r < (COUT == 32 ? 16 : 4); ++r) acc[r] = 0.0f;
+    const float* xin = a.x + (int64_t)n * Hi * Wi * ld + kh * CPL;
+    float sc[NG][CPL], sh[NG][CPL];                                  // this lane's channels: pending InPlaceABN of the producer
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            sc[g][j] = lazy ? a.scale[g * KL * CPL + kh * CPL + j] : 1.0f;
+            sh[g][j] = lazy ? a.shift[g * KL * CPL + kh * CPL + j] : 0.0f;
+        }
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        const int yi = y * S - P + ky;
+        const bool yin = live && yi >= 0 && yi < Hi;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const int xi = x * S - P + kx;
+            const bool in = yin && xi >= 0 && xi < Wi;
+            const float* src = xin + (in ? ((int64_t)yi * Wi + xi) * ld : 0);
+            const float* wt = wp + (int64_t)((ky * K + kx) * CIN + kh * CPL) * COUT + m;
+            fcpl av[NG];
+            float bw[NG][CPL];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                av[g] = *reinterpret_cast<const fcpl*>(src + g * KL * CPL);
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) bw[g][j] = wt[(g * KL * CPL + j) * COUT];
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                fcpl v = av[g];
+                if (lazy) {
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) v[j] = act_apply(v[j], sc[g][j], sh[g][j]);
+                }
+                if (!in) {
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) v[j] = 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    if constexpr (COUT == 32) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], bw[g][j], acc, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j], bw[g][j], acc, 0, 0, 0);
+                }
+            }
+        }
+    }
+    // D: COUT = 32: register r of lane (col m, half kh) = tile pixel (r & 3) + 8 (r >> 2) + 4 kh; COUT = 16: register r = tile pixel 4 kh + r
+    float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+    for (int r = 0; r < (COUT == 32 ? 16 : 4); ++r) {
+        const int row = COUT == 32 ? (r & 3) + 8 * (r >> 2) + 4 * kh : 4 * kh + r;
+        const int64_t op = tile * MT + row;
+        if (op < npix) { out[op * COUT + m] = acc[r]; ssum += acc[r]; ssq = fmaf(acc[r], acc[r], ssq); }
+    }
+    if (stats) {
+        ssum += __shfl_xor(ssum, 32); ssq += __shfl_xor(ssq, 32);
+        if (COUT == 16) { ssum += __shfl_xor(ssum, 16); ssq += __shfl_xor(ssq, 16); }
+        if (kh == 0) { stats[(tile * 2) * COUT + m] = ssum; stats[(tile * 2 + 1) * COUT + m] = ssq; }
+    }
+}
+
+static bool conv2d_mfma_shape(int Cin, int Cout, int ksize, int stride)
+{
+    const int key = ((Cin * 100 + Cout) * 10 + ksize) * 10 + stride;
+    return g_conv_mfma && (key == ((8 * 100 + 16) * 10 + 5) * 10 + 2 || key == ((16 * 100 + 16) * 10 + 3) * 10 + 1 ||
+                           key == ((16 * 100 + 32) * 10 + 5) * 10 + 2 || key == ((32 * 100 + 32) * 10 + 3) * 10 + 1);
+}
+
+// number of M-tiles (= rows of InPlaceABN partial sums) mvsnerf_conv2d_fwd_stats leaves for this layer; 0: the layer has no matrix-core kernel
+extern "C" int mvsnerf_conv2d_mfma_tiles(int Cin, int Cout, int N, int H, int W, int ksize, int stride)
+{
+    if (!conv2d_mfma_shape(Cin, Cout, ksize, stride) || N < 1 || H < 1 || W < 1) return 0;
+    const int P = ksize / 2, Ho = (H + 2 * P - ksize) / stride + 1, Wo = (W + 2 * P - ksize) / stride + 1;
+    const int64_t npix = (int64_t)N * Ho * Wo, MT = Cout == 32 ? 32 : 16;
+    return (int)((npix + MT - 1) / MT);
+}
+
+static int conv2d_mfma_launch(const ActSrc& a, int Cin, int cin_ld, int N, int H, int W, const float* wpacked, int Cout, int ksize, int stride,
+                              float* out, float* stats, hipStream_t st)
+{
+    const int P = ksize / 2, Ho = (H + 2 * P - ksize) / stride + 1, Wo = (W + 2 * P - ksize) / stride + 1;
+    const unsigned tiles = (unsigned)mvsnerf_conv2d_mfma_tiles(Cin, Cout, N, H, W, ksize, stride);
+    const unsigned nwg = (tiles + 3) / 4;
+#define MVS_C2M(CIN, COUT, K, S) conv2d_mfma_kernel<CIN, COUT, K, S><<<nwg, 256, 0, st>>>(a, cin_ld, N, H, W, wpacked, out, Ho, Wo, stats)
+    if (Cin == 8) MVS_C2M(8, 16, 5, 2);
+    else if (Cin == 16 && Cout == 16) MVS_C2M(16, 16, 3, 1);
+    else if (Cin == 16) MVS_C2M(16, 32, 5, 2);
+    else MVS_C2M(32, 32, 3, 1);
+#undef MVS_C2M
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// mvsnerf_conv2d_fwd of a layer with a matrix-core kernel (mvsnerf_conv2d_mfma_tiles > 0; no bias) that also leaves the InPlaceABN partial
+// sums of its raw output: stats_part[tiles][2][Cout] for mvsnerf_abn_finalize
+extern "C" int mvsnerf_conv2d_fwd_stats(const float* x, const float* scale, const float* shift, int Cin, int cin_ld, int N, int H, int W,
+                                        const float* wpacked, int Cout, int ksize, int stride, float* out, float* stats_part, void* stream)
+{
+    if (!x || !wpacked || !out || !stats_part || ((scale == nullptr) != (shift == nullptr)) || N < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
+    if ((cin_ld & 3) || cin_ld < Cin || !mvs_aligned16(x) || !mvs_aligned16(out)) return MVSNERF_EALIGN;
+    if (!conv2d_mfma_shape(Cin, Cout, ksize, stride)) return MVSNERF_EUNSUPPORTED;
+    return conv2d_mfma_launch(ActSrc{x, scale, shift}, Cin, cin_ld, N, H, W, wpacked, Cout, ksize, stride, out, stats_part, (hipStream_t)stream);
+}
+
 extern "C" int mvsnerf_conv2d_fwd(const float* x, const float* scale, const float* shift, int Cin, int cin_ld,
                                   int N, int H, int W, const float* wpacked, const float* bias, int Cout,
                                   int ksize, int stride, float* out, void* stream)
@@ -98,6 +235,8 @@ extern "C" int mvsnerf_conv2d_fwd(const float* x, const float* scale, const floa
     const int Ho = (H + 2 * P - ksize) / stride + 1, Wo = (W + 2 * P - ksize) / stride + 1;
     const ActSrc a{x, scale, shift};
     hipStream_t st = (hipStream_t)stream;
+    if (!bias && conv2d_mfma_shape(Cin, Cout, ksize, stride))
+        return conv2d_mfma_launch(a, Cin, cin_ld, N, H, W, wpacked, Cout, ksize, stride, out, nullptr, st);
     const unsigned tiles = (unsigned)(((Wo + 15) / 16) * ((Ho + 15) / 16) * N);
 #define MVS_C2D(CIN, CT, K, S, COUT) conv2d_kernel<CIN, CT, K, S, COUT><<<dim3(tiles, COUT / CT), 256, 0, st>>>(a, cin_ld, H, W, wpacked, bias, out, Ho, Wo)
     const int key = ((Cin * 100 + Cout) * 10 + ksize) * 10 + stride;

@@ -163,15 +163,24 @@ class _PackedConv2d:
         return buf
 
 
-def _conv2d(src, dims_in, cin_ld, wbuf, cin_k, cout_k, ksize, stride, bias=None):
-    """2-D convolution kernel launch (padding k//2): input (N,H,W) with channel stride cin_ld -> raw (N,Ho,Wo,cout_k)."""
+def _conv2d(src, dims_in, cin_ld, wbuf, cin_k, cout_k, ksize, stride, bias=None, want_stats=False):
+    """2-D convolution kernel launch (padding k//2): input (N,H,W) with channel stride cin_ld -> raw (N,Ho,Wo,cout_k).
+    want_stats: returns (raw, InPlaceABN partial sums | None) - the matrix-core layers leave them from their own launch."""
     N, H, W, _ = dims_in
     P = ksize // 2
     Ho, Wo = (H + 2 * P - ksize) // stride + 1, (W + 2 * P - ksize) // stride + 1
     out = torch.empty((N, Ho, Wo, cout_k), device=wbuf.device, dtype=torch.float32)
-    check(_lib.lib().mvsnerf_conv2d_fwd(*_ptrs(src), cin_k, cin_ld, N, H, W, wbuf.data_ptr(), 0 if bias is None else bias.data_ptr(), cout_k,
-                                        ksize, stride, out.data_ptr(), stream_ptr()), "conv2d_fwd")
-    return out
+    lib = _lib.lib()
+    if want_stats and bias is None and FUSED_ABN_STATS:
+        nblk = lib.mvsnerf_conv2d_mfma_tiles(cin_k, cout_k, N, H, W, ksize, stride)
+        if nblk > 0:
+            part = torch.empty(nblk * 2 * cout_k, device=out.device, dtype=torch.float32)
+            check(lib.mvsnerf_conv2d_fwd_stats(*_ptrs(src), cin_k, cin_ld, N, H, W, wbuf.data_ptr(), cout_k, ksize, stride, out.data_ptr(),
+                                               part.data_ptr(), stream_ptr()), "conv2d_fwd_stats")
+            return out, (part, nblk)
+    check(lib.mvsnerf_conv2d_fwd(*_ptrs(src), cin_k, cin_ld, N, H, W, wbuf.data_ptr(), 0 if bias is None else bias.data_ptr(), cout_k,
+                                 ksize, stride, out.data_ptr(), stream_ptr()), "conv2d_fwd")
+    return (out, None) if want_stats else out
 
 
 class ConvBnReLU(nn.Module):
@@ -188,9 +197,10 @@ class ConvBnReLU(nn.Module):
 
     def lazy(self, src, dims_in, cin_ld):
         pk = self._packed
-        raw = _conv2d(src, dims_in, cin_ld, pk.get(), pk.cin_pad, pk.cout, self.k, self.stride)
+        raw, partials = _conv2d(src, dims_in, cin_ld, pk.get(), pk.cin_pad, pk.cout, self.k, self.stride, want_stats=True)
         N, H, W, C = raw.shape
-        scale, shift, mean, invstd = _abn_stats(raw, N * H * W, self.bn, update_running=self.bn.training)
+        scale, shift, mean, invstd = _abn_stats(raw, N * H * W, self.bn, update_running=self.bn.training,
+                                                partials=partials if self.bn.training else None)
         return _Lazy(raw, scale, shift, (N, H, W, C), mean, invstd)
 
     def forward(self, x):
@@ -760,12 +770,14 @@ def _abn_bwd(lz, bn, g1, g2=None):
     D, H, W, C = lz.dims
     dev = lz.x.device
     gx = torch.empty((D, H, W, C), device=dev, dtype=torch.float32)
-    gwb = torch.empty((2, C), device=dev, dtype=torch.float32)
+    # two tensors of their own, not two rows of one: autograd's AccumulateGrad takes a gradient over as `.grad` only when it owns its storage,
+    # a view is CLONED - 36 device copies per training step (18 InPlaceABN layers) showed up as __amd_rocclr_copyBuffer in the kernel trace
+    gbw, gbb = torch.empty(C, device=dev, dtype=torch.float32), torch.empty(C, device=dev, dtype=torch.float32)
     ws = torch.empty(_lib.lib().mvsnerf_abn_workspace_floats(C), device=dev, dtype=torch.float32)
     check(_lib.lib().mvsnerf_abn_bwd(lz.x.data_ptr(), D * H * W, C, dev_f32(bn.weight.detach(), "bn.weight"), lz.scale.data_ptr(), lz.shift.data_ptr(),
                                      lz.mean.data_ptr(), lz.invstd.data_ptr(), g1.data_ptr(), 0 if g2 is None else g2.data_ptr(),
-                                     gx.data_ptr(), gwb[0].data_ptr(), gwb[1].data_ptr(), ws.data_ptr(), stream_ptr()), "abn_bwd")
-    return gx, gwb[0], gwb[1]
+                                     gx.data_ptr(), gbw.data_ptr(), gbb.data_ptr(), ws.data_ptr(), stream_ptr()), "abn_bwd")
+    return gx, gbw, gbb
 
 
 def _wgrad(G1, G2, A, X1, X2, B, ldx, g_dims, x_dims, stride, shape, sums=None):
@@ -1129,7 +1141,7 @@ def bench_encode(rig, dev, pad, iters=6):
             t_vals = torch.linspace(0.0, 1.0, steps=net.D, device=dev)
             dv = (nf[0] * (1.0 - t_vals) + nf[1] * t_vals).unsqueeze(0)
             if BLOCKED_COST:
-                cost, _ = net._sweep(imgs, feats_l, proj, dv, pad, True, blocked=True)      # what MVSNet.forward does without gradients
+                cost, _ = net._sweep(imgs, feats_l, proj, dv, pad, True, blocked="bf16" if ENCODER_PRECISION == "bf16" else True)   # what MVSNet.forward does without gradients
             else:
                 cost, _ = net.build_volume_costvar_img(imgs, feats_l, proj, dv, pad=pad)
             torch.cuda.synchronize(); t2 = time.perf_counter()

@@ -553,13 +553,10 @@ class RayMarchFunction(torch.autograd.Function):
         gslots = torch.empty(lib.mvsnerf_mlp_gradslot_floats(N * S), **f32)
         ws = torch.empty(lib.mvsnerf_mlp_bwd_workspace_floats(), **f32)
         d_feat = torch.empty((N * S, C), **f32)         # C = 8: the volume features only; C = F: the colour volume is a parameter too
-        # the 22 gradient tensors are views of ONE zero-filled buffer (one fill launch instead of 22); 16-byte aligned slices
-        sizes = [(p.numel() + 3) // 4 * 4 for p in mlp_params]
-        flat = torch.zeros(sum(sizes), **f32)
-        views, off = [], 0
-        for p, n in zip(mlp_params, sizes):
-            views.append(flat[off:off + p.numel()].view_as(p))
-            off += n
+        # 22 gradient tensors of their own, zeroed by ONE multi-tensor launch.  (They used to be views of one zero-filled buffer: autograd's
+        # AccumulateGrad clones a gradient that does not own its storage - 22 device copies per step in the kernel trace.)
+        views = [torch.empty_like(p, memory_format=torch.contiguous_format) for p in mlp_params]
+        torch._foreach_zero_(views)
         gws, gbs = views[0::2], views[1::2]
         gwp = (ctypes.c_void_p * 11)(*[g.data_ptr() for g in gws])
         gbp = (ctypes.c_void_p * 11)(*[g.data_ptr() for g in gbs])
