@@ -28,6 +28,9 @@ static inline int mvs_raise_lds_cap(const void* fn, int bytes, unsigned long lon
     return 0;
 }
 
+// smallest multiple of 4 that is >= n and whose quarter is odd: an LDS row stride (in floats) that walks all 16 bank groups of 16 bytes
+__host__ __device__ inline int mvs_odd_quad_stride(int n) { const int q = (n + 3) >> 2; return (q | 1) << 2; }
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -96,16 +96,35 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
     static_assert(C == 32, "lane q owns float4 numbers q and q + 4 of a 32-channel pixel");
     constexpr int VPB = 256, VPP = 64;                           // voxels per block / per pass
     extern __shared__ __attribute__((aligned(16))) float lds_[];
-    const int GS = (V - 1) * 8 + 2;                              // per voxel: per source view {w_nw,w_ne,w_sw,w_se, t_nw,t_ne,t_sw,t_se}; then {1/count, ref pixel}
+    // per voxel: per source view {w_nw,w_ne,w_sw,w_se, t_nw,t_ne,t_sw,t_se}; then {1/count, ref pixel}.  Row strides in floats with
+    // stride / 4 ODD: consecutive rows then start on different 16-byte bank groups (16 rows cover all 64 banks once), so that the 16-byte
+    // reads of 16 voxels' rows (phase 2, flush) do not collide.  (Round 2 had 18 and CP + 4 = 48: PMC SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+    // = 0.61; 48 floats put rows v and v + 4 on the same banks for the flush's ds_read_b128 and all rows on two bank phases for the stores.)
+    const int GS = mvs_odd_quad_stride((V - 1) * 8 + 2);
     float* geo = lds_;                                           // [VPB][GS]
-    const int RS = blocked == 2 ? ((CP + 15) & ~15) + 4 : CP + 4;  // staging row: +4 floats break the bank stride; bf16 mode stages whole 16-channel blocks
+    const int RS = mvs_odd_quad_stride((blocked == 2 ? ((CP + 15) & ~15) : CP) + 1);   // staging row (bf16 mode stages whole 16-channel blocks)
     float* stage = lds_ + ((VPB * GS + 3) & ~3);                 // [VPP][RS]
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const int64_t nvox = (int64_t)D * Hp * Wp;
-    const int64_t v0 = (int64_t)blockIdx.x * VPB;
+    // Workgroup -> voxels.  Workgroups are dealt to the 8 XCDs round-robin and every XCD has its own 4 MB L2; the source feature maps are
+    // V x 2.6 MB.  With workgroup b taking voxels 256 b .. 256 b + 255 every XCD swept every row of every plane and its L2 kept missing:
+    // PMC FETCH_SIZE 1.27 GB per launch for 8.6 MB of input (profiles/r03_pmc_enc_summary.json, round-3 tree before this change) - with the
+    // 0.84 GB written that is 6.2 TB/s through the fabric, i.e. the kernel ran at the MEMORY system's limit, not the VALU's.  Now XCD k owns
+    // the band of rows [k RB, (k+1) RB) of every depth plane: its taps fall into ~RB + 2 rows of each source view (1.5 MB at config 2),
+    // which stay in its L2 for the whole launch.  A workgroup takes 256 consecutive voxels of one (plane, band) slab (a contiguous range
+    // of the volume, so the flush still writes contiguous spans); the last chunk of a slab is short.
+    const int RB = (Hp + 7) >> 3;                                // rows per band
+    const int CPS = (RB * Wp + VPB - 1) / VPB;                   // chunks per (plane, band) slab
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int d_blk = jb / CPS, chunk = jb - d_blk * CPS;
+    const int band_rows = min(RB, Hp - xcd * RB);                // the last band may be short (or empty)
+    const int slab = band_rows > 0 ? band_rows * Wp : 0;
+    const int64_t v0 = ((int64_t)d_blk * Hp + (int64_t)xcd * RB) * Wp + (int64_t)chunk * VPB;
+    const int n_blk = min(VPB, slab - chunk * VPB);              // voxels of this workgroup (<= 0: nothing to do)
+    if (n_blk <= 0) return;
     {   // ---- phase 1
         const int64_t i = v0 + threadIdx.x;
-        if (i < nvox) {
+        if ((int)threadIdx.x < n_blk) {
             float* o = geo + threadIdx.x * GS;
             const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), d = (int)(i / ((int64_t)Wp * Hp));
             const float u = (float)(x - pad), v = (float)(y - pad);     // utils.py:603-605
@@ -153,8 +172,8 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
     float* o = stage + vloc * RS;
     for (int pass = 0; pass < VPB / VPP; ++pass) {
         const int vb = pass * VPP + vloc;
-        const int64_t i_raw = v0 + vb;
-        const bool live = i_raw < nvox;
+        if (pass * VPP >= n_blk) break;                          // (uniform) a short last chunk has fewer passes
+        const bool live = vb < n_blk;
         const float* g = geo + (live ? vb : 0) * GS;             // dead lanes recompute the block's first voxel (their rows are not flushed)
         const float inv = g[(V - 1) * 8];
         const int refpix = __float_as_int(g[(V - 1) * 8 + 1]);
@@ -209,12 +228,12 @@ __global__ __launch_bounds__(256) void planesweep_kernel(
             o[c_var + c] = s2[j] * inv - mean * mean;                // :890
         }
         if (q == 0)
-            for (int c = c_var + C; c < RS - 4; ++c) o[c] = 0.0f;
+            for (int c = c_var + C; c < (blocked == 2 ? ((CP + 15) & ~15) : CP); ++c) o[c] = 0.0f;
         // flush this pass's 64 consecutive voxels (one contiguous CP*64*4-byte span of the cost volume) with coalesced 16-byte stores
         __syncthreads();
         {
             const int64_t p0 = v0 + pass * VPP;
-            const int64_t nv = nvox - p0 < VPP ? (nvox - p0 > 0 ? nvox - p0 : 0) : VPP;
+            const int64_t nv = n_blk - pass * VPP < VPP ? n_blk - pass * VPP : VPP;
             const int n4 = (int)(nv * CP / 4);
             if (!blocked) {
                 f32x4* dst = reinterpret_cast<f32x4*>(cost + p0 * CP);
@@ -287,12 +306,14 @@ static int planesweep_launch(const float* feats_cl, const float* imgs_cl, const 
     if (!mvs_aligned16(feats_cl) || (imgs_cl && !mvs_aligned16(imgs_cl))) return MVSNERF_EALIGN;
     const int64_t nvox = (int64_t)D * (H + 2 * pad) * (W + 2 * pad);
     if ((CP & 3) || !mvs_aligned16(cost)) return MVSNERF_EALIGN;
-    const size_t lds = ((((size_t)256 * ((V - 1) * 8 + 2) + 3) & ~(size_t)3) + (size_t)64 * ((blocked == 2 ? ((CP + 15) & ~15) : CP) + 4)) * sizeof(float);
+    const size_t lds = ((((size_t)256 * mvs_odd_quad_stride((V - 1) * 8 + 2) + 3) & ~(size_t)3) +
+                        (size_t)64 * mvs_odd_quad_stride((blocked == 2 ? ((CP + 15) & ~15) : CP) + 1)) * sizeof(float);
     if (lds > 48 * 1024) {      // many source views: raise the dynamic-LDS cap (idempotent)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(planesweep_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    planesweep_kernel<32><<<mvs_cdiv(nvox, 256), 256, lds, (hipStream_t)stream>>>(feats_cl, imgs_cl, proj, depth, V, H, W, D, pad, cost, CP, masks, with_img, blocked);
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad, RB = (Hp + 7) >> 3, CPS = (RB * Wp + 255) / 256;
+    planesweep_kernel<32><<<(unsigned)(8 * D * CPS), 256, lds, (hipStream_t)stream>>>(feats_cl, imgs_cl, proj, depth, V, H, W, D, pad, cost, CP, masks, with_img, blocked);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
@@ -1433,8 +1454,15 @@ __global__ __launch_bounds__(256, NSRC <= 2 ? 4 : 2) void planesweep_bwd_tiles_k
     const int tid = threadIdx.x;
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const int ntx = (Wp + TS - 1) / TS, nty = (Hp + TS - 1) / TS;
-    const int tile = blockIdx.x % (ntx * nty), chunk = blockIdx.x / (ntx * nty);
-    const int x0 = (tile % ntx) * TS, y0 = (tile / ntx) * TS;
+    // XCD k (= blockIdx.x & 7: workgroups are dealt round-robin) owns the tile rows [k RBT, (k+1) RBT) of every depth chunk: its gathers
+    // and scatters stay inside ~8 RBT + 2 rows of each feature map, which fit its L2 (as in planesweep_kernel; round 2 fetched 1.35 GB per
+    // launch for 0.6 GB of gradient input).  gridDim.x = 8 x RBT x ntx x chunks: rows past the volume return at once.
+    const int RBT = (nty + 7) >> 3;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int chunk = jb / (RBT * ntx), rem = jb - chunk * (RBT * ntx);
+    const int ty = xcd * RBT + rem / ntx;
+    if (ty >= nty) return;
+    const int x0 = (rem % ntx) * TS, y0 = ty * TS;
     const int d_begin = chunk * DCH, d_end = min(D, d_begin + DCH);
     const float sx = (float)(W - 1) / 2.0f, sy = (float)(H - 1) / 2.0f;
     // phase-1 role: voxel pv of the tile, source views tid>>6, +4, ...
@@ -1618,7 +1646,8 @@ static int planesweep_bwd_tiles_launch(const float* feat, const float* proj, con
         const int rc = mvs_raise_lds_cap((const void*)planesweep_bwd_tiles_kernel<32, CL, NSRC, PW>, (int)lds, &cap_mask);
         if (rc != MVSNERF_OK) return rc;
     }
-    const dim3 grid((unsigned)(((Wp + 7) / 8) * ((Hp + 7) / 8) * ((D + DCH - 1) / DCH)), 32 / CL);
+    const int nty = (Hp + 7) / 8, RBT = (nty + 7) / 8;
+    const dim3 grid((unsigned)(8 * RBT * ((Wp + 7) / 8) * ((D + DCH - 1) / DCH)), 32 / CL);
     planesweep_bwd_tiles_kernel<32, CL, NSRC, PW><<<grid, 256, lds, st>>>(feat, proj, depth, H, W, D, pad, g_cost, CP, c_var, g_feat, DCH);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
