@@ -5,7 +5,7 @@ mkdir -p gpurun_out/r3_pmc_enc
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
   tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
   rm -rf gpurun_out/r3_pmc_enc/$tag
-  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d gpurun_out/r3_pmc_enc/$tag -o p -- python scratch/enc_only.py > gpurun_out/r3_pmc_enc/$tag.log 2>&1
+  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d gpurun_out/r3_pmc_enc/$tag -o p -- python scratch/r3/enc_only.py > gpurun_out/r3_pmc_enc/$tag.log 2>&1
 done
 python - <<'PY'
 import csv, glob, collections, json

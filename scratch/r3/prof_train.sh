@@ -5,7 +5,7 @@ for mode in fp32 amp; do
   rm -rf gpurun_out/r3_prof_train_$mode
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r3_prof_train_$mode -o t -- python scratch/r3/train_prof.py $mode 5 > gpurun_out/r3_prof_train_$mode.log 2>&1
   grep "train step" gpurun_out/r3_prof_train_$mode.log
-  python scratch/prof_summary.py gpurun_out/r3_prof_train_$mode 60 > gpurun_out/r3_train_kernel_summary_$mode.txt
+  python scratch/r3/prof_summary.py gpurun_out/r3_prof_train_$mode 60 > gpurun_out/r3_train_kernel_summary_$mode.txt
   find gpurun_out/r3_prof_train_$mode -name "*kernel_stats.csv" -exec cp {} gpurun_out/r3_train_kernel_stats_$mode.csv \;
   find gpurun_out/r3_prof_train_$mode -name "*kernel_trace.csv" -delete
 done
