@@ -868,6 +868,81 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_c16to8_mfma4_kernel(ActSrc x
 }  // namespace
 
 // Called by mvsnerf_conv3d_fwd (encoder.hip) for the layers with 32 / 64 output channels; MVSNERF_EUNSUPPORTED = not instantiated.
+// ---------------------------------------------------------------------------------------------------------------------------
+// conv1 (8 -> 16, stride 2) and conv2 (16 -> 16; and its data gradient) of CostRegNet (models.py:757-758) on v_mfma_f32_16x16x4_f32 - the
+// last VALU convolutions of the U-Net (47 / 79 TFLOP/s, LDS conflict rate 0.63 in the tiled VALU kernel).  One WAVE per
+// 32 consecutive output voxels = two 16-voxel M-tiles that share every B operand; lane (m = lane & 15, kh = lane >> 4): A = CPL consecutive
+// input channels of voxel m at the tap (channels CPL kh + j, one 8- or 16-byte load, pending InPlaceABN applied on the fly), B = the same
+// channels of w32[tap][ci / 8][co][ci % 8] (the layout of the 32/64-channel kernels above) for output channel m.  No LDS: the 27-fold
+// re-read of the input is served by L1/L2.  Leaves the InPlaceABN partial sums of its 32-voxel tiles when asked.
+template <int CIN, int S>
+__global__ __launch_bounds__(256) void conv3d_k3_mfma16_kernel(ActSrc a, int ld, int Di, int Hi, int Wi, const float* __restrict__ w32,
+                                                              float* __restrict__ out, int Do, int Ho, int Wo, float* __restrict__ stats)
+{
+    constexpr int COUT = 16, CPL = CIN / 4, CB8 = CIN / 8;
+    static_assert(CIN == 8 || CIN == 16, "8 or 16 input channels");
+    typedef float fcpl __attribute__((ext_vector_type(CPL)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kh = lane >> 4;
+    const int64_t nvox = (int64_t)Do * Ho * Wo;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile * 32 >= nvox) return;
+    int xs[2], ys[2], zs[2];
+    bool live[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int64_t v = tile * 32 + h * 16 + m;
+        live[h] = v < nvox;
+        const int64_t vc = live[h] ? v : nvox - 1;
+        xs[h] = (int)(vc % Wo); ys[h] = (int)((vc / Wo) % Ho); zs[h] = (int)(vc / ((int64_t)Wo * Ho));
+    }
+    const bool lazy = a.scale != nullptr;
+    float sc[CPL], sh[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { sc[j] = lazy ? a.scale[kh * CPL + j] : 1.0f; sh[j] = lazy ? a.shift[kh * CPL + j] : 0.0f; }
+    f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    // this lane's weights of a tap: channels CPL kh .. CPL kh + CPL - 1 of output channel m
+    const float* wl = w32 + ((int64_t)((CIN == 16 ? (kh >> 1) : 0) * COUT + m)) * 8 + (CIN == 16 ? (kh & 1) * 4 : kh * 2);
+#pragma unroll 3
+    for (int tap = 0; tap < 27; ++tap) {
+        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+        const fcpl bw = *reinterpret_cast<const fcpl*>(wl + (int64_t)tap * CB8 * COUT * 8);
+        fcpl av[2];
+        bool in[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int zi = zs[h] * S - 1 + dz, yi = ys[h] * S - 1 + dy, xi = xs[h] * S - 1 + dx;
+            in[h] = live[h] && zi >= 0 && zi < Di && yi >= 0 && yi < Hi && xi >= 0 && xi < Wi;
+            av[h] = *reinterpret_cast<const fcpl*>(a.x + (in[h] ? ((int64_t)zi * Hi + yi) * Wi + xi : 0) * ld + kh * CPL);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            fcpl v = av[h];
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                if (lazy) v[j] = act_apply(v[j], sc[j], sh[j]);
+                if (!in[h]) v[j] = 0.0f;                           // zero padding of the ACTIVATED input
+            }
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j], bw[j], acc[h], 0, 0, 0);
+        }
+    }
+    // D: register r of lane (col m, group kh) = voxel 4 kh + r of the 16-voxel tile
+    float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t ov = tile * 32 + h * 16 + 4 * kh + r;
+            if (ov < nvox) { out[ov * COUT + m] = acc[h][r]; ssum += acc[h][r]; ssq = fmaf(acc[h][r], acc[h][r], ssq); }
+        }
+    if (stats) {
+        ssum += __shfl_xor(ssum, 16); ssq += __shfl_xor(ssq, 16);
+        ssum += __shfl_xor(ssum, 32); ssq += __shfl_xor(ssq, 32);
+        if (kh == 0) { stats[(tile * 2) * COUT + m] = ssum; stats[(tile * 2 + 1) * COUT + m] = ssq; }
+    }
+}
+
 int mvs_conv3d_mfma32_tiles(int D, int H, int W, int stride)
 {
     const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
@@ -881,7 +956,10 @@ int mvs_conv3d_mfma32(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int
     const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const unsigned grid = mvs_cdiv((int64_t)Do * Ho * Wo, 32);
 #define MVS_M32(CIN, COUT, S) conv3d_k3_mfma32_kernel<CIN, COUT, S><<<grid, 512, 0, st>>>(a, cin_ld, D, H, W, w32, out, Do, Ho, Wo, stats)
+    const unsigned grid16 = (grid + 3) / 4;
     switch (Cin * 1000 + Cout * 10 + stride) {
+        case 8 * 1000 + 16 * 10 + 2:  conv3d_k3_mfma16_kernel<8, 2><<<grid16, 256, 0, st>>>(a, cin_ld, D, H, W, w32, out, Do, Ho, Wo, stats); break;    // conv1
+        case 16 * 1000 + 16 * 10 + 1: conv3d_k3_mfma16_kernel<16, 1><<<grid16, 256, 0, st>>>(a, cin_ld, D, H, W, w32, out, Do, Ho, Wo, stats); break;   // conv2 (and its data gradient)
         case 16 * 1000 + 32 * 10 + 2: MVS_M32(16, 32, 2); break;     // conv3 (and the data gradient of conv9)
         case 32 * 1000 + 32 * 10 + 1: MVS_M32(32, 32, 1); break;     // conv4 (and its data gradient)
         case 32 * 1000 + 64 * 10 + 2: MVS_M32(32, 64, 2); break;     // conv5 (and the data gradient of conv7)
@@ -923,7 +1001,7 @@ int mvs_convT3d_mfma32(const float* x, int Cin, int D, int H, int W, const float
 bool mvs_conv3d_mfma32_supported(int Cin, int Cout, int stride)
 {
     const int k = Cin * 1000 + Cout * 10 + stride;
-    return k == 16322 || k == 32321 || k == 32642 || k == 64641;
+    return k == 8162 || k == 16161 || k == 16322 || k == 32321 || k == 32642 || k == 64641;
 }
 
 int mvs_conv_w32_repack(const float* wpacked, float* w32, int Cin, int Cout, hipStream_t st)
