@@ -869,8 +869,11 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_c16to8_mfma4_kernel(ActSrc x
 
 // Called by mvsnerf_conv3d_fwd (encoder.hip) for the layers with 32 / 64 output channels; MVSNERF_EUNSUPPORTED = not instantiated.
 // ---------------------------------------------------------------------------------------------------------------------------
-// conv1 (8 -> 16, stride 2) and conv2 (16 -> 16; and its data gradient) of CostRegNet (models.py:757-758) on v_mfma_f32_16x16x4_f32 - the
-// last VALU convolutions of the U-Net (47 / 79 TFLOP/s, LDS conflict rate 0.63 in the tiled VALU kernel).  One WAVE per
+// conv1 (8 -> 16, stride 2; and the data gradient of conv11, the same shape) of CostRegNet (models.py:757) on v_mfma_f32_16x16x4_f32.
+// Measured (profiles/r03_*): 110 us against 109 us for the VALU kernel it replaces - the layer reads 150 MB and is bound by that - but the
+// InPlaceABN statistics now come out of the same launch.  The SAME kernel for conv2 (16 -> 16, stride 1; template <16, 1>) ran 159 us against
+// 116 us for the LDS-tiled VALU kernel (one wave per 32 voxels re-reads every input voxel 27 times through L1: 2.3 GB of L1 traffic for a
+// 37 MB tensor, where the tiled kernel stages a halo once) and is NOT dispatched: conv2 keeps the VALU kernel.  One WAVE per
 // 32 consecutive output voxels = two 16-voxel M-tiles that share every B operand; lane (m = lane & 15, kh = lane >> 4): A = CPL consecutive
 // input channels of voxel m at the tap (channels CPL kh + j, one 8- or 16-byte load, pending InPlaceABN applied on the fly), B = the same
 // channels of w32[tap][ci / 8][co][ci % 8] (the layout of the 32/64-channel kernels above) for output channel m.  No LDS: the 27-fold
@@ -959,7 +962,6 @@ int mvs_conv3d_mfma32(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int
     const unsigned grid16 = (grid + 3) / 4;
     switch (Cin * 1000 + Cout * 10 + stride) {
         case 8 * 1000 + 16 * 10 + 2:  conv3d_k3_mfma16_kernel<8, 2><<<grid16, 256, 0, st>>>(a, cin_ld, D, H, W, w32, out, Do, Ho, Wo, stats); break;    // conv1
-        case 16 * 1000 + 16 * 10 + 1: conv3d_k3_mfma16_kernel<16, 1><<<grid16, 256, 0, st>>>(a, cin_ld, D, H, W, w32, out, Do, Ho, Wo, stats); break;   // conv2 (and its data gradient)
         case 16 * 1000 + 32 * 10 + 2: MVS_M32(16, 32, 2); break;     // conv3 (and the data gradient of conv9)
         case 32 * 1000 + 32 * 10 + 1: MVS_M32(32, 32, 1); break;     // conv4 (and its data gradient)
         case 32 * 1000 + 64 * 10 + 2: MVS_M32(32, 64, 2); break;     // conv5 (and the data gradient of conv7)
@@ -1001,7 +1003,7 @@ int mvs_convT3d_mfma32(const float* x, int Cin, int D, int H, int W, const float
 bool mvs_conv3d_mfma32_supported(int Cin, int Cout, int stride)
 {
     const int k = Cin * 1000 + Cout * 10 + stride;
-    return k == 8162 || k == 16161 || k == 16322 || k == 32321 || k == 32642 || k == 64641;
+    return k == 8162 || k == 16322 || k == 32321 || k == 32642 || k == 64641;
 }
 
 int mvs_conv_w32_repack(const float* wpacked, float* w32, int Cin, int Cout, hipStream_t st)
