@@ -1413,6 +1413,7 @@ __global__ __launch_bounds__(256) void planesweep_bwd_kernel(const float* __rest
     }
 }
 
+#ifdef MVSNERF_DEV_KNOBS   // measured and dropped (1.24 ms at config 2 where the column form below takes 0.31): kept for scratch/dev_tests only
 // ---- plane-sweep backward, tile form.  The scatter above is bound by the atomics themselves: float atomics of one XCD cannot stay in its
 // L2 when seven other XCDs add to the same feature maps, so each of the 9 x 4.7 M 128-byte updates crosses the fabric (3.6 TB/s of atomic
 // traffic at 1.5 ms).  Here a workgroup owns an 8 x 8 column of voxels (CL = 16 of the 32 channels) over DCH consecutive depth planes and
@@ -1632,8 +1633,139 @@ __global__ __launch_bounds__(256, NSRC <= 2 ? 4 : 2) void planesweep_bwd_tiles_k
     }
 }
 
-MVS_KNOB_DEF(g_psw_bwd_tiles, 1)   // 0 (dev build only) = the per-voxel scatter kernel for every shape; the product uses it for V == 1
+#endif
 
+// ---- plane-sweep backward, column form.  A thread owns ONE channel of ONE voxel column (x, y) and walks the depth planes itself.  Along
+// a column the sample point in a source view moves by the disparity step - a fraction of a pixel per plane for any rig the sweep is meant
+// for (0.07 px at config 2) - so the four tap PIXELS stay the same for many consecutive planes; only the bilinear weights change.  The
+// thread therefore keeps, per source view, the four tap values and four gradient accumulators in registers and touches memory only when
+// the tap set changes: it sends the accumulators (one float atomic per tap with a non-zero sum) and gathers the new taps.  At config 2
+// that is ~10 tap sets per column and view over 128 planes: the gathers and the atomics of the scatter kernel divided by ~13, no LDS
+// atomics, no patch, and each gradient value of the cost volume is read exactly once (the tile form read it once per channel half too,
+// but per plane it paid 36 gathers and 36 LDS atomics per thread).  What remains per plane and thread is one coalesced 4-byte load,
+// the geometry from LDS and ~30 multiply-adds.  A rig whose taps move every plane degrades to the scatter kernel's traffic, not below it.
+//   Workgroup = NV = 8 consecutive columns of one row x 32 channels.  Geometry (7 divisions per voxel and view) is computed once per
+// voxel, DCH planes at a time: NV x NSRC x DCH items over the 256 threads -> LDS -> read back by the 32 channel lanes (broadcast reads).
+// The reference view's gradient of a pixel has exactly one column contributing: register sum over all planes, one plain read-add-write.
+template <int C, int NSRC>
+__global__ __launch_bounds__(256) void planesweep_bwd_columns_kernel(const float* __restrict__ feat, const float* __restrict__ proj,
+                                                                     const float* __restrict__ depth, int H, int W, int D, int pad,
+                                                                     const float* __restrict__ g_cost, int CP, int c_var, float* __restrict__ g_feat)
+{
+    static_assert(C == 32, "one lane per channel, 8 columns per workgroup");
+    constexpr int NV = 8, DCH = 16, GI = 12;                          // columns per workgroup, planes per geometry batch, floats per item
+    // per (plane, column, source view): {w_nw,w_ne,w_sw,w_se | byte offset of the 4 tap pixels in a feature map | view counts (0/1), -, -, -}
+    __shared__ __attribute__((aligned(16))) float geo[DCH * NV * NSRC * GI];
+    const int tid = threadIdx.x;
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const int nbx = (Wp + NV - 1) / NV;
+    const int y = blockIdx.x / nbx, x0 = (blockIdx.x - y * nbx) * NV;
+    const float sx = (float)(W - 1) / 2.0f, sy = (float)(H - 1) / 2.0f;
+    const int vl = tid >> 5, c = tid & 31, x = x0 + vl;
+    const bool valid = x < Wp;
+    const bool interior = valid && x >= pad && x < W + pad && y >= pad && y < H + pad;
+    const int64_t refoff = interior ? ((int64_t)(y - pad) * W + (x - pad)) * C + c : 0;
+    const float ref = interior ? feat[refoff] : 0.f;
+    float racc = 0.f;
+    int4 cur[NSRC];                                                   // tap set in the registers (byte offsets), -1: none yet
+    float tap[NSRC][4], acc[NSRC][4];
+#pragma unroll
+    for (int vs = 0; vs < NSRC; ++vs) {
+        cur[vs] = int4{-1, -1, -1, -1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { tap[vs][k] = 0.f; acc[vs][k] = 0.f; }
+    }
+    auto send = [&](int vs) {
+        float* gview = g_feat + (int64_t)(vs + 1) * H * W * C + c;
+        const int o[4] = {cur[vs].x, cur[vs].y, cur[vs].z, cur[vs].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (acc[vs][k] != 0.f) { atomicAdd(gview + (o[k] >> 2), acc[vs][k]); acc[vs][k] = 0.f; }
+    };
+    const float* gcol = g_cost + ((int64_t)y * Wp + x) * CP + c_var + c;
+    const int64_t gplane = (int64_t)Hp * Wp * CP;
+    for (int d0 = 0; d0 < D; d0 += DCH) {
+        // ---- geometry of DCH planes x NV columns x NSRC views
+        for (int it = tid; it < DCH * NV * NSRC; it += 256) {
+            const int dl = it / (NV * NSRC), r = it - dl * (NV * NSRC), pv = r / NSRC, vs = r - pv * NSRC;
+            const int d = min(d0 + dl, D - 1), vx = x0 + pv;
+            const bool pvalid = vx < Wp;
+            const float u = (float)(vx - pad), v = (float)(y - pad), dep = depth[d];
+            const float* P = proj + (vs + 1) * 12;
+            const float p0 = fmaf(P[2], 1.0f, fmaf(P[1], v, P[0] * u)) + P[3] / dep;
+            const float p1 = fmaf(P[6], 1.0f, fmaf(P[5], v, P[4] * u)) + P[7] / dep;
+            const float p2 = fmaf(P[10], 1.0f, fmaf(P[9], v, P[8] * u)) + P[11] / dep;
+            const float gx = (p0 / p2) / sx - 1.0f, gy = (p1 / p2) / sy - 1.0f;
+            const bool inside = gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f;
+            const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1), iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+            const float fxx = floorf(ix), fyy = floorf(iy);
+            const float wx1 = ix - fxx, wx0 = (fxx + 1.0f) - ix, wy1 = iy - fyy, wy0 = (fyy + 1.0f) - iy;
+            const bool x0in = fxx >= 0.f && fxx <= (float)(W - 1), x1in = fxx + 1.f >= 0.f && fxx + 1.f <= (float)(W - 1);
+            const bool y0in = fyy >= 0.f && fyy <= (float)(H - 1), y1in = fyy + 1.f >= 0.f && fyy + 1.f <= (float)(H - 1);
+            const bool any = pvalid && (x0in || x1in) && (y0in || y1in);
+            const int xa = any ? min(max((int)fxx, 0), W - 1) : 0, xb = any ? min(max((int)fxx + 1, 0), W - 1) : 0;
+            const int ya = any ? min(max((int)fyy, 0), H - 1) : 0, yb = any ? min(max((int)fyy + 1, 0), H - 1) : 0;
+            float* ov = geo + it * GI;
+            *reinterpret_cast<f32x4*>(ov) = f32x4{(any && x0in && y0in) ? wx0 * wy0 : 0.f, (any && x1in && y0in) ? wx1 * wy0 : 0.f,
+                                                  (any && x0in && y1in) ? wx0 * wy1 : 0.f, (any && x1in && y1in) ? wx1 * wy1 : 0.f};
+            *reinterpret_cast<int4*>(ov + 4) = int4{(ya * W + xa) * C * 4, (ya * W + xb) * C * 4, (yb * W + xa) * C * 4, (yb * W + xb) * C * 4};
+            ov[8] = (pvalid && inside) ? 1.0f : 0.0f;
+        }
+        // this thread's DCH gradient values: all loads in flight before the first is used
+        float gv[DCH];
+#pragma unroll
+        for (int dl = 0; dl < DCH; ++dl) gv[dl] = (valid && d0 + dl < D) ? gcol[(int64_t)(d0 + dl) * gplane] : 0.f;
+        __syncthreads();
+#pragma unroll 2
+        for (int dl = 0; dl < DCH; ++dl) {
+            const float* o = geo + (dl * NV + vl) * NSRC * GI;
+            float cnt = 1.0f, s = ref, wv[NSRC];
+            f32x4 wq[NSRC];
+#pragma unroll
+            for (int vs = 0; vs < NSRC; ++vs) {
+                wq[vs] = *reinterpret_cast<const f32x4*>(o + vs * GI);
+                const int4 gb = *reinterpret_cast<const int4*>(o + vs * GI + 4);
+                cnt += o[vs * GI + 8];
+                if ((gb.x != cur[vs].x) | (gb.y != cur[vs].y) | (gb.z != cur[vs].z) | (gb.w != cur[vs].w)) {   // new tap set: send, gather
+                    send(vs);
+                    cur[vs] = gb;
+                    const char* fb = reinterpret_cast<const char*>(feat + (int64_t)(vs + 1) * H * W * C + c);
+                    tap[vs][0] = *reinterpret_cast<const float*>(fb + gb.x); tap[vs][1] = *reinterpret_cast<const float*>(fb + gb.y);
+                    tap[vs][2] = *reinterpret_cast<const float*>(fb + gb.z); tap[vs][3] = *reinterpret_cast<const float*>(fb + gb.w);
+                }
+                wv[vs] = fmaf(tap[vs][3], wq[vs][3], fmaf(tap[vs][2], wq[vs][2], fmaf(tap[vs][1], wq[vs][1], tap[vs][0] * wq[vs][0])));
+                s += wv[vs];
+            }
+            const float inv = 1.0f / cnt;
+            const float k2 = gv[dl] * 2.0f * inv, mean = s * inv;
+            racc += k2 * (ref - mean);
+#pragma unroll
+            for (int vs = 0; vs < NSRC; ++vs) {
+                const float gw_ = k2 * (wv[vs] - mean);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[vs][k] = fmaf(gw_, wq[vs][k], acc[vs][k]);
+            }
+        }
+        __syncthreads();                                              // the next batch overwrites geo
+    }
+#pragma unroll
+    for (int vs = 0; vs < NSRC; ++vs) send(vs);
+    if (interior) g_feat[refoff] += racc;                             // the only contribution to this element of view 0
+}
+
+MVS_KNOB_DEF(g_psw_bwd_tiles, 2)   // 2: column form; dev build only: 1 = tile form, 0 = per-voxel scatter for every shape (the product uses it for V == 1)
+
+template <int NSRC>
+static int planesweep_bwd_columns_launch(const float* feat, const float* proj, const float* depth, int H, int W, int D, int pad, const float* g_cost,
+                                         int CP, int c_var, float* g_feat, hipStream_t st)
+{
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    planesweep_bwd_columns_kernel<32, NSRC><<<(unsigned)(Hp * ((Wp + 7) / 8)), 256, 0, st>>>(feat, proj, depth, H, W, D, pad, g_cost, CP, c_var, g_feat);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+#ifdef MVSNERF_DEV_KNOBS
 template <int NSRC>
 static int planesweep_bwd_tiles_launch(const float* feat, const float* proj, const float* depth, int H, int W, int D, int pad, const float* g_cost, int CP,
                                        int c_var, float* g_feat, hipStream_t st)
@@ -1653,13 +1785,25 @@ static int planesweep_bwd_tiles_launch(const float* feat, const float* proj, con
     return MVSNERF_OK;
 }
 
+#endif
+
 extern "C" int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float* proj, const float* depth, int V, int C, int H, int W, int D, int pad,
                                               const float* g_cost, int CP, int with_img, float* g_feats_cl, void* stream)
 {
     if (!feats_cl || !proj || !depth || !g_cost || !g_feats_cl || V < 1 || V > 8 || H < 2 || W < 2 || D < 1 || pad < 0) return MVSNERF_EINVAL;
     if (C != 32) return MVSNERF_EUNSUPPORTED;
     const int64_t nvox = (int64_t)D * (H + 2 * pad) * (W + 2 * pad);
-    if (g_psw_bwd_tiles && V >= 2) {
+    if (g_psw_bwd_tiles == 2 && V >= 2) {
+        hipStream_t st = (hipStream_t)stream;
+        const int cv = with_img ? 3 * V : 0;
+        switch (V - 1) {
+#define MVS_PBC(N) case N: return planesweep_bwd_columns_launch<N>(feats_cl, proj, depth, H, W, D, pad, g_cost, CP, cv, g_feats_cl, st)
+            MVS_PBC(1); MVS_PBC(2); MVS_PBC(3); MVS_PBC(4); MVS_PBC(5); MVS_PBC(6); MVS_PBC(7);
+#undef MVS_PBC
+        }
+    }
+#ifdef MVSNERF_DEV_KNOBS
+    if (g_psw_bwd_tiles == 1 && V >= 2) {
         hipStream_t st = (hipStream_t)stream;
         const int cv = with_img ? 3 * V : 0;
         switch (V - 1) {
@@ -1668,6 +1812,7 @@ extern "C" int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float
 #undef MVS_PBT
         }
     }
+#endif
     const size_t lds = (size_t)256 * ((V - 1) * 8 + 2) * sizeof(float);
     planesweep_bwd_kernel<32><<<mvs_cdiv(nvox, 256), 256, lds, (hipStream_t)stream>>>(feats_cl, proj, depth, V, H, W, D, pad, g_cost, CP,
                                                                                     with_img ? 3 * V : 0, g_feats_cl);

@@ -305,7 +305,7 @@ def test_planesweep_bwd_tiles_vs_scatter(V, H, W, pad, D, with_img):
     g_cost = torch.randn((D, Hp, Wp, CP), device=DEV, generator=g)
     L = _lib.lib()
     out, ms = {}, {}
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         assert L.mvsnerf_tune(b"psw_bwd_tiles", mode) == 0
         try:
             for rep in range(3):
@@ -319,8 +319,10 @@ def test_planesweep_bwd_tiles_vs_scatter(V, H, W, pad, D, with_img):
                 assert rc == 0
             out[mode], ms[mode] = gf, e0.elapsed_time(e1)
         finally:
-            L.mvsnerf_tune(b"psw_bwd_tiles", 1)
+            L.mvsnerf_tune(b"psw_bwd_tiles", 2)
     scale = float(out[0].abs().max())
     err = float((out[0] - out[1]).abs().max())
-    print(f"[planesweep bwd V={V} {D}x{Hp}x{Wp}] scatter {ms[0]:.3f} ms, tiles {ms[1]:.3f} ms; max diff {err:.2e} (|g| max {scale:.1f})")
-    assert scale > 0 and err < 2e-5 * scale
+    err2 = float((out[0] - out[2]).abs().max())
+    print(f"[planesweep bwd V={V} {D}x{Hp}x{Wp}] scatter {ms[0]:.3f} ms, tiles {ms[1]:.3f} ms, columns {ms[2]:.3f} ms; "
+          f"max diff tiles {err:.2e} columns {err2:.2e} (|g| max {scale:.1f})")
+    assert scale > 0 and err < 2e-5 * scale and err2 < 2e-5 * scale
