@@ -158,7 +158,7 @@ int mvsnerf_conv_transpose3d_c8_supported(int Cin, int Cout);
  * pending InPlaceABN of the producers and the U-Net skip sum are applied while staging, no materialised input.
  * Both 8-channel producers can leave the InPlaceABN statistics of their output as per-workgroup partial sums (stats_part: 2 * 8 floats per
  * workgroup, *_tiles(...) workgroups; NULL = not wanted) so that the full-resolution output is not read again; mvsnerf_abn_finalize is
- * stage 2 of mvsnerf_abn_stats on such partials (part[(b * 2 + {sum, sum of squares}) * C + c]). */
+ * stage 2 of mvsnerf_abn_stats on such partials (part[({sum, sum of squares} * C + c) * n_blocks + b]: channel-major, each channel's n_blocks partial sums contiguous). */
 int mvsnerf_conv_transpose3d_c8_fwd(const float* x1, const float* scale1, const float* shift1, const float* x2, const float* scale2, const float* shift2,
                                     int Cin, int D, int H, int W, const float* wq, float* out, float* stats_part, void* stream);
 int mvsnerf_conv_transpose3d_c8_tiles(int D, int H, int W);
@@ -229,7 +229,7 @@ int mvsnerf_conv2d_fwd(const float* x, const float* scale, const float* shift, i
                        int N, int H, int W, const float* wpacked, const float* bias, int Cout,
                        int ksize, int stride, float* out, void* stream);
 /* The 16- / 32-output-channel layers (conv1.x, conv2.x, and the stride-1 data gradients) run on the fp32 matrix cores inside
- * mvsnerf_conv2d_fwd.  conv2d_fwd_stats is that launch + the InPlaceABN partial sums of the raw output (stats_part[tiles][2][Cout] for
+ * mvsnerf_conv2d_fwd.  conv2d_fwd_stats is that launch + the InPlaceABN partial sums of the raw output (stats_part[2][Cout][tiles] for
  * mvsnerf_abn_finalize; conv2d_mfma_tiles(...) rows, 0 = the layer has no matrix-core kernel -> MVSNERF_EUNSUPPORTED). */
 int mvsnerf_conv2d_mfma_tiles(int Cin, int Cout, int N, int H, int W, int ksize, int stride);
 int mvsnerf_conv2d_fwd_stats(const float* x, const float* scale, const float* shift, int Cin, int cin_ld, int N, int H, int W,

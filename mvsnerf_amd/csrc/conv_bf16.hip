@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 3) void conv3d_k3s1_c8_bf16_kernel(const __bf1
             }
         }
     }
-    if (stats) {          // InPlaceABN partial sums of this tile: part[(tile * 2 + {sum, sum of squares}) * 8 + channel] (abn_finalize_kernel's layout)
+    if (stats) {          // InPlaceABN partial sums of this tile: abn_part_at(...) of common.h, slot = tile (abn_finalize_kernel's layout)
         __syncthreads();
         float* red = reinterpret_cast<float*>(lds);
         ssum += __shfl_xor(ssum, 16); ssq += __shfl_xor(ssq, 16);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 3) void conv3d_k3s1_c8_bf16_kernel(const __bf1
         __syncthreads();
         if (wave == 0 && lane < 16) {
             const float v = (red[lane] + red[16 + lane]) + (red[32 + lane] + red[48 + lane]);
-            stats[((int64_t)tile_id * 2 + (lane >> 3)) * 8 + (lane & 7)] = v;
+            stats[abn_part_at(lane >> 3, lane & 7, 8, tile_id, gridDim.x)] = v;
         }
     }
 }

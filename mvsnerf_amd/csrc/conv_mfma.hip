@@ -38,8 +38,8 @@ __device__ const f32x4 g_zero16 = {0.0f, 0.0f, 0.0f, 0.0f};   // what a DMA lane
 // Per-workgroup InPlaceABN statistics of an 8-channel output tile straight from the accumulators (the layer's raw output is not read
 // again by abn_partial_kernel: 150 MB for the two full-resolution layers): lane (mb, nb, i) holds values of channel 4 nb + i only, so a
 // lane sums its own values, the 8 lanes of a channel meet by xor-shuffle over the mb bits, the 4 waves in LDS; workgroup `slot` writes
-// part[(slot * 2 + {sum, sum of squares}) * 8 + channel] - the layout abn_finalize_kernel reads.
-__device__ __forceinline__ void c8_tile_stats(float s, float q, int lane, int wave, float* red /* [4][16] */, float* __restrict__ part, int slot)
+// part[abn_part_at({sum, sum of squares}, channel, 8, slot, nslots)] - the layout abn_finalize_kernel reads (common.h).
+__device__ __forceinline__ void c8_tile_stats(float s, float q, int lane, int wave, float* red /* [4][16] */, float* __restrict__ part, int slot, int nslots)
 {
 #pragma unroll
     for (int o = 8; o <= 32; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
@@ -47,7 +47,7 @@ __device__ __forceinline__ void c8_tile_stats(float s, float q, int lane, int wa
     __syncthreads();
     if (wave == 0 && lane < 16) {
         const float v = (red[lane] + red[16 + lane]) + (red[32 + lane] + red[48 + lane]);
-        part[((int64_t)slot * 2 + (lane >> 3)) * 8 + (lane & 7)] = v;
+        part[abn_part_at(lane >> 3, lane & 7, 8, slot, nslots)] = v;
     }
 }
 
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_mfma4_kernel(const floa
     }
     if (stats) {
         __syncthreads();                                          // the tiles are free: reuse their first floats
-        c8_tile_stats(ssum, ssq, lane, wave, lds4, stats, tile_id);
+        c8_tile_stats(ssum, ssq, lane, wave, lds4, stats, tile_id, gridDim.x);
     }
 }
 
@@ -499,8 +499,8 @@ __global__ __launch_bounds__(512) void conv3d_k3_mfma32_kernel(ActSrc a, int ld,
         if (stats) {                                              // InPlaceABN partial sums of this M-tile (abn_finalize_kernel's layout)
             ssum += __shfl_xor(ssum, 32); ssq += __shfl_xor(ssq, 32);
             if (kh == 0) {
-                stats[((int64_t)blockIdx.x * 2) * COUT + nb * 32 + m] = ssum;
-                stats[((int64_t)blockIdx.x * 2 + 1) * COUT + nb * 32 + m] = ssq;
+                stats[abn_part_at(0, nb * 32 + m, COUT, blockIdx.x, gridDim.x)] = ssum;
+                stats[abn_part_at(1, nb * 32 + m, COUT, blockIdx.x, gridDim.x)] = ssq;
             }
         }
     }
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_c16to8_mfma4_kernel(ActSrc x
     }
     if (stats) {
         __syncthreads();                                              // the input tile is free
-        c8_tile_stats(ssum, ssq, lane, wave, xt, stats, tile_id);
+        c8_tile_stats(ssum, ssq, lane, wave, xt, stats, tile_id, gridDim.x);
     }
 }
 
@@ -942,7 +942,8 @@ __global__ __launch_bounds__(256) void conv3d_k3_mfma16_kernel(ActSrc a, int ld,
     if (stats) {
         ssum += __shfl_xor(ssum, 16); ssq += __shfl_xor(ssq, 16);
         ssum += __shfl_xor(ssum, 32); ssq += __shfl_xor(ssq, 32);
-        if (kh == 0) { stats[(tile * 2) * COUT + m] = ssum; stats[(tile * 2 + 1) * COUT + m] = ssq; }
+        const int64_t ntiles = (nvox + 31) / 32;
+        if (kh == 0) { stats[abn_part_at(0, m, COUT, tile, ntiles)] = ssum; stats[abn_part_at(1, m, COUT, tile, ntiles)] = ssq; }
     }
 }
 

@@ -833,7 +833,7 @@ __global__ __launch_bounds__(256) void abn_partial_kernel(const float* __restric
         const int gg = c / 4, k = c % 4;
         float acc = 0.f;
         for (int j = gg; j < 256; j += G) acc += sh[j * 8 + which * 4 + k];
-        part[((int64_t)blockIdx.x * 2 + which) * C + c] = acc;
+        part[abn_part_at(which, c, C, blockIdx.x, gridDim.x)] = acc;
     }
 }
 
@@ -843,12 +843,21 @@ __global__ __launch_bounds__(256) void abn_finalize_kernel(const float* __restri
                                     float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift,
                                     float* __restrict__ mean_out, float* __restrict__ invstd_out)
 {
-    // one workgroup of 256 threads per channel: thread t adds the partials of workgroups t, t+256, ... (<= 4 independent loads; a single
-    // wavefront walking 1024 partials in 16 dependent steps made this a 8.5 us kernel, 10-18 of them per scene encode), then a
-    // fixed-order tree in LDS (deterministic), fp64 throughout
+    // one workgroup of 256 threads per channel: thread t adds the partials of slots t, t+256, ... - two contiguous runs of the
+    // channel-major partial array (abn_part_at), four independent loads in flight per run - then a fixed-order tree in LDS
+    // (deterministic), fp64 throughout
     const int c = blockIdx.x, t = threadIdx.x;
+    const float* ps = part + abn_part_at(0, c, C, 0, nblocks);
+    const float* pq = part + abn_part_at(1, c, C, 0, nblocks);
     double s = 0.0, q = 0.0;
-    for (int b = t; b < nblocks; b += 256) { s += (double)part[((int64_t)b * 2) * C + c]; q += (double)part[((int64_t)b * 2 + 1) * C + c]; }
+    int b = t;
+    for (; b + 768 < nblocks; b += 1024) {
+        const float s0 = ps[b], s1 = ps[b + 256], s2 = ps[b + 512], s3 = ps[b + 768];
+        const float q0 = pq[b], q1 = pq[b + 256], q2 = pq[b + 512], q3 = pq[b + 768];
+        s += ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+        q += ((double)q0 + (double)q1) + ((double)q2 + (double)q3);
+    }
+    for (; b < nblocks; b += 256) { s += (double)ps[b]; q += (double)pq[b]; }
     __shared__ double rs[256], rq[256];
     rs[t] = s; rq[t] = q;
     __syncthreads();
@@ -904,7 +913,7 @@ extern "C" int mvsnerf_abn_stats(const float* x, int64_t n_vox, int C, const flo
     return MVSNERF_OK;
 }
 
-// stage 2 alone, for producers that leave the per-workgroup sums themselves (part[(b * 2 + {sum, sum of squares}) * C + c], b < n_blocks)
+// stage 2 alone, for producers that leave the per-workgroup sums themselves (part[({sum, sum of squares} * C + c) * n_blocks + b], b < n_blocks)
 extern "C" int mvsnerf_abn_finalize(const float* part, int n_blocks, int C, int64_t n_vox, const float* weight, const float* bias,
                                     float* running_mean, float* running_var, float momentum, float eps,
                                     float* scale, float* shift, float* mean_out, float* invstd_out, void* stream)
@@ -1000,7 +1009,7 @@ __global__ __launch_bounds__(256) void abn_bwd_partial_kernel(const float* __res
         const int gg = c / 4, k = c % 4;
         float acc = 0.f;
         for (int j = gg; j < 256; j += G) acc += shm[j * 8 + which * 4 + k];
-        part[((int64_t)blockIdx.x * 2 + which) * C + c] = acc;
+        part[abn_part_at(which, c, C, blockIdx.x, gridDim.x)] = acc;
     }
 }
 
@@ -1009,8 +1018,17 @@ __global__ __launch_bounds__(64) void abn_bwd_finalize_kernel(const float* __res
                                                              float* __restrict__ g_weight, float* __restrict__ g_bias)
 {
     const int c = blockIdx.x, lane = threadIdx.x;
+    const float* ps = part + abn_part_at(0, c, C, 0, nblocks);
+    const float* pq = part + abn_part_at(1, c, C, 0, nblocks);
     double s = 0.0, q = 0.0;
-    for (int b = lane; b < nblocks; b += 64) { s += (double)part[((int64_t)b * 2) * C + c]; q += (double)part[((int64_t)b * 2 + 1) * C + c]; }
+    int b = lane;
+    for (; b + 192 < nblocks; b += 256) {                              // contiguous runs (channel-major partials), four loads in flight
+        const float s0 = ps[b], s1 = ps[b + 64], s2 = ps[b + 128], s3 = ps[b + 192];
+        const float q0 = pq[b], q1 = pq[b + 64], q2 = pq[b + 128], q3 = pq[b + 192];
+        s += ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+        q += ((double)q0 + (double)q1) + ((double)q2 + (double)q3);
+    }
+    for (; b < nblocks; b += 64) { s += (double)ps[b]; q += (double)pq[b]; }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { s += __shfl_xor(s, d); q += __shfl_xor(q, d); }
     if (lane != 0) return;

@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ActSrc a, int ld, int 
     if (stats) {
         ssum += __shfl_xor(ssum, 32); ssq += __shfl_xor(ssq, 32);
         if (COUT == 16) { ssum += __shfl_xor(ssum, 16); ssq += __shfl_xor(ssq, 16); }
-        if (kh == 0) { stats[(tile * 2) * COUT + m] = ssum; stats[(tile * 2 + 1) * COUT + m] = ssq; }
+        const int64_t ntiles = (npix + MT - 1) / MT;
+        if (kh == 0) { stats[abn_part_at(0, m, COUT, tile, ntiles)] = ssum; stats[abn_part_at(1, m, COUT, tile, ntiles)] = ssq; }
     }
 }
 
@@ -215,7 +216,7 @@ static int conv2d_mfma_launch(const ActSrc& a, int Cin, int cin_ld, int N, int H
 }
 
 // mvsnerf_conv2d_fwd of a layer with a matrix-core kernel (mvsnerf_conv2d_mfma_tiles > 0; no bias) that also leaves the InPlaceABN partial
-// sums of its raw output: stats_part[tiles][2][Cout] for mvsnerf_abn_finalize
+// sums of its raw output: stats_part[2][Cout][tiles] for mvsnerf_abn_finalize
 extern "C" int mvsnerf_conv2d_fwd_stats(const float* x, const float* scale, const float* shift, int Cin, int cin_ld, int N, int H, int W,
                                         const float* wpacked, int Cout, int ksize, int stride, float* out, float* stats_part, void* stream)
 {

@@ -3,7 +3,7 @@
 // ATen launches).
 #include "common.h"
 
-extern "C" int mvsnerf_abi_version(void) { return 8; }
+extern "C" int mvsnerf_abi_version(void) { return 9; }
 
 // mlp.hip: gather + MLP in one launch (three source views, fp32 kernel); MVSNERF_EUNSUPPORTED -> take the two-launch path
 int mvs_mlp_fwd_gather(const float* packed, const float* vol, int D, int H, int W, const float* imgs_nhwc4, int V, int IH, int IW,

@@ -25,7 +25,7 @@ def test_library_builds_and_exports_header_symbols():
     missing = [n for n in names if not hasattr(l, n)]
     assert not missing, f"declared in the header but not exported: {missing}"
     assert sorted(_lib.SIGNATURES) == names, (set(names) ^ set(_lib.SIGNATURES))
-    assert _lib.lib().mvsnerf_abi_version() == 8
+    assert _lib.lib().mvsnerf_abi_version() == 9
     # no A/B switches and no diagnostics state in the product library (csrc/knobs.h: dev build only)
     exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert not re.search(r"mvsnerf_tune|mvsnerf_debug|\bg_(conv|mlp|psw|split)_", exported)

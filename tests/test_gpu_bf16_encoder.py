@@ -74,7 +74,7 @@ def test_conv0_bf16_forward_and_dgrad_vs_emulation(cin, dims):
     print(f"[conv0 bf16 fwd cin={cin} {D}x{H}x{W}] {ms_f:.3f} ms; max err vs emulation {err:.2e} (|out| max {scale:.1f})")
     assert torch.isfinite(out).all() and err < (2e-5 if big else 3e-6) * scale
     # InPlaceABN partial sums of the tiles
-    s = part.view(ntile, 2, 8).double().sum(0)
+    s = part.view(2, 8, ntile).double().sum(2)          # channel-major partials: [{sum, sum of squares}][channel][tile]
     assert float((s[0] - out.double().sum((0, 1, 2))).abs().max()) < 1e-6 * float(out.double().abs().sum((0, 1, 2)).max())
     assert float((s[1] - (out.double() ** 2).sum((0, 1, 2))).abs().max()) < 1e-6 * float((out.double() ** 2).sum((0, 1, 2)).max())
     # ---- data gradient of the last 32 input channels (the variance channels)
