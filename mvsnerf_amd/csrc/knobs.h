@@ -18,6 +18,7 @@
 MVS_KNOB_DECL(g_conv_mfma, 1)       // convolutions / weight gradients on the matrix cores where a kernel exists (0: the VALU kernels)
 MVS_KNOB_DECL(g_conv_tiled, 1)      // LDS-tiled VALU 3x3x3 kernels (0: one thread per voxel through L1)
 MVS_KNOB_DECL(g_conv_xcd, 1)        // tiles renumbered so that an XCD walks a contiguous range (0: round-robin)
+MVS_KNOB_DECL(g_psw_fwd_reuse, 1)    // plane sweep: a workgroup walks 64 columns x 4 planes and keeps unchanged taps in registers; 0: 256 voxels of one plane
 MVS_KNOB_DECL(g_psw_bwd_tiles, 2)   // plane-sweep backward: 2 column form (taps and sums in registers along depth), 1 LDS-patch tiles, 0 one float atomic per tap
 MVS_KNOB_DECL(g_mlp_variant, 3)     // 3: 32 points/wave, 2 waves/SIMD, LDS-DMA weight slabs; 0/1/2/4: the dropped schedules
 MVS_KNOB_DECL(g_mlp_gather, 0)      // 1: gen_pts_feats in the MLP kernel's prologue (measured 1 % slower)

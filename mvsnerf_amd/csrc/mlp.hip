@@ -711,6 +711,7 @@ extern "C" int mvsnerf_tune(const char* key, int value)
 {
     if (!key) return MVSNERF_EINVAL;
     if (__builtin_strcmp(key, "conv_tiled") == 0) { g_conv_tiled = value ? 1 : 0; return MVSNERF_OK; }
+    if (__builtin_strcmp(key, "psw_fwd_reuse") == 0) { g_psw_fwd_reuse = value ? 1 : 0; return MVSNERF_OK; }
     if (__builtin_strcmp(key, "psw_bwd_tiles") == 0) { g_psw_bwd_tiles = value < 0 ? 0 : (value > 2 ? 2 : value); return MVSNERF_OK; }
     if (__builtin_strcmp(key, "conv_xcd") == 0) { g_conv_xcd = value ? 1 : 0; return MVSNERF_OK; }
     if (__builtin_strcmp(key, "conv_mfma") == 0) { g_conv_mfma = value ? 1 : 0; return MVSNERF_OK; }
