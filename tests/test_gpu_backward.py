@@ -286,16 +286,20 @@ def test_bf16_training_vs_torch_emulation():
     assert not bad, f"vs fp32 oracle: {bad}\nall: {errs_f}"
 
 
-@pytest.mark.parametrize("V,H,W,pad,D,with_img", [(3, 30, 41, 3, 10, True), (5, 16, 24, 4, 19, True), (2, 32, 32, 0, 8, False), (3, 128, 160, 24, 128, False)])
-def test_planesweep_bwd_vs_float64_autograd(V, H, W, pad, D, with_img):
-    """The plane-sweep backward (register sum over depth for the reference view, 64-bit fixed-point LDS patches for the source views)
-    against float64 autograd through a torch restatement of models.py:839-893 on the same GPU.  The last case is the training shape
-    (timed).  (A/B against the per-voxel scatter kernel it replaced: scratch/dev_tests.)"""
+@pytest.mark.parametrize("V,H,W,pad,D,with_img,bscale", [(3, 30, 41, 3, 10, True, 1.0), (5, 16, 24, 4, 19, True, 1.0), (2, 32, 32, 0, 8, False, 1.0),
+                                                        (8, 20, 28, 2, 9, True, 1.0), (3, 24, 33, 2, 37, False, 6.0), (3, 128, 160, 24, 128, False, 1.0)])
+def test_planesweep_bwd_vs_float64_autograd(V, H, W, pad, D, with_img, bscale):
+    """The plane-sweep backward (column form: a thread walks the depth planes of one voxel column and channel with the taps and the
+    gradient sums of every source view in registers, memory is touched only when the tap set changes) against float64 autograd through
+    a torch restatement of models.py:839-893 on the same GPU.  Cases: 1, 2, 4 and 7 source views; widths that are not a multiple of the
+    8-column workgroup; depths that are not a multiple of the 16-plane geometry batch; bscale = 6: baselines six times wider, so the taps
+    move by more than a pixel per plane and the send / gather path runs on nearly every plane.  The last case is the training shape
+    (timed).  (A/B against the scatter and LDS-patch kernels it replaced: scratch/dev_tests.)"""
     import torch.nn.functional as F
     from mvsnerf_amd import _lib
     from mvsnerf_amd.ops import stream_ptr
     from mvsnerf_amd.synth import make_rig
-    base = (0.0, 0.25, -0.25, 0.12, -0.12, 0.1)
+    base = tuple(b * bscale for b in (0.0, 0.25, -0.25, 0.12, -0.12, 0.1, -0.3, 0.3, 0.2))
     rig = make_rig(H * 4, W * 4, n_views=V + 1, seed=77, baselines=base[:V + 1], rot_deg=2.0, smooth=True)
     proj = rig["proj_mats"][0, :V].contiguous().to(DEV)
     nf = rig["near_fars"][0, 0]

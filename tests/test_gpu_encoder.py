@@ -107,6 +107,32 @@ def test_midsize_vs_oracle(mvs):
     assert ok, f"CostRegNet vs oracle {e}"
 
 
+@pytest.mark.parametrize("V,bscale,with_img,pad,D", [(3, 6.0, True, 3, 21), (5, 1.0, True, 2, 10), (2, 3.0, False, 0, 13), (8, 1.0, True, 1, 6)])
+def test_planesweep_tap_reuse_vs_oracle(mvs, V, bscale, with_img, pad, D):
+    """planesweep_kernel walks a voxel column through 4 depth planes with the source taps in registers and gathers again only when a
+    tap address changes.  Both paths against the CPU oracle, bit for bit: bscale = 1 rigs move the taps by a fraction of a pixel per
+    plane (mostly reuse), bscale = 3 / 6 by more than a pixel (a gather on nearly every plane); 1, 2, 4 and 7 source views; depths that
+    are not a multiple of 4; widths that are not a multiple of the 16-column wave."""
+    from mvsnerf_amd.synth import make_rig
+    from oracle import mvsnerf_oracle as O
+    H, W = 22, 29
+    base = tuple(b * bscale for b in (0.0, 0.25, -0.25, 0.12, -0.12, 0.1, -0.3, 0.3, 0.2))
+    rig = make_rig(H * 4, W * 4, n_views=V + 1, seed=31, baselines=base[:V + 1], rot_deg=2.0, smooth=True)
+    imgs, proj = rig["images"][:, :V], rig["proj_mats"][:, :V]
+    feats = torch.randn((1, V, 32, H, W), generator=torch.Generator().manual_seed(V))
+    dv = O.depth_planes(2.125, 4.525, D)
+    with torch.no_grad():
+        if with_img:
+            cost_ref, masks_ref = O.build_volume_costvar_img(imgs, feats, proj, dv, pad)
+            cost, masks = mvs.build_volume_costvar_img(imgs.to(DEV), feats.to(DEV), proj.to(DEV), dv.to(DEV), pad=pad)
+            assert maxabs(cost.cpu()[:, :3 * V], cost_ref[:, :3 * V]) < 1e-6      # thumbnails inherit the resize's 1e-7
+        else:
+            cost_ref, masks_ref = O.build_volume_costvar(feats, proj, dv, pad)
+            cost, masks = mvs.build_volume_costvar(feats.to(DEV), proj.to(DEV), dv.to(DEV), pad=pad)
+    assert torch.equal(masks.cpu().reshape(masks_ref.shape), masks_ref)
+    assert bool((cost.cpu()[:, -32:] == cost_ref[:, -32:]).all()), maxabs(cost.cpu()[:, -32:], cost_ref[:, -32:])
+
+
 def test_abn_stats_and_conv_vs_torch_full_size():
     """Config-2 size (128x176x208): the train-mode ABN statistics and conv0 against torch fp32 on the same GPU."""
     import torch.nn.functional as F
