@@ -32,9 +32,11 @@ __global__ __launch_bounds__(256) void volume_sample_c8_kernel(
         const int64_t p = p0 + j;
         const int64_t pc = p < P ? p : (P - 1);
         // same op order as the reference: grid = ndc*2-1 (utils.py:381); unnormalise ((g+1)/2)*(size-1)
-        const float gx = ndc[pc * 3 + 0] * 2.0f - 1.0f;
-        const float gy = ndc[pc * 3 + 1] * 2.0f - 1.0f;
-        const float gz = ndc[pc * 3 + 2] * 2.0f - 1.0f;
+        typedef float f32x3 __attribute__((ext_vector_type(3)));
+        const f32x3 nd = *reinterpret_cast<const f32x3*>(ndc + pc * 3);            // one 12-byte load (4-byte aligned is enough for dwordx3)
+        const float gx = nd[0] * 2.0f - 1.0f;
+        const float gy = nd[1] * 2.0f - 1.0f;
+        const float gz = nd[2] * 2.0f - 1.0f;
         const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
         const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
         const float iz = ((gz + 1.0f) / 2.0f) * (float)(D - 1);
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void volume_sample_c8_kernel(
             const bool in = x_in && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
             vw[k] = (wx * (yc ? (iy - fy) : ((fy + 1.0f) - iy))) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
             const float* src = in ? vol + vox_off8<SMALL>((int)czf, (int)cyf, (int)cxf, H, W) + ch : reinterpret_cast<const float*>(&g_zero_tap);
-            vv[k] = *reinterpret_cast<const f32x4*>(src);
+            vv[k] = ldg16(src);
         }
         acc[j] = trilinear_fold_x0_lane(vv, vw);                                  // ATen's term order and roundings (sample_dev.h); valid in the x0 lanes
     }
@@ -271,20 +273,22 @@ __global__ __launch_bounds__(256) void gather_fused_kernel(GatherArgs a)
         const bool in = x_in && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
         vw[k] = (wx * (yc ? (iy - fy) : ((fy + 1.0f) - iy))) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
         const float* src = in ? a.vol + vox_off8<SMALL>((int)czf, (int)cyf, (int)cxf, H, W) + ch : reinterpret_cast<const float*>(&g_zero_tap);
-        vv[k] = *reinterpret_cast<const f32x4*>(src);
+        vv[k] = ldg16(src);
     }
     // ---- colour lookup of view q (+4): issue its taps before the volume taps are consumed
-    const float px = a.pts[p * 3 + 0], py = a.pts[p * 3 + 1], pz = a.pts[p * 3 + 2];
+    typedef float f32x3 __attribute__((ext_vector_type(3)));
+    const f32x3 pp = *reinterpret_cast<const f32x3*>(a.pts + p * 3);              // one 12-byte load
+    const float px = pp[0], py = pp[1], pz = pp[2];
     float* frow = a.feat + p * (idx_t)a.feat_stride;
     for (int v = q; v < a.V; v += 4) {
         const int IW = a.IW, IH = a.IH;
         const ColorTap t = color_project(px, py, pz, a.w2c + v * 16, a.Kmat + v * 9, IW, IH);
         const float* pl = a.img + (SMALL ? (int64_t)((__umul24(v * IH + t.y0, IW) + t.x0) << 2) : (((int64_t)v * IH + t.y0) * IW + t.x0) * 4);
         const float* zt = reinterpret_cast<const float*>(&g_zero_tap);
-        const f32x4 t_nw = *reinterpret_cast<const f32x4*>(pl);
-        const f32x4 t_ne = *reinterpret_cast<const f32x4*>(t.x1in ? pl + 4 : zt);
-        const f32x4 t_sw = *reinterpret_cast<const f32x4*>(t.y1in ? pl + (int64_t)IW * 4 : zt);
-        const f32x4 t_se = *reinterpret_cast<const f32x4*>((t.x1in && t.y1in) ? pl + (int64_t)IW * 4 + 4 : zt);
+        const f32x4 t_nw = ldg16(pl);
+        const f32x4 t_ne = ldg16(t.x1in ? pl + 4 : zt);
+        const f32x4 t_sw = ldg16(t.y1in ? pl + (int64_t)IW * 4 : zt);
+        const f32x4 t_se = ldg16((t.x1in && t.y1in) ? pl + (int64_t)IW * 4 + 4 : zt);
         f32x4 o;
 #pragma unroll
         for (int c = 0; c < 3; ++c) o[c] = color_blend(t, t_nw[c], t_ne[c], t_sw[c], t_se[c]);

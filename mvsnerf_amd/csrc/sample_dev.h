@@ -7,6 +7,14 @@
 // A 16-byte block of zeros: out-of-volume taps read it instead of branching around the load (zeros padding, exactly).
 static __device__ const f32x4 g_zero_tap = {0.0f, 0.0f, 0.0f, 0.0f};
 
+// 16-byte load through the GLOBAL address space.  A pointer chosen between a kernel argument and &g_zero_tap reaches the load as a generic
+// pointer and becomes flat_load_dwordx4 (aperture check, counts against lgkmcnt as well as vmcnt); both targets are global memory.
+__device__ __forceinline__ f32x4 ldg16(const float* p)
+{
+    typedef const f32x4 __attribute__((address_space(1))) * gptr;
+    return *(gptr)p;
+}
+
 // float offset of voxel (z,y,x)'s 8-channel vector.  SMALL: 32-bit arithmetic on full-rate 24-bit multiplies (the launcher
 // checks D*H < 2^24, W < 2^24, D*H*W*8 < 2^31); v_mul_lo_u32 / v_mad_u64_u32 are quarter-rate and were 40 % of the lookup's
 // instruction slots.
@@ -131,8 +139,8 @@ __device__ __forceinline__ void trilinear8_of(const float* __restrict__ vol, int
         const bool in = (cxf >= 0.0f) && (cxf <= (float)(W - 1)) && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
         const float w = ((xc ? (ix - fx) : ((fx + 1.0f) - ix)) * (yc ? (iy - fy) : ((fy + 1.0f) - iy))) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
         const float* src = in ? vol + vox_off8<SMALL>((int)czf, (int)cyf, (int)cxf, H, W) : reinterpret_cast<const float*>(&g_zero_tap);
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(in ? src + 4 : src);
+        const f32x4 v0 = ldg16(src);
+        const f32x4 v1 = ldg16(in ? src + 4 : src);
         out[0] = out[0] + v0 * w;
         out[1] = out[1] + v1 * w;
     }
