@@ -1,8 +1,11 @@
-"""One generalizable-training run at config-3 shapes for rocprofv3 (2 warm-up + N timed steps).  usage: train_prof.py [amp] [steps]"""
+"""One generalizable-training run at config-3 shapes for rocprofv3 (2 warm-up + N timed steps).  usage: train_prof.py [amp] [steps]
+MVS_LIB=<path of another build of the library> selects it (same-box A/B of a kernel change)."""
 import sys, time, torch, os
 sys.path.insert(0, '.')
 import numpy as np
-from mvsnerf_amd import train
+from mvsnerf_amd import train, _lib
+if os.environ.get('MVS_LIB'):
+    _lib.LIB_PATH = os.environ['MVS_LIB']; _lib._lib = None
 amp = len(sys.argv) > 1 and sys.argv[1] == "amp"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = 'cuda'
