@@ -335,9 +335,15 @@ struct WgradArgs {
 
 // BF: both operand rows are rounded to bf16 on load and the 32 points of a tile are contracted by two v_mfma_f32_32x32x16_bf16
 // (lane (i, kkh) holds points [16 kkh, 16 kkh + 16): MFMA m takes its points 8m..8m+7 - the same assignment for A and B).
+// Weight-gradient GEMMs of the SAME shape run as ONE launch (blockIdx.y = job): a GEMM alone is <= 256 workgroups of one wave per SIMD,
+// i.e. latency-bound; two workgroups of different layers per CU cover each other's waits (the registers allow two).
+constexpr int WG_MULTI = 5;
+struct WgradJobs { WgradArgs j[WG_MULTI]; };
+
 template <int RA_BLOCKS, int NBB, bool BF>
-__global__ __launch_bounds__(64 * RA_BLOCKS) void mlp_wgrad_kernel(WgradArgs w)
+__global__ __launch_bounds__(64 * RA_BLOCKS) void mlp_wgrad_kernel(WgradJobs jobs)
 {
+    const WgradArgs& w = jobs.j[blockIdx.y];
     const int lane = threadIdx.x & 63, ablk = threadIdx.x >> 6;
     const int i = lane & 31, kkh = lane >> 5;
     constexpr int RB = NBB * 32;
@@ -445,9 +451,9 @@ extern "C" int mvsnerf_partial_sum_multi(int n_jobs, const float* const* partial
                                          float* scratch, void* stream);
 
 // ------------------------------------------------------------------------------------------ host orchestration
-static int launch_wgrad(int ra_blocks, int nbb, const WgradArgs& w, int grid, hipStream_t st, bool bf)
+static int launch_wgrad(int ra_blocks, int nbb, const WgradJobs& w, int n_jobs, int grid, hipStream_t st, bool bf)
 {
-#define MVS_WG(RAB, NB) do { if (bf) mlp_wgrad_kernel<RAB, NB, true><<<grid, 64 * RAB, 0, st>>>(w); else mlp_wgrad_kernel<RAB, NB, false><<<grid, 64 * RAB, 0, st>>>(w); } while (0)
+#define MVS_WG(RAB, NB) do { if (bf) mlp_wgrad_kernel<RAB, NB, true><<<dim3(grid, n_jobs), 64 * RAB, 0, st>>>(w); else mlp_wgrad_kernel<RAB, NB, false><<<dim3(grid, n_jobs), 64 * RAB, 0, st>>>(w); } while (0)
     switch (ra_blocks * 10 + nbb) {
         case 42: MVS_WG(4, 2); break;
         case 44: MVS_WG(4, 4); break;
@@ -535,6 +541,10 @@ static int mlp_bwd_impl(bool bf, const float* packed_fwd, const float* packed_bw
     ScatterJobs SJ;
     SJ.n = 0;
     int sblk = 0;
+    // GEMMs are queued by shape (ra_blocks, nbb) and every shape is launched once, its jobs side by side (blockIdx.y)
+    constexpr int N_SHAPES = 6;
+    int shape_key[N_SHAPES], shape_n[N_SHAPES], n_shapes = 0;
+    WgradJobs shape_jobs[N_SHAPES];
     auto gemm = [&](int a_slot, int ra_blocks, int b_slot0, int nblk0, int b_slot1, int nbb, int RA, int RB) -> int {
         WgradArgs w{gslots, ts_g, a_slot, saved, ts_s, b_slot0, nblk0, b_slot1, n_tiles, part_next};
         const int64_t n_out = (int64_t)RA * (RB + 1);
@@ -542,7 +552,16 @@ static int mlp_bwd_impl(bool bf, const float* packed_fwd, const float* packed_bw
         ++n_gemm;
         part_next += (size_t)grid * n_out;
         red_next += n_out;
-        return launch_wgrad(ra_blocks, nbb, w, grid, st, bf);
+        const int key = ra_blocks * 10 + nbb;
+        int k = 0;
+        while (k < n_shapes && shape_key[k] != key) ++k;
+        if (k == n_shapes) {
+            if (n_shapes == N_SHAPES) return MVSNERF_EUNSUPPORTED;
+            shape_key[k] = key; shape_n[k] = 0; ++n_shapes;
+        }
+        if (shape_n[k] == WG_MULTI) return MVSNERF_EUNSUPPORTED;
+        shape_jobs[k].j[shape_n[k]++] = w;
+        return MVSNERF_OK;
     };
     auto scatter = [&](int RA, int RB, const int* rowmap, const int* colmap, float* w_out, int ld, float* b_out) {     // of the LAST gemm's sums
         const int j = SJ.n++;
@@ -575,6 +594,8 @@ static int mlp_bwd_impl(bool bf, const float* packed_fwd, const float* packed_bw
     scatter(32, 192, M_G4RGB, maps + 928, gw[10], 64, gb[10]);          // 192 entries: [act64 | -1 x128]
     scatter(32, 192, M_G4A, maps + 1120, gw[8], WIDTH, gb[8]);          // 192 entries: [-1 x64 | act128]
     SJ.blk[SJ.n] = sblk;
+    for (int k = 0; k < n_shapes; ++k)
+        if ((rc = launch_wgrad(shape_key[k] / 10, shape_key[k] % 10, shape_jobs[k], shape_n[k], grid, st, bf))) return rc;
     if ((rc = mvsnerf_partial_sum_multi(n_gemm, ps_part, ps_np, ps_no, ps_dst, red_scratch, stream))) return rc;
     mlp_wgrad_scatter_multi_kernel<<<sblk, 256, 0, st>>>(SJ);
     MVS_LAUNCH_CHECK();
