@@ -1153,4 +1153,42 @@ def bench_encode(rig, dev, pad, iters=6):
     med = [sorted(r[i] for r in rec[1:] or rec)[len(rec[1:] or rec) // 2] for i in range(4)]
     times = {"feature_net": round(med[0] * 1e3, 3), "planesweep_costvar": round(med[1] * 1e3, 3), "cost_reg_net": round(med[2] * 1e3, 3),
              "total": round(med[3] * 1e3, 3), "iters": len(rec)}
+    # the product call, free-running: MVSNet.forward back to back, host synchronisation only around the whole batch (the per-stage numbers
+    # above stop the queue three times per encode, and the first launches after each stop start late)
+    with torch.no_grad():
+        net(imgs, proj, nf, pad=pad)
+        single = []
+        for _ in range(iters):                                       # one isolated call: launch to completion, nothing overlapped
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            net(imgs, proj, nf, pad=pad)
+            torch.cuda.synchronize(); single.append(time.perf_counter() - t0)
+        times["forward_single_call"] = round(sorted(single)[len(single) // 2] * 1e3, 3)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(iters):
+            vol_f = net(imgs, proj, nf, pad=pad)[0]
+        torch.cuda.synchronize()
+        times["forward_free_running"] = round((time.perf_counter() - t0) / iters * 1e3, 3)
+        times["note"] = ("feature_net / planesweep_costvar / cost_reg_net / total: stage by stage with a host synchronisation after each stage "
+                         "(comparable with earlier rounds); forward_single_call: MVSNet.forward, the product call, one isolated call; "
+                         "forward_free_running: the same call back to back")
+        # the same forward captured ONCE into a hipGraph and replayed (torch.cuda.CUDAGraph: every launch of the encode - ~80 kernels -
+        # is issued by the GPU's own scheduler, no Python / ctypes launch path in between)
+        try:
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    vol_g = net(imgs, proj, nf, pad=pad)[0]
+            torch.cuda.current_stream().wait_stream(side)
+            g.replay(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                g.replay()
+            torch.cuda.synchronize()
+            times["forward_hipgraph_replay"] = round((time.perf_counter() - t0) / iters * 1e3, 3)
+            times["hipgraph_volume_equals_eager"] = bool(torch.equal(vol_g, vol_f))
+        except Exception as e:                                       # capture is an extra: the eager numbers stand on their own
+            times["forward_hipgraph_replay"] = None
+            times["hipgraph_error"] = str(e)[:200]
     return vol, times
