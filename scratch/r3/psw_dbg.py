@@ -1,3 +1,9 @@
+"""Ablation of the plane-sweep forward kernel ("an ablation said why").  NOT runnable against the committed sources: it
+drove a temporary `psw_dbg` bit mask that was patched into planesweep_kernel (the 64-column x 4-plane, 256-thread form of that moment) for
+one measurement and removed again:
+    bit 0: the flush keeps its LDS reads but skips the global stores        bit 1: no mask stores
+    bit 2: phase 2 skips the source-view loop (no gathers, no blends)       bit 3: phase 1 skips the source-view loop (no divisions)
+Measured (config 2, ms): 0 -> 0.360, 1 -> 0.326, 2 -> 0.348, 4 -> 0.221, 8 -> 0.314, 12 -> 0.192, 7 -> 0.202, 15 -> 0.173."""
 import ctypes, os, sys
 sys.path.insert(0, '.')
 import torch
