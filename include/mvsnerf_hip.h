@@ -120,6 +120,12 @@ int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const float* shift1
                        const float* x2, const float* scale2, const float* shift2,
                        int Cin, int cin_ld, int D, int H, int W, const float* wpacked, int Cout, int stride,
                        float* out, void* stream);
+/* conv2 of CostRegNet (16 -> 16, stride 1; models.py:736 ConvBnReLU3D -> InPlaceABN) with the InPlaceABN partial sums of its raw output from the
+ * same launch: stats_part[2][16][mvsnerf_conv3d_tiled_tiles(D, H, W)] floats for mvsnerf_abn_finalize.  One lazily-activated source; other
+ * shapes return MVSNERF_EUNSUPPORTED. */
+int mvsnerf_conv3d_tiled_tiles(int D, int H, int W);
+int mvsnerf_conv3d_fwd_stats(const float* x1, const float* scale1, const float* shift1, int Cin, int cin_ld, int D, int H, int W,
+                             const float* wpacked, int Cout, int stride, float* out, float* stats_part, void* stream);
 /* conv0 of CostRegNet (models.py:756; k3, stride 1, Cout = 8, raw input) on v_mfma_f32_4x4x1_16B_f32, input in channel
  * blocks of four (see mvsnerf_planesweep_costvar_blocked_fwd), Cin = 4*ceil((32+3V)/4) channels of which the first Cin_real = 32+3V exist
  * (products with the zero padding are skipped).  Weights: wq[ci/4][tap][co][4] = mvsnerf_conv3d_pack_weights_c8 of the
@@ -151,6 +157,11 @@ int mvsnerf_conv3d_mfma_tiles(int D, int H, int W, int stride);
  * mvsnerf_conv3d_pack_weights_mfma; raw out[2D][2H][2W][Cout]. */
 int mvsnerf_conv_transpose3d_mfma_supported(int Cin, int Cout);
 int mvsnerf_conv_transpose3d_mfma_fwd(const float* x, int Cin, int D, int H, int W, const float* w32, int Cout, float* out, void* stream);
+/* ... and the InPlaceABN partial sums of the raw output from the same launch (conv7 / conv9: models.py:739-746 feed an InPlaceABN): stats_part
+ * [2][Cout][mvsnerf_conv_transpose3d_mfma_tiles(Cin, Cout, D, H, W)] floats for mvsnerf_abn_finalize (0 tiles: layer not built). */
+int mvsnerf_conv_transpose3d_mfma_tiles(int Cin, int Cout, int D, int H, int W);
+int mvsnerf_conv_transpose3d_mfma_fwd_stats(const float* x, int Cin, int D, int H, int W, const float* w32, int Cout, float* out,
+                                            float* stats_part, void* stream);
 /* The 16 -> 8 layer (conv11, and conv1's data gradient) without padded products on v_mfma_f32_4x4x1 (the parity-class form above spends
  * 44 % of its products on zero weights at 8 output channels).  wq: [ci/4][tap][co][4] = mvsnerf_pack_weights_multi kind 1 of the layer. */
 int mvsnerf_conv_transpose3d_c8_supported(int Cin, int Cout);
@@ -229,8 +240,9 @@ int mvsnerf_conv2d_fwd(const float* x, const float* scale, const float* shift, i
                        int N, int H, int W, const float* wpacked, const float* bias, int Cout,
                        int ksize, int stride, float* out, void* stream);
 /* The 16- / 32-output-channel layers (conv1.x, conv2.x, and the stride-1 data gradients) run on the fp32 matrix cores inside
- * mvsnerf_conv2d_fwd.  conv2d_fwd_stats is that launch + the InPlaceABN partial sums of the raw output (stats_part[2][Cout][tiles] for
- * mvsnerf_abn_finalize; conv2d_mfma_tiles(...) rows, 0 = the layer has no matrix-core kernel -> MVSNERF_EUNSUPPORTED). */
+ * mvsnerf_conv2d_fwd.  conv2d_fwd_stats is a layer's launch + the InPlaceABN partial sums of the raw output (stats_part[2][Cout][tiles] for
+ * mvsnerf_abn_finalize): the matrix-core layers and the two full-resolution 8-channel layers conv0.0 / conv0.1 (VALU kernel, 16 x 16 pixel
+ * tiles).  conv2d_mfma_tiles(...) = the number of partial-sum rows that launch leaves; 0 = this layer cannot -> MVSNERF_EUNSUPPORTED. */
 int mvsnerf_conv2d_mfma_tiles(int Cin, int Cout, int N, int H, int W, int ksize, int stride);
 int mvsnerf_conv2d_fwd_stats(const float* x, const float* scale, const float* shift, int Cin, int cin_ld, int N, int H, int W,
                              const float* wpacked, int Cout, int ksize, int stride, float* out, float* stats_part, void* stream);

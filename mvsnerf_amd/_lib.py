@@ -98,6 +98,10 @@ SIGNATURES = {
     "mvsnerf_conv3d_mfma_tiles": (_c_i, [_c_i] * 4),
     "mvsnerf_conv_transpose3d_mfma_supported": (_c_i, [_c_i, _c_i]),
     "mvsnerf_conv_transpose3d_mfma_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_conv3d_tiled_tiles": (_c_i, [_c_i, _c_i, _c_i]),
+    "mvsnerf_conv3d_fwd_stats": (_c_i, [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_conv_transpose3d_mfma_fwd_stats": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_conv_transpose3d_mfma_tiles": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_i]),
     "mvsnerf_conv_transpose3d_c8_supported": (_c_i, [_c_i, _c_i]),
     "mvsnerf_conv3d_c8_blocked_tiles": (_c_i, [_c_i] * 3),
     "mvsnerf_conv3d_c8_blocked_fwd_stats": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_fp]),

@@ -521,7 +521,8 @@ __global__ __launch_bounds__(512) void conv3d_k3_mfma32_kernel(ActSrc a, int ld,
 // kernel), one wave per tile and no reduction at all is the right shape there.
 template <int CIN, int COUT, int WAVES, int TPW>
 __global__ __launch_bounds__(64 * WAVES * TPW) void convT3d_k3s2_mfma32_kernel(const float* __restrict__ x, int Di, int Hi, int Wi,
-                                                                              const float* __restrict__ w32, float* __restrict__ out)
+                                                                              const float* __restrict__ w32, float* __restrict__ out,
+                                                                              float* __restrict__ stats)
 {
     constexpr int NCLS = 32 / COUT, MD = NCLS == 1 ? 0 : NCLS == 2 ? 1 : 2;      // merged dimensions: none | x | y and x
     constexpr int CB = CIN / 8;
@@ -582,6 +583,7 @@ __global__ __launch_bounds__(64 * WAVES * TPW) void convT3d_k3s2_mfma32_kernel(c
     }
     if (wave == 0) {
         const int Ho = 2 * Hi, Wo = 2 * Wi;
+        float ssum = 0.f, ssq = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = acc[r];
@@ -594,6 +596,19 @@ __global__ __launch_bounds__(64 * WAVES * TPW) void convT3d_k3s2_mfma32_kernel(c
             if (ip < nin) {
                 const int jx = (int)(ip % Wi), jy = (int)((ip / Wi) % Hi), jz = (int)(ip / ((int64_t)Wi * Hi));
                 out[((((int64_t)(2 * jz + pz)) * Ho + 2 * jy + py_c) * Wo + 2 * jx + px_c) * COUT + co] = v;
+                ssum += v; ssq = fmaf(v, v, ssq);
+            }
+        }
+        if (stats) {
+            // InPlaceABN partial sums of this (M-tile, outer parity class): the lanes of a channel are its two halves (kh) and its NCLS merged
+            // parity classes (columns co + COUT icls); slot = tile * gridDim.y + class, gridDim.x * TPW * gridDim.y slots (abn_part_at)
+            ssum += __shfl_xor(ssum, 32); ssq += __shfl_xor(ssq, 32);
+#pragma unroll
+            for (int o = COUT; o < 32; o <<= 1) { ssum += __shfl_xor(ssum, o); ssq += __shfl_xor(ssq, o); }
+            if (lane < COUT) {
+                const int64_t nslots = (int64_t)gridDim.x * TPW * gridDim.y, slot = tile * gridDim.y + blockIdx.y;
+                stats[abn_part_at(0, co, COUT, slot, nslots)] = ssum;
+                stats[abn_part_at(1, co, COUT, slot, nslots)] = ssq;
             }
         }
     }
@@ -986,10 +1001,18 @@ int mvs_convT3d_c16to8_mfma4(const ActSrc& xa, const ActSrc& xb, int D, int H, i
 }
 
 // transposed convolution; plain (materialised) input x[D][H][W][Cin]
-int mvs_convT3d_mfma32(const float* x, int Cin, int D, int H, int W, const float* w32, int Cout, float* out, hipStream_t st)
+// rows of InPlaceABN partial sums the kernel leaves (stats != NULL): (M-tiles rounded up to the workgroup's TPW) x outer parity classes
+int mvs_convT3d_mfma32_tiles(int Cin, int Cout, int D, int H, int W)
 {
     const int64_t tiles = ((int64_t)D * H * W + 31) / 32;
-#define MVS_T32(CIN, COUT, WV, TPW) convT3d_k3s2_mfma32_kernel<CIN, COUT, WV, TPW><<<dim3(mvs_cdiv(tiles, TPW), 8 / (32 / COUT)), 64 * WV * TPW, 0, st>>>(x, D, H, W, w32, out)
+    const int tpw = Cin == 64 ? 1 : (Cin == 32 ? 2 : 4);
+    return (int)(mvs_cdiv(tiles, tpw) * tpw * (8 / (32 / Cout)));
+}
+
+int mvs_convT3d_mfma32(const float* x, int Cin, int D, int H, int W, const float* w32, int Cout, float* out, float* stats, hipStream_t st)
+{
+    const int64_t tiles = ((int64_t)D * H * W + 31) / 32;
+#define MVS_T32(CIN, COUT, WV, TPW) convT3d_k3s2_mfma32_kernel<CIN, COUT, WV, TPW><<<dim3(mvs_cdiv(tiles, TPW), 8 / (32 / COUT)), 64 * WV * TPW, 0, st>>>(x, D, H, W, w32, out, stats)
     switch (Cin * 100 + Cout) {
         case 64 * 100 + 32: MVS_T32(64, 32, 8, 1); break;      // conv7:  8..64 units per tile
         case 32 * 100 + 16: MVS_T32(32, 16, 2, 2); break;      // conv9:  8..32

@@ -829,7 +829,8 @@ __device__ __forceinline__ void conv_tile_chunk(const ActSrc& a, const ActSrc& b
 // s_waitcnt, VALU issues 45 % of the time, scalar-cache miss rate 1.5 %, LDS busy 24 % (63 % of that bank conflicts).
 template <int CIN, int CT, int COUT>
 __global__ __launch_bounds__(256) void conv3d_k3s1_tiled_kernel(ActSrc a, ActSrc b, int ld, int D, int H, int W,
-                                                               const float* __restrict__ wp, float* __restrict__ out, int swz)
+                                                               const float* __restrict__ wp, float* __restrict__ out, int swz,
+                                                               float* __restrict__ stats = nullptr)
 {
     __shared__ __attribute__((aligned(16))) float tile[600 * 12];
     const int nbx = (W + 7) / 8, nby = (H + 7) / 8;
@@ -850,10 +851,33 @@ __global__ __launch_bounds__(256) void conv3d_k3s1_tiled_kernel(ActSrc a, ActSrc
     if constexpr (CIN > 60) MVS_CHUNK(60, CIN - 60);
 #undef MVS_CHUNK
     const int ox = bx * 8 + tx, oy = by * 8 + ty, oz = bz * 4 + tz;
-    if (ox < W && oy < H && oz < D) {
+    const bool inside = ox < W && oy < H && oz < D;
+    if (inside) {
         float* o = out + (((int64_t)oz * H + oy) * W + ox) * COUT + cg;
 #pragma unroll
         for (int k = 0; k < CT; k += 4) *reinterpret_cast<f32x4*>(o + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+    }
+    if constexpr (256 % CT == 0 && CT <= 32 && CT >= 4) {
+        if (stats) {
+            // InPlaceABN partial sums of this tile's CT channels (conv2: no statistics pass re-reads the output).  The 256 voxel values of a
+            // channel go through the (now free) input tile: channel k gets 256 / CT lanes of one wave, each adds CT values and their squares,
+            // a shuffle tree finishes; fixed order.  Slot = tile, gridDim.x slots (abn_part_at).
+            constexpr int LPC = 256 / CT;                        // lanes per channel (8 .. 64: inside a wave)
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < CT; ++k) tile[k * 256 + tid] = inside ? acc[k] : 0.0f;
+            __syncthreads();
+            const int k = tid / LPC, part = tid % LPC;
+            float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+            for (int i = 0; i < CT; ++i) { const float v = tile[k * 256 + part * CT + i]; ssum += v; ssq = fmaf(v, v, ssq); }
+#pragma unroll
+            for (int o = 1; o < LPC; o <<= 1) { ssum += __shfl_xor(ssum, o); ssq += __shfl_xor(ssq, o); }
+            if (part == 0) {
+                stats[abn_part_at(0, cg + k, COUT, tile_id, gridDim.x)] = ssum;
+                stats[abn_part_at(1, cg + k, COUT, tile_id, gridDim.x)] = ssq;
+            }
+        }
     }
 }
 
@@ -908,7 +932,8 @@ int mvs_conv3d_mfma32(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int
 int mvs_conv3d_mfma32_tiles(int D, int H, int W, int stride);
 bool mvs_conv3d_mfma32_supported(int Cin, int Cout, int stride);
 int mvs_conv_w32_repack(const float* wpacked, float* w32, int Cin, int Cout, hipStream_t st);
-int mvs_convT3d_mfma32(const float* x, int Cin, int D, int H, int W, const float* w32, int Cout, float* out, hipStream_t st);
+int mvs_convT3d_mfma32(const float* x, int Cin, int D, int H, int W, const float* w32, int Cout, float* out, float* stats, hipStream_t st);
+int mvs_convT3d_mfma32_tiles(int Cin, int Cout, int D, int H, int W);
 MVS_KNOB_DEF(g_conv_tiled, 1)
 MVS_KNOB_DEF(g_conv_xcd, 1)
 static bool act_ok(const float* x, const float* sc, const float* sh) { return x && ((sc == nullptr) == (sh == nullptr)) && mvs_aligned16(x); }
@@ -956,6 +981,24 @@ extern "C" int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const fl
     }
 #undef MVS_CONV
 #undef MVS_CONV_TILED
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// conv2 (16 -> 16, stride 1: the LDS-tiled VALU kernel) leaving the InPlaceABN partial sums of its raw output from the same launch:
+// stats_part[2][16][mvsnerf_conv3d_tiled_tiles(D, H, W)] for mvsnerf_abn_finalize.  Other shapes: MVSNERF_EUNSUPPORTED (mvsnerf_conv3d_fwd
+// + mvsnerf_abn_stats, or the matrix-core entries with their own statistics).
+extern "C" int mvsnerf_conv3d_tiled_tiles(int D, int H, int W) { return (D < 1 || H < 1 || W < 1) ? 0 : ((W + 7) / 8) * ((H + 7) / 8) * ((D + 3) / 4); }
+
+extern "C" int mvsnerf_conv3d_fwd_stats(const float* x1, const float* scale1, const float* shift1, int Cin, int cin_ld, int D, int H, int W,
+                                        const float* wpacked, int Cout, int stride, float* out, float* stats_part, void* stream)
+{
+    if (!act_ok(x1, scale1, shift1) || !wpacked || !out || !stats_part || D < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
+    if ((cin_ld & 3) || cin_ld < Cin || !mvs_aligned16(out)) return MVSNERF_EALIGN;
+    if (Cin != 16 || Cout != 16 || stride != 1 || !g_conv_tiled) return MVSNERF_EUNSUPPORTED;
+    const ActSrc a{x1, scale1, shift1}, b{nullptr, nullptr, nullptr};
+    conv3d_k3s1_tiled_kernel<16, 16, 16><<<dim3((unsigned)mvsnerf_conv3d_tiled_tiles(D, H, W), 1), 256, 0, (hipStream_t)stream>>>(a, b, cin_ld, D, H, W, wpacked, out,
+                                                                                                                         g_conv_xcd, stats_part);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
@@ -1020,7 +1063,24 @@ extern "C" int mvsnerf_conv_transpose3d_mfma_fwd(const float* x, int Cin, int D,
 {
     if (!x || !w32 || !out || D < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
     if (!mvs_aligned16(x) || !mvs_aligned16(w32) || !mvs_aligned16(out)) return MVSNERF_EALIGN;
-    return mvs_convT3d_mfma32(x, Cin, D, H, W, w32, Cout, out, (hipStream_t)stream);
+    return mvs_convT3d_mfma32(x, Cin, D, H, W, w32, Cout, out, nullptr, (hipStream_t)stream);
+}
+
+// the same launch + the InPlaceABN partial sums of the raw output (conv7 / conv9: no statistics pass re-reads it):
+// stats_part[2][Cout][mvsnerf_conv_transpose3d_mfma_tiles(Cin, Cout, D, H, W)] for mvsnerf_abn_finalize
+extern "C" int mvsnerf_conv_transpose3d_mfma_tiles(int Cin, int Cout, int D, int H, int W)
+{
+    if (!mvsnerf_conv_transpose3d_mfma_supported(Cin, Cout) || D < 1 || H < 1 || W < 1) return 0;
+    return mvs_convT3d_mfma32_tiles(Cin, Cout, D, H, W);
+}
+
+extern "C" int mvsnerf_conv_transpose3d_mfma_fwd_stats(const float* x, int Cin, int D, int H, int W, const float* w32, int Cout, float* out,
+                                                       float* stats_part, void* stream)
+{
+    if (!x || !w32 || !out || !stats_part || D < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
+    if (!mvs_aligned16(x) || !mvs_aligned16(w32)) return MVSNERF_EALIGN;
+    if (!mvsnerf_conv_transpose3d_mfma_supported(Cin, Cout)) return MVSNERF_EUNSUPPORTED;
+    return mvs_convT3d_mfma32(x, Cin, D, H, W, w32, Cout, out, stats_part, (hipStream_t)stream);
 }
 
 int mvs_convT3d_c16to8_mfma4(const ActSrc& xa, const ActSrc& xb, int D, int H, int W, const float* wq, float* out, int xcd, float* stats, hipStream_t st);

@@ -42,7 +42,7 @@ extern "C" int mvsnerf_conv2d_pack_weights(const float* w, int ci_real, int co_r
 template <int CIN, int CT, int K, int S, int COUT>     // COUT a template constant: weight offsets are s_load immediates (see encoder.hip)
 __global__ __launch_bounds__(256) void conv2d_kernel(ActSrc a, int ld, int Hi, int Wi, const float* __restrict__ wp,
                                                      const float* __restrict__ bias,
-                                                     float* __restrict__ out, int Ho, int Wo)
+                                                     float* __restrict__ out, int Ho, int Wo, float* __restrict__ stats = nullptr)
 {
     constexpr int P = K / 2;
     const int nbx = (Wo + 15) >> 4, nby = (Ho + 15) >> 4;
@@ -85,6 +85,27 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ActSrc a, int ld, int Hi, i
         float* o = out + (((int64_t)n * Ho + y) * Wo + x) * COUT + cg;
 #pragma unroll
         for (int k = 0; k < CT; k += 4) *reinterpret_cast<f32x4*>(o + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+    }
+    if constexpr (CT == 8) {
+        if (stats) {
+            // InPlaceABN partial sums of this 16 x 16 tile's 8 channels (conv0.0 / conv0.1: the full-resolution output is not read again):
+            // channel k gets the 32 lanes tid / 32 == k, each adds 8 pixel values and their squares, a shuffle tree finishes; fixed
+            // order.  Slot = tile, gridDim.x slots (abn_part_at, common.h).
+            __shared__ float red[8 * 256];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) red[k * 256 + threadIdx.x] = live ? acc[k] : 0.0f;
+            __syncthreads();
+            const int k = threadIdx.x >> 5, part = threadIdx.x & 31;
+            float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float v = red[k * 256 + part * 8 + i]; ssum += v; ssq = fmaf(v, v, ssq); }
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) { ssum += __shfl_xor(ssum, o); ssq += __shfl_xor(ssq, o); }
+            if (part == 0) {
+                stats[abn_part_at(0, cg + k, COUT, tile_id, gridDim.x)] = ssum;
+                stats[abn_part_at(1, cg + k, COUT, tile_id, gridDim.x)] = ssq;
+            }
+        }
     }
 }
 
@@ -191,9 +212,13 @@ static bool conv2d_mfma_shape(int Cin, int Cout, int ksize, int stride)
 }
 
 // number of M-tiles (= rows of InPlaceABN partial sums) mvsnerf_conv2d_fwd_stats leaves for this layer; 0: the layer has no matrix-core kernel
+static bool conv2d_valu_stats_shape(int Cin, int Cout, int ksize, int stride) { return (Cin == 4 || Cin == 8) && Cout == 8 && ksize == 3 && stride == 1; }
+
 extern "C" int mvsnerf_conv2d_mfma_tiles(int Cin, int Cout, int N, int H, int W, int ksize, int stride)
 {
-    if (!conv2d_mfma_shape(Cin, Cout, ksize, stride) || N < 1 || H < 1 || W < 1) return 0;
+    if (N < 1 || H < 1 || W < 1) return 0;
+    if (conv2d_valu_stats_shape(Cin, Cout, ksize, stride)) return ((W + 15) / 16) * ((H + 15) / 16) * N;   // conv0.0 / conv0.1: the VALU kernel's 16 x 16 tiles
+    if (!conv2d_mfma_shape(Cin, Cout, ksize, stride)) return 0;
     const int P = ksize / 2, Ho = (H + 2 * P - ksize) / stride + 1, Wo = (W + 2 * P - ksize) / stride + 1;
     const int64_t npix = (int64_t)N * Ho * Wo, MT = Cout == 32 ? 32 : 16;
     return (int)((npix + MT - 1) / MT);
@@ -222,6 +247,14 @@ extern "C" int mvsnerf_conv2d_fwd_stats(const float* x, const float* scale, cons
 {
     if (!x || !wpacked || !out || !stats_part || ((scale == nullptr) != (shift == nullptr)) || N < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
     if ((cin_ld & 3) || cin_ld < Cin || !mvs_aligned16(x) || !mvs_aligned16(out)) return MVSNERF_EALIGN;
+    if (conv2d_valu_stats_shape(Cin, Cout, ksize, stride)) {
+        const ActSrc a{x, scale, shift};
+        const unsigned tiles = (unsigned)mvsnerf_conv2d_mfma_tiles(Cin, Cout, N, H, W, ksize, stride);
+        if (Cin == 4) conv2d_kernel<4, 8, 3, 1, 8><<<dim3(tiles, 1), 256, 0, (hipStream_t)stream>>>(a, cin_ld, H, W, wpacked, nullptr, out, H, W, stats_part);
+        else conv2d_kernel<8, 8, 3, 1, 8><<<dim3(tiles, 1), 256, 0, (hipStream_t)stream>>>(a, cin_ld, H, W, wpacked, nullptr, out, H, W, stats_part);
+        MVS_LAUNCH_CHECK();
+        return MVSNERF_OK;
+    }
     if (!conv2d_mfma_shape(Cin, Cout, ksize, stride)) return MVSNERF_EUNSUPPORTED;
     return conv2d_mfma_launch(ActSrc{x, scale, shift}, Cin, cin_ld, N, H, W, wpacked, Cout, ksize, stride, out, stats_part, (hipStream_t)stream);
 }

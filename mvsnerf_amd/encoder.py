@@ -559,6 +559,15 @@ def _conv(src1, src2, dims_in, cin_ld, wbuf, cin_k, cout_k, stride, packed=None,
         return out if want_stats is None else (out, None if part is None else (part, nblk))
     if callable(wbuf):
         wbuf = wbuf()               # the VALU layout is only packed when this branch runs (no eager pk.get() per step)
+    if want_stats and FUSED_ABN_STATS and src2 is None and (cin_k, cout_k, stride) == (16, 16, 1):
+        nblk = _lib.lib().mvsnerf_conv3d_tiled_tiles(D, H, W)          # conv2: statistics from the convolution's own launch
+        part = torch.empty(nblk * 2 * cout_k, device=out.device, dtype=torch.float32)
+        rc = _lib.lib().mvsnerf_conv3d_fwd_stats(*_ptrs(src1), cin_k, cin_ld, D, H, W, wbuf.data_ptr(), cout_k, stride, out.data_ptr(),
+                                                 part.data_ptr(), stream_ptr())
+        if rc == 0:
+            return out, (part, nblk)
+        if rc != -2:                                                   # MVSNERF_EUNSUPPORTED: fall through to the plain launch
+            check(rc, "conv3d_fwd_stats")
     check(_lib.lib().mvsnerf_conv3d_fwd(*_ptrs(src1), *_ptrs(src2), cin_k, cin_ld, D, H, W, wbuf.data_ptr(), cout_k, stride,
                                         out.data_ptr(), stream_ptr()), "conv3d_fwd")
     return out if want_stats is None else (out, None)
@@ -583,6 +592,12 @@ def _conv_t(src1, src2, dims_in, wbuf, cin_k, cout_k, packed=None, mode="fwd", w
         return out if want_stats is None else (out, None if part is None else (part, nblk))
     if (packed is not None and src2 is None and torch.is_tensor(src1) and cin_k % 8 == 0
             and _lib.lib().mvsnerf_conv_transpose3d_mfma_supported(cin_k, cout_k)):
+        if want_stats and FUSED_ABN_STATS:                             # conv7 / conv9: the statistics come from the accumulators
+            nblk = _lib.lib().mvsnerf_conv_transpose3d_mfma_tiles(cin_k, cout_k, D, H, W)
+            part = torch.empty(nblk * 2 * cout_k, device=out.device, dtype=torch.float32)
+            check(_lib.lib().mvsnerf_conv_transpose3d_mfma_fwd_stats(src1.data_ptr(), cin_k, D, H, W, packed.get_mfma(mode).data_ptr(), cout_k,
+                                                                     out.data_ptr(), part.data_ptr(), stream_ptr()), "conv_transpose3d_mfma_fwd_stats")
+            return out, (part, nblk)
         check(_lib.lib().mvsnerf_conv_transpose3d_mfma_fwd(src1.data_ptr(), cin_k, D, H, W, packed.get_mfma(mode).data_ptr(), cout_k,
                                                            out.data_ptr(), stream_ptr()), "conv_transpose3d_mfma_fwd")
         return out if want_stats is None else (out, None)
