@@ -161,6 +161,42 @@ def test_abn_stats_and_conv_vs_torch_full_size():
         assert maxabs(raw.cpu(), ref.cpu()) < 2e-4
 
 
+@pytest.mark.parametrize("layer", ["conv2", "conv7", "conv9", "feat0.0", "feat0.1"])
+def test_fwd_stats_partials_equal_the_sums_of_the_output(layer):
+    """The convolutions that leave their own InPlaceABN partial sums (conv2: LDS-tiled VALU kernel; conv7 / conv9: transposed matrix-core
+    kernel, one slot per M-tile and parity class; FeatureNet conv0.0 / conv0.1: VALU kernel): the partials, summed in float64, are the
+    per-channel sum and sum of squares of the raw output the same launch wrote - on shapes whose last tiles are ragged."""
+    from mvsnerf_amd import encoder as E
+    g = torch.Generator().manual_seed(11)
+    if layer == "conv2":
+        conv = E.ConvBnReLU3D(16, 16).to(DEV)
+        d, h, w = 7, 19, 29
+        x = torch.randn((d, h, w, 16), generator=g).to(DEV)
+        raw, part = E._conv(x, None, (d, h, w, 16), 16, conv._packed.get, 16, 16, 1, packed=conv._packed, want_stats=True)
+    elif layer in ("conv7", "conv9"):
+        cin, cout = (64, 32) if layer == "conv7" else (32, 16)
+        up = E._UpBlock(cin, cout, E.InPlaceABN).to(DEV)
+        d, h, w = 3, 7, 11
+        x = torch.randn((d, h, w, cin), generator=g).to(DEV)
+        raw, part = E._conv_t(x, None, (d, h, w, cin), up._packed.get, cin, cout, packed=up._packed, want_stats=True)
+    else:
+        cin = 3 if layer == "feat0.0" else 8
+        blk = E.ConvBnReLU(cin, 8, 3, 1, 1).to(DEV)
+        n, h, w = 2, 37, 45
+        ld = 4 if cin == 3 else 8
+        x = torch.zeros((n, h, w, ld)); x[..., :cin] = torch.randn((n, h, w, cin), generator=g)
+        x = x.to(DEV)
+        pk = blk._packed
+        raw, part = E._conv2d(x, (n, h, w, ld), ld, pk.get(), pk.cin_pad, pk.cout, 3, 1, want_stats=True)
+    assert part is not None, "the layer did not leave its statistics"
+    buf, nblk = part
+    C = raw.shape[-1]
+    sums = buf.view(2, C, nblk).double().sum(2).cpu()
+    r = raw.reshape(-1, C).double().cpu()
+    assert float((sums[0] - r.sum(0)).abs().max()) < 1e-3 * max(1.0, float(r.sum(0).abs().max()))
+    assert float((sums[1] - (r * r).sum(0)).abs().max()) < 1e-5 * float((r * r).sum(0).max())
+
+
 def _blocked(x_cl, cp):
     """(D,H,W,C) channel-last -> [cp/4][D*H*W][4] (zero padding channels)."""
     D, H, W, C = x_cl.shape
