@@ -1159,37 +1159,44 @@ __global__ __launch_bounds__(256) void abn_partial_kernel(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void abn_finalize_kernel(const float* __restrict__ part, int nblocks, int C, int64_t n,
+__global__ __launch_bounds__(1024) void abn_finalize_kernel(const float* __restrict__ part, int nblocks, int C, int64_t n,
                                     const float* __restrict__ weight, const float* __restrict__ bias,
                                     float* __restrict__ running_mean, float* __restrict__ running_var,
                                     float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift,
                                     float* __restrict__ mean_out, float* __restrict__ invstd_out)
 {
-    // one workgroup of 256 threads per channel: thread t adds the partials of slots t, t+256, ... - two contiguous runs of the
-    // channel-major partial array (abn_part_at), four independent loads in flight per run - then a fixed-order tree in LDS
-    // (deterministic), fp64 throughout
+    // one workgroup of 1024 threads per channel: thread t adds the partials of slots t, t+1024, ... - two contiguous runs of the
+    // channel-major partial array (abn_part_at), four independent loads in flight per run (a full-resolution layer has ~9 k slots: three
+    // rounds; 256 threads needed nine, each a round trip to L2) - then a shuffle tree inside the wave and the 16 wave sums in a fixed
+    // order (deterministic), fp64 throughout
     const int c = blockIdx.x, t = threadIdx.x;
     const float* ps = part + abn_part_at(0, c, C, 0, nblocks);
     const float* pq = part + abn_part_at(1, c, C, 0, nblocks);
     double s = 0.0, q = 0.0;
     int b = t;
-    for (; b + 768 < nblocks; b += 1024) {
-        const float s0 = ps[b], s1 = ps[b + 256], s2 = ps[b + 512], s3 = ps[b + 768];
-        const float q0 = pq[b], q1 = pq[b + 256], q2 = pq[b + 512], q3 = pq[b + 768];
+    for (; b + 3072 < nblocks; b += 4096) {
+        const float s0 = ps[b], s1 = ps[b + 1024], s2 = ps[b + 2048], s3 = ps[b + 3072];
+        const float q0 = pq[b], q1 = pq[b + 1024], q2 = pq[b + 2048], q3 = pq[b + 3072];
         s += ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
         q += ((double)q0 + (double)q1) + ((double)q2 + (double)q3);
     }
-    for (; b < nblocks; b += 256) { s += (double)ps[b]; q += (double)pq[b]; }
-    __shared__ double rs[256], rq[256];
-    rs[t] = s; rq[t] = q;
-    __syncthreads();
+    {   // the (up to three) remaining rounds: all loads first
+        float sv[3] = {0.f, 0.f, 0.f}, qv[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int d = 128; d >= 1; d >>= 1) {
-        if (t < d) { rs[t] += rs[t + d]; rq[t] += rq[t + d]; }
-        __syncthreads();
+        for (int k = 0; k < 3; ++k)
+            if (b + k * 1024 < nblocks) { sv[k] = ps[b + k * 1024]; qv[k] = pq[b + k * 1024]; }
+        s += ((double)sv[0] + (double)sv[1]) + (double)sv[2];
+        q += ((double)qv[0] + (double)qv[1]) + (double)qv[2];
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { s += __shfl_xor(s, d); q += __shfl_xor(q, d); }
+    __shared__ double rs[16], rq[16];
+    if ((t & 63) == 0) { rs[t >> 6] = s; rq[t >> 6] = q; }
+    __syncthreads();
     if (t != 0) return;
-    s = rs[0]; q = rq[0];
+    s = 0.0; q = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { s += rs[w]; q += rq[w]; }
     const double mean = s / (double)n;
     double var = q / (double)n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -1230,7 +1237,7 @@ extern "C" int mvsnerf_abn_stats(const float* x, int64_t n_vox, int C, const flo
         default: return MVSNERF_EUNSUPPORTED;
     }
     MVS_LAUNCH_CHECK();
-    abn_finalize_kernel<<<C, 256, 0, st>>>(workspace, nb, C, n_vox, weight, bias, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out);
+    abn_finalize_kernel<<<C, 1024, 0, st>>>(workspace, nb, C, n_vox, weight, bias, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
@@ -1242,7 +1249,7 @@ extern "C" int mvsnerf_abn_finalize(const float* part, int n_blocks, int C, int6
 {
     if (!part || n_blocks < 1 || C < 1 || n_vox < 1 || !weight || !bias || !scale || !shift) return MVSNERF_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return MVSNERF_EINVAL;
-    abn_finalize_kernel<<<C, 256, 0, (hipStream_t)stream>>>(part, n_blocks, C, n_vox, weight, bias, running_mean, running_var, momentum, eps, scale, shift,
+    abn_finalize_kernel<<<C, 1024, 0, (hipStream_t)stream>>>(part, n_blocks, C, n_vox, weight, bias, running_mean, running_var, momentum, eps, scale, shift,
                                                             mean_out, invstd_out);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
