@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256) void conv3d_k3s1_tiled_kernel(ActSrc a, ActSrc
 #pragma unroll
         for (int k = 0; k < CT; k += 4) *reinterpret_cast<f32x4*>(o + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
     }
-    if constexpr (256 % CT == 0 && CT <= 32 && CT >= 4) {
+    if constexpr (256 % CT == 0 && CT >= 4 && CT * 256 <= 600 * 12) {     // the channel values must fit the input tile they reuse
         if (stats) {
             // InPlaceABN partial sums of this tile's CT channels (conv2: no statistics pass re-reads the output).  The 256 voxel values of a
             // channel go through the (now free) input tile: channel k gets 256 / CT lanes of one wave, each adds CT values and their squares,
