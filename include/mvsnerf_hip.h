@@ -457,7 +457,14 @@ int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream);
  * operand is the sum of n_split bf16 pieces and a product is accumulated in fp32 from the piece products of combined order
  * < n_split, so n_split = 3 reproduces fp32 products to ~2^-24 on the bf16 matrix cores at 6/16 of the fp32-MFMA time
  * (the technique BLAS libraries ship as "BF16x9/x6 FP32 emulation").  Same arguments and results layout as mvsnerf_mlp_fwd;
- * `packed_f32` (mvsnerf_mlp_pack) supplies the fp32 bias / head vectors.  Opt-in: the default path is the fp32 MFMA kernel. */
+ * `packed_f32` (mvsnerf_mlp_pack) supplies the fp32 bias / head vectors.  Opt-in: the default path is the fp32 MFMA kernel.
+ *
+ * n_split = MVSNERF_SPLIT_FP16 ("fp16x3", mlp_f16x3.hip): TWO FP16 pieces per operand, both rounded to nearest, and the three piece products
+ * a0*w0 + a0*w1 + a1*w0 on v_mfma_f32_32x32x16_f16.  fp16 carries 11 significant bits, so two pieces hold 22 and what is dropped is
+ * <= 2^-22 of a product - fp32-grade like n_split = 3, at half the matrix-core work - in exchange for fp16's RANGE: operands above 65504
+ * saturate, lo pieces of operands below 2^-3 are fp16 subnormals (kept by gfx950's matrix cores).  The shipped network's activations
+ * stay below 200; a network that leaves the window wants n_split = 3. */
+#define MVSNERF_SPLIT_FP16 18
 size_t mvsnerf_mlp_packed_split_elems(int F, int n_split);
 int mvsnerf_mlp_pack_split(const float* const w[11], int F, int n_split, void* packed_split, void* stream);
 int mvsnerf_mlp_fwd_split(const void* packed_split, const float* packed_f32, int F, int n_split, const float* ndc, int ndc_stride,

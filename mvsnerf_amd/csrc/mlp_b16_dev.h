@@ -1,0 +1,74 @@
+// What the 16-bit-operand MLP kernels share (mlp_bf16.hip: v_mfma_f32_32x32x16_bf16 and its split variants; mlp_f16x3.hip:
+// v_mfma_f32_32x32x16_f16): the k-step geometry of a 32x32x16 instruction on the transposed-layer scheme of mlp_layout.h, the
+// weight-pack argument block, accumulator initialisation from the fragment-ordered bias vectors and the in-register positional
+// encoding.  Both instructions use the same operand layout (lane = row/column l & 31, k elements 8 * (l >> 5) .. + 7), so the
+// k-maps below serve both.
+#pragma once
+#include "common.h"
+#include "mlp_layout.h"
+
+namespace mlp {
+
+constexpr int B_PE_STEPS = 4;        // 64 padded embedding inputs / 16
+constexpr int B_ACT_STEPS = 8;       // 128 / 16
+constexpr int B_VIEW_STEPS = 9;      // 128 feature + 3 dir (+13 zero) / 16
+
+__host__ __device__ inline int b_feat_steps(int F) { return ((F / 2) + 7) / 8; }
+__host__ __device__ inline size_t b_seg(int steps, int nb) { return (size_t)steps * nb * 64 * 8; }      // bf16 elements
+
+// input column of (element t of the lane half h); t = 8*step + j
+__host__ __device__ inline int b_col(int kmap, int t, int h, int F)
+{
+    switch (kmap) {
+    case K_PE:    return t < PE_STEPS ? kmap_col(K_PE, t, h, F) : -1;
+    case K_FEAT:  return t < F / 2 ? h * (F / 2) + t : -1;
+    case K_ACT:   return t < 64 ? act_n(t, h) : -1;
+    case K_VIEWS: return t < 64 ? act_n(t, h) : t == 64 ? WIDTH + h : t == 65 ? (h ? -1 : WIDTH + 2) : -1;
+    }
+    return -1;
+}
+
+struct PackBArgs { const float* w[11]; int F; };
+
+template <int NBLK>
+__device__ __forceinline__ void init_acc_b(f32x16 (&acc)[NBLK], const float* __restrict__ vec_h)
+{
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(vec_h + b * 16 + r4 * 4);
+            acc[b][r4 * 4 + 0] = v[0]; acc[b][r4 * 4 + 1] = v[1]; acc[b][r4 * 4 + 2] = v[2]; acc[b][r4 * 4 + 3] = v[3];
+        }
+}
+
+__device__ __forceinline__ float pe_sc(float x, int want_cos)      // same routine as mlp.hip
+{
+    x = fminf(fmaxf(x, -65536.0f), 65536.0f);
+    const float k = rintf(x * 0.63661977236758134f);
+    float r = fmaf(k, -1.5703125f, x);
+    r = fmaf(k, -4.837512969970703125e-4f, r);
+    r = fmaf(k, -7.54978995489188e-8f, r);
+    const float r2 = r * r;
+    const float sn = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f) * r2, r, r);
+    const float cs = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f) * r2, r2, fmaf(-0.5f, r2, 1.0f));
+    const int q = (int)k + want_cos;
+    const float v = (q & 1) ? cs : sn;
+    return (q & 2) ? -v : v;
+}
+
+__device__ __forceinline__ float pe_op(int t, int half, float px, float py, float pz)
+{
+    if (t == 0) return half ? py : px;
+    if (t == 1) return half ? 0.0f : pz;
+    const int j = t - 2, f = j / 3, c = j - 3 * f;
+    return pe_sc((c == 0 ? px : c == 1 ? py : pz) * (float)(1 << f), half);
+}
+
+}  // namespace mlp
+
+// mlp_f16x3.hip: the two-piece fp16 split behind mvsnerf_mlp_{packed_split_elems, pack_split, fwd_split}(n_split = MVSNERF_SPLIT_FP16)
+size_t mvs_mlp_f16x3_elems(int F);
+int mvs_mlp_f16x3_pack(const float* const w[11], int F, void* packed, hipStream_t st);
+int mvs_mlp_f16x3_fwd(const void* packed_h, const float* packed_f32, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
+                      const float* dirs, int dirs_stride, int64_t P, int S, int alpha_only, float* raw, hipStream_t st);

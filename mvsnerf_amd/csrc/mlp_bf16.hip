@@ -10,6 +10,7 @@
 #include "common.h"
 #include "lds_dma.h"
 #include "mlp_layout.h"
+#include "mlp_b16_dev.h"
 #include "knobs.h"
 
 using namespace mlp;
@@ -17,13 +18,6 @@ using namespace mlp;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
-
-constexpr int B_PE_STEPS = 4;        // 64 padded embedding inputs / 16
-constexpr int B_ACT_STEPS = 8;       // 128 / 16
-constexpr int B_VIEW_STEPS = 9;      // 128 feature + 3 dir (+13 zero) / 16
-
-__host__ __device__ inline int b_feat_steps(int F) { return ((F / 2) + 7) / 8; }
-__host__ __device__ inline size_t b_seg(int steps, int nb) { return (size_t)steps * nb * 64 * 8; }      // bf16 elements
 
 struct LayoutB { size_t featw, l0, l1, l2, l3, l4, l5a, l5b, feat, views, total; int fsteps; };
 __host__ __device__ inline LayoutB layout_b(int F)
@@ -44,20 +38,6 @@ __host__ __device__ inline LayoutB layout_b(int F)
     L.total = o;
     return L;
 }
-
-// input column of (element t of the lane half h); t = 8*step + j
-__host__ __device__ inline int b_col(int kmap, int t, int h, int F)
-{
-    switch (kmap) {
-    case K_PE:    return t < PE_STEPS ? kmap_col(K_PE, t, h, F) : -1;
-    case K_FEAT:  return t < F / 2 ? h * (F / 2) + t : -1;
-    case K_ACT:   return t < 64 ? act_n(t, h) : -1;
-    case K_VIEWS: return t < 64 ? act_n(t, h) : t == 64 ? WIDTH + h : t == 65 ? (h ? -1 : WIDTH + 2) : -1;
-    }
-    return -1;
-}
-
-struct PackBArgs { const float* w[11]; int F; };
 
 __device__ inline void pack_b_segment(__bf16* __restrict__ dst, const float* __restrict__ W, int ld, int col_off, int kmap,
                                       int steps, int nb, int F, int tid, int nthreads)
@@ -115,41 +95,6 @@ __device__ __forceinline__ void gemm_b(const char* __restrict__ w, f32x16 (&acc)
             acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nb], 0, 0, 0);
         }
     }
-}
-
-template <int NBLK>
-__device__ __forceinline__ void init_acc_b(f32x16 (&acc)[NBLK], const float* __restrict__ vec_h)
-{
-#pragma unroll
-    for (int b = 0; b < NBLK; ++b)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(vec_h + b * 16 + r4 * 4);
-            acc[b][r4 * 4 + 0] = v[0]; acc[b][r4 * 4 + 1] = v[1]; acc[b][r4 * 4 + 2] = v[2]; acc[b][r4 * 4 + 3] = v[3];
-        }
-}
-
-__device__ __forceinline__ float pe_sc(float x, int want_cos)      // same routine as mlp.hip (kept local: separate TU)
-{
-    x = fminf(fmaxf(x, -65536.0f), 65536.0f);
-    const float k = rintf(x * 0.63661977236758134f);
-    float r = fmaf(k, -1.5703125f, x);
-    r = fmaf(k, -4.837512969970703125e-4f, r);
-    r = fmaf(k, -7.54978995489188e-8f, r);
-    const float r2 = r * r;
-    const float sn = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f) * r2, r, r);
-    const float cs = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f) * r2, r2, fmaf(-0.5f, r2, 1.0f));
-    const int q = (int)k + want_cos;
-    const float v = (q & 1) ? cs : sn;
-    return (q & 2) ? -v : v;
-}
-
-__device__ __forceinline__ float pe_op(int t, int half, float px, float py, float pz)
-{
-    if (t == 0) return half ? py : px;
-    if (t == 1) return half ? 0.0f : pz;
-    const int j = t - 2, f = j / 3, c = j - 3 * f;
-    return pe_sc((c == 0 ? px : c == 1 ? py : pz) * (float)(1 << f), half);
 }
 
 __device__ __forceinline__ bf16x8 pack8(const float* v)
@@ -828,15 +773,18 @@ MVS_KNOB_DEF(g_split_sched, 0)    // knobs.h
 
 extern "C" size_t mvsnerf_mlp_packed_split_elems(int F, int n_split)
 {
-    if (F < 2 || F > MAX_F || (F & 1) || n_split < 1 || n_split > 3) return 0;
+    if (F < 2 || F > MAX_F || (F & 1)) return 0;
+    if (n_split == MVSNERF_SPLIT_FP16) return mvs_mlp_f16x3_elems(F);
+    if (n_split < 1 || n_split > 3) return 0;
     return sp_total_elems(n_split, F);
 }
 
 extern "C" int mvsnerf_mlp_pack_split(const float* const w[11], int F, int n_split, void* packed_split, void* stream)
 {
     if (!w || !packed_split) return MVSNERF_EINVAL;
-    if (F < 2 || F > MAX_F || (F & 1) || n_split < 1 || n_split > 3) return MVSNERF_EUNSUPPORTED;
+    if (F < 2 || F > MAX_F || (F & 1) || ((n_split < 1 || n_split > 3) && n_split != MVSNERF_SPLIT_FP16)) return MVSNERF_EUNSUPPORTED;
     if (!mvs_aligned16(packed_split)) return MVSNERF_EALIGN;
+    if (n_split == MVSNERF_SPLIT_FP16) return mvs_mlp_f16x3_pack(w, F, packed_split, (hipStream_t)stream);
     PackBArgs a;
     for (int i = 0; i < 11; ++i) { if (!w[i]) return MVSNERF_EINVAL; a.w[i] = w[i]; }
     a.F = F;
@@ -851,10 +799,12 @@ extern "C" int mvsnerf_mlp_fwd_split(const void* packed_split, const float* pack
 {
     if (!packed_split || !packed_f32 || !ndc || !feat || !raw || N < 0 || S < 1 || feat_stride < F || ndc_stride < 3) return MVSNERF_EINVAL;
     if (!alpha_only && (!dirs || dirs_stride < 3)) return MVSNERF_EINVAL;
-    if (F < 2 || F > MAX_F || (F & 1) || n_split < 1 || n_split > 3) return MVSNERF_EUNSUPPORTED;
+    if (F < 2 || F > MAX_F || (F & 1) || ((n_split < 1 || n_split > 3) && n_split != MVSNERF_SPLIT_FP16)) return MVSNERF_EUNSUPPORTED;
     if (!mvs_aligned16(packed_split) || !mvs_aligned16(raw)) return MVSNERF_EALIGN;
     const int64_t P = N * S;
     if (P == 0) return MVSNERF_OK;
+    if (n_split == MVSNERF_SPLIT_FP16)
+        return mvs_mlp_f16x3_fwd(packed_split, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, (hipStream_t)stream);
     const __bf16* wq = reinterpret_cast<const __bf16*>(packed_split);
     hipStream_t st = (hipStream_t)stream;
     int rc;

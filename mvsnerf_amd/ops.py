@@ -282,8 +282,8 @@ def mlp_pack(weights, biases, F):
     return packed
 
 
-MLP_PRECISION = "fp32"      # "fp32" (default) | "bf16" | "bf16x3" | "bf16x6" (opt-in); see set_mlp_precision
-N_SPLIT = {"bf16x3": 2, "bf16x6": 3}
+MLP_PRECISION = "fp32"      # "fp32" (default) | "bf16" | "bf16x3" | "bf16x6" | "fp16x3" (opt-in); see set_mlp_precision
+N_SPLIT = {"bf16x3": 2, "bf16x6": 3, "fp16x3": 18}      # n_split of mvsnerf_mlp_*_split; 18 = MVSNERF_SPLIT_FP16 (include/mvsnerf_hip.h)
 
 
 def set_mlp_precision(mode):
@@ -293,11 +293,13 @@ def set_mlp_precision(mode):
                 reference's AMP switch (train_mvs_nerf_pl.py:317-318): forward, data- and weight-gradient GEMMs on bf16 operands
                 with fp32 accumulation, fp32 master weights and fp32 gradients
       (the split modes below are inference-only)
-      "bf16x6"  split-bf16 fp32 emulation: operands as 3 bf16 pieces, 6 bf16 MFMAs per product (fp32-grade results)
-      "bf16x3"  2 pieces, 3 MFMAs (~1e-5 relative)"""
+      "bf16x6"  split-bf16 fp32 emulation: operands as 3 bf16 pieces, 6 bf16 MFMAs per product (fp32-grade results, fp32's range)
+      "bf16x3"  2 bf16 pieces, 3 MFMAs (~1e-5 relative)
+      "fp16x3"  2 FP16 pieces, 3 v_mfma_f32_32x32x16_f16 per product: fp32-grade results (two fp16 pieces carry 22 bits) at half the
+                matrix-core work of "bf16x6"; operands must stay inside fp16's range (|x| < 65504; csrc/mlp_f16x3.hip)"""
     global MLP_PRECISION
-    if mode not in ("fp32", "bf16", "bf16x3", "bf16x6"):
-        raise ValueError("mlp precision must be 'fp32', 'bf16', 'bf16x3' or 'bf16x6'")
+    if mode not in ("fp32", "bf16", "bf16x3", "bf16x6", "fp16x3"):
+        raise ValueError("mlp precision must be 'fp32', 'bf16', 'bf16x3', 'bf16x6' or 'fp16x3'")
     MLP_PRECISION = mode
 
 

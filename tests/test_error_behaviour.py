@@ -28,6 +28,14 @@ def test_c_abi_rejects_bad_arguments_without_launching():
     assert l.mvsnerf_planesweep_costvar_fwd(p, 0, p, p, 3, 16, 8, 8, 4, 0, p, 16, p, 0, 0) == EUNSUPPORTED   # C != 32
     assert l.mvsnerf_raymarch_fwd(None, 0) == EINVAL and l.mvsnerf_render_pixels_fwd(None, 0) == EINVAL
     assert l.mvsnerf_render_workspace_floats(0, 128, 3) == 0
+    # split-MLP weight buffers: n_split 1..3 = bf16 pieces, MVSNERF_SPLIT_FP16 (18) = two fp16 pieces per operand (hi plane + lo plane per layer)
+    seg = lambda steps, nb: steps * nb * 512
+    assert l.mvsnerf_mlp_packed_split_elems(20, 18) == 2 * (seg(2, 4) + seg(4, 4) + 4 * seg(8, 4) + seg(4, 4) + 2 * seg(8, 4) + seg(9, 2)) == 256000
+    assert l.mvsnerf_mlp_packed_split_elems(20, 4) == 0 and l.mvsnerf_mlp_packed_split_elems(21, 18) == 0 and l.mvsnerf_mlp_packed_split_elems(20, 3) > 0
+    wp = (ctypes.c_void_p * 11)(*[p] * 11)
+    assert l.mvsnerf_mlp_pack_split(wp, 20, 4, p, 0) == EUNSUPPORTED and l.mvsnerf_mlp_pack_split(wp, 20, 18, p + 4, 0) == EALIGN
+    assert l.mvsnerf_mlp_fwd_split(p, p, 20, 7, p, 3, p, 20, p, 3, 1, 1, 0, p, 0) == EUNSUPPORTED
+    assert l.mvsnerf_mlp_fwd_split(p, p, 20, 18, p, 3, p, 20, p, 3, 0, 1, 0, p, 0) == 0                # empty batch: no launch
     assert not hasattr(l, "mvsnerf_tune") and not hasattr(l, "mvsnerf_debug_set_census")     # the product library has no A/B switches (csrc/knobs.h)
 
 
