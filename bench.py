@@ -472,6 +472,28 @@ def main():
                 # rate at THAT clock is 64 FLOP/clk/SIMD x 1024 SIMDs x clock - what the matrix pipes could deliver in this launch at most
                 "peak_at_sustained_clock": round(64 * 1024 * clock / 1e3, 1),
                 "frac_of_sustained_clock_peak": round(tf / (64 * 1024 * clock / 1e3), 4)}
+        if a.mlp_precision != "fp32":
+            # --mlp-precision <opt-in mode>: the timed step ran that mode's kernel, so `roofline` describes THAT kernel (issued 16-bit
+            # matrix-core work = pieces products x the algorithmic FLOPs, against the dense bf16/fp16 peak); the fp32 kernel's object moves to `rooflines`
+            n_mfma = {"bf16": 1, "bf16x3": 3, "bf16x6": 6, "fp16x3": 3}[a.mlp_precision]
+            with torch.no_grad():
+                if a.mlp_precision == "bf16":
+                    pbm = net.packed_bf16(F)
+                    k_mode = lambda: lib.mvsnerf_mlp_fwd_bf16(pbm.data_ptr(), packed.data_ptr(), F, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3,
+                                                              N_RAYS, N_SAMPLES, 0, raw.data_ptr(), st().cuda_stream)
+                    kname = "mlp_fwd_bf16_kernel"
+                else:
+                    psm, nsm = net.packed_split(F, ops.N_SPLIT[a.mlp_precision])
+                    k_mode = lambda: lib.mvsnerf_mlp_fwd_split(psm.data_ptr(), packed.data_ptr(), F, nsm, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3,
+                                                               N_RAYS, N_SAMPLES, 0, raw.data_ptr(), st().cuda_stream)
+                    kname = "mlp_fwd_f16x3_kernel" if a.mlp_precision == "fp16x3" else "mlp_fwd_split_kernel"
+                t_mode = event_time(k_mode, 100)
+            roofs.append(roof)
+            tfm = n_mfma * FLOP_PER_SAMPLE * P / (t_mode * 1e-3) / 1e12
+            roof = {"kernel": kname, "bound": "mfma", "achieved": round(tfm, 1), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tfm / PEAK_16BIT_MFMA_TFLOPS, 4), "traffic": pmc_traffic(kname), "traffic_source": _pmc_summary()[1],
+                    "avg_launch_ms": round(t_mode, 4), "piece_products_per_product": n_mfma,
+                    "fp32_equivalent_tflops": round(FLOP_PER_SAMPLE * P / (t_mode * 1e-3) / 1e12, 1)}
         for name, t, bps in (("gather_fused_kernel", t_gat, VOL_BYTES_PER_SAMPLE + COL_BYTES_PER_SAMPLE),
                              ("volume_sample_c8_kernel", t_vol, VOL_BYTES_PER_SAMPLE), ("color_sample_kernel", t_col, COL_BYTES_PER_SAMPLE),
                              ("composite_kernel", t_cmp, 28)):
@@ -578,6 +600,18 @@ def main():
                                        "note": "MVSSystem.render_view: MVSNet encode + 320 sub-batches of 1024 rays x 128 samples through "
                                                "mvsnerf_render_pixels_fwd (one FFI call; ray generation, fused gather, MLP, compositing per sub-batch). "
                                                "With the default 4096-ray sub-batches the same frame takes 0.090 s (profiles/r01_configs_2_4_5.txt)"}
+            # (i-b) the same frame with the opt-in fp16x3 MLP kernel (fp32-grade results, csrc/mlp_f16x3.hip); NOT the headline arithmetic
+            with torch.no_grad():
+                rgb32, _ = system.render_view(batch, batch_rays=N_RAYS)
+                with ops.mlp_precision("fp16x3"):
+                    system.render_view(batch, batch_rays=N_RAYS)
+                    torch.cuda.synchronize(); f0 = time.perf_counter()
+                    rgb16, _ = system.render_view(batch, batch_rays=N_RAYS)
+                    torch.cuda.synchronize(); fdt16 = time.perf_counter() - f0
+            extras["frame_512x640_fp16x3"] = {"seconds": round(fdt16, 4), "rays_per_s_incl_encode": round(H_IMG * W_IMG / fdt16, 1),
+                                              "max_abs_rgb_diff_vs_fp32_frame": float((rgb16 - rgb32).abs().max()),
+                                              "note": "the same MVSSystem.render_view call under ops.mlp_precision('fp16x3'): encode (fp32 kernels) + 320 sub-batches"}
+            del rgb32, rgb16
             # (ii) one generalizable-training step (config 3 shapes, fp32): encode + ray march + full backward + Adam
             opt = system.configure_optimizers()[0][0]
             torch.manual_seed(0)

@@ -13,7 +13,7 @@
 // LOG2_SA / LOG2_SW pre-scale activations / weights by exact powers of two (undone in the fp32 epilogues) should a network need another window.
 //
 // Structure: the transposed-layer scheme of mlp_layout.h - 32 points per wave, the C/D fragment of one layer IS the B operand of the
-// next, activations never leave the register file (here as 2 x 32 registers of fp16 pieces instead of 64 fp32 ones) - with EIGHT waves
+// next, activations never leave the register file (fp32; split into their fp16 pieces per k-step inside the GEMM loop) - with EIGHT waves
 // (256 points) per workgroup sharing each layer's weights: a layer is one 64 KB slab (hi plane | lo plane), two slabs alternate in LDS,
 // the next one arrives by LDS-DMA while the current one is multiplied (one barrier per layer), 132 KB of LDS = one workgroup = two
 // waves per SIMD.  Per k-step and output block a wave reads one hi and one lo weight fragment (ds_read_b128) for three MFMAs.
@@ -102,9 +102,16 @@ __device__ __forceinline__ HL split8h(const float* v)
     return r;
 }
 
+// DEV probe (scratch/r3/build_variant.sh; never defined in the product build): -DH3_NO_DMA fetches no weight slab at all (garbage results) - the
+// floor of MFMA + VALU + barriers: 77.4 us against 82.7 us with the slabs, i.e. the L2 -> LDS stream (256 MB per launch) is NOT what bounds the
+// kernel.  Measured without effect and removed: per-workgroup rotation of the piece order, non-temporal DMA loads.
 __device__ __forceinline__ void slab_dma(char* __restrict__ dst, const _Float16* __restrict__ src, size_t n_elems, int wave, int lane)
 {
+#if defined(H3_NO_DMA)
+    (void)dst; (void)src; (void)n_elems; (void)wave; (void)lane;
+#else
     lds_dma<H3_WAVES>(dst, src, (int)(n_elems >> 9), wave, lane);      // 1 KB (512 fp16) per wave-instruction (lds_dma.h)
+#endif
 }
 
 __device__ __forceinline__ void slab_sync()
@@ -114,11 +121,15 @@ __device__ __forceinline__ void slab_sync()
 }
 
 // acc[nb] += W[block nb] * act over STEPS k-steps of 16: per step and block pair two hi + two lo weight fragments, six MFMAs on two
-// independent accumulators, smallest piece products first
+// independent accumulators, smallest piece products first.  (Groups of four blocks - 12 MFMAs between fragment loads - measured the same, 85.7 vs
+// 84.7 us, with more spilled registers; the two waves of a SIMD taking turns in s_setprio per k-step: 87.6 vs 84.9 us.)
 template <int STEPS, int NBLK, typename BFN>
 __device__ __forceinline__ void gemm_h(const char* __restrict__ w_hi, const char* __restrict__ w_lo, f32x16 (&acc)[NBLK], int lane, BFN bfn)
 {
     static_assert(NBLK % 2 == 0, "output blocks are taken in pairs");
+    // one lane base per plane; every fragment of the segment is then an immediate offset of the ds_read (<= 65520 from the hi-plane base)
+    const f16x8* __restrict__ fh = reinterpret_cast<const f16x8*>(w_hi) + lane;
+    const f16x8* __restrict__ fl = reinterpret_cast<const f16x8*>(w_lo) + lane;
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
         const HL b = bfn(s);
@@ -127,9 +138,8 @@ __device__ __forceinline__ void gemm_h(const char* __restrict__ w_hi, const char
             f16x8 ah[2], al[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int off = ((s * NBLK + nb + e) * 64 + lane) * 16;
-                ah[e] = *reinterpret_cast<const f16x8*>(w_hi + off);
-                al[e] = *reinterpret_cast<const f16x8*>(w_lo + off);
+                ah[e] = fh[(s * NBLK + nb + e) * 64];
+                al[e] = fl[(s * NBLK + nb + e) * 64];
             }
 #pragma unroll
             for (int e = 0; e < 2; ++e) acc[nb + e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[e], b.hi, acc[nb + e], 0, 0, 0);
@@ -162,6 +172,14 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
     constexpr size_t ACT_PLANE = (size_t)B_ACT_STEPS * 4 * 512, PE_PLANE = (size_t)B_PE_STEPS * 4 * 512;     // fp16 elements of one plane
     constexpr size_t VIEW_PLANE = (size_t)B_VIEW_STEPS * 2 * 512;
     const size_t feat_plane = b_seg(L.fsteps, 4);
+#ifdef H3_CENSUS      // DEV probe: shader-clock stamps of this wave's phases, 32 per tile, behind the results (scratch/r3/h3_census.py allocates them)
+    unsigned* cen = reinterpret_cast<unsigned*>(raw + P * (ALPHA_ONLY ? 1 : 4)) + ((int64_t)blockIdx.x * H3_WAVES + wave) * 32;
+    int cen_i = 0;
+#define H3_STAMP() do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if (lane == 0 && cen_i < 32) cen[cen_i] = (unsigned)t__; ++cen_i; } while (0)
+#else
+#define H3_STAMP() do {} while (0)
+#endif
+    H3_STAMP();                                   // 0: wave start
 
     // slab 0 = pts_bias weights + layer 0 (contiguous in the packed buffer)
     slab_dma(buf0, wq + L.s0, L.l1 - L.s0, wave, lane);
@@ -183,7 +201,14 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
         pe[s] = split8h(t8);
     }
     float bias[64];                               // pts_bias(feat) / SW: relu(acc * bias) is then SA times the true activation
-    HL hb[8];                                     // the current activations as B operands: k-step s holds values q = 8s .. 8s+7 of this lane
+    // the current activations, 64 fp32 values per lane; k-step s of the next GEMM takes values q = 8s .. 8s+7 as its B operand and splits them
+    // there, between the MFMAs (splitting once in the layer epilogue instead - 64 registers of pieces - measured 86.8 against 84.7 us)
+    float h[64];
+    auto act = [&](int s) { return split8h(h + 8 * (s & 7)); };
+    auto put = [&](int s, const float* v8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[8 * s + j] = v8[j];
+    };
     // epilogue of a modulated ReLU layer; the clamp only matters where fp16 would overflow
     auto finish = [&](f32x16 (&acc)[4]) {
 #pragma unroll
@@ -194,11 +219,12 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
                 const int q = 8 * s + j;
                 v8[j] = __builtin_amdgcn_fmed3f(acc[q >> 4][q & 15] * bias[q], 0.0f, H_MAX);
             }
-            hb[s] = split8h(v8);
+            put(s, v8);
         }
     };
 
     slab_sync();
+    H3_STAMP();
     slab_dma(buf1, wq + L.l1, 2 * ACT_PLANE, wave, lane);
     {   // bias = pts_bias(feat)
         f32x16 acc[4];
@@ -209,6 +235,7 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
         if (L.fsteps == 1) gemm_h<1, 4>(wh, wl, acc, lane, fb);
         else if (L.fsteps == 2) gemm_h<2, 4>(wh, wl, acc, lane, fb);
         else gemm_h<3, 4>(wh, wl, acc, lane, fb);
+        H3_STAMP();
 #pragma unroll
         for (int q = 0; q < 64; ++q) bias[q] = acc[q >> 4][q & 15] * (1.0f / (SA * SW * SW));
     }
@@ -217,7 +244,9 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
         init_acc_b<4>(acc, vec + V_L0 + half * 64);
         const char* wh = buf0 + feat_plane * 4;
         gemm_h<B_PE_STEPS, 4>(wh, wh + PE_PLANE * 2, acc, lane, [&](int s) { return pe[s]; });
+        H3_STAMP();
         finish(acc);
+        H3_STAMP();
     }
     // layers 1..4: slabs alternate buf1, buf0, buf1, buf0
 #pragma unroll 1
@@ -225,23 +254,30 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
         char* cur = (layer & 1) ? buf1 : buf0;
         char* nxt = (layer & 1) ? buf0 : buf1;
         slab_sync();
+        H3_STAMP();
         if (layer < 4) slab_dma(nxt, wq + L.l1 + (size_t)layer * 2 * ACT_PLANE, 2 * ACT_PLANE, wave, lane);
         else slab_dma(nxt, wq + L.l5a, 2 * PE_PLANE, wave, lane);                    // after layer 4 (in buf0): L5a -> buf1
         f32x16 acc[4];
         init_acc_b<4>(acc, vec + V_L0 + 128 * layer + half * 64);
-        gemm_h<B_ACT_STEPS, 4>(cur, cur + ACT_PLANE * 2, acc, lane, [&](int s) { return hb[s]; });
+        gemm_h<B_ACT_STEPS, 4>(cur, cur + ACT_PLANE * 2, acc, lane, act);
+        H3_STAMP();
         finish(acc);
+        H3_STAMP();
     }
     float sigma;
     {   // layer 5 on cat([pts, h4]): L5a in buf1, L5b -> buf0
         f32x16 acc[4];
         slab_sync();
+        H3_STAMP();
         slab_dma(buf0, wq + L.l5b, 2 * ACT_PLANE, wave, lane);
         init_acc_b<4>(acc, vec + V_L0 + 128 * 5 + half * 64);
         gemm_h<B_PE_STEPS, 4>(buf1, buf1 + PE_PLANE * 2, acc, lane, [&](int s) { return pe[s]; });
+        H3_STAMP();
         slab_sync();
+        H3_STAMP();
         if (!ALPHA_ONLY) slab_dma(buf1, wq + L.feat, 2 * ACT_PLANE, wave, lane);
-        gemm_h<B_ACT_STEPS, 4>(buf0, buf0 + ACT_PLANE * 2, acc, lane, [&](int s) { return hb[s]; });
+        gemm_h<B_ACT_STEPS, 4>(buf0, buf0 + ACT_PLANE * 2, acc, lane, act);
+        H3_STAMP();
         // alpha_linear on the fp32 activations (before they are split), then the split for feature_linear
         const float* wa = vec + V_WA + half * 64;
         float part = 0.0f;
@@ -254,10 +290,11 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
                 v8[j] = __builtin_amdgcn_fmed3f(acc[q >> 4][q & 15] * bias[q], 0.0f, H_MAX);
                 part = fmaf(wa[q], v8[j], part);
             }
-            if (!ALPHA_ONLY) hb[s] = split8h(v8);
+            if (!ALPHA_ONLY) put(s, v8);
         }
         part += __shfl_xor(part, 32);
         sigma = fmaxf(fmaf(part, 1.0f / SA, vec[V_BA]), 0.0f);
+        H3_STAMP();
     }
     if (ALPHA_ONLY) {
         if (live && half == 0) raw[p_raw] = sigma;
@@ -266,9 +303,11 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
     {   // feature_linear (buf1, no activation), then views -> buf0
         f32x16 acc[4];
         slab_sync();
+        H3_STAMP();
         slab_dma(buf0, wq + L.views, 2 * VIEW_PLANE, wave, lane);
         init_acc_b<4>(acc, vec + V_FEAT + half * 64);
-        gemm_h<B_ACT_STEPS, 4>(buf1, buf1 + ACT_PLANE * 2, acc, lane, [&](int s) { return hb[s]; });
+        gemm_h<B_ACT_STEPS, 4>(buf1, buf1 + ACT_PLANE * 2, acc, lane, act);
+        H3_STAMP();
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             float v8[8];
@@ -277,7 +316,7 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
                 const int q = 8 * s + j;
                 v8[j] = __builtin_amdgcn_fmed3f(acc[q >> 4][q & 15] * (1.0f / SW), -H_MAX, H_MAX);
             }
-            hb[s] = split8h(v8);
+            put(s, v8);
         }
     }
     {   // views_linears[0] + rgb head
@@ -288,8 +327,10 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
         const HL d8 = split8h(dl);
         f32x16 acc[2];
         slab_sync();
+        H3_STAMP();
         init_acc_b<2>(acc, vec + V_VIEWS + half * 32);
-        gemm_h<B_VIEW_STEPS, 2>(buf0, buf0 + VIEW_PLANE * 2, acc, lane, [&](int s) { return s < 8 ? hb[s < 8 ? s : 0] : d8; });
+        gemm_h<B_VIEW_STEPS, 2>(buf0, buf0 + VIEW_PLANE * 2, acc, lane, [&](int s) { return s < 8 ? act(s) : d8; });
+        H3_STAMP();
         float rgb[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -301,6 +342,7 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
             rgb[c] = 1.0f / (1.0f + expf(-fmaf(part, 1.0f / (SA * SW), vec[V_BR + c])));
         }
         if (live && half == 0) *reinterpret_cast<f32x4*>(raw + p_raw * 4) = f32x4{rgb[0], rgb[1], rgb[2], sigma};
+        H3_STAMP();
     }
 }
 

@@ -69,8 +69,10 @@ def test_fp16x3_config2_vs_oracle_is_fp32_grade(net20):
     print("fp16x3 config 2:", e)
     n_over = int(((h[5][..., 3] - ref[6][..., 3]).abs() > 1e-4).sum())
     assert n_over == 0, f"{n_over} of {h[5][..., 3].numel()} sigma samples off by more than 1e-4"
-    assert e["sigma_vs_oracle"] < 5e-5 and e["raw_rgb_vs_oracle"] < 2e-5 and e["rgb_map_vs_oracle"] < 1e-5
-    assert e["weights_vs_oracle"] < 1e-5 and e["depth_vs_oracle"] < 3e-5 and e["alpha_vs_oracle"] < 1e-5
+    # bounds at <= 5x the measurements on MI355X (gpurun_out/measured_errs.jsonl, profiles/r03_measured_errs.jsonl): sigma 1.14e-5 of <= 20.4
+    # (the fp32-MFMA kernel on the same inputs: 9.5e-6), raw rgb 3.8e-6, rgb map 1.7e-6, weights 6.6e-7, depth 7.2e-7, alpha 1.6e-6
+    assert e["sigma_vs_oracle"] < 5e-5 and e["raw_rgb_vs_oracle"] < 1.5e-5 and e["rgb_map_vs_oracle"] < 8e-6
+    assert e["weights_vs_oracle"] < 3e-6 and e["depth_vs_oracle"] < 3.5e-6 and e["alpha_vs_oracle"] < 8e-6
     # fp32-grade: no further from the oracle than a few times the fp32 kernel itself
     assert e["sigma_vs_oracle"] < 5 * e["fp32_kernel_sigma_vs_oracle"] + 1e-5
     mse = float(((h[0] - ref[0]) ** 2).mean())
@@ -91,7 +93,7 @@ def test_fp16x3_ragged_shapes_and_sigma_only_path(net20, n_rays, n_samples):
     rgb, feat, w, depth, alpha, raw, sig = _render(net20, "fp16x3", n_samples, pose, pts, ndc, z, ro, dirs, vol, imgs)
     es, er, eo = float((raw[..., 3] - ref[6][..., 3]).abs().max()), float((raw[..., :3] - ref[6][..., :3]).abs().max()), float((sig - ref_sigma).abs().max())
     record_err(f"fp16x3_ragged_{n_rays}x{n_samples}:sigma", es)
-    assert es < 5e-5 and er < 2e-5 and eo < 5e-5, (es, er, eo)
+    assert es < 3.5e-5 and er < 1.5e-5 and eo < 3.5e-5, (es, er, eo)          # measured: sigma <= 7.6e-6 over these shapes
     assert sig.shape == (n_rays, n_samples, 1) and float((sig[..., 0] - raw[..., 3]).abs().max()) <= 1e-6      # both launches: the same arithmetic
     assert float((rgb - ref[0]).abs().max()) < 1e-5 and float((w - ref[2]).abs().max()) < 1e-5 and float((depth - ref[3]).abs().max()) < 5e-5
 
@@ -161,4 +163,4 @@ def test_fp16x3_frame_render_matches_the_fp32_frame(net20):
         b = ops.render_pixels(*args, packed_split=net20.packed_split(20, ops.N_SPLIT["fp16x3"]), **common)
     e = float((a["rgb"] - b["rgb"]).abs().max())
     record_err("fp16x3_frame:rgb_vs_fp32_kernel", e)
-    assert e < 1e-5 and float((a["depth"] - b["depth"]).abs().max()) < 5e-5
+    assert e < 9e-6 and float((a["depth"] - b["depth"]).abs().max()) < 5e-5          # measured 1.8e-6
