@@ -29,6 +29,10 @@ st = torch.cuda.current_stream().cuda_stream
 for _ in range(200):
     lib.mvsnerf_mlp_fwd_split(ps.data_ptr(), packed.data_ptr(), F, ns, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3, N, S, 0, raw.data_ptr(), st)
 torch.cuda.synchronize()
+raw[N * S * 4:].zero_()          # stamps of ONE launch in the steady state of back-to-back launches (32-bit stamps wrap within seconds)
+for _ in range(3):
+    lib.mvsnerf_mlp_fwd_split(ps.data_ptr(), packed.data_ptr(), F, ns, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3, N, S, 0, raw.data_ptr(), st)
+torch.cuda.synchronize()
 c = raw[N * S * 4:].view(torch.int32).cpu().numpy().astype(np.int64).reshape(n_tiles, 32) & 0xffffffff
 names = ["start", "sync0 (prologue + slab 0)", "G bias", "G l0", "E l0"] + sum([[f"S l{i}", f"G l{i}", f"E l{i}"] for i in range(1, 5)], []) + \
         ["S l5a", "G l5 pe", "S l5b", "G l5 act", "E l5 + sigma", "S feat", "G feat", "S views (+E feat)", "G views", "end (rgb head, store)"]
@@ -36,11 +40,8 @@ nst = len(names)
 t = c[:, :nst]
 d = (t[:, 1:] - t[:, :-1]) & 0xffffffff
 t0 = t[:, 0]
-first = t0.min()
-rel = (t0 - first) & 0xffffffff
-wg = np.arange(n_tiles) // 8
-print(f"tiles {n_tiles}; wave lifetime mean {((t[:, nst - 1] - t0) & 0xffffffff).mean():.0f} cycles; kernel span (first start -> last end) {int((((t[:, nst - 1] - first) & 0xffffffff)).max())} cycles")
-print(f"wave start after the first wave: workgroups 0-255 mean {rel[wg < 256].mean():.0f} max {rel[wg < 256].max()}, workgroups 256-511 mean {rel[wg >= 256].mean():.0f} min {rel[wg >= 256].min()} max {rel[wg >= 256].max()}")
+print(f"tiles {n_tiles}; wave lifetime mean {((t[:, nst - 1] - t0) & 0xffffffff).mean():.0f} cycles")
+# (the s_memtime counters of different CUs are not synchronised: only differences within a wave are used)
 tot = 0
 for i in range(nst - 1):
     print(f"  {names[i + 1]:28s} mean {d[:, i].mean():8.0f}   p10 {np.percentile(d[:, i], 10):8.0f}   p90 {np.percentile(d[:, i], 90):8.0f}")

@@ -29,6 +29,9 @@ def test_c_abi_rejects_bad_arguments_without_launching():
     assert l.mvsnerf_raymarch_fwd(None, 0) == EINVAL and l.mvsnerf_render_pixels_fwd(None, 0) == EINVAL
     assert l.mvsnerf_render_workspace_floats(0, 128, 3) == 0
     # split-MLP weight buffers: n_split 1..3 = bf16 pieces, MVSNERF_SPLIT_FP16 (18) = two fp16 pieces per operand (hi plane + lo plane per layer)
+    import os, re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mvsnerf_hip.h")).read()
+    assert int(re.search(r"#define MVSNERF_SPLIT_FP16 (\d+)", hdr).group(1)) == ops.N_SPLIT["fp16x3"] == 18      # the Python mode table follows the header
     seg = lambda steps, nb: steps * nb * 512
     assert l.mvsnerf_mlp_packed_split_elems(20, 18) == 2 * (seg(2, 4) + seg(4, 4) + 4 * seg(8, 4) + seg(4, 4) + 2 * seg(8, 4) + seg(9, 2)) == 256000
     assert l.mvsnerf_mlp_packed_split_elems(20, 4) == 0 and l.mvsnerf_mlp_packed_split_elems(21, 18) == 0 and l.mvsnerf_mlp_packed_split_elems(20, 3) > 0
