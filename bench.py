@@ -361,7 +361,7 @@ def main():
         enc_ready = True
     except ImportError:
         enc_ready = False
-    encode_ms_bf16 = None
+    encode_ms_bf16 = encode_ms_h3 = None
     if enc_ready:
         vol, encode_ms = encoder.bench_encode(rig, dev, PAD)
         volume_src = "mvsnet-encode"
@@ -372,6 +372,12 @@ def main():
             encode_ms_bf16["max_abs_volume_diff_vs_fp32_encode"] = float((vol_b - vol).abs().max())
             encode_ms_bf16["volume_abs_max"] = float(vol.abs().max())
             del vol_b
+            # opt-in as well: conv0 with fp32-GRADE results from the fp16 matrix cores (two fp16 pieces per operand, csrc/conv_f16x3.hip)
+            with encoder.encoder_precision("fp16x3"):
+                vol_h, encode_ms_h3 = encoder.bench_encode(rig, dev, PAD)
+            encode_ms_h3["max_abs_volume_diff_vs_fp32_encode"] = float((vol_h - vol).abs().max())
+            encode_ms_h3["volume_abs_max"] = float(vol.abs().max())
+            del vol_h
     else:
         vol = torch.randn((1, 8, D_PLANES, h, w), generator=torch.Generator().manual_seed(5)).to(dev)
         vol = vol.contiguous(memory_format=torch.channels_last_3d)
@@ -711,7 +717,7 @@ def main():
                        "weights": "mvsnerf-v0 checkpoint", "volume": volume_src, "rays_per_step_per_gpu": N_RAYS,
                        "parallelism": f"ray-sharded x{world}, no data-path collective",
                        "clock_settle_ms": a.settle_ms},
-            "encode_ms": encode_ms, "encode_ms_bf16_conv0": encode_ms_bf16,
+            "encode_ms": encode_ms, "encode_ms_bf16_conv0": encode_ms_bf16, "encode_ms_fp16x3_conv0": encode_ms_h3,
             "roofline": roof, "rooflines": roofs, "cpu_baseline": cpu, "multi_gpu": multi, "extras": extras,
         }))
     if world > 1:

@@ -85,6 +85,17 @@ size_t mvsnerf_conv0_bf16_packed_elems(int Cin);
 int mvsnerf_conv0_bf16_pack(const float* w, int Cin, void* packed, void* stream);
 int mvsnerf_conv0_bf16_tiles(int D, int H, int W);
 int mvsnerf_conv0_bf16_fwd(const void* x16, int Cin, int D, int H, int W, const void* packed, float* out, float* stats_part, void* stream);
+/* conv0 with fp32-GRADE results from the fp16 matrix cores (csrc/conv_f16x3.hip; opt-in `encoder.encoder_precision("fp16x3")`, inference): every
+ * operand as two fp16 pieces, x*w ~= x0*w0 + x0*w1 + x1*w0 on v_mfma_f32_16x16x32_f16 (dropped: <= 2^-22 of a product), fp32 accumulation.
+ *   planesweep_costvar_f16x2_fwd  the plane sweep (fp32 arithmetic) storing fp16(x/16) and fp16(x/16 - hi): cost16x2[2][ceil(CP/16)][D*Hp*Wp][16],
+ *                                 hi plane then lo plane (the reference operation it replaces: models.py:839-893, as mvsnerf_planesweep_costvar_fwd)
+ *   conv0_f16x3_pack / _fwd       w[8][Cin][3][3][3] -> fp16 pieces of 16 w; out / stats_part / tiles as mvsnerf_conv0_bf16_fwd (models.py:756) */
+int mvsnerf_planesweep_costvar_f16x2_fwd(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,
+                                         int V, int C, int H, int W, int D, int pad, void* cost16x2, int CP, float* masks,
+                                         int with_img, void* stream);
+size_t mvsnerf_conv0_f16x3_packed_elems(int Cin);
+int mvsnerf_conv0_f16x3_pack(const float* w, int Cin, void* packed, void* stream);
+int mvsnerf_conv0_f16x3_fwd(const void* x16x2, int Cin, int D, int H, int W, const void* packed, float* out, float* stats_part, void* stream);
 /*   conv0_bf16_dgrad_pack / conv0_bf16_dgrad   data gradient w.r.t. the n_ci (16 or 32) input channels starting at c_first (the plane sweep's
  *                                backward needs the 32 variance channels only): g = gradient of conv0's raw output, fp32 [D][H][W][8], rounded
  *                                to bf16 on the way into the matrix cores; gx[D][H][W][n_ci] fp32 */

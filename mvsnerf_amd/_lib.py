@@ -87,6 +87,10 @@ SIGNATURES = {
     "mvsnerf_conv0_bf16_pack": (_c_i, [_c_fp, _c_i, _c_fp, _c_fp]),
     "mvsnerf_conv0_bf16_tiles": (_c_i, [_c_i] * 3),
     "mvsnerf_conv0_bf16_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_planesweep_costvar_f16x2_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp]),
+    "mvsnerf_conv0_f16x3_packed_elems": (ctypes.c_size_t, [_c_i]),
+    "mvsnerf_conv0_f16x3_pack": (_c_i, [_c_fp, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_conv0_f16x3_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_conv0_bf16_dgrad_packed_elems": (ctypes.c_size_t, [_c_i]),
     "mvsnerf_conv0_bf16_dgrad_pack": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp]),
     "mvsnerf_conv0_bf16_dgrad": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_fp]),

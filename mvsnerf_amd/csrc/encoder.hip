@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void planesweep_blocks_kernel(
     // = 0.61; 48 floats put rows v and v + 4 on the same banks for the flush's ds_read_b128 and all rows on two bank phases for the stores.)
     const int GS = mvs_odd_quad_stride((V - 1) * 8 + 2);
     float* geo = lds_;                                           // [VPB][GS]
-    const int RS = mvs_odd_quad_stride((blocked == 2 ? ((CP + 15) & ~15) : CP) + 1);   // staging row (bf16 mode stages whole 16-channel blocks)
+    const int RS = mvs_odd_quad_stride((blocked >= 2 ? ((CP + 15) & ~15) : CP) + 1);   // staging row (bf16 mode stages whole 16-channel blocks)
     float* stage = lds_ + ((VPB * GS + 3) & ~3);                 // [VPP][RS]
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const int64_t nvox = (int64_t)D * Hp * Wp;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void planesweep_blocks_kernel(
             o[c_var + c] = s2[j] * inv - mean * mean;                // :890
         }
         if (q == 0)
-            for (int c = c_var + C; c < (blocked == 2 ? ((CP + 15) & ~15) : CP); ++c) o[c] = 0.0f;
+            for (int c = c_var + C; c < (blocked >= 2 ? ((CP + 15) & ~15) : CP); ++c) o[c] = 0.0f;
         // flush this pass's 64 consecutive voxels (one contiguous CP*64*4-byte span of the cost volume) with coalesced 16-byte stores
         __syncthreads();
         {
@@ -261,6 +261,27 @@ __global__ __launch_bounds__(256) void planesweep_blocks_kernel(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { h[e] = (__bf16)lo[e]; h[4 + e] = (__bf16)hi[e]; }
                     *reinterpret_cast<bf16x8_t*>(cost16 + (((int64_t)cb * nvox + p0 + vox) << 4) + (rem & 1) * 8) = h;
+                }
+            } else if (blocked == 3) {
+                // two fp16 pieces of x * 2^-4 (conv_f16x3.hip): hi = fp16(x'), lo = fp16(x' - hi), both round to nearest, in the bf16 mode's blocks
+                // of sixteen channels; the lo plane follows the hi plane
+                typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+                _Float16* cost16 = reinterpret_cast<_Float16*>(cost);
+                const int nb16 = (CP + 15) >> 4, per = nv * 2, n_k = per * nb16;
+                const int64_t lo_plane = (int64_t)nb16 * nvox * 16;
+                for (int k = threadIdx.x; k < n_k; k += VPB) {
+                    const int cb = k / per, rem = k - cb * per, vox = rem >> 1, c0 = cb * 16 + (rem & 1) * 8;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + vox * RS + c0), hi = *reinterpret_cast<const f32x4*>(stage + vox * RS + c0 + 4);
+                    f16x8_t h0, h1;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = fminf(fmaxf((e < 4 ? lo[e] : hi[e - 4]) * 0.0625f, -65504.0f), 65504.0f);
+                        const _Float16 a = (_Float16)v;
+                        h0[e] = a; h1[e] = (_Float16)(v - (float)a);
+                    }
+                    const int64_t at = (((int64_t)cb * nvox + p0 + vox) << 4) + (rem & 1) * 8;
+                    *reinterpret_cast<f16x8_t*>(cost16 + at) = h0;
+                    *reinterpret_cast<f16x8_t*>(cost16 + lo_plane + at) = h1;
                 }
             } else {
                 // channel block cb (four channels) of these nv voxels is one contiguous run of nv * 16 bytes: k -> (cb, voxel)
@@ -304,7 +325,7 @@ __global__ __launch_bounds__(64) void planesweep_kernel(
     // = 0.61; 48 floats put rows v and v + 4 on the same banks for the flush's ds_read_b128 and all rows on two bank phases for the stores.)
     const int GS = mvs_odd_quad_stride((V - 1) * 8 + 2);
     float* geo = lds_;                                           // [NP][NC][GS]
-    const int RS = mvs_odd_quad_stride((blocked == 2 ? ((CP + 15) & ~15) : CP) + 1);   // staging row (bf16 mode stages whole 16-channel blocks)
+    const int RS = mvs_odd_quad_stride((blocked >= 2 ? ((CP + 15) & ~15) : CP) + 1);   // staging row (bf16 mode stages whole 16-channel blocks)
     float* stage = lds_ + ((VPB * GS + 3) & ~3);                 // [16][RS]: the 16 columns of a group
     const int TS = 3 * V + 1;                                    // warped thumbnails of a voxel, written and read back by the same lane
     float* thumbs = stage + 16 * RS;                             // [NP][NC][TS] (with_img only)
@@ -469,7 +490,7 @@ __global__ __launch_bounds__(64) void planesweep_kernel(
                 if (q == (vv & 3)) { o[3 * vv] = th[3 * vv]; o[3 * vv + 1] = th[3 * vv + 1]; o[3 * vv + 2] = th[3 * vv + 2]; }
         }
         if (q == 0)
-            for (int c = c_var + C; c < (blocked == 2 ? ((CP + 15) & ~15) : CP); ++c) o[c] = 0.0f;
+            for (int c = c_var + C; c < (blocked >= 2 ? ((CP + 15) & ~15) : CP); ++c) o[c] = 0.0f;
         // flush this plane's n_col consecutive voxels (one contiguous span of the cost volume) with coalesced 16-byte stores
         __syncthreads();
         {
@@ -495,6 +516,27 @@ __global__ __launch_bounds__(64) void planesweep_kernel(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { h[e] = (__bf16)lo[e]; h[4 + e] = (__bf16)hi[e]; }
                     *reinterpret_cast<bf16x8_t*>(cost16 + (((int64_t)cb * nvox + p0 + vox) << 4) + (rem & 1) * 8) = h;
+                }
+            } else if (blocked == 3) {
+                // two fp16 pieces of x * 2^-4 (conv_f16x3.hip): hi = fp16(x'), lo = fp16(x' - hi), both round to nearest, in the bf16 mode's blocks
+                // of sixteen channels; the lo plane follows the hi plane
+                typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+                _Float16* cost16 = reinterpret_cast<_Float16*>(cost);
+                const int nb16 = (CP + 15) >> 4, per = nv * 2, n_k = per * nb16;
+                const int64_t lo_plane = (int64_t)nb16 * nvox * 16;
+                for (int k = threadIdx.x; k < n_k; k += VPB) {
+                    const int cb = k / per, rem = k - cb * per, vox = rem >> 1, c0 = cb * 16 + (rem & 1) * 8;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + vox * RS + c0), hi = *reinterpret_cast<const f32x4*>(stage + vox * RS + c0 + 4);
+                    f16x8_t h0, h1;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = fminf(fmaxf((e < 4 ? lo[e] : hi[e - 4]) * 0.0625f, -65504.0f), 65504.0f);
+                        const _Float16 a = (_Float16)v;
+                        h0[e] = a; h1[e] = (_Float16)(v - (float)a);
+                    }
+                    const int64_t at = (((int64_t)cb * nvox + p0 + vox) << 4) + (rem & 1) * 8;
+                    *reinterpret_cast<f16x8_t*>(cost16 + at) = h0;
+                    *reinterpret_cast<f16x8_t*>(cost16 + lo_plane + at) = h1;
                 }
             } else {
                 // channel block cb (four channels) of these nv voxels is one contiguous run of nv * 16 bytes: k -> (cb, voxel)
@@ -538,6 +580,15 @@ extern "C" int mvsnerf_planesweep_costvar_bf16_fwd(const float* feats_cl, const 
     return planesweep_launch(feats_cl, imgs_cl, proj, depth, V, C, H, W, D, pad, reinterpret_cast<float*>(cost16), CP, masks, with_img, 2, stream);
 }
 
+// The cost volume as two fp16 pieces of x * 2^-4, each in the bf16 mode's layout: cost16[2][ceil(CP/16)][D*Hp*Wp][16] (hi plane, then lo plane; channels
+// >= CP are zero) - the operand of the fp32-grade fp16 conv0 (conv_f16x3.hip).  The sweep's own arithmetic is the fp32 one; only the store splits.
+extern "C" int mvsnerf_planesweep_costvar_f16x2_fwd(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,
+                                                    int V, int C, int H, int W, int D, int pad, void* cost16x2, int CP, float* masks,
+                                                    int with_img, void* stream)
+{
+    return planesweep_launch(feats_cl, imgs_cl, proj, depth, V, C, H, W, D, pad, reinterpret_cast<float*>(cost16x2), CP, masks, with_img, 3, stream);
+}
+
 MVS_KNOB_DEF(g_psw_fwd_reuse, 1)   // knobs.h
 
 static int planesweep_launch(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,
@@ -553,7 +604,7 @@ static int planesweep_launch(const float* feats_cl, const float* imgs_cl, const 
     if ((CP & 3) || !mvs_aligned16(cost)) return MVSNERF_EALIGN;
     const int Hp = H + 2 * pad, Wp = W + 2 * pad, RB = (Hp + 7) >> 3;
     const size_t lds_geo = (((size_t)256 * mvs_odd_quad_stride((V - 1) * 8 + 2) + 3) & ~(size_t)3);
-    const size_t lds_stage = (size_t)64 * mvs_odd_quad_stride((blocked == 2 ? ((CP + 15) & ~15) : CP) + 1);
+    const size_t lds_stage = (size_t)64 * mvs_odd_quad_stride((blocked >= 2 ? ((CP + 15) & ~15) : CP) + 1);
 #ifdef MVSNERF_DEV_KNOBS
     if (!g_psw_fwd_reuse) {
         const size_t lds = (lds_geo + lds_stage) * sizeof(float);
@@ -568,7 +619,7 @@ static int planesweep_launch(const float* feats_cl, const float* imgs_cl, const 
     }
 #endif
     const size_t lds = ((((size_t)64 * mvs_odd_quad_stride((V - 1) * 8 + 2) + 3) & ~(size_t)3) +
-                        (size_t)16 * mvs_odd_quad_stride((blocked == 2 ? ((CP + 15) & ~15) : CP) + 1) + (with_img ? (size_t)64 * (3 * V + 1) : 0) + 4 * 7 * 3) * sizeof(float);
+                        (size_t)16 * mvs_odd_quad_stride((blocked >= 2 ? ((CP + 15) & ~15) : CP) + 1) + (with_img ? (size_t)64 * (3 * V + 1) : 0) + 4 * 7 * 3) * sizeof(float);
     static unsigned long long cap_mask = 0;
     if (lds > 48 * 1024) {      // many source views: raise the dynamic-LDS cap (idempotent, per device)
         const int rc = mvs_raise_lds_cap(reinterpret_cast<const void*>(planesweep_kernel<32, 4>), (int)lds, &cap_mask);

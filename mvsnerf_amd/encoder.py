@@ -18,18 +18,20 @@ from ._lib import check, dev_f32, stream_ptr
 
 ABN_EPS, ABN_MOMENTUM, ABN_SLOPE = 1e-5, 0.1, 0.01
 
-ENCODER_PRECISION = "fp32"      # "fp32" | "bf16": see encoder_precision
+ENCODER_PRECISION = "fp32"      # "fp32" | "bf16" | "fp16x3": see encoder_precision
 
 
 class encoder_precision:
     """`with encoder.encoder_precision("bf16"): ...` - the reference's AMP switch for the scene encoder (train_mvs_nerf_pl.py:317-318
     `precision=16 if args.use_amp`; BASELINE config 3): the plane sweep stores the cost volume as bf16 and conv0 of CostRegNet (74.5 % of the
     encoder's FLOPs) runs forward, data gradient and weight gradient on v_mfma_f32_16x16x32_bf16 (csrc/conv_bf16.hip) - operands rounded to
-    bf16, fp32 accumulation, fp32 statistics / master weights / gradients.  The other layers keep their fp32 kernels.  Default "fp32"."""
+    bf16, fp32 accumulation, fp32 statistics / master weights / gradients.  The other layers keep their fp32 kernels.  Default "fp32".
+    "fp16x3" (inference; a step that needs gradients keeps the fp32 kernels): conv0 with fp32-GRADE results from the fp16 matrix cores - the plane sweep
+    stores every cost value as two fp16 pieces, conv0 multiplies x0*w0 + x0*w1 + x1*w0 (csrc/conv_f16x3.hip; what is dropped is <= 2^-22 of a product)."""
 
     def __init__(self, mode):
-        if mode not in ("fp32", "bf16"):
-            raise ValueError("encoder precision must be 'fp32' or 'bf16'")
+        if mode not in ("fp32", "bf16", "fp16x3"):
+            raise ValueError("encoder precision must be 'fp32', 'bf16' or 'fp16x3'")
         self.mode = mode
 
     def __enter__(self):
@@ -486,6 +488,22 @@ class _PackedConv:
         return buf
 
 
+def _get_f16x3_conv0(pk):
+    """fp16 hi / lo B fragments of conv0 (csrc/conv_f16x3.hip), cached like the other layouts of _PackedConv."""
+    w = pk.conv.weight
+    key = (w.data_ptr(), w._version, _lib.weights_epoch())
+    hit = pk.cache.get("f16x3_fwd")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    if pk.transposed or pk.conv.stride[0] != 1 or pk.cout != 8:
+        raise RuntimeError("fp16x3 conv0: stride-1 Conv3d with 8 output channels (conv0)")
+    lib = _lib.lib()
+    buf = torch.empty(lib.mvsnerf_conv0_f16x3_packed_elems(pk.cin), device=w.device, dtype=torch.float16)
+    check(lib.mvsnerf_conv0_f16x3_pack(dev_f32(w.detach().contiguous(), "conv weight"), pk.cin, buf.data_ptr(), stream_ptr()), "conv0_f16x3_pack")
+    pk.cache["f16x3_fwd"] = (key, buf)
+    return buf
+
+
 def _abn_stats(raw, n_vox, bn, update_running=True, partials=None):
     """Train-mode InPlaceABN statistics of a raw layer output -> (scale, shift, mean, invstd).  partials = (buffer, n_blocks): the
     producing kernel already left per-workgroup sums (mvsnerf_*_fwd_stats), only stage 2 runs."""
@@ -713,14 +731,18 @@ class CostRegNet(nn.Module):
         if isinstance(x, _BlockedCost16):
             pk = self.conv0._packed
             if x.n_ch != pk.cin:
-                raise RuntimeError(f"CostRegNet: bf16 cost volume has {x.n_ch} channels, conv0 expects {pk.cin}")
+                raise RuntimeError(f"CostRegNet: 16-bit cost volume has {x.n_ch} channels, conv0 expects {pk.cin}")
             raw = torch.empty((D, H, W, pk.cout), device=x.buf.device, dtype=torch.float32)
             lib = _lib.lib()
             want = self.conv0.bn.training and FUSED_ABN_STATS
-            nblk = lib.mvsnerf_conv0_bf16_tiles(D, H, W)
+            nblk = lib.mvsnerf_conv0_bf16_tiles(D, H, W)                   # the fp16x3 kernel has the same tiles / statistics slots
             part = torch.empty(nblk * 16, device=raw.device, dtype=torch.float32) if want else None
-            check(lib.mvsnerf_conv0_bf16_fwd(x.buf.data_ptr(), pk.cin, D, H, W, pk.get_bf16_conv0().data_ptr(), raw.data_ptr(),
-                                             0 if part is None else part.data_ptr(), stream_ptr()), "conv0_bf16_fwd")
+            if isinstance(x, _BlockedCostH2):
+                check(lib.mvsnerf_conv0_f16x3_fwd(x.buf.data_ptr(), pk.cin, D, H, W, _get_f16x3_conv0(pk).data_ptr(), raw.data_ptr(),
+                                                  0 if part is None else part.data_ptr(), stream_ptr()), "conv0_f16x3_fwd")
+            else:
+                check(lib.mvsnerf_conv0_bf16_fwd(x.buf.data_ptr(), pk.cin, D, H, W, pk.get_bf16_conv0().data_ptr(), raw.data_ptr(),
+                                                 0 if part is None else part.data_ptr(), stream_ptr()), "conv0_bf16_fwd")
             scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self.conv0.bn, update_running=self.conv0.bn.training,
                                                     partials=None if part is None else (part, nblk))
             c0 = _Lazy(raw, scale, shift, (D, H, W, pk.cout), mean, invstd)
@@ -932,6 +954,17 @@ class _BlockedCost16(_BlockedCost):
     __slots__ = ()
 
 
+def _inference_hand_off():
+    """`blocked` of the no-grad plane sweep -> conv0 hand-off for the current encoder precision."""
+    return {"bf16": "bf16", "fp16x3": "fp16x2"}.get(ENCODER_PRECISION, True)
+
+
+class _BlockedCostH2(_BlockedCost16):
+    """Two fp16 pieces of cost / 16 in that layout, hi plane then lo plane: buf[2][ceil(n_ch/16)][D*H*W][16] torch.float16
+    (mvsnerf_planesweep_costvar_f16x2_fwd -> the fp32-grade fp16 conv0 of csrc/conv_f16x3.hip; encoder_precision("fp16x3"), inference)."""
+    __slots__ = ()
+
+
 def _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img, blocked=False):
     """One-pass plane sweep (homo_warp + cost variance [+ warped thumbnails]).  Returns (cost view, masks, saved);
     blocked=True: the cost volume comes back as a _BlockedCost instead of a logical NCDHW view."""
@@ -956,6 +989,13 @@ def _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img, blocked=Fa
     masks = torch.empty((V, D, Hp, Wp) if with_img else (1, D, Hp, Wp), device=dev, dtype=torch.float32)
     proj = proj_mats[0].detach().contiguous()
     depth = depth_values[0].detach().contiguous()
+    if blocked == "fp16x2":
+        nb16 = (n_ch + 15) // 16
+        cost = torch.empty((2, nb16, D * Hp * Wp, 16), device=dev, dtype=torch.float16)
+        check(lib.mvsnerf_planesweep_costvar_f16x2_fwd(feats_cl.data_ptr(), imgs_cl_p, dev_f32(proj, "proj_mats"), dev_f32(depth, "depth_values"),
+                                                       V, C, H, W, D, pad, cost.data_ptr(), CP, masks.data_ptr(), int(with_img), stream_ptr()),
+              "planesweep_costvar_f16x2_fwd")
+        return _BlockedCostH2(cost, n_ch, nb16 * 16, (D, Hp, Wp)), masks.unsqueeze(0), (feats_cl, proj, depth, (V, C, H, W, D, pad, CP, n_ch))
     if blocked == "bf16":
         nb16 = (n_ch + 15) // 16
         cost = torch.empty((nb16, D * Hp * Wp, 16), device=dev, dtype=torch.bfloat16)
@@ -1120,7 +1160,7 @@ class MVSNet(nn.Module):
                 and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.cost_reg_2.parameters()))
                 and (32 + 3 * V + 3) // 4 * 4 in _BLOCKED_CIN)
         if fast:
-            cost, _ = self._sweep(imgs, feats_l, proj_mats, depth_values, pad, True, blocked="bf16" if ENCODER_PRECISION == "bf16" else True)
+            cost, _ = self._sweep(imgs, feats_l, proj_mats, depth_values, pad, True, blocked=_inference_hand_off())
             return self.cost_reg_2(cost), feats_l, depth_values
         if BLOCKED_COST and not return_color and torch.is_grad_enabled() and (32 + 3 * V + 3) // 4 * 4 in _BLOCKED_CIN and B == 1:
             # training: the same blocked hand-off inside one autograd node
@@ -1156,7 +1196,7 @@ def bench_encode(rig, dev, pad, iters=6):
             t_vals = torch.linspace(0.0, 1.0, steps=net.D, device=dev)
             dv = (nf[0] * (1.0 - t_vals) + nf[1] * t_vals).unsqueeze(0)
             if BLOCKED_COST:
-                cost, _ = net._sweep(imgs, feats_l, proj, dv, pad, True, blocked="bf16" if ENCODER_PRECISION == "bf16" else True)   # what MVSNet.forward does without gradients
+                cost, _ = net._sweep(imgs, feats_l, proj, dv, pad, True, blocked=_inference_hand_off())   # what MVSNet.forward does without gradients
             else:
                 cost, _ = net.build_volume_costvar_img(imgs, feats_l, proj, dv, pad=pad)
             torch.cuda.synchronize(); t2 = time.perf_counter()
