@@ -37,6 +37,7 @@ for k, v in keep.items():
     if isinstance(v, dict): print(k, {c: round(x['mean'], 1) for c, x in v.items()})
 PY
 rm -rf $O/pmc
+cp $O/r03_pmc_summary.json profiles/r03_pmc_summary.json      # (on the box) so that the bench line below reports the traffic measured on THESE kernel sources
 python bench.py > $O/r03_bench.json 2> $O/r03_bench.err
 python bench.py --mlp-precision fp16x3 --no-extras > $O/r03b_bench_fp16x3.json 2> $O/r03b_bench_fp16x3.err
 ls -la $O
