@@ -364,18 +364,21 @@ def main():
     encode_ms_bf16 = encode_ms_h3 = None
     if enc_ready:
         vol, encode_ms = encoder.bench_encode(rig, dev, PAD)
+        encode_ms["conv0_arithmetic"] = ("fp16x3: two fp16 pieces per operand, x0*w0 + x0*w1 + x1*w0 on v_mfma_f32_16x16x32_f16, fp32 accumulation (the default of a no-grad "
+                                         "encode; encode_ms_fp32_conv0 = the same encode with conv0 on v_mfma_f32_4x4x1_16B_f32)")
         volume_src = "mvsnet-encode"
         if not a.no_extras:
             # opt-in (NOT the headline volume, which stays fp32): the encoder with conv0 on the bf16 matrix cores from a bf16 cost volume
             with encoder.encoder_precision("bf16"):
                 vol_b, encode_ms_bf16 = encoder.bench_encode(rig, dev, PAD)
-            encode_ms_bf16["max_abs_volume_diff_vs_fp32_encode"] = float((vol_b - vol).abs().max())
+            encode_ms_bf16["max_abs_volume_diff_vs_default_encode"] = float((vol_b - vol).abs().max())
             encode_ms_bf16["volume_abs_max"] = float(vol.abs().max())
             del vol_b
-            # opt-in as well: conv0 with fp32-GRADE results from the fp16 matrix cores (two fp16 pieces per operand, csrc/conv_f16x3.hip)
-            with encoder.encoder_precision("fp16x3"):
+            # the same encode with conv0 on the fp32-MFMA kernel (encoder_precision "fp32"): the default above ("auto") runs conv0 of a no-grad encode as
+            # two fp16 pieces per operand, three fp16 matrix-core products per product, fp32 accumulation (csrc/conv_f16x3.hip; fp32-grade: DESIGN.md 0a)
+            with encoder.encoder_precision("fp32"):
                 vol_h, encode_ms_h3 = encoder.bench_encode(rig, dev, PAD)
-            encode_ms_h3["max_abs_volume_diff_vs_fp32_encode"] = float((vol_h - vol).abs().max())
+            encode_ms_h3["max_abs_volume_diff_vs_default_encode"] = float((vol_h - vol).abs().max())
             encode_ms_h3["volume_abs_max"] = float(vol.abs().max())
             del vol_h
     else:
@@ -717,7 +720,7 @@ def main():
                        "weights": "mvsnerf-v0 checkpoint", "volume": volume_src, "rays_per_step_per_gpu": N_RAYS,
                        "parallelism": f"ray-sharded x{world}, no data-path collective",
                        "clock_settle_ms": a.settle_ms},
-            "encode_ms": encode_ms, "encode_ms_bf16_conv0": encode_ms_bf16, "encode_ms_fp16x3_conv0": encode_ms_h3,
+            "encode_ms": encode_ms, "encode_ms_bf16_conv0": encode_ms_bf16, "encode_ms_fp32_conv0": encode_ms_h3,
             "roofline": roof, "rooflines": roofs, "cpu_baseline": cpu, "multi_gpu": multi, "extras": extras,
         }))
     if world > 1:

@@ -18,20 +18,24 @@ from ._lib import check, dev_f32, stream_ptr
 
 ABN_EPS, ABN_MOMENTUM, ABN_SLOPE = 1e-5, 0.1, 0.01
 
-ENCODER_PRECISION = "fp32"      # "fp32" | "bf16" | "fp16x3": see encoder_precision
+ENCODER_PRECISION = "auto"      # "auto" | "fp32" | "bf16" | "fp16x3": see encoder_precision
 
 
 class encoder_precision:
-    """`with encoder.encoder_precision("bf16"): ...` - the reference's AMP switch for the scene encoder (train_mvs_nerf_pl.py:317-318
-    `precision=16 if args.use_amp`; BASELINE config 3): the plane sweep stores the cost volume as bf16 and conv0 of CostRegNet (74.5 % of the
-    encoder's FLOPs) runs forward, data gradient and weight gradient on v_mfma_f32_16x16x32_bf16 (csrc/conv_bf16.hip) - operands rounded to
-    bf16, fp32 accumulation, fp32 statistics / master weights / gradients.  The other layers keep their fp32 kernels.  Default "fp32".
-    "fp16x3" (inference; a step that needs gradients keeps the fp32 kernels): conv0 with fp32-GRADE results from the fp16 matrix cores - the plane sweep
-    stores every cost value as two fp16 pieces, conv0 multiplies x0*w0 + x0*w1 + x1*w0 (csrc/conv_f16x3.hip; what is dropped is <= 2^-22 of a product)."""
+    """`with encoder.encoder_precision(mode): ...` - the arithmetic of conv0 of CostRegNet (models.py:756; 74.5 % of the encoder's FLOPs).  Every
+    other layer, the plane sweep's own arithmetic, InPlaceABN statistics, master weights and gradients are fp32 in every mode.
+      "auto" (default)  a no-grad scene encode (validation_step / render_view / fine-tuning's one-off encode) takes the fp32-GRADE fp16 kernel
+                "fp16x3" below; a step that needs gradients takes the fp32-MFMA kernels
+      "fp32"    conv0 on v_mfma_f32_4x4x1_16B_f32 (csrc/conv_mfma.hip) everywhere
+      "fp16x3"  = "auto": the plane sweep stores every cost value as two fp16 pieces of x / 16, conv0 multiplies x0*w0 + x0*w1 + x1*w0 on
+                v_mfma_f32_16x16x32_f16 (csrc/conv_f16x3.hip; dropped: <= 2^-22 of a product).  Measured: as far from the CPU oracle as the fp32 kernel
+                (DESIGN.md 0a), 0.53 instead of 0.81 ms; cost values saturate at 2^20 (the shipped FeatureNet: < 450)
+      "bf16"    the reference's AMP switch (train_mvs_nerf_pl.py:317-318 `precision=16 if args.use_amp`; BASELINE config 3): the cost volume is stored as
+                bf16 and conv0 runs forward, data gradient and weight gradient on v_mfma_f32_16x16x32_bf16 (csrc/conv_bf16.hip): operands ROUNDED to bf16."""
 
     def __init__(self, mode):
-        if mode not in ("fp32", "bf16", "fp16x3"):
-            raise ValueError("encoder precision must be 'fp32', 'bf16' or 'fp16x3'")
+        if mode not in ("auto", "fp32", "bf16", "fp16x3"):
+            raise ValueError("encoder precision must be 'auto', 'fp32', 'bf16' or 'fp16x3'")
         self.mode = mode
 
     def __enter__(self):
@@ -956,7 +960,7 @@ class _BlockedCost16(_BlockedCost):
 
 def _inference_hand_off():
     """`blocked` of the no-grad plane sweep -> conv0 hand-off for the current encoder precision."""
-    return {"bf16": "bf16", "fp16x3": "fp16x2"}.get(ENCODER_PRECISION, True)
+    return {"bf16": "bf16", "fp16x3": "fp16x2", "auto": "fp16x2"}.get(ENCODER_PRECISION, True)
 
 
 class _BlockedCostH2(_BlockedCost16):

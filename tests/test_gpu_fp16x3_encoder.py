@@ -1,4 +1,5 @@
-"""Opt-in fp32-GRADE conv0 on the fp16 matrix cores (csrc/conv_f16x3.hip; `encoder.encoder_precision("fp16x3")`, inference): the plane sweep's
+"""fp32-GRADE conv0 on the fp16 matrix cores (csrc/conv_f16x3.hip; what a no-grad scene encode runs by default, `encoder.encoder_precision("fp32")` selects
+the fp32-MFMA kernel instead): the plane sweep's
 two-piece fp16 store, conv0 = x0*w0 + x0*w1 + x1*w0 against float64 convolutions of the UN-rounded fp32 operands (the claim is fp32 grade, not
 "equal to an emulation of its own rounding"), and the scene encode end to end against the fp32 path and the CPU oracle
 (reference: models.py:756 conv0, :839-893 plane sweep)."""
@@ -86,8 +87,9 @@ def test_conv0_f16x3_forward_vs_float64(cin, dims):
 
 
 def test_encode_fp16x3_vs_fp32_path_and_oracle():
-    """MVSNet.forward (3 x 256x320 images, 64 planes, shipped weights) under encoder_precision("fp16x3") against the default fp32 kernels and
-    against the CPU oracle: the volume moves by no more than the fp32 path's own distance from the oracle."""
+    """MVSNet.forward (3 x 256x320 images, 64 planes, shipped weights) with the fp16 conv0 (the default of a no-grad encode = "fp16x3") against
+    the all-fp32 kernels (encoder_precision("fp32")) and against the CPU oracle: the volume moves by no more than the fp32 path's own distance
+    from the oracle."""
     from mvsnerf_amd import encoder as E, models
     from mvsnerf_amd.synth import make_rig
     from oracle import mvsnerf_oracle as O
@@ -102,9 +104,13 @@ def test_encode_fp16x3_vs_fp32_path_and_oracle():
     net = net.to(DEV).train()
     net.D = D
     with torch.no_grad():
-        v32 = net(imgs.to(DEV), proj.to(DEV), nf.to(DEV), pad=pad)[0].float().cpu().reshape(ovol.shape)
+        with E.encoder_precision("fp32"):
+            v32 = net(imgs.to(DEV), proj.to(DEV), nf.to(DEV), pad=pad)[0].float().cpu().reshape(ovol.shape)
         with E.encoder_precision("fp16x3"):
             v16 = net(imgs.to(DEV), proj.to(DEV), nf.to(DEV), pad=pad)[0].float().cpu().reshape(ovol.shape)
+        assert E.ENCODER_PRECISION == "auto"
+        vdef = net(imgs.to(DEV), proj.to(DEV), nf.to(DEV), pad=pad)[0].float().cpu().reshape(ovol.shape)
+    assert torch.equal(vdef, v16) and not torch.equal(v32, v16)       # the default of a no-grad encode IS the fp16 conv0
     e32, e16, d = float((v32 - ovol).abs().max()), float((v16 - ovol).abs().max()), float((v16 - v32).abs().max())
     record_err("encode_fp16x3:vs_oracle", e16, scale=float(ovol.abs().max()))
     record_err("encode_fp16x3:fp32_path_vs_oracle", e32, scale=float(ovol.abs().max()))
