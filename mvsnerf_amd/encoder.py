@@ -28,7 +28,7 @@ class encoder_precision:
                 "fp16x3" below; a step that needs gradients takes the fp32-MFMA kernels
       "fp32"    conv0 on v_mfma_f32_4x4x1_16B_f32 (csrc/conv_mfma.hip) everywhere
       "fp16x3"  = "auto": the plane sweep stores every cost value as two fp16 pieces of x / 16, conv0 multiplies x0*w0 + x0*w1 + x1*w0 on
-                v_mfma_f32_16x16x32_f16 (csrc/conv_f16x3.hip; dropped: <= 2^-22 of a product).  Measured: as far from the CPU oracle as the fp32 kernel
+                v_mfma_f32_16x16x32_f16 (csrc/conv_f16x3.hip; dropped: <= 2^-22 of a product).  Measured: as far from the reference's CPU results as the fp32 kernel
                 (DESIGN.md 0a), 0.53 instead of 0.81 ms; cost values saturate at 2^20 (the shipped FeatureNet: < 450)
       "bf16"    the reference's AMP switch (train_mvs_nerf_pl.py:317-318 `precision=16 if args.use_amp`; BASELINE config 3): the cost volume is stored as
                 bf16 and conv0 runs forward, data gradient and weight gradient on v_mfma_f32_16x16x32_bf16 (csrc/conv_bf16.hip): operands ROUNDED to bf16."""
