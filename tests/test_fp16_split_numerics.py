@@ -69,3 +69,23 @@ def test_three_piece_products_are_fp32_grade_on_the_shipped_mlp():
     scale = float(y64.abs().max())
     assert e16 < 3 * e32 + 1e-6 * scale, (e16, e32)            # fp32 grade (measured: 2.4e-6 against the fp32 path's 2.9e-6 on config-2-like inputs)
     assert eb > 10 * e16                                       # the two-piece bf16 split is not
+
+
+def test_two_piece_conv0_is_closer_to_float64_than_the_fp32_convolution():
+    """conv0 of CostRegNet (models.py:756) with the shipped weights on cost-volume-like values: the operands as two fp16 pieces of x/16 and 16 w
+    (what csrc/conv_f16x3.hip multiplies; piece convolutions in float64 here) against the float64 convolution, next to torch's fp32 convolution."""
+    import torch.nn.functional as F
+    _, sd = load_weights()
+    w = sd["cost_reg_2.conv0.conv.weight"]
+    g = torch.Generator().manual_seed(2)
+    x = torch.cat([torch.rand((1, 9, 10, 20, 24), generator=g), torch.randn((1, 32, 10, 20, 24), generator=g).abs() * 60], 1)     # thumbnails | variances
+    xs, ws = x * 0.0625, w * 16.0
+    x0, x1 = _pieces(xs, torch.float16)
+    w0, w1 = _pieces(ws, torch.float16)
+    with torch.no_grad():
+        y64 = F.conv3d(x.double(), w.double(), padding=1)
+        y32 = F.conv3d(x, w, padding=1)
+        ys = F.conv3d(x0, w0, padding=1) + F.conv3d(x0, w1, padding=1) + F.conv3d(x1, w0, padding=1)
+    e32, es, scale = float((y32.double() - y64).abs().max()), float((ys - y64).abs().max()), float(y64.abs().max())
+    assert es < 4e-7 * scale, (es, scale)          # 22-bit operands: ~3 x 2^-22 per product, partly cancelling over 41 x 27 terms
+    assert es < e32                                # below the rounding noise of an fp32 summation
