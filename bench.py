@@ -402,13 +402,14 @@ def main():
         pts, ndc, z, ro, rdir = batches[i % n_batches]
         return renderer.rendering(args, pose, pts, ndc, z, ro, rdir, vol, src, network_fn=net, network_query_fn=qfn)
 
+    import gc
+    gc.collect(); gc.disable()                # no cyclic-GC pause of the Python host inside the timed region (nothing is skipped: the steps allocate no cycles).
+                                              # Collected HERE, before the clock-settle phase: a ~0.1 s host pause between warmup and timing lets the GPU clocks drop
     with torch.no_grad():
         settle(step, a.settle_ms, indexed=True)
         for i in range(a.warmup):
             step(i)
         torch.cuda.synchronize()
-        import gc
-        gc.collect(); gc.disable()            # no cyclic-GC pause of the Python host inside the timed region (nothing is skipped: the steps allocate no cycles)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -651,11 +652,11 @@ def main():
                 ops.set_mlp_precision(mode)
                 gc_on = gc.isenabled()
                 try:
+                    gc.collect(); gc.disable()                 # before the warm steps: no host pause between them and the timed loops
                     with torch.no_grad():
                         for i in range(10):
                             step(i)
                         torch.cuda.synchronize()
-                        gc.collect(); gc.disable()
                         reps = []
                         for _ in range(3):
                             b0 = time.perf_counter()
