@@ -9,7 +9,7 @@
  *   - plain pointers + sizes, no torch types.  Every pointer is a DEVICE pointer (fp32 unless noted)
  *     owned by the caller; outputs are caller-allocated and fully written.  The library allocates
  *     nothing and has no behavioural state: its only process-global data are per-device "dynamic-LDS cap already
- *     raised" bits (idempotent).  (The A/B switches between kernel variants exist only in the dev build, csrc/knobs.h.)
+ *     raised" bits (idempotent).  (Which kernel family a dispatcher picks is a compile-time constant, csrc/knobs.h; only the entry points declared here are exported, csrc/exports.map.)
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls only enqueue work.
  *   - return 0 on success, a negative MVSNERF_E* for rejected arguments (nothing was launched),
  *     or a positive hipError_t from the launch.

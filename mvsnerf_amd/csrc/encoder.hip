@@ -83,221 +83,6 @@ extern "C" int mvsnerf_resize_bilinear(const float* src, float* dst, int NC, int
 // wave change their tap set at different planes, so every plane stalled some lane group of every wave on a gather;
 // scratch/r3/psw_fwd_columns_dropped.hip.txt.)  Writes the voxel's CP-channel vector once (the reference moves ~10 GB for the same result).
 // =============================================================================================
-#ifdef MVSNERF_DEV_KNOBS   // round 2/3's mapping (256 consecutive voxels of one plane per workgroup, every voxel gathers): A/B only
-template <int C>   // feature channels (32)
-__global__ __launch_bounds__(256) void planesweep_blocks_kernel(
-    const float* __restrict__ feat,   // [V][H][W][C]
-    const float* __restrict__ img,    // [V][H][W][4] or null
-    const float* __restrict__ proj,   // [V][3][4]
-    const float* __restrict__ depth,  // [D]
-    int V, int H, int W, int D, int pad,
-    float* __restrict__ cost, int CP,   // [D][Hp][Wp][CP]
-    float* __restrict__ masks,          // with img: [V][D][Hp][Wp] per-view; else [D][Hp][Wp] count
-    int with_img, int blocked)          // blocked 1: cost[CP/4][D*Hp*Wp][4] (channel blocks of four, see mvsnerf_planesweep_costvar_blocked_fwd);
-                                        // 2: bf16 in channel blocks of sixteen, cost16[ceil(CP/16)][D*Hp*Wp][16] (mvsnerf_planesweep_costvar_bf16_fwd)
-{
-    // fp32 arithmetic of the CPU reference path, operation for operation (scratch/r3/cpu_arith_probe.py, cpu_var_probe.py compare candidate
-    // formulas with reference-generated fixtures BIT FOR BIT): the projection is a k-ordered fma chain (sgemm), grid_sample's blend is
-    // fma(se, w_se, fma(sw, w_sw, fma(ne, w_ne, nw * w_nw))), and everything in models.py:879-890 is one ATen op per rounding
-    // (x**2, +, *count, -): no contraction anywhere else.
-#pragma clang fp contract(off)
-    static_assert(C == 32, "lane q owns float4 numbers q and q + 4 of a 32-channel pixel");
-    constexpr int VPB = 256, VPP = 64;                           // voxels per block / per pass
-    extern __shared__ __attribute__((aligned(16))) float lds_[];
-    // per voxel: per source view {w_nw,w_ne,w_sw,w_se, t_nw,t_ne,t_sw,t_se}; then {1/count, ref pixel}.  Row strides in floats with
-    // stride / 4 ODD: consecutive rows then start on different 16-byte bank groups (16 rows cover all 64 banks once), so that the 16-byte
-    // reads of 16 voxels' rows (phase 2, flush) do not collide.  (Round 2 had 18 and CP + 4 = 48: PMC SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
-    // = 0.61; 48 floats put rows v and v + 4 on the same banks for the flush's ds_read_b128 and all rows on two bank phases for the stores.)
-    const int GS = mvs_odd_quad_stride((V - 1) * 8 + 2);
-    float* geo = lds_;                                           // [VPB][GS]
-    const int RS = mvs_odd_quad_stride((blocked >= 2 ? ((CP + 15) & ~15) : CP) + 1);   // staging row (bf16 mode stages whole 16-channel blocks)
-    float* stage = lds_ + ((VPB * GS + 3) & ~3);                 // [VPP][RS]
-    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
-    const int64_t nvox = (int64_t)D * Hp * Wp;
-    // Workgroup -> voxels.  Workgroups are dealt to the 8 XCDs round-robin and every XCD has its own 4 MB L2; the source feature maps are
-    // V x 2.6 MB.  With workgroup b taking voxels 256 b .. 256 b + 255 every XCD swept every row of every plane and its L2 kept missing:
-    // PMC FETCH_SIZE 1.27 GB per launch for 8.6 MB of input (profiles/r03_pmc_enc_summary.json, round-3 tree before this change) - with the
-    // 0.84 GB written that is 6.2 TB/s through the fabric, i.e. the kernel ran at the MEMORY system's limit, not the VALU's.  Now XCD k owns
-    // the band of rows [k RB, (k+1) RB) of every depth plane: its taps fall into ~RB + 2 rows of each source view (1.5 MB at config 2),
-    // which stay in its L2 for the whole launch.  A workgroup takes 256 consecutive voxels of one (plane, band) slab (a contiguous range
-    // of the volume, so the flush still writes contiguous spans); the last chunk of a slab is short.
-    const int RB = (Hp + 7) >> 3;                                // rows per band
-    const int CPS = (RB * Wp + VPB - 1) / VPB;                   // chunks per (plane, band) slab
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int d_blk = jb / CPS, chunk = jb - d_blk * CPS;
-    const int band_rows = min(RB, Hp - xcd * RB);                // the last band may be short (or empty)
-    const int slab = band_rows > 0 ? band_rows * Wp : 0;
-    const int64_t v0 = ((int64_t)d_blk * Hp + (int64_t)xcd * RB) * Wp + (int64_t)chunk * VPB;
-    const int n_blk = min(VPB, slab - chunk * VPB);              // voxels of this workgroup (<= 0: nothing to do)
-    if (n_blk <= 0) return;
-    {   // ---- phase 1
-        const int64_t i = v0 + threadIdx.x;
-        if ((int)threadIdx.x < n_blk) {
-            float* o = geo + threadIdx.x * GS;
-            const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), d = (int)(i / ((int64_t)Wp * Hp));
-            const float u = (float)(x - pad), v = (float)(y - pad);     // utils.py:603-605
-            const float dep = depth[d];
-            const bool interior = x >= pad && x < W + pad && y >= pad && y < H + pad;
-            if (with_img) masks[i] = 1.0f;                          // view 0 mask (models.py:869)
-            float cnt = 1.0f;
-            for (int vv = 1; vv < V; ++vv) {
-                const float* P = proj + vv * 12;
-                // utils.py:612  R @ (u,v,1) + T/depth   (k-ordered fma chain like the reference's bmm)
-                const float p0 = fmaf(P[2], 1.0f, fmaf(P[1], v, P[0] * u)) + P[3] / dep;
-                const float p1 = fmaf(P[6], 1.0f, fmaf(P[5], v, P[4] * u)) + P[7] / dep;
-                const float p2 = fmaf(P[10], 1.0f, fmaf(P[9], v, P[8] * u)) + P[11] / dep;
-                const float gx = (p0 / p2) / ((float)(W - 1) / 2.0f) - 1.0f;          // :617-620 (un-padded W,H)
-                const float gy = (p1 / p2) / ((float)(H - 1) / 2.0f) - 1.0f;
-                const float m = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;   // models.py:875-876
-                cnt += m;
-                if (with_img) masks[(int64_t)vv * nvox + i] = m;
-                // F.grid_sample bilinear, zeros padding, align_corners=True (utils.py:625)
-                const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
-                const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
-                const float fx = floorf(ix), fy = floorf(iy);
-                const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
-                const bool x0in = fx >= 0.f && fx <= (float)(W - 1), x1in = fx + 1.f >= 0.f && fx + 1.f <= (float)(W - 1);
-                const bool y0in = fy >= 0.f && fy <= (float)(H - 1), y1in = fy + 1.f >= 0.f && fy + 1.f <= (float)(H - 1);
-                float* ov = o + (vv - 1) * 8;
-                ov[0] = (x0in && y0in) ? wx0 * wy0 : 0.f; ov[1] = (x1in && y0in) ? wx1 * wy0 : 0.f;
-                ov[2] = (x0in && y1in) ? wx0 * wy1 : 0.f; ov[3] = (x1in && y1in) ? wx1 * wy1 : 0.f;
-                // clamp the tap addresses (weights are already zero where a tap is outside)
-                const bool any = (x0in || x1in) && (y0in || y1in);
-                const int xa = any ? min(max((int)fx, 0), W - 1) : 0, xb = any ? min(max((int)fx + 1, 0), W - 1) : 0;
-                const int ya = any ? min(max((int)fy, 0), H - 1) : 0, yb = any ? min(max((int)fy + 1, 0), H - 1) : 0;
-                ov[4] = __int_as_float(ya * W + xa); ov[5] = __int_as_float(ya * W + xb);
-                ov[6] = __int_as_float(yb * W + xa); ov[7] = __int_as_float(yb * W + xb);
-            }
-            if (!with_img) masks[i] = cnt;                          // build_volume_costvar returns the count (models.py:821)
-            o[(V - 1) * 8] = 1.0f / cnt;                            // models.py:889
-            o[(V - 1) * 8 + 1] = __int_as_float(interior ? (y - pad) * W + (x - pad) : -1);
-        }
-    }
-    __syncthreads();
-    // ---- phase 2
-    const int q = threadIdx.x & 3, vloc = threadIdx.x >> 2;
-    const int c_var = with_img ? 3 * V : 0;
-    float* o = stage + vloc * RS;
-    for (int pass = 0; pass < VPB / VPP; ++pass) {
-        const int vb = pass * VPP + vloc;
-        if (pass * VPP >= n_blk) break;                          // (uniform) a short last chunk has fewer passes
-        const bool live = vb < n_blk;
-        const float* g = geo + (live ? vb : 0) * GS;             // dead lanes recompute the block's first voxel (their rows are not flushed)
-        const float inv = g[(V - 1) * 8];
-        const int refpix = __float_as_int(g[(V - 1) * 8 + 1]);
-        const bool interior = refpix >= 0;
-        float s[8], s2[8];                                       // channels 4q..4q+3 and 16+4q..16+4q+3
-        if (interior) {                                          // ref volume: zero-padded ref feature (models.py:856,862)
-            const f32x4* r = reinterpret_cast<const f32x4*>(feat + (int64_t)refpix * C);
-            const f32x4 t0 = r[q], t1 = r[q + 4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { s[k] = t0[k]; s2[k] = t0[k] * t0[k]; s[4 + k] = t1[k]; s2[4 + k] = t1[k] * t1[k]; }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) { s[c] = 0.f; s2[c] = 0.f; }
-        }
-        if (with_img && q == 0) {                                // channels 0:3 = ref thumbnail, border := 0 (models.py:858-860)
-            const float* ri = img + (int64_t)(interior ? refpix : 0) * 4;
-            o[0] = interior ? ri[0] : 0.f; o[1] = interior ? ri[1] : 0.f; o[2] = interior ? ri[2] : 0.f;
-        }
-        for (int vv = 1; vv < V; ++vv) {
-            const float* gv = g + (vv - 1) * 8;
-            const float w_nw = gv[0], w_ne = gv[1], w_sw = gv[2], w_se = gv[3];
-            const int a_nw = __float_as_int(gv[4]), a_ne = __float_as_int(gv[5]), a_sw = __float_as_int(gv[6]), a_se = __float_as_int(gv[7]);
-            const float* fb = feat + (int64_t)vv * H * W * C;
-            const f32x4* t_nw = reinterpret_cast<const f32x4*>(fb + (int64_t)a_nw * C);
-            const f32x4* t_ne = reinterpret_cast<const f32x4*>(fb + (int64_t)a_ne * C);
-            const f32x4* t_sw = reinterpret_cast<const f32x4*>(fb + (int64_t)a_sw * C);
-            const f32x4* t_se = reinterpret_cast<const f32x4*>(fb + (int64_t)a_se * C);
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const f32x4 a = t_nw[q + 4 * hh], b = t_ne[q + 4 * hh], c_ = t_sw[q + 4 * hh], e = t_se[q + 4 * hh];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float wv = fmaf(e[k], w_se, fmaf(c_[k], w_sw, fmaf(b[k], w_ne, a[k] * w_nw)));   // ATen's nw,ne,sw,se chain
-                    s[hh * 4 + k] += wv;                             // models.py:880
-                    s2[hh * 4 + k] += wv * wv;                       // :881 (the square is rounded before it is added)
-                }
-            }
-            if (with_img && q == (vv & 3)) {                         // warped thumbnail with the same grid (models.py:872), one lane per view
-                const float* ib = img + (int64_t)vv * H * W * 4;
-                const f32x4 a = *reinterpret_cast<const f32x4*>(ib + (int64_t)a_nw * 4);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(ib + (int64_t)a_ne * 4);
-                const f32x4 c_ = *reinterpret_cast<const f32x4*>(ib + (int64_t)a_sw * 4);
-                const f32x4 e = *reinterpret_cast<const f32x4*>(ib + (int64_t)a_se * 4);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) o[3 * vv + k] = fmaf(e[k], w_se, fmaf(c_[k], w_sw, fmaf(b[k], w_ne, a[k] * w_nw)));
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = (j < 4 ? 4 * q : 16 + 4 * q - 4) + j;
-            const float mean = s[j] * inv;
-            o[c_var + c] = s2[j] * inv - mean * mean;                // :890
-        }
-        if (q == 0)
-            for (int c = c_var + C; c < (blocked >= 2 ? ((CP + 15) & ~15) : CP); ++c) o[c] = 0.0f;
-        // flush this pass's 64 consecutive voxels (one contiguous CP*64*4-byte span of the cost volume) with coalesced 16-byte stores
-        __syncthreads();
-        {
-            const int64_t p0 = v0 + pass * VPP;
-            const int64_t nv = n_blk - pass * VPP < VPP ? n_blk - pass * VPP : VPP;
-            const int n4 = (int)(nv * CP / 4);
-            if (!blocked) {
-                f32x4* dst = reinterpret_cast<f32x4*>(cost + p0 * CP);
-                for (int k = threadIdx.x; k < n4; k += 256) {
-                    const int vox = (k * 4) / CP, c = (k * 4) - vox * CP;
-                    dst[k] = *reinterpret_cast<const f32x4*>(stage + vox * RS + c);
-                }
-            } else if (blocked == 2) {
-                // bf16 (round to nearest even), blocks of sixteen channels: the two 16-byte halves of a voxel's block, voxels consecutive
-                typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-                __bf16* cost16 = reinterpret_cast<__bf16*>(cost);
-                const int nb16 = (CP + 15) >> 4, per = (int)nv * 2, n_k = per * nb16;
-                for (int k = threadIdx.x; k < n_k; k += 256) {
-                    const int cb = k / per, rem = k - cb * per, vox = rem >> 1, c0 = cb * 16 + (rem & 1) * 8;
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + vox * RS + c0), hi = *reinterpret_cast<const f32x4*>(stage + vox * RS + c0 + 4);
-                    bf16x8_t h;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { h[e] = (__bf16)lo[e]; h[4 + e] = (__bf16)hi[e]; }
-                    *reinterpret_cast<bf16x8_t*>(cost16 + (((int64_t)cb * nvox + p0 + vox) << 4) + (rem & 1) * 8) = h;
-                }
-            } else if (blocked == 3) {
-                // two fp16 pieces of x * 2^-4 (conv_f16x3.hip): hi = fp16(x'), lo = fp16(x' - hi), both round to nearest, in the bf16 mode's blocks
-                // of sixteen channels; the lo plane follows the hi plane
-                typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-                _Float16* cost16 = reinterpret_cast<_Float16*>(cost);
-                const int nb16 = (CP + 15) >> 4, per = nv * 2, n_k = per * nb16;
-                const int64_t lo_plane = (int64_t)nb16 * nvox * 16;
-                for (int k = threadIdx.x; k < n_k; k += VPB) {
-                    const int cb = k / per, rem = k - cb * per, vox = rem >> 1, c0 = cb * 16 + (rem & 1) * 8;
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + vox * RS + c0), hi = *reinterpret_cast<const f32x4*>(stage + vox * RS + c0 + 4);
-                    f16x8_t h0, h1;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float v = fminf(fmaxf((e < 4 ? lo[e] : hi[e - 4]) * 0.0625f, -65504.0f), 65504.0f);
-                        const _Float16 a = (_Float16)v;
-                        h0[e] = a; h1[e] = (_Float16)(v - (float)a);
-                    }
-                    const int64_t at = (((int64_t)cb * nvox + p0 + vox) << 4) + (rem & 1) * 8;
-                    *reinterpret_cast<f16x8_t*>(cost16 + at) = h0;
-                    *reinterpret_cast<f16x8_t*>(cost16 + lo_plane + at) = h1;
-                }
-            } else {
-                // channel block cb (four channels) of these nv voxels is one contiguous run of nv * 16 bytes: k -> (cb, voxel)
-                const int nblk = CP >> 2, n_k = (int)nv * nblk;
-                for (int k = threadIdx.x; k < n_k; k += 256) {
-                    const int cb = k / (int)nv, vox = k - cb * (int)nv;
-                    *reinterpret_cast<f32x4*>(cost + (((int64_t)cb * nvox + p0 + vox) << 2)) =
-                        *reinterpret_cast<const f32x4*>(stage + vox * RS + cb * 4);
-                }
-            }
-        }
-        __syncthreads();                                         // the staging rows are rewritten by the next pass
-    }
-}
-
-#endif
 
 template <int C, int NP>   // feature channels (32), depth planes per wave
 __global__ __launch_bounds__(64) void planesweep_kernel(
@@ -589,7 +374,6 @@ extern "C" int mvsnerf_planesweep_costvar_f16x2_fwd(const float* feats_cl, const
     return planesweep_launch(feats_cl, imgs_cl, proj, depth, V, C, H, W, D, pad, reinterpret_cast<float*>(cost16x2), CP, masks, with_img, 3, stream);
 }
 
-MVS_KNOB_DEF(g_psw_fwd_reuse, 1)   // knobs.h
 
 static int planesweep_launch(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,
                              int V, int C, int H, int W, int D, int pad, float* cost, int CP, float* masks,
@@ -605,21 +389,8 @@ static int planesweep_launch(const float* feats_cl, const float* imgs_cl, const 
     const int Hp = H + 2 * pad, Wp = W + 2 * pad, RB = (Hp + 7) >> 3;
     const size_t lds_geo = (((size_t)256 * mvs_odd_quad_stride((V - 1) * 8 + 2) + 3) & ~(size_t)3);
     const size_t lds_stage = (size_t)64 * mvs_odd_quad_stride((blocked >= 2 ? ((CP + 15) & ~15) : CP) + 1);
-#ifdef MVSNERF_DEV_KNOBS
-    if (!g_psw_fwd_reuse) {
-        const size_t lds = (lds_geo + lds_stage) * sizeof(float);
-        if (lds > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(planesweep_blocks_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-        }
-        const int CPS = (RB * Wp + 255) / 256;
-        planesweep_blocks_kernel<32><<<(unsigned)(8 * D * CPS), 256, lds, (hipStream_t)stream>>>(feats_cl, imgs_cl, proj, depth, V, H, W, D, pad, cost, CP, masks, with_img, blocked);
-        MVS_LAUNCH_CHECK();
-        return MVSNERF_OK;
-    }
-#endif
     const size_t lds = ((((size_t)64 * mvs_odd_quad_stride((V - 1) * 8 + 2) + 3) & ~(size_t)3) +
-                        (size_t)16 * mvs_odd_quad_stride((blocked >= 2 ? ((CP + 15) & ~15) : CP) + 1) + (with_img ? (size_t)64 * (3 * V + 1) : 0) + 4 * 7 * 3) * sizeof(float);
+                        (size_t)16 * mvs_odd_quad_stride((blocked >= 2 ? ((CP + 15) & ~15) : CP) + 1) + (with_img ? (size_t)64 * (3 * V + 1) : 0) + (size_t)4 * (V > 1 ? V - 1 : 1) * 3) * sizeof(float);   // geo | stage | thumbs | tdv[NP = 4][V-1][3]
     static unsigned long long cap_mask = 0;
     if (lds > 48 * 1024) {      // many source views: raise the dynamic-LDS cap (idempotent, per device)
         const int rc = mvs_raise_lds_cap(reinterpret_cast<const void*>(planesweep_kernel<32, 4>), (int)lds, &cap_mask);
@@ -975,7 +746,6 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_kernel(ActSrc a, ActSrc b, i
     for (int k = 0; k < CT; k += 4) *reinterpret_cast<f32x4*>(o + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
 }
 
-MVS_KNOB_DEF(g_conv_mfma, 1)    // knobs.h: constants in the product build
 int mvs_conv3d_c8_mfma(const ActSrc& a, const ActSrc& b, int Cin, int cin_real, int cin_ld, int D, int H, int W, const float* wpacked, float* out,
                        int xcd, hipStream_t st);
 int mvs_conv3d_mfma32(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int D, int H, int W, const float* w32, int Cout, int stride,
@@ -985,8 +755,6 @@ bool mvs_conv3d_mfma32_supported(int Cin, int Cout, int stride);
 int mvs_conv_w32_repack(const float* wpacked, float* w32, int Cin, int Cout, hipStream_t st);
 int mvs_convT3d_mfma32(const float* x, int Cin, int D, int H, int W, const float* w32, int Cout, float* out, float* stats, hipStream_t st);
 int mvs_convT3d_mfma32_tiles(int Cin, int Cout, int D, int H, int W);
-MVS_KNOB_DEF(g_conv_tiled, 1)
-MVS_KNOB_DEF(g_conv_xcd, 1)
 static bool act_ok(const float* x, const float* sc, const float* sh) { return x && ((sc == nullptr) == (sh == nullptr)) && mvs_aligned16(x); }
 
 extern "C" int mvsnerf_conv3d_fwd(const float* x1, const float* scale1, const float* shift1,
@@ -1811,227 +1579,6 @@ __global__ __launch_bounds__(256) void planesweep_bwd_kernel(const float* __rest
     }
 }
 
-#ifdef MVSNERF_DEV_KNOBS   // measured and dropped (1.24 ms at config 2 where the column form below takes 0.31): kept for scratch/dev_tests only
-// ---- plane-sweep backward, tile form.  The scatter above is bound by the atomics themselves: float atomics of one XCD cannot stay in its
-// L2 when seven other XCDs add to the same feature maps, so each of the 9 x 4.7 M 128-byte updates crosses the fabric (3.6 TB/s of atomic
-// traffic at 1.5 ms).  Here a workgroup owns an 8 x 8 column of voxels (CL = 16 of the 32 channels) over DCH consecutive depth planes and
-// merges before it sends:
-//   * reference view: voxel (d, y, x) always lands on pixel (y - pad, x - pad) - the sum over the depth planes is kept in a register and
-//     leaves as ONE atomic per pixel, channel and depth chunk (D / DCH instead of D);
-//   * source views: the 256 taps of a plane's tile fall on ~10 x 10 pixels, and consecutive planes move that footprint by a fraction of
-//     a pixel (the disparity step).  They are added into a PW x PW-pixel LDS patch per view, centred on where the tile's middle lands in
-//     the first of DSUB planes; after DSUB planes the touched pixels are flushed with one global atomic each.  A tap outside the patch
-//     (strongly magnifying view pairs) goes straight to memory, so the result never depends on the patch size.
-// The LDS sums are 64-bit FIXED POINT.  Measured on gfx950 (scratch/r2/lds_atomic_rate.hip): ds_add_f32 retires one wave-instruction
-// per ~170 clocks per CU (the 64 lanes serialise), ds_add_u64 one per ~9; with float LDS atomics this kernel ran 2x SLOWER than the plain
-// scatter.  Per group of DSUB planes the scale is 2^45 / (a power-of-two bound of 128 max|g| over the tile's first plane): a term is
-// exact to 2^-45 of that bound (fp32 keeps 2^-24 of the running sum), the sums cannot overflow (terms < 2^50, int64 accumulators), and
-// the patch sum no longer depends on the order of the additions.  float -> fixed point is one v_fma_f64 (add 1.5 * 2^52, read the mantissa).
-// Occupancy decides the rest: the plane loop is a chain of latencies (geometry -> barrier -> 36 gathers per thread -> adds -> barrier), so
-// PW = 10 (34 KB of LDS) with the registers capped at 128 - four workgroups per CU - runs at 1.16 ms where PW = 12 (45 KB, three per CU)
-// took 1.45; a window in unclamped coordinates with the features staged in LDS as well (two workgroups per CU) was slower than either.
-template <int C, int CL, int NSRC, int PW>
-__global__ __launch_bounds__(256, NSRC <= 2 ? 4 : 2) void planesweep_bwd_tiles_kernel(const float* __restrict__ feat, const float* __restrict__ proj,
-                                                                  const float* __restrict__ depth, int H, int W, int D, int pad,
-                                                                  const float* __restrict__ g_cost, int CP, int c_var, float* __restrict__ g_feat, int DCH)
-{
-    static_assert(C % CL == 0 && 256 % CL == 0 && CL >= 4, "channel split");
-    constexpr int TS = 8, NVX = TS * TS, PP = PW * PW, DSUB = 4, GS = NSRC * 16;
-    constexpr int VPP = 256 / CL;                                     // voxels per pass of the workgroup
-    constexpr int KV = NVX / VPP;                                     // voxels per thread and plane
-    constexpr int KB = (NSRC <= 4 || KV < 4) ? KV : KV / 2;           // voxels whose gathers are in flight together
-    typedef unsigned long long u64;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    // per (voxel, source view), written by ONE thread in phase 1 so that the channel lanes of phase 2 only multiply and add:
-    //   {w_nw,w_ne,w_sw,w_se | byte offset of the 4 tap pixels in a feature map | index of the 4 taps in `patch` (-1: outside) |
-    //    view counts this voxel (0/1), all four taps inside the patch (0/1), -, -}
-    float* geo = smem;                                                // [NVX][NSRC][16]
-    int* org = reinterpret_cast<int*>(geo + NVX * GS);                // [NSRC]{x, y} of the patch's first pixel (16 ints)
-    float* wmax = reinterpret_cast<float*>(org + 16);                 // [4] per-wave max |g| of the group's first plane, then 4 spare
-    double* fx = reinterpret_cast<double*>(wmax + 8);                 // {scale, 1 / scale} of the current group, then float limit in fx[2]
-    u64* patch = reinterpret_cast<u64*>(fx + 4);                      // [NSRC][PP][CL]
-    const int tid = threadIdx.x;
-    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
-    const int ntx = (Wp + TS - 1) / TS, nty = (Hp + TS - 1) / TS;
-    // XCD k (= blockIdx.x & 7: workgroups are dealt round-robin) owns the tile rows [k RBT, (k+1) RBT) of every depth chunk: its gathers
-    // and scatters stay inside ~8 RBT + 2 rows of each feature map, which fit its L2 (as in planesweep_kernel; round 2 fetched 1.35 GB per
-    // launch for 0.6 GB of gradient input).  gridDim.x = 8 x RBT x ntx x chunks: rows past the volume return at once.
-    const int RBT = (nty + 7) >> 3;
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int chunk = jb / (RBT * ntx), rem = jb - chunk * (RBT * ntx);
-    const int ty = xcd * RBT + rem / ntx;
-    if (ty >= nty) return;
-    const int x0 = (rem % ntx) * TS, y0 = ty * TS;
-    const int d_begin = chunk * DCH, d_end = min(D, d_begin + DCH);
-    const float sx = (float)(W - 1) / 2.0f, sy = (float)(H - 1) / 2.0f;
-    // phase-1 role: voxel pv of the tile, source views tid>>6, +4, ...
-    const int pv = tid & 63, vx = x0 + (pv & 7), vy = y0 + (pv >> 3);
-    const bool pvalid = vx < Wp && vy < Hp;
-    const float u = (float)(vx - pad), v = (float)(vy - pad);
-    // phase-2 role: channel c of voxels vl0 + VPP k
-    const int cl = tid & (CL - 1), c = blockIdx.y * CL + cl, vl0 = tid / CL;
-    float ref[KV], racc[KV];
-#pragma unroll
-    for (int k = 0; k < KV; ++k) {
-        const int vl = vl0 + VPP * k, x2 = x0 + (vl & 7), y2 = y0 + (vl >> 3);
-        const bool interior = x2 >= pad && x2 < W + pad && y2 >= pad && y2 < H + pad;
-        ref[k] = interior ? feat[(int64_t)((y2 - pad) * W + (x2 - pad)) * C + c] : 0.f;
-        racc[k] = 0.f;
-    }
-    for (int i = tid; i < NSRC * PP * CL; i += 256) patch[i] = 0;
-    auto flush = [&]() {                                              // caller guarantees every ds_add has been issued and synchronised
-        const double inv = fx[1];
-        for (int i = tid; i < NSRC * PP * CL; i += 256) {             // i % CL == cl: CL lanes send one contiguous piece of a pixel's line
-            const long long q = (long long)patch[i];
-            if (q != 0) {
-                patch[i] = 0;
-                const int slot = i / CL, vs = slot / PP, sp = slot - vs * PP;
-                const int px = org[vs * 2] + sp % PW, py = org[vs * 2 + 1] + sp / PW;
-                atomicAdd(g_feat + ((int64_t)(vs + 1) * H * W + (int64_t)py * W + px) * C + c, (float)((double)q * inv));
-            }
-        }
-    };
-    const float* lane_feat = feat + c;
-    u64* lane_patch = patch + cl;
-    for (int d = d_begin; d < d_end; ++d) {
-        const float dep = depth[d];
-        if (((d - d_begin) % DSUB) == 0) {
-            if (d != d_begin) {
-                flush();
-                __syncthreads();                                      // flush() reads org[]: nobody may move the patch origin (below) before every wave has flushed
-            }
-            // fixed-point scale of this group from max |g| over the tile's first plane
-            float m = 0.f;
-#pragma unroll
-            for (int k = 0; k < KV; ++k) {
-                const int vl = vl0 + VPP * k, x2 = x0 + (vl & 7), y2 = y0 + (vl >> 3);
-                if (x2 < Wp && y2 < Hp) m = fmaxf(m, fabsf(g_cost[(((int64_t)d * Hp + y2) * Wp + x2) * CP + c_var + c]));
-            }
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            if ((tid & 63) == 0) wmax[tid >> 6] = m;
-            if (tid < NSRC) {                                         // centre the patch on where the tile's middle lands in this plane
-                const float* P = proj + (tid + 1) * 12;
-                const float uc = (float)(x0 - pad) + 3.5f, vc = (float)(y0 - pad) + 3.5f;
-                const float p0 = fmaf(P[1], vc, P[0] * uc) + P[2] + P[3] / dep, p1 = fmaf(P[5], vc, P[4] * uc) + P[6] + P[7] / dep;
-                const float p2 = fmaf(P[9], vc, P[8] * uc) + P[10] + P[11] / dep;
-                const float cx = fminf(fmaxf(p0 / p2, -4096.f), 1e6f), cy = fminf(fmaxf(p1 / p2, -4096.f), 1e6f);
-                org[tid * 2] = (int)floorf(cx) - PW / 2 + 1;
-                org[tid * 2 + 1] = (int)floorf(cy) - PW / 2 + 1;
-            }
-            __syncthreads();                                          // (also: the flush above is complete before anybody adds again)
-            if (tid == 0) {
-                const float mm = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-                int e = 0;
-                frexpf(fmaxf(mm, 1e-30f) * 128.0f, &e);               // bound < 2^e
-                const int se = min(45 - e, 120);
-                fx[0] = ldexp(1.0, se);
-                fx[1] = ldexp(1.0, -se);
-                reinterpret_cast<float*>(fx + 2)[0] = ldexpf(1.0f, 50 - se);      // |term| below this stays under 2^50 after scaling
-            }
-        }
-        for (int vs = tid >> 6; vs < NSRC; vs += 4) {
-            const float* P = proj + (vs + 1) * 12;
-            const float p0 = fmaf(P[2], 1.0f, fmaf(P[1], v, P[0] * u)) + P[3] / dep;
-            const float p1 = fmaf(P[6], 1.0f, fmaf(P[5], v, P[4] * u)) + P[7] / dep;
-            const float p2 = fmaf(P[10], 1.0f, fmaf(P[9], v, P[8] * u)) + P[11] / dep;
-            const float gx = (p0 / p2) / sx - 1.0f, gy = (p1 / p2) / sy - 1.0f;
-            const bool inside = gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f;
-            const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1), iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
-            const float fxx = floorf(ix), fyy = floorf(iy);
-            const float wx1 = ix - fxx, wx0 = (fxx + 1.0f) - ix, wy1 = iy - fyy, wy0 = (fyy + 1.0f) - iy;
-            const bool x0in = fxx >= 0.f && fxx <= (float)(W - 1), x1in = fxx + 1.f >= 0.f && fxx + 1.f <= (float)(W - 1);
-            const bool y0in = fyy >= 0.f && fyy <= (float)(H - 1), y1in = fyy + 1.f >= 0.f && fyy + 1.f <= (float)(H - 1);
-            const bool any = pvalid && (x0in || x1in) && (y0in || y1in);
-            const int xa = any ? min(max((int)fxx, 0), W - 1) : 0, xb = any ? min(max((int)fxx + 1, 0), W - 1) : 0;
-            const int ya = any ? min(max((int)fyy, 0), H - 1) : 0, yb = any ? min(max((int)fyy + 1, 0), H - 1) : 0;
-            const f32x4 wq = {(any && x0in && y0in) ? wx0 * wy0 : 0.f, (any && x1in && y0in) ? wx1 * wy0 : 0.f,
-                              (any && x0in && y1in) ? wx0 * wy1 : 0.f, (any && x1in && y1in) ? wx1 * wy1 : 0.f};
-            const int ox = org[vs * 2], oy = org[vs * 2 + 1];
-            const unsigned rxa = (unsigned)(xa - ox), rxb = (unsigned)(xb - ox), rya = (unsigned)(ya - oy), ryb = (unsigned)(yb - oy);
-            const bool xai = rxa < (unsigned)PW, xbi = rxb < (unsigned)PW, yai = rya < (unsigned)PW, ybi = ryb < (unsigned)PW;
-            const int pb = vs * PP;
-            const int4 po = {(xai && yai) ? (int)((pb + rya * PW + rxa) * CL) : -1, (xbi && yai) ? (int)((pb + rya * PW + rxb) * CL) : -1,
-                             (xai && ybi) ? (int)((pb + ryb * PW + rxa) * CL) : -1, (xbi && ybi) ? (int)((pb + ryb * PW + rxb) * CL) : -1};
-            const int4 gb = {(ya * W + xa) * C * 4, (ya * W + xb) * C * 4, (yb * W + xa) * C * 4, (yb * W + xb) * C * 4};
-            float* ov = geo + (pv * NSRC + vs) * 16;
-            *reinterpret_cast<f32x4*>(ov) = wq;
-            *reinterpret_cast<int4*>(ov + 4) = gb;
-            *reinterpret_cast<int4*>(ov + 8) = po;
-            *reinterpret_cast<f32x4*>(ov + 12) = f32x4{(pvalid && inside) ? 1.0f : 0.0f, (xai && xbi && yai && ybi) ? 1.0f : 0.0f, 0.f, 0.f};
-        }
-        __syncthreads();
-        const double scale = fx[0];
-        const float lim = reinterpret_cast<const float*>(fx + 2)[0];
-        auto to_fixed = [&](float val) -> u64 {                       // round(val * scale) for |val * scale| < 2^51
-            const double t = fma((double)val, scale, 6755399441055744.0);
-            return (u64)(__double_as_longlong(t) - 0x4338000000000000LL);
-        };
-#pragma unroll 1
-        for (int k0 = 0; k0 < KV; k0 += KB) {
-            float gv[KB], tap[KB][NSRC][4];
-#pragma unroll
-            for (int kk = 0; kk < KB; ++kk) {
-                const int vl = vl0 + VPP * (k0 + kk), x2 = x0 + (vl & 7), y2 = y0 + (vl >> 3);
-                gv[kk] = (x2 < Wp && y2 < Hp) ? g_cost[(((int64_t)d * Hp + y2) * Wp + x2) * CP + c_var + c] : 0.f;
-                const float* o = geo + (vl * NSRC) * 16;
-#pragma unroll
-                for (int vs = 0; vs < NSRC; ++vs) {
-                    const char* fb = reinterpret_cast<const char*>(lane_feat + (int64_t)(vs + 1) * H * W * C);
-                    const int4 gb = *reinterpret_cast<const int4*>(o + vs * 16 + 4);
-                    tap[kk][vs][0] = *reinterpret_cast<const float*>(fb + gb.x); tap[kk][vs][1] = *reinterpret_cast<const float*>(fb + gb.y);
-                    tap[kk][vs][2] = *reinterpret_cast<const float*>(fb + gb.z); tap[kk][vs][3] = *reinterpret_cast<const float*>(fb + gb.w);
-                }
-            }
-#pragma unroll
-            for (int kk = 0; kk < KB; ++kk) {
-                const int k = k0 + kk, vl = vl0 + VPP * k;
-                const float* o = geo + (vl * NSRC) * 16;
-                float cnt = 1.0f, s = ref[k], wv[NSRC];
-                f32x4 wq[NSRC];
-#pragma unroll
-                for (int vs = 0; vs < NSRC; ++vs) {
-                    wq[vs] = *reinterpret_cast<const f32x4*>(o + vs * 16);
-                    cnt += o[vs * 16 + 12];
-                    wv[vs] = fmaf(tap[kk][vs][3], wq[vs][3], fmaf(tap[kk][vs][2], wq[vs][2], fmaf(tap[kk][vs][1], wq[vs][1], tap[kk][vs][0] * wq[vs][0])));
-                    s += wv[vs];
-                }
-                const float inv = 1.0f / cnt;
-                const float k2 = gv[kk] * 2.0f * inv, mean = s * inv;
-                racc[k] += k2 * (ref[k] - mean);
-#pragma unroll
-                for (int vs = 0; vs < NSRC; ++vs) {
-                    const float gw_ = k2 * (wv[vs] - mean);
-                    const int4 po = *reinterpret_cast<const int4*>(o + vs * 16 + 8);
-                    if (o[vs * 16 + 13] != 0.f && fabsf(gw_) < lim) { // all four taps inside the patch (a zero-weight tap adds 0), in range
-                        atomicAdd(lane_patch + po.x, to_fixed(gw_ * wq[vs][0])); atomicAdd(lane_patch + po.y, to_fixed(gw_ * wq[vs][1]));
-                        atomicAdd(lane_patch + po.z, to_fixed(gw_ * wq[vs][2])); atomicAdd(lane_patch + po.w, to_fixed(gw_ * wq[vs][3]));
-                    } else {
-                        const int4 gb = *reinterpret_cast<const int4*>(o + vs * 16 + 4);
-                        const int pos[4] = {po.x, po.y, po.z, po.w}, gbs[4] = {gb.x, gb.y, gb.z, gb.w};
-                        float* gview = g_feat + (int64_t)(vs + 1) * H * W * C + c;
-#pragma unroll 1
-                        for (int t = 0; t < 4; ++t) {
-                            const float val = gw_ * wq[vs][t];
-                            if (wq[vs][t] == 0.f) continue;
-                            if (pos[t] >= 0 && fabsf(val) < lim) atomicAdd(lane_patch + pos[t], to_fixed(val));
-                            else atomicAdd(gview + (gbs[t] >> 2), val);
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    flush();
-#pragma unroll
-    for (int k = 0; k < KV; ++k) {
-        const int vl = vl0 + VPP * k, x2 = x0 + (vl & 7), y2 = y0 + (vl >> 3);
-        if (x2 >= pad && x2 < W + pad && y2 >= pad && y2 < H + pad) atomicAdd(g_feat + (int64_t)((y2 - pad) * W + (x2 - pad)) * C + c, racc[k]);
-    }
-}
-
-#endif
 
 // ---- plane-sweep backward, column form.  A thread owns ONE channel of ONE voxel column (x, y) and walks the depth planes itself.  Along
 // a column the sample point in a source view moves by the disparity step - a fraction of a pixel per plane for any rig the sweep is meant
@@ -2151,7 +1698,6 @@ __global__ __launch_bounds__(256) void planesweep_bwd_columns_kernel(const float
     if (interior) g_feat[refoff] += racc;                             // the only contribution to this element of view 0
 }
 
-MVS_KNOB_DEF(g_psw_bwd_tiles, 2)   // 2: column form; dev build only: 1 = tile form, 0 = per-voxel scatter for every shape (the product uses it for V == 1)
 
 template <int NSRC>
 static int planesweep_bwd_columns_launch(const float* feat, const float* proj, const float* depth, int H, int W, int D, int pad, const float* g_cost,
@@ -2163,27 +1709,6 @@ static int planesweep_bwd_columns_launch(const float* feat, const float* proj, c
     return MVSNERF_OK;
 }
 
-#ifdef MVSNERF_DEV_KNOBS
-template <int NSRC>
-static int planesweep_bwd_tiles_launch(const float* feat, const float* proj, const float* depth, int H, int W, int D, int pad, const float* g_cost, int CP,
-                                       int c_var, float* g_feat, hipStream_t st)
-{
-    constexpr int PW = 10, DCH = 16, CL = 16;
-    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
-    const size_t lds = (size_t)(64 * NSRC * 16 + 16 + 8 + 8) * sizeof(float) + (size_t)NSRC * PW * PW * CL * 8;
-    static unsigned long long cap_mask = 0;
-    if (lds > 64 * 1024) {
-        const int rc = mvs_raise_lds_cap((const void*)planesweep_bwd_tiles_kernel<32, CL, NSRC, PW>, (int)lds, &cap_mask);
-        if (rc != MVSNERF_OK) return rc;
-    }
-    const int nty = (Hp + 7) / 8, RBT = (nty + 7) / 8;
-    const dim3 grid((unsigned)(8 * RBT * ((Wp + 7) / 8) * ((D + DCH - 1) / DCH)), 32 / CL);
-    planesweep_bwd_tiles_kernel<32, CL, NSRC, PW><<<grid, 256, lds, st>>>(feat, proj, depth, H, W, D, pad, g_cost, CP, c_var, g_feat, DCH);
-    MVS_LAUNCH_CHECK();
-    return MVSNERF_OK;
-}
-
-#endif
 
 extern "C" int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float* proj, const float* depth, int V, int C, int H, int W, int D, int pad,
                                               const float* g_cost, int CP, int with_img, float* g_feats_cl, void* stream)
@@ -2191,7 +1716,7 @@ extern "C" int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float
     if (!feats_cl || !proj || !depth || !g_cost || !g_feats_cl || V < 1 || V > 8 || H < 2 || W < 2 || D < 1 || pad < 0) return MVSNERF_EINVAL;
     if (C != 32) return MVSNERF_EUNSUPPORTED;
     const int64_t nvox = (int64_t)D * (H + 2 * pad) * (W + 2 * pad);
-    if (g_psw_bwd_tiles == 2 && V >= 2) {
+    if (V >= 2) {                                           // column form; a single view has no taps to keep: the per-voxel scatter below
         hipStream_t st = (hipStream_t)stream;
         const int cv = with_img ? 3 * V : 0;
         switch (V - 1) {
@@ -2200,17 +1725,6 @@ extern "C" int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float
 #undef MVS_PBC
         }
     }
-#ifdef MVSNERF_DEV_KNOBS
-    if (g_psw_bwd_tiles == 1 && V >= 2) {
-        hipStream_t st = (hipStream_t)stream;
-        const int cv = with_img ? 3 * V : 0;
-        switch (V - 1) {
-#define MVS_PBT(N) case N: return planesweep_bwd_tiles_launch<N>(feats_cl, proj, depth, H, W, D, pad, g_cost, CP, cv, g_feats_cl, st)
-            MVS_PBT(1); MVS_PBT(2); MVS_PBT(3); MVS_PBT(4); MVS_PBT(5); MVS_PBT(6); MVS_PBT(7);
-#undef MVS_PBT
-        }
-    }
-#endif
     const size_t lds = (size_t)256 * ((V - 1) * 8 + 2) * sizeof(float);
     planesweep_bwd_kernel<32><<<mvs_cdiv(nvox, 256), 256, lds, (hipStream_t)stream>>>(feats_cl, proj, depth, V, H, W, D, pad, g_cost, CP,
                                                                                     with_img ? 3 * V : 0, g_feats_cl);

@@ -8,7 +8,6 @@
 // memory.  MFMA-bound: 251 392 FLOP per point against 12 B + 4*F B read and 16 B written.
 #include "common.h"
 #include "mlp_layout.h"
-#include "sample_dev.h"
 #include "lds_dma.h"
 #include "knobs.h"
 
@@ -78,23 +77,12 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(PackArgs a, float* __rest
     }
 }
 
-#ifdef MVSNERF_DEV_KNOBS
-// 16-point-tile variant (mlp16.hip, dev build only): its own fragment order, appended to the packed buffer
-size_t mvs_mlp16_packed_floats(int F);
-int mvs_mlp16_pack(const float* const w[11], const float* const b[11], int F, float* packed16, hipStream_t st);
-int mvs_mlp16_fwd(const float* packed16, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
-                  const float* dirs, int dirs_stride, int64_t P, int S, int alpha_only, float* raw, hipStream_t st);
-#endif
 static size_t off16(int F) { return (layout(F).total + 3) & ~(size_t)3; }
 
 extern "C" size_t mvsnerf_mlp_packed_floats(int F)
 {
     if (F < 2 || F > MAX_F || (F & 1)) return 0;
-#ifdef MVSNERF_DEV_KNOBS
-    return off16(F) + mvs_mlp16_packed_floats(F);
-#else
     return off16(F);
-#endif
 }
 
 extern "C" int mvsnerf_mlp_pack(const float* const w[11], const float* const b[11], int F, float* packed, void* stream)
@@ -110,11 +98,7 @@ extern "C" int mvsnerf_mlp_pack(const float* const w[11], const float* const b[1
     a.F = F;
     mlp_pack_kernel<<<64, 256, 0, (hipStream_t)stream>>>(a, packed);
     MVS_LAUNCH_CHECK();
-#ifdef MVSNERF_DEV_KNOBS
-    return mvs_mlp16_pack(w, b, F, packed + off16(F), (hipStream_t)stream);
-#else
     return MVSNERF_OK;
-#endif
 }
 
 // ------------------------------------------------------------------------------------------ compute
@@ -210,197 +194,6 @@ __device__ __forceinline__ float pe_operand(int t, int half, float px, float py,
     return pe_sin_or_cos(x, half);
 }
 
-#ifdef MVSNERF_DEV_KNOBS   // schedules 0/1/2 (register-staged weights): measured and dropped, dev build only
-// G groups of 32 points per wave; WPS = waves per SIMD the register budget is capped for.
-// SAVE (training forward, G == 1): every operand the backward pass needs is written in slot format (mlp_layout.h);
-// the stores are fire-and-forget and hide under the MFMAs.
-template <bool ALPHA_ONLY, int G, int WPS, bool SAVE>
-__global__ __launch_bounds__(256, WPS) void mlp_fwd_kernel(
-    const float* __restrict__ packed, int F, const float* __restrict__ ndc, int ndc_stride,
-    const float* __restrict__ feat, int feat_stride, const float* __restrict__ dirs, int dirs_stride,
-    int64_t P, int S, float* __restrict__ raw, float* __restrict__ saved)
-{
-    static_assert(!SAVE || (G == 1 && !ALPHA_ONLY), "training forward is built for 32 points per wave");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* wbuf = lds;
-    float* vec = lds + WBUF_FLOATS;
-
-    const Layout L = layout(F);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int half = lane >> 5;
-    int64_t p_raw[G], p[G];
-    bool live[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        p_raw[g] = ((int64_t)blockIdx.x * 4 + wave) * (32 * G) + g * 32 + (lane & 31);
-        live[g] = p_raw[g] < P;
-        p[g] = live[g] ? p_raw[g] : P - 1;
-    }
-
-    float* sv = nullptr;      // this wave's tile of the activation store
-    if (SAVE) sv = saved + ((int64_t)blockIdx.x * 4 + wave) * (SLOTS_SAVED * 64) + lane;
-    auto save = [&](int slot, float v) { if (SAVE) sv[slot * 64] = v; };
-
-    // stage A: fragment vectors + pts_bias weights + layer 0
-    for (int i = tid; i < V_TOTAL; i += 256) vec[i] = packed[L.vec + i];
-    stage_weights(wbuf, packed + L.biasw, (int)(L.l1 - L.biasw), tid);
-
-    float px[G], py[G], pz[G];
-    float fv[G][MAX_F / 2];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        px[g] = ndc[p[g] * ndc_stride + 0]; py[g] = ndc[p[g] * ndc_stride + 1]; pz[g] = ndc[p[g] * ndc_stride + 2];
-        const float* fp = feat + p[g] * feat_stride + half * (F / 2);
-#pragma unroll
-        for (int i = 0; i < MAX_F / 2; ++i) fv[g][i] = i < F / 2 ? fp[i] : 0.0f;
-    }
-    __syncthreads();
-
-    // bias = pts_bias(feat)   (models.py:200)
-    float bias[G][64];
-    {
-        f32x16 acc[G][4];
-        init_acc<4, G>(acc, vec + V_BIASG + half * 64);
-        auto fb = [&](int g, int t) { return fv[g][t]; };          // fv is zero beyond F/2
-        // F/2 <= 20 real k-steps padded to fsteps in {4,8,12,16,20}
-        switch (L.fsteps) {
-            case 4:  gemm_stage<1, 4, G>(wbuf, acc, lane, fb); break;
-            case 8:  gemm_stage<2, 4, G>(wbuf, acc, lane, fb); break;
-            case 12: gemm_stage<3, 4, G>(wbuf, acc, lane, fb); break;
-            case 16: gemm_stage<4, 4, G>(wbuf, acc, lane, fb); break;
-            default: gemm_stage<5, 4, G>(wbuf, acc, lane, fb); break;
-        }
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int q = 0; q < 64; ++q) { bias[g][q] = acc[g][q >> 4][q & 15]; save(S_BM + q, bias[g][q]); }
-        if (SAVE) {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) save(S_FV + t, fv[0][t]);
-#pragma unroll
-            for (int t = 0; t < PE_STEPS; ++t) save(S_E + t, pe_operand(t, half, px[0], py[0], pz[0]));
-        }
-    }
-
-    float h[G][64];
-    auto pe = [&](int g, int t) { return pe_operand(t, half, px[g], py[g], pz[g]); };
-    auto hb = [&](int g, int t) { return h[g][t]; };
-    // layer 0: h = relu((W0 pe + b0) * bias)   (models.py:202-203)
-    {
-        f32x16 acc[G][4];
-        init_acc<4, G>(acc, vec + V_L0 + half * 64);
-        gemm_stage<PE_STEPS / 4, 4, G>(wbuf + seg_floats(L.fsteps, 4), acc, lane, pe);
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int q = 0; q < 64; ++q) { h[g][q] = fmaxf(acc[g][q >> 4][q & 15] * bias[g][q], 0.0f); save(S_H + q, h[g][q]); }
-    }
-    // layers 1..4
-#pragma unroll 1
-    for (int layer = 1; layer <= 4; ++layer) {
-        __syncthreads();
-        stage_weights(wbuf, packed + L.l1 + (size_t)(layer - 1) * seg_floats(ACT_STEPS, 4), WBUF_FLOATS, tid);
-        __syncthreads();
-        f32x16 acc[G][4];
-        init_acc<4, G>(acc, vec + V_L0 + 128 * layer + half * 64);
-        gemm_stage<ACT_STEPS / 4, 4, G>(wbuf, acc, lane, hb);
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int q = 0; q < 64; ++q) { h[g][q] = fmaxf(acc[g][q >> 4][q & 15] * bias[g][q], 0.0f); save(S_H + layer * 64 + q, h[g][q]); }
-    }
-    // layer 5 on cat([pts, h])  (skip connection after layer 4, models.py:204-205)
-    {
-        f32x16 acc[G][4];
-        __syncthreads();
-        stage_weights(wbuf, packed + L.l5a, (int)seg_floats(PE_STEPS, 4), tid);
-        __syncthreads();
-        init_acc<4, G>(acc, vec + V_L0 + 128 * 5 + half * 64);
-        gemm_stage<PE_STEPS / 4, 4, G>(wbuf, acc, lane, pe);
-        __syncthreads();
-        stage_weights(wbuf, packed + L.l5b, WBUF_FLOATS, tid);
-        __syncthreads();
-        gemm_stage<ACT_STEPS / 4, 4, G>(wbuf, acc, lane, hb);
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int q = 0; q < 64; ++q) { h[g][q] = fmaxf(acc[g][q >> 4][q & 15] * bias[g][q], 0.0f); save(S_H + 5 * 64 + q, h[g][q]); }
-    }
-    // alpha = relu(alpha_linear(h))   (models.py:209)
-    float sigma[G];
-    {
-        const float* wa = vec + V_WA + half * 64;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float part = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 64; ++q) part = fmaf(wa[q], h[g][q], part);
-            part += __shfl_xor(part, 32);
-            sigma[g] = fmaxf(part + vec[V_BA], 0.0f);
-        }
-    }
-    if (ALPHA_ONLY) {
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-            if (live[g] && half == 0) raw[p_raw[g]] = sigma[g];
-        return;
-    }
-    // feature = feature_linear(h)  (no activation, models.py:210)
-    {
-        f32x16 acc[G][4];
-        __syncthreads();
-        stage_weights(wbuf, packed + L.feat, WBUF_FLOATS, tid);
-        __syncthreads();
-        init_acc<4, G>(acc, vec + V_FEAT + half * 64);
-        gemm_stage<ACT_STEPS / 4, 4, G>(wbuf, acc, lane, hb);
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int q = 0; q < 64; ++q) { h[g][q] = acc[g][q >> 4][q & 15]; save(S_FE + q, h[g][q]); }
-    }
-    // h_v = relu(views_linears[0](cat[feature, dir]))   (models.py:211-215)
-    {
-        float d0[G], d1[G], d2[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int64_t ray = p[g] / S;
-            d0[g] = dirs[ray * dirs_stride + 0]; d1[g] = dirs[ray * dirs_stride + 1]; d2[g] = dirs[ray * dirs_stride + 2];
-        }
-        f32x16 acc[G][2];
-        __syncthreads();
-        stage_weights(wbuf, packed + L.views, (int)seg_floats(VIEW_STEPS, 2), tid);
-        __syncthreads();
-        init_acc<2, G>(acc, vec + V_VIEWS + half * 32);
-        gemm_stage<VIEW_STEPS / 4, 2, G>(wbuf, acc, lane, [&](int g, int t) {
-            return t < ACT_STEPS ? h[g][t < ACT_STEPS ? t : 0]
-                 : t == ACT_STEPS ? (half ? d1[g] : d0[g]) : t == ACT_STEPS + 1 ? (half ? 0.0f : d2[g]) : 0.0f;
-        });
-        if (SAVE) {
-#pragma unroll
-            for (int q = 0; q < 32; ++q) save(S_HV + q, fmaxf(acc[0][q >> 4][q & 15], 0.0f));
-            save(S_DR + 0, half ? d1[0] : d0[0]);
-            save(S_DR + 1, half ? 0.0f : d2[0]);
-        }
-        // rgb = sigmoid(rgb_linear(h_v))   (models.py:217);  out = cat([rgb, alpha]) models.py:218
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float rgb[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float* wr = vec + V_WR + c * 64 + half * 32;
-                float part = 0.0f;
-#pragma unroll
-                for (int q = 0; q < 32; ++q) part = fmaf(wr[q], fmaxf(acc[g][q >> 4][q & 15], 0.0f), part);
-                part += __shfl_xor(part, 32);
-                const float x = part + vec[V_BR + c];
-                rgb[c] = 1.0f / (1.0f + expf(-x));
-            }
-            if (live[g] && half == 0)
-                *reinterpret_cast<f32x4*>(raw + p_raw[g] * 4) = f32x4{rgb[0], rgb[1], rgb[2], sigma[g]};
-        }
-    }
-}
-#endif
 
 // ------------------------------------------------------------------------------------------ pipelined forward
 // Measured on MI355X: 0.237 ms per 1024x128 batch = 139 TFLOP/s = 88 % of the 157.3 TFLOP/s fp32-MFMA peak; PMC:
@@ -431,26 +224,12 @@ __device__ __forceinline__ void slab_sync()
     __syncthreads();                                      // ... everybody's have, and everybody left the other buffer
 }
 
-// GATHER (opt-in, see g_mlp_gather; three source views, rendering() of a whole batch): gen_dir_feature + gen_pts_feats
-// (renderer.py:111-136) run in this kernel's prologue instead of a launch of their own - every lane computes the 20-float feature row of its point with the device
-// functions the gather kernels use (sample_dev.h: same bits), keeps the half it feeds to pts_bias in registers and stores it to the
-// `input_feat` output; the lookup's memory latency hides behind the co-resident workgroup's matrix work.  Removes a 11 us launch
-// (+ the launch boundary) per 1024 x 128 batch.
-struct GatherIn {
-    const float* vol; int D, H, W;          // channel-last neural volume [D][H][W][8]
-    const float* img; int IH, IW;           // channel-last source images [3][IH][IW][4]
-    const float* w2c; const float* Kmat;    // [3][4][4], [3][3][3]
-    const float* pts; const float* rays_dir;
-    float* feat_out;                        // [P][20]
-};
-
-template <bool ALPHA_ONLY, bool SAVE, bool GATHER = false>
+template <bool ALPHA_ONLY, bool SAVE>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
     const float* __restrict__ packed, int F, const float* __restrict__ ndc, int ndc_stride,
     const float* __restrict__ feat, int feat_stride, const float* __restrict__ dirs, int dirs_stride,
-    int64_t P, int S, float* __restrict__ raw, float* __restrict__ saved, long long* __restrict__ census, GatherIn gi = GatherIn{})
+    int64_t P, int S, float* __restrict__ raw, float* __restrict__ saved, long long* __restrict__ census)
 {
-    static_assert(!GATHER || !ALPHA_ONLY, "the fused gather serves rendering(): colours are wanted");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     long long t_start = 0, c_start = 0;
     if (census) { t_start = wall_clock64(); c_start = __builtin_amdgcn_s_memtime(); }
@@ -477,44 +256,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
     for (int i = tid; i < V_TOTAL; i += 256) vec[i] = packed[L.vec + i];
     const float px = ndc[p * ndc_stride + 0], py = ndc[p * ndc_stride + 1], pz = ndc[p * ndc_stride + 2];
     float fv[MAX_F / 2];
-    float gd0 = 0.0f, gd1 = 0.0f, gd2 = 0.0f;             // GATHER: view-direction feature of this point's ray
-    if constexpr (GATHER) {
-        // [0:8] trilinear volume features | [8+4v : 12+4v] (r, g, b, in-frustum mask) of source view v = 0, 1, 2      (F = 20)
-        f32x4 row[5];
-        {
-            f32x4 v8[2];
-            trilinear8_of<true>(gi.vol, gi.D, gi.H, gi.W, px, py, pz, v8);
-            row[0] = v8[0]; row[1] = v8[1];
-        }
-        const float wx = gi.pts[p * 3 + 0], wy = gi.pts[p * 3 + 1], wz = gi.pts[p * 3 + 2];
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            const ColorTap t = color_project(wx, wy, wz, gi.w2c + v * 16, gi.Kmat + v * 9, gi.IW, gi.IH);
-            const float* pl = gi.img + (int64_t)((__umul24(v * gi.IH + t.y0, gi.IW) + t.x0) << 2);
-            const float* zt = reinterpret_cast<const float*>(&g_zero_tap);
-            const f32x4 t_nw = *reinterpret_cast<const f32x4*>(pl);
-            const f32x4 t_ne = *reinterpret_cast<const f32x4*>(t.x1in ? pl + 4 : zt);
-            const f32x4 t_sw = *reinterpret_cast<const f32x4*>(t.y1in ? pl + (int64_t)gi.IW * 4 : zt);
-            const f32x4 t_se = *reinterpret_cast<const f32x4*>((t.x1in && t.y1in) ? pl + (int64_t)gi.IW * 4 + 4 : zt);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) row[2 + v][c] = color_blend(t, t_nw[c], t_ne[c], t_sw[c], t_se[c]);
-            row[2 + v][3] = color_mask(t);
-        }
-        // this lane's operands: features [10 half, 10 half + 10)
-#pragma unroll
-        for (int i = 0; i < MAX_F / 2; ++i) {
-            const int lo = i, hi = 10 + i;
-            fv[i] = i < 10 ? (half ? row[hi >> 2][hi & 3] : row[lo >> 2][lo & 3]) : 0.0f;
-        }
-        if (live) {      // the `input_feat` output of rendering(): each half-lane stores the ten floats it holds
-            float* frow = gi.feat_out + p * 20 + half * 10;
-#pragma unroll
-            for (int i = 0; i < 10; i += 2) *reinterpret_cast<f32x2*>(frow + i) = f32x2{fv[i], fv[i + 1]};
-        }
-        float d3[3];
-        dir_feature_of(gi.rays_dir + (p / S) * 3, gi.w2c, 1, d3);       // reference view = view 0 (renderer.py:142-147)
-        gd0 = d3[0]; gd1 = d3[1]; gd2 = d3[2];
-    } else {
+    {
         const float* fp = feat + p * feat_stride + half * (F / 2);
 #pragma unroll
         for (int i = 0; i < MAX_F / 2; ++i) fv[i] = i < F / 2 ? fp[i] : 0.0f;
@@ -626,8 +368,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
     // ---- views_linears[0] + rgb head: slab 15 (buf1)
     {
         float d0, d1, d2;
-        if constexpr (GATHER) { d0 = gd0; d1 = gd1; d2 = gd2; }
-        else { const int64_t ray = p / S; d0 = dirs[ray * dirs_stride + 0]; d1 = dirs[ray * dirs_stride + 1]; d2 = dirs[ray * dirs_stride + 2]; }
+        { const int64_t ray = p / S; d0 = dirs[ray * dirs_stride + 0]; d1 = dirs[ray * dirs_stride + 1]; d2 = dirs[ray * dirs_stride + 2]; }
         f32x16 acc[G][2];
         slab_sync();
         init_acc<2, G>(acc, vec + V_VIEWS + half * 32);
@@ -674,65 +415,8 @@ static int launch_mlp_pipe(const float* packed, int F, const float* ndc, int ndc
     return MVSNERF_OK;
 }
 
-// Gather fused into the MLP kernel's prologue (knob g_mlp_gather, dev build only): rendering() with three source views runs the lookups
-// in this kernel instead of a launch of their own.  Measured at config 2 (scratch/ab_gather.py): 0.2574 ms/step fused vs 0.2551 ms with the
-// separate 11 us gather launch - the lookup's memory latency sits in front of every workgroup's first GEMM (the pts_bias product needs the
-// features), and the 512 workgroups of the first round all pay it at once; the stand-alone gather kernel hides the same latency behind
-// 2048 waves of its own.  The product build therefore always answers MVSNERF_EUNSUPPORTED here and raymarch.hip launches the gather kernel.
-MVS_KNOB_DEF(g_mlp_gather, 0)
-MVS_KNOB_DEF(g_mlp_variant, 3)
-
-// Used by mvsnerf_raymarch_fwd / mvsnerf_render_pixels_fwd (raymarch.hip): gather + MLP in one launch, or MVSNERF_EUNSUPPORTED
-// (the caller then launches the gather kernel and the plain MLP kernel).
-int mvs_mlp_fwd_gather(const float* packed, const float* vol, int D, int H, int W, const float* imgs_nhwc4, int V, int IH, int IW,
-                       const float* w2c, const float* K, const float* pts, const float* ndc, const float* rays_dir,
-                       int64_t N, int S, float* feat, float* raw, hipStream_t st)
-{
-#ifdef MVSNERF_DEV_KNOBS
-    const int64_t P = N * S;
-    const bool small = (int64_t)D * H < (1 << 24) && W < (1 << 24) && (int64_t)D * H * W * 8 < ((int64_t)1 << 31) &&
-                       (int64_t)V * IH < (1 << 24) && IW < (1 << 24) && (int64_t)V * IH * IW * 4 < ((int64_t)1 << 31);
-    if (!g_mlp_gather || g_mlp_variant != 3 || V != 3 || !small || P < 1) return MVSNERF_EUNSUPPORTED;
-    if (!mvs_aligned16(packed) || !mvs_aligned16(raw) || !mvs_aligned16(vol) || !mvs_aligned16(imgs_nhwc4) || (reinterpret_cast<uintptr_t>(feat) & 7u)) return MVSNERF_EUNSUPPORTED;
-    const size_t lds_bytes = PIPE_LDS_FLOATS * sizeof(float);
-    static unsigned long long lds_cap_set = 0;
-    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_pipe_kernel<false, false, true>), (int)lds_bytes, &lds_cap_set)) return rc_;
-    const GatherIn gi{vol, D, H, W, imgs_nhwc4, IH, IW, w2c, K, pts, rays_dir, feat};
-    mlp_fwd_pipe_kernel<false, false, true><<<mvs_cdiv(P, 128), 256, lds_bytes, st>>>(packed, 20, ndc, 3, nullptr, 20, nullptr, 3, P, S, raw, nullptr, nullptr, gi);
-    MVS_LAUNCH_CHECK();
-    return MVSNERF_OK;
-#else
-    return MVSNERF_EUNSUPPORTED;
-#endif
-}
-
-#ifdef MVSNERF_DEV_KNOBS
-extern "C" int mvsnerf_tune(const char* key, int value)
-{
-    if (!key) return MVSNERF_EINVAL;
-    if (__builtin_strcmp(key, "conv_tiled") == 0) { g_conv_tiled = value ? 1 : 0; return MVSNERF_OK; }
-    if (__builtin_strcmp(key, "psw_fwd_reuse") == 0) { g_psw_fwd_reuse = value ? 1 : 0; return MVSNERF_OK; }
-    if (__builtin_strcmp(key, "psw_bwd_tiles") == 0) { g_psw_bwd_tiles = value < 0 ? 0 : (value > 2 ? 2 : value); return MVSNERF_OK; }
-    if (__builtin_strcmp(key, "conv_xcd") == 0) { g_conv_xcd = value ? 1 : 0; return MVSNERF_OK; }
-    if (__builtin_strcmp(key, "conv_mfma") == 0) { g_conv_mfma = value ? 1 : 0; return MVSNERF_OK; }
-    if (__builtin_strcmp(key, "mlp_gather") == 0) { g_mlp_gather = value ? 1 : 0; return MVSNERF_OK; }
-    if (__builtin_strcmp(key, "mlp_variant") == 0) { if (value < 0 || value > 4) return MVSNERF_EINVAL; g_mlp_variant = value; return MVSNERF_OK; }
-    if (__builtin_strcmp(key, "split_sched") == 0) { if (value < 0 || value > 1) return MVSNERF_EINVAL; g_split_sched = value; return MVSNERF_OK; }
-    return MVSNERF_EINVAL;
-}
-
-template <bool AO, int G, int WPS, bool SAVE = false>
-static int launch_mlp(const float* packed, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
-                      const float* dirs, int dirs_stride, int64_t P, int S, float* raw, hipStream_t st, float* saved = nullptr)
-{
-    const size_t lds_bytes = LDS_FLOATS * sizeof(float);
-    static unsigned long long lds_cap_set = 0;          // per-device bit mask (common.h)
-    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_kernel<AO, G, WPS, SAVE>), (int)lds_bytes, &lds_cap_set)) return rc_;
-    mlp_fwd_kernel<AO, G, WPS, SAVE><<<mvs_cdiv(P, 128 * G), 256, lds_bytes, st>>>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, saved);
-    MVS_LAUNCH_CHECK();
-    return MVSNERF_OK;
-}
-#endif
+// (The lookups fused into this kernel's prologue were measured in round 2 - 0.2574 ms/step against 0.2551 ms with the separate 11 us gather
+// launch, whose 2048 waves hide the lookup latency that every workgroup's first GEMM would otherwise wait for - and are not built.)
 
 static int mlp_fwd_checked(const float* packed, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
                            const float* dirs, int dirs_stride, int64_t N, int S, int alpha_only, float* raw, void* stream, long long* census)
@@ -745,21 +429,6 @@ static int mlp_fwd_checked(const float* packed, int F, const float* ndc, int ndc
     const int64_t P = N * S;
     if (P == 0) return MVSNERF_OK;
     hipStream_t st = (hipStream_t)stream;
-#ifdef MVSNERF_DEV_KNOBS
-    if (g_mlp_variant == 4)                        // 16 points per wave (mlp16.hip), its weights follow the 32-point layout in `packed`
-        return mvs_mlp16_fwd(packed + off16(F), F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st);
-#define MVS_MLP(AO, G, WPS) launch_mlp<AO, G, WPS>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, st)
-    switch (g_mlp_variant * 2 + (alpha_only ? 1 : 0)) {
-        case 0: return MVS_MLP(false, 1, 2);
-        case 1: return MVS_MLP(true, 1, 2);
-        case 2: return MVS_MLP(false, 2, 1);
-        case 3: return MVS_MLP(true, 2, 1);
-        case 4: return MVS_MLP(false, 1, 1);
-        case 5: return MVS_MLP(true, 1, 1);
-        default: break;
-    }
-#undef MVS_MLP
-#endif
     if (alpha_only) return launch_mlp_pipe<true, false>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, st, nullptr, census);
     return launch_mlp_pipe<false, false>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, st, nullptr, census);
 }
@@ -789,26 +458,6 @@ extern "C" int mvsnerf_mlp_fwd_train(const float* packed, int F, const float* nd
     if (!mvs_aligned16(packed) || !mvs_aligned16(raw) || !mvs_aligned16(saved)) return MVSNERF_EALIGN;
     const int64_t P = N * S;
     if (P == 0) return MVSNERF_OK;
-#ifdef MVSNERF_DEV_KNOBS
-    if (g_mlp_variant != 3)
-        return launch_mlp<false, 1, 2, true>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, (hipStream_t)stream, saved);
-#endif
     return launch_mlp_pipe<false, true>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, (hipStream_t)stream, saved);
 }
 
-#ifdef MVSNERF_DEV_KNOBS
-// diagnostics: resident workgroups per CU the runtime grants the MLP kernels (A/B tooling, not part of the reference surface)
-extern "C" int mvsnerf_debug_mlp_occupancy(int variant)
-{
-    int n = -1;
-    hipError_t e;
-    if (variant == 3) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_pipe_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PIPE_LDS_FLOATS * sizeof(float)));
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mlp_fwd_pipe_kernel<false, false>, 256, PIPE_LDS_FLOATS * sizeof(float));
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<false, 1, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_FLOATS * sizeof(float)));
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mlp_fwd_kernel<false, 1, 2, false>, 256, LDS_FLOATS * sizeof(float));
-    }
-    return e == hipSuccess ? n : -(int)e;
-}
-#endif

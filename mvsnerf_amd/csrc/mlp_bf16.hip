@@ -769,7 +769,6 @@ extern "C" int mvsnerf_mlp_fwd_bf16_train(const void* packed_bf16, const float* 
     return MVSNERF_OK;
 }
 
-MVS_KNOB_DEF(g_split_sched, 0)    // knobs.h
 
 extern "C" size_t mvsnerf_mlp_packed_split_elems(int F, int n_split)
 {
@@ -812,8 +811,7 @@ extern "C" int mvsnerf_mlp_fwd_split(const void* packed_split, const float* pack
         case 1: rc = launch_split<1, 0>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st); break;
         case 2: rc = launch_split<2, 0>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st); break;
         default:
-            if (g_split_sched == 1) rc = launch_split<3, 1>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st);
-            else rc = launch_split<3, 0>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st);
+            rc = launch_split<3, 0>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, alpha_only, raw, st);
             break;
     }
     if (rc) return rc;

@@ -5,11 +5,6 @@
 
 extern "C" int mvsnerf_abi_version(void) { return 9; }
 
-// mlp.hip: gather + MLP in one launch (three source views, fp32 kernel); MVSNERF_EUNSUPPORTED -> take the two-launch path
-int mvs_mlp_fwd_gather(const float* packed, const float* vol, int D, int H, int W, const float* imgs_nhwc4, int V, int IH, int IW,
-                       const float* w2c, const float* K, const float* pts, const float* ndc, const float* rays_dir,
-                       int64_t N, int S, float* feat, float* raw, hipStream_t st);
-
 extern "C" int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream)
 {
     if (!a) return MVSNERF_EINVAL;
@@ -20,16 +15,7 @@ extern "C" int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream
     const int F = 8 + 4 * a->V;
     const int64_t P = a->N * a->S;
     int rc;
-    bool mlp_done = false;
-    if (a->imgs_nhwc4 && !a->packed_mlp_split && !a->packed_mlp_bf16) {
-        // gen_dir_feature + gen_pts_feats in the prologue of the MLP kernel: ONE launch for lookups + network
-        rc = mvs_mlp_fwd_gather(a->packed_mlp, a->vol, a->D, a->H, a->W, a->imgs_nhwc4, a->V, a->IH, a->IW, a->w2c, a->K, a->rays_pts, a->rays_ndc,
-                                a->rays_dir, a->N, a->S, a->input_feat, a->raw, (hipStream_t)stream);
-        if (rc == MVSNERF_OK) mlp_done = true;
-        else if (rc != MVSNERF_EUNSUPPORTED) return rc;
-    }
-    if (mlp_done) {
-    } else if (a->imgs_nhwc4) {
+    if (a->imgs_nhwc4) {
         // gen_dir_feature + gen_pts_feats in one launch (channel-last source images supplied by the caller)
         if ((rc = mvsnerf_gather_fwd(a->vol, a->D, a->H, a->W, a->imgs_nhwc4, a->V, a->IH, a->IW, a->w2c, a->K, a->rays_pts, a->rays_ndc,
                                      a->N, a->S, a->rays_dir, a->input_feat, F, a->dirs_tmp, stream))) return rc;
@@ -41,8 +27,7 @@ extern "C" int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream
         if ((rc = mvsnerf_color_sample_fwd(a->imgs, a->V, a->IH, a->IW, a->w2c, a->K, a->rays_pts, P, 1, a->input_feat + 8, F, stream))) return rc;
     }
     // network_query_fn (renderer.py:156 -> run_network_mvs 42-63)
-    if (mlp_done) rc = MVSNERF_OK;
-    else if (a->packed_mlp_split)
+    if (a->packed_mlp_split)
         rc = mvsnerf_mlp_fwd_split(a->packed_mlp_split, a->packed_mlp, F, a->n_split, a->rays_ndc, 3, a->input_feat, F, a->dirs_tmp, 3, a->N, a->S, 0, a->raw, stream);
     else if (a->packed_mlp_bf16)
         rc = mvsnerf_mlp_fwd_bf16(a->packed_mlp_bf16, a->packed_mlp, F, a->rays_ndc, 3, a->input_feat, F, a->dirs_tmp, 3, a->N, a->S, 0, a->raw, stream);
@@ -100,16 +85,6 @@ extern "C" int mvsnerf_render_pixels_fwd(const mvsnerf_render_args* a, void* str
         const int64_t n = a->n_pixels - off < B ? a->n_pixels - off : B;
         if ((rc = mvsnerf_raygen_fwd(nullptr, nullptr, a->first_pixel + off, a->W_img, a->H_img, a->W_ref, a->H_ref, a->K_tgt, a->c2w_tgt, a->K_ref, a->w2c_ref,
                                      a->near_far_tgt, a->near_far_ref, a->pad, a->lindisp, nullptr, n, S, pts, rdir, ndc, z, nullptr, stream))) return rc;
-        rc = MVSNERF_EUNSUPPORTED;
-        if (!a->packed_mlp_split && !a->packed_mlp_bf16)
-            rc = mvs_mlp_fwd_gather(a->packed_mlp, a->vol, a->D, a->H, a->W, a->imgs_nhwc4, a->V, a->IH, a->IW, a->w2c, a->K, pts, ndc, rdir, n, S, feat, raw,
-                                    (hipStream_t)stream);
-        if (rc == MVSNERF_OK) {
-            if ((rc = mvsnerf_composite_fwd(raw, z, n, S, a->white_bkgd, a->rgb + off * 3, a->disp ? a->disp + off : nullptr,
-                                            a->acc ? a->acc + off : nullptr, nullptr, a->depth ? a->depth + off : nullptr, nullptr, stream))) return rc;
-            continue;
-        }
-        if (rc != MVSNERF_EUNSUPPORTED) return rc;
         if ((rc = mvsnerf_gather_fwd(a->vol, a->D, a->H, a->W, a->imgs_nhwc4, a->V, a->IH, a->IW, a->w2c, a->K, pts, ndc, n, S, rdir,
                                      feat, F, dirs, stream))) return rc;
         if (a->packed_mlp_split)

@@ -83,7 +83,9 @@ def gen_pts_feats(imgs, volume_feature, rays_pts, pose_ref, rays_ndc, feat_dim, 
     if feat_dim != 8 + 4 * V:
         raise RuntimeError(f"feat_dim {feat_dim} != 8 + 4*V ({V} views)")
     if img_feat is not None:          # renderer.py:126-127,133: feat_dim grows by V*Cf; columns [8 | V x (rgb, Cf feature channels, mask)]
-        feat_dim += img_feat.shape[1] * img_feat.shape[2]
+        if img_feat.shape[1] != V:        # the reference's cat (utils.py:329) would raise on mismatched view counts; here columns would stay unwritten
+            raise RuntimeError(f"gen_pts_feats: img_feat holds {img_feat.shape[1]} views, imgs {V}")
+        feat_dim += V * img_feat.shape[2]
         out = torch.empty((N, S, feat_dim), device=rays_pts.device, dtype=torch.float32)
         ops.volume_sample(vol_cl, rays_ndc.contiguous(), out=out, out_stride=feat_dim)
         ops.color_feat_sample(imgs[0].contiguous(), img_feat[0, :V].contiguous(), pose_ref["w2cs"][:V].contiguous(),

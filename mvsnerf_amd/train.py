@@ -170,12 +170,17 @@ class MVSSystem(_ModuleShim):
         if getattr(args, "with_depth", False):
             mask = rays_depth > 0
             if getattr(args, "with_depth_loss", False):
-                depth_term = self.loss(depth_pred, rays_depth, mask)
-                loss = loss + depth_term
                 if self.dp_mode() == "ray" and D.world_rank()[0] > 1:
-                    # the depth term is a mean over the MASKED rays: weight by local masked count x world / global masked count (every
-                    # rank holds the full draw before slicing, so the global count is local knowledge; device tensors, no host sync)
-                    depth_scale = mask.sum() * float(D.world_rank()[0]) / n_masked_all.clamp_min(1)
+                    # The depth term is a mean over the MASKED rays of the whole draw.  A rank's slice (128 rays at 8 GPUs) may hold none of
+                    # them: a local masked mean would then be NaN, and the flat all-reduce would hand that NaN to every rank.  So: local masked
+                    # SUM (0 for an empty slice) x world / global masked count - every rank holds the full draw before slicing, so the global
+                    # count is local knowledge (device tensors, no host sync); the rank-averaged gradient is that of the global mean.
+                    dsum = torch.nn.functional.smooth_l1_loss(depth_pred[mask], rays_depth[mask], reduction="sum") * 2 ** (1 - 2)
+                    depth_term = dsum / mask.sum().clamp_min(1)                     # reported: local mean (0 when the slice has no masked ray)
+                    depth_scale = dsum * float(D.world_rank()[0]) / n_masked_all.clamp_min(1)   # back-propagated
+                else:
+                    depth_term = self.loss(depth_pred, rays_depth, mask)
+                loss = loss + depth_term
             with torch.no_grad():                                        # :130-138
                 err = (depth_pred - rays_depth)[mask].abs()
                 for t in self.eval_metric:
@@ -200,7 +205,7 @@ class MVSSystem(_ModuleShim):
         # the global mean; what is reported / logged stays the plain local mean ('loss_unscaled')
         if loss_scale == 1.0 and depth_scale is None:
             return {"loss": loss}
-        scaled = img_loss * loss_scale + (0 if depth_term is None else depth_term * (depth_scale if depth_scale is not None else loss_scale))
+        scaled = img_loss * loss_scale + (0 if depth_term is None else (depth_scale if depth_scale is not None else depth_term * loss_scale))
         return {"loss": scaled, "loss_unscaled": loss.detach()}
 
     @torch.no_grad()

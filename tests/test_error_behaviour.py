@@ -39,7 +39,7 @@ def test_c_abi_rejects_bad_arguments_without_launching():
     assert l.mvsnerf_mlp_pack_split(wp, 20, 4, p, 0) == EUNSUPPORTED and l.mvsnerf_mlp_pack_split(wp, 20, 18, p + 4, 0) == EALIGN
     assert l.mvsnerf_mlp_fwd_split(p, p, 20, 7, p, 3, p, 20, p, 3, 1, 1, 0, p, 0) == EUNSUPPORTED
     assert l.mvsnerf_mlp_fwd_split(p, p, 20, 18, p, 3, p, 20, p, 3, 0, 1, 0, p, 0) == 0                # empty batch: no launch
-    assert not hasattr(l, "mvsnerf_tune") and not hasattr(l, "mvsnerf_debug_set_census")     # the product library has no A/B switches (csrc/knobs.h)
+    assert not hasattr(l, "mvsnerf_tune") and not hasattr(l, "mvsnerf_debug_set_census")     # the library has no A/B switches (csrc/knobs.h: constants)
 
 
 def test_python_layer_raises_and_names_the_op():

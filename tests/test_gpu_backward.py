@@ -294,7 +294,7 @@ def test_planesweep_bwd_vs_float64_autograd(V, H, W, pad, D, with_img, bscale):
     a torch restatement of models.py:839-893 on the same GPU.  Cases: 1, 2, 4 and 7 source views; widths that are not a multiple of the
     8-column workgroup; depths that are not a multiple of the 16-plane geometry batch; bscale = 6: baselines six times wider, so the taps
     move by more than a pixel per plane and the send / gather path runs on nearly every plane.  The last case is the training shape
-    (timed).  (A/B against the scatter and LDS-patch kernels it replaced: scratch/dev_tests.)"""
+    (timed)."""
     import torch.nn.functional as F
     from mvsnerf_amd import _lib
     from mvsnerf_amd.ops import stream_ptr

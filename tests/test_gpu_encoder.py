@@ -107,16 +107,17 @@ def test_midsize_vs_oracle(mvs):
     assert ok, f"CostRegNet vs oracle {e}"
 
 
-@pytest.mark.parametrize("V,bscale,with_img,pad,D", [(3, 6.0, True, 3, 21), (5, 1.0, True, 2, 10), (2, 3.0, False, 0, 13), (8, 1.0, True, 1, 6)])
+@pytest.mark.parametrize("V,bscale,with_img,pad,D", [(3, 6.0, True, 3, 21), (5, 1.0, True, 2, 10), (2, 3.0, False, 0, 13), (8, 1.0, True, 1, 6), (10, 1.0, True, 1, 5), (12, 1.0, False, 0, 4)])
 def test_planesweep_tap_reuse_vs_oracle(mvs, V, bscale, with_img, pad, D):
     """planesweep_kernel walks a voxel column through 4 depth planes with the source taps in registers and gathers again only when a
     tap address changes.  Both paths against the CPU oracle, bit for bit: bscale = 1 rigs move the taps by a fraction of a pixel per
-    plane (mostly reuse), bscale = 3 / 6 by more than a pixel (a gather on nearly every plane); 1, 2, 4 and 7 source views; depths that
+    plane (mostly reuse), bscale = 3 / 6 by more than a pixel (a gather on nearly every plane); 1, 2, 4, 7, 9 and 11 source views (more than
+    eight views: the per-plane T / depth table in LDS is sized from V - ADVICE round 3); depths that
     are not a multiple of 4; widths that are not a multiple of the 16-column wave."""
     from mvsnerf_amd.synth import make_rig
     from oracle import mvsnerf_oracle as O
     H, W = 22, 29
-    base = tuple(b * bscale for b in (0.0, 0.25, -0.25, 0.12, -0.12, 0.1, -0.3, 0.3, 0.2))
+    base = tuple(b * bscale for b in (0.0, 0.25, -0.25, 0.12, -0.12, 0.1, -0.3, 0.3, 0.2, -0.2, 0.15, -0.15, 0.05))
     rig = make_rig(H * 4, W * 4, n_views=V + 1, seed=31, baselines=base[:V + 1], rot_deg=2.0, smooth=True)
     imgs, proj = rig["images"][:, :V], rig["proj_mats"][:, :V]
     feats = torch.randn((1, V, 32, H, W), generator=torch.Generator().manual_seed(V))
@@ -277,7 +278,7 @@ def test_conv0_blocked_wgrad_full_size_vs_rows_kernel():
 def test_conv3d_wgrad_vs_float64(A, B, stride, dims, g2, xact):
     """The matrix-core weight gradient of the 16/32/64-channel layers (wgrad_mfma.hip), with the lazily applied activations and the skip
     sum of the transposed layers, against its float64 definition  gw[a,b,tap] = sum_vox G[vox,a] * X[vox*stride + tap - 1, b]
-    (27 float64 matrix products on the GPU).  (The A/B against the VALU kernel it replaced: scratch/dev_tests.)"""
+    (27 float64 matrix products on the GPU)."""
     from mvsnerf_amd import _lib
     from mvsnerf_amd.ops import stream_ptr
     import torch.nn.functional as F

@@ -90,7 +90,7 @@ def test_convbnrelu_standalone():
 ])
 def test_conv2d_wgrad_vs_float64(A, B, k, stride, hw, ldx):
     """FeatureNet's weight gradients on the matrix cores (wgrad_mfma.hip, the images as the z axis) with the lazily applied InPlaceABN
-    of the input layer, against the float64 definition.  (A/B against the VALU kernel it replaced: scratch/dev_tests.)"""
+    of the input layer, against the float64 definition."""
     from mvsnerf_amd import _lib
     from mvsnerf_amd.ops import stream_ptr
     N, (Ho, Wo) = 3, hw
