@@ -364,8 +364,10 @@ def main():
     encode_ms_bf16 = encode_ms_h3 = None
     if enc_ready:
         vol, encode_ms = encoder.bench_encode(rig, dev, PAD)
-        encode_ms["conv0_arithmetic"] = ("fp16x3: two fp16 pieces per operand, x0*w0 + x0*w1 + x1*w0 on v_mfma_f32_16x16x32_f16, fp32 accumulation (the default of a no-grad "
-                                         "encode; encode_ms_fp32_conv0 = the same encode with conv0 on v_mfma_f32_4x4x1_16B_f32)")
+        encode_ms["conv0_arithmetic"] = ("guarded fp16x3 (the default of a no-grad encode): two fp16 pieces per operand, x0*w0 + x0*w1 + x1*w0 on v_mfma_f32_16x16x32_f16, fp32 "
+                                         "accumulation; a cost value or weight outside fp16's range trips a device-side guard and the fp32 sweep + fp32-MFMA conv0 enqueued behind "
+                                         "the pair (predicated on it) recompute the layer; encode_ms_fp32_conv0 = the same encode with conv0 on v_mfma_f32_4x4x1_16B_f32")
+        encode_ms["guard_fallbacks_so_far"] = ops.guard_fallbacks()
         volume_src = "mvsnet-encode"
         if not a.no_extras:
             # opt-in (NOT the headline volume, which stays fp32): the encoder with conv0 on the bf16 matrix cores from a bf16 cost volume
@@ -602,25 +604,29 @@ def main():
             batch = train.batch_to_device(train.synthetic_batch(H_IMG, W_IMG, seed=1234), dev)
             # sub-batches of 1024 rays = the reference's chunk (and the headline batch): every launch of the MLP kernel in this
             # process then has the same size, so its rocprofv3 average is comparable with roofline.avg_launch_ms
-            system.render_view(batch, batch_rays=N_RAYS)
-            torch.cuda.synchronize(); f0 = time.perf_counter()
-            system.render_view(batch, batch_rays=N_RAYS)
-            torch.cuda.synchronize(); fdt = time.perf_counter() - f0
-            extras["frame_512x640"] = {"seconds": round(fdt, 4), "rays_per_s_incl_encode": round(H_IMG * W_IMG / fdt, 1),
-                                       "note": "MVSSystem.render_view: MVSNet encode + 320 sub-batches of 1024 rays x 128 samples through "
-                                               "mvsnerf_render_pixels_fwd (one FFI call; ray generation, fused gather, MLP, compositing per sub-batch). "
-                                               "With the default 4096-ray sub-batches the same frame takes 0.090 s (profiles/r01_configs_2_4_5.txt)"}
-            # (i-b) the same frame with the opt-in fp16x3 MLP kernel (fp32-grade results, csrc/mlp_f16x3.hip); NOT the headline arithmetic
-            with torch.no_grad():
+            from mvsnerf_amd import encoder as _E
+            fb0 = ops.guard_fallbacks()
+            with torch.no_grad(), ops.mlp_precision("auto"):          # the library default: guarded fp16 kernels for the no-grad encode and the MLP
+                system.render_view(batch, batch_rays=N_RAYS)
+                torch.cuda.synchronize(); f0 = time.perf_counter()
+                rgb16, _ = system.render_view(batch, batch_rays=N_RAYS)
+                torch.cuda.synchronize(); fdt = time.perf_counter() - f0
+            fb1 = ops.guard_fallbacks()
+            with torch.no_grad(), ops.mlp_precision("fp32"), _E.encoder_precision("fp32"):
+                system.render_view(batch, batch_rays=N_RAYS)
+                torch.cuda.synchronize(); f0 = time.perf_counter()
                 rgb32, _ = system.render_view(batch, batch_rays=N_RAYS)
-                with ops.mlp_precision("fp16x3"):
-                    system.render_view(batch, batch_rays=N_RAYS)
-                    torch.cuda.synchronize(); f0 = time.perf_counter()
-                    rgb16, _ = system.render_view(batch, batch_rays=N_RAYS)
-                    torch.cuda.synchronize(); fdt16 = time.perf_counter() - f0
-            extras["frame_512x640_fp16x3"] = {"seconds": round(fdt16, 4), "rays_per_s_incl_encode": round(H_IMG * W_IMG / fdt16, 1),
-                                              "max_abs_rgb_diff_vs_fp32_frame": float((rgb16 - rgb32).abs().max()),
-                                              "note": "the same MVSSystem.render_view call under ops.mlp_precision('fp16x3'): encode (fp32 kernels) + 320 sub-batches"}
+                torch.cuda.synchronize(); fdt32 = time.perf_counter() - f0
+            extras["frame_512x640"] = {"seconds": round(fdt, 4), "rays_per_s_incl_encode": round(H_IMG * W_IMG / fdt, 1),
+                                       "max_abs_rgb_diff_vs_fp32_kernels_frame": float((rgb16 - rgb32).abs().max()),
+                                       "guard_fallbacks_during_the_two_frames": fb1 - fb0,
+                                       "note": "MVSSystem.render_view in the library default (ops.MLP_PRECISION = encoder.ENCODER_PRECISION = 'auto'): MVSNet encode + 320 "
+                                               "sub-batches of 1024 rays x 128 samples through mvsnerf_render_pixels_fwd (one FFI call; ray generation, fused gather, "
+                                               "GUARDED fp16x3 MLP = fp16 kernel + predicated fp32-MFMA kernel, compositing per sub-batch); results are fp32-grade and "
+                                               "cannot saturate (include/mvsnerf_hip.h, guarded 16-bit sequences)"}
+            extras["frame_512x640_fp32_kernels"] = {"seconds": round(fdt32, 4), "rays_per_s_incl_encode": round(H_IMG * W_IMG / fdt32, 1),
+                                                    "note": "the same call with ops.mlp_precision('fp32') and encoder_precision('fp32'): every product on the fp32 matrix-core "
+                                                            "instructions (the arithmetic of the headline step)"}
             del rgb32, rgb16
             # (ii) one generalizable-training step (config 3 shapes, fp32): encode + ray march + full backward + Adam
             opt = system.configure_optimizers()[0][0]
@@ -688,12 +694,22 @@ def main():
             # (iv), (v) opt-in fp32 EMULATION on the 16-bit matrix cores; NOT the headline (whose arithmetic stays fp32 MFMA):
             #   bf16x6: operands as 3 bf16 pieces, 6 v_mfma_f32_32x32x16_bf16 per product (fp32's range)
             #   fp16x3: operands as 2 fp16 pieces (2 x 11 = 22 significant bits), 3 v_mfma_f32_32x32x16_f16 per product (fp16's range)
-            for mode, n_mfma, what in (("bf16x6", 6, "fp32 operands split into 3 bf16 pieces, 6 v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate"),
+            for mode, n_mfma, what in (("auto", 3, "THE LIBRARY DEFAULT for no-grad rendering: the guarded sequence = fp16x3 kernel (below) reporting out-of-range values through a "
+                                                  "device-side guard word + the fp32-MFMA kernel predicated on it + compositing that re-arms the guard; mlp_kernel_ms is the "
+                                                  "HIP-event time of mvsnerf_mlp_fwd_guarded (both MLP launches + the re-arm launch)"),
+                                       ("bf16x6", 6, "fp32 operands split into 3 bf16 pieces, 6 v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate"),
                                        ("fp16x3", 3, "fp32 operands split into 2 fp16 pieces (22 significant bits), 3 v_mfma_f32_32x32x16_f16 per product, fp32 accumulate; "
                                                      "256 points per workgroup share each layer's weights (csrc/mlp_f16x3.hip)")):
-                ps, ns = net.packed_split(F, ops.N_SPLIT[mode])
-                xdt, xreps, gx, rawx, t_x = mlp_mode(mode, lambda: lib.mvsnerf_mlp_fwd_split(ps.data_ptr(), packed.data_ptr(), F, ns, ndc.data_ptr(), 3, feat.data_ptr(), F,
-                                                                                             dirs.data_ptr(), 3, N_RAYS, N_SAMPLES, 0, raw.data_ptr(), st().cuda_stream))
+                ps, ns = net.packed_split(F, ops.N_SPLIT["fp16x3" if mode == "auto" else mode])
+                if mode == "auto":
+                    gw = ops.guard_words(dev)
+                    fb0 = ops.guard_fallbacks()
+                    launch_x = lambda: lib.mvsnerf_mlp_fwd_guarded(ps.data_ptr(), packed.data_ptr(), F, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3,
+                                                                   N_RAYS, N_SAMPLES, 0, raw.data_ptr(), gw.data_ptr(), st().cuda_stream)
+                else:
+                    launch_x = lambda: lib.mvsnerf_mlp_fwd_split(ps.data_ptr(), packed.data_ptr(), F, ns, ndc.data_ptr(), 3, feat.data_ptr(), F,
+                                                                 dirs.data_ptr(), 3, N_RAYS, N_SAMPLES, 0, raw.data_ptr(), st().cuda_stream)
+                xdt, xreps, gx, rawx, t_x = mlp_mode(mode, launch_x)
                 tfl = n_mfma * FLOP_PER_SAMPLE * P / (t_x * 1e-3) / 1e12
                 e = {"rays_per_s": round(N_RAYS / xdt, 1), "ms_per_step": round(xdt * 1e3, 4), "ms_per_step_reps": [round(r * 1e3, 4) for r in xreps],
                      "mlp_kernel_ms": round(t_x, 4), "mlp_tflops_fp32_equiv": round(FLOP_PER_SAMPLE * P / (t_x * 1e-3) / 1e12, 1),
@@ -701,14 +717,17 @@ def main():
                                   "note": f"{n_mfma} x the algorithmic FLOPs of the MLP (issued 16-bit matrix-core work) over the HIP-event duration of the kernel alone"},
                      "max_abs_rgb_diff_vs_fp32_path": float((gx[0] - g32[0]).abs().max()),
                      "max_abs_sigma_diff_vs_fp32_kernel": float((rawx[..., 3] - raw32[..., 3]).abs().max()),
-                     "note": what + f"; opt-in via ops.set_mlp_precision('{mode}'); parity tests: tests/test_gpu_raymarch.py, tests/test_gpu_fp16x3.py"}
+                     "note": what + (f"; opt-in via ops.set_mlp_precision('{mode}'); parity tests: tests/test_gpu_raymarch.py, tests/test_gpu_fp16x3.py" if mode != "auto"
+                                     else "; parity / overflow tests: tests/test_gpu_guard.py, tests/test_gpu_fp16x3.py")}
+                if mode == "auto":
+                    e["guard_fallbacks"] = ops.guard_fallbacks() - fb0
                 if cpu is not None and "max_abs_sigma_err_same_volume" in cpu:
                     # against the CPU oracle on the same batch and the same (GPU-built) volume: the numbers the fp32 kernel reports in cpu_baseline
                     serr_x = (rawx[..., 3].cpu() - o[6][..., 3]).abs()
                     e["max_abs_sigma_err_vs_cpu_oracle_same_volume"] = float(serr_x.max())
                     e["n_sigma_over_1e-4_vs_cpu_oracle"] = int((serr_x > 1e-4).sum())
                     e["max_abs_rgb_err_vs_cpu_oracle"] = float((gx[0].cpu() - o[0]).abs().max())
-                extras[mode + "_mlp_mode"] = e
+                extras[("guarded_default" if mode == "auto" else mode) + "_mlp_mode"] = e
         print(json.dumps({
             "metric": "rendered rays/sec (1024-ray batch, 128 samples)", "value": round(rays_per_s, 1), "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),

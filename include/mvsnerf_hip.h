@@ -461,6 +461,7 @@ typedef struct {
     const float* imgs_nhwc4;                /* NULL: three gather launches from `imgs` (NCHW); else [V][IH][IW][4] copies of the
                                                same images and ONE fused gather launch (mvsnerf_gather_fwd) (ABI v3) */
     const void* packed_mlp_split; int n_split;   /* NULL/0, or mvsnerf_mlp_pack_split output: split-bf16 MLP (ABI v5) */
+    int* guard;                             /* NULL, or a guard word pair with n_split = MVSNERF_SPLIT_FP16: the guarded sequence below (ABI v10) */
 } mvsnerf_raymarch_args;
 int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream);
 
@@ -481,6 +482,39 @@ int mvsnerf_mlp_pack_split(const float* const w[11], int F, int n_split, void* p
 int mvsnerf_mlp_fwd_split(const void* packed_split, const float* packed_f32, int F, int n_split, const float* ndc, int ndc_stride,
                           const float* feat, int feat_stride, const float* dirs, int dirs_stride,
                           int64_t N, int S, int alpha_only, float* raw, void* stream);
+
+/* ---- Guarded 16-bit sequences (ABI v10) ----
+ * The two-piece fp16 kernels ("fp16x3": the MLP above, conv0 of CostRegNet below) give fp32-grade results at 2-2.5x the fp32-MFMA rate, but an
+ * fp16 piece cannot hold more than 65504: a value outside that range saturates.  A GUARDED sequence makes them safe to use by default without a
+ * host synchronisation: `guard` is a device buffer of 4 ints owned by the caller (zero it once); the 16-bit kernels set guard[0] when an operand,
+ * a stored value or (at pack time, through a status word behind the packed weights) a weight left fp16's range; the fp32 kernels of the same
+ * stage are enqueued right behind them PREDICATED on guard[0] (they leave at once when it is 0, and overwrite the results when it is set); the
+ * last kernel of the sequence counts the event in guard[1] and re-arms guard[0] = 0.  The caller reads results that are the fp32 kernels'
+ * whenever the 16-bit ones were out of range, and may read guard[1] (number of sequences that fell back) whenever it synchronises anyway.
+ *   - mvsnerf_raymarch_fwd / mvsnerf_render_pixels_fwd: args.guard with n_split = MVSNERF_SPLIT_FP16 (gather -> fp16x3 MLP -> predicated fp32-MFMA
+ *     MLP -> compositing, which also re-arms the guard);
+ *   - mvsnerf_mlp_fwd_guarded: the stand-alone network query (run_network_mvs, renderer.py:42-63; alpha_only = forward_alpha);
+ *   - mvsnerf_sweep_conv0_guarded_fwd (scene encode): two-piece plane sweep -> fp16x3 conv0 -> predicated {fp32 plane sweep in channel blocks,
+ *     fp32-MFMA conv0, InPlaceABN partial sums} -> re-arm.  `cost32` (the fp32 hand-off, (CP/4) * D*Hp*Wp * 4 floats) is scratch that is only
+ *     written when the guard trips.  stats_part: mvsnerf_conv0_bf16_tiles(D, Hp, Wp) slots x 16 floats in either case. */
+int mvsnerf_mlp_fwd_guarded(const void* packed_fp16, const float* packed_f32, int F, const float* ndc, int ndc_stride,
+                            const float* feat, int feat_stride, const float* dirs, int dirs_stride,
+                            int64_t N, int S, int alpha_only, float* raw, int* guard, void* stream);
+typedef struct {
+    const float* feats_cl; const float* imgs_cl;   /* [V][H][W][32], [V][H][W][4] as for mvsnerf_planesweep_costvar_fwd (with_img = 1) */
+    const float* proj; const float* depth;         /* [V][3][4], [D] */
+    int V, H, W, D, pad, CP;                       /* CP = 3V + 32 rounded up to a multiple of 4 */
+    float* masks;                                  /* [V][D][Hp][Wp] */
+    void* cost16x2;                                /* two fp16 planes: 2 * ceil(CP/16) * D*Hp*Wp * 16 halfs */
+    float* cost32;                                 /* fp32 blocks of four channels: (CP/4) * D*Hp*Wp * 4 floats (written only on fallback) */
+    const void* w_f16x3;                           /* mvsnerf_conv0_f16x3_pack */
+    const float* w_c8;                             /* mvsnerf_conv3d_pack_weights_c8 (the fp32-MFMA conv0's layout) */
+    int Cin;                                       /* real input channels 3V + 32 */
+    float* out;                                    /* raw conv0 output [D][Hp][Wp][8] */
+    float* stats_part;                             /* InPlaceABN partial sums (see above) or NULL */
+    int* guard;
+} mvsnerf_sweep_conv0_args;
+int mvsnerf_sweep_conv0_guarded_fwd(const mvsnerf_sweep_conv0_args* a, void* stream);
 
 /* ---- importance sampling of the fine-tuning option --use_density_volume ----
  * sample_pdf (data/ray_utils.py:96-139): bins[N][n_bins] ascending, weights[N][n_bins-1], u[N][n_importance] uniform draws
@@ -521,6 +555,7 @@ typedef struct {
     float* workspace; size_t workspace_floats;
     float* rgb; float* depth; float* acc; float* disp;      /* rgb required, others may be NULL */
     const void* packed_mlp_split; int n_split;              /* NULL/0, or mvsnerf_mlp_pack_split output (ABI v5) */
+    int* guard;                                             /* NULL, or guard words with n_split = MVSNERF_SPLIT_FP16: every sub-batch is a guarded sequence (ABI v10) */
 } mvsnerf_render_args;
 size_t mvsnerf_render_workspace_floats(int batch_rays, int S, int V);
 int mvsnerf_render_pixels_fwd(const mvsnerf_render_args* a, void* stream);

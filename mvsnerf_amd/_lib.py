@@ -28,7 +28,7 @@ class RaymarchArgs(ctypes.Structure):
         ("N", _c_l), ("S", _c_i), ("white_bkgd", _c_i),
         ("dirs_tmp", _c_fp), ("input_feat", _c_fp), ("raw", _c_fp),
         ("rgb_map", _c_fp), ("disp", _c_fp), ("acc", _c_fp), ("weights", _c_fp), ("depth", _c_fp), ("alpha", _c_fp),
-        ("packed_mlp_bf16", _c_fp), ("imgs_nhwc4", _c_fp), ("packed_mlp_split", _c_fp), ("n_split", _c_i),
+        ("packed_mlp_bf16", _c_fp), ("imgs_nhwc4", _c_fp), ("packed_mlp_split", _c_fp), ("n_split", _c_i), ("guard", _c_fp),
     ]
 
 
@@ -69,7 +69,17 @@ class RenderArgs(ctypes.Structure):
         ("first_pixel", _c_l), ("n_pixels", _c_l),
         ("S", _c_i), ("white_bkgd", _c_i), ("batch_rays", _c_i),
         ("workspace", _c_fp), ("workspace_floats", ctypes.c_size_t),
-        ("rgb", _c_fp), ("depth", _c_fp), ("acc", _c_fp), ("disp", _c_fp), ("packed_mlp_split", _c_fp), ("n_split", _c_i),
+        ("rgb", _c_fp), ("depth", _c_fp), ("acc", _c_fp), ("disp", _c_fp), ("packed_mlp_split", _c_fp), ("n_split", _c_i), ("guard", _c_fp),
+    ]
+
+
+class SweepConv0Args(ctypes.Structure):
+    """mvsnerf_sweep_conv0_args (include/mvsnerf_hip.h): the guarded head of a no-grad scene encode."""
+    _fields_ = [
+        ("feats_cl", _c_fp), ("imgs_cl", _c_fp), ("proj", _c_fp), ("depth", _c_fp),
+        ("V", _c_i), ("H", _c_i), ("W", _c_i), ("D", _c_i), ("pad", _c_i), ("CP", _c_i),
+        ("masks", _c_fp), ("cost16x2", _c_fp), ("cost32", _c_fp), ("w_f16x3", _c_fp), ("w_c8", _c_fp), ("Cin", _c_i),
+        ("out", _c_fp), ("stats_part", _c_fp), ("guard", _c_fp),
     ]
 
 
@@ -161,6 +171,8 @@ SIGNATURES = {
     "mvsnerf_mlp_packed_split_elems": (ctypes.c_size_t, [_c_i, _c_i]),
     "mvsnerf_mlp_pack_split": (_c_i, [ctypes.POINTER(_c_fp), _c_i, _c_i, _c_fp, _c_fp]),
     "mvsnerf_mlp_fwd_split": (_c_i, [_c_fp, _c_fp, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_mlp_fwd_guarded": (_c_i, [_c_fp, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_sweep_conv0_guarded_fwd": (_c_i, [ctypes.POINTER(SweepConv0Args), _c_fp]),
     "mvsnerf_mlp_packed_bf16_elems": (ctypes.c_size_t, [_c_i]),
     "mvsnerf_mlp_pack_bf16": (_c_i, [ctypes.POINTER(_c_fp), _c_i, _c_fp, _c_fp]),
     "mvsnerf_mlp_fwd_bf16": (_c_i, [_c_fp, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp]),

@@ -12,6 +12,7 @@ __global__ __launch_bounds__(256) void composite_kernel(
 {
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (o.guard && blockIdx.x == 0 && threadIdx.x == 0) mvs_guard_consume(o.guard);
     if (ray >= N) return;                                   // wave-uniform
     const float* rr = raw + ray * S * 4;
     const float* zr = z + ray * S;
@@ -68,9 +69,19 @@ __global__ __launch_bounds__(256) void composite_kernel(
     }
 }
 
+int mvs_composite_fwd(const float* raw, const float* z, int64_t N, int S, int white_bkgd, float* rgb_map, float* disp, float* acc, float* weights,
+                      float* depth, float* alpha, int* guard, void* stream);
+
 extern "C" int mvsnerf_composite_fwd(const float* raw, const float* z, int64_t N, int S, int white_bkgd,
                                      float* rgb_map, float* disp, float* acc, float* weights,
                                      float* depth, float* alpha, void* stream)
+{
+    return mvs_composite_fwd(raw, z, N, S, white_bkgd, rgb_map, disp, acc, weights, depth, alpha, nullptr, stream);
+}
+
+// guard != NULL: the launch also ends a guarded 16-bit sequence (raymarch.hip)
+int mvs_composite_fwd(const float* raw, const float* z, int64_t N, int S, int white_bkgd, float* rgb_map, float* disp, float* acc, float* weights,
+                      float* depth, float* alpha, int* guard, void* stream)
 {
     if (!raw || !z || N < 0 || S < 1) return MVSNERF_EINVAL;
     if (!mvs_aligned16(raw)) return MVSNERF_EALIGN;
@@ -78,7 +89,7 @@ extern "C" int mvsnerf_composite_fwd(const float* raw, const float* z, int64_t N
     hipStream_t st = (hipStream_t)stream;
     const int chunk = (S + 63) / 64;
     const unsigned grid = mvs_cdiv(N, 4);
-const CompositeOut o{rgb_map, disp, acc, weights, depth, alpha, white_bkgd};
+    const CompositeOut o{rgb_map, disp, acc, weights, depth, alpha, white_bkgd, guard};
 #define MVS_COMP(C) composite_kernel<C><<<grid, 256, 0, st>>>(raw, z, N, S, chunk, o)
     switch (chunk) {
         case 1: MVS_COMP(1); break;

@@ -7,7 +7,15 @@
 
 struct CompositeOut {
     float* rgb_map; float* disp; float* acc_map; float* weights; float* depth_map; float* alpha_out; int white_bkgd;
+    int* guard;      // non-NULL: this launch ends a guarded 16-bit sequence - count a tripped guard and re-arm it (mvs_guard_consume)
 };
+
+// Last step of a guarded 16-bit sequence (include/mvsnerf_hip.h): by one thread of a kernel that is stream-ordered behind the predicated
+// fp32 kernels.  guard[0]: tripped (re-armed here), guard[1]: number of sequences that fell back so far.
+__device__ __forceinline__ void mvs_guard_consume(int* guard)
+{
+    if (guard[0]) { guard[1] += 1; guard[0] = 0; }
+}
 
 // lane l owns samples s0 = l*NR .. s0+NR-1 (values rv[i] = {r,g,b,sigma}; samples >= S are ignored), zr = z_vals of the ray
 template <int NR>

@@ -1,6 +1,8 @@
 // conv0 of CostRegNet (models.py:756: 3x3x3, stride 1, Cin = 32 + 3V -> 8 channels; 74.5 % of the encoder's FLOPs) with fp32-GRADE results from
-// the fp16 matrix cores: the two-piece operand split of mlp_f16x3.hip applied to the encoder's largest layer.  Opt-in
-// (`encoder.encoder_precision("fp16x3")`, inference); the default conv0 stays the fp32-MFMA kernel of conv_mfma.hip.
+// the fp16 matrix cores: the two-piece operand split of mlp_f16x3.hip applied to the encoder's largest layer.  conv0 of every no-grad encode
+// (`encoder.ENCODER_PRECISION = "auto"`) as a GUARDED sequence: a cost value or weight outside fp16's range sets the guard word and the fp32
+// plane sweep + fp32-MFMA conv0 of conv_mfma.hip, enqueued behind this kernel and predicated on that word, recompute the layer
+// (mvsnerf_sweep_conv0_guarded_fwd, encoder.hip).  `encoder_precision("fp16x3")` is the unguarded pair (saturating); gradients take fp32 kernels.
 //
 //     x = x0 + x1 (+ 2^-22 |x|),  x0 = fp16(x), x1 = fp16(x - x0);   w likewise;      x * w ~= x0*w0 + x0*w1 + x1*w0      (dropped: x1*w1 <= 2^-22 |x w|)
 //
@@ -46,7 +48,7 @@ constexpr int HBUF = HT_BYTES + 2 * HW_PIECES * 1024;           // 51200 B: thre
 
 __global__ __launch_bounds__(256, 3) void conv3d_k3s1_c8_f16x3_kernel(const _Float16* __restrict__ x16, int nblk16, int D, int H, int W,
                                                                      const _Float16* __restrict__ wq, float* __restrict__ out,
-                                                                     float* __restrict__ stats)
+                                                                     float* __restrict__ stats, int* __restrict__ guard)
 {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int nbx = (W + HTX - 1) / HTX, nby = (H + HTY - 1) / HTY;
@@ -55,6 +57,7 @@ __global__ __launch_bounds__(256, 3) void conv3d_k3s1_c8_f16x3_kernel(const _Flo
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = bx * HTX - 1, y0 = by * HTY - 1, z0 = bz * HTZ - 1;
     const int64_t nvox = (int64_t)D * H * W;
+    if (guard && blockIdx.x == 0 && tid == 0 && (float)wq[(int64_t)nblk16 * 7680] != 0.0f) guard[0] = 1;     // status word behind the weights: one was clamped at pack time
     // DMA slots of this lane: piece p = wave + 4 j holds tile voxels 32 p .. 32 p + 31, lane -> (voxel 32 p + lane / 2, half lane & 1)
     int goff[HT_SLOTS];                                          // byte offset inside a channel block, -1: zeros
 #pragma unroll
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(256) void conv0_pack_f16x3_kernel(const float* __re
         const int dz = p / 3, dx = p - 3 * dz;
         v = w[((int64_t)co * Cin + ci) * 27 + (dz * 3 + dy) * 3 + dx] * (float)(1 << W_SCALE_LOG2);
     }
+    if (!(fabsf(v) <= 65504.0f)) wq[(int64_t)nblk16 * 7680] = (_Float16)1.0f;      // status word (zeroed by the launcher): the guarded encode then always takes fp32
     v = fminf(fmaxf(v, -65504.0f), 65504.0f);
     const _Float16 hi = (_Float16)v;
     const int local = i - c * 3840;
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256) void conv0_pack_f16x3_kernel(const float* __re
 extern "C" size_t mvsnerf_conv0_f16x3_packed_elems(int Cin)
 {
     if (Cin < 1) return 0;
-    return (size_t)((Cin + 15) / 16) * 2 * 5 * 3 * 4 * 8 * 8;
+    return (size_t)((Cin + 15) / 16) * 2 * 5 * 3 * 4 * 8 * 8 + 8;          // + 8 status elements: [0] != 0 when a weight left fp16's range
 }
 
 extern "C" int mvsnerf_conv0_f16x3_pack(const float* w, int Cin, void* packed, void* stream)
@@ -215,12 +219,14 @@ extern "C" int mvsnerf_conv0_f16x3_pack(const float* w, int Cin, void* packed, v
     if (!w || !packed || Cin < 1) return MVSNERF_EINVAL;
     if (!mvs_aligned16(packed)) return MVSNERF_EALIGN;
     const int nblk = (Cin + 15) / 16;
+    hipError_t e = hipMemsetAsync(reinterpret_cast<_Float16*>(packed) + (size_t)nblk * 7680, 0, 8 * sizeof(_Float16), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
     conv0_pack_f16x3_kernel<<<mvs_cdiv((int64_t)nblk * 3840, 256), 256, 0, (hipStream_t)stream>>>(w, Cin, nblk, reinterpret_cast<_Float16*>(packed));
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
 
-extern "C" int mvsnerf_conv0_f16x3_fwd(const void* x16, int Cin, int D, int H, int W, const void* packed, float* out, float* stats_part, void* stream)
+int mvs_conv0_f16x3_fwd(const void* x16, int Cin, int D, int H, int W, const void* packed, float* out, float* stats_part, int* guard, hipStream_t st)
 {
     if (!x16 || !packed || !out || Cin < 1 || D < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
     if (!mvs_aligned16(x16) || !mvs_aligned16(packed)) return MVSNERF_EALIGN;
@@ -228,8 +234,13 @@ extern "C" int mvsnerf_conv0_f16x3_fwd(const void* x16, int Cin, int D, int H, i
     static unsigned long long cap_mask = 0;
     if (int rc = mvs_raise_lds_cap(reinterpret_cast<const void*>(conv3d_k3s1_c8_f16x3_kernel), HBUF, &cap_mask)) return rc;
     const int tiles = ((W + HTX - 1) / HTX) * ((H + HTY - 1) / HTY) * ((D + HTZ - 1) / HTZ);       // = mvsnerf_conv0_bf16_tiles(D, H, W): same tile, same statistics slots
-    conv3d_k3s1_c8_f16x3_kernel<<<tiles, 256, HBUF, (hipStream_t)stream>>>(
-        reinterpret_cast<const _Float16*>(x16), (Cin + 15) / 16, D, H, W, reinterpret_cast<const _Float16*>(packed), out, stats_part);
+    conv3d_k3s1_c8_f16x3_kernel<<<tiles, 256, HBUF, st>>>(
+        reinterpret_cast<const _Float16*>(x16), (Cin + 15) / 16, D, H, W, reinterpret_cast<const _Float16*>(packed), out, stats_part, guard);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
+}
+
+extern "C" int mvsnerf_conv0_f16x3_fwd(const void* x16, int Cin, int D, int H, int W, const void* packed, float* out, float* stats_part, void* stream)
+{
+    return mvs_conv0_f16x3_fwd(x16, Cin, D, H, W, packed, out, stats_part, nullptr, (hipStream_t)stream);
 }

@@ -337,9 +337,10 @@ __device__ __forceinline__ void mfma_chunk4(const float* __restrict__ wtile, con
 
 template <int CIN, int CREAL>
 __global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_mfma4_kernel(const float* __restrict__ x4, int D, int H, int W, const float* __restrict__ wq,
-                                                                     float* __restrict__ out, int swz, float* __restrict__ stats)
+                                                                     float* __restrict__ out, int swz, float* __restrict__ stats, const int* __restrict__ run_if)
 {
     static_assert(CIN % 4 == 0 && CREAL <= CIN && CREAL > CIN - 4, "chunks of four channels; only the last one may be partly padding");
+    if (run_if && *run_if == 0) return;                           // fp32 half of a guarded 16-bit sequence (include/mvsnerf_hip.h)
     constexpr int NCH = CIN / 4;
     __shared__ __attribute__((aligned(1024))) float lds4[2 * (T4_FLOATS + W4_FLOATS)];
     constexpr int BUF = T4_FLOATS + W4_FLOATS;                    // one (tile, weights) buffer; the two alternate
@@ -1069,11 +1070,12 @@ int mvs_conv3d_c8_wgrad4(const float* x4, int Cin, int cin_real, int D, int H, i
 // conv0 on a cost volume in channel blocks of four (mvsnerf_conv3d_c8_blocked_fwd)
 int mvs_conv3d_c8_mfma4_tiles(int D, int H, int W) { return ((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ); }
 
-int mvs_conv3d_c8_mfma4(const float* x4, int Cin, int cin_real, int D, int H, int W, const float* wq, float* out, int xcd, float* stats, hipStream_t st)
+int mvs_conv3d_c8_mfma4(const float* x4, int Cin, int cin_real, int D, int H, int W, const float* wq, float* out, int xcd, float* stats, hipStream_t st,
+                        const int* run_if)
 {
     if ((int64_t)D * H * W * 4 >= (int64_t)1 << 31) return MVSNERF_EUNSUPPORTED;
     const unsigned grid = (unsigned)(((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ));
-#define MVS_L4(CIN, CREAL) case CIN * 100 + CREAL: conv3d_k3s1_c8_mfma4_kernel<CIN, CREAL><<<grid, 256, 0, st>>>(x4, D, H, W, wq, out, xcd, stats); break
+#define MVS_L4(CIN, CREAL) case CIN * 100 + CREAL: conv3d_k3s1_c8_mfma4_kernel<CIN, CREAL><<<grid, 256, 0, st>>>(x4, D, H, W, wq, out, xcd, stats, run_if); break
     switch (Cin * 100 + cin_real) {
         MVS_L4(32, 32); MVS_L4(36, 35); MVS_L4(40, 38); MVS_L4(44, 41); MVS_L4(44, 44); MVS_L4(48, 47); MVS_L4(52, 50); MVS_L4(56, 53); MVS_L4(56, 56);
         default: return MVSNERF_EUNSUPPORTED;

@@ -93,8 +93,11 @@ __global__ __launch_bounds__(64) void planesweep_kernel(
     int V, int H, int W, int D, int pad,
     float* __restrict__ cost, int CP,   // [D][Hp][Wp][CP]
     float* __restrict__ masks,          // with img: [V][D][Hp][Wp] per-view; else [D][Hp][Wp] count
-    int with_img, int blocked)          // blocked 1: cost[CP/4][D*Hp*Wp][4] (channel blocks of four, see mvsnerf_planesweep_costvar_blocked_fwd);
+    int with_img, int blocked,          // blocked 1: cost[CP/4][D*Hp*Wp][4] (channel blocks of four, see mvsnerf_planesweep_costvar_blocked_fwd);
                                         // 2: bf16 in channel blocks of sixteen, cost16[ceil(CP/16)][D*Hp*Wp][16] (mvsnerf_planesweep_costvar_bf16_fwd)
+                                        // 3: two fp16 pieces of x / 16 in that layout (mvsnerf_planesweep_costvar_f16x2_fwd)
+    int* __restrict__ guard,            // blocked 3 in a guarded sequence (include/mvsnerf_hip.h): guard[0] = 1 when a value did not fit an fp16 piece
+    const int* __restrict__ run_if)     // fp32 half of a guarded sequence: the launch does its work only when *run_if != 0
 {
     // fp32 arithmetic of the CPU reference path, operation for operation (scratch/r3/cpu_arith_probe.py, cpu_var_probe.py compare candidate
     // formulas with reference-generated fixtures BIT FOR BIT): the projection is a k-ordered fma chain (sgemm), grid_sample's blend is
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(64) void planesweep_kernel(
     // (x**2, +, *count, -): no contraction anywhere else.
 #pragma clang fp contract(off)
     static_assert(C == 32, "lane q owns float4 numbers q and q + 4 of a 32-channel pixel");
+    if (run_if && *run_if == 0) return;
     constexpr int NC = 64 / NP, VPB = 64;                        // columns x depth planes of a workgroup = one wave
     extern __shared__ __attribute__((aligned(16))) float lds_[];
     // per voxel: per source view {w_nw,w_ne,w_sw,w_se, t_nw,t_ne,t_sw,t_se}; then {1/count, ref pixel}.  Row strides in floats with
@@ -313,12 +317,16 @@ __global__ __launch_bounds__(64) void planesweep_kernel(
                     const int cb = k / per, rem = k - cb * per, vox = rem >> 1, c0 = cb * 16 + (rem & 1) * 8;
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + vox * RS + c0), hi = *reinterpret_cast<const f32x4*>(stage + vox * RS + c0 + 4);
                     f16x8_t h0, h1;
+                    float big = 0.0f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float v = fminf(fmaxf((e < 4 ? lo[e] : hi[e - 4]) * 0.0625f, -65504.0f), 65504.0f);
+                        const float x = (e < 4 ? lo[e] : hi[e - 4]) * 0.0625f;
+                        big = fmaxf(big, fabsf(x));
+                        const float v = fminf(fmaxf(x, -65504.0f), 65504.0f);
                         const _Float16 a = (_Float16)v;
                         h0[e] = a; h1[e] = (_Float16)(v - (float)a);
                     }
+                    if (guard && big > 65504.0f) guard[0] = 1;          // saturated: the fp32 sweep + conv0 behind this launch take over
                     const int64_t at = (((int64_t)cb * nvox + p0 + vox) << 4) + (rem & 1) * 8;
                     *reinterpret_cast<f16x8_t*>(cost16 + at) = h0;
                     *reinterpret_cast<f16x8_t*>(cost16 + lo_plane + at) = h1;
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(64) void planesweep_kernel(
 
 static int planesweep_launch(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,
                              int V, int C, int H, int W, int D, int pad, float* cost, int CP, float* masks,
-                             int with_img, int blocked, void* stream);
+                             int with_img, int blocked, void* stream, int* guard = nullptr, const int* run_if = nullptr);
 
 extern "C" int mvsnerf_planesweep_costvar_fwd(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,
                                               int V, int C, int H, int W, int D, int pad, float* cost, int CP, float* masks,
@@ -377,7 +385,7 @@ extern "C" int mvsnerf_planesweep_costvar_f16x2_fwd(const float* feats_cl, const
 
 static int planesweep_launch(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,
                              int V, int C, int H, int W, int D, int pad, float* cost, int CP, float* masks,
-                             int with_img, int blocked, void* stream)
+                             int with_img, int blocked, void* stream, int* guard, const int* run_if)
 {
     if (!feats_cl || !proj || !depth || !cost || !masks || V < 1 || H < 2 || W < 2 || D < 1 || pad < 0) return MVSNERF_EINVAL;
     if (with_img && !imgs_cl) return MVSNERF_EINVAL;
@@ -397,7 +405,7 @@ static int planesweep_launch(const float* feats_cl, const float* imgs_cl, const 
         if (rc != MVSNERF_OK) return rc;
     }
     const int CPS = (RB * Wp + 15) / 16;
-    planesweep_kernel<32, 4><<<(unsigned)(8 * ((D + 3) / 4) * CPS), 64, lds, (hipStream_t)stream>>>(feats_cl, imgs_cl, proj, depth, V, H, W, D, pad, cost, CP, masks, with_img, blocked);
+    planesweep_kernel<32, 4><<<(unsigned)(8 * ((D + 3) / 4) * CPS), 64, lds, (hipStream_t)stream>>>(feats_cl, imgs_cl, proj, depth, V, H, W, D, pad, cost, CP, masks, with_img, blocked, guard, run_if);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
@@ -822,7 +830,8 @@ extern "C" int mvsnerf_conv3d_fwd_stats(const float* x1, const float* scale1, co
     return MVSNERF_OK;
 }
 
-int mvs_conv3d_c8_mfma4(const float* x4, int Cin, int cin_real, int D, int H, int W, const float* wq, float* out, int xcd, float* stats, hipStream_t st);
+int mvs_conv3d_c8_mfma4(const float* x4, int Cin, int cin_real, int D, int H, int W, const float* wq, float* out, int xcd, float* stats, hipStream_t st,
+                        const int* run_if = nullptr);
 int mvs_conv3d_c8_mfma4_tiles(int D, int H, int W);
 int mvs_conv_w4_repack(const float* wpacked, float* wq, int Cin, hipStream_t st);
 
@@ -952,8 +961,9 @@ extern "C" int mvsnerf_conv_transpose3d_fwd(const float* x1, const float* scale1
 // and updates running_mean / running_var (momentum, unbiased variance) like F.batch_norm does.
 // ---------------------------------------------------------------------------------------------
 template <int C>
-__global__ __launch_bounds__(256) void abn_partial_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ part)
+__global__ __launch_bounds__(256) void abn_partial_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ part, const int* __restrict__ run_if = nullptr)
 {
+    if (run_if && *run_if == 0) return;                          // fp32 half of a guarded sequence (mvsnerf_sweep_conv0_guarded_fwd)
     // thread t handles channel group (t % (C/4)) of voxels t / (C/4) + k*stride  -> float4 loads, fully coalesced
     constexpr int G = C / 4;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1072,6 +1082,47 @@ extern "C" int mvsnerf_abn_finalize(const float* part, int n_blocks, int C, int6
                                                             mean_out, invstd_out);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
+}
+
+// ---- guarded scene-encode head (include/mvsnerf_hip.h "guarded 16-bit sequences"): models.py:839-893 + conv0 of :756
+int mvs_conv0_f16x3_fwd(const void* x16, int Cin, int D, int H, int W, const void* packed, float* out, float* stats_part, int* guard, hipStream_t st);   // conv_f16x3.hip
+
+__global__ void guard_consume_kernel(int* guard)
+{
+    if (guard[0]) { guard[1] += 1; guard[0] = 0; }
+}
+
+// for entries outside this file (raymarch.hip)
+int mvs_guard_consume(int* guard, hipStream_t st)
+{
+    guard_consume_kernel<<<1, 1, 0, st>>>(guard);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+extern "C" int mvsnerf_sweep_conv0_guarded_fwd(const mvsnerf_sweep_conv0_args* a, void* stream)
+{
+    if (!a || !a->guard || !a->cost16x2 || !a->cost32 || !a->w_f16x3 || !a->w_c8 || !a->out || !a->imgs_cl) return MVSNERF_EINVAL;
+    if (a->Cin != 3 * a->V + 32 || a->CP != ((a->Cin + 3) & ~3)) return MVSNERF_EINVAL;
+    if (!mvs_aligned16(a->cost32) || !mvs_aligned16(a->out) || !mvs_aligned16(a->w_c8)) return MVSNERF_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const int Hp = a->H + 2 * a->pad, Wp = a->W + 2 * a->pad;
+    int rc;
+    // 1. the fp16 pair; both report through guard[0]
+    if ((rc = planesweep_launch(a->feats_cl, a->imgs_cl, a->proj, a->depth, a->V, 32, a->H, a->W, a->D, a->pad, reinterpret_cast<float*>(a->cost16x2), a->CP,
+                                a->masks, 1, 3, stream, a->guard, nullptr))) return rc;
+    if ((rc = mvs_conv0_f16x3_fwd(a->cost16x2, a->Cin, a->D, Hp, Wp, a->w_f16x3, a->out, a->stats_part, a->guard, st))) return rc;
+    // 2. the fp32 pair, predicated on guard[0]: same masks, same output, the statistics in the fp16 kernel's slots
+    if ((rc = planesweep_launch(a->feats_cl, a->imgs_cl, a->proj, a->depth, a->V, 32, a->H, a->W, a->D, a->pad, a->cost32, a->CP,
+                                a->masks, 1, 1, stream, nullptr, a->guard))) return rc;
+    if ((rc = mvs_conv3d_c8_mfma4(a->cost32, a->CP, a->Cin, a->D, Hp, Wp, a->w_c8, a->out, g_conv_xcd, nullptr, st, a->guard))) return rc;
+    if (a->stats_part) {
+        const int slots = ((Wp + 15) / 16) * ((Hp + 7) / 8) * ((a->D + 3) / 4);           // mvsnerf_conv0_bf16_tiles(D, Hp, Wp)
+        abn_partial_kernel<8><<<slots, 256, 0, st>>>(a->out, (int64_t)a->D * Hp * Wp, a->stats_part, a->guard);
+        MVS_LAUNCH_CHECK();
+    }
+    // 3. count the event, re-arm
+    return mvs_guard_consume(a->guard, st);
 }
 
 // out = leaky(x1*scale1+shift1) [+ leaky(x2*scale2+shift2)]  (materialises an activated tensor, e.g. the final

@@ -228,8 +228,11 @@ template <bool ALPHA_ONLY, bool SAVE>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
     const float* __restrict__ packed, int F, const float* __restrict__ ndc, int ndc_stride,
     const float* __restrict__ feat, int feat_stride, const float* __restrict__ dirs, int dirs_stride,
-    int64_t P, int S, float* __restrict__ raw, float* __restrict__ saved, long long* __restrict__ census)
+    int64_t P, int S, float* __restrict__ raw, float* __restrict__ saved, long long* __restrict__ census, const int* __restrict__ run_if)
 {
+    // second half of a guarded 16-bit sequence (include/mvsnerf_hip.h): launched behind the fp16x3 kernel, does its work only when that kernel
+    // reported a value outside fp16's range (wave-uniform scalar load; 1024 workgroups that leave at once cost ~2 us of an untripped batch)
+    if (run_if && *run_if == 0) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     long long t_start = 0, c_start = 0;
     if (census) { t_start = wall_clock64(); c_start = __builtin_amdgcn_s_memtime(); }
@@ -405,12 +408,13 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
 
 template <bool AO, bool SAVE>
 static int launch_mlp_pipe(const float* packed, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
-                           const float* dirs, int dirs_stride, int64_t P, int S, float* raw, hipStream_t st, float* saved = nullptr, long long* census = nullptr)
+                           const float* dirs, int dirs_stride, int64_t P, int S, float* raw, hipStream_t st, float* saved = nullptr, long long* census = nullptr,
+                           const int* run_if = nullptr)
 {
     const size_t lds_bytes = PIPE_LDS_FLOATS * sizeof(float);
     static unsigned long long lds_cap_set = 0;          // per-device bit mask (common.h)
     if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_pipe_kernel<AO, SAVE>), (int)lds_bytes, &lds_cap_set)) return rc_;
-    mlp_fwd_pipe_kernel<AO, SAVE><<<mvs_cdiv(P, 128), 256, lds_bytes, st>>>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, saved, census);
+    mlp_fwd_pipe_kernel<AO, SAVE><<<mvs_cdiv(P, 128), 256, lds_bytes, st>>>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, saved, census, run_if);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
@@ -419,7 +423,8 @@ static int launch_mlp_pipe(const float* packed, int F, const float* ndc, int ndc
 // launch, whose 2048 waves hide the lookup latency that every workgroup's first GEMM would otherwise wait for - and are not built.)
 
 static int mlp_fwd_checked(const float* packed, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
-                           const float* dirs, int dirs_stride, int64_t N, int S, int alpha_only, float* raw, void* stream, long long* census)
+                           const float* dirs, int dirs_stride, int64_t N, int S, int alpha_only, float* raw, void* stream, long long* census,
+                           const int* run_if = nullptr)
 {
     if (!packed || !ndc || !feat || !raw || N < 0 || S < 1 || feat_stride < F || ndc_stride < 3) return MVSNERF_EINVAL;
     if (!alpha_only && dirs_stride < 3) return MVSNERF_EINVAL;
@@ -429,8 +434,15 @@ static int mlp_fwd_checked(const float* packed, int F, const float* ndc, int ndc
     const int64_t P = N * S;
     if (P == 0) return MVSNERF_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (alpha_only) return launch_mlp_pipe<true, false>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, st, nullptr, census);
-    return launch_mlp_pipe<false, false>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, st, nullptr, census);
+    if (alpha_only) return launch_mlp_pipe<true, false>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, st, nullptr, census, run_if);
+    return launch_mlp_pipe<false, false>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, st, nullptr, census, run_if);
+}
+
+// mvsnerf_mlp_fwd predicated on a guard word (raymarch.hip: the fp32 re-run of a guarded fp16x3 batch)
+int mvs_mlp_fwd_if(const float* packed, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
+                   const float* dirs, int dirs_stride, int64_t N, int S, int alpha_only, float* raw, const int* run_if, void* stream)
+{
+    return mlp_fwd_checked(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, N, S, alpha_only, raw, stream, nullptr, run_if);
 }
 
 extern "C" int mvsnerf_mlp_fwd(const float* packed, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,

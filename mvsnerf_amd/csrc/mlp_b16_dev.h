@@ -71,4 +71,4 @@ __device__ __forceinline__ float pe_op(int t, int half, float px, float py, floa
 size_t mvs_mlp_f16x3_elems(int F);
 int mvs_mlp_f16x3_pack(const float* const w[11], int F, void* packed, hipStream_t st);
 int mvs_mlp_f16x3_fwd(const void* packed_h, const float* packed_f32, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
-                      const float* dirs, int dirs_stride, int64_t P, int S, int alpha_only, float* raw, hipStream_t st);
+                      const float* dirs, int dirs_stride, int64_t P, int S, int alpha_only, float* raw, hipStream_t st, int* guard = nullptr);

@@ -1,5 +1,8 @@
 // "fp16x3": fp32-grade results of the fused Embedder + Renderer_ours forward (models.py:145-222) from THREE v_mfma_f32_32x32x16_f16 per
-// product.  Opt-in, inference only (ops.set_mlp_precision("fp16x3")); the fp32-MFMA kernel of mlp.hip stays the default and the headline.
+// product.  Inference only.  What a no-grad rendering() runs by default (ops.MLP_PRECISION = "auto") as a GUARDED sequence: the kernel reports
+// every value that left fp16's range through the guard word and the fp32-MFMA kernel of mlp.hip, enqueued right behind it and predicated on that
+// word, recomputes the batch (include/mvsnerf_hip.h, "guarded 16-bit sequences").  ops.set_mlp_precision("fp16x3") is the unguarded kernel alone
+// (saturating); the headline of bench.py stays on the fp32-MFMA kernel.
 //
 // Every fp32 operand is written as the sum of two fp16 pieces, both rounded to nearest:
 //     a = a0 + a1 + r,   a0 = fp16(a),  a1 = fp16(a - a0),   |r| <= 2^-22 |a|      (fp16 carries 11 significant bits; a - a0 is exact)
@@ -36,6 +39,7 @@ constexpr int H3_LDS_BYTES = 2 * H3_BUF_BYTES + V_TOTAL * 4;
 constexpr int LOG2_SA = 0, LOG2_SW = 0;                              // operand scales 2^LOG2_SA (activations), 2^LOG2_SW (weights)
 constexpr float SA = (float)(1 << LOG2_SA), SW = (float)(1 << LOG2_SW);
 constexpr float H_MAX = 65504.0f;                                    // largest finite fp16
+constexpr int H3_TAIL = 8;                                           // status elements behind the packed weights (16 bytes); [0] != 0: a weight was clamped
 
 // packed buffer (fp16 elements), in the order the kernel streams it; every slab = [hi plane | lo plane] of its segment(s)
 struct LayoutH { size_t s0, l1, l5a, l5b, feat, views, total; int fsteps; };
@@ -50,13 +54,13 @@ __host__ __device__ inline LayoutH layout_h(int F)
     L.l5b = o;   o += 2 * b_seg(B_ACT_STEPS, 4);
     L.feat = o;  o += 2 * b_seg(B_ACT_STEPS, 4);
     L.views = o; o += 2 * b_seg(B_VIEW_STEPS, 2);
-    L.total = o;
+    L.total = o;                                                    // followed by H3_TAIL status elements (pack: "a weight was clamped")
     return L;
 }
 
 // one segment: hi plane at dst[0 .. n), lo plane at dst[n .. 2n), n = steps * nb * 512; element order of a plane = pack_b_segment's
 __device__ inline void pack_h_planes(_Float16* __restrict__ dst, const float* __restrict__ W, int ld, int col_off, int kmap,
-                                     int steps, int nb, int F, int tid, int nthreads)
+                                     int steps, int nb, int F, int tid, int nthreads, _Float16* __restrict__ clamped)
 {
     const int n = steps * nb * 64 * 8;
     for (int i = tid; i < n; i += nthreads) {
@@ -65,6 +69,7 @@ __device__ inline void pack_h_planes(_Float16* __restrict__ dst, const float* __
         const int col = b_col(kmap, 8 * s + j, lane >> 5, F);
         const int row = b * 32 + (lane & 31);
         float w = col < 0 ? 0.0f : W[(size_t)row * ld + col_off + col] * SW;
+        if (!(fabsf(w) <= H_MAX)) *clamped = (_Float16)1.0f;             // outside fp16's range (or NaN): the guarded sequence then always takes the fp32 kernel
         w = fminf(fmaxf(w, -H_MAX), H_MAX);
         const _Float16 hi = (_Float16)w;
         dst[i] = hi;
@@ -77,13 +82,13 @@ __global__ __launch_bounds__(256) void mlp_pack_h3_kernel(PackBArgs a, _Float16*
     const LayoutH L = layout_h(a.F);
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
     const size_t act = 2 * b_seg(B_ACT_STEPS, 4);
-    pack_h_planes(packed + L.s0, a.w[6], a.F, 0, K_FEAT, L.fsteps, 4, a.F, tid, nt);
-    pack_h_planes(packed + L.s0 + 2 * b_seg(L.fsteps, 4), a.w[0], PE_DIM, 0, K_PE, B_PE_STEPS, 4, a.F, tid, nt);
-    for (int l = 1; l <= 4; ++l) pack_h_planes(packed + L.l1 + (l - 1) * act, a.w[l], WIDTH, 0, K_ACT, B_ACT_STEPS, 4, a.F, tid, nt);
-    pack_h_planes(packed + L.l5a, a.w[5], WIDTH + PE_DIM, 0, K_PE, B_PE_STEPS, 4, a.F, tid, nt);
-    pack_h_planes(packed + L.l5b, a.w[5], WIDTH + PE_DIM, PE_DIM, K_ACT, B_ACT_STEPS, 4, a.F, tid, nt);
-    pack_h_planes(packed + L.feat, a.w[7], WIDTH, 0, K_ACT, B_ACT_STEPS, 4, a.F, tid, nt);
-    pack_h_planes(packed + L.views, a.w[9], WIDTH + 3, 0, K_VIEWS, B_VIEW_STEPS, 2, a.F, tid, nt);
+    pack_h_planes(packed + L.s0, a.w[6], a.F, 0, K_FEAT, L.fsteps, 4, a.F, tid, nt, packed + L.total);
+    pack_h_planes(packed + L.s0 + 2 * b_seg(L.fsteps, 4), a.w[0], PE_DIM, 0, K_PE, B_PE_STEPS, 4, a.F, tid, nt, packed + L.total);
+    for (int l = 1; l <= 4; ++l) pack_h_planes(packed + L.l1 + (l - 1) * act, a.w[l], WIDTH, 0, K_ACT, B_ACT_STEPS, 4, a.F, tid, nt, packed + L.total);
+    pack_h_planes(packed + L.l5a, a.w[5], WIDTH + PE_DIM, 0, K_PE, B_PE_STEPS, 4, a.F, tid, nt, packed + L.total);
+    pack_h_planes(packed + L.l5b, a.w[5], WIDTH + PE_DIM, PE_DIM, K_ACT, B_ACT_STEPS, 4, a.F, tid, nt, packed + L.total);
+    pack_h_planes(packed + L.feat, a.w[7], WIDTH, 0, K_ACT, B_ACT_STEPS, 4, a.F, tid, nt, packed + L.total);
+    pack_h_planes(packed + L.views, a.w[9], WIDTH + 3, 0, K_VIEWS, B_VIEW_STEPS, 2, a.F, tid, nt, packed + L.total);
 }
 
 // ------------------------------------------------------------------------------------------ kernel
@@ -155,7 +160,7 @@ template <bool ALPHA_ONLY>
 __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
     const _Float16* __restrict__ wq, const float* __restrict__ packed_f32, int F, const float* __restrict__ ndc, int ndc_stride,
     const float* __restrict__ feat, int feat_stride, const float* __restrict__ dirs, int dirs_stride,
-    int64_t P, int S, float* __restrict__ raw)
+    int64_t P, int S, float* __restrict__ raw, int* __restrict__ guard)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_h[];
     char* buf0 = lds_h;
@@ -192,6 +197,17 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
 #pragma unroll
         for (int i = 0; i < 24; ++i) fv[i] = i < F / 2 ? fp[i] * SA : 0.0f;
     }
+    // guard: the largest magnitude this lane hands to an fp16 split (features; layer outputs before their clamp).  Positions and view directions
+    // are bounded by construction.  Reported once, at the end (guard != NULL: the caller enqueues the fp32 kernel behind this one, predicated on it).
+    float gmax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) gmax = fmaxf(gmax, fabsf(fv[i]));
+    auto report = [&]() {
+        if (guard) {
+            if (gmax > H_MAX) guard[0] = 1;
+            if (blockIdx.x == 0 && tid == 0 && (float)wq[L.total] != 0.0f) guard[0] = 1;      // a weight was clamped at pack time
+        }
+    };
     HL pe[B_PE_STEPS];                            // positional-encoding operands (reused by layer 5)
 #pragma unroll
     for (int s = 0; s < B_PE_STEPS; ++s) {
@@ -217,7 +233,9 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int q = 8 * s + j;
-                v8[j] = __builtin_amdgcn_fmed3f(acc[q >> 4][q & 15] * bias[q], 0.0f, H_MAX);
+                const float x = acc[q >> 4][q & 15] * bias[q];
+                gmax = fmaxf(gmax, x);
+                v8[j] = __builtin_amdgcn_fmed3f(x, 0.0f, H_MAX);
             }
             put(s, v8);
         }
@@ -287,7 +305,9 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int q = 8 * s + j;
-                v8[j] = __builtin_amdgcn_fmed3f(acc[q >> 4][q & 15] * bias[q], 0.0f, H_MAX);
+                const float x = acc[q >> 4][q & 15] * bias[q];
+                gmax = fmaxf(gmax, x);
+                v8[j] = __builtin_amdgcn_fmed3f(x, 0.0f, H_MAX);
                 part = fmaf(wa[q], v8[j], part);
             }
             if (!ALPHA_ONLY) put(s, v8);
@@ -298,6 +318,7 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
     }
     if (ALPHA_ONLY) {
         if (live && half == 0) raw[p_raw] = sigma;
+        report();
         return;
     }
     {   // feature_linear (buf1, no activation), then views -> buf0
@@ -314,11 +335,14 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int q = 8 * s + j;
-                v8[j] = __builtin_amdgcn_fmed3f(acc[q >> 4][q & 15] * (1.0f / SW), -H_MAX, H_MAX);
+                const float x = acc[q >> 4][q & 15] * (1.0f / SW);
+                gmax = fmaxf(gmax, fabsf(x));
+                v8[j] = __builtin_amdgcn_fmed3f(x, -H_MAX, H_MAX);
             }
             put(s, v8);
         }
     }
+    report();
     {   // views_linears[0] + rgb head
         const int64_t ray = p / S;
         float dl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -349,20 +373,22 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
 }  // namespace
 
 // internal entries behind mvsnerf_mlp_{packed_split_elems, pack_split, fwd_split}(n_split = MVSNERF_SPLIT_FP16) in mlp_bf16.hip
-size_t mvs_mlp_f16x3_elems(int F) { return layout_h(F).total; }
+size_t mvs_mlp_f16x3_elems(int F) { return layout_h(F).total + H3_TAIL; }
 
 int mvs_mlp_f16x3_pack(const float* const w[11], int F, void* packed, hipStream_t st)
 {
     PackBArgs a;
     for (int i = 0; i < 11; ++i) { if (!w[i]) return MVSNERF_EINVAL; a.w[i] = w[i]; }
     a.F = F;
+    hipError_t e = hipMemsetAsync(reinterpret_cast<_Float16*>(packed) + layout_h(F).total, 0, H3_TAIL * sizeof(_Float16), st);      // status: nothing clamped
+    if (e != hipSuccess) return (int)e;
     mlp_pack_h3_kernel<<<64, 256, 0, st>>>(a, reinterpret_cast<_Float16*>(packed));
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
 
 int mvs_mlp_f16x3_fwd(const void* packed_h, const float* packed_f32, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
-                      const float* dirs, int dirs_stride, int64_t P, int S, int alpha_only, float* raw, hipStream_t st)
+                      const float* dirs, int dirs_stride, int64_t P, int S, int alpha_only, float* raw, hipStream_t st, int* guard)
 {
     static unsigned long long cap_a = 0, cap_b = 0;         // per-device bit masks (common.h)
     if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_f16x3_kernel<false>), H3_LDS_BYTES, &cap_a)) return rc_;
@@ -370,9 +396,9 @@ int mvs_mlp_f16x3_fwd(const void* packed_h, const float* packed_f32, int F, cons
     const _Float16* wq = reinterpret_cast<const _Float16*>(packed_h);
     const unsigned grid = mvs_cdiv(P, 32 * H3_WAVES);
     if (alpha_only)
-        mlp_fwd_f16x3_kernel<true><<<grid, H3_THREADS, H3_LDS_BYTES, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
+        mlp_fwd_f16x3_kernel<true><<<grid, H3_THREADS, H3_LDS_BYTES, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, guard);
     else
-        mlp_fwd_f16x3_kernel<false><<<grid, H3_THREADS, H3_LDS_BYTES, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
+        mlp_fwd_f16x3_kernel<false><<<grid, H3_THREADS, H3_LDS_BYTES, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, guard);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }

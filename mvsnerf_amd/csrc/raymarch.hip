@@ -3,7 +3,38 @@
 // ATen launches).
 #include "common.h"
 
-extern "C" int mvsnerf_abi_version(void) { return 9; }
+extern "C" int mvsnerf_abi_version(void) { return 10; }
+
+// internal pieces of the guarded 16-bit sequences (include/mvsnerf_hip.h)
+int mvs_mlp_f16x3_fwd(const void* packed_h, const float* packed_f32, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
+                      const float* dirs, int dirs_stride, int64_t P, int S, int alpha_only, float* raw, hipStream_t st, int* guard);                       // mlp_f16x3.hip
+int mvs_mlp_fwd_if(const float* packed, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
+                   const float* dirs, int dirs_stride, int64_t N, int S, int alpha_only, float* raw, const int* run_if, void* stream);                      // mlp.hip
+int mvs_composite_fwd(const float* raw, const float* z, int64_t N, int S, int white_bkgd, float* rgb_map, float* disp, float* acc, float* weights,
+                      float* depth, float* alpha, int* guard, void* stream);                                                                               // composite.hip
+int mvs_guard_consume(int* guard, hipStream_t st);                                                                                                         // encoder.hip
+
+// fp16x3 kernel reporting through guard[0], then the fp32-MFMA kernel predicated on it (same inputs, same output buffer)
+static int mlp_guarded_pair(const void* packed_h, const float* packed_f32, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,
+                            const float* dirs, int dirs_stride, int64_t N, int S, int alpha_only, float* raw, int* guard, void* stream)
+{
+    if (!packed_h || !packed_f32 || !ndc || !feat || !raw || !guard || N < 0 || S < 1 || feat_stride < F || ndc_stride < 3) return MVSNERF_EINVAL;
+    if (!alpha_only && (!dirs || dirs_stride < 3)) return MVSNERF_EINVAL;
+    if (F < 2 || F > 40 || (F & 1)) return MVSNERF_EUNSUPPORTED;
+    if (!mvs_aligned16(packed_h) || !mvs_aligned16(packed_f32) || !mvs_aligned16(raw)) return MVSNERF_EALIGN;
+    if (N * S == 0) return MVSNERF_OK;
+    if (int rc = mvs_mlp_f16x3_fwd(packed_h, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, N * S, S, alpha_only, raw, (hipStream_t)stream, guard)) return rc;
+    return mvs_mlp_fwd_if(packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, N, S, alpha_only, raw, guard, stream);
+}
+
+extern "C" int mvsnerf_mlp_fwd_guarded(const void* packed_fp16, const float* packed_f32, int F, const float* ndc, int ndc_stride,
+                                       const float* feat, int feat_stride, const float* dirs, int dirs_stride,
+                                       int64_t N, int S, int alpha_only, float* raw, int* guard, void* stream)
+{
+    if (int rc = mlp_guarded_pair(packed_fp16, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, N, S, alpha_only, raw, guard, stream)) return rc;
+    if (N * S == 0) return MVSNERF_OK;
+    return mvs_guard_consume(guard, (hipStream_t)stream);
+}
 
 extern "C" int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream)
 {
@@ -27,15 +58,20 @@ extern "C" int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream
         if ((rc = mvsnerf_color_sample_fwd(a->imgs, a->V, a->IH, a->IW, a->w2c, a->K, a->rays_pts, P, 1, a->input_feat + 8, F, stream))) return rc;
     }
     // network_query_fn (renderer.py:156 -> run_network_mvs 42-63)
-    if (a->packed_mlp_split)
+    const bool guarded = a->guard && a->packed_mlp_split && a->n_split == MVSNERF_SPLIT_FP16;
+    if (a->guard && !guarded) return MVSNERF_EINVAL;
+    if (guarded)
+        rc = mlp_guarded_pair(a->packed_mlp_split, a->packed_mlp, F, a->rays_ndc, 3, a->input_feat, F, a->dirs_tmp, 3, a->N, a->S, 0, a->raw, a->guard, stream);
+    else if (a->packed_mlp_split)
         rc = mvsnerf_mlp_fwd_split(a->packed_mlp_split, a->packed_mlp, F, a->n_split, a->rays_ndc, 3, a->input_feat, F, a->dirs_tmp, 3, a->N, a->S, 0, a->raw, stream);
     else if (a->packed_mlp_bf16)
         rc = mvsnerf_mlp_fwd_bf16(a->packed_mlp_bf16, a->packed_mlp, F, a->rays_ndc, 3, a->input_feat, F, a->dirs_tmp, 3, a->N, a->S, 0, a->raw, stream);
     else
         rc = mvsnerf_mlp_fwd(a->packed_mlp, F, a->rays_ndc, 3, a->input_feat, F, a->dirs_tmp, 3, a->N, a->S, 0, a->raw, stream);
     if (rc) return rc;
-    // raw2outputs (renderer.py:162)
-    return mvsnerf_composite_fwd(a->raw, a->z_vals, a->N, a->S, a->white_bkgd, a->rgb_map, a->disp, a->acc, a->weights, a->depth, a->alpha, stream);
+    // raw2outputs (renderer.py:162); in a guarded sequence the same launch counts a fallback and re-arms the guard
+    return mvs_composite_fwd(a->raw, a->z_vals, a->N, a->S, a->white_bkgd, a->rgb_map, a->disp, a->acc, a->weights, a->depth, a->alpha,
+                             guarded && P > 0 ? a->guard : nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -71,6 +107,8 @@ extern "C" int mvsnerf_render_pixels_fwd(const mvsnerf_render_args* a, void* str
     if (a->first_pixel + a->n_pixels > (int64_t)a->W_img * a->H_img) return MVSNERF_EINVAL;
     if (a->workspace_floats < render_ws_floats(a->batch_rays, a->S, a->V)) return MVSNERF_EINVAL;
     const int F = 8 + 4 * a->V, S = a->S;
+    const bool guarded = a->guard && a->packed_mlp_split && a->n_split == MVSNERF_SPLIT_FP16;
+    if (a->guard && !guarded) return MVSNERF_EINVAL;
     const int64_t B = a->batch_rays, P = B * S;
     auto r4 = [](int64_t n) { return (n + 3) & ~(int64_t)3; };
     float* pts = a->workspace;
@@ -87,15 +125,18 @@ extern "C" int mvsnerf_render_pixels_fwd(const mvsnerf_render_args* a, void* str
                                      a->near_far_tgt, a->near_far_ref, a->pad, a->lindisp, nullptr, n, S, pts, rdir, ndc, z, nullptr, stream))) return rc;
         if ((rc = mvsnerf_gather_fwd(a->vol, a->D, a->H, a->W, a->imgs_nhwc4, a->V, a->IH, a->IW, a->w2c, a->K, pts, ndc, n, S, rdir,
                                      feat, F, dirs, stream))) return rc;
-        if (a->packed_mlp_split)
+        if (guarded)
+            rc = mlp_guarded_pair(a->packed_mlp_split, a->packed_mlp, F, ndc, 3, feat, F, dirs, 3, n, S, 0, raw, a->guard, stream);
+        else if (a->packed_mlp_split)
             rc = mvsnerf_mlp_fwd_split(a->packed_mlp_split, a->packed_mlp, F, a->n_split, ndc, 3, feat, F, dirs, 3, n, S, 0, raw, stream);
         else if (a->packed_mlp_bf16)
             rc = mvsnerf_mlp_fwd_bf16(a->packed_mlp_bf16, a->packed_mlp, F, ndc, 3, feat, F, dirs, 3, n, S, 0, raw, stream);
         else
             rc = mvsnerf_mlp_fwd(a->packed_mlp, F, ndc, 3, feat, F, dirs, 3, n, S, 0, raw, stream);
         if (rc) return rc;
-        if ((rc = mvsnerf_composite_fwd(raw, z, n, S, a->white_bkgd, a->rgb + off * 3, a->disp ? a->disp + off : nullptr,
-                                        a->acc ? a->acc + off : nullptr, nullptr, a->depth ? a->depth + off : nullptr, nullptr, stream))) return rc;
+        if ((rc = mvs_composite_fwd(raw, z, n, S, a->white_bkgd, a->rgb + off * 3, a->disp ? a->disp + off : nullptr,
+                                    a->acc ? a->acc + off : nullptr, nullptr, a->depth ? a->depth + off : nullptr, nullptr,
+                                    guarded ? a->guard : nullptr, stream))) return rc;
     }
     return MVSNERF_OK;
 }

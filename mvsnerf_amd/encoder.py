@@ -8,6 +8,7 @@ Internally every 3-D tensor is channel-last in HBM; the tensors handed back to c
 NCDHW views of that memory (no copies), e.g. the neural volume is (1,8,D,h,w) with channels_last_3d
 strides and feeds the ray-march kernels without a transpose.
 """
+import ctypes
 import time
 
 import torch
@@ -24,12 +25,15 @@ ENCODER_PRECISION = "auto"      # "auto" | "fp32" | "bf16" | "fp16x3": see encod
 class encoder_precision:
     """`with encoder.encoder_precision(mode): ...` - the arithmetic of conv0 of CostRegNet (models.py:756; 74.5 % of the encoder's FLOPs).  Every
     other layer, the plane sweep's own arithmetic, InPlaceABN statistics, master weights and gradients are fp32 in every mode.
-      "auto" (default)  a no-grad scene encode (validation_step / render_view / fine-tuning's one-off encode) takes the fp32-GRADE fp16 kernel
-                "fp16x3" below; a step that needs gradients takes the fp32-MFMA kernels
+      "auto" (default)  a step that needs gradients takes the fp32-MFMA kernels; a no-grad scene encode (validation_step / render_view / fine-tuning's
+                one-off encode) runs the GUARDED fp16 sequence (mvsnerf_sweep_conv0_guarded_fwd): the "fp16x3" pair below, which reports a cost
+                value or weight outside fp16's range through a device-side guard word, followed by the fp32 plane sweep + fp32-MFMA conv0
+                predicated on that word - they recompute the layer when it is set and cost ~10 us when it is not.  No host synchronisation; the
+                volume never saturates (ops.guard_fallbacks() counts the fallbacks).
       "fp32"    conv0 on v_mfma_f32_4x4x1_16B_f32 (csrc/conv_mfma.hip) everywhere
-      "fp16x3"  = "auto": the plane sweep stores every cost value as two fp16 pieces of x / 16, conv0 multiplies x0*w0 + x0*w1 + x1*w0 on
+      "fp16x3"  the UNGUARDED pair: the plane sweep stores every cost value as two fp16 pieces of x / 16, conv0 multiplies x0*w0 + x0*w1 + x1*w0 on
                 v_mfma_f32_16x16x32_f16 (csrc/conv_f16x3.hip; dropped: <= 2^-22 of a product).  Measured: as far from the reference's CPU results as the fp32 kernel
-                (DESIGN.md 0a), 0.53 instead of 0.81 ms; cost values saturate at 2^20 (the shipped FeatureNet: < 450)
+                (DESIGN.md), 0.53 instead of 0.81 ms; cost values SATURATE at 2^20 (the shipped FeatureNet: < 450)
       "bf16"    the reference's AMP switch (train_mvs_nerf_pl.py:317-318 `precision=16 if args.use_amp`; BASELINE config 3): the cost volume is stored as
                 bf16 and conv0 runs forward, data gradient and weight gradient on v_mfma_f32_16x16x32_bf16 (csrc/conv_bf16.hip): operands ROUNDED to bf16."""
 
@@ -732,7 +736,13 @@ class CostRegNet(nn.Module):
             _, C, D, H, W = x.shape
         if D % 8 or H % 8 or W % 8:
             raise RuntimeError(f"CostRegNet needs D,h,w divisible by 8 (three stride-2 stages), got {(D, H, W)}")
-        if isinstance(x, _BlockedCost16):
+        if isinstance(x, _Conv0Done):          # conv0 already ran inside the guarded encode head (_plane_sweep, blocked="guarded")
+            raw = x.buf
+            scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self.conv0.bn, update_running=self.conv0.bn.training,
+                                                    partials=None if x.part is None else (x.part, x.nblk))
+            c0 = _Lazy(raw, scale, shift, (D, H, W, 8), mean, invstd)
+            buf, ld = None, 0
+        elif isinstance(x, _BlockedCost16):
             pk = self.conv0._packed
             if x.n_ch != pk.cin:
                 raise RuntimeError(f"CostRegNet: 16-bit cost volume has {x.n_ch} channels, conv0 expects {pk.cin}")
@@ -960,7 +970,7 @@ class _BlockedCost16(_BlockedCost):
 
 def _inference_hand_off():
     """`blocked` of the no-grad plane sweep -> conv0 hand-off for the current encoder precision."""
-    return {"bf16": "bf16", "fp16x3": "fp16x2", "auto": "fp16x2"}.get(ENCODER_PRECISION, True)
+    return {"bf16": "bf16", "fp16x3": "fp16x2", "auto": "guarded"}.get(ENCODER_PRECISION, True)
 
 
 class _BlockedCostH2(_BlockedCost16):
@@ -969,7 +979,17 @@ class _BlockedCostH2(_BlockedCost16):
     __slots__ = ()
 
 
-def _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img, blocked=False):
+class _Conv0Done(_BlockedCost):
+    """Hand-off of the guarded encode head (mvsnerf_sweep_conv0_guarded_fwd): the plane sweep AND conv0 have run; `buf` is conv0's raw output
+    (D,H,W,8), `part` its InPlaceABN partial sums (or None in eval mode), `nblk` their slot count."""
+    __slots__ = ("part", "nblk")
+
+    def __init__(self, raw, n_ch, dims, part, nblk):
+        super().__init__(raw, n_ch, 0, dims)
+        self.part, self.nblk = part, nblk
+
+
+def _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img, blocked=False, conv0=None):
     """One-pass plane sweep (homo_warp + cost variance [+ warped thumbnails]).  Returns (cost view, masks, saved);
     blocked=True: the cost volume comes back as a _BlockedCost instead of a logical NCDHW view."""
     B, V, C, H, W = feats.shape
@@ -993,6 +1013,28 @@ def _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img, blocked=Fa
     masks = torch.empty((V, D, Hp, Wp) if with_img else (1, D, Hp, Wp), device=dev, dtype=torch.float32)
     proj = proj_mats[0].detach().contiguous()
     depth = depth_values[0].detach().contiguous()
+    if blocked == "guarded":
+        # no-grad default: two-piece fp16 sweep -> fp16x3 conv0 -> {fp32 sweep, fp32-MFMA conv0, statistics} predicated on the guard word, one call
+        from . import ops as _ops
+        pk = conv0._packed
+        if not with_img or pk.cin != n_ch or pk.cout != 8:
+            raise RuntimeError(f"guarded encode head: conv0 expects {pk.cin} channels, the sweep produces {n_ch}")
+        nb16 = (n_ch + 15) // 16
+        nvox = D * Hp * Wp
+        # one buffer for both hand-offs: the fp32 blocks (CP * 4 B per voxel) are only written after the fp16x3 conv0 has consumed the fp16
+        # planes (nb16 * 64 B per voxel), in stream order
+        scratch = torch.empty(max(2 * nb16 * 16 * 2, CP * 4) * nvox, device=dev, dtype=torch.uint8)
+        raw = torch.empty((D, Hp, Wp, 8), device=dev, dtype=torch.float32)
+        want = conv0.bn.training and FUSED_ABN_STATS
+        nblk = lib.mvsnerf_conv0_bf16_tiles(D, Hp, Wp)
+        part = torch.empty(nblk * 16, device=dev, dtype=torch.float32) if want else None
+        a = _lib.SweepConv0Args(
+            feats_cl=feats_cl.data_ptr(), imgs_cl=imgs_cl_p, proj=dev_f32(proj, "proj_mats"), depth=dev_f32(depth, "depth_values"),
+            V=V, H=H, W=W, D=D, pad=pad, CP=CP, masks=masks.data_ptr(), cost16x2=scratch.data_ptr(), cost32=scratch.data_ptr(),
+            w_f16x3=_get_f16x3_conv0(pk).data_ptr(), w_c8=pk.get_c8().data_ptr(), Cin=n_ch, out=raw.data_ptr(),
+            stats_part=0 if part is None else part.data_ptr(), guard=_ops.guard_words(dev).data_ptr())
+        check(lib.mvsnerf_sweep_conv0_guarded_fwd(ctypes.byref(a), stream_ptr()), "sweep_conv0_guarded_fwd")
+        return _Conv0Done(raw, n_ch, (D, Hp, Wp), part, nblk), masks.unsqueeze(0), (feats_cl, proj, depth, (V, C, H, W, D, pad, CP, n_ch))
     if blocked == "fp16x2":
         nb16 = (n_ch + 15) // 16
         cost = torch.empty((2, nb16, D * Hp * Wp, 16), device=dev, dtype=torch.float16)
@@ -1137,7 +1179,8 @@ class MVSNet(nn.Module):
             raise RuntimeError("MVSNet: batch size must be 1 (the reference assumes it, models.py:916)")
         if torch.is_grad_enabled() and feats.requires_grad:
             return _PlaneSweepFunction.apply(feats, imgs, proj_mats, depth_values, pad, with_img)
-        cost, masks, _ = _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img, blocked=blocked)
+        cost, masks, _ = _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img, blocked=blocked,
+                                      conv0=self.cost_reg_2.conv0 if blocked == "guarded" else None)
         return cost, masks
 
     def build_volume_costvar(self, feats, proj_mats, depth_values, pad=0):
@@ -1227,7 +1270,8 @@ def bench_encode(rig, dev, pad, iters=6):
             vol_f = net(imgs, proj, nf, pad=pad)[0]
         torch.cuda.synchronize()
         times["forward_free_running"] = round((time.perf_counter() - t0) / iters * 1e3, 3)
-        times["note"] = ("feature_net / planesweep_costvar / cost_reg_net / total: stage by stage with a host synchronisation after each stage "
+        times["note"] = ("feature_net / planesweep_costvar / cost_reg_net / total: stage by stage with a host synchronisation after each stage; in the guarded default "
+                         "the plane-sweep stage is mvsnerf_sweep_conv0_guarded_fwd and therefore INCLUDES conv0 (and cost_reg_net starts at conv0's statistics) "
                          "(comparable with earlier rounds); forward_single_call: MVSNet.forward, the product call, one isolated call; "
                          "forward_free_running: the same call back to back")
         # the same forward captured ONCE into a hipGraph and replayed (torch.cuda.CUDAGraph: every launch of the encode - ~80 kernels -

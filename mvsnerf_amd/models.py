@@ -128,10 +128,13 @@ class Renderer_ours(nn.Module):
 
     def packed_alt(self, feat_dim=None):
         """Keyword arguments selecting the MLP kernel of ops.raymarch / ops.render_pixels for the current ops.MLP_PRECISION."""
-        if ops.MLP_PRECISION == "bf16":
+        mode = ops.inference_mlp_mode()
+        if mode == "bf16":
             return {"packed_bf16": self.packed_bf16(feat_dim)}
-        if ops.MLP_PRECISION in ops.N_SPLIT:
-            return {"packed_split": self.packed_split(feat_dim, ops.N_SPLIT[ops.MLP_PRECISION])}
+        if mode == "guarded":        # the default: fp16x3 kernel + predicated fp32-MFMA kernel behind it (ops.set_mlp_precision)
+            return {"packed_split": self.packed_split(feat_dim, ops.N_SPLIT["fp16x3"]), "guard": ops.guard_words(self.pts_bias.weight.device)}
+        if mode in ops.N_SPLIT:
+            return {"packed_split": self.packed_split(feat_dim, ops.N_SPLIT[mode])}
         return {}
 
     # -- queries ----------------------------------------------------------------------------
@@ -143,11 +146,15 @@ class Renderer_ours(nn.Module):
         F = feat.shape[-1]
         vd = None if alpha_only else viewdirs.contiguous()        # named: a temporary would be freed before the launch
         dptr = 0 if alpha_only else ops.dev_f32(vd, "viewdirs")
-        if ops.MLP_PRECISION == "bf16":
+        mode = ops.inference_mlp_mode()
+        if mode == "bf16":
             return ops.mlp_forward_bf16(self.packed_bf16(F), self.packed(F), F, ops.dev_f32(pts, "pts"), 3, ops.dev_f32(feat, "feat"), F,
                                         dptr, 3, N, S, alpha_only, pts.device)
-        if ops.MLP_PRECISION in ops.N_SPLIT:
-            ps, ns = self.packed_split(F, ops.N_SPLIT[ops.MLP_PRECISION])
+        if mode == "guarded":
+            ps, _ = self.packed_split(F, ops.N_SPLIT["fp16x3"])
+            return ops.mlp_forward_guarded(ps, self.packed(F), F, ops.dev_f32(pts, "pts"), 3, ops.dev_f32(feat, "feat"), F, dptr, 3, N, S, alpha_only, pts.device)
+        if mode in ops.N_SPLIT:
+            ps, ns = self.packed_split(F, ops.N_SPLIT[mode])
             return ops.mlp_forward_split(ps, ns, self.packed(F), F, ops.dev_f32(pts, "pts"), 3, ops.dev_f32(feat, "feat"), F,
                                          dptr, 3, N, S, alpha_only, pts.device)
         return ops.mlp_forward(self.packed(F), F, ops.dev_f32(pts, "pts"), 3, ops.dev_f32(feat, "feat"), F, dptr, 3, N, S, alpha_only, pts.device)

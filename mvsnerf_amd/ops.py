@@ -282,25 +282,39 @@ def mlp_pack(weights, biases, F):
     return packed
 
 
-MLP_PRECISION = "fp32"      # "fp32" (default) | "bf16" | "bf16x3" | "bf16x6" | "fp16x3" (opt-in); see set_mlp_precision
+MLP_PRECISION = "auto"      # "auto" (default) | "fp32" | "bf16" | "bf16x3" | "bf16x6" | "fp16x3"; see set_mlp_precision
 N_SPLIT = {"bf16x3": 2, "bf16x6": 3, "fp16x3": 18}      # n_split of mvsnerf_mlp_*_split; 18 = MVSNERF_SPLIT_FP16 (include/mvsnerf_hip.h)
+_MODES = ("auto", "fp32", "bf16", "bf16x3", "bf16x6", "fp16x3")
 
 
 def set_mlp_precision(mode):
     """Select the matrix-core arithmetic of the MLP:
-      "fp32"    v_mfma_f32_32x32x2_f32 (default; the headline / parity path; inference and training)
+      "auto"    (default) a step that needs gradients runs "fp32"; a no-grad rendering / network query runs the GUARDED fp16x3 sequence:
+                the two-piece fp16 kernel (fp32-grade results, 2.5x the fp32-MFMA rate) reports any operand outside fp16's range through
+                a device-side guard word, and the fp32-MFMA kernel enqueued right behind it - predicated on that word - recomputes the
+                batch when it is set.  No host synchronisation, results never saturate (include/mvsnerf_hip.h, "guarded 16-bit
+                sequences"); ops.guard_fallbacks() tells how often the fp32 kernel had to step in.
+      "fp32"    v_mfma_f32_32x32x2_f32 everywhere (the arithmetic of bench.py's headline and of the parity tests that pin the fp32 kernel)
       "bf16"    v_mfma_f32_32x32x16_bf16, operands rounded to bf16 (BASELINE configs 3/4; ~1e-2 errors); in training this is the
                 reference's AMP switch (train_mvs_nerf_pl.py:317-318): forward, data- and weight-gradient GEMMs on bf16 operands
                 with fp32 accumulation, fp32 master weights and fp32 gradients
       (the split modes below are inference-only)
       "bf16x6"  split-bf16 fp32 emulation: operands as 3 bf16 pieces, 6 bf16 MFMAs per product (fp32-grade results, fp32's range)
       "bf16x3"  2 bf16 pieces, 3 MFMAs (~1e-5 relative)
-      "fp16x3"  2 FP16 pieces, 3 v_mfma_f32_32x32x16_f16 per product: fp32-grade results (two fp16 pieces carry 22 bits) at half the
-                matrix-core work of "bf16x6"; operands must stay inside fp16's range (|x| < 65504; csrc/mlp_f16x3.hip)"""
+      "fp16x3"  the UNGUARDED two-piece fp16 kernel alone: operands above 65504 saturate (csrc/mlp_f16x3.hip)"""
     global MLP_PRECISION
-    if mode not in ("fp32", "bf16", "bf16x3", "bf16x6", "fp16x3"):
-        raise ValueError("mlp precision must be 'fp32', 'bf16', 'bf16x3', 'bf16x6' or 'fp16x3'")
+    if mode not in _MODES:
+        raise ValueError(f"mlp precision must be one of {_MODES}")
     MLP_PRECISION = mode
+
+
+def inference_mlp_mode():
+    """What a no-grad query runs under the current MLP_PRECISION ("guarded" for "auto")."""
+    return "guarded" if MLP_PRECISION == "auto" else MLP_PRECISION
+
+
+def training_mlp_mode():
+    return "fp32" if MLP_PRECISION == "auto" else MLP_PRECISION
 
 
 class mlp_precision:
@@ -317,6 +331,27 @@ class mlp_precision:
         set_mlp_precision(self.prev)
 
 
+_guards = {}
+
+
+def guard_words(device=None):
+    """The guard words of this device's guarded 16-bit sequences: int32[4] = {tripped (re-armed by every sequence), sequences that fell back
+    to the fp32 kernels so far, 0, 0}; allocated once per device, owned here (the library allocates nothing)."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    g = _guards.get(idx)
+    if g is None:
+        g = _guards[idx] = torch.zeros(4, device=torch.device("cuda", idx), dtype=torch.int32)
+    return g
+
+
+def guard_fallbacks(device=None):
+    """Number of guarded sequences (ray-march batches, network queries, scene encodes) whose fp32 kernels had to take over because a value
+    left fp16's range.  Reading it synchronises - it is for tests and reports, the hot path never looks at it."""
+    return int(guard_words(device)[1].item())
+
+
 def mlp_pack_split(weights, F, n_split):
     n = _lib.lib().mvsnerf_mlp_packed_split_elems(F, n_split)
     if n == 0:
@@ -331,6 +366,14 @@ def mlp_forward_split(packed_split, n_split, packed, F, ndc_ptr, ndc_stride, fea
     raw = torch.empty((N * S, 1 if alpha_only else 4), device=device, dtype=torch.float32)
     check(_lib.lib().mvsnerf_mlp_fwd_split(packed_split.data_ptr(), packed.data_ptr(), F, n_split, ndc_ptr, ndc_stride, feat_ptr, feat_stride,
                                            dirs_ptr, dirs_stride, N, S, int(alpha_only), raw.data_ptr(), stream_ptr()), "mlp_fwd_split")
+    return raw
+
+
+def mlp_forward_guarded(packed_h, packed, F, ndc_ptr, ndc_stride, feat_ptr, feat_stride, dirs_ptr, dirs_stride, N, S, alpha_only, device):
+    raw = torch.empty((N * S, 1 if alpha_only else 4), device=device, dtype=torch.float32)
+    check(_lib.lib().mvsnerf_mlp_fwd_guarded(packed_h.data_ptr(), packed.data_ptr(), F, ndc_ptr, ndc_stride, feat_ptr, feat_stride,
+                                             dirs_ptr, dirs_stride, N, S, int(alpha_only), raw.data_ptr(), guard_words(device).data_ptr(), stream_ptr()),
+          "mlp_fwd_guarded")
     return raw
 
 
@@ -375,7 +418,8 @@ def composite(raw, z_vals, white_bkgd=False):
 
 
 # ------------------------------------------------------------------ fused ray march
-def raymarch(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd=False, packed_bf16=None, packed_split=None):
+def raymarch(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd=False, packed_bf16=None, packed_split=None,
+             guard=None):
     """One FFI call for rendering() (renderer.py:138-165).  Returns dict of outputs."""
     _need_no_grad(vol_cl, imgs, rays_pts, rays_ndc, z_vals, rays_dir, op="raymarch")
     N, S = z_vals.shape
@@ -400,14 +444,15 @@ def raymarch(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, z_vals,
         out["rgb_map"].data_ptr(), out["disp"].data_ptr(), out["acc"].data_ptr(), out["weights"].data_ptr(),
         out["depth"].data_ptr(), out["alpha"].data_ptr(), 0 if packed_bf16 is None else packed_bf16.data_ptr(),
         channels_last_images(imgs).data_ptr() if FUSED_GATHER else 0,
-        0 if packed_split is None else packed_split[0].data_ptr(), 0 if packed_split is None else int(packed_split[1]))
+        0 if packed_split is None else packed_split[0].data_ptr(), 0 if packed_split is None else int(packed_split[1]),
+        0 if guard is None else guard.data_ptr())
     check(_lib.lib().mvsnerf_raymarch_fwd(ctypes.byref(a), stream_ptr()), "raymarch_fwd")
     return out
 
 
 def render_pixels(vol_cl, imgs, w2cs, intrinsics, packed, H, W, K_tgt, c2w_tgt, K_ref, w2c_ref, nf_tgt, nf_ref, N_samples,
                   first_pixel=0, n_pixels=None, pad=0, lindisp=False, white_bkgd=False, packed_bf16=None, batch_rays=4096,
-                  want=("depth",), ref_hw=None, packed_split=None):
+                  want=("depth",), ref_hw=None, packed_split=None, guard=None):
     """Pixel range of one target view in ONE FFI call (the chunk loop of validation_step, train_mvs_nerf_pl.py:198-208).
     Returns dict with rgb (n,3) and the requested extras among depth/acc/disp (n,)."""
     _need_no_grad(vol_cl, imgs, op="render_pixels")
@@ -438,7 +483,8 @@ def render_pixels(vol_cl, imgs, w2cs, intrinsics, packed, H, W, K_tgt, c2w_tgt, 
         c(K_tgt, "K_tgt"), c(c2w_tgt, "c2w_tgt"), c(K_ref, "K_ref"), c(w2c_ref, "w2c_ref"), c(nf_tgt, "near_far_tgt"), c(nf_ref, "near_far_ref"),
         W, H, int(pad), int(bool(lindisp)), 0 if ref_hw is None else int(ref_hw[1]), 0 if ref_hw is None else int(ref_hw[0]), int(first_pixel), n, int(N_samples), int(bool(white_bkgd)), B,
         ws.data_ptr(), ws_n, out["rgb"].data_ptr(), *[0 if out[k] is None else out[k].data_ptr() for k in ("depth", "acc", "disp")],
-        0 if packed_split is None else packed_split[0].data_ptr(), 0 if packed_split is None else int(packed_split[1]))
+        0 if packed_split is None else packed_split[0].data_ptr(), 0 if packed_split is None else int(packed_split[1]),
+        0 if guard is None else guard.data_ptr())
     check(lib.mvsnerf_render_pixels_fwd(ctypes.byref(a), stream_ptr()), "render_pixels_fwd")
     return {k: v for k, v in out.items() if v is not None}
 
@@ -510,9 +556,9 @@ class RayMarchFunction(torch.autograd.Function):
         F = 8 + 4 * V
         if C not in (8, F):
             raise RuntimeError(f"ray march: the volume has {C} channels; expected 8 or 8 + 4V = {F}")
-        if MLP_PRECISION not in ("fp32", "bf16"):
+        if training_mlp_mode() not in ("fp32", "bf16"):
             raise RuntimeError(f"training runs the MLP in 'fp32' or 'bf16' (ops.set_mlp_precision), not {MLP_PRECISION!r}")
-        bf16 = MLP_PRECISION == "bf16"
+        bf16 = training_mlp_mode() == "bf16"
         dev = rays_pts.device
         f32 = dict(device=dev, dtype=torch.float32)
         feat = torch.empty((N, S, F), **f32)

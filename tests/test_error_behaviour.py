@@ -33,12 +33,17 @@ def test_c_abi_rejects_bad_arguments_without_launching():
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mvsnerf_hip.h")).read()
     assert int(re.search(r"#define MVSNERF_SPLIT_FP16 (\d+)", hdr).group(1)) == ops.N_SPLIT["fp16x3"] == 18      # the Python mode table follows the header
     seg = lambda steps, nb: steps * nb * 512
-    assert l.mvsnerf_mlp_packed_split_elems(20, 18) == 2 * (seg(2, 4) + seg(4, 4) + 4 * seg(8, 4) + seg(4, 4) + 2 * seg(8, 4) + seg(9, 2)) == 256000
+    assert l.mvsnerf_mlp_packed_split_elems(20, 18) == 2 * (seg(2, 4) + seg(4, 4) + 4 * seg(8, 4) + seg(4, 4) + 2 * seg(8, 4) + seg(9, 2)) + 8 == 256008      # + 8 status elements ("a weight was clamped", read by the guarded sequence)
     assert l.mvsnerf_mlp_packed_split_elems(20, 4) == 0 and l.mvsnerf_mlp_packed_split_elems(21, 18) == 0 and l.mvsnerf_mlp_packed_split_elems(20, 3) > 0
     wp = (ctypes.c_void_p * 11)(*[p] * 11)
     assert l.mvsnerf_mlp_pack_split(wp, 20, 4, p, 0) == EUNSUPPORTED and l.mvsnerf_mlp_pack_split(wp, 20, 18, p + 4, 0) == EALIGN
     assert l.mvsnerf_mlp_fwd_split(p, p, 20, 7, p, 3, p, 20, p, 3, 1, 1, 0, p, 0) == EUNSUPPORTED
     assert l.mvsnerf_mlp_fwd_split(p, p, 20, 18, p, 3, p, 20, p, 3, 0, 1, 0, p, 0) == 0                # empty batch: no launch
+    # guarded sequences (ABI 10): a guard needs the fp16 weight planes; null guard / null struct are rejected before anything is launched
+    assert l.mvsnerf_mlp_fwd_guarded(p, p, 20, p, 3, p, 20, p, 3, 1, 1, 0, p, 0, 0) == EINVAL             # no guard words
+    assert l.mvsnerf_mlp_fwd_guarded(p, p, 20, p, 3, p, 20, p, 3, 0, 1, 0, p, p, 0) == 0                  # empty batch: no launch
+    assert l.mvsnerf_sweep_conv0_guarded_fwd(None, 0) == EINVAL
+    assert l.mvsnerf_conv0_f16x3_packed_elems(41) == 3 * 7680 + 8
     assert not hasattr(l, "mvsnerf_tune") and not hasattr(l, "mvsnerf_debug_set_census")     # the library has no A/B switches (csrc/knobs.h: constants)
 
 

@@ -1,0 +1,187 @@
+"""Guarded 16-bit sequences (include/mvsnerf_hip.h, ABI 10): what a no-grad rendering() / network query / scene encode runs by default.
+The two-piece fp16 kernels report a value outside fp16's range through a device-side guard word; the fp32 kernels of the same stage are
+enqueued behind them, predicated on that word, and overwrite the results when it is set.  Claims tested here:
+  * in range: the default IS the fp16x3 kernels' result (bit for bit) and no fallback is counted;
+  * out of range (an MLP with 3e4x weights; weights that do not fit fp16 at pack time; features beyond 65504; a scene whose variance
+    channels exceed 2^20): the default returns the FP32 kernels' result - not a saturated one - and the fallback is counted;
+  * the guard re-arms itself: an in-range batch after a tripped one is served by the fp16 kernels again.
+Reference arithmetic being protected: models.py:194-222 (Renderer_ours.forward), models.py:756 (conv0 of CostRegNet)."""
+import copy
+
+import pytest
+import torch
+
+from tests.util import load_weights, record_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def net20():
+    from tests.test_gpu_fp16x3 import _load_net
+    return _load_net()
+
+
+def _batch(n_rays=40, n_samples=24, seed=0, feat_scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    ndc = torch.rand((n_rays, n_samples, 3), generator=g).to(DEV)
+    feat = (torch.randn((n_rays, n_samples, 20), generator=g) * feat_scale).to(DEV)
+    dirs = torch.nn.functional.normalize(torch.randn((n_rays, 3), generator=g), dim=-1).to(DEV)
+    return ndc, feat, dirs
+
+
+def _query(net, mode, ndc, feat, dirs):
+    from mvsnerf_amd import ops
+    N, S = ndc.shape[:2]
+    with ops.mlp_precision(mode), torch.no_grad():
+        raw = net.nerf.query(ndc, feat, dirs, N, S).clone()
+        sig = net.nerf.query(ndc, feat, None, N, S).clone()
+    return raw, sig
+
+
+def test_default_is_the_guarded_mode_and_in_range_batches_stay_on_fp16(net20):
+    from mvsnerf_amd import ops
+    assert ops.MLP_PRECISION == "auto" and ops.inference_mlp_mode() == "guarded" and ops.training_mlp_mode() == "fp32"
+    ndc, feat, dirs = _batch()
+    before = ops.guard_fallbacks()
+    raw_d, sig_d = _query(net20, "auto", ndc, feat, dirs)
+    raw_h, sig_h = _query(net20, "fp16x3", ndc, feat, dirs)
+    raw_f, sig_f = _query(net20, "fp32", ndc, feat, dirs)
+    assert ops.guard_fallbacks() == before                                   # nothing left fp16's range: the fp32 kernels left at once
+    assert torch.equal(raw_d, raw_h) and torch.equal(sig_d, sig_h)           # ... and the results are the fp16x3 kernel's
+    e = float((raw_d - raw_f).abs().max())
+    record_err("guard:in_range_vs_fp32_kernel", e, scale=float(raw_f.abs().max()))
+    assert e < 5e-5 * max(1.0, float(raw_f.abs().max()))                     # fp32-grade (tests/test_gpu_fp16x3.py holds the tight bounds)
+    assert int(ops.guard_words()[0].item()) == 0                             # re-armed
+
+
+@pytest.mark.parametrize("what", ["activations", "weights", "features"])
+def test_out_of_range_mlp_returns_the_fp32_result(net20, what):
+    """`an MLP with 3e4x weights must return the fp32 result, not a saturated one`."""
+    from mvsnerf_amd import ops
+    net = copy.deepcopy(net20)
+    fs = 1.0
+    with torch.no_grad():
+        if what == "activations":
+            net.nerf.pts_linears[1].weight.mul_(3e4)        # h1 ~ 1e5: beyond fp16 in the layer epilogue (weights themselves still fit)
+        elif what == "weights":
+            net.nerf.pts_linears[2].weight.mul_(1e6)        # |w| up to ~1e5: clamped at pack time -> status word behind the packed planes
+        else:
+            fs = 3e5                                        # volume / colour features beyond 65504: the B operand of pts_bias's GEMM
+    net.invalidate_packed()
+    ndc, feat, dirs = _batch(seed=3, feat_scale=fs)
+    before = ops.guard_fallbacks()
+    raw_d, sig_d = _query(net, "auto", ndc, feat, dirs)
+    assert ops.guard_fallbacks() == before + 2                               # both queries (rgb+sigma, sigma only) fell back
+    raw_f, sig_f = _query(net, "fp32", ndc, feat, dirs)
+    raw_h, sig_h = _query(net, "fp16x3", ndc, feat, dirs)                     # the unguarded kernel alone: saturated / non-finite
+    assert torch.equal(raw_d, raw_f) and torch.equal(sig_d, sig_f)           # the guarded default returned the fp32-MFMA kernel's bits
+    assert not torch.equal(raw_h, raw_f)
+    bad = float((sig_h - sig_f).abs().max()) if bool(torch.isfinite(sig_h).all()) else float("inf")
+    print(f"guard[{what}]: unguarded fp16x3 differs from fp32 by {bad:.3g} in sigma (max |sigma| {float(sig_f.abs().max()):.3g}); guarded: 0")
+    # re-armed: the shipped network on an in-range batch is served by the fp16 kernels again, without a fallback
+    n0 = ops.guard_fallbacks()
+    r2, _ = _query(net20, "auto", *_batch(seed=5))
+    r2h, _ = _query(net20, "fp16x3", *_batch(seed=5))
+    assert ops.guard_fallbacks() == n0 and torch.equal(r2, r2h)
+
+
+def test_guarded_rendering_and_frame_render(net20):
+    """The same guard inside the one-call entries: mvsnerf_raymarch_fwd (rendering()) and mvsnerf_render_pixels_fwd (per sub-batch)."""
+    from mvsnerf_amd import ops
+    from mvsnerf_amd.synth import make_rig, pose_ref_of
+    from tests.test_gpu_fp16x3 import _render
+    from oracle import mvsnerf_oracle as O
+    big = copy.deepcopy(net20)
+    with torch.no_grad():
+        big.nerf.pts_linears[1].weight.mul_(3e4)
+    big.invalidate_packed()
+    rig = make_rig(64, 96, seed=11, rot_deg=2.0)
+    pose = pose_ref_of(rig)
+    g = torch.Generator().manual_seed(0)
+    vol = torch.randn((1, 8, 16, 24, 32), generator=g)
+    pts, dirs, _, ndc, zv, ro, _ = O.build_rays(rig["images_raw"], pose, rig["near_fars"], 96, 32, pad=4,
+                                                t_rand=torch.rand((96, 32), generator=g), generator=g)
+    imgs = rig["images_raw"][:, :3]
+    for net, trips in ((net20, 0), (big, 1)):
+        before = ops.guard_fallbacks()
+        d = _render(net, "auto", 32, pose, pts, ndc, zv, ro, dirs, vol, imgs)
+        n_fb = ops.guard_fallbacks() - before
+        f = _render(net, "fp32", 32, pose, pts, ndc, zv, ro, dirs, vol, imgs)
+        h = _render(net, "fp16x3", 32, pose, pts, ndc, zv, ro, dirs, vol, imgs)
+        want = f if trips else h
+        assert n_fb == 2 * trips                       # rendering() + the sigma-only query of _render
+        for a, b in zip(d, want):
+            assert torch.equal(a, b)
+    # frame render: 2500 pixels in sub-batches of 1024 = three guarded sequences
+    H, W, S, pad = 48, 64, 24, 4
+    rig = make_rig(H, W, seed=11, rot_deg=2.0, smooth=True)
+    pd = {k: v.to(DEV) for k, v in pose_ref_of(rig).items()}
+    vol_cl = ops.channels_last_volume(torch.randn((1, 8, 16, H // 4 + 2 * pad, W // 4 + 2 * pad), generator=g).to(DEV))
+    im = rig["images_raw"][0, :3].to(DEV)
+    common = dict(first_pixel=100, n_pixels=2500, pad=pad, batch_rays=1024, want=("depth", "acc"))
+    for net, trips in ((net20, 0), (big, 3)):
+        args = (vol_cl, im, pd["w2cs"][:3].contiguous(), pd["intrinsics"][:3].contiguous(), net.packed(20), H, W, pd["intrinsics"][-1], pd["c2ws"][-1],
+                pd["intrinsics"][-1], pd["w2cs"][0], pd["near_fars"][-1], pd["near_fars"][0], S)
+        with torch.no_grad():
+            before = ops.guard_fallbacks()
+            with ops.mlp_precision("auto"):
+                d = ops.render_pixels(*args, **net.packed_alt(20), **common)
+            n_fb = ops.guard_fallbacks() - before
+            f = ops.render_pixels(*args, **common)
+            h = ops.render_pixels(*args, packed_split=net.packed_split(20, ops.N_SPLIT["fp16x3"]), **common)
+        assert n_fb == trips
+        want = f if trips else h
+        for k in ("rgb", "depth", "acc"):
+            assert torch.equal(d[k], want[k]), k
+
+
+def test_out_of_range_scene_encode_returns_the_fp32_volume():
+    """`a scene scaled so that variance channels exceed 2^20`.  FeatureNet's last layer (1x1 `toplayer`, no norm) is scaled by
+    2000: features x 2000, variance channels x 4e6 (beyond 2^20 * 16 ... 1e9).  The default no-grad encode must return what the fp32 kernels
+    return; the unguarded fp16 pair returns a saturated volume."""
+    from mvsnerf_amd import encoder as E, models, ops
+    from mvsnerf_amd.synth import make_rig
+    _, mvs_sd = load_weights()
+    H, W, D, pad = 128, 160, 32, 8
+    rig = make_rig(H, W, seed=1234)
+    imgs, proj, nf = rig["images"][:, :3].to(DEV), rig["proj_mats"][:, :3].to(DEV), rig["near_fars"][0, 0].to(DEV)
+
+    def build(scale):
+        net = models.MVSNet()
+        net.load_state_dict(mvs_sd)
+        with torch.no_grad():
+            net.feature.toplayer.weight.mul_(scale)
+            net.feature.toplayer.bias.mul_(scale)
+        net = net.to(DEV).train()
+        net.D = D
+        return net
+
+    def run(net, mode):
+        with torch.no_grad(), E.encoder_precision(mode):
+            return net(imgs, proj, nf, pad=pad)[0].float().clone()
+
+    # in range (shipped weights): default == the fp16 pair, no fallback
+    net = build(1.0)
+    before = ops.guard_fallbacks()
+    v_auto, v_h = run(net, "auto"), run(net, "fp16x3")
+    assert ops.guard_fallbacks() == before and torch.equal(v_auto, v_h)
+    # out of range
+    net = build(2000.0)
+    before = ops.guard_fallbacks()
+    v_auto = run(net, "auto")
+    assert ops.guard_fallbacks() == before + 1
+    v_f, v_h = run(net, "fp32"), run(net, "fp16x3")
+    scale = float(v_f.abs().max())
+    e_guard, e_sat = float((v_auto - v_f).abs().max()), float((v_h - v_f).abs().max())
+    record_err("guard:encode_fallback_vs_fp32_path", e_guard, scale=scale)
+    print(f"guarded encode, variance beyond 2^20: default vs fp32 kernels {e_guard:.3g}, unguarded fp16 pair vs fp32 kernels {e_sat:.3g} (|vol| <= {scale:.3g})")
+    # same kernels, same cost volume; only the InPlaceABN partial sums of conv0 are grouped differently (statistics slots of the fp16 tile)
+    assert e_guard <= 2e-6 * scale
+    assert e_sat > 100 * max(e_guard, 1e-7 * scale)                         # what the guard is for
+    assert int(ops.guard_words()[0].item()) == 0
+    # and the shipped weights afterwards: fp16 again
+    net = build(1.0)
+    n0 = ops.guard_fallbacks()
+    assert torch.equal(run(net, "auto"), run(net, "fp16x3")) and ops.guard_fallbacks() == n0
