@@ -107,6 +107,9 @@ def parse():
     ap.add_argument("--settle-ms", type=float, default=100.0,
                     help="untimed steps of the same workload run before the W warmup steps until the GPU clocks have left the idle state")
     ap.add_argument("--no-extras", action="store_true", help="skip the end-to-end frame / training-step timings")
+    ap.add_argument("--shared-gpu-dry-run", action="store_true",
+                    help="plumbing check for a 1-GPU box: --gpus N ranks all on cuda:0, collectives over gloo (RCCL refuses several ranks per device); runs the "
+                         "torch.distributed.run re-exec and the collective-carrying legs end to end and prints NO headline (no metric / value keys)")
     ap.add_argument("--multi-gpu-legs", action="store_true", help="run the collective-carrying legs (tile-parallel frame, DP training step) "
                                                                   "also at N = 1 (they always run at N > 1)")
     return ap.parse_args()
@@ -190,7 +193,7 @@ def self_launch(a):
     import socket
     import subprocess
     n_vis = torch.cuda.device_count()
-    if n_vis < a.gpus:
+    if n_vis < a.gpus and not a.shared_gpu_dry_run:
         raise SystemExit(f"bench.py --gpus {a.gpus}: only {n_vis} GPU(s) visible; refusing to report a {a.gpus}-GPU number from fewer ranks")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -229,8 +232,9 @@ def timed_collective(fn, dev, world):
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
+        from mvsnerf_amd import distributed as D
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        D.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt, out
 
@@ -239,7 +243,8 @@ def all_ranks_true(flag, dev, world):
     import torch.distributed as dist
     t = torch.tensor([1 if flag else 0], device=dev, dtype=torch.int32)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        from mvsnerf_amd import distributed as D
+        D.all_reduce(t, op=dist.ReduceOp.MIN)
     return bool(t.item())
 
 
@@ -261,14 +266,14 @@ def multi_gpu_legs(dev, rank, world, train_steps=5):
         n_flat = sum(p.numel() for p in system.grad_vars)
         flat = torch.zeros(n_flat, device=dev)
         for _ in range(5):
-            dist.all_reduce(flat)
+            D.all_reduce(flat)
         torch.cuda.synchronize(); dist.barrier()
         t0 = time.perf_counter()
         for _ in range(50):
-            dist.all_reduce(flat)
+            D.all_reduce(flat)
         torch.cuda.synchronize()
         out["grad_allreduce"] = {"bytes": n_flat * 4, "us_per_allreduce": round((time.perf_counter() - t0) / 50 * 1e6, 1), "n_ranks": world,
-                                 "note": "dist.all_reduce of one flat fp32 buffer (RCCL over xGMI), 50 back-to-back calls"}
+                                 "note": "all_reduce of one flat fp32 buffer (%s), 50 back-to-back calls" % ("RCCL over xGMI" if dist.get_backend() == "nccl" else "gloo via host memory: dry run")}
         del system, flat
     # ---- (i) tile-parallel frame
     system = load_system(dev)
@@ -302,7 +307,7 @@ def multi_gpu_legs(dev, rank, world, train_steps=5):
         chk = torch.stack([p.detach().double().sum() for p in system.grad_vars]).sum().reshape(1)
         lo, hi = chk.clone(), chk.clone()
         if world > 1:
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            D.all_reduce(lo, op=dist.ReduceOp.MIN); D.all_reduce(hi, op=dist.ReduceOp.MAX)
         in_sync = bool((lo == hi).item())
         if not in_sync:
             raise SystemExit(f"rank {rank}: parameters diverged across ranks after {mode}-sharded steps")
@@ -328,13 +333,31 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher must start exactly one rank per requested GPU")
+    if a.shared_gpu_dry_run:
+        local = 0                                  # every rank on the one visible GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.shared_gpu_dry_run:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         if dist.get_world_size() != a.gpus:
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {a.gpus}")
+    if a.shared_gpu_dry_run:
+        # NOT a measurement: N ranks time-share one GPU and the collectives cross host memory.  It proves that the launcher path, the sharding,
+        # seeding and gather code and the HIP kernels run together under world size N, and that N-rank results equal 1-rank results.
+        multi = multi_gpu_legs(dev, rank, world, train_steps=2)
+        if rank == 0:
+            multi["measured_on_hardware"] = False
+            multi["note"] = ("shared-GPU dry run: %d ranks on ONE GPU, gloo collectives staged through host memory; timings are meaningless and are "
+                             "reported only to show that every leg ran" % world)
+            print(json.dumps({"shared_gpu_dry_run": True, "n_ranks": world, "gpus_visible": torch.cuda.device_count(), "multi_gpu": multi}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from mvsnerf_amd import _lib, models, ops, renderer
     from mvsnerf_amd.synth import make_rig, pose_ref_of

@@ -464,6 +464,10 @@ typedef struct {
     int* guard;                             /* NULL, or a guard word pair with n_split = MVSNERF_SPLIT_FP16: the guarded sequence below (ABI v10) */
 } mvsnerf_raymarch_args;
 int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream);
+/* K independent ray batches (the K iterations of a render loop over renderer.py:138-165) enqueued by ONE host call: a[0..K) are complete argument
+ * blocks (they may share everything but the ray tensors and the outputs).  The first failing block's code is returned; blocks before it have
+ * been enqueued.  Exists because one batch is ~0.1 ms of GPU work: a caller that crosses the FFI once per batch is paced by its own host code (ABI v10). */
+int mvsnerf_raymarch_fwd_batched(const mvsnerf_raymarch_args* a, int K, void* stream);
 
 /* Split-bf16 MLP ("bf16x3" n_split = 2, "bf16x6" n_split = 3; n_split = 1 is plain bf16 on the same kernel): every fp32
  * operand is the sum of n_split bf16 pieces and a product is accumulated in fp32 from the piece products of combined order

@@ -191,6 +191,7 @@ SIGNATURES = {
     "mvsnerf_volume_sample_bwd": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_fp, _c_l, _c_fp, _c_i, _c_fp, _c_fp]),
     "mvsnerf_composite_fwd": (_c_i, [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_raymarch_fwd": (_c_i, [ctypes.POINTER(RaymarchArgs), _c_fp]),
+    "mvsnerf_raymarch_fwd_batched": (_c_i, [ctypes.POINTER(RaymarchArgs), _c_i, _c_fp]),
     "mvsnerf_raymarch_train_fwd": (_c_i, [ctypes.POINTER(RaymarchTrainArgs), _c_fp]),
     "mvsnerf_raymarch_bwd": (_c_i, [ctypes.POINTER(RaymarchBwdArgs), _c_fp]),
 }
@@ -234,12 +235,13 @@ def check(rc, op):
         raise RuntimeError(f"libmvsnerf_hip: {op} failed: {kind}")
 
 
-def dev_f32(t, name):
-    """Validate a tensor handed to the C ABI: CUDA(HIP) device, fp32, contiguous."""
+def dev_f32(t, name, cur=None):
+    """Validate a tensor handed to the C ABI: CUDA(HIP) device, fp32, contiguous.  cur: torch.cuda.current_device() when the caller has
+    already asked for it (one query per FFI call instead of one per tensor: the ray-march step is paced by this host path)."""
     if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
         raise RuntimeError(f"{name}: expected a contiguous float32 tensor on the GPU, got "
                            f"{type(t).__name__} {getattr(t, 'dtype', None)} {getattr(t, 'device', None)}")
-    if t.device.index != torch.cuda.current_device():
+    if t.device.index != (torch.cuda.current_device() if cur is None else cur):
         # kernels are launched on the CURRENT device's stream (stream_ptr): a tensor living on another GPU would be dereferenced
         # by the wrong device.  One process per GPU with torch.cuda.set_device(LOCAL_RANK) is the supported layout.
         raise RuntimeError(f"{name}: tensor is on {t.device} but the current device is cuda:{torch.cuda.current_device()} "

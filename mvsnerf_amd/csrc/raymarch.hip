@@ -74,6 +74,14 @@ extern "C" int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream
                              guarded && P > 0 ? a->guard : nullptr, stream);
 }
 
+extern "C" int mvsnerf_raymarch_fwd_batched(const mvsnerf_raymarch_args* a, int K, void* stream)
+{
+    if (!a || K < 0) return MVSNERF_EINVAL;
+    for (int k = 0; k < K; ++k)
+        if (int rc = mvsnerf_raymarch_fwd(a + k, stream)) return rc;
+    return MVSNERF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Full-frame / pixel-range render = the chunk loop of validation_step (train_mvs_nerf_pl.py:198-208):
 //   for each chunk: build_rays_test (utils.py:243-297) -> rendering (renderer.py:138-165) -> keep rgb and depth.

@@ -56,6 +56,46 @@ def _collective_needed(group=None):
     return dist.get_world_size(group) > 1 or _FORCE_COLLECTIVES
 
 
+# ------------------------------------------------------------------ collectives
+# The three collectives of the path.  backend "nccl" (= RCCL over xGMI): straight through, device buffers.  backend "gloo" with DEVICE
+# tensors - the shared-GPU dry run (tests/test_gpu_shared.py, `bench.py --shared-gpu-dry-run`: several ranks on ONE GPU, which RCCL
+# refuses) - stages through host memory, so that every line of the N-rank code paths (sharding, seeding, padding, gather order) runs
+# against the HIP kernels on a 1-GPU box.  Host tensors (the CPU tests) go straight to gloo.
+def _stage(t, group):
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce(t, op=None, group=None):
+    op = dist.ReduceOp.SUM if op is None else op
+    if _stage(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
+def all_gather_into_tensor(out, inp, group=None):
+    if _stage(inp, group):
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h, inp.cpu(), group=group)
+        out.copy_(h)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+    return out
+
+
+def broadcast(t, src=0, group=None):
+    if _stage(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
 def init_from_env(device=None):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract).
     Returns (rank, world).  No-op for world size 1."""
@@ -92,7 +132,7 @@ def all_gather_rows(local, n_total, group=None):
     pad = torch.zeros((width, *local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
     out = torch.empty((world * width, *local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
+    all_gather_into_tensor(out, pad, group=group)
     return torch.cat([out[r * width:r * width + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], 0)
 
 
@@ -125,7 +165,7 @@ class FlatGradAllReduce:
                 v.zero_()
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.div_(dist.get_world_size(self.group))
         for v, p in zip(self.views, self.params):
             if p.grad is None:
@@ -182,7 +222,7 @@ def _assemble_frame(packed, H, W, chunk, n_chunks, world, group, device=None):
     if packed is not None:
         pad[:packed.shape[0]] = packed
     out = torch.empty((world * width, 4), dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(out, pad, group=group)
+    all_gather_into_tensor(out, pad, group=group)
     full = torch.cat([out[r * width:r * width + (b - a)] for r, (a, b) in enumerate(px)], 0)
     return full[:, :3], full[:, 3]
 
@@ -216,7 +256,7 @@ def common_seed(device=None, group=None):
     seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
     if _collective_needed(group):
         t = seed.to(device) if device is not None else seed
-        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         seed = t.cpu()
     return int(seed.item())
 

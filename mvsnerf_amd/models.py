@@ -94,12 +94,24 @@ class Renderer_ours(nn.Module):
             raise NotImplementedError(
                 "the HIP MLP kernel is specialised for netdepth=6, netwidth=128, skips=[4], multires=10, raw view dirs "
                 f"(got D={self.D}, W={self.W}, skips={self.skips}, in_ch_pts={self.in_ch_pts}, in_ch_views={self.in_ch_views})")
-        lins = self._linears()
-        key = (_lib.weights_epoch(),) + tuple((l.weight.data_ptr(), l.weight._version, l.bias.data_ptr(), l.bias._version) for l in lins)
+        key = self._weights_key()
         if self._packed is None or key != self._packed_key:
+            lins = self._linears()
             self._packed = ops.mlp_pack([l.weight.detach() for l in lins], [l.bias.detach() for l in lins], F)
             self._packed_key = key
         return self._packed
+
+    def _weights_key(self):
+        """(optimizer-step epoch, data_ptr and _version of the 22 tensors).  The Parameter objects are looked up through nn.Module.__getattr__
+        once and kept (a module attribute access costs ~0.5 us, and this key is built on every rendering() call: 44 of them were a third
+        of the step's host time); the kept list is re-made when the first or last parameter object was replaced (load_state_dict(assign=True))."""
+        c = self.__dict__.get("_plist")
+        if c is None or c[1]._parameters["weight"] is not c[0][0] or c[2]._parameters["bias"] is not c[0][-1]:
+            lins = self._linears()
+            c = ([t for l in lins for t in (l.weight, l.bias)], lins[0], lins[-1])
+            self.__dict__["_plist"] = c
+        pl = c[0]
+        return (_lib.weights_epoch(), *[p._version for p in pl], *[p.data_ptr() for p in pl])
 
     def invalidate_packed(self):
         """Drop the packed-weight caches.  The caches key on (data_ptr, tensor._version, optimizer-step epoch - _lib.weights_epoch); writes through `.data` (`p.data.copy_()`,
@@ -107,34 +119,38 @@ class Renderer_ours(nn.Module):
         (MVSNet.invalidate_packed does the same for the encoder's convolution weights)."""
         self._packed = self._packed_key = None
         self._packed_b = self._packed_s = None
+        self.__dict__["_plist"] = None
 
-    def packed_bf16(self, feat_dim=None):
-        """bf16 fragment-ordered weights for the opt-in bf16-MFMA kernel (same cache policy as packed())."""
+    def packed_bf16(self, feat_dim=None, fresh=False):
+        """bf16 fragment-ordered weights for the opt-in bf16-MFMA kernel (same cache policy as packed()).
+        fresh: packed() has just been called for these weights (same host call) - its key is current."""
         F = self.in_ch_feat if feat_dim is None else feat_dim
-        self.packed(F)                      # validates the architecture and keeps the fp32 vectors current
+        if not fresh:
+            self.packed(F)                  # validates the architecture and keeps the fp32 vectors current
         if getattr(self, "_packed_b", None) is None or self._packed_b_key != self._packed_key:
             self._packed_b = ops.mlp_pack_bf16([l.weight.detach() for l in self._linears()], F)
             self._packed_b_key = self._packed_key
         return self._packed_b
 
-    def packed_split(self, feat_dim=None, n_split=3):
-        """(split-bf16 weight planes, n_split) for the opt-in bf16x3 / bf16x6 kernels (same cache policy as packed())."""
+    def packed_split(self, feat_dim=None, n_split=3, fresh=False):
+        """(split weight planes, n_split) for the bf16x3 / bf16x6 / fp16x3 kernels (same cache policy as packed(); fresh: see packed_bf16)."""
         F = self.in_ch_feat if feat_dim is None else feat_dim
-        self.packed(F)
+        if not fresh:
+            self.packed(F)
         cache = getattr(self, "_packed_s", None)
         if cache is None or cache[0] != (self._packed_key, n_split):
             self._packed_s = ((self._packed_key, n_split), ops.mlp_pack_split([l.weight.detach() for l in self._linears()], F, n_split))
         return self._packed_s[1], n_split
 
-    def packed_alt(self, feat_dim=None):
+    def packed_alt(self, feat_dim=None, fresh=False):
         """Keyword arguments selecting the MLP kernel of ops.raymarch / ops.render_pixels for the current ops.MLP_PRECISION."""
         mode = ops.inference_mlp_mode()
         if mode == "bf16":
-            return {"packed_bf16": self.packed_bf16(feat_dim)}
+            return {"packed_bf16": self.packed_bf16(feat_dim, fresh)}
         if mode == "guarded":        # the default: fp16x3 kernel + predicated fp32-MFMA kernel behind it (ops.set_mlp_precision)
-            return {"packed_split": self.packed_split(feat_dim, ops.N_SPLIT["fp16x3"]), "guard": ops.guard_words(self.pts_bias.weight.device)}
+            return {"packed_split": self.packed_split(feat_dim, ops.N_SPLIT["fp16x3"], fresh), "guard": ops.guard_words(self._packed.device)}
         if mode in ops.N_SPLIT:
-            return {"packed_split": self.packed_split(feat_dim, ops.N_SPLIT[mode])}
+            return {"packed_split": self.packed_split(feat_dim, ops.N_SPLIT[mode], fresh)}
         return {}
 
     # -- queries ----------------------------------------------------------------------------
@@ -199,8 +215,8 @@ class MVSNeRF(nn.Module):
     def packed_split(self, feat_dim=None, n_split=3):
         return self.nerf.packed_split(feat_dim, n_split)
 
-    def packed_alt(self, feat_dim=None):
-        return self.nerf.packed_alt(feat_dim)
+    def packed_alt(self, feat_dim=None, fresh=False):
+        return self.nerf.packed_alt(feat_dim, fresh)
 
     def invalidate_packed(self):
         self.nerf.invalidate_packed()

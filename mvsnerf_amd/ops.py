@@ -40,6 +40,16 @@ def channels_last_volume(volume_feature):
     Zero-copy when the tensor is already channels_last_3d (what our MVSNet / RefVolume produce);
     otherwise one HIP transpose, cached on (storage, version)."""
     v = volume_feature
+    hit = _cl_cache.get("last")          # the same tensor object, unmodified, as in the previous call (a render loop): ~0.3 us instead of ~6
+    if hit is not None and hit[0] is v and hit[1] == (v._version, _lib.weights_epoch()):
+        return hit[2]
+    out = _channels_last_volume(v)
+    _cl_cache["last"] = (v, (v._version, _lib.weights_epoch()), out)
+    return out
+
+
+def _channels_last_volume(volume_feature):
+    v = volume_feature
     if v.dim() == 5:
         if v.shape[0] != 1:
             raise RuntimeError("volume batch must be 1 (the reference assumes it too, models.py:916)")
@@ -418,10 +428,8 @@ def composite(raw, z_vals, white_bkgd=False):
 
 
 # ------------------------------------------------------------------ fused ray march
-def raymarch(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd=False, packed_bf16=None, packed_split=None,
-             guard=None):
-    """One FFI call for rendering() (renderer.py:138-165).  Returns dict of outputs."""
-    _need_no_grad(vol_cl, imgs, rays_pts, rays_ndc, z_vals, rays_dir, op="raymarch")
+def _raymarch_block(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd, packed_bf16, packed_split, guard, want, imgs_cl, cur):
+    """Output tensors + the filled mvsnerf_raymarch_args of one batch."""
     N, S = z_vals.shape
     V = imgs.shape[0]
     F = 8 + 4 * V
@@ -429,25 +437,57 @@ def raymarch(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, z_vals,
     D, H, W, C = vol_cl.shape
     if C != 8:
         raise RuntimeError("raymarch: the neural volume must have 8 channels")
-    f32 = dict(device=dev, dtype=torch.float32)
+    empty = torch.empty
     out = {
-        "input_feat": torch.empty((N, S, F), **f32), "raw": torch.empty((N, S, 4), **f32),
-        "rgb_map": torch.empty((N, 3), **f32), "disp": torch.empty((N,), **f32), "acc": torch.empty((N,), **f32),
-        "weights": torch.empty((N, S), **f32), "depth": torch.empty((N,), **f32), "alpha": torch.empty((N, S), **f32),
+        "input_feat": empty((N, S, F), device=dev, dtype=torch.float32), "raw": empty((N, S, 4), device=dev, dtype=torch.float32),
+        "rgb_map": empty((N, 3), device=dev, dtype=torch.float32), "weights": empty((N, S), device=dev, dtype=torch.float32),
+        "depth": empty((N,), device=dev, dtype=torch.float32), "alpha": empty((N, S), device=dev, dtype=torch.float32),
     }
-    dirs_tmp = torch.empty((N, 3), **f32)
-    a = _lib.RaymarchArgs(
-        dev_f32(vol_cl, "volume"), D, H, W, dev_f32(imgs, "imgs"), V, imgs.shape[2], imgs.shape[3],
-        dev_f32(w2cs, "w2cs"), dev_f32(intrinsics, "intrinsics"), dev_f32(packed, "packed"),
-        dev_f32(rays_pts, "rays_pts"), dev_f32(rays_ndc, "rays_ndc"), dev_f32(z_vals, "z_vals"), dev_f32(rays_dir, "rays_dir"),
+    for k in want:
+        out[k] = empty((N,), device=dev, dtype=torch.float32)
+    out["_dirs_tmp"] = dirs_tmp = empty((N, 3), device=dev, dtype=torch.float32)
+    if imgs_cl is None and FUSED_GATHER:
+        imgs_cl = channels_last_images(imgs)
+    a = (
+        dev_f32(vol_cl, "volume", cur), D, H, W, dev_f32(imgs, "imgs", cur), V, imgs.shape[2], imgs.shape[3],
+        dev_f32(w2cs, "w2cs", cur), dev_f32(intrinsics, "intrinsics", cur), dev_f32(packed, "packed", cur),
+        dev_f32(rays_pts, "rays_pts", cur), dev_f32(rays_ndc, "rays_ndc", cur), dev_f32(z_vals, "z_vals", cur), dev_f32(rays_dir, "rays_dir", cur),
         N, S, int(bool(white_bkgd)), dirs_tmp.data_ptr(), out["input_feat"].data_ptr(), out["raw"].data_ptr(),
-        out["rgb_map"].data_ptr(), out["disp"].data_ptr(), out["acc"].data_ptr(), out["weights"].data_ptr(),
+        out["rgb_map"].data_ptr(), out["disp"].data_ptr() if "disp" in out else 0, out["acc"].data_ptr() if "acc" in out else 0, out["weights"].data_ptr(),
         out["depth"].data_ptr(), out["alpha"].data_ptr(), 0 if packed_bf16 is None else packed_bf16.data_ptr(),
-        channels_last_images(imgs).data_ptr() if FUSED_GATHER else 0,
+        imgs_cl.data_ptr() if (FUSED_GATHER and imgs_cl is not None) else 0,
         0 if packed_split is None else packed_split[0].data_ptr(), 0 if packed_split is None else int(packed_split[1]),
         0 if guard is None else guard.data_ptr())
-    check(_lib.lib().mvsnerf_raymarch_fwd(ctypes.byref(a), stream_ptr()), "raymarch_fwd")
+    return out, a
+
+
+def raymarch(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd=False, packed_bf16=None, packed_split=None,
+             guard=None, want=("disp", "acc"), imgs_cl=None):
+    """One FFI call for rendering() (renderer.py:138-165).  Returns dict of outputs.
+    want: which of the optional per-ray maps `disp` / `acc` to produce (rendering() returns neither: it passes ()).
+    imgs_cl: the channel-last copy of `imgs` when the caller already holds it (renderer's per-scene cache)."""
+    _need_no_grad(vol_cl, imgs, rays_pts, rays_ndc, z_vals, rays_dir, op="raymarch")
+    out, a = _raymarch_block(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, z_vals, rays_dir, white_bkgd, packed_bf16, packed_split,
+                             guard, want, imgs_cl, torch.cuda.current_device())
+    blk = _lib.RaymarchArgs(*a)
+    check(_lib.lib().mvsnerf_raymarch_fwd(ctypes.byref(blk), stream_ptr()), "raymarch_fwd")
     return out
+
+
+def raymarch_batched(vol_cl, imgs, w2cs, intrinsics, packed, ray_batches, white_bkgd=False, packed_bf16=None, packed_split=None, guard=None, want=(),
+                     imgs_cl=None):
+    """K ray batches of one scene in ONE FFI call (mvsnerf_raymarch_fwd_batched): ray_batches = [(rays_pts, rays_ndc, z_vals, rays_dir), ...].
+    Returns the list of per-batch output dicts of raymarch().  One batch is ~0.1 ms of GPU work; issued one call at a time, a render loop is
+    paced by the host."""
+    cur = torch.cuda.current_device()
+    outs, blocks = [], (_lib.RaymarchArgs * len(ray_batches))()
+    for k, (pts, ndc, z, rdir) in enumerate(ray_batches):
+        _need_no_grad(vol_cl, imgs, pts, ndc, z, rdir, op="raymarch_batched")
+        out, a = _raymarch_block(vol_cl, imgs, w2cs, intrinsics, packed, pts, ndc, z, rdir, white_bkgd, packed_bf16, packed_split, guard, want, imgs_cl, cur)
+        blocks[k] = _lib.RaymarchArgs(*a)
+        outs.append(out)
+    check(_lib.lib().mvsnerf_raymarch_fwd_batched(blocks, len(ray_batches), stream_ptr()), "raymarch_fwd_batched")
+    return outs
 
 
 def render_pixels(vol_cl, imgs, w2cs, intrinsics, packed, H, W, K_tgt, c2w_tgt, K_ref, w2c_ref, nf_tgt, nf_ref, N_samples,
@@ -659,14 +699,14 @@ def volume_grad_from_all_ranks(d_feat, ndc, gvol_cl, group=None, scatter=_scatte
     # shards may differ by one ray: gather the counts, pad to the largest
     cnt = torch.tensor([P], device=d_feat.device, dtype=torch.int64)
     cnts = torch.empty(world, device=d_feat.device, dtype=torch.int64)
-    dist.all_gather_into_tensor(cnts, cnt, group=group)
+    DD.all_gather_into_tensor(cnts, cnt, group=group)
     cnts = [int(c) for c in cnts.tolist()]
     width = max(cnts)
     row = torch.zeros((width, C + 4), device=d_feat.device, dtype=torch.float32)          # [d_feat (C) | ndc (3) | pad] -> 16-byte rows
     row[:P, :C] = d_feat
     row[:P, C:C + 3] = ndc
     allrows = torch.empty((world * width, C + 4), device=d_feat.device, dtype=torch.float32)
-    dist.all_gather_into_tensor(allrows, row, group=group)
+    DD.all_gather_into_tensor(allrows, row, group=group)
     for r, n in enumerate(cnts):
         if n == 0:
             continue

@@ -99,6 +99,23 @@ def gen_pts_feats(imgs, volume_feature, rays_pts, pose_ref, rays_ndc, feat_dim, 
     return out
 
 
+_scene = [None]
+
+
+def _scene_views(imgs, pose_ref, V):
+    """(imgs[0], w2cs[:V], intrinsics[:V], channel-last images) of the scene a render loop keeps passing: the three slices / contiguous()
+    calls and the transpose-cache lookup cost ~10 us per rendering() call, more than the 4 kernel launches.  One entry, keyed on the
+    identity and version of the three tensors (the entry holds them, so an id cannot be recycled while it is compared)."""
+    w2cs, K = pose_ref["w2cs"], pose_ref["intrinsics"]
+    hit = _scene[0]
+    if (hit is not None and hit[0] is imgs and hit[1] is w2cs and hit[2] is K and hit[3] == (V, imgs._version, w2cs._version, K._version)):
+        return hit[4]
+    im0 = imgs[0].contiguous()
+    val = (im0, w2cs[:V].contiguous(), K[:V].contiguous(), ops.channels_last_images(im0) if ops.FUSED_GATHER else None)
+    _scene[0] = (imgs, w2cs, K, (V, imgs._version, w2cs._version, K._version), val)
+    return val
+
+
 def rendering(args, pose_ref, rays_pts, rays_ndc, depth_candidates, rays_o, rays_dir,
               volume_feature=None, imgs=None, network_fn=None, img_feat=None, network_query_fn=None, white_bkgd=False, **kwargs):
     """renderer.py:138-165.  Returns (rgb_map, input_feat, weights, depth_map, alpha, {}) - note that the
@@ -122,10 +139,11 @@ def rendering(args, pose_ref, rays_pts, rays_ndc, depth_candidates, rays_o, rays
                                      rays_ndc.contiguous(), depth_candidates.contiguous(), rays_dir.contiguous(), white_bkgd,
                                      dp_samples=getattr(args, "dp_volume_grad", "allreduce") == "samples" and vol.requires_grad)
         else:
-            out = ops.raymarch(ops.channels_last_volume(vol), imgs[0].contiguous(),
-                               pose_ref["w2cs"][:V].contiguous(), pose_ref["intrinsics"][:V].contiguous(),
+            sc = _scene_views(imgs, pose_ref, V)
+            out = ops.raymarch(ops.channels_last_volume(vol), sc[0], sc[1], sc[2],
                                network_fn.packed(args.feat_dim), rays_pts.contiguous(), rays_ndc.contiguous(),
-                               depth_candidates.contiguous(), rays_dir.contiguous(), white_bkgd, **network_fn.packed_alt(args.feat_dim))
+                               depth_candidates.contiguous(), rays_dir.contiguous(), white_bkgd, want=(), imgs_cl=sc[3],
+                               **network_fn.packed_alt(args.feat_dim, fresh=True))
         rendering.last_raw = out["raw"]          # sigma lives in raw[...,3]; kept for parity tests / density queries
         return out["rgb_map"], out["input_feat"], out["weights"], out["depth"], out["alpha"], {}
 
@@ -138,6 +156,29 @@ def rendering(args, pose_ref, rays_pts, rays_ndc, depth_candidates, rays_o, rays
     rendering.last_raw = raw
     rgb_map, _, _, weights, depth_map, alpha = raw2outputs(raw, depth_candidates, None, white_bkgd, args.net_type)
     return rgb_map, input_feat, weights, depth_map, alpha, {}
+
+
+def rendering_batched(args, pose_ref, ray_batches, volume_feature=None, imgs=None, network_fn=None, network_query_fn=None, white_bkgd=False, **kwargs):
+    """K calls of rendering() (renderer.py:138-165) on one scene as ONE host call: ray_batches = [(rays_pts, rays_ndc, depth_candidates, rays_o,
+    rays_dir), ...] (rendering()'s positional ray arguments).  Returns the list of rendering()'s 6-tuples.  No gradients (inference loops:
+    validation_step's chunk loop, notebooks' render loops); an extension - the reference has no such entry, its loop body is rendering()."""
+    from .models import MVSNeRF, RefVolume
+    vol = volume_feature.feat_volume if isinstance(volume_feature, RefVolume) else volume_feature
+    if not (pose_ref is not None and isinstance(network_fn, MVSNeRF) and getattr(network_query_fn, "_mvsnerf_fused", False) and vol is not None):
+        raise NotImplementedError("rendering_batched: the fused configuration only (what create_nerf_mvs builds); call rendering() per batch otherwise")
+    if bool(getattr(args, "use_color_volume", False)):
+        raise NotImplementedError("rendering_batched: use_color_volume renders piecewise - call rendering() per batch")
+    V = imgs.shape[1]
+    if args.feat_dim != 8 + 4 * V:
+        raise RuntimeError(f"args.feat_dim {args.feat_dim} != 8 + 4*V ({V} views)")
+    sc = _scene_views(imgs, pose_ref, V)
+    packed = network_fn.packed(args.feat_dim)
+    outs = ops.raymarch_batched(ops.channels_last_volume(vol), sc[0], sc[1], sc[2], packed,
+                                [(b[0].contiguous(), b[1].contiguous(), b[2].contiguous(), b[4].contiguous()) for b in ray_batches],
+                                white_bkgd, imgs_cl=sc[3], **network_fn.packed_alt(args.feat_dim, fresh=True))
+    if outs:
+        rendering.last_raw = outs[-1]["raw"]
+    return [(o["rgb_map"], o["input_feat"], o["weights"], o["depth"], o["alpha"], {}) for o in outs]
 
 
 def render_density(network_fn, rays_pts, density_feature, network_query_fn, chunk=1024 * 5):

@@ -375,7 +375,7 @@ class MVSSystem(_ModuleShim):
         if not bufs:
             return
         flat = torch.cat([b.reshape(-1) for b in bufs])
-        torch.distributed.broadcast(flat, src=0)
+        D.broadcast(flat, src=0)
         off = 0
         for b in bufs:
             b.copy_(flat[off:off + b.numel()].view_as(b))
@@ -586,7 +586,7 @@ class MVSSystemFinetune(_ModuleShim):
             optimizer.step()
             self.global_step += 1
             if self.args.dp_volume_grad == "samples" and resync > 0 and self.global_step % resync == 0 and D._collective_needed():
-                torch.distributed.broadcast(ops.channels_last_volume(self.volume.feat_volume.data), src=0)     # the (D,H,W,C) view of the same memory
+                D.broadcast(ops.channels_last_volume(self.volume.feat_volume.data), src=0)     # the (D,H,W,C) view of the same memory
             losses.append(out["loss"].detach())
         return [float(l) for l in losses]                                   # one host synchronisation, after the last step is enqueued
 

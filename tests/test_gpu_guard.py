@@ -185,3 +185,34 @@ def test_out_of_range_scene_encode_returns_the_fp32_volume():
     net = build(1.0)
     n0 = ops.guard_fallbacks()
     assert torch.equal(run(net, "auto"), run(net, "fp16x3")) and ops.guard_fallbacks() == n0
+
+
+def test_rendering_batched_equals_per_batch_rendering(net20):
+    """mvsnerf_raymarch_fwd_batched / renderer.rendering_batched: K batches in one host call = K calls of rendering(), bit for bit, in the
+    guarded default and on the fp32 kernels; ragged batch sizes; an empty list is a no-op."""
+    from mvsnerf_amd import ops, renderer as R
+    from mvsnerf_amd.synth import make_rig, pose_ref_of
+    from tests.test_gpu_fp16x3 import _qfn
+    from tests.test_gpu_raymarch import _args
+    from oracle import mvsnerf_oracle as O
+    rig = make_rig(64, 96, seed=11, rot_deg=2.0)
+    pose = pose_ref_of(rig)
+    pose_d = {k: v.to(DEV) for k, v in pose.items()}
+    g = torch.Generator().manual_seed(0)
+    vol = torch.randn((1, 8, 16, 24, 32), generator=g).to(DEV)
+    imgs = rig["images_raw"][:, :3].to(DEV)
+    batches = []
+    for n in (96, 1, 33):
+        pts, dirs, _, ndc, zv, ro, _ = O.build_rays(rig["images_raw"], pose, rig["near_fars"], n, 32, pad=4, t_rand=torch.rand((n, 32), generator=g), generator=g)
+        batches.append(tuple(t.to(DEV) for t in (pts, ndc, zv, ro, dirs)))
+    qfn, _ = _qfn()
+    args = _args(N_samples=32)
+    for mode in ("auto", "fp32"):
+        with ops.mlp_precision(mode), torch.no_grad():
+            one = [R.rendering(args, pose_d, *b, vol, imgs, network_fn=net20, network_query_fn=qfn) for b in batches]
+            many = R.rendering_batched(args, pose_d, batches, vol, imgs, network_fn=net20, network_query_fn=qfn)
+            assert R.rendering_batched(args, pose_d, [], vol, imgs, network_fn=net20, network_query_fn=qfn) == []
+        assert len(many) == len(one)
+        for a, b in zip(one, many):
+            for x, y in zip(a[:5], b[:5]):
+                assert torch.equal(x, y)
