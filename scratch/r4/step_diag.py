@@ -80,9 +80,9 @@ def main():
                 step(i)
             pr.disable()
             torch.cuda.synchronize()
-            if mode in ("bf16x6", "fp16x3"):
+            if mode in ("auto",):
                 sio = io.StringIO()
-                pstats.Stats(pr, stream=sio).sort_stats("cumulative").print_stats(14)
+                pstats.Stats(pr, stream=sio).sort_stats("cumulative").print_stats(22)
                 print(sio.getvalue()[:3500])
     ops.set_mlp_precision("fp32")
 
