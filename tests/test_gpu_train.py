@@ -231,7 +231,7 @@ def test_use_amp_training_step_runs_bf16_and_learns():
         out["loss"].backward()
         losses[amp] = float(out["loss"].detach())
         assert all(p.grad is None or p.grad.dtype == torch.float32 for p in sys_.parameters())
-        assert ops.MLP_PRECISION == "fp32"                       # the switch is scoped to the step
+        assert ops.MLP_PRECISION == "auto"                       # the switch is scoped to the step (back to the library default)
         if amp:
             torch.manual_seed(6)
             hist = sys_.fit_steps([batch] * 12)
