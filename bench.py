@@ -474,8 +474,9 @@ def main():
             raw = torch.empty((N_RAYS, N_SAMPLES, 4), device=dev)
             outs = [torch.empty(sh, device=dev) for sh in ((N_RAYS, 3), (N_RAYS,), (N_RAYS,), (N_RAYS, N_SAMPLES), (N_RAYS,), (N_RAYS, N_SAMPLES))]
             # raw C-ABI calls with pre-allocated outputs (capturable into a hipGraph)
-            k_vol = lambda: lib.mvsnerf_volume_sample_fwd(vol_cl.data_ptr(), vol_cl.shape[0], vol_cl.shape[1], vol_cl.shape[2], 8, ndc.data_ptr(), P,
-                                                          feat.data_ptr(), F, st().cuda_stream)
+            vol_p, vol_l = ops.vol_ptr_layout(vol_cl)          # the encoder's volume: depth-fastest (MVSNERF_VOL_HWDC)
+            k_vol = lambda: lib.mvsnerf_volume_sample_fwd(vol_p, vol_cl.shape[0], vol_cl.shape[1], vol_cl.shape[2], 8, ndc.data_ptr(), P,
+                                                          feat.data_ptr(), F, vol_l, st().cuda_stream)
             k_col = lambda: lib.mvsnerf_color_sample_fwd(src[0].data_ptr(), N_SRC, H_IMG, W_IMG, w2c3.data_ptr(), k3.data_ptr(), pts.data_ptr(), P, 1,
                                                          feat.data_ptr() + 32, F, st().cuda_stream)
             k_mlp = lambda: lib.mvsnerf_mlp_fwd(packed.data_ptr(), F, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3, N_RAYS, N_SAMPLES, 0,
@@ -483,9 +484,9 @@ def main():
             k_cmp = lambda: lib.mvsnerf_composite_fwd(raw.data_ptr(), z.data_ptr(), N_RAYS, N_SAMPLES, 0, *[o.data_ptr() for o in outs], st().cuda_stream)
             icl = ops.channels_last_images(src[0])
             dirs_g = torch.empty_like(dirs)
-            k_gat = lambda: lib.mvsnerf_gather_fwd(vol_cl.data_ptr(), vol_cl.shape[0], vol_cl.shape[1], vol_cl.shape[2], icl.data_ptr(), N_SRC, H_IMG, W_IMG,
+            k_gat = lambda: lib.mvsnerf_gather_fwd(vol_p, vol_cl.shape[0], vol_cl.shape[1], vol_cl.shape[2], icl.data_ptr(), N_SRC, H_IMG, W_IMG,
                                                    w2c3.data_ptr(), k3.data_ptr(), pts.data_ptr(), ndc.data_ptr(), N_RAYS, N_SAMPLES, rdir.data_ptr(),
-                                                   feat.data_ptr(), F, dirs_g.data_ptr(), st().cuda_stream)
+                                                   feat.data_ptr(), F, dirs_g.data_ptr(), vol_l, st().cuda_stream)
             t_gat = event_time(k_gat, 400, graph_batch=40)
             t_vol = event_time(k_vol, 400, graph_batch=40)
             t_col = event_time(k_col, 400, graph_batch=40)
@@ -545,7 +546,7 @@ def main():
             from oracle import mvsnerf_oracle as O
             sd = load_mlp_weights()
             cpose = {k: v.cpu() for k, v in pose.items()}
-            cvol = ops.ndhwc_to_ncdhw(ops.channels_last_volume(vol))[None].cpu()
+            cvol = vol.detach().cpu().contiguous()               # the logical (1,8,D,h,w) tensor, reference layout, for the CPU oracle
             cb = [tuple(t.cpu() for t in b) for b in batches[:4]]
             csrc = src.cpu()
             n_default = torch.get_num_threads()

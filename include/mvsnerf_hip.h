@@ -32,6 +32,16 @@ extern "C" {
 #define MVSNERF_EUNSUPPORTED (-2) /* shape outside what the kernels are specialised for */
 #define MVSNERF_EALIGN (-3)  /* pointer not 16-byte aligned where required */
 
+/* Memory order of a neural volume handed to the ray-march entries (ABI v10).
+ *   MVSNERF_VOL_DHWC  vol[d][y][x][c]  what the reference's NCDHW tensor becomes with one transpose (mvsnerf_ncdhw_to_ndhwc); learnable
+ *                     volumes (RefVolume) keep it, and so do volume GRADIENTS in every case.
+ *   MVSNERF_VOL_HWDC  vol[y][x][d][c]  depth fastest: what the scene encoder emits (mvsnerf_abn_apply_add_hwdc).  The samples of a ray
+ *                     walk depth, so the consecutive samples of a ray read ONE contiguous run of voxels per (y, x) column instead of a
+ *                     64-byte piece of a different 128-byte line per depth plane: the lookup's memory-side traffic halves.
+ * Both describe the same logical (C, D, H, W) tensor; results are bit-identical. */
+#define MVSNERF_VOL_DHWC 0
+#define MVSNERF_VOL_HWDC 1
+
 /* ABI version; bumped on any signature change. */
 int mvsnerf_abi_version(void);
 
@@ -200,6 +210,12 @@ int mvsnerf_abn_stats(const float* x, int64_t n_vox, int C, const float* weight,
 int mvsnerf_abn_apply_add(const float* x1, const float* scale1, const float* shift1,
                           const float* x2, const float* scale2, const float* shift2,
                           int64_t n_vox, int C, float* out, void* stream);
+/* The same sum for the 8-channel neural volume (conv0 + conv11(x), models.py:766), WRITTEN depth-fastest: x1, x2 [D][H][W][8] ->
+ * out[H][W][D][8] (MVSNERF_VOL_HWDC: what the ray march reads best).  Tiles of 32 depth planes x 16 columns go through LDS, so that
+ * both the reads (along x) and the writes (along depth) are contiguous runs. */
+int mvsnerf_abn_apply_add_hwdc(const float* x1, const float* scale1, const float* shift1,
+                               const float* x2, const float* scale2, const float* shift2,
+                               int D, int H, int W, float* out, void* stream);
 
 /* ---- encoder backward (generalizable training, train_mvs_nerf_pl.py:104-168) ----
  * Data gradients of the convolutions reuse the forward kernels with re-packed weights (mvsnerf_conv3d_pack_weights:
@@ -297,11 +313,12 @@ int mvsnerf_raygen_train_fwd(const float* xs, const float* ys, int W_img, int H_
 
 /* Trilinear lookup of the channel-last volume: replaces F.grid_sample 5-D in
  * utils.py:357-383 (index_point_feature) and models.py:941-950 (RefVolume.forward).
- * vol[D][H][W][C] (C == 8); ndc[P][3] = (x->W, y->H, z->D) in [0,1]; zeros padding, align_corners=True.
- * out[p*out_stride + c], c < C  (out_stride lets it write the first 8 columns of input_feat). */
+ * vol: C channels per voxel in the memory order `vol_layout` (MVSNERF_VOL_DHWC / MVSNERF_VOL_HWDC); ndc[P][3] = (x->W, y->H, z->D) in
+ * [0,1]; zeros padding, align_corners=True.  out[p*out_stride + c], c < C  (out_stride lets it write the first 8 columns of input_feat).
+ * C == 8 with 16-byte aligned rows takes the four-lanes-per-sample kernels; the same bits in either layout. */
 int mvsnerf_volume_sample_fwd(const float* vol, int D, int H, int W, int C,
                               const float* ndc, int64_t P,
-                              float* out, int out_stride, void* stream);
+                              float* out, int out_stride, int vol_layout, void* stream);
 
 /* Per-view colour lookup: replaces utils.py:300-332 (build_color_volume, img_feat=None) including
  * get_ndc_coordinate (utils.py:112-146) for each source view.
@@ -334,7 +351,7 @@ int mvsnerf_dir_feature_fwd(const float* rays_dir, const float* w2c_ref, int64_t
  * Results are bit-identical to volume_sample_fwd / color_sample_fwd(with_mask=1) / dir_feature_fwd(normalize=1). */
 int mvsnerf_gather_fwd(const float* vol, int D, int H, int W, const float* imgs_nhwc4, int V, int IH, int IW,
                        const float* w2c, const float* K, const float* pts, const float* ndc, int64_t N, int S,
-                       const float* rays_dir, float* feat, int feat_stride, float* dirs_out, void* stream);
+                       const float* rays_dir, float* feat, int feat_stride, float* dirs_out, int vol_layout, void* stream);
 
 /* Stand-alone positional encoding, Embedder.embed (models.py:47-51): x[P][d] ->
  * out[P][d*(1+2L)] = [x | sin(x_c*2^f), f-major | cos(...)].  The MLP kernel below embeds internally;
@@ -462,6 +479,7 @@ typedef struct {
                                                same images and ONE fused gather launch (mvsnerf_gather_fwd) (ABI v3) */
     const void* packed_mlp_split; int n_split;   /* NULL/0, or mvsnerf_mlp_pack_split output: split-bf16 MLP (ABI v5) */
     int* guard;                             /* NULL, or a guard word pair with n_split = MVSNERF_SPLIT_FP16: the guarded sequence below (ABI v10) */
+    int vol_layout;                         /* MVSNERF_VOL_DHWC (0) / MVSNERF_VOL_HWDC: memory order of `vol` (ABI v10) */
 } mvsnerf_raymarch_args;
 int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream);
 /* K independent ray batches (the K iterations of a render loop over renderer.py:138-165) enqueued by ONE host call: a[0..K) are complete argument
@@ -560,6 +578,7 @@ typedef struct {
     float* rgb; float* depth; float* acc; float* disp;      /* rgb required, others may be NULL */
     const void* packed_mlp_split; int n_split;              /* NULL/0, or mvsnerf_mlp_pack_split output (ABI v5) */
     int* guard;                                             /* NULL, or guard words with n_split = MVSNERF_SPLIT_FP16: every sub-batch is a guarded sequence (ABI v10) */
+    int vol_layout;                                         /* memory order of `vol` (ABI v10) */
 } mvsnerf_render_args;
 size_t mvsnerf_render_workspace_floats(int batch_rays, int S, int V);
 int mvsnerf_render_pixels_fwd(const mvsnerf_render_args* a, void* stream);
@@ -572,7 +591,7 @@ int mvsnerf_render_pixels_fwd(const mvsnerf_render_args* a, void* stream);
  * bf16 != 0 selects the bf16-MFMA MLP kernels (packed_mlp_bf16 / packed_bwd = the bf16 packs), else fp32.
  * Gradient inputs g_* may be NULL (= zero).  gvol == NULL skips the volume gradient (frozen volume); it must be zero-initialised. */
 typedef struct {
-    const float* vol; int D, H, W, C;       /* [D][H][W][C], C = 8 or 8+4V (--use_color_volume) */
+    const float* vol; int D, H, W, C;       /* C = 8 or 8+4V (--use_color_volume) channels per voxel, memory order vol_layout */
     const float* imgs_nhwc4; int V, IH, IW; /* [V][IH][IW][4]; unused when C == 8+4V */
     const float* w2c; const float* K;       /* [V][4][4], [V][3][3] */
     const float* packed_mlp; const void* packed_mlp_bf16; int bf16;
@@ -583,6 +602,7 @@ typedef struct {
     float* raw;                             /* [N][S][4] */
     float* saved;                           /* mvsnerf_mlp_saved_floats(N*S) */
     float* rgb_map; float* disp; float* acc; float* weights; float* depth; float* alpha;
+    int vol_layout;                         /* memory order of `vol` (ABI v10); the gradient volume of mvsnerf_raymarch_bwd is DHWC in either case */
 } mvsnerf_raymarch_train_args;
 int mvsnerf_raymarch_train_fwd(const mvsnerf_raymarch_train_args* a, void* stream);
 

@@ -28,7 +28,7 @@ class RaymarchArgs(ctypes.Structure):
         ("N", _c_l), ("S", _c_i), ("white_bkgd", _c_i),
         ("dirs_tmp", _c_fp), ("input_feat", _c_fp), ("raw", _c_fp),
         ("rgb_map", _c_fp), ("disp", _c_fp), ("acc", _c_fp), ("weights", _c_fp), ("depth", _c_fp), ("alpha", _c_fp),
-        ("packed_mlp_bf16", _c_fp), ("imgs_nhwc4", _c_fp), ("packed_mlp_split", _c_fp), ("n_split", _c_i), ("guard", _c_fp),
+        ("packed_mlp_bf16", _c_fp), ("imgs_nhwc4", _c_fp), ("packed_mlp_split", _c_fp), ("n_split", _c_i), ("guard", _c_fp), ("vol_layout", _c_i),
     ]
 
 
@@ -41,7 +41,7 @@ class RaymarchTrainArgs(ctypes.Structure):
         ("rays_pts", _c_fp), ("rays_ndc", _c_fp), ("z_vals", _c_fp), ("rays_dir", _c_fp),
         ("N", _c_l), ("S", _c_i), ("white_bkgd", _c_i),
         ("dirs_tmp", _c_fp), ("input_feat", _c_fp), ("raw", _c_fp), ("saved", _c_fp),
-        ("rgb_map", _c_fp), ("disp", _c_fp), ("acc", _c_fp), ("weights", _c_fp), ("depth", _c_fp), ("alpha", _c_fp),
+        ("rgb_map", _c_fp), ("disp", _c_fp), ("acc", _c_fp), ("weights", _c_fp), ("depth", _c_fp), ("alpha", _c_fp), ("vol_layout", _c_i),
     ]
 
 
@@ -69,7 +69,7 @@ class RenderArgs(ctypes.Structure):
         ("first_pixel", _c_l), ("n_pixels", _c_l),
         ("S", _c_i), ("white_bkgd", _c_i), ("batch_rays", _c_i),
         ("workspace", _c_fp), ("workspace_floats", ctypes.c_size_t),
-        ("rgb", _c_fp), ("depth", _c_fp), ("acc", _c_fp), ("disp", _c_fp), ("packed_mlp_split", _c_fp), ("n_split", _c_i), ("guard", _c_fp),
+        ("rgb", _c_fp), ("depth", _c_fp), ("acc", _c_fp), ("disp", _c_fp), ("packed_mlp_split", _c_fp), ("n_split", _c_i), ("guard", _c_fp), ("vol_layout", _c_i),
     ]
 
 
@@ -155,11 +155,12 @@ SIGNATURES = {
     "mvsnerf_ray_points_fwd": (_c_i, [_c_fp, _c_i, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_l, _c_i, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_render_workspace_floats": (ctypes.c_size_t, [_c_i, _c_i, _c_i]),
     "mvsnerf_render_pixels_fwd": (_c_i, [ctypes.POINTER(RenderArgs), _c_fp]),
-    "mvsnerf_gather_fwd": (_c_i, [_c_fp] + [_c_i] * 3 + [_c_fp] + [_c_i] * 3 + [_c_fp] * 4 + [_c_l, _c_i, _c_fp, _c_fp, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_gather_fwd": (_c_i, [_c_fp] + [_c_i] * 3 + [_c_fp] + [_c_i] * 3 + [_c_fp] * 4 + [_c_l, _c_i, _c_fp, _c_fp, _c_i, _c_fp, _c_i, _c_fp]),
     "mvsnerf_abn_apply_add": (_c_i, [_c_fp] * 6 + [_c_l, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_abn_apply_add_hwdc": (_c_i, [_c_fp] * 6 + [_c_i, _c_i, _c_i, _c_fp, _c_fp]),
     "mvsnerf_raygen_fwd": (_c_i, [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i] + [_c_fp] * 6 + [_c_i, _c_i, _c_fp, _c_l, _c_i] + [_c_fp] * 6),
     "mvsnerf_raygen_train_fwd": (_c_i, [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i] + [_c_fp] * 6 + [_c_i, _c_i, _c_fp, _c_l, _c_i] + [_c_fp] * 3 + [_c_i] + [_c_fp] * 8),
-    "mvsnerf_volume_sample_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_l, _c_fp, _c_i, _c_fp]),
+    "mvsnerf_volume_sample_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_l, _c_fp, _c_i, _c_i, _c_fp]),
     "mvsnerf_color_sample_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_i, _c_fp]),
     "mvsnerf_color_feat_sample_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_i, _c_fp]),
     "mvsnerf_dir_feature_fwd": (_c_i, [_c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp]),

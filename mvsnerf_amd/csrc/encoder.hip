@@ -1167,6 +1167,66 @@ extern "C" int mvsnerf_abn_apply_add(const float* x1, const float* scale1, const
     return MVSNERF_OK;
 }
 
+// The 8-channel sum of two lazily-activated tensors, written DEPTH-FASTEST: a, b [D][H][W][8] -> out[H][W][D][8] (MVSNERF_VOL_HWDC, the
+// layout the ray march reads best: sample_dev.h).  A workgroup owns a tile of 32 depth planes x 16 x-columns of one row y: it reads 32
+// runs of 512 B (along x), applies leaky(x * scale + shift) to both operands, adds, parks the tile in LDS and writes 16 runs of 1 KB (along
+// depth).  Both sides of the transpose are contiguous; nothing else differs from abn_apply_add_kernel (same operation order per element).
+__global__ __launch_bounds__(256) void abn_apply_add_hwdc_kernel(ActSrc a, ActSrc b, int D, int H, int W, float* __restrict__ out)
+{
+    constexpr int TZ = 32, TX = 16, ROW = TX * 8 + 8;             // LDS row of a depth plane: 128 floats + 8 pad (spreads the column reads over the banks)
+    __shared__ __attribute__((aligned(16))) float tile[TZ * ROW];
+    const int nbx = (W + TX - 1) / TX, nbz = (D + TZ - 1) / TZ;
+    const int bx = blockIdx.x % nbx, bz = (blockIdx.x / nbx) % nbz, y = blockIdx.x / (nbx * nbz);
+    const int x0 = bx * TX, z0 = bz * TZ;
+    const int tid = threadIdx.x;
+    const int c4 = (tid & 1) * 4;                                  // this thread's channel quad, in both phases
+    f32x4 sa, ha, sb = {0, 0, 0, 0}, hb = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sa[k] = a.scale[c4 + k]; ha[k] = a.shift[c4 + k]; if (b.x) { sb[k] = b.scale[c4 + k]; hb[k] = b.shift[c4 + k]; } }
+    // phase 1: float4 number f of the tile = (plane f / 32, column (f % 32) / 2, quad f % 2): consecutive threads read consecutive 16 bytes
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int f = tid + 256 * r, zi = f >> 5, xi = (f & 31) >> 1;
+        const int z = z0 + zi, x = x0 + xi;
+        if (z < D && x < W) {
+            const int64_t at = ((((int64_t)z * H + y) * W + x) << 3) + c4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(a.x + at);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = act_apply(v[k], sa[k], ha[k]);
+            if (b.x) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(b.x + at);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += act_apply(t[k], sb[k], hb[k]);
+            }
+            *reinterpret_cast<f32x4*>(tile + zi * ROW + xi * 8 + c4) = v;
+        }
+    }
+    __syncthreads();
+    // phase 2: float4 number f = (column f / 64, plane (f % 64) / 2, quad f % 2): consecutive threads write consecutive 16 bytes of a column's run
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int f = tid + 256 * r, xi = f >> 6, zi = (f & 63) >> 1;
+        const int z = z0 + zi, x = x0 + xi;
+        if (z < D && x < W)
+            *reinterpret_cast<f32x4*>(out + (((((int64_t)y * W + x) * D + z) << 3) + c4)) = *reinterpret_cast<const f32x4*>(tile + zi * ROW + xi * 8 + c4);
+    }
+}
+
+extern "C" int mvsnerf_abn_apply_add_hwdc(const float* x1, const float* scale1, const float* shift1,
+                                          const float* x2, const float* scale2, const float* shift2,
+                                          int D, int H, int W, float* out, void* stream)
+{
+    if (!x1 || !scale1 || !shift1 || !out || D < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
+    if (x2 && (!scale2 || !shift2)) return MVSNERF_EINVAL;
+    if (!mvs_aligned16(x1) || !mvs_aligned16(out) || (x2 && !mvs_aligned16(x2))) return MVSNERF_EALIGN;
+    const ActSrc a{x1, scale1, shift1}, b{x2, scale2, shift2};
+    const int64_t nblk = (int64_t)((W + 15) / 16) * ((D + 31) / 32) * H;
+    if (nblk >= ((int64_t)1 << 31)) return MVSNERF_EUNSUPPORTED;
+    abn_apply_add_hwdc_kernel<<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(a, b, D, H, W, out);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
 // =============================================================================================
 // BACKWARD of the encoder (generalizable training, train_mvs_nerf_pl.py:104-168)
 // =============================================================================================

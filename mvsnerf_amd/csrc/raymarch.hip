@@ -49,12 +49,12 @@ extern "C" int mvsnerf_raymarch_fwd(const mvsnerf_raymarch_args* a, void* stream
     if (a->imgs_nhwc4) {
         // gen_dir_feature + gen_pts_feats in one launch (channel-last source images supplied by the caller)
         if ((rc = mvsnerf_gather_fwd(a->vol, a->D, a->H, a->W, a->imgs_nhwc4, a->V, a->IH, a->IW, a->w2c, a->K, a->rays_pts, a->rays_ndc,
-                                     a->N, a->S, a->rays_dir, a->input_feat, F, a->dirs_tmp, stream))) return rc;
+                                     a->N, a->S, a->rays_dir, a->input_feat, F, a->dirs_tmp, a->vol_layout, stream))) return rc;
     } else {
         // view-direction feature in the reference camera frame (renderer.py:142-147)
         if ((rc = mvsnerf_dir_feature_fwd(a->rays_dir, a->w2c, a->N, 1, a->dirs_tmp, stream))) return rc;
         // gen_pts_feats (renderer.py:124-136): input_feat[..., :8] = volume lookup, [..., 8:] = colours + masks
-        if ((rc = mvsnerf_volume_sample_fwd(a->vol, a->D, a->H, a->W, 8, a->rays_ndc, P, a->input_feat, F, stream))) return rc;
+        if ((rc = mvsnerf_volume_sample_fwd(a->vol, a->D, a->H, a->W, 8, a->rays_ndc, P, a->input_feat, F, a->vol_layout, stream))) return rc;
         if ((rc = mvsnerf_color_sample_fwd(a->imgs, a->V, a->IH, a->IW, a->w2c, a->K, a->rays_pts, P, 1, a->input_feat + 8, F, stream))) return rc;
     }
     // network_query_fn (renderer.py:156 -> run_network_mvs 42-63)
@@ -132,7 +132,7 @@ extern "C" int mvsnerf_render_pixels_fwd(const mvsnerf_render_args* a, void* str
         if ((rc = mvsnerf_raygen_fwd(nullptr, nullptr, a->first_pixel + off, a->W_img, a->H_img, a->W_ref, a->H_ref, a->K_tgt, a->c2w_tgt, a->K_ref, a->w2c_ref,
                                      a->near_far_tgt, a->near_far_ref, a->pad, a->lindisp, nullptr, n, S, pts, rdir, ndc, z, nullptr, stream))) return rc;
         if ((rc = mvsnerf_gather_fwd(a->vol, a->D, a->H, a->W, a->imgs_nhwc4, a->V, a->IH, a->IW, a->w2c, a->K, pts, ndc, n, S, rdir,
-                                     feat, F, dirs, stream))) return rc;
+                                     feat, F, dirs, a->vol_layout, stream))) return rc;
         if (guarded)
             rc = mlp_guarded_pair(a->packed_mlp_split, a->packed_mlp, F, ndc, 3, feat, F, dirs, 3, n, S, 0, raw, a->guard, stream);
         else if (a->packed_mlp_split)
@@ -165,11 +165,11 @@ extern "C" int mvsnerf_raymarch_train_fwd(const mvsnerf_raymarch_train_args* a, 
     if (a->C == F && a->C != 8) {
         // --use_color_volume (renderer.py:134-135): the volume already holds the projected colours
         if ((rc = mvsnerf_dir_feature_fwd(a->rays_dir, a->w2c, a->N, 1, a->dirs_tmp, stream))) return rc;
-        if ((rc = mvsnerf_volume_sample_fwd(a->vol, a->D, a->H, a->W, a->C, a->rays_ndc, P, a->input_feat, F, stream))) return rc;
+        if ((rc = mvsnerf_volume_sample_fwd(a->vol, a->D, a->H, a->W, a->C, a->rays_ndc, P, a->input_feat, F, a->vol_layout, stream))) return rc;
     } else if (a->C == 8) {
         if (!a->imgs_nhwc4 || !a->K || !a->rays_pts) return MVSNERF_EINVAL;
         if ((rc = mvsnerf_gather_fwd(a->vol, a->D, a->H, a->W, a->imgs_nhwc4, a->V, a->IH, a->IW, a->w2c, a->K, a->rays_pts, a->rays_ndc,
-                                     a->N, a->S, a->rays_dir, a->input_feat, F, a->dirs_tmp, stream))) return rc;
+                                     a->N, a->S, a->rays_dir, a->input_feat, F, a->dirs_tmp, a->vol_layout, stream))) return rc;
     } else {
         return MVSNERF_EUNSUPPORTED;
     }

@@ -1,8 +1,9 @@
 // Gather kernels of the ray march: trilinear volume lookup, per-view colour lookup, view-direction
 // feature, and the NCDHW<->NDHWC boundary transposes.  All HBM/L2-bound; no MFMA.
 //
-// Layout: volume is channel-last vol[d][y][x][8] so that one trilinear corner = one 32-byte sector
-// and the two x-neighbours of a corner pair are one 64-byte contiguous read.
+// Layouts (include/mvsnerf_hip.h): MVSNERF_VOL_DHWC vol[d][y][x][8] - one trilinear corner = one 32-byte sector, the two x-neighbours of
+// a corner pair one 64-byte read - and MVSNERF_VOL_HWDC vol[y][x][d][8], depth fastest: what the encoder emits, because the samples of a ray
+// walk depth (the `_zfast` kernels below; sample_dev.h).  Same arithmetic, same bits.
 #include "common.h"
 #include "sample_dev.h"
 #include <type_traits>
@@ -66,10 +67,31 @@ __global__ __launch_bounds__(256) void volume_sample_c8_kernel(
     }
 }
 
-// Generic-C fallback of the same op (C != 8, e.g. colour volumes): one thread per (sample, channel).
+// ---------------------------------------------------------------------------------------------
+// The same lookup on a depth-fastest volume (MVSNERF_VOL_HWDC, sample_dev.h): four lanes per sample, lane = (y, x) column.
+// ---------------------------------------------------------------------------------------------
+template <bool SMALL>
+__global__ __launch_bounds__(256) void volume_sample_c8_zfast_kernel(
+    const float* __restrict__ vol, int D, int H, int W,
+    const float* __restrict__ ndc, int64_t P, float* __restrict__ out, int out_stride)
+{
+#pragma clang fp contract(off)
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = (int)(tid & 3);
+    const int64_t p = tid >> 2;
+    const int64_t pc = p < P ? p : (P - 1);
+    typedef float f32x3 __attribute__((ext_vector_type(3)));
+    const f32x3 nd = *reinterpret_cast<const f32x3*>(ndc + pc * 3);
+    const ZfastTaps t = zfast_taps<SMALL>(vol, D, H, W, nd[0], nd[1], nd[2], q);
+    f32x4 lo, hi;
+    zfast_fold(t, lo, hi);
+    if (p < P && q < 2) *reinterpret_cast<f32x4*>(out + p * out_stride + q * 4) = q ? hi : lo;
+}
+
+// Generic-C fallback of the same op (C != 8, e.g. colour volumes): one thread per (sample, channel); either layout.
 __global__ __launch_bounds__(256) void volume_sample_generic_kernel(
     const float* __restrict__ vol, int D, int H, int W, int C,
-    const float* __restrict__ ndc, int64_t P, float* __restrict__ out, int out_stride)
+    const float* __restrict__ ndc, int64_t P, float* __restrict__ out, int out_stride, int zfast)
 {
 #pragma clang fp contract(off)
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -87,24 +109,31 @@ __global__ __launch_bounds__(256) void volume_sample_generic_kernel(
         const float cx = fx + xc, cy = fy + yc, cz = fz + zc;
         const float w = ((xc ? ix - fx : fx + 1.0f - ix) * (yc ? iy - fy : fy + 1.0f - iy)) * (zc ? iz - fz : fz + 1.0f - iz);
         if (cx >= 0.0f && cx <= (float)(W - 1) && cy >= 0.0f && cy <= (float)(H - 1) && cz >= 0.0f && cz <= (float)(D - 1))
-            acc += vol[((((int64_t)cz * H + (int)cy) * W + (int)cx)) * C + c] * w;
+            acc += vol[(zfast ? (((int64_t)cy * W + (int)cx) * D + (int)cz) : (((int64_t)cz * H + (int)cy) * W + (int)cx)) * C + c] * w;
     }
     out[p * out_stride + c] = acc;
 }
 
 extern "C" int mvsnerf_volume_sample_fwd(const float* vol, int D, int H, int W, int C,
-                                         const float* ndc, int64_t P, float* out, int out_stride, void* stream)
+                                         const float* ndc, int64_t P, float* out, int out_stride, int vol_layout, void* stream)
 {
     if (!vol || !ndc || !out || D < 1 || H < 1 || W < 1 || C < 1 || P < 0 || out_stride < C) return MVSNERF_EINVAL;
+    if (vol_layout != MVSNERF_VOL_DHWC && vol_layout != MVSNERF_VOL_HWDC) return MVSNERF_EINVAL;
     if (P == 0) return MVSNERF_OK;
     hipStream_t st = (hipStream_t)stream;
     if (C == 8 && !mvs_aligned16(vol)) return MVSNERF_EALIGN;
     if (C == 8 && !(out_stride & 3) && mvs_aligned16(out)) {      // 16-byte row stores; rows of another stride take the per-channel kernel (same bits)
-        const bool small = (int64_t)D * H < (1 << 24) && W < (1 << 24) && (int64_t)D * H * W * 8 < ((int64_t)1 << 31);
-        if (small) volume_sample_c8_kernel<1, true><<<mvs_cdiv(P * 4, 256), 256, 0, st>>>(vol, D, H, W, ndc, P, out, out_stride);
-        else volume_sample_c8_kernel<1, false><<<mvs_cdiv(P * 4, 256), 256, 0, st>>>(vol, D, H, W, ndc, P, out, out_stride);
+        const bool small = (int64_t)D * H < (1 << 24) && W < (1 << 24) && (int64_t)H * W < (1 << 24) && D < (1 << 24) && (int64_t)D * H * W * 8 < ((int64_t)1 << 31);
+        const unsigned grid = mvs_cdiv(P * 4, 256);
+        if (vol_layout == MVSNERF_VOL_HWDC) {
+            if (small) volume_sample_c8_zfast_kernel<true><<<grid, 256, 0, st>>>(vol, D, H, W, ndc, P, out, out_stride);
+            else volume_sample_c8_zfast_kernel<false><<<grid, 256, 0, st>>>(vol, D, H, W, ndc, P, out, out_stride);
+        } else {
+            if (small) volume_sample_c8_kernel<1, true><<<grid, 256, 0, st>>>(vol, D, H, W, ndc, P, out, out_stride);
+            else volume_sample_c8_kernel<1, false><<<grid, 256, 0, st>>>(vol, D, H, W, ndc, P, out, out_stride);
+        }
     } else {
-        volume_sample_generic_kernel<<<mvs_cdiv(P * C, 256), 256, 0, st>>>(vol, D, H, W, C, ndc, P, out, out_stride);
+        volume_sample_generic_kernel<<<mvs_cdiv(P * C, 256), 256, 0, st>>>(vol, D, H, W, C, ndc, P, out, out_stride, vol_layout == MVSNERF_VOL_HWDC);
     }
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
@@ -241,7 +270,7 @@ struct GatherArgs {
     float* feat; int feat_stride; float* dirs_out;
 };
 
-template <bool SMALL>
+template <bool SMALL, bool ZFAST>      // ZFAST: the volume is depth-fastest (MVSNERF_VOL_HWDC): lane = (y, x) column, see sample_dev.h
 __global__ __launch_bounds__(256) void gather_fused_kernel(GatherArgs a)
 {
 #pragma clang fp contract(off)
@@ -252,28 +281,33 @@ __global__ __launch_bounds__(256) void gather_fused_kernel(GatherArgs a)
     using idx_t = typename std::conditional<SMALL, unsigned, int64_t>::type;      // SMALL: sample offsets fit 32 bits (checked by the launcher)
     const idx_t p = (idx_t)(live ? p_raw : a.P - 1);
     const int D = a.D, H = a.H, W = a.W;
-    // ---- trilinear volume lookup (identical to volume_sample_c8_kernel<1>)
+    // ---- trilinear volume lookup (identical to volume_sample_c8_kernel<1> / volume_sample_c8_zfast_kernel)
     const int xc = q >> 1, ch = (q & 1) * 4;
-    const float gx = a.ndc[p * 3 + 0] * 2.0f - 1.0f;
-    const float gy = a.ndc[p * 3 + 1] * 2.0f - 1.0f;
-    const float gz = a.ndc[p * 3 + 2] * 2.0f - 1.0f;
-    const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
-    const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
-    const float iz = ((gz + 1.0f) / 2.0f) * (float)(D - 1);
-    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-    const float wx = xc ? (ix - fx) : ((fx + 1.0f) - ix);
-    const float cxf = fx + (float)xc;
-    const bool x_in = (cxf >= 0.0f) && (cxf <= (float)(W - 1));
     f32x4 vv[4];
     float vw[4];
+    ZfastTaps zt;
+    if constexpr (ZFAST) {
+        zt = zfast_taps<SMALL>(a.vol, D, H, W, a.ndc[p * 3 + 0], a.ndc[p * 3 + 1], a.ndc[p * 3 + 2], q);
+    } else {
+        const float gx = a.ndc[p * 3 + 0] * 2.0f - 1.0f;
+        const float gy = a.ndc[p * 3 + 1] * 2.0f - 1.0f;
+        const float gz = a.ndc[p * 3 + 2] * 2.0f - 1.0f;
+        const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+        const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+        const float iz = ((gz + 1.0f) / 2.0f) * (float)(D - 1);
+        const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+        const float wx = xc ? (ix - fx) : ((fx + 1.0f) - ix);
+        const float cxf = fx + (float)xc;
+        const bool x_in = (cxf >= 0.0f) && (cxf <= (float)(W - 1));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int zc = k >> 1, yc = k & 1;
-        const float cyf = fy + (float)yc, czf = fz + (float)zc;
-        const bool in = x_in && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
-        vw[k] = (wx * (yc ? (iy - fy) : ((fy + 1.0f) - iy))) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
-        const float* src = in ? a.vol + vox_off8<SMALL>((int)czf, (int)cyf, (int)cxf, H, W) + ch : reinterpret_cast<const float*>(&g_zero_tap);
-        vv[k] = ldg16(src);
+        for (int k = 0; k < 4; ++k) {
+            const int zc = k >> 1, yc = k & 1;
+            const float cyf = fy + (float)yc, czf = fz + (float)zc;
+            const bool in = x_in && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
+            vw[k] = (wx * (yc ? (iy - fy) : ((fy + 1.0f) - iy))) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
+            const float* src = in ? a.vol + vox_off8<SMALL>((int)czf, (int)cyf, (int)cxf, H, W) + ch : reinterpret_cast<const float*>(&g_zero_tap);
+            vv[k] = ldg16(src);
+        }
     }
     // ---- colour lookup of view q (+4): issue its taps before the volume taps are consumed
     typedef float f32x3 __attribute__((ext_vector_type(3)));
@@ -295,9 +329,15 @@ __global__ __launch_bounds__(256) void gather_fused_kernel(GatherArgs a)
         o[3] = color_mask(t);
         if (live) *reinterpret_cast<f32x4*>(frow + 8 + 4 * v) = o;
     }
-    // ---- fold the volume taps in ATen's term order and roundings (sample_dev.h: the sum is valid in the x0 lanes)
-    const f32x4 acc = trilinear_fold_x0_lane(vv, vw);
-    if (live && xc == 0) *reinterpret_cast<f32x4*>(frow + ch) = acc;
+    // ---- fold the volume taps in ATen's term order and roundings (sample_dev.h)
+    if constexpr (ZFAST) {
+        f32x4 lo, hi;
+        zfast_fold(zt, lo, hi);                                                   // all four lanes hold all eight sums
+        if (live && q < 2) *reinterpret_cast<f32x4*>(frow + q * 4) = q ? hi : lo;
+    } else {
+        const f32x4 acc = trilinear_fold_x0_lane(vv, vw);                         // valid in the x0 lanes
+        if (live && xc == 0) *reinterpret_cast<f32x4*>(frow + ch) = acc;
+    }
     // ---- view-direction feature: lane 3 of quad number n < N handles ray n (no p / S: a 64-bit division costs every lane of
     // the wave dozens of instruction slots)
     if (q == 3 && a.dirs_out && p_raw < a.N) dir_feature_of(a.rays_dir + p_raw * 3, a.w2c, 1, a.dirs_out + p_raw * 3);   // reference view = view 0
@@ -305,8 +345,9 @@ __global__ __launch_bounds__(256) void gather_fused_kernel(GatherArgs a)
 
 extern "C" int mvsnerf_gather_fwd(const float* vol, int D, int H, int W, const float* imgs_nhwc4, int V, int IH, int IW,
                                   const float* w2c, const float* K, const float* pts, const float* ndc, int64_t N, int S,
-                                  const float* rays_dir, float* feat, int feat_stride, float* dirs_out, void* stream)
+                                  const float* rays_dir, float* feat, int feat_stride, float* dirs_out, int vol_layout, void* stream)
 {
+    if (vol_layout != MVSNERF_VOL_DHWC && vol_layout != MVSNERF_VOL_HWDC) return MVSNERF_EINVAL;
     if (!vol || !imgs_nhwc4 || !w2c || !K || !pts || !ndc || !feat || D < 1 || H < 1 || W < 1 || V < 1 || IH < 2 || IW < 2 || N < 0 || S < 1)
         return MVSNERF_EINVAL;
     if (dirs_out && !rays_dir) return MVSNERF_EINVAL;
@@ -315,11 +356,18 @@ extern "C" int mvsnerf_gather_fwd(const float* vol, int D, int H, int W, const f
     if (N == 0) return MVSNERF_OK;
     const int64_t P = N * S;
     const GatherArgs a{vol, D, H, W, imgs_nhwc4, V, IH, IW, w2c, K, pts, ndc, P, N, rays_dir, feat, feat_stride, dirs_out};
-    const bool small = (int64_t)D * H < (1 << 24) && W < (1 << 24) && (int64_t)D * H * W * 8 < ((int64_t)1 << 31) &&
+    const bool small = (int64_t)D * H < (1 << 24) && W < (1 << 24) && (int64_t)H * W < (1 << 24) && D < (1 << 24) && (int64_t)D * H * W * 8 < ((int64_t)1 << 31) &&
                        (int64_t)V * IH < (1 << 24) && IW < (1 << 24) && (int64_t)V * IH * IW * 4 < ((int64_t)1 << 31) &&
                        P * (int64_t)(feat_stride > 3 ? feat_stride : 3) < ((int64_t)1 << 31);
-    if (small) gather_fused_kernel<true><<<mvs_cdiv(P * 4, 256), 256, 0, (hipStream_t)stream>>>(a);
-    else gather_fused_kernel<false><<<mvs_cdiv(P * 4, 256), 256, 0, (hipStream_t)stream>>>(a);
+    const unsigned grid = mvs_cdiv(P * 4, 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (vol_layout == MVSNERF_VOL_HWDC) {
+        if (small) gather_fused_kernel<true, true><<<grid, 256, 0, st>>>(a);
+        else gather_fused_kernel<false, true><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (small) gather_fused_kernel<true, false><<<grid, 256, 0, st>>>(a);
+        else gather_fused_kernel<false, false><<<grid, 256, 0, st>>>(a);
+    }
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }

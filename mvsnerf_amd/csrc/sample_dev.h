@@ -1,4 +1,4 @@
-// Device functions shared by the gather kernels (sample.hip) and the fused gather prologue of the MLP kernel (mlp.hip): the arithmetic
+// Device functions shared by the gather kernels (sample.hip): the arithmetic
 // of the trilinear volume lookup, the per-view colour lookup and the view-direction feature lives here ONCE, so that every kernel that
 // produces `input_feat` produces the same bits.
 #pragma once
@@ -119,29 +119,76 @@ __device__ __forceinline__ f32x4 trilinear_fold_x0_lane(const f32x4 (&v)[4], con
     return acc;
 }
 
-// The 8-channel trilinear lookup of ONE sample by ONE lane, in the arithmetic of volume_sample_c8_kernel / gather_fused_kernel (where
-// four lanes share a sample): per x corner and channel half, the four (z, y) taps are folded in the order k = 0..3, then the two x
-// corners are added (low corner + high corner).  out[0..3] = channels 0-3, out[4..7] = channels 4-7.
+// ---------------------------------------------------------------------------------------------
+// Depth-fastest volumes (MVSNERF_VOL_HWDC, vol[y][x][d][8]).  The samples of a ray walk DEPTH: with depth as the fastest voxel index the
+// sixteen consecutive samples a wave holds read, per (y, x) column, ONE contiguous run of ~17 voxels (544 B, five 128-byte lines) instead of
+// 34 separate (z, y) rows 1.2 MB apart of which 64 B each are used - the memory-side traffic of the lookup halves.
+// Lane q of a sample's quad owns the COLUMN (yc = q >> 1, xc = q & 1): its two depth taps z0, z0 + 1 are 64 contiguous bytes (four 16-byte
+// loads).  The fold reproduces ATen's term order (z0,y0,x0), (z0,y0,x1), (z0,y1,x0), (z0,y1,x1), (z1,...) - every product rounded, added
+// one after the other from 0 - with DPP quad broadcasts: term j of a depth plane is lane j's product.  All four lanes end with the same
+// eight sums; lane 0 stores channels 0-3, lane 1 channels 4-7.  Bit-identical to the DHWC kernels (tests/test_gpu_layout.py).
+// ---------------------------------------------------------------------------------------------
 template <bool SMALL>
-__device__ __forceinline__ void trilinear8_of(const float* __restrict__ vol, int D, int H, int W, float nx, float ny, float nz, f32x4 (&out)[2])
+__device__ __forceinline__ int64_t vox_off8_zfast(int z, int y, int x, int D, int W)
+{
+    if constexpr (SMALL) return (int64_t)((__umul24(__umul24(y, W) + x, D) + z) << 3);     // launcher: H*W < 2^24, D < 2^24, D*H*W*8 < 2^31
+    else return ((((int64_t)y * W + x) * D + z) << 3);
+}
+
+template <int J>
+__device__ __forceinline__ float quad_bcast(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), J * 0x55, 0xf, 0xf, false));   // quad_perm:[J,J,J,J]
+}
+
+struct ZfastTaps { f32x4 v[4]; float w0, w1; };      // v[0], v[1] = channels 0-3, 4-7 of the z0 tap; v[2], v[3] of the z0 + 1 tap
+
+// issue the four loads of lane q's column for the sample at normalised coordinates (nx, ny, nz)
+template <bool SMALL>
+__device__ __forceinline__ ZfastTaps zfast_taps(const float* __restrict__ vol, int D, int H, int W, float nx, float ny, float nz, int q)
 {
 #pragma clang fp contract(off)
+    ZfastTaps t;
+    // same op order as the reference: grid = ndc*2-1 (utils.py:381); unnormalise ((g+1)/2)*(size-1)
     const float gx = nx * 2.0f - 1.0f, gy = ny * 2.0f - 1.0f, gz = nz * 2.0f - 1.0f;
     const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
     const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
     const float iz = ((gz + 1.0f) / 2.0f) * (float)(D - 1);
     const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-    out[0] = f32x4{0, 0, 0, 0}; out[1] = f32x4{0, 0, 0, 0};
+    const int yc = q >> 1, xc = q & 1;
+    // weights as ATen forms them: (x1-ix) for the low corner, (ix-x0) for the high one; w = (wx * wy) * wz
+    const float wxy = (xc ? (ix - fx) : ((fx + 1.0f) - ix)) * (yc ? (iy - fy) : ((fy + 1.0f) - iy));
+    t.w0 = wxy * ((fz + 1.0f) - iz);
+    t.w1 = wxy * (iz - fz);
+    const float cxf = fx + (float)xc, cyf = fy + (float)yc, czf = fz + 1.0f;
+    // NaN / huge coordinates: the float compares reject them before any int conversion is used
+    const bool col_in = (cxf >= 0.0f) && (cxf <= (float)(W - 1)) && (cyf >= 0.0f) && (cyf <= (float)(H - 1));
+    const bool z0_in = col_in && (fz >= 0.0f) && (fz <= (float)(D - 1));
+    const bool z1_in = col_in && (czf >= 0.0f) && (czf <= (float)(D - 1));
+    const float* zt = reinterpret_cast<const float*>(&g_zero_tap);
+    const float* s0 = z0_in ? vol + vox_off8_zfast<SMALL>((int)fz, (int)cyf, (int)cxf, D, W) : zt;
+    const float* s1 = z1_in ? vol + vox_off8_zfast<SMALL>((int)czf, (int)cyf, (int)cxf, D, W) : zt;
+    t.v[0] = ldg16(s0);
+    t.v[1] = ldg16(z0_in ? s0 + 4 : zt);
+    t.v[2] = ldg16(s1);
+    t.v[3] = ldg16(z1_in ? s1 + 4 : zt);
+    return t;
+}
+
+// the eight channel sums of the sample (identical in the quad's four lanes)
+__device__ __forceinline__ void zfast_fold(const ZfastTaps& t, f32x4& lo, f32x4& hi)
+{
+#pragma clang fp contract(off)
+    lo = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    hi = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {                     // ATen's order: (z0,y0,x0), (z0,y0,x1), (z0,y1,x0), ... every term rounded, then added
-        const int zc = k >> 2, yc = (k >> 1) & 1, xc = k & 1;
-        const float cxf = fx + (float)xc, cyf = fy + (float)yc, czf = fz + (float)zc;
-        const bool in = (cxf >= 0.0f) && (cxf <= (float)(W - 1)) && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
-        const float w = ((xc ? (ix - fx) : ((fx + 1.0f) - ix)) * (yc ? (iy - fy) : ((fy + 1.0f) - iy))) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
-        const float* src = in ? vol + vox_off8<SMALL>((int)czf, (int)cyf, (int)cxf, H, W) : reinterpret_cast<const float*>(&g_zero_tap);
-        const f32x4 v0 = ldg16(src);
-        const f32x4 v1 = ldg16(in ? src + 4 : src);
-        out[0] = out[0] + v0 * w;
-        out[1] = out[1] + v1 * w;
+    for (int z = 0; z < 2; ++z) {
+        const float w = z ? t.w1 : t.w0;
+        const f32x4 pl = t.v[2 * z] * w, ph = t.v[2 * z + 1] * w;          // every term v * w rounded (no fma)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            lo[c] = lo[c] + quad_bcast<0>(pl[c]); lo[c] = lo[c] + quad_bcast<1>(pl[c]); lo[c] = lo[c] + quad_bcast<2>(pl[c]); lo[c] = lo[c] + quad_bcast<3>(pl[c]);
+            hi[c] = hi[c] + quad_bcast<0>(ph[c]); hi[c] = hi[c] + quad_bcast<1>(ph[c]); hi[c] = hi[c] + quad_bcast<2>(ph[c]); hi[c] = hi[c] + quad_bcast<3>(ph[c]);
+        }
     }
 }

@@ -641,6 +641,20 @@ def _apply_add(a, b=None):
     return out
 
 
+VOLUME_LAYOUT = "hwdc"      # memory order of the neural volume CostRegNet emits: "hwdc" vol[y][x][d][8] (depth fastest, what the ray march
+                            # reads best: include/mvsnerf_hip.h MVSNERF_VOL_HWDC) | "dhwc" vol[d][y][x][8].  The logical tensor is the same.
+
+
+def _neural_volume(a, b):
+    """conv0 + conv11(x) (models.py:766) as the logical (1,8,D,h,w) tensor handed to callers, in the VOLUME_LAYOUT memory order."""
+    D, H, W, C = a.dims
+    if VOLUME_LAYOUT == "dhwc" or C != 8:
+        return _cl_view_to_ncdhw(_apply_add(a, b))
+    out = torch.empty((H, W, D, C), device=a.x.device, dtype=torch.float32)
+    check(_lib.lib().mvsnerf_abn_apply_add_hwdc(*_ptrs(a), *_ptrs(b), D, H, W, out.data_ptr(), stream_ptr()), "abn_apply_add_hwdc")
+    return out.permute(3, 2, 0, 1).unsqueeze(0)
+
+
 # ------------------------------------------------------------------ 3-D blocks
 class ConvBnReLU3D(nn.Module):
     """reference models.py:674-685: Conv3d(k3, bias=False) + InPlaceABN (train-mode statistics)."""
@@ -799,11 +813,11 @@ class CostRegNet(nn.Module):
         """x: logical (1,Cin,D,h,w) cost volume (D,h,w divisible by 8).  Returns (1,8,D,h,w), channel-last memory."""
         if isinstance(x, _BlockedCost):          # internal no-grad hand-off from MVSNet.forward
             _, lz = self._run(x)
-            return _cl_view_to_ncdhw(_apply_add(lz[0], lz[9]))
+            return _neural_volume(lz[0], lz[9])
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return _CostRegFunction.apply(x, self, *_costreg_params(self))
         _, lz = self._run(x)
-        return _cl_view_to_ncdhw(_apply_add(lz[0], lz[9]))
+        return _neural_volume(lz[0], lz[9])
 
 
 def _grad_cl(g, C):
@@ -907,7 +921,7 @@ class _CostRegFunction(torch.autograd.Function):
     def forward(ctx, x, net, *params):
         (buf, ld), lz = net._run(x)
         ctx.net, ctx.buf, ctx.ld, ctx.lz, ctx.xshape = net, buf, ld, lz, tuple(x.shape)
-        return _cl_view_to_ncdhw(_apply_add(lz[0], lz[9]))
+        return _neural_volume(lz[0], lz[9])
 
     @staticmethod
     def backward(ctx, g_out):
@@ -1093,7 +1107,7 @@ class _SweepRegFunction(torch.autograd.Function):
         cost, _, saved = _plane_sweep(imgs, feats, proj_mats, depth_values, pad, True, blocked="bf16" if ENCODER_PRECISION == "bf16" else True)
         _, lz = net._run(cost)
         ctx.net, ctx.cost, ctx.lz, ctx.saved = net, cost, lz, saved
-        return _cl_view_to_ncdhw(_apply_add(lz[0], lz[9]))
+        return _neural_volume(lz[0], lz[9])
 
     @staticmethod
     def backward(ctx, g_out):

@@ -35,10 +35,24 @@ class _Keep:
         return dev_f32(t, name)
 
 
+VOL_DHWC, VOL_HWDC = 0, 1      # MVSNERF_VOL_* of include/mvsnerf_hip.h
+
+
+def vol_ptr_layout(vol_cl, cur=None):
+    """(device pointer, MVSNERF_VOL_* layout) of a (D,H,W,C)-shaped volume view as channels_last_volume returns it: contiguous memory is
+    vol[d][y][x][c]; a view whose (H,W,D,C) permutation is contiguous is the depth-fastest vol[y][x][d][c] the encoder emits."""
+    if vol_cl.is_contiguous():
+        return dev_f32(vol_cl, "volume", cur), VOL_DHWC
+    m = vol_cl.permute(1, 2, 0, 3)
+    if m.is_contiguous():
+        return dev_f32(m, "volume", cur), VOL_HWDC
+    raise RuntimeError("volume: expected vol[d][y][x][c] or vol[y][x][d][c] memory (ops.channels_last_volume makes one of them)")
+
+
 def channels_last_volume(volume_feature):
-    """(1,C,D,H,W) reference-layout volume -> contiguous (D,H,W,C) tensor the kernels read.
-    Zero-copy when the tensor is already channels_last_3d (what our MVSNet / RefVolume produce);
-    otherwise one HIP transpose, cached on (storage, version)."""
+    """(1,C,D,H,W) reference-layout volume -> (D,H,W,C)-shaped tensor the kernels read: a zero-copy VIEW when the memory already is
+    channel-last in one of the two orders of include/mvsnerf_hip.h - vol[d][y][x][c] (RefVolume, channels_last_3d tensors) or the
+    depth-fastest vol[y][x][d][c] our MVSNet emits; otherwise one HIP transpose to vol[d][y][x][c], cached on (storage, version)."""
     v = volume_feature
     hit = _cl_cache.get("last")          # the same tensor object, unmodified, as in the previous call (a render loop): ~0.3 us instead of ~6
     if hit is not None and hit[0] is v and hit[1] == (v._version, _lib.weights_epoch()):
@@ -57,8 +71,8 @@ def _channels_last_volume(volume_feature):
     if v.dim() != 4:
         raise RuntimeError(f"volume must be (1,C,D,H,W) or (C,D,H,W), got {tuple(volume_feature.shape)}")
     cl = v.permute(1, 2, 3, 0)
-    if cl.is_contiguous():
-        dev_f32(cl, "volume")
+    if cl.is_contiguous() or cl.permute(1, 2, 0, 3).is_contiguous():
+        vol_ptr_layout(cl)
         return cl
     # cache key: storage identity + version.  The entry keeps the source storage alive, so the caching
     # allocator cannot hand the same address to a different tensor while the entry exists.
@@ -105,15 +119,19 @@ def gather(vol_cl, imgs, w2cs, intrinsics, rays_pts, rays_ndc, rays_dir=None):
     feat = torch.empty((N, S, F), device=rays_ndc.device, dtype=torch.float32)
     dirs = None if rays_dir is None else torch.empty((N, 3), device=rays_ndc.device, dtype=torch.float32)
     icl = channels_last_images(imgs)
-    check(_lib.lib().mvsnerf_gather_fwd(dev_f32(vol_cl, "volume"), D, H, W, icl.data_ptr(), V, imgs.shape[2], imgs.shape[3],
+    vp, vl = vol_ptr_layout(vol_cl)
+    check(_lib.lib().mvsnerf_gather_fwd(vp, D, H, W, icl.data_ptr(), V, imgs.shape[2], imgs.shape[3],
                                         dev_f32(w2cs, "w2cs"), dev_f32(intrinsics, "intrinsics"), dev_f32(rays_pts, "rays_pts"),
                                         dev_f32(rays_ndc, "rays_ndc"), N, S, 0 if rays_dir is None else dev_f32(rays_dir, "rays_dir"),
-                                        feat.data_ptr(), F, 0 if dirs is None else dirs.data_ptr(), stream_ptr()), "gather_fwd")
+                                        feat.data_ptr(), F, 0 if dirs is None else dirs.data_ptr(), vl, stream_ptr()), "gather_fwd")
     return feat, dirs
 
 
 def ndhwc_to_ncdhw(vol_cl):
+    """vol[d][y][x][c] memory -> a contiguous (C,D,H,W) tensor (boundary helper for callers that want the reference's layout)."""
     D, H, W, C = vol_cl.shape
+    if not vol_cl.is_contiguous():
+        raise RuntimeError("ndhwc_to_ncdhw: vol[d][y][x][c] memory expected (a depth-fastest volume converts with tensor.contiguous())")
     dst = torch.empty((C, D, H, W), device=vol_cl.device, dtype=torch.float32)
     check(_lib.lib().mvsnerf_ndhwc_to_ncdhw(dev_f32(vol_cl, "volume"), dst.data_ptr(), C, D, H, W, stream_ptr()), "ndhwc_to_ncdhw")
     return dst
@@ -128,8 +146,9 @@ def volume_sample(vol_cl, ndc, out=None, out_stride=None):
     if out is None:
         out = torch.empty((*ndc.shape[:-1], C), device=ndc.device, dtype=torch.float32)
         out_stride = C
-    check(_lib.lib().mvsnerf_volume_sample_fwd(dev_f32(vol_cl, "volume"), D, H, W, C, dev_f32(ndc, "ndc"), P,
-                                               out.data_ptr(), out_stride, stream_ptr()), "volume_sample_fwd")
+    vp, vl = vol_ptr_layout(vol_cl)
+    check(_lib.lib().mvsnerf_volume_sample_fwd(vp, D, H, W, C, dev_f32(ndc, "ndc"), P,
+                                               out.data_ptr(), out_stride, vl, stream_ptr()), "volume_sample_fwd")
     return out
 
 
@@ -448,8 +467,9 @@ def _raymarch_block(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, 
     out["_dirs_tmp"] = dirs_tmp = empty((N, 3), device=dev, dtype=torch.float32)
     if imgs_cl is None and FUSED_GATHER:
         imgs_cl = channels_last_images(imgs)
+    vp, vl = vol_ptr_layout(vol_cl, cur)
     a = (
-        dev_f32(vol_cl, "volume", cur), D, H, W, dev_f32(imgs, "imgs", cur), V, imgs.shape[2], imgs.shape[3],
+        vp, D, H, W, dev_f32(imgs, "imgs", cur), V, imgs.shape[2], imgs.shape[3],
         dev_f32(w2cs, "w2cs", cur), dev_f32(intrinsics, "intrinsics", cur), dev_f32(packed, "packed", cur),
         dev_f32(rays_pts, "rays_pts", cur), dev_f32(rays_ndc, "rays_ndc", cur), dev_f32(z_vals, "z_vals", cur), dev_f32(rays_dir, "rays_dir", cur),
         N, S, int(bool(white_bkgd)), dirs_tmp.data_ptr(), out["input_feat"].data_ptr(), out["raw"].data_ptr(),
@@ -457,7 +477,7 @@ def _raymarch_block(vol_cl, imgs, w2cs, intrinsics, packed, rays_pts, rays_ndc, 
         out["depth"].data_ptr(), out["alpha"].data_ptr(), 0 if packed_bf16 is None else packed_bf16.data_ptr(),
         imgs_cl.data_ptr() if (FUSED_GATHER and imgs_cl is not None) else 0,
         0 if packed_split is None else packed_split[0].data_ptr(), 0 if packed_split is None else int(packed_split[1]),
-        0 if guard is None else guard.data_ptr())
+        0 if guard is None else guard.data_ptr(), vl)
     return out, a
 
 
@@ -517,14 +537,15 @@ def render_pixels(vol_cl, imgs, w2cs, intrinsics, packed, H, W, K_tgt, c2w_tgt, 
     if n == 0:
         return {k: v for k, v in out.items() if v is not None}
     c = _Keep()
+    vp, vl = vol_ptr_layout(vol_cl)
     a = _lib.RenderArgs(
-        dev_f32(vol_cl, "volume"), D, Hv, Wv, channels_last_images(imgs).data_ptr(), V, imgs.shape[2], imgs.shape[3],
+        vp, D, Hv, Wv, channels_last_images(imgs).data_ptr(), V, imgs.shape[2], imgs.shape[3],
         c(w2cs, "w2cs"), c(intrinsics, "intrinsics"), packed.data_ptr(), 0 if packed_bf16 is None else packed_bf16.data_ptr(),
         c(K_tgt, "K_tgt"), c(c2w_tgt, "c2w_tgt"), c(K_ref, "K_ref"), c(w2c_ref, "w2c_ref"), c(nf_tgt, "near_far_tgt"), c(nf_ref, "near_far_ref"),
         W, H, int(pad), int(bool(lindisp)), 0 if ref_hw is None else int(ref_hw[1]), 0 if ref_hw is None else int(ref_hw[0]), int(first_pixel), n, int(N_samples), int(bool(white_bkgd)), B,
         ws.data_ptr(), ws_n, out["rgb"].data_ptr(), *[0 if out[k] is None else out[k].data_ptr() for k in ("depth", "acc", "disp")],
         0 if packed_split is None else packed_split[0].data_ptr(), 0 if packed_split is None else int(packed_split[1]),
-        0 if guard is None else guard.data_ptr())
+        0 if guard is None else guard.data_ptr(), vl)
     check(lib.mvsnerf_render_pixels_fwd(ctypes.byref(a), stream_ptr()), "render_pixels_fwd")
     return {k: v for k, v in out.items() if v is not None}
 
@@ -609,8 +630,9 @@ class RayMarchFunction(torch.autograd.Function):
         weights, alpha = torch.empty((N, S), **f32), torch.empty((N, S), **f32)
         packed_b = mlp_pack_bf16([p.detach() for p in mlp_params[0::2]], F) if bf16 else None
         icl = channels_last_images(imgs) if C == 8 else None
+        vp, vl = vol_ptr_layout(vol_cl)
         a = _lib.RaymarchTrainArgs(
-            vol=dev_f32(vol_cl, "volume"), D=D, H=H, W=W, C=C,
+            vol=vp, vol_layout=vl, D=D, H=H, W=W, C=C,
             imgs_nhwc4=0 if icl is None else icl.data_ptr(), V=V, IH=imgs.shape[2], IW=imgs.shape[3],
             w2c=dev_f32(w2cs, "w2cs"), K=dev_f32(intrinsics, "intrinsics"), packed_mlp=packed.data_ptr(),
             packed_mlp_bf16=0 if packed_b is None else packed_b.data_ptr(), bf16=int(bf16),

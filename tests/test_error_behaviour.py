@@ -15,10 +15,10 @@ def test_c_abi_rejects_bad_arguments_without_launching():
     l = _lib.lib()
     buf = (ctypes.c_float * 64)()
     p = ctypes.addressof(buf)
-    assert l.mvsnerf_volume_sample_fwd(0, 4, 4, 4, 8, p, 1, p, 8, 0) == EINVAL                # null volume
-    assert l.mvsnerf_volume_sample_fwd(p, 4, 4, 4, 8, p, -1, p, 8, 0) == EINVAL               # negative count
-    assert l.mvsnerf_volume_sample_fwd(p, 4, 4, 4, 8, p, 0, p, 8, 0) == 0                     # empty input is a no-op
-    assert l.mvsnerf_volume_sample_fwd(p + 4, 4, 4, 4, 8, p, 1, p, 8, 0) == EALIGN            # misaligned volume (16-byte channel vectors)
+    assert l.mvsnerf_volume_sample_fwd(0, 4, 4, 4, 8, p, 1, p, 8, 0, 0) == EINVAL                # null volume
+    assert l.mvsnerf_volume_sample_fwd(p, 4, 4, 4, 8, p, -1, p, 8, 0, 0) == EINVAL               # negative count
+    assert l.mvsnerf_volume_sample_fwd(p, 4, 4, 4, 8, p, 0, p, 8, 1, 0) == 0 and l.mvsnerf_volume_sample_fwd(p, 4, 4, 4, 8, p, 1, p, 8, 2, 0) == EINVAL                     # empty input is a no-op
+    assert l.mvsnerf_volume_sample_fwd(p + 4, 4, 4, 4, 8, p, 1, p, 8, 0, 0) == EALIGN            # misaligned volume (16-byte channel vectors)
     assert l.mvsnerf_composite_fwd(0, p, 1, 4, 0, p, p, p, p, p, p, 0) == EINVAL
     assert l.mvsnerf_composite_fwd(p, p, 0, 4, 0, p, p, p, p, p, p, 0) == 0
     assert l.mvsnerf_mlp_fwd(p, 21, p, 3, p, 21, p, 3, 1, 1, 0, p, 0) == EUNSUPPORTED         # odd feat_dim
