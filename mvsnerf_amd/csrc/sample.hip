@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void volume_sample_c8_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same lookup on a depth-fastest volume (MVSNERF_VOL_HWDC, sample_dev.h): four lanes per sample, lane = (y, x) column.
+// The same lookup on a depth-fastest volume (MVSNERF_VOL_HWDC, sample_dev.h): four lanes per sample, lane = (row y, channel half).
 // ---------------------------------------------------------------------------------------------
 template <bool SMALL>
 __global__ __launch_bounds__(256) void volume_sample_c8_zfast_kernel(
@@ -83,9 +83,8 @@ __global__ __launch_bounds__(256) void volume_sample_c8_zfast_kernel(
     typedef float f32x3 __attribute__((ext_vector_type(3)));
     const f32x3 nd = *reinterpret_cast<const f32x3*>(ndc + pc * 3);
     const ZfastTaps t = zfast_taps<SMALL>(vol, D, H, W, nd[0], nd[1], nd[2], q);
-    f32x4 lo, hi;
-    zfast_fold(t, lo, hi);
-    if (p < P && q < 2) *reinterpret_cast<f32x4*>(out + p * out_stride + q * 4) = q ? hi : lo;
+    const f32x4 acc = zfast_fold_y0_lane(t);                                      // ATen's term order and roundings; valid in the y0 lanes
+    if (p < P && q < 2) *reinterpret_cast<f32x4*>(out + p * out_stride + q * 4) = acc;
 }
 
 // Generic-C fallback of the same op (C != 8, e.g. colour volumes): one thread per (sample, channel); either layout.
@@ -270,7 +269,7 @@ struct GatherArgs {
     float* feat; int feat_stride; float* dirs_out;
 };
 
-template <bool SMALL, bool ZFAST>      // ZFAST: the volume is depth-fastest (MVSNERF_VOL_HWDC): lane = (y, x) column, see sample_dev.h
+template <bool SMALL, bool ZFAST>      // ZFAST: the volume is depth-fastest (MVSNERF_VOL_HWDC): lane = (row y, channel half), see sample_dev.h
 __global__ __launch_bounds__(256) void gather_fused_kernel(GatherArgs a)
 {
 #pragma clang fp contract(off)
@@ -331,9 +330,8 @@ __global__ __launch_bounds__(256) void gather_fused_kernel(GatherArgs a)
     }
     // ---- fold the volume taps in ATen's term order and roundings (sample_dev.h)
     if constexpr (ZFAST) {
-        f32x4 lo, hi;
-        zfast_fold(zt, lo, hi);                                                   // all four lanes hold all eight sums
-        if (live && q < 2) *reinterpret_cast<f32x4*>(frow + q * 4) = q ? hi : lo;
+        const f32x4 acc = zfast_fold_y0_lane(zt);                                 // valid in the y0 lanes
+        if (live && q < 2) *reinterpret_cast<f32x4*>(frow + q * 4) = acc;
     } else {
         const f32x4 acc = trilinear_fold_x0_lane(vv, vw);                         // valid in the x0 lanes
         if (live && xc == 0) *reinterpret_cast<f32x4*>(frow + ch) = acc;

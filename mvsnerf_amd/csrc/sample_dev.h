@@ -122,11 +122,14 @@ __device__ __forceinline__ f32x4 trilinear_fold_x0_lane(const f32x4 (&v)[4], con
 // ---------------------------------------------------------------------------------------------
 // Depth-fastest volumes (MVSNERF_VOL_HWDC, vol[y][x][d][8]).  The samples of a ray walk DEPTH: with depth as the fastest voxel index the
 // sixteen consecutive samples a wave holds read, per (y, x) column, ONE contiguous run of ~17 voxels (544 B, five 128-byte lines) instead of
-// 34 separate (z, y) rows 1.2 MB apart of which 64 B each are used - the memory-side traffic of the lookup halves.
-// Lane q of a sample's quad owns the COLUMN (yc = q >> 1, xc = q & 1): its two depth taps z0, z0 + 1 are 64 contiguous bytes (four 16-byte
-// loads).  The fold reproduces ATen's term order (z0,y0,x0), (z0,y0,x1), (z0,y1,x0), (z0,y1,x1), (z1,...) - every product rounded, added
-// one after the other from 0 - with DPP quad broadcasts: term j of a depth plane is lane j's product.  All four lanes end with the same
-// eight sums; lane 0 stores channels 0-3, lane 1 channels 4-7.  Bit-identical to the DHWC kernels (tests/test_gpu_layout.py).
+// 34 separate (z, y) rows 1.2 MB apart of which 64 B each are used.
+// Lane q of a sample's quad owns (yc = q >> 1, channel half h = q & 1): for both x columns of its row y it loads its 16-byte half of the z0
+// and the z0 + 1 voxel - the two lanes of a row cover the 64 contiguous bytes of each column.  The fold reproduces ATen's term order
+// (z0,y0,x0), (z0,y0,x1), (z0,y1,x0), (z0,y1,x1), (z1,...) - every product rounded, added one after the other from 0 - in the y0 lanes: own
+// (z, x0), own (z, x1), then the y1 partner's two (one DPP quad swap each), per depth plane.  Same instruction count as the DHWC fold
+// (16 products, 16 swaps, 32 additions; the lookups are bound by the instruction stream of the eight waves a SIMD holds as much as by
+// memory: a first version with one lane per column and quad broadcasts - 64 DPP additions - made the fused gather 14 % SLOWER).
+// Bit-identical to the DHWC kernels (tests/test_gpu_layout.py).
 // ---------------------------------------------------------------------------------------------
 template <bool SMALL>
 __device__ __forceinline__ int64_t vox_off8_zfast(int z, int y, int x, int D, int W)
@@ -135,15 +138,9 @@ __device__ __forceinline__ int64_t vox_off8_zfast(int z, int y, int x, int D, in
     else return ((((int64_t)y * W + x) * D + z) << 3);
 }
 
-template <int J>
-__device__ __forceinline__ float quad_bcast(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), J * 0x55, 0xf, 0xf, false));   // quad_perm:[J,J,J,J]
-}
+// taps of lane q in ATen's order within its row: k = 2 zc + xc -> v[k] = this lane's channel half of voxel (z0 + zc, y, x0 + xc), w[k] its weight
+struct ZfastTaps { f32x4 v[4]; float w[4]; };
 
-struct ZfastTaps { f32x4 v[4]; float w0, w1; };      // v[0], v[1] = channels 0-3, 4-7 of the z0 tap; v[2], v[3] of the z0 + 1 tap
-
-// issue the four loads of lane q's column for the sample at normalised coordinates (nx, ny, nz)
 template <bool SMALL>
 __device__ __forceinline__ ZfastTaps zfast_taps(const float* __restrict__ vol, int D, int H, int W, float nx, float ny, float nz, int q)
 {
@@ -155,40 +152,39 @@ __device__ __forceinline__ ZfastTaps zfast_taps(const float* __restrict__ vol, i
     const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
     const float iz = ((gz + 1.0f) / 2.0f) * (float)(D - 1);
     const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-    const int yc = q >> 1, xc = q & 1;
+    const int yc = q >> 1, ch = (q & 1) * 4;
     // weights as ATen forms them: (x1-ix) for the low corner, (ix-x0) for the high one; w = (wx * wy) * wz
-    const float wxy = (xc ? (ix - fx) : ((fx + 1.0f) - ix)) * (yc ? (iy - fy) : ((fy + 1.0f) - iy));
-    t.w0 = wxy * ((fz + 1.0f) - iz);
-    t.w1 = wxy * (iz - fz);
-    const float cxf = fx + (float)xc, cyf = fy + (float)yc, czf = fz + 1.0f;
+    const float wy = yc ? (iy - fy) : ((fy + 1.0f) - iy);
+    const float cyf = fy + (float)yc;
     // NaN / huge coordinates: the float compares reject them before any int conversion is used
-    const bool col_in = (cxf >= 0.0f) && (cxf <= (float)(W - 1)) && (cyf >= 0.0f) && (cyf <= (float)(H - 1));
-    const bool z0_in = col_in && (fz >= 0.0f) && (fz <= (float)(D - 1));
-    const bool z1_in = col_in && (czf >= 0.0f) && (czf <= (float)(D - 1));
+    const bool y_in = (cyf >= 0.0f) && (cyf <= (float)(H - 1));
     const float* zt = reinterpret_cast<const float*>(&g_zero_tap);
-    const float* s0 = z0_in ? vol + vox_off8_zfast<SMALL>((int)fz, (int)cyf, (int)cxf, D, W) : zt;
-    const float* s1 = z1_in ? vol + vox_off8_zfast<SMALL>((int)czf, (int)cyf, (int)cxf, D, W) : zt;
-    t.v[0] = ldg16(s0);
-    t.v[1] = ldg16(z0_in ? s0 + 4 : zt);
-    t.v[2] = ldg16(s1);
-    t.v[3] = ldg16(z1_in ? s1 + 4 : zt);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int zc = k >> 1, xc = k & 1;
+        const float cxf = fx + (float)xc, czf = fz + (float)zc;
+        const bool in = y_in && (cxf >= 0.0f) && (cxf <= (float)(W - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1));
+        t.w[k] = ((xc ? (ix - fx) : ((fx + 1.0f) - ix)) * wy) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
+        t.v[k] = ldg16(in ? vol + vox_off8_zfast<SMALL>((int)czf, (int)cyf, (int)cxf, D, W) + ch : zt);
+    }
     return t;
 }
 
-// the eight channel sums of the sample (identical in the quad's four lanes)
-__device__ __forceinline__ void zfast_fold(const ZfastTaps& t, f32x4& lo, f32x4& hi)
+// the four channel sums of this lane's half; valid in the y0 lanes (q < 2)
+__device__ __forceinline__ f32x4 zfast_fold_y0_lane(const ZfastTaps& t)
 {
 #pragma clang fp contract(off)
-    lo = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    hi = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int z = 0; z < 2; ++z) {
-        const float w = z ? t.w1 : t.w0;
-        const f32x4 pl = t.v[2 * z] * w, ph = t.v[2 * z + 1] * w;          // every term v * w rounded (no fma)
+        const f32x4 a = t.v[2 * z] * t.w[2 * z], b = t.v[2 * z + 1] * t.w[2 * z + 1];     // every term v * w rounded (no fma)
+        f32x4 pa, pb;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            lo[c] = lo[c] + quad_bcast<0>(pl[c]); lo[c] = lo[c] + quad_bcast<1>(pl[c]); lo[c] = lo[c] + quad_bcast<2>(pl[c]); lo[c] = lo[c] + quad_bcast<3>(pl[c]);
-            hi[c] = hi[c] + quad_bcast<0>(ph[c]); hi[c] = hi[c] + quad_bcast<1>(ph[c]); hi[c] = hi[c] + quad_bcast<2>(ph[c]); hi[c] = hi[c] + quad_bcast<3>(ph[c]);
-        }
+        for (int c = 0; c < 4; ++c) { pa[c] = quad_swap2(a[c]); pb[c] = quad_swap2(b[c]); }
+        acc = acc + a;                  // (z, y0, x0)
+        acc = acc + b;                  // (z, y0, x1)
+        acc = acc + pa;                 // (z, y1, x0): the partner two lanes further in the quad
+        acc = acc + pb;                 // (z, y1, x1)
     }
+    return acc;
 }

@@ -12,10 +12,13 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import load_weights, maxabs
+from tests.util import load_weights, maxabs, record_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+# absolute (rgb, weights, depth) / relative-to-max (feats, vol_*) bounds; to be kept at <= 5x the measured values
+TOL4 = {"feats": 1e-4, "vol_max": 5e-4, "vol_rms": 2e-5, "rgb": 1e-4, "weights": 2e-4, "depth": 1e-3}
+TOL5 = {"rgb": 1e-4, "depth": 1e-3}
 
 
 def _args(feat_dim, n_samples):
@@ -79,10 +82,15 @@ def test_config4_shape_five_views_800x800_192_planes():
     psnr_b = 10 * np.log10(1.0 / max(float(((rgb_b.cpu() - ref[0]) ** 2).mean()), 1e-20))
     print(f"[config 4 shape] feats err {e_feat:.2e}; volume err max {e_vol:.2e} rms {rms_vol:.2e} (|vol| max {vmax:.2f}); "
           f"rgb err {e_rgb:.2e}, weights err {e_alpha:.2e}, depth err {maxabs(depth.cpu(), ref[3]):.2e}; bf16-MLP PSNR vs fp32 oracle {psnr_b:.1f} dB")
-    assert e_feat < 1e-4 * max(1.0, float(feats_ref.abs().max()))
-    assert e_vol < 5e-4 * max(1.0, vmax) and rms_vol < 2e-5 * max(1.0, vmax)
-    assert e_rgb < 1e-4
-    assert e_alpha < 2e-4 and maxabs(depth.cpu(), ref[3]) < 1e-3
+    e_depth = maxabs(depth.cpu(), ref[3])
+    for tag, err, scale in (("feats", e_feat, float(feats_ref.abs().max())), ("vol_max", e_vol, vmax), ("vol_rms", rms_vol, vmax), ("rgb", e_rgb, 1.0),
+                            ("weights", e_alpha, 1.0), ("depth", e_depth, float(ref[3].abs().max()))):
+        record_err(f"config4:{tag}", err, scale=scale)
+    # bounds at <= 5x the values measured on MI355X (profiles/r04_measured_errs.jsonl), like every other parity file
+    assert e_feat < TOL4["feats"] * max(1.0, float(feats_ref.abs().max()))
+    assert e_vol < TOL4["vol_max"] * max(1.0, vmax) and rms_vol < TOL4["vol_rms"] * max(1.0, vmax)
+    assert e_rgb < TOL4["rgb"]
+    assert e_alpha < TOL4["weights"] and e_depth < TOL4["depth"]
     assert psnr_b > 40.0
 
 
@@ -124,5 +132,7 @@ def test_config5_shape_1008x756_target_over_960x640_sources():
             worst_rgb = max(worst_rgb, maxabs(rgb[sl], ref[0]))
             worst_depth = max(worst_depth, maxabs(depth[sl], ref[3]))
     print(f"[config 5 shape] 4 x 1024 pixels of the 1008x756 frame: rgb err {worst_rgb:.2e}, depth err {worst_depth:.2e}")
-    assert worst_rgb < 1e-4
-    assert worst_depth < 1e-3
+    record_err("config5:rgb", worst_rgb, scale=1.0)
+    record_err("config5:depth", worst_depth, scale=float(depth.abs().max()))
+    assert worst_rgb < TOL5["rgb"]
+    assert worst_depth < TOL5["depth"]

@@ -63,7 +63,7 @@ def test_golden_costreg(name, mvs):
     assert vol.shape == c["ref_vol_small"].shape
     ok, e = close(vol, c["ref_vol_small"], 2e-5, 2e-6)          # measured 7.4e-6 at |vol| <= 5.5
     assert ok, f"CostRegNet {e}"
-    assert vol[0].permute(1, 2, 3, 0).is_contiguous()         # channel-last memory, feeds the ray march with no transpose
+    assert vol[0].permute(2, 3, 1, 0).is_contiguous()         # depth-fastest channel-last memory [y][x][d][c]: feeds the ray march with no transpose
     assert not torch.equal(rm_before, mvs.cost_reg_2.conv0.bn.running_mean)   # train-mode side effect reproduced
 
 
