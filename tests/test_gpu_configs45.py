@@ -16,9 +16,11 @@ from tests.util import load_weights, maxabs, record_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-# absolute (rgb, weights, depth) / relative-to-max (feats, vol_*) bounds; to be kept at <= 5x the measured values
-TOL4 = {"feats": 1e-4, "vol_max": 5e-4, "vol_rms": 2e-5, "rgb": 1e-4, "weights": 2e-4, "depth": 1e-3}
-TOL5 = {"rgb": 1e-4, "depth": 1e-3}
+# absolute (rgb, weights, depth) / relative-to-max (feats, vol_*) bounds at <= 5x what MI355X measured in the guarded default mode
+# (profiles/r04_measured_errs.jsonl: config4 feats 1.2e-6, vol_max 1.4e-6, vol_rms 7.6e-8 of the maximum; rgb 1.7e-5, weights 2.4e-5, depth 4.8e-6;
+# config5 rgb 1.7e-5, depth 1.6e-4)
+TOL4 = {"feats": 6e-6, "vol_max": 7e-6, "vol_rms": 4e-7, "rgb": 8e-5, "weights": 1.2e-4, "depth": 2.5e-5}
+TOL5 = {"rgb": 8e-5, "depth": 8e-4}
 
 
 def _args(feat_dim, n_samples):
