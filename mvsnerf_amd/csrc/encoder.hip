@@ -84,8 +84,9 @@ extern "C" int mvsnerf_resize_bilinear(const float* src, float* dst, int NC, int
 // scratch/r3/psw_fwd_columns_dropped.hip.txt.)  Writes the voxel's CP-channel vector once (the reference moves ~10 GB for the same result).
 // =============================================================================================
 
-template <int C, int NP>   // feature channels (32), depth planes per wave
-__global__ __launch_bounds__(64) void planesweep_kernel(
+template <int C, int NP>   // feature channels (32), depth planes per wave; `bid`: the workgroup (= wave) index
+__device__ __forceinline__ void planesweep_tile(
+    const unsigned bid,
     const float* __restrict__ feat,   // [V][H][W][C]
     const float* __restrict__ img,    // [V][H][W][4] or null
     const float* __restrict__ proj,   // [V][3][4]
@@ -96,8 +97,7 @@ __global__ __launch_bounds__(64) void planesweep_kernel(
     int with_img, int blocked,          // blocked 1: cost[CP/4][D*Hp*Wp][4] (channel blocks of four, see mvsnerf_planesweep_costvar_blocked_fwd);
                                         // 2: bf16 in channel blocks of sixteen, cost16[ceil(CP/16)][D*Hp*Wp][16] (mvsnerf_planesweep_costvar_bf16_fwd)
                                         // 3: two fp16 pieces of x / 16 in that layout (mvsnerf_planesweep_costvar_f16x2_fwd)
-    int* __restrict__ guard,            // blocked 3 in a guarded sequence (include/mvsnerf_hip.h): guard[0] = 1 when a value did not fit an fp16 piece
-    const int* __restrict__ run_if)     // fp32 half of a guarded sequence: the launch does its work only when *run_if != 0
+    int* __restrict__ guard)            // blocked 3 in a guarded sequence (include/mvsnerf_hip.h): guard[0] = 1 when a value did not fit an fp16 piece
 {
     // fp32 arithmetic of the CPU reference path, operation for operation (scratch/r3/cpu_arith_probe.py, cpu_var_probe.py compare candidate
     // formulas with reference-generated fixtures BIT FOR BIT): the projection is a k-ordered fma chain (sgemm), grid_sample's blend is
@@ -105,7 +105,6 @@ __global__ __launch_bounds__(64) void planesweep_kernel(
     // (x**2, +, *count, -): no contraction anywhere else.
 #pragma clang fp contract(off)
     static_assert(C == 32, "lane q owns float4 numbers q and q + 4 of a 32-channel pixel");
-    if (run_if && *run_if == 0) return;
     constexpr int NC = 64 / NP, VPB = 64;                        // columns x depth planes of a workgroup = one wave
     extern __shared__ __attribute__((aligned(16))) float lds_[];
     // per voxel: per source view {w_nw,w_ne,w_sw,w_se, t_nw,t_ne,t_sw,t_se}; then {1/count, ref pixel}.  Row strides in floats with
@@ -132,7 +131,7 @@ __global__ __launch_bounds__(64) void planesweep_kernel(
     //    the L1s per launch).  A rig whose taps move every plane gathers as often as before.
     const int RB = (Hp + 7) >> 3;                                // rows per band
     const int CPS = (RB * Wp + NC - 1) / NC;                     // chunks per band slab
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int xcd = bid & 7, jb = bid >> 3;
     const int dg = jb / CPS, chunk = jb - dg * CPS;
     const int band_rows = min(RB, Hp - xcd * RB);                // the last band may be short (or empty)
     const int slab = band_rows > 0 ? band_rows * Wp : 0;
@@ -346,6 +345,29 @@ __global__ __launch_bounds__(64) void planesweep_kernel(
     }
 }
 
+template <int C, int NP>
+__global__ __launch_bounds__(64) void planesweep_kernel(
+    const float* __restrict__ feat, const float* __restrict__ img, const float* __restrict__ proj, const float* __restrict__ depth,
+    int V, int H, int W, int D, int pad, float* __restrict__ cost, int CP, float* __restrict__ masks, int with_img, int blocked, int* __restrict__ guard)
+{
+    planesweep_tile<C, NP>(blockIdx.x, feat, img, proj, depth, V, H, W, D, pad, cost, CP, masks, with_img, blocked, guard);
+}
+
+// fp32 half of a guarded sequence (mvsnerf_sweep_conv0_guarded_fwd): a persistent grid that walks the `n_wg` workgroup indices of the plain
+// launch only when *run_if != 0 - when the guard is clear 2048 waves leave at once instead of 73 k (16 us of every encode).
+template <int C, int NP>
+__global__ __launch_bounds__(64) void planesweep_if_kernel(
+    const float* __restrict__ feat, const float* __restrict__ img, const float* __restrict__ proj, const float* __restrict__ depth,
+    int V, int H, int W, int D, int pad, float* __restrict__ cost, int CP, float* __restrict__ masks, int with_img, int blocked,
+    unsigned n_wg, const int* __restrict__ run_if)
+{
+    if (*run_if == 0) return;
+    for (unsigned bid = blockIdx.x; bid < n_wg; bid += gridDim.x) {
+        planesweep_tile<C, NP>(bid, feat, img, proj, depth, V, H, W, D, pad, cost, CP, masks, with_img, blocked, nullptr);
+        __syncthreads();
+    }
+}
+
 static int planesweep_launch(const float* feats_cl, const float* imgs_cl, const float* proj, const float* depth,
                              int V, int C, int H, int W, int D, int pad, float* cost, int CP, float* masks,
                              int with_img, int blocked, void* stream, int* guard = nullptr, const int* run_if = nullptr);
@@ -405,7 +427,16 @@ static int planesweep_launch(const float* feats_cl, const float* imgs_cl, const 
         if (rc != MVSNERF_OK) return rc;
     }
     const int CPS = (RB * Wp + 15) / 16;
-    planesweep_kernel<32, 4><<<(unsigned)(8 * ((D + 3) / 4) * CPS), 64, lds, (hipStream_t)stream>>>(feats_cl, imgs_cl, proj, depth, V, H, W, D, pad, cost, CP, masks, with_img, blocked, guard, run_if);
+    const unsigned n_wg = (unsigned)(8 * ((D + 3) / 4) * CPS);
+    if (run_if) {
+        static unsigned long long cap_if = 0;
+        if (lds > 48 * 1024)
+            if (const int rc = mvs_raise_lds_cap(reinterpret_cast<const void*>(planesweep_if_kernel<32, 4>), (int)lds, &cap_if)) return rc;
+        planesweep_if_kernel<32, 4><<<n_wg < 4096u ? n_wg : 4096u, 64, lds, (hipStream_t)stream>>>(feats_cl, imgs_cl, proj, depth, V, H, W, D, pad, cost, CP, masks, with_img, blocked, n_wg, run_if);
+        MVS_LAUNCH_CHECK();
+        return MVSNERF_OK;
+    }
+    planesweep_kernel<32, 4><<<n_wg, 64, lds, (hipStream_t)stream>>>(feats_cl, imgs_cl, proj, depth, V, H, W, D, pad, cost, CP, masks, with_img, blocked, guard);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
@@ -1168,12 +1199,12 @@ extern "C" int mvsnerf_abn_apply_add(const float* x1, const float* scale1, const
 }
 
 // The 8-channel sum of two lazily-activated tensors, written DEPTH-FASTEST: a, b [D][H][W][8] -> out[H][W][D][8] (MVSNERF_VOL_HWDC, the
-// layout the ray march reads best: sample_dev.h).  A workgroup owns a tile of 32 depth planes x 16 x-columns of one row y: it reads 32
-// runs of 512 B (along x), applies leaky(x * scale + shift) to both operands, adds, parks the tile in LDS and writes 16 runs of 1 KB (along
-// depth).  Both sides of the transpose are contiguous; nothing else differs from abn_apply_add_kernel (same operation order per element).
+// layout the ray march reads best: sample_dev.h).  A workgroup owns a tile of 32 depth planes x 32 x-columns of one row y: it reads 32
+// runs of 1 KB (along x), applies leaky(x * scale + shift) to both operands, adds, parks the tile in LDS and writes 32 runs of 1 KB (along
+// depth; a 32 x 16 tile - 512-byte read runs - took 82 us where the channel-last epilogue takes 30).  Both sides of the transpose are contiguous; nothing else differs from abn_apply_add_kernel (same operation order per element).
 __global__ __launch_bounds__(256) void abn_apply_add_hwdc_kernel(ActSrc a, ActSrc b, int D, int H, int W, float* __restrict__ out)
 {
-    constexpr int TZ = 32, TX = 16, ROW = TX * 8 + 8;             // LDS row of a depth plane: 128 floats + 8 pad (spreads the column reads over the banks)
+    constexpr int TZ = 32, TX = 32, ROW = TX * 8 + 8;             // LDS row of a depth plane: 256 floats + 8 pad (spreads the column reads over the banks)
     __shared__ __attribute__((aligned(16))) float tile[TZ * ROW];
     const int nbx = (W + TX - 1) / TX, nbz = (D + TZ - 1) / TZ;
     const int bx = blockIdx.x % nbx, bz = (blockIdx.x / nbx) % nbz, y = blockIdx.x / (nbx * nbz);
@@ -1183,10 +1214,10 @@ __global__ __launch_bounds__(256) void abn_apply_add_hwdc_kernel(ActSrc a, ActSr
     f32x4 sa, ha, sb = {0, 0, 0, 0}, hb = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 4; ++k) { sa[k] = a.scale[c4 + k]; ha[k] = a.shift[c4 + k]; if (b.x) { sb[k] = b.scale[c4 + k]; hb[k] = b.shift[c4 + k]; } }
-    // phase 1: float4 number f of the tile = (plane f / 32, column (f % 32) / 2, quad f % 2): consecutive threads read consecutive 16 bytes
+    // phase 1: float4 number f of the tile = (plane f / 64, column (f % 64) / 2, quad f % 2): consecutive threads read consecutive 16 bytes
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int f = tid + 256 * r, zi = f >> 5, xi = (f & 31) >> 1;
+    for (int r = 0; r < 8; ++r) {
+        const int f = tid + 256 * r, zi = f >> 6, xi = (f & 63) >> 1;
         const int z = z0 + zi, x = x0 + xi;
         if (z < D && x < W) {
             const int64_t at = ((((int64_t)z * H + y) * W + x) << 3) + c4;
@@ -1204,7 +1235,7 @@ __global__ __launch_bounds__(256) void abn_apply_add_hwdc_kernel(ActSrc a, ActSr
     __syncthreads();
     // phase 2: float4 number f = (column f / 64, plane (f % 64) / 2, quad f % 2): consecutive threads write consecutive 16 bytes of a column's run
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < 8; ++r) {
         const int f = tid + 256 * r, xi = f >> 6, zi = (f & 63) >> 1;
         const int z = z0 + zi, x = x0 + xi;
         if (z < D && x < W)
@@ -1220,7 +1251,7 @@ extern "C" int mvsnerf_abn_apply_add_hwdc(const float* x1, const float* scale1, 
     if (x2 && (!scale2 || !shift2)) return MVSNERF_EINVAL;
     if (!mvs_aligned16(x1) || !mvs_aligned16(out) || (x2 && !mvs_aligned16(x2))) return MVSNERF_EALIGN;
     const ActSrc a{x1, scale1, shift1}, b{x2, scale2, shift2};
-    const int64_t nblk = (int64_t)((W + 15) / 16) * ((D + 31) / 32) * H;
+    const int64_t nblk = (int64_t)((W + 31) / 32) * ((D + 31) / 32) * H;
     if (nblk >= ((int64_t)1 << 31)) return MVSNERF_EUNSUPPORTED;
     abn_apply_add_hwdc_kernel<<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(a, b, D, H, W, out);
     MVS_LAUNCH_CHECK();

@@ -224,20 +224,18 @@ __device__ __forceinline__ void slab_sync()
     __syncthreads();                                      // ... everybody's have, and everybody left the other buffer
 }
 
+// One tile = 128 points = one workgroup's work; `tile` is the workgroup index in the plain kernel and the loop variable of the predicated one below.
 template <bool ALPHA_ONLY, bool SAVE>
-__global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
-    const float* __restrict__ packed, int F, const float* __restrict__ ndc, int ndc_stride,
+__device__ __forceinline__ void mlp_fwd_pipe_tile(
+    const unsigned tile, const float* __restrict__ packed, int F, const float* __restrict__ ndc, int ndc_stride,
     const float* __restrict__ feat, int feat_stride, const float* __restrict__ dirs, int dirs_stride,
-    int64_t P, int S, float* __restrict__ raw, float* __restrict__ saved, long long* __restrict__ census, const int* __restrict__ run_if)
+    int64_t P, int S, float* __restrict__ raw, float* __restrict__ saved, long long* __restrict__ census)
 {
-    // second half of a guarded 16-bit sequence (include/mvsnerf_hip.h): launched behind the fp16x3 kernel, does its work only when that kernel
-    // reported a value outside fp16's range (wave-uniform scalar load; 1024 workgroups that leave at once cost ~2 us of an untripped batch)
-    if (run_if && *run_if == 0) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     long long t_start = 0, c_start = 0;
     if (census) { t_start = wall_clock64(); c_start = __builtin_amdgcn_s_memtime(); }
     int stamp_i = 4;
-    auto stamp = [&]() { if (census && threadIdx.x == 0 && stamp_i < 16) census[blockIdx.x * 16 + stamp_i] = wall_clock64(); ++stamp_i; };
+    auto stamp = [&]() { if (census && threadIdx.x == 0 && stamp_i < 16) census[tile * 16 + stamp_i] = wall_clock64(); ++stamp_i; };
     float* buf0 = lds;
     float* buf1 = lds + SLAB_FLOATS;
     float* vec = lds + 2 * SLAB_FLOATS;
@@ -246,11 +244,11 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
-    const int64_t p_raw = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+    const int64_t p_raw = ((int64_t)tile * 4 + wave) * 32 + (lane & 31);
     const bool live = p_raw < P;
     const int64_t p = live ? p_raw : P - 1;
     float* sv = nullptr;
-    if (SAVE) sv = saved + ((int64_t)blockIdx.x * 4 + wave) * (SLOTS_SAVED * 64) + lane;
+    if (SAVE) sv = saved + ((int64_t)tile * 4 + wave) * (SLOTS_SAVED * 64) + lane;
     auto save = [&](int slot, float v) { if (SAVE) sv[slot * 64] = v; };
     constexpr int HALF = (int)(ACT_STEPS / 2) * 4 * 64;                   // floats of half a 128x128 layer
 
@@ -398,11 +396,38 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
         if (live && half == 0) *reinterpret_cast<f32x4*>(raw + p_raw * 4) = f32x4{rgb[0], rgb[1], rgb[2], sigma};
     }
     if (census && tid == 0) {
-        census[blockIdx.x * 16 + 0] = t_start;
-        census[blockIdx.x * 16 + 1] = wall_clock64();
-        census[blockIdx.x * 16 + 2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
-        census[blockIdx.x * 16 + 3] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
-        census[blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memtime() - c_start;                      // shader-clock ticks of this workgroup
+        census[tile * 16 + 0] = t_start;
+        census[tile * 16 + 1] = wall_clock64();
+        census[tile * 16 + 2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+        census[tile * 16 + 3] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
+        census[tile * 16 + 13] = __builtin_amdgcn_s_memtime() - c_start;                      // shader-clock ticks of this workgroup
+    }
+}
+
+template <bool ALPHA_ONLY, bool SAVE>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_kernel(
+    const float* __restrict__ packed, int F, const float* __restrict__ ndc, int ndc_stride,
+    const float* __restrict__ feat, int feat_stride, const float* __restrict__ dirs, int dirs_stride,
+    int64_t P, int S, float* __restrict__ raw, float* __restrict__ saved, long long* __restrict__ census)
+{
+    mlp_fwd_pipe_tile<ALPHA_ONLY, SAVE>(blockIdx.x, packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, saved, census);
+}
+
+// Second half of a guarded 16-bit sequence (include/mvsnerf_hip.h): launched behind the fp16x3 kernel, does its work only when that kernel
+// reported a value outside fp16's range.  A small persistent grid that walks the tiles: when the guard is clear - the usual case - a few
+// hundred workgroups leave at once (the plain kernel's 1024 early exits, each waiting for its 69 KB of LDS, cost ~3 us of every batch);
+// when it is set, the same per-tile code runs and the results are the plain kernel's bits.
+template <bool ALPHA_ONLY>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_pipe_if_kernel(
+    const float* __restrict__ packed, int F, const float* __restrict__ ndc, int ndc_stride,
+    const float* __restrict__ feat, int feat_stride, const float* __restrict__ dirs, int dirs_stride,
+    int64_t P, int S, float* __restrict__ raw, const int* __restrict__ run_if)
+{
+    if (*run_if == 0) return;
+    const unsigned n_tiles = (unsigned)((P + 127) / 128);
+    for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        mlp_fwd_pipe_tile<ALPHA_ONLY, false>(tile, packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, nullptr, nullptr);
+        __syncthreads();                                       // the next tile's first slabs overwrite what the last GEMMs of this one read
     }
 }
 
@@ -412,9 +437,21 @@ static int launch_mlp_pipe(const float* packed, int F, const float* ndc, int ndc
                            const int* run_if = nullptr)
 {
     const size_t lds_bytes = PIPE_LDS_FLOATS * sizeof(float);
+    if (run_if) {                                       // predicated on a guard word: persistent grid (never with an activation store or a census)
+        if constexpr (!SAVE) {
+            static unsigned long long cap_if = 0;
+            if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_pipe_if_kernel<AO>), (int)lds_bytes, &cap_if)) return rc_;
+            const unsigned n_tiles = mvs_cdiv(P, 128);
+            mlp_fwd_pipe_if_kernel<AO><<<n_tiles < 512u ? n_tiles : 512u, 256, lds_bytes, st>>>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, run_if);
+            MVS_LAUNCH_CHECK();
+            return MVSNERF_OK;
+        } else {
+            return MVSNERF_EINVAL;
+        }
+    }
     static unsigned long long lds_cap_set = 0;          // per-device bit mask (common.h)
     if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_pipe_kernel<AO, SAVE>), (int)lds_bytes, &lds_cap_set)) return rc_;
-    mlp_fwd_pipe_kernel<AO, SAVE><<<mvs_cdiv(P, 128), 256, lds_bytes, st>>>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, saved, census, run_if);
+    mlp_fwd_pipe_kernel<AO, SAVE><<<mvs_cdiv(P, 128), 256, lds_bytes, st>>>(packed, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw, saved, census);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
