@@ -1199,12 +1199,13 @@ extern "C" int mvsnerf_abn_apply_add(const float* x1, const float* scale1, const
 }
 
 // The 8-channel sum of two lazily-activated tensors, written DEPTH-FASTEST: a, b [D][H][W][8] -> out[H][W][D][8] (MVSNERF_VOL_HWDC, the
-// layout the ray march reads best: sample_dev.h).  A workgroup owns a tile of 32 depth planes x 32 x-columns of one row y: it reads 32
-// runs of 1 KB (along x), applies leaky(x * scale + shift) to both operands, adds, parks the tile in LDS and writes 32 runs of 1 KB (along
-// depth; a 32 x 16 tile - 512-byte read runs - took 82 us where the channel-last epilogue takes 30).  Both sides of the transpose are contiguous; nothing else differs from abn_apply_add_kernel (same operation order per element).
+// layout the ray march reads best: sample_dev.h).  A workgroup owns a tile of 32 depth planes x 16 x-columns of one row y: it reads 32
+// runs of 512 B (along x), applies leaky(x * scale + shift) to both operands, adds, parks the tile in LDS and writes 16 runs of 1 KB (along
+// depth): 82 us at config 2, what the channel-last epilogue takes for the same 450 MB (78 us); a 32 x 32 tile (34 KB of LDS, four
+// workgroups per CU instead of nine) took 101 us.  Both sides of the transpose are contiguous; nothing else differs from abn_apply_add_kernel (same operation order per element).
 __global__ __launch_bounds__(256) void abn_apply_add_hwdc_kernel(ActSrc a, ActSrc b, int D, int H, int W, float* __restrict__ out)
 {
-    constexpr int TZ = 32, TX = 32, ROW = TX * 8 + 8;             // LDS row of a depth plane: 256 floats + 8 pad (spreads the column reads over the banks)
+    constexpr int TZ = 32, TX = 16, ROW = TX * 8 + 8;             // LDS row of a depth plane: 128 floats + 8 pad (spreads the column reads over the banks)
     __shared__ __attribute__((aligned(16))) float tile[TZ * ROW];
     const int nbx = (W + TX - 1) / TX, nbz = (D + TZ - 1) / TZ;
     const int bx = blockIdx.x % nbx, bz = (blockIdx.x / nbx) % nbz, y = blockIdx.x / (nbx * nbz);
@@ -1214,10 +1215,10 @@ __global__ __launch_bounds__(256) void abn_apply_add_hwdc_kernel(ActSrc a, ActSr
     f32x4 sa, ha, sb = {0, 0, 0, 0}, hb = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 4; ++k) { sa[k] = a.scale[c4 + k]; ha[k] = a.shift[c4 + k]; if (b.x) { sb[k] = b.scale[c4 + k]; hb[k] = b.shift[c4 + k]; } }
-    // phase 1: float4 number f of the tile = (plane f / 64, column (f % 64) / 2, quad f % 2): consecutive threads read consecutive 16 bytes
+    // phase 1: float4 number f of the tile = (plane f / 32, column (f % 32) / 2, quad f % 2): consecutive threads read consecutive 16 bytes
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int f = tid + 256 * r, zi = f >> 6, xi = (f & 63) >> 1;
+    for (int r = 0; r < 4; ++r) {
+        const int f = tid + 256 * r, zi = f >> 5, xi = (f & 31) >> 1;
         const int z = z0 + zi, x = x0 + xi;
         if (z < D && x < W) {
             const int64_t at = ((((int64_t)z * H + y) * W + x) << 3) + c4;
@@ -1235,7 +1236,7 @@ __global__ __launch_bounds__(256) void abn_apply_add_hwdc_kernel(ActSrc a, ActSr
     __syncthreads();
     // phase 2: float4 number f = (column f / 64, plane (f % 64) / 2, quad f % 2): consecutive threads write consecutive 16 bytes of a column's run
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < 4; ++r) {
         const int f = tid + 256 * r, xi = f >> 6, zi = (f & 63) >> 1;
         const int z = z0 + zi, x = x0 + xi;
         if (z < D && x < W)
@@ -1251,7 +1252,7 @@ extern "C" int mvsnerf_abn_apply_add_hwdc(const float* x1, const float* scale1, 
     if (x2 && (!scale2 || !shift2)) return MVSNERF_EINVAL;
     if (!mvs_aligned16(x1) || !mvs_aligned16(out) || (x2 && !mvs_aligned16(x2))) return MVSNERF_EALIGN;
     const ActSrc a{x1, scale1, shift1}, b{x2, scale2, shift2};
-    const int64_t nblk = (int64_t)((W + 31) / 32) * ((D + 31) / 32) * H;
+    const int64_t nblk = (int64_t)((W + 15) / 16) * ((D + 31) / 32) * H;
     if (nblk >= ((int64_t)1 << 31)) return MVSNERF_EUNSUPPORTED;
     abn_apply_add_hwdc_kernel<<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(a, b, D, H, W, out);
     MVS_LAUNCH_CHECK();
