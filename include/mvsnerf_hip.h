@@ -217,6 +217,26 @@ int mvsnerf_abn_apply_add_hwdc(const float* x1, const float* scale1, const float
                                const float* x2, const float* scale2, const float* shift2,
                                int D, int H, int W, float* out, void* stream);
 
+/* ---- conv1 ... conv11 of CostRegNet on the bf16 matrix cores (use_amp: train_mvs_nerf_pl.py:317-318 `precision=16`; models.py:725-769) ----
+ * Forward and data gradients of the nine 3x3x3 layers behind conv0 (conv0 itself: the mvsnerf_conv0_bf16_* entries above): the arguments of
+ * mvsnerf_conv3d_fwd / mvsnerf_conv_transpose3d_fwd - two lazily-activated fp32 sources, channel-last - with bf16 weight fragments
+ * (mvsnerf_conv3d_bf16_pack from the generic [27][Cin][Cout] layout of mvsnerf_conv3d_pack_weights: the layer's own weights or the re-packed
+ * ones of its data gradient) and, when stats_part != NULL, the InPlaceABN partial sums of the output (mvsnerf_conv3d_bf16_tiles /
+ * mvsnerf_conv_transpose3d_bf16_tiles slots x 2 x Cout floats, for mvsnerf_abn_finalize).  Operands are rounded to bf16 on load (round to
+ * nearest even), products accumulate in fp32, outputs are fp32.  Cin, Cout in {8, 16, 32, 64} (transposed: Cin >= 16); other shapes:
+ * MVSNERF_EUNSUPPORTED (mvsnerf_conv3d_bf16_packed_elems returns 0). */
+size_t mvsnerf_conv3d_bf16_packed_elems(int Cin, int Cout, int transposed);
+int mvsnerf_conv3d_bf16_pack(const float* wpacked, int Cin, int Cout, int transposed, void* wq, void* stream);
+int mvsnerf_conv3d_bf16_tiles(int D, int H, int W, int stride);
+int mvsnerf_conv3d_bf16_fwd(const float* x1, const float* scale1, const float* shift1,
+                            const float* x2, const float* scale2, const float* shift2,
+                            int Cin, int cin_ld, int D, int H, int W, const void* wq, int Cout, int stride,
+                            float* out, float* stats_part, void* stream);
+int mvsnerf_conv_transpose3d_bf16_tiles(int D, int H, int W);
+int mvsnerf_conv_transpose3d_bf16_fwd(const float* x1, const float* scale1, const float* shift1,
+                                      const float* x2, const float* scale2, const float* shift2,
+                                      int Cin, int D, int H, int W, const void* wq, int Cout, float* out, float* stats_part, void* stream);
+
 /* ---- encoder backward (generalizable training, train_mvs_nerf_pl.py:104-168) ----
  * Data gradients of the convolutions reuse the forward kernels with re-packed weights (mvsnerf_conv3d_pack_weights:
  * `flip` mirrors the taps; a stride-2 conv's data gradient is the transposed conv and vice versa).

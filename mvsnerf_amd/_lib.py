@@ -106,6 +106,12 @@ SIGNATURES = {
     "mvsnerf_conv0_bf16_dgrad": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_fp]),
     "mvsnerf_conv0_bf16_wgrad_parts": (_c_i, [_c_i] * 3),
     "mvsnerf_conv0_bf16_wgrad": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_conv3d_bf16_packed_elems": (ctypes.c_size_t, [_c_i, _c_i, _c_i]),
+    "mvsnerf_conv3d_bf16_pack": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_conv3d_bf16_tiles": (_c_i, [_c_i] * 4),
+    "mvsnerf_conv3d_bf16_fwd": (_c_i, [_c_fp] * 6 + [_c_i] * 5 + [_c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_conv_transpose3d_bf16_tiles": (_c_i, [_c_i] * 3),
+    "mvsnerf_conv_transpose3d_bf16_fwd": (_c_i, [_c_fp] * 6 + [_c_i] * 4 + [_c_fp, _c_i, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_conv3d_mfma_supported": (_c_i, [_c_i, _c_i, _c_i]),
     "mvsnerf_conv3d_pack_weights_mfma": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_fp]),
     "mvsnerf_conv3d_mfma_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),

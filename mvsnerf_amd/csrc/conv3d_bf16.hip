@@ -1,0 +1,327 @@
+// conv1 ... conv11 of CostRegNet (models.py:725-769: 3x3x3, stride 1 / 2, and the three stride-2 transposed layers) on the bf16 matrix cores:
+// the rest of the encoder side of the reference's `precision=16 if args.use_amp` (train_mvs_nerf_pl.py:317-318; BASELINE config 3 "bf16") next
+// to conv0 (conv_bf16.hip).  Forward AND data gradients: a data gradient is the same convolution with re-packed weights (mirrored taps for
+// stride 1; stride-2 conv <-> transposed conv), exactly as on the fp32 path.  Operands are rounded to bf16 (round to nearest even) on their way
+// into the A / B fragments, products accumulate in fp32, activations stay fp32 in HBM with their pending InPlaceABN applied on load, the
+// InPlaceABN partial sums of the output leave with the same launch.
+//
+// One v_mfma_f32_16x16x32_bf16 multiplies 16 output voxels (A rows) x 32 k-values by 32 k x 16 output channels.  k enumerates (tap, input
+// channel) with the channel fastest; a lane (m = lane & 15, kg = lane >> 4) feeds the 8 consecutive k-values 32 ks + 8 kg .. + 7, i.e. eight
+// consecutive channels of ONE tap of its voxel (Cin is 8, 16, 32 or 64, so a group of eight never straddles taps): two 16-byte loads of the
+// channel-last input, straight from L1 / L2 (these volumes are at most 37 MB; the 27-fold re-read never reaches HBM), activated, rounded, used.
+// Weights are packed once per weight change into fragment order [k-step][16-column block][lane][8] (16 bytes per lane and MFMA).
+// A wave owns an M-tile of 16 voxels and ALL output channels (1, 2 or 4 column blocks); four waves per workgroup share the statistics slot.
+//
+// Transposed layers: out[o] = sum over taps k with o = 2 i - 1 + k.  The eight parity classes of o = 2 i + p are eight gather-form
+// convolutions over the input lattice with 1 / 2 / 4 / 8 taps (per dimension: p = 0 -> kernel index 1 from input i; p = 1 -> kernel index 0
+// from input i + 1 and kernel index 2 from input i); blockIdx.y = class, an M-tile = 16 consecutive lattice positions, no zero work.
+#include "common.h"
+#include "act.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
+
+// lazily-activated operand tables in LDS: [0] scale a, [1] shift a, [2] scale b, [3] shift b
+template <int CIN>
+__device__ __forceinline__ void stage_act(const ActSrc& a, const ActSrc& b, float (*act)[CIN], int tid)
+{
+    for (int c = tid; c < CIN; c += 256) {
+        act[0][c] = a.scale ? a.scale[c] : 1.0f; act[1][c] = a.scale ? a.shift[c] : 0.0f;
+        act[2][c] = (b.x && b.scale) ? b.scale[c] : 1.0f; act[3][c] = (b.x && b.scale) ? b.shift[c] : 0.0f;
+    }
+    __syncthreads();
+}
+
+// eight consecutive channels c0 .. c0 + 7 at float offset `off` of the (first + second) source, activated, rounded to bf16; zeros when !in
+template <int CIN>
+__device__ __forceinline__ bf16x8 load_a8(const ActSrc& a, const ActSrc& b, const float (*act)[CIN], int64_t off, int c0, bool in)
+{
+    f32x4 v0 = *reinterpret_cast<const f32x4*>(a.x + off), v1 = *reinterpret_cast<const f32x4*>(a.x + off + 4);
+    if (a.scale) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v0[j] = act_apply(v0[j], act[0][c0 + j], act[1][c0 + j]); v1[j] = act_apply(v1[j], act[0][c0 + 4 + j], act[1][c0 + 4 + j]); }
+    }
+    if (b.x) {
+        f32x4 t0 = *reinterpret_cast<const f32x4*>(b.x + off), t1 = *reinterpret_cast<const f32x4*>(b.x + off + 4);
+        if (b.scale) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { t0[j] = act_apply(t0[j], act[2][c0 + j], act[3][c0 + j]); t1[j] = act_apply(t1[j], act[2][c0 + 4 + j], act[3][c0 + 4 + j]); }
+        }
+        v0 += t0; v1 += t1;
+    }
+    if (!in) { v0 = f32x4{0, 0, 0, 0}; v1 = v0; }                 // zero padding of the ACTIVATED input
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { r[j] = (__bf16)v0[j]; r[4 + j] = (__bf16)v1[j]; }
+    return r;
+}
+
+// D fragment -> memory + InPlaceABN partial sums.  Lane (n = lane & 15, g = lane >> 4): acc[nt][r] = voxel `vox_of(4 g + r)`, channel 16 nt + n.
+template <int NT, typename VOXFN>
+__device__ __forceinline__ void store_tile(const f32x4 (&acc)[NT], int Cout, float* __restrict__ out, float* __restrict__ stats, int64_t slot, int64_t nslots,
+                                           float (*red)[2][NT * 16], int tid, VOXFN vox_of)
+{
+    const int lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
+    int64_t ov[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ov[r] = vox_of(4 * g + r);        // -1: no such voxel
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ch = nt * 16 + n;
+        float s = 0.f, q = 0.f;
+        if (ch < Cout) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ov[r] >= 0) { const float v = acc[nt][r]; out[ov[r] * Cout + ch] = v; s += v; q = fmaf(v, v, q); }
+        }
+        if (stats) {
+            s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+            if (g == 0) { red[wave][0][ch] = s; red[wave][1][ch] = q; }
+        }
+    }
+    if (stats) {          // one slot per workgroup: abn_part_at(...) of common.h (abn_finalize_kernel's layout)
+        __syncthreads();
+        if (tid < 2 * NT * 16) {
+            const int which = tid / (NT * 16), c = tid - which * (NT * 16);
+            if (c < Cout) stats[abn_part_at(which, c, Cout, slot, nslots)] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ conv, stride S
+// KSPLIT = 1: the four waves of a workgroup own four M-tiles.  KSPLIT = 4 (layers with few voxels: conv4 ... conv6 have 73 k / 9 k outputs,
+// i.e. less than one M-tile per SIMD, and a wave's k-loop would be one long chain of exposed load latencies): the four waves share ONE
+// M-tile, take every fourth k-step and meet in LDS; wave 0 adds the partial accumulators in a fixed order and stores.
+template <int CIN, int NT, int S, int KSPLIT>
+__global__ __launch_bounds__(256) void conv3d_k3_bf16_kernel(ActSrc a, ActSrc b, int ld, int Di, int Hi, int Wi, const __bf16* __restrict__ wq, int Cout,
+                                                            float* __restrict__ out, int Do, int Ho, int Wo, float* __restrict__ stats)
+{
+    constexpr int KS = (27 * CIN + 31) / 32, LOG = ilog2c(CIN);
+    static_assert((1 << LOG) == CIN && CIN >= 8, "Cin: a power of two >= 8 (groups of eight channels never straddle taps)");
+    static_assert(KSPLIT == 1 || KSPLIT == 4, "one M-tile per wave, or one per workgroup");
+    __shared__ float act[4][CIN];
+    __shared__ float red[4][2][NT * 16];
+    __shared__ __attribute__((aligned(16))) float part[KSPLIT == 4 ? 3 * NT * 64 * 4 : 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, kg = lane >> 4;
+    stage_act<CIN>(a, b, act, tid);
+    const int64_t nvox = (int64_t)Do * Ho * Wo;
+    const int64_t tile0 = (KSPLIT == 1 ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x) * 16;
+    const int64_t vox = tile0 + m;
+    const bool live = vox < nvox;
+    const int64_t vc = live ? vox : nvox - 1;
+    const int x = (int)(vc % Wo), y = (int)((vc / Wo) % Ho), z = (int)(vc / ((int64_t)Wo * Ho));
+    const int zb = z * S - 1, yb = y * S - 1, xb = x * S - 1;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
+    const bf16x8* __restrict__ wl = reinterpret_cast<const bf16x8*>(wq) + lane;
+#pragma unroll 2
+    for (int ks = (KSPLIT == 1 ? 0 : wave); ks < KS; ks += KSPLIT) {
+        const int kb = ks * 32 + kg * 8;
+        const int tap = kb >> LOG, c0 = kb & (CIN - 1);
+        const int dz = tap / 9, r9 = tap - dz * 9, dy = r9 / 3, dx = r9 - dy * 3;
+        const int zi = zb + dz, yi = yb + dy, xi = xb + dx;
+        const bool in = live && tap < 27 && zi >= 0 && zi < Di && yi >= 0 && yi < Hi && xi >= 0 && xi < Wi;
+        const int64_t off = in ? (((int64_t)zi * Hi + yi) * Wi + xi) * ld + c0 : 0;
+        const bf16x8 av = load_a8<CIN>(a, b, act, off, c0, in);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wl[(ks * NT + nt) * 64], acc[nt], 0, 0, 0);
+    }
+    if constexpr (KSPLIT == 4) {
+        if (wave > 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(part + (((wave - 1) * NT + nt) * 64 + lane) * 4) = acc[nt];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] += *reinterpret_cast<const f32x4*>(part + ((w * NT + nt) * 64 + lane) * 4);
+        }
+    }
+    store_tile<NT>(acc, Cout, out, stats, blockIdx.x, gridDim.x, red, tid, [&](int r) {
+        const int64_t o = tile0 + r;
+        return (o < nvox && (KSPLIT == 1 || wave == 0)) ? o : (int64_t)-1;
+    });
+}
+
+// ------------------------------------------------------------------------------------------------------------------ transposed conv, stride 2
+template <int CIN, int NT>
+__global__ __launch_bounds__(256) void convT3d_k3s2_bf16_kernel(ActSrc a, ActSrc b, int Di, int Hi, int Wi, const __bf16* __restrict__ wq, int Cout,
+                                                               float* __restrict__ out, float* __restrict__ stats)
+{
+    constexpr int KSMAX = (8 * CIN) / 32, LOG = ilog2c(CIN);
+    __shared__ float act[4][CIN];
+    __shared__ float red[4][2][NT * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, kg = lane >> 4;
+    stage_act<CIN>(a, b, act, tid);
+    const int cls = blockIdx.y, pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+    const int ntaps = (1 + pz) * (1 + py) * (1 + px), ks_n = (ntaps * CIN + 31) / 32;
+    const int64_t nvox = (int64_t)Di * Hi * Wi;                   // input lattice positions
+    const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+    const int64_t vox = tile0 + m;
+    const bool live = vox < nvox;
+    const int64_t vc = live ? vox : nvox - 1;
+    const int x = (int)(vc % Wi), y = (int)((vc / Wi) % Hi), z = (int)(vc / ((int64_t)Wi * Hi));
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
+    const bf16x8* __restrict__ wl = reinterpret_cast<const bf16x8*>(wq) + (int64_t)cls * KSMAX * NT * 64 + lane;
+#pragma unroll 2
+    for (int ks = 0; ks < ks_n; ++ks) {
+        const int kb = ks * 32 + kg * 8;
+        const int t = kb >> LOG, c0 = kb & (CIN - 1);
+        // sub-tap bits of the dimensions with parity 1, x lowest: bit 0 -> kernel index 0, input i + 1; bit 1 -> kernel index 2, input i
+        int bits = t;
+        const int sx = px ? (bits & 1) : 1; bits >>= px;
+        const int sy = py ? (bits & 1) : 1; bits >>= py;
+        const int sz = pz ? (bits & 1) : 1;
+        const int zi = z + (sz ? 0 : 1), yi = y + (sy ? 0 : 1), xi = x + (sx ? 0 : 1);
+        const bool in = live && t < ntaps && zi < Di && yi < Hi && xi < Wi;
+        const int64_t off = in ? (((int64_t)zi * Hi + yi) * Wi + xi) * CIN + c0 : 0;
+        const bf16x8 av = load_a8<CIN>(a, b, act, off, c0, in);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wl[(ks * NT + nt) * 64], acc[nt], 0, 0, 0);
+    }
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    store_tile<NT>(acc, Cout, out, stats, (int64_t)blockIdx.y * gridDim.x + blockIdx.x, (int64_t)8 * gridDim.x, red, tid, [&](int r) {
+        const int64_t i = tile0 + r;
+        if (i >= nvox) return (int64_t)-1;
+        const int ix = (int)(i % Wi), iy = (int)((i / Wi) % Hi), iz = (int)(i / ((int64_t)Wi * Hi));
+        return ((int64_t)(2 * iz + pz) * Ho + (2 * iy + py)) * Wo + (2 * ix + px);
+    });
+}
+
+// ------------------------------------------------------------------------------------------------------------------ weight fragments
+// wp[27][Cin][Cout] fp32 (mvsnerf_conv3d_pack_weights: the generic layout of the layer or of its data gradient) -> bf16 B fragments.
+// conv:        wq[ks][nt][lane][8],  k = 32 ks + 8 (lane >> 4) + j = tap * Cin + ci, column 16 nt + (lane & 15)
+// transposed:  wq[class][ks][nt][lane][8] (KSMAX k-steps reserved per class), k = t * Cin + ci with t the class's sub-tap number (kernel above)
+__global__ __launch_bounds__(256) void conv3d_bf16_pack_kernel(const float* __restrict__ wp, int Cin, int Cout, int NT, int transposed, __bf16* __restrict__ wq)
+{
+    const int log = 31 - __clz(Cin);
+    const int ksn = transposed ? (8 * Cin) / 32 : (27 * Cin + 31) / 32;
+    const int64_t per = (int64_t)ksn * NT * 64 * 8, total = per * (transposed ? 8 : 1);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cls = (int)(i / per);
+    const int64_t r = i - cls * per;
+    const int j = (int)(r & 7), lane = (int)((r >> 3) & 63), nt = (int)((r >> 9) % NT), ks = (int)((r >> 9) / NT);
+    const int kb = ks * 32 + (lane >> 4) * 8 + j, t = kb >> log, ci = kb & (Cin - 1), co = nt * 16 + (lane & 15);
+    int tap = -1;
+    if (!transposed) tap = t < 27 ? t : -1;
+    else {
+        const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1, ntaps = (1 + pz) * (1 + py) * (1 + px);
+        if (t < ntaps) {
+            int bits = t;
+            const int sx = px ? (bits & 1) : 1; bits >>= px;
+            const int sy = py ? (bits & 1) : 1; bits >>= py;
+            const int sz = pz ? (bits & 1) : 1;
+            const int kx = px ? (sx ? 2 : 0) : 1, ky = py ? (sy ? 2 : 0) : 1, kz = pz ? (sz ? 2 : 0) : 1;
+            tap = kz * 9 + ky * 3 + kx;
+        }
+    }
+    wq[i] = (__bf16)((tap >= 0 && co < Cout) ? wp[((int64_t)tap * Cin + ci) * Cout + co] : 0.0f);
+}
+
+bool shape_ok(int Cin, int Cout) { return (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 8 || Cout == 16 || Cout == 32 || Cout == 64); }
+int n_col_blocks(int Cout) { return (Cout + 15) / 16; }
+
+}  // namespace
+
+extern "C" size_t mvsnerf_conv3d_bf16_packed_elems(int Cin, int Cout, int transposed)
+{
+    if (!shape_ok(Cin, Cout)) return 0;
+    const size_t ksn = transposed ? (size_t)(8 * Cin) / 32 : (size_t)(27 * Cin + 31) / 32;
+    return ksn * n_col_blocks(Cout) * 512 * (transposed ? 8 : 1);
+}
+
+extern "C" int mvsnerf_conv3d_bf16_pack(const float* wpacked, int Cin, int Cout, int transposed, void* wq, void* stream)
+{
+    if (!wpacked || !wq) return MVSNERF_EINVAL;
+    if (!shape_ok(Cin, Cout)) return MVSNERF_EUNSUPPORTED;
+    if (!mvs_aligned16(wq)) return MVSNERF_EALIGN;
+    const size_t total = mvsnerf_conv3d_bf16_packed_elems(Cin, Cout, transposed);
+    conv3d_bf16_pack_kernel<<<mvs_cdiv((int64_t)total, 256), 256, 0, (hipStream_t)stream>>>(wpacked, Cin, Cout, n_col_blocks(Cout), transposed ? 1 : 0,
+                                                                                        reinterpret_cast<__bf16*>(wq));
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// InPlaceABN statistics slots of the launches below (input dims) = workgroups: 64 output voxels each, or 16 when the layer is small enough for
+// the k-split form (fewer than 8192 M-tiles of 16 voxels); x 8 parity classes when transposed
+static bool ksplit_of(int64_t nvox_out) { return (nvox_out + 15) / 16 < 8192; }
+
+extern "C" int mvsnerf_conv3d_bf16_tiles(int D, int H, int W, int stride)
+{
+    if (stride != 1 && stride != 2) return 0;
+    const int64_t nvox = (int64_t)((D - 1) / stride + 1) * ((H - 1) / stride + 1) * ((W - 1) / stride + 1);
+    return (int)(ksplit_of(nvox) ? (nvox + 15) / 16 : (nvox + 63) / 64);
+}
+
+extern "C" int mvsnerf_conv_transpose3d_bf16_tiles(int D, int H, int W) { return (int)(8 * (((int64_t)D * H * W + 63) / 64)); }
+
+static bool act_ok16(const float* x, const float* sc, const float* sh) { return x && ((sc == nullptr) == (sh == nullptr)) && mvs_aligned16(x); }
+
+extern "C" int mvsnerf_conv3d_bf16_fwd(const float* x1, const float* scale1, const float* shift1,
+                                       const float* x2, const float* scale2, const float* shift2,
+                                       int Cin, int cin_ld, int D, int H, int W, const void* wq, int Cout, int stride,
+                                       float* out, float* stats_part, void* stream)
+{
+    if (!act_ok16(x1, scale1, shift1) || !wq || !out || D < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
+    if (x2 && !act_ok16(x2, scale2, shift2)) return MVSNERF_EINVAL;
+    if ((stride != 1 && stride != 2) || !shape_ok(Cin, Cout)) return MVSNERF_EUNSUPPORTED;
+    if ((cin_ld & 3) || cin_ld < Cin || !mvs_aligned16(wq)) return MVSNERF_EALIGN;
+    const ActSrc a{x1, scale1, shift1}, b{x2, scale2, shift2};
+    const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;   // k3 p1
+    const unsigned grid = (unsigned)mvsnerf_conv3d_bf16_tiles(D, H, W, stride);
+    hipStream_t st = (hipStream_t)stream;
+    const __bf16* w = reinterpret_cast<const __bf16*>(wq);
+    const bool split = ksplit_of((int64_t)Do * Ho * Wo);
+#define MVS_C16(CIN, NT, S) do { if (split) conv3d_k3_bf16_kernel<CIN, NT, S, 4><<<grid, 256, 0, st>>>(a, b, cin_ld, D, H, W, w, Cout, out, Do, Ho, Wo, stats_part); \
+                                 else conv3d_k3_bf16_kernel<CIN, NT, S, 1><<<grid, 256, 0, st>>>(a, b, cin_ld, D, H, W, w, Cout, out, Do, Ho, Wo, stats_part); } while (0)
+    switch ((Cin * 100 + n_col_blocks(Cout)) * 10 + stride) {
+        case (8 * 100 + 1) * 10 + 1: MVS_C16(8, 1, 1); break;    case (8 * 100 + 1) * 10 + 2: MVS_C16(8, 1, 2); break;
+        case (16 * 100 + 1) * 10 + 1: MVS_C16(16, 1, 1); break;  case (16 * 100 + 1) * 10 + 2: MVS_C16(16, 1, 2); break;
+        case (16 * 100 + 2) * 10 + 1: MVS_C16(16, 2, 1); break;  case (16 * 100 + 2) * 10 + 2: MVS_C16(16, 2, 2); break;
+        case (32 * 100 + 1) * 10 + 2: MVS_C16(32, 1, 2); break;
+        case (32 * 100 + 2) * 10 + 1: MVS_C16(32, 2, 1); break;  case (32 * 100 + 2) * 10 + 2: MVS_C16(32, 2, 2); break;
+        case (32 * 100 + 4) * 10 + 1: MVS_C16(32, 4, 1); break;  case (32 * 100 + 4) * 10 + 2: MVS_C16(32, 4, 2); break;
+        case (64 * 100 + 2) * 10 + 2: MVS_C16(64, 2, 2); break;
+        case (64 * 100 + 4) * 10 + 1: MVS_C16(64, 4, 1); break;  case (64 * 100 + 4) * 10 + 2: MVS_C16(64, 4, 2); break;
+        default: return MVSNERF_EUNSUPPORTED;
+    }
+#undef MVS_C16
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+extern "C" int mvsnerf_conv_transpose3d_bf16_fwd(const float* x1, const float* scale1, const float* shift1,
+                                                 const float* x2, const float* scale2, const float* shift2,
+                                                 int Cin, int D, int H, int W, const void* wq, int Cout, float* out, float* stats_part, void* stream)
+{
+    if (!act_ok16(x1, scale1, shift1) || !wq || !out || D < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
+    if (x2 && !act_ok16(x2, scale2, shift2)) return MVSNERF_EINVAL;
+    if (!shape_ok(Cin, Cout) || Cin < 16) return MVSNERF_EUNSUPPORTED;
+    if (!mvs_aligned16(wq)) return MVSNERF_EALIGN;
+    const ActSrc a{x1, scale1, shift1}, b{x2, scale2, shift2};
+    const dim3 grid((unsigned)(((int64_t)D * H * W + 63) / 64), 8);
+    hipStream_t st = (hipStream_t)stream;
+    const __bf16* w = reinterpret_cast<const __bf16*>(wq);
+#define MVS_T16(CIN, NT) convT3d_k3s2_bf16_kernel<CIN, NT><<<grid, 256, 0, st>>>(a, b, D, H, W, w, Cout, out, stats_part)
+    switch (Cin * 100 + n_col_blocks(Cout)) {
+        case 16 * 100 + 1: MVS_T16(16, 1); break;
+        case 32 * 100 + 1: MVS_T16(32, 1); break;
+        case 32 * 100 + 2: MVS_T16(32, 2); break;
+        case 64 * 100 + 2: MVS_T16(64, 2); break;
+        case 64 * 100 + 4: MVS_T16(64, 4); break;
+        default: return MVSNERF_EUNSUPPORTED;
+    }
+#undef MVS_T16
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}

@@ -473,6 +473,28 @@ class _PackedConv:
         """[tap][ci/8][co][8] layout of get(mode)'s weights for the matrix-core kernels of the 32/64-channel layers."""
         return self._cached(mode + "_m32", 2, mode, "get_mfma", mode)
 
+    def get_bf16(self, mode="fwd"):
+        """bf16 B fragments of get(mode)'s convolution for the generic bf16 kernels (csrc/conv3d_bf16.hip); None when the shape has no such kernel.
+        The KERNEL that runs `mode` is transposed when exactly one of (layer is transposed, mode is its data gradient of a strided layer) holds:
+        a stride-2 Conv3d's data gradient is a transposed convolution and vice versa."""
+        w = self.conv.weight
+        ci_real, co_real, ci_pad, co_pad, _, _, _ = self._params(mode)
+        strided = self.conv.stride[0] == 2
+        kernel_t = (self.transposed != (mode == "dgrad")) if strided else False
+        lib = _lib.lib()
+        n = lib.mvsnerf_conv3d_bf16_packed_elems(ci_pad, co_pad, int(kernel_t))
+        if n == 0 or ci_real != ci_pad or (kernel_t and ci_pad < 16):
+            return None
+        key = (w.data_ptr(), w._version, _lib.weights_epoch())
+        name = mode + "_bf16"
+        hit = self.cache.get(name)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        buf = torch.empty(n, device=w.device, dtype=torch.bfloat16)
+        check(lib.mvsnerf_conv3d_bf16_pack(self.get(mode).data_ptr(), ci_pad, co_pad, int(kernel_t), buf.data_ptr(), stream_ptr()), "conv3d_bf16_pack")
+        self.cache[name] = (key, buf)
+        return buf
+
     def get_bf16_conv0(self, dgrad=None):
         """bf16 B fragments of the 8-output-channel stride-1 layer (csrc/conv_bf16.hip): dgrad None -> forward; (c_first, n_ci) -> the
         data gradient w.r.t. input channels c_first .. c_first + n_ci - 1."""
@@ -565,6 +587,23 @@ def _ptrs(src):
     return src.data_ptr(), 0, 0
 
 
+_LAYER_BF16 = [False]      # conv1 ... conv11 on the bf16 matrix cores (csrc/conv3d_bf16.hip): set for the extent of a forward / backward by _layer_precision
+
+
+class _layer_precision:
+    """The arithmetic of the 3-D layers behind conv0 for the enclosed launches: bf16 operands (use_amp, encoder_precision("bf16")) or fp32.
+    A backward pass re-enters it with what its forward ran (the `with encoder_precision(...)` of the caller is long gone by then)."""
+
+    def __init__(self, bf16):
+        self.bf16 = bool(bf16)
+
+    def __enter__(self):
+        self.prev, _LAYER_BF16[0] = _LAYER_BF16[0], self.bf16
+
+    def __exit__(self, *exc):
+        _LAYER_BF16[0] = self.prev
+
+
 def _conv(src1, src2, dims_in, cin_ld, wbuf, cin_k, cout_k, stride, packed=None, mode="fwd", want_stats=None):
     """k3 p1 convolution kernel launch: input (D,H,W) with channel stride cin_ld -> raw (Do,Ho,Wo,cout_k).
     packed (+ mode): the layer's _PackedConv - lets the 32/64-channel layers take the matrix-core kernel with its own weight layout.
@@ -573,6 +612,16 @@ def _conv(src1, src2, dims_in, cin_ld, wbuf, cin_k, cout_k, stride, packed=None,
     Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
     dev = (src1.x if isinstance(src1, _Lazy) else src1).device
     out = torch.empty((Do, Ho, Wo, cout_k), device=dev, dtype=torch.float32)
+    wq = packed.get_bf16(mode) if (_LAYER_BF16[0] and packed is not None) else None
+    if wq is not None:               # use_amp: bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulation, statistics from the same launch
+        lib = _lib.lib()
+        part, nblk = None, 0
+        if want_stats and FUSED_ABN_STATS:
+            nblk = lib.mvsnerf_conv3d_bf16_tiles(D, H, W, stride)
+            part = torch.empty(nblk * 2 * cout_k, device=out.device, dtype=torch.float32)
+        check(lib.mvsnerf_conv3d_bf16_fwd(*_ptrs(src1), *_ptrs(src2), cin_k, cin_ld, D, H, W, wq.data_ptr(), cout_k, stride, out.data_ptr(),
+                                          0 if part is None else part.data_ptr(), stream_ptr()), "conv3d_bf16_fwd")
+        return out if want_stats is None else (out, None if part is None else (part, nblk))
     if packed is not None and src2 is None and _lib.lib().mvsnerf_conv3d_mfma_supported(cin_k, cout_k, stride):
         lib = _lib.lib()
         x, sc, sh = _ptrs(src1)
@@ -607,6 +656,16 @@ def _conv_t(src1, src2, dims_in, wbuf, cin_k, cout_k, packed=None, mode="fwd", w
     D, H, W, _ = dims_in
     dev = (src1.x if isinstance(src1, _Lazy) else src1).device
     out = torch.empty((2 * D, 2 * H, 2 * W, cout_k), device=dev, dtype=torch.float32)
+    wq = packed.get_bf16(mode) if (_LAYER_BF16[0] and packed is not None) else None
+    if wq is not None:               # use_amp: the eight parity classes as bf16 gather-form convolutions (csrc/conv3d_bf16.hip)
+        lib = _lib.lib()
+        part, nblk = None, 0
+        if want_stats and FUSED_ABN_STATS:
+            nblk = lib.mvsnerf_conv_transpose3d_bf16_tiles(D, H, W)
+            part = torch.empty(nblk * 2 * cout_k, device=out.device, dtype=torch.float32)
+        check(lib.mvsnerf_conv_transpose3d_bf16_fwd(*_ptrs(src1), *_ptrs(src2), cin_k, D, H, W, wq.data_ptr(), cout_k, out.data_ptr(),
+                                                    0 if part is None else part.data_ptr(), stream_ptr()), "conv_transpose3d_bf16_fwd")
+        return out if want_stats is None else (out, None if part is None else (part, nblk))
     if packed is not None and _lib.lib().mvsnerf_conv_transpose3d_c8_supported(cin_k, cout_k):
         lib = _lib.lib()            # lazily-activated sources and the skip sum are applied while staging; statistics from the same launch
         part, nblk = None, 0
@@ -797,15 +856,16 @@ class CostRegNet(nn.Module):
         else:
             buf, ld = _as_channel_last(x, self.conv0._packed_cin_pad())
             c0 = self.conv0.lazy(buf, (D, H, W, ld), ld)
-        c1 = self.conv1.lazy(c0, c0.dims, 8)
-        c2 = self.conv2.lazy(c1, c1.dims, 16)
-        c3 = self.conv3.lazy(c2, c2.dims, 16)
-        c4 = self.conv4.lazy(c3, c3.dims, 32)
-        c5 = self.conv5.lazy(c4, c4.dims, 32)
-        c6 = self.conv6.lazy(c5, c5.dims, 64)
-        u7 = self.conv7.lazy(c6, c6.dims)                       # x = conv4 + conv7(x)   (models.py:762)
-        u9 = self.conv9.lazy(c4, c4.dims, src2=u7)              # x = conv2 + conv9(x)   (:764)
-        u11 = self.conv11.lazy(c2, c2.dims, src2=u9)            # x = conv0 + conv11(x)  (:766)
+        with _layer_precision(ENCODER_PRECISION == "bf16"):     # use_amp: conv1 ... conv11 on the bf16 matrix cores as well (csrc/conv3d_bf16.hip)
+            c1 = self.conv1.lazy(c0, c0.dims, 8)
+            c2 = self.conv2.lazy(c1, c1.dims, 16)
+            c3 = self.conv3.lazy(c2, c2.dims, 16)
+            c4 = self.conv4.lazy(c3, c3.dims, 32)
+            c5 = self.conv5.lazy(c4, c4.dims, 32)
+            c6 = self.conv6.lazy(c5, c5.dims, 64)
+            u7 = self.conv7.lazy(c6, c6.dims)                       # x = conv4 + conv7(x)   (models.py:762)
+            u9 = self.conv9.lazy(c4, c4.dims, src2=u7)              # x = conv2 + conv9(x)   (:764)
+            u11 = self.conv11.lazy(c2, c2.dims, src2=u9)            # x = conv0 + conv11(x)  (:766)
         _flush_nbt()
         return (buf, ld), [c0, c1, c2, c3, c4, c5, c6, u7, u9, u11]
 
@@ -921,6 +981,7 @@ class _CostRegFunction(torch.autograd.Function):
     def forward(ctx, x, net, *params):
         (buf, ld), lz = net._run(x)
         ctx.net, ctx.buf, ctx.ld, ctx.lz, ctx.xshape = net, buf, ld, lz, tuple(x.shape)
+        ctx.layers_bf16 = ENCODER_PRECISION == "bf16"
         return _neural_volume(lz[0], lz[9])
 
     @staticmethod
@@ -938,7 +999,8 @@ class _CostRegFunction(torch.autograd.Function):
                 return gw, None
             return gw, _conv(gx, None, c0.dims, pk.cout, lambda: pk.get("dgrad"), pk.cout, pk.cin_pad, 1, packed=pk, mode="dgrad")
 
-        g_cost, flat = _costreg_backward(net, lz, g_out, conv0_grads, sums)
+        with _layer_precision(ctx.layers_bf16):
+            g_cost, flat = _costreg_backward(net, lz, g_out, conv0_grads, sums)
         return (None if g_cost is None else _cl_view_to_ncdhw(g_cost, ctx.xshape[1]), None, *flat)
 
 
@@ -1107,6 +1169,7 @@ class _SweepRegFunction(torch.autograd.Function):
         cost, _, saved = _plane_sweep(imgs, feats, proj_mats, depth_values, pad, True, blocked="bf16" if ENCODER_PRECISION == "bf16" else True)
         _, lz = net._run(cost)
         ctx.net, ctx.cost, ctx.lz, ctx.saved = net, cost, lz, saved
+        ctx.layers_bf16 = ENCODER_PRECISION == "bf16"
         return _neural_volume(lz[0], lz[9])
 
     @staticmethod
@@ -1139,7 +1202,8 @@ class _SweepRegFunction(torch.autograd.Function):
                 return gw, None
             return gw, _conv(gx, None, c0.dims, pk.cout, pk.get_dgrad_slice(3 * V, C), pk.cout, C, 1)     # d cost[variance channels]
 
-        g_var, flat = _costreg_backward(net, lz, g_out, conv0_grads, sums)
+        with _layer_precision(ctx.layers_bf16):
+            g_var, flat = _costreg_backward(net, lz, g_out, conv0_grads, sums)
         g_feats = None
         if g_var is not None:
             g_feats_cl = torch.zeros((V, H, W, C), device=feats_cl.device, dtype=torch.float32)

@@ -1,6 +1,6 @@
 """torch.profiler view of the use_amp training step: which Python lines launch the small copy / fill / elementwise kernels."""
 import sys, torch
-sys.path.insert(0, '.')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); os.chdir(ROOT)
 import numpy as np
 from mvsnerf_amd import train
 from torch.profiler import profile, ProfilerActivity

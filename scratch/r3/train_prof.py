@@ -1,7 +1,7 @@
 """One generalizable-training run at config-3 shapes for rocprofv3 (2 warm-up + N timed steps).  usage: train_prof.py [amp] [steps]
 MVS_LIB=<path of another build of the library> selects it (same-box A/B of a kernel change)."""
 import sys, time, torch, os
-sys.path.insert(0, '.')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); os.chdir(ROOT)
 import numpy as np
 from mvsnerf_amd import train, _lib
 if os.environ.get('MVS_LIB'):

@@ -162,4 +162,8 @@ def test_training_node_bf16_vs_fp32_gradients():
     e_gw = {n: rel(res["bf16"][2][n], res["fp32"][2][n]) for n in res["fp32"][2]}
     worst = max(e_gw, key=e_gw.get)
     print(f"bf16 training node vs fp32: volume {e_vol:.2e}, d feats {e_gf:.2e}, worst weight gradient {e_gw[worst]:.2e} ({worst})")
-    assert 0 < e_vol < 5e-3 and e_gf < 0.15 and e_gw[worst] < 0.4     # measured 6.0e-4 / 4.3e-2 / 0.18 (conv6: batch statistics over 24 voxels in this tiny volume)
+    # round 3 (conv0 alone on bf16 operands) measured 6.0e-4 / 4.3e-2 / 0.18 (conv6: batch statistics over 24 voxels in this tiny volume); since round 4
+    # conv1 ... conv11 round their operands as well (tests/test_gpu_bf16_layers.py holds the per-layer bounds)
+    from tests.util import record_err
+    record_err("bf16_node_tiny:volume", e_vol); record_err("bf16_node_tiny:d_feats", e_gf); record_err("bf16_node_tiny:worst_weight_grad", e_gw[worst])
+    assert 0 < e_vol < 3e-2 and e_gf < 0.4 and e_gw[worst] < 0.8

@@ -1,0 +1,162 @@
+"""conv1 ... conv11 of CostRegNet on the bf16 matrix cores (csrc/conv3d_bf16.hip; the reference's `precision=16 if args.use_amp`,
+train_mvs_nerf_pl.py:317-318, applied to models.py:725-769): every layer shape, forward and data gradient, against float64 convolutions of
+exactly the kernel's operands - activations and weights rounded to bf16 (round to nearest even), products and sums exact - plus the
+InPlaceABN partial sums that leave with the same launch, lazily-activated / two-source inputs, ragged sizes and the k-split form of the
+small layers; then the whole plane sweep -> CostRegNet training node under use_amp against the fp32 node."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from tests.util import record_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+# (Cin, Cout, stride, transposed, dims): the nine layers at small sizes (both M-tile forms: > and < 8192 tiles), ragged edges
+LAYERS = [
+    (8, 16, 2, False, (12, 20, 36)),      # conv1
+    (16, 16, 1, False, (9, 13, 21)),      # conv2
+    (16, 16, 1, False, (40, 60, 64)),     # conv2, enough voxels for one M-tile per wave
+    (16, 32, 2, False, (10, 14, 18)),     # conv3
+    (32, 32, 1, False, (6, 10, 14)),      # conv4
+    (32, 64, 2, False, (8, 12, 12)),      # conv5
+    (64, 64, 1, False, (4, 6, 10)),       # conv6
+    (64, 32, 2, True, (4, 5, 7)),         # conv7
+    (32, 16, 2, True, (6, 7, 9)),         # conv9
+    (16, 8, 2, True, (8, 12, 20)),        # conv11
+    (16, 8, 2, True, (24, 40, 48)),       # conv11, many tiles
+]
+
+
+def _layer(cin, cout, stride, transposed, seed):
+    torch.manual_seed(seed)
+    conv = (nn.ConvTranspose3d(cin, cout, 3, padding=1, output_padding=1, stride=2, bias=False) if transposed
+            else nn.Conv3d(cin, cout, 3, stride=stride, padding=1, bias=False))
+    return conv.to(DEV)
+
+
+@pytest.mark.parametrize("cin,cout,stride,transposed,dims", LAYERS)
+def test_bf16_layer_forward_and_dgrad_vs_float64(cin, cout, stride, transposed, dims):
+    from mvsnerf_amd import encoder as E
+    D, H, W = dims
+    conv = _layer(cin, cout, stride, transposed, cin * 100 + cout)
+    pk = E._PackedConv(conv, transposed)
+    g = torch.Generator(DEV).manual_seed(D * 31 + W)
+    x = torch.randn((D, H, W, cin), device=DEV, generator=g)
+    w64 = _bf(conv.weight.detach()).double()
+    xr = _bf(x).double().permute(3, 0, 1, 2)[None]
+    with torch.no_grad(), E._layer_precision(True):
+        assert pk.get_bf16("fwd") is not None and pk.get_bf16("dgrad") is not None
+        if transposed:
+            out, partials = E._conv_t(x, None, (D, H, W, cin), pk.get, cin, cout, packed=pk, want_stats=True)
+            ref = F.conv_transpose3d(xr, w64, stride=2, padding=1, output_padding=1)[0].permute(1, 2, 3, 0)
+        else:
+            out, partials = E._conv(x, None, (D, H, W, cin), cin, pk.get, cin, cout, stride, packed=pk, want_stats=True)
+            ref = F.conv3d(xr, w64, stride=stride, padding=1)[0].permute(1, 2, 3, 0)
+        assert out.shape == ref.shape
+        scale, err = float(ref.abs().max()), float((out.double() - ref).abs().max())
+        record_err(f"bf16_layer_fwd:{cin}->{cout}s{stride}{'T' if transposed else ''}:{dims}", err, scale=scale)
+        assert torch.isfinite(out).all() and err < 3e-6 * scale, (err, scale)          # fp32 accumulation of exact products
+        # InPlaceABN partial sums of the same launch
+        part, nblk = partials
+        s = part.view(2, cout, nblk).double().sum(2)
+        o64 = out.double()
+        assert float((s[0] - o64.sum((0, 1, 2))).abs().max()) < 1e-6 * float(o64.abs().sum((0, 1, 2)).max())
+        assert float((s[1] - (o64 ** 2).sum((0, 1, 2))).abs().max()) < 1e-6 * float((o64 ** 2).sum((0, 1, 2)).max())
+        # data gradient: the same kernels with re-packed weights (stride-2 conv <-> transposed conv)
+        Do, Ho, Wo = out.shape[:3]
+        go = torch.randn((Do, Ho, Wo, cout), device=DEV, generator=g)
+        gr = _bf(go).double().permute(3, 0, 1, 2)[None]
+        if transposed:
+            gx = E._conv(go, None, (Do, Ho, Wo, cout), cout, lambda: pk.get("dgrad"), cout, cin, 2, packed=pk, mode="dgrad")
+            refg = F.conv3d(gr, w64, stride=2, padding=1)[0].permute(1, 2, 3, 0)
+        elif stride == 1:
+            gx = E._conv(go, None, (Do, Ho, Wo, cout), cout, lambda: pk.get("dgrad"), cout, cin, 1, packed=pk, mode="dgrad")
+            refg = F.conv_transpose3d(gr, w64, stride=1, padding=1)[0].permute(1, 2, 3, 0)
+        else:
+            gx = E._conv_t(go, None, (Do, Ho, Wo, cout), lambda: pk.get("dgrad"), cout, cin, packed=pk, mode="dgrad")
+            refg = F.conv_transpose3d(gr, w64, stride=2, padding=1, output_padding=1)[0].permute(1, 2, 3, 0)[:D, :H, :W]
+            gx = gx[:D, :H, :W]          # an odd input size has one row less than 2 x the output (the layer is only used on even sizes)
+        scale, err = float(refg.abs().max()), float((gx.double() - refg).abs().max())
+        record_err(f"bf16_layer_dgrad:{cin}->{cout}s{stride}{'T' if transposed else ''}:{dims}", err, scale=scale)
+        assert tuple(gx.shape[:3]) == tuple(refg.shape[:3]) and err < 3e-6 * scale, (err, scale)
+    # and the fp32 kernels are what runs outside the context
+    with torch.no_grad():
+        o32 = (E._conv_t(x, None, (D, H, W, cin), pk.get, cin, cout, packed=pk) if transposed
+               else E._conv(x, None, (D, H, W, cin), cin, pk.get, cin, cout, stride, packed=pk))
+    assert not torch.equal(o32, out)
+
+
+def test_bf16_layer_with_lazy_and_two_source_input():
+    """The U-Net hands a layer its input as raw conv output + pending InPlaceABN (scale, shift) and, for the up-sampling layers, as the SUM
+    of two such tensors (skip connection): the activation is applied in fp32 on load, the sum is rounded to bf16 once."""
+    from mvsnerf_amd import encoder as E
+    D, H, W, cin, cout = 8, 12, 20, 16, 8
+    conv = _layer(cin, cout, 2, True, 5)
+    pk = E._PackedConv(conv, True)
+    g = torch.Generator(DEV).manual_seed(3)
+    x1, x2 = torch.randn((D, H, W, cin), device=DEV, generator=g), torch.randn((D, H, W, cin), device=DEV, generator=g)
+    sc1, sh1 = torch.rand(cin, device=DEV, generator=g) + 0.5, torch.randn(cin, device=DEV, generator=g) * 0.3
+    sc2, sh2 = torch.rand(cin, device=DEV, generator=g) + 0.5, torch.randn(cin, device=DEV, generator=g) * 0.3
+    l1, l2 = E._Lazy(x1, sc1, sh1, (D, H, W, cin)), E._Lazy(x2, sc2, sh2, (D, H, W, cin))
+    act = lambda x, sc, sh: F.leaky_relu(torch.addcmul(sh, x, sc), 0.01)
+    with torch.no_grad(), E._layer_precision(True):
+        out = E._conv_t(l1, l2, (D, H, W, cin), pk.get, cin, cout, packed=pk)
+        xin = act(x1, sc1, sh1) + act(x2, sc2, sh2)
+        ref = F.conv_transpose3d(_bf(xin).double().permute(3, 0, 1, 2)[None], _bf(conv.weight.detach()).double(), stride=2, padding=1,
+                                 output_padding=1)[0].permute(1, 2, 3, 0)
+        conv2 = _layer(cin, 16, 1, False, 6)
+        pk2 = E._PackedConv(conv2, False)
+        out2 = E._conv(l1, None, (D, H, W, cin), cin, pk2.get, cin, 16, 1, packed=pk2)
+        ref2 = F.conv3d(_bf(act(x1, sc1, sh1)).double().permute(3, 0, 1, 2)[None], _bf(conv2.weight.detach()).double(), padding=1)[0].permute(1, 2, 3, 0)
+    # the kernel forms x * scale + shift with one fma, torch's addcmul may round twice: a value on a bf16 rounding boundary can land on the
+    # other side (one operand off by 2^-8 relative) - a handful of outputs move by ~1e-3 of the maximum, everything else agrees to 3e-6
+    for o, r, tag in ((out, ref, "convT_two_lazy"), (out2, ref2, "conv_lazy")):
+        d = (o.double() - r).abs()
+        scale = float(r.abs().max())
+        record_err(f"bf16_layer_lazy:{tag}", float(d.max()), scale=scale)
+        assert float(d.max()) < 4e-3 * scale and float((d > 1e-5 * scale).double().mean()) < 0.02
+
+
+def test_use_amp_training_node_runs_every_layer_in_bf16_and_stays_close_to_fp32():
+    """The plane sweep -> CostRegNet autograd node with encoder_precision('bf16'): conv0 AND conv1 ... conv11, forward and data gradients, on
+    bf16 operands (weight gradients of conv1 ... conv11 stay on the fp32 matrix-core kernels); against the fp32 node on the same inputs."""
+    from mvsnerf_amd import encoder as E, models
+    from tests.test_gpu_bf16_encoder import _sweep_inputs
+    from tests.util import load_weights
+    _, mvs_sd = load_weights()
+    V, H, W, D, pad = 3, 32, 40, 32, 4
+    imgs, feats, proj, dv = _sweep_inputs(V, H, W, D, pad, seed=9)
+    res = {}
+    for prec in ("fp32", "bf16"):
+        net = models.MVSNet()
+        net.load_state_dict(mvs_sd)
+        net = net.to(DEV).train()
+        f = feats.clone().requires_grad_(True)
+        with E.encoder_precision(prec):
+            vol = E._SweepRegFunction.apply(f, imgs, proj, dv, pad, net.cost_reg_2, *E._costreg_params(net.cost_reg_2))
+        # the backward runs OUTSIDE the precision context, as in training_step: it must still take the forward's arithmetic
+        gen = torch.Generator(DEV).manual_seed(1)
+        if prec == "bf16":
+            pk = net.cost_reg_2.conv2._packed
+            assert "fwd_bf16" in pk.cache and "dgrad_bf16" not in pk.cache
+        (vol * torch.randn(vol.shape, device=DEV, generator=gen)).sum().backward()
+        if prec == "bf16":
+            for lay in net.cost_reg_2._layers()[1:]:
+                assert "fwd_bf16" in lay._packed.cache and "dgrad_bf16" in lay._packed.cache, "a layer fell back to fp32"
+        else:
+            assert all("fwd_bf16" not in lay._packed.cache for lay in net.cost_reg_2._layers())
+        res[prec] = (vol.detach(), f.grad.detach(), {n: p.grad.detach() for n, p in net.cost_reg_2.named_parameters()})
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-12))
+    e_vol, e_gf = rel(res["bf16"][0], res["fp32"][0]), rel(res["bf16"][1], res["fp32"][1])
+    e_gw = {n: rel(res["bf16"][2][n], res["fp32"][2][n]) for n in res["fp32"][2]}
+    worst = max(e_gw, key=e_gw.get)
+    record_err("bf16_node:volume", e_vol); record_err("bf16_node:d_feats", e_gf); record_err("bf16_node:worst_weight_grad", e_gw[worst])
+    print(f"bf16 training node (all layers) vs fp32: volume {e_vol:.2e}, d feats {e_gf:.2e}, worst weight gradient {e_gw[worst]:.2e} ({worst})")
+    assert 0 < e_vol < 3e-2 and e_gf < 0.3 and e_gw[worst] < 0.6
