@@ -165,7 +165,9 @@ int mvsnerf_conv3d_c8_blocked_wgrad(const float* x_blocked, int Cin, int Cin_rea
 /* All weight re-layouts of a step in one launch (<= 64 jobs, host arrays): job j gathers from the layer's own weight tensor w[j] with
  * params[9 j ..] = {kind, ntaps, ci_real, co_real, ci_pad, co_pad, s_ci, s_co, flip}; kind 0 = conv3d/conv2d_pack_weights' [tap][ci][co],
  * 1 = conv3d_pack_weights_c8's [ci/4][tap][co][4], 2 = conv3d_pack_weights_mfma's [tap][ci/8][co][8] (both straight from w, not from a packed
- * copy).  The weights change with every optimizer step; separately these are ~50 launches of a few microseconds each. */
+ * copy), 3 / 4 = the bf16 fragments of mvsnerf_conv3d_bf16_fwd / mvsnerf_conv_transpose3d_bf16_fwd (dst[j] is then a bf16 buffer of
+ * mvsnerf_conv3d_bf16_packed_elems(ci_pad, co_pad, kind == 4) elements; ntaps = 27).  The weights change with every optimizer step;
+ * separately these are ~70 launches of a few microseconds each. */
 int mvsnerf_pack_weights_multi(int n_jobs, const float* const* w, float* const* dst, const int* params, void* stream);
 int mvsnerf_conv3d_mfma_supported(int Cin, int Cout, int stride);
 int mvsnerf_conv3d_pack_weights_mfma(const float* wpacked, int Cin, int Cout, float* w32, void* stream);

@@ -12,11 +12,17 @@
 // Weights are packed once per weight change into fragment order [k-step][16-column block][lane][8] (16 bytes per lane and MFMA).
 // A wave owns an M-tile of 16 voxels and ALL output channels (1, 2 or 4 column blocks); four waves per workgroup share the statistics slot.
 //
-// Transposed layers: out[o] = sum over taps k with o = 2 i - 1 + k.  The eight parity classes of o = 2 i + p are eight gather-form
-// convolutions over the input lattice with 1 / 2 / 4 / 8 taps (per dimension: p = 0 -> kernel index 1 from input i; p = 1 -> kernel index 0
-// from input i + 1 and kernel index 2 from input i); blockIdx.y = class, an M-tile = 16 consecutive lattice positions, no zero work.
+// Transposed layers: out[o] = sum over taps k with o = 2 i - 1 + k; per dimension an output of parity 0 (o = 2 i) has one tap (kernel index
+// 1, input i), one of parity 1 two (kernel index 0 from input i + 1, kernel index 2 from input i).  An M-tile = 16 consecutive positions i of
+// the INPUT lattice; the columns of the MFMA are the output channels of BOTH x parities (column = px * Cout + channel: the two output voxels
+// 2 ix, 2 ix + 1 of a position are 2 Cout contiguous floats and consecutive positions are contiguous, so the stores are full lines; a
+// column whose parity has no tap at an x offset carries a zero weight: 25 % of the products), k enumerates (z sub-tap, y sub-tap, x offset,
+// channel), and the wave walks the four (z, y) parity classes itself - 1 + 2 + 2 + 4 tap pairs - with the index arithmetic done once.  (First
+// version: one launch class per (pz, py, px), 8 output channels in 16 columns, 4-byte stores at a two-voxel stride: conv11 272 us against
+// 112 us on the fp32 matrix-core kernel.)
 #include "common.h"
 #include "act.h"
+#include "conv3d_bf16_layout.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -151,93 +157,111 @@ __global__ __launch_bounds__(256) void conv3d_k3_bf16_kernel(ActSrc a, ActSrc b,
 }
 
 // ------------------------------------------------------------------------------------------------------------------ transposed conv, stride 2
-template <int CIN, int NT>
+template <int CIN, int NT>          // NT = 2 * Cout / 16 column blocks (both x parities)
 __global__ __launch_bounds__(256) void convT3d_k3s2_bf16_kernel(ActSrc a, ActSrc b, int Di, int Hi, int Wi, const __bf16* __restrict__ wq, int Cout,
                                                                float* __restrict__ out, float* __restrict__ stats)
 {
-    constexpr int KSMAX = (8 * CIN) / 32, LOG = ilog2c(CIN);
+    constexpr int LOG = ilog2c(CIN), KSC = (8 * CIN) / 32;        // k-steps reserved per (pz, py) class in wq (the class with four (z, y) tap pairs)
+    static_assert(CIN >= 16, "two x offsets x Cin must fill whole k-steps");
     __shared__ float act[4][CIN];
     __shared__ float red[4][2][NT * 16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, kg = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, kg = lane >> 4, n = lane & 15, g = lane >> 4;
     stage_act<CIN>(a, b, act, tid);
-    const int cls = blockIdx.y, pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
-    const int ntaps = (1 + pz) * (1 + py) * (1 + px), ks_n = (ntaps * CIN + 31) / 32;
     const int64_t nvox = (int64_t)Di * Hi * Wi;                   // input lattice positions
     const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
     const int64_t vox = tile0 + m;
     const bool live = vox < nvox;
     const int64_t vc = live ? vox : nvox - 1;
     const int x = (int)(vc % Wi), y = (int)((vc / Wi) % Hi), z = (int)(vc / ((int64_t)Wi * Hi));
-    f32x4 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
-    const bf16x8* __restrict__ wl = reinterpret_cast<const bf16x8*>(wq) + (int64_t)cls * KSMAX * NT * 64 + lane;
-#pragma unroll 2
-    for (int ks = 0; ks < ks_n; ++ks) {
-        const int kb = ks * 32 + kg * 8;
-        const int t = kb >> LOG, c0 = kb & (CIN - 1);
-        // sub-tap bits of the dimensions with parity 1, x lowest: bit 0 -> kernel index 0, input i + 1; bit 1 -> kernel index 2, input i
-        int bits = t;
-        const int sx = px ? (bits & 1) : 1; bits >>= px;
-        const int sy = py ? (bits & 1) : 1; bits >>= py;
-        const int sz = pz ? (bits & 1) : 1;
-        const int zi = z + (sz ? 0 : 1), yi = y + (sy ? 0 : 1), xi = x + (sx ? 0 : 1);
-        const bool in = live && t < ntaps && zi < Di && yi < Hi && xi < Wi;
-        const int64_t off = in ? (((int64_t)zi * Hi + yi) * Wi + xi) * CIN + c0 : 0;
-        const bf16x8 av = load_a8<CIN>(a, b, act, off, c0, in);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wl[(ks * NT + nt) * 64], acc[nt], 0, 0, 0);
-    }
     const int Ho = 2 * Hi, Wo = 2 * Wi;
-    store_tile<NT>(acc, Cout, out, stats, (int64_t)blockIdx.y * gridDim.x + blockIdx.x, (int64_t)8 * gridDim.x, red, tid, [&](int r) {
-        const int64_t i = tile0 + r;
-        if (i >= nvox) return (int64_t)-1;
+    // rows of the D fragment this lane stores: positions tile0 + 4 g + r
+    int64_t obase[4];                                             // float offset of output voxel (2 iz, 2 iy, 2 ix), -1: no such position
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = tile0 + 4 * g + r;
         const int ix = (int)(i % Wi), iy = (int)((i / Wi) % Hi), iz = (int)(i / ((int64_t)Wi * Hi));
-        return ((int64_t)(2 * iz + pz) * Ho + (2 * iy + py)) * Wo + (2 * ix + px);
-    });
+        obase[r] = i < nvox ? (((int64_t)(2 * iz) * Ho + 2 * iy) * Wo + 2 * ix) * Cout : (int64_t)-1;
+    }
+    float ssum[NT], ssq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { ssum[nt] = 0.f; ssq[nt] = 0.f; }
+    const bf16x8* __restrict__ wl = reinterpret_cast<const bf16x8*>(wq) + lane;
+#pragma unroll 1
+    for (int cls = 0; cls < 4; ++cls) {
+        const int pz = cls >> 1, py = cls & 1;
+        const int ks_n = ((1 + pz) * (1 + py) * 2 * CIN) / 32;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
+#pragma unroll 2
+        for (int ks = 0; ks < ks_n; ++ks) {
+            const int kb = ks * 32 + kg * 8;
+            const int t = kb >> LOG, c0 = kb & (CIN - 1);
+            // t = ((sz) * (1 + py) + sy) * 2 + sx with the sub-tap bits of the parity-1 dimensions: bit 0 -> kernel index 0, input i + 1; bit 1 ->
+            // kernel index 2, input i (x: both always - the column's parity picks its weight)
+            int bits = t;
+            const int sx = bits & 1; bits >>= 1;
+            const int sy = py ? (bits & 1) : 1; bits >>= py;
+            const int sz = pz ? (bits & 1) : 1;
+            const int zi = z + (sz ? 0 : 1), yi = y + (sy ? 0 : 1), xi = x + (sx ? 0 : 1);
+            const bool in = live && zi < Di && yi < Hi && xi < Wi;
+            const int64_t off = in ? (((int64_t)zi * Hi + yi) * Wi + xi) * CIN + c0 : 0;
+            const bf16x8 av = load_a8<CIN>(a, b, act, off, c0, in);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wl[((cls * KSC + ks) * NT + nt) * 64], acc[nt], 0, 0, 0);
+        }
+        // D: lane (n, g): acc[nt][r] = position tile0 + 4 g + r, column 16 nt + n = px * Cout + channel -> 2 Cout contiguous floats per position
+        const int64_t coff = ((int64_t)pz * Ho + py) * Wo * Cout;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (obase[r] >= 0) { const float v = acc[nt][r]; out[obase[r] + coff + nt * 16 + n] = v; ssum[nt] += v; ssq[nt] = fmaf(v, v, ssq[nt]); }
+    }
+    if (stats) {
+        // channel of column 16 nt + n: (16 nt + n) % Cout; the two x parities of a channel: NT = 1 (Cout 8) lanes n, n ^ 8; NT = 2 blocks 0, 1; NT = 4 blocks (0, 2), (1, 3)
+        constexpr int NCH = NT == 1 ? 1 : NT / 2;                 // column blocks per parity
+        float cs[NCH], cq[NCH];
+        if constexpr (NT == 1) { cs[0] = ssum[0] + __shfl_xor(ssum[0], 8); cq[0] = ssq[0] + __shfl_xor(ssq[0], 8); }
+        else {
+#pragma unroll
+            for (int h = 0; h < NCH; ++h) { cs[h] = ssum[h] + ssum[h + NCH]; cq[h] = ssq[h] + ssq[h + NCH]; }
+        }
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) {
+            cs[h] += __shfl_xor(cs[h], 16); cq[h] += __shfl_xor(cq[h], 16);
+            cs[h] += __shfl_xor(cs[h], 32); cq[h] += __shfl_xor(cq[h], 32);
+            if (g == 0 && (NT > 1 || n < 8)) { red[wave][0][h * 16 + n] = cs[h]; red[wave][1][h * 16 + n] = cq[h]; }
+        }
+        __syncthreads();
+        if (tid < 2 * Cout) {
+            const int which = tid / Cout, c = tid - which * Cout;
+            stats[abn_part_at(which, c, Cout, blockIdx.x, gridDim.x)] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------ weight fragments
 // wp[27][Cin][Cout] fp32 (mvsnerf_conv3d_pack_weights: the generic layout of the layer or of its data gradient) -> bf16 B fragments.
-// conv:        wq[ks][nt][lane][8],  k = 32 ks + 8 (lane >> 4) + j = tap * Cin + ci, column 16 nt + (lane & 15)
-// transposed:  wq[class][ks][nt][lane][8] (KSMAX k-steps reserved per class), k = t * Cin + ci with t the class's sub-tap number (kernel above)
-__global__ __launch_bounds__(256) void conv3d_bf16_pack_kernel(const float* __restrict__ wp, int Cin, int Cout, int NT, int transposed, __bf16* __restrict__ wq)
+// conv:        wq[ks][nt][lane][8],  k = 32 ks + 8 (lane >> 4) + j = tap * Cin + ci, column 16 nt + (lane & 15) = output channel
+// transposed:  wq[class pz, py][ks][nt][lane][8] (Cin / 4 k-steps reserved per class), k = t * Cin + ci with t the class's sub-tap number,
+//              column = px * Cout + output channel (kernel above)
+__global__ __launch_bounds__(256) void conv3d_bf16_pack_kernel(const float* __restrict__ wp, int Cin, int Cout, int transposed, int64_t total, __bf16* __restrict__ wq)
 {
-    const int log = 31 - __clz(Cin);
-    const int ksn = transposed ? (8 * Cin) / 32 : (27 * Cin + 31) / 32;
-    const int64_t per = (int64_t)ksn * NT * 64 * 8, total = per * (transposed ? 8 : 1);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int cls = (int)(i / per);
-    const int64_t r = i - cls * per;
-    const int j = (int)(r & 7), lane = (int)((r >> 3) & 63), nt = (int)((r >> 9) % NT), ks = (int)((r >> 9) / NT);
-    const int kb = ks * 32 + (lane >> 4) * 8 + j, t = kb >> log, ci = kb & (Cin - 1), co = nt * 16 + (lane & 15);
-    int tap = -1;
-    if (!transposed) tap = t < 27 ? t : -1;
-    else {
-        const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1, ntaps = (1 + pz) * (1 + py) * (1 + px);
-        if (t < ntaps) {
-            int bits = t;
-            const int sx = px ? (bits & 1) : 1; bits >>= px;
-            const int sy = py ? (bits & 1) : 1; bits >>= py;
-            const int sz = pz ? (bits & 1) : 1;
-            const int kx = px ? (sx ? 2 : 0) : 1, ky = py ? (sy ? 2 : 0) : 1, kz = pz ? (sz ? 2 : 0) : 1;
-            tap = kz * 9 + ky * 3 + kx;
-        }
-    }
-    wq[i] = (__bf16)((tap >= 0 && co < Cout) ? wp[((int64_t)tap * Cin + ci) * Cout + co] : 0.0f);
+    int tap, ci, co;
+    wq[i] = (__bf16)(mvs_conv3d_bf16_coords(i, Cin, Cout, transposed, tap, ci, co) ? wp[((int64_t)tap * Cin + ci) * Cout + co] : 0.0f);
 }
 
-bool shape_ok(int Cin, int Cout) { return (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 8 || Cout == 16 || Cout == 32 || Cout == 64); }
+bool shape_ok(int Cin, int Cout) { return mvs_conv3d_bf16_shape_ok(Cin, Cout); }
 int n_col_blocks(int Cout) { return (Cout + 15) / 16; }
 
 }  // namespace
 
 extern "C" size_t mvsnerf_conv3d_bf16_packed_elems(int Cin, int Cout, int transposed)
 {
-    if (!shape_ok(Cin, Cout)) return 0;
-    const size_t ksn = transposed ? (size_t)(8 * Cin) / 32 : (size_t)(27 * Cin + 31) / 32;
-    return ksn * n_col_blocks(Cout) * 512 * (transposed ? 8 : 1);
+    return mvs_conv3d_bf16_elems(Cin, Cout, transposed);
 }
 
 extern "C" int mvsnerf_conv3d_bf16_pack(const float* wpacked, int Cin, int Cout, int transposed, void* wq, void* stream)
@@ -245,9 +269,9 @@ extern "C" int mvsnerf_conv3d_bf16_pack(const float* wpacked, int Cin, int Cout,
     if (!wpacked || !wq) return MVSNERF_EINVAL;
     if (!shape_ok(Cin, Cout)) return MVSNERF_EUNSUPPORTED;
     if (!mvs_aligned16(wq)) return MVSNERF_EALIGN;
-    const size_t total = mvsnerf_conv3d_bf16_packed_elems(Cin, Cout, transposed);
-    conv3d_bf16_pack_kernel<<<mvs_cdiv((int64_t)total, 256), 256, 0, (hipStream_t)stream>>>(wpacked, Cin, Cout, n_col_blocks(Cout), transposed ? 1 : 0,
-                                                                                        reinterpret_cast<__bf16*>(wq));
+    const size_t total = mvs_conv3d_bf16_elems(Cin, Cout, transposed);
+    if (total == 0) return MVSNERF_EUNSUPPORTED;
+    conv3d_bf16_pack_kernel<<<mvs_cdiv((int64_t)total, 256), 256, 0, (hipStream_t)stream>>>(wpacked, Cin, Cout, transposed ? 1 : 0, (int64_t)total, reinterpret_cast<__bf16*>(wq));
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
@@ -263,7 +287,7 @@ extern "C" int mvsnerf_conv3d_bf16_tiles(int D, int H, int W, int stride)
     return (int)(ksplit_of(nvox) ? (nvox + 15) / 16 : (nvox + 63) / 64);
 }
 
-extern "C" int mvsnerf_conv_transpose3d_bf16_tiles(int D, int H, int W) { return (int)(8 * (((int64_t)D * H * W + 63) / 64)); }
+extern "C" int mvsnerf_conv_transpose3d_bf16_tiles(int D, int H, int W) { return (int)(((int64_t)D * H * W + 63) / 64); }
 
 static bool act_ok16(const float* x, const float* sc, const float* sh) { return x && ((sc == nullptr) == (sh == nullptr)) && mvs_aligned16(x); }
 
@@ -309,16 +333,14 @@ extern "C" int mvsnerf_conv_transpose3d_bf16_fwd(const float* x1, const float* s
     if (!shape_ok(Cin, Cout) || Cin < 16) return MVSNERF_EUNSUPPORTED;
     if (!mvs_aligned16(wq)) return MVSNERF_EALIGN;
     const ActSrc a{x1, scale1, shift1}, b{x2, scale2, shift2};
-    const dim3 grid((unsigned)(((int64_t)D * H * W + 63) / 64), 8);
+    const unsigned grid = (unsigned)(((int64_t)D * H * W + 63) / 64);
     hipStream_t st = (hipStream_t)stream;
     const __bf16* w = reinterpret_cast<const __bf16*>(wq);
 #define MVS_T16(CIN, NT) convT3d_k3s2_bf16_kernel<CIN, NT><<<grid, 256, 0, st>>>(a, b, D, H, W, w, Cout, out, stats_part)
-    switch (Cin * 100 + n_col_blocks(Cout)) {
-        case 16 * 100 + 1: MVS_T16(16, 1); break;
-        case 32 * 100 + 1: MVS_T16(32, 1); break;
-        case 32 * 100 + 2: MVS_T16(32, 2); break;
-        case 64 * 100 + 2: MVS_T16(64, 2); break;
-        case 64 * 100 + 4: MVS_T16(64, 4); break;
+    switch (Cin * 100 + Cout) {
+        case 16 * 100 + 8: MVS_T16(16, 1); break;           // conv11, data gradient of conv1
+        case 32 * 100 + 16: MVS_T16(32, 2); break;          // conv9, data gradient of conv3
+        case 64 * 100 + 32: MVS_T16(64, 4); break;          // conv7, data gradient of conv5
         default: return MVSNERF_EUNSUPPORTED;
     }
 #undef MVS_T16

@@ -10,6 +10,7 @@
 // into per-channel (scale, shift); every consumer applies leaky_relu(x*scale+shift) while loading.
 // Skip additions (models.py:762-766) are the sum of two such lazily-activated tensors.
 #include "common.h"
+#include "conv3d_bf16_layout.h"
 #include "act.h"
 #include "knobs.h"
 
@@ -519,8 +520,10 @@ extern "C" int mvsnerf_conv3d_pack_weights(const float* w, int ci_real, int co_r
 // launch.  A job gathers straight from the nn.Conv / nn.ConvTranspose weight tensor:
 //   value(tap, ci, co) = (ci < ci_real && co < co_real) ? w[ci * s_ci + co * s_co + (flip ? ntaps - 1 - tap : tap)] : 0
 // into layout kind 0: dst[tap][ci][co] (conv3d_pack_weights / conv2d_pack_weights), 1: dst[ci/4][tap][co][ci%4] (conv3d_pack_weights_c8),
-// 2: dst[tap][ci/8][co][ci%8] (conv3d_pack_weights_mfma).
+// 2: dst[tap][ci/8][co][ci%8] (conv3d_pack_weights_mfma), 3 / 4: the bf16 B fragments of conv3d_bf16.hip for a convolution / a transposed
+// convolution (dst is a __bf16 buffer of mvsnerf_conv3d_bf16_packed_elems(ci_pad, co_pad, kind == 4) elements; 27 taps).
 constexpr int MVS_PACK_JOBS = 64;
+
 struct PackJobs {
     const float* w[MVS_PACK_JOBS];
     float* dst[MVS_PACK_JOBS];
@@ -528,6 +531,7 @@ struct PackJobs {
     short ntaps[MVS_PACK_JOBS];
     signed char flip[MVS_PACK_JOBS], kind[MVS_PACK_JOBS];
     int blk[MVS_PACK_JOBS + 1];
+    int n_elems[MVS_PACK_JOBS];
     int n;
 };
 
@@ -537,6 +541,17 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(PackJobs J)
     while (j + 1 < J.n && (int)blockIdx.x >= J.blk[j + 1]) ++j;
     const int i = (blockIdx.x - J.blk[j]) * 256 + threadIdx.x;
     const int ntaps = J.ntaps[j], cip = J.ci_pad[j], cop = J.co_pad[j];
+    if (J.kind[j] >= 3) {                                         // bf16 fragments (conv3d_bf16.hip)
+        if (i >= J.n_elems[j]) return;
+        int tap, ci, co;
+        float v = 0.f;
+        if (mvs_conv3d_bf16_coords(i, cip, cop, J.kind[j] == 4, tap, ci, co) && ci < J.ci_real[j] && co < J.co_real[j]) {
+            if (J.flip[j]) tap = ntaps - 1 - tap;
+            v = J.w[j][(int64_t)ci * J.s_ci[j] + (int64_t)co * J.s_co[j] + tap];
+        }
+        reinterpret_cast<__bf16*>(J.dst[j])[i] = (__bf16)v;
+        return;
+    }
     if (i >= ntaps * cip * cop) return;
     int tap, ci, co;
     if (J.kind[j] == 0) { co = i % cop; ci = (i / cop) % cip; tap = i / (cop * cip); }
@@ -555,13 +570,19 @@ extern "C" int mvsnerf_pack_weights_multi(int n_jobs, const float* const* w, flo
     int b = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const int* q = params + 9 * j;
-        if (!w[j] || !dst[j] || q[0] < 0 || q[0] > 2 || q[1] < 1 || q[1] > 27 || q[2] < 1 || q[3] < 1 || q[4] < q[2] || q[5] < q[3]) return MVSNERF_EINVAL;
+        if (!w[j] || !dst[j] || q[0] < 0 || q[0] > 4 || q[1] < 1 || q[1] > 27 || q[2] < 1 || q[3] < 1 || q[4] < q[2] || q[5] < q[3]) return MVSNERF_EINVAL;
+        size_t n_el = (size_t)q[1] * q[4] * q[5];
+        if (q[0] >= 3) {
+            n_el = q[1] == 27 ? mvs_conv3d_bf16_elems(q[4], q[5], q[0] == 4) : 0;
+            if (n_el == 0) return MVSNERF_EUNSUPPORTED;
+        }
         if ((q[0] == 1 && (q[4] & 3)) || (q[0] == 2 && (q[4] & 7))) return MVSNERF_EINVAL;
         J.w[j] = w[j]; J.dst[j] = dst[j];
         J.kind[j] = (signed char)q[0]; J.ntaps[j] = (short)q[1]; J.ci_real[j] = q[2]; J.co_real[j] = q[3]; J.ci_pad[j] = q[4]; J.co_pad[j] = q[5];
         J.s_ci[j] = q[6]; J.s_co[j] = q[7]; J.flip[j] = (signed char)(q[8] ? 1 : 0);
         J.blk[j] = b;
-        b += (q[1] * q[4] * q[5] + 255) / 256;
+        J.n_elems[j] = (int)n_el;
+        b += (int)((n_el + 255) / 256);
     }
     J.blk[n_jobs] = b;
     pack_weights_multi_kernel<<<b, 256, 0, (hipStream_t)stream>>>(J);

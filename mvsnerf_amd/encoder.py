@@ -483,15 +483,18 @@ class _PackedConv:
         kernel_t = (self.transposed != (mode == "dgrad")) if strided else False
         lib = _lib.lib()
         n = lib.mvsnerf_conv3d_bf16_packed_elems(ci_pad, co_pad, int(kernel_t))
-        if n == 0 or ci_real != ci_pad or (kernel_t and ci_pad < 16):
+        if n == 0 or ci_real != ci_pad:
             return None
         key = (w.data_ptr(), w._version, _lib.weights_epoch())
         name = mode + "_bf16"
         hit = self.cache.get(name)
         if hit is not None and hit[0] == key:
             return hit[1]
+        _, _, _, _, s_ci, s_co, flip = self._params(mode)
         buf = torch.empty(n, device=w.device, dtype=torch.bfloat16)
-        check(lib.mvsnerf_conv3d_bf16_pack(self.get(mode).data_ptr(), ci_pad, co_pad, int(kernel_t), buf.data_ptr(), stream_ptr()), "conv3d_bf16_pack")
+        # straight from the nn weights (kinds 3 / 4 of mvsnerf_pack_weights_multi): batched with the step's other re-layouts by MVSNet.prepack
+        _pack(dev_f32(w.detach().contiguous(), "conv weight"), buf, 4 if kernel_t else 3, 27, ci_real, co_real, ci_pad, co_pad, s_ci, s_co, flip)
+        _log_pack(self, "get_bf16", mode)
         self.cache[name] = (key, buf)
         return buf
 
