@@ -590,6 +590,7 @@ def _ptrs(src):
     return src.data_ptr(), 0, 0
 
 
+BF16_LAYERS = True         # A/B switch (scratch/r4): False keeps conv1 ... conv11 on the fp32 kernels under use_amp (round 3's behaviour)
 _LAYER_BF16 = [False]      # conv1 ... conv11 on the bf16 matrix cores (csrc/conv3d_bf16.hip): set for the extent of a forward / backward by _layer_precision
 
 
@@ -859,7 +860,7 @@ class CostRegNet(nn.Module):
         else:
             buf, ld = _as_channel_last(x, self.conv0._packed_cin_pad())
             c0 = self.conv0.lazy(buf, (D, H, W, ld), ld)
-        with _layer_precision(ENCODER_PRECISION == "bf16"):     # use_amp: conv1 ... conv11 on the bf16 matrix cores as well (csrc/conv3d_bf16.hip)
+        with _layer_precision(ENCODER_PRECISION == "bf16" and BF16_LAYERS):     # use_amp: conv1 ... conv11 on the bf16 matrix cores as well (csrc/conv3d_bf16.hip)
             c1 = self.conv1.lazy(c0, c0.dims, 8)
             c2 = self.conv2.lazy(c1, c1.dims, 16)
             c3 = self.conv3.lazy(c2, c2.dims, 16)
@@ -984,7 +985,7 @@ class _CostRegFunction(torch.autograd.Function):
     def forward(ctx, x, net, *params):
         (buf, ld), lz = net._run(x)
         ctx.net, ctx.buf, ctx.ld, ctx.lz, ctx.xshape = net, buf, ld, lz, tuple(x.shape)
-        ctx.layers_bf16 = ENCODER_PRECISION == "bf16"
+        ctx.layers_bf16 = ENCODER_PRECISION == "bf16" and BF16_LAYERS
         return _neural_volume(lz[0], lz[9])
 
     @staticmethod
@@ -1172,7 +1173,7 @@ class _SweepRegFunction(torch.autograd.Function):
         cost, _, saved = _plane_sweep(imgs, feats, proj_mats, depth_values, pad, True, blocked="bf16" if ENCODER_PRECISION == "bf16" else True)
         _, lz = net._run(cost)
         ctx.net, ctx.cost, ctx.lz, ctx.saved = net, cost, lz, saved
-        ctx.layers_bf16 = ENCODER_PRECISION == "bf16"
+        ctx.layers_bf16 = ENCODER_PRECISION == "bf16" and BF16_LAYERS
         return _neural_volume(lz[0], lz[9])
 
     @staticmethod

@@ -3,7 +3,9 @@ MVS_LIB=<path of another build of the library> selects it (same-box A/B of a ker
 import sys, time, torch, os
 import os; ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); os.chdir(ROOT)
 import numpy as np
-from mvsnerf_amd import train, _lib
+from mvsnerf_amd import train, _lib, encoder
+if os.environ.get('MVS_BF16_LAYERS') == '0':
+    encoder.BF16_LAYERS = False
 if os.environ.get('MVS_LIB'):
     _lib.LIB_PATH = os.environ['MVS_LIB']; _lib._lib = None
 amp = len(sys.argv) > 1 and sys.argv[1] == "amp"
@@ -20,4 +22,8 @@ torch.manual_seed(0)
 system.fit_steps([batch] * 2, opt)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 system.fit_steps([batch] * steps, opt)
-torch.cuda.synchronize(); print("train step ms (%s)" % ("use_amp" if amp else "fp32"), (time.perf_counter() - t0) / steps * 1e3)
+torch.cuda.synchronize(); print("train step ms (%s, bf16 layers %s)" % ("use_amp" if amp else "fp32", encoder.BF16_LAYERS), (time.perf_counter() - t0) / steps * 1e3)
+for rep in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    system.fit_steps([batch] * steps, opt)
+    torch.cuda.synchronize(); print("   again:", (time.perf_counter() - t0) / steps * 1e3)
