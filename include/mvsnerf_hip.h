@@ -239,6 +239,15 @@ int mvsnerf_conv_transpose3d_bf16_fwd(const float* x1, const float* scale1, cons
                                       const float* x2, const float* scale2, const float* shift2,
                                       int Cin, int D, int H, int W, const void* wq, int Cout, float* out, float* stats_part, void* stream);
 
+/* FeatureNet's 2-D layers (models.py:688-722) on the same bf16 kernels under use_amp: [N][H][W][C] images, ksize 1 | 3 | 5, stride 1 | 2,
+ * padding ksize / 2, one lazily-activated source, optional bias (the 1x1 toplayer); weights = mvsnerf_pack_weights_multi kind 3 with
+ * ntaps = ksize^2.  Built for the eight ConvBnReLU layers, the toplayer and their stride-1 data gradients (the two 5x5 stride-2 data
+ * gradients stay on mvsnerf_conv2d_dgrad_k5s2). */
+size_t mvsnerf_conv2d_bf16_packed_elems(int Cin, int Cout, int ksize);
+int mvsnerf_conv2d_bf16_tiles(int N, int H, int W, int ksize, int stride);
+int mvsnerf_conv2d_bf16_fwd(const float* x, const float* scale, const float* shift, int Cin, int cin_ld, int N, int H, int W,
+                            const void* wq, const float* bias, int Cout, int ksize, int stride, float* out, float* stats_part, void* stream);
+
 /* ---- encoder backward (generalizable training, train_mvs_nerf_pl.py:104-168) ----
  * Data gradients of the convolutions reuse the forward kernels with re-packed weights (mvsnerf_conv3d_pack_weights:
  * `flip` mirrors the taps; a stride-2 conv's data gradient is the transposed conv and vice versa).

@@ -102,12 +102,15 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[NT], int Cout, flo
 // KSPLIT = 1: the four waves of a workgroup own four M-tiles.  KSPLIT = 4 (layers with few voxels: conv4 ... conv6 have 73 k / 9 k outputs,
 // i.e. less than one M-tile per SIMD, and a wave's k-loop would be one long chain of exposed load latencies): the four waves share ONE
 // M-tile, take every fourth k-step and meet in LDS; wave 0 adds the partial accumulators in a fixed order and stores.
-template <int CIN, int NT, int S, int KSPLIT>
-__global__ __launch_bounds__(256) void conv3d_k3_bf16_kernel(ActSrc a, ActSrc b, int ld, int Di, int Hi, int Wi, const __bf16* __restrict__ wq, int Cout,
-                                                            float* __restrict__ out, int Do, int Ho, int Wo, float* __restrict__ stats)
+// KZ x K x K taps, padding K / 2 (KZ / 2 along z): 3, 3 for the 3-D layers; 1, K for FeatureNet's 2-D layers (models.py:688-722) with the images as
+// z (not strided).  Cin = 4 (the image layer, 3 real channels): a lane's eight k-values are two taps x four channels.  bias: the 1x1 toplayer.
+template <int CIN, int NT, int S, int KSPLIT, int KZ, int K>
+__global__ __launch_bounds__(256) void conv_bf16_kernel(ActSrc a, ActSrc b, int ld, int Di, int Hi, int Wi, const __bf16* __restrict__ wq, int Cout,
+                                                       float* __restrict__ out, int Do, int Ho, int Wo, float* __restrict__ stats, const float* __restrict__ bias)
 {
-    constexpr int KS = (27 * CIN + 31) / 32, LOG = ilog2c(CIN);
-    static_assert((1 << LOG) == CIN && CIN >= 8, "Cin: a power of two >= 8 (groups of eight channels never straddle taps)");
+    constexpr int NTAP = KZ * K * K, PZ = KZ / 2, P = K / 2, SZ = KZ == 1 ? 1 : S;
+    constexpr int KS = (NTAP * CIN + 31) / 32, LOG = ilog2c(CIN);
+    static_assert((1 << LOG) == CIN && CIN >= 4, "Cin: a power of two >= 4 (groups of eight channels never straddle taps; Cin 4: two taps per group)");
     static_assert(KSPLIT == 1 || KSPLIT == 4, "one M-tile per wave, or one per workgroup");
     __shared__ float act[4][CIN];
     __shared__ float red[4][2][NT * 16];
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_bf16_kernel(ActSrc a, ActSrc b,
     const bool live = vox < nvox;
     const int64_t vc = live ? vox : nvox - 1;
     const int x = (int)(vc % Wo), y = (int)((vc / Wo) % Ho), z = (int)(vc / ((int64_t)Wo * Ho));
-    const int zb = z * S - 1, yb = y * S - 1, xb = x * S - 1;
+    const int zb = z * SZ - PZ, yb = y * S - P, xb = x * S - P;
     f32x4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
@@ -128,12 +131,32 @@ __global__ __launch_bounds__(256) void conv3d_k3_bf16_kernel(ActSrc a, ActSrc b,
 #pragma unroll 2
     for (int ks = (KSPLIT == 1 ? 0 : wave); ks < KS; ks += KSPLIT) {
         const int kb = ks * 32 + kg * 8;
-        const int tap = kb >> LOG, c0 = kb & (CIN - 1);
-        const int dz = tap / 9, r9 = tap - dz * 9, dy = r9 / 3, dx = r9 - dy * 3;
-        const int zi = zb + dz, yi = yb + dy, xi = xb + dx;
-        const bool in = live && tap < 27 && zi >= 0 && zi < Di && yi >= 0 && yi < Hi && xi >= 0 && xi < Wi;
-        const int64_t off = in ? (((int64_t)zi * Hi + yi) * Wi + xi) * ld + c0 : 0;
-        const bf16x8 av = load_a8<CIN>(a, b, act, off, c0, in);
+        bf16x8 av;
+        if constexpr (CIN == 4) {                                 // taps kb / 4 and kb / 4 + 1, four channels each
+            f32x4 v[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int tap = (kb >> 2) + hh;
+                const int dz = tap / (K * K), rr = tap - dz * (K * K), dy = rr / K, dx = rr - dy * K;
+                const int zi = zb + dz, yi = yb + dy, xi = xb + dx;
+                const bool in = live && tap < NTAP && zi >= 0 && zi < Di && yi >= 0 && yi < Hi && xi >= 0 && xi < Wi;
+                v[hh] = *reinterpret_cast<const f32x4*>(a.x + (in ? (((int64_t)zi * Hi + yi) * Wi + xi) * ld : 0));
+                if (a.scale) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[hh][j] = act_apply(v[hh][j], act[0][j], act[1][j]);
+                }
+                if (!in) v[hh] = f32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { av[j] = (__bf16)v[0][j]; av[4 + j] = (__bf16)v[1][j]; }
+        } else {
+            const int tap = kb >> LOG, c0 = kb & (CIN - 1);
+            const int dz = tap / (K * K), rr = tap - dz * (K * K), dy = rr / K, dx = rr - dy * K;
+            const int zi = zb + dz, yi = yb + dy, xi = xb + dx;
+            const bool in = live && tap < NTAP && zi >= 0 && zi < Di && yi >= 0 && yi < Hi && xi >= 0 && xi < Wi;
+            const int64_t off = in ? (((int64_t)zi * Hi + yi) * Wi + xi) * ld + c0 : 0;
+            av = load_a8<CIN>(a, b, act, off, c0, in);
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wl[(ks * NT + nt) * 64], acc[nt], 0, 0, 0);
     }
@@ -148,6 +171,14 @@ __global__ __launch_bounds__(256) void conv3d_k3_bf16_kernel(ActSrc a, ActSrc b,
             for (int w = 0; w < 3; ++w)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[nt] += *reinterpret_cast<const f32x4*>(part + ((w * NT + nt) * 64 + lane) * 4);
+        }
+    }
+    if (bias) {                                                   // D: lane (n = lane & 15, .): column 16 nt + n
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float bv = (nt * 16 + (lane & 15)) < Cout ? bias[nt * 16 + (lane & 15)] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[nt][r] += bv;
         }
     }
     store_tile<NT>(acc, Cout, out, stats, blockIdx.x, gridDim.x, red, tid, [&](int r) {
@@ -306,8 +337,8 @@ extern "C" int mvsnerf_conv3d_bf16_fwd(const float* x1, const float* scale1, con
     hipStream_t st = (hipStream_t)stream;
     const __bf16* w = reinterpret_cast<const __bf16*>(wq);
     const bool split = ksplit_of((int64_t)Do * Ho * Wo);
-#define MVS_C16(CIN, NT, S) do { if (split) conv3d_k3_bf16_kernel<CIN, NT, S, 4><<<grid, 256, 0, st>>>(a, b, cin_ld, D, H, W, w, Cout, out, Do, Ho, Wo, stats_part); \
-                                 else conv3d_k3_bf16_kernel<CIN, NT, S, 1><<<grid, 256, 0, st>>>(a, b, cin_ld, D, H, W, w, Cout, out, Do, Ho, Wo, stats_part); } while (0)
+#define MVS_C16(CIN, NT, S) do { if (split) conv_bf16_kernel<CIN, NT, S, 4, 3, 3><<<grid, 256, 0, st>>>(a, b, cin_ld, D, H, W, w, Cout, out, Do, Ho, Wo, stats_part, nullptr); \
+                                 else conv_bf16_kernel<CIN, NT, S, 1, 3, 3><<<grid, 256, 0, st>>>(a, b, cin_ld, D, H, W, w, Cout, out, Do, Ho, Wo, stats_part, nullptr); } while (0)
     switch ((Cin * 100 + n_col_blocks(Cout)) * 10 + stride) {
         case (8 * 100 + 1) * 10 + 1: MVS_C16(8, 1, 1); break;    case (8 * 100 + 1) * 10 + 2: MVS_C16(8, 1, 2); break;
         case (16 * 100 + 1) * 10 + 1: MVS_C16(16, 1, 1); break;  case (16 * 100 + 1) * 10 + 2: MVS_C16(16, 1, 2); break;
@@ -344,6 +375,58 @@ extern "C" int mvsnerf_conv_transpose3d_bf16_fwd(const float* x1, const float* s
         default: return MVSNERF_EUNSUPPORTED;
     }
 #undef MVS_T16
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ FeatureNet (2-D)
+// The same kernel with 1 x k x k taps over [N][H][W][C] images (z = image, never strided): models.py:688-722 under use_amp.  ksize 1 | 3 | 5,
+// stride 1 | 2 (padding ksize / 2), one lazily-activated source, optional bias (the 1x1 toplayer).  Weights: mvsnerf_pack_weights_multi kind 3
+// with ntaps = ksize^2 from the Conv2d weight (or its data-gradient view).  Shapes: the eight layers + toplayer and their stride-1 data gradients.
+extern "C" size_t mvsnerf_conv2d_bf16_packed_elems(int Cin, int Cout, int ksize)
+{
+    if (ksize != 1 && ksize != 3 && ksize != 5) return 0;
+    return mvs_conv3d_bf16_elems(Cin, Cout, 0, ksize * ksize);
+}
+
+static int64_t conv2d_out_pixels(int N, int H, int W, int ksize, int stride)
+{
+    const int P = ksize / 2;
+    return (int64_t)N * ((H + 2 * P - ksize) / stride + 1) * ((W + 2 * P - ksize) / stride + 1);
+}
+
+extern "C" int mvsnerf_conv2d_bf16_tiles(int N, int H, int W, int ksize, int stride)
+{
+    if ((stride != 1 && stride != 2) || (ksize != 1 && ksize != 3 && ksize != 5)) return 0;
+    const int64_t npix = conv2d_out_pixels(N, H, W, ksize, stride);
+    return (int)(ksplit_of(npix) ? (npix + 15) / 16 : (npix + 63) / 64);
+}
+
+extern "C" int mvsnerf_conv2d_bf16_fwd(const float* x, const float* scale, const float* shift, int Cin, int cin_ld, int N, int H, int W,
+                                       const void* wq, const float* bias, int Cout, int ksize, int stride, float* out, float* stats_part, void* stream)
+{
+    if (!act_ok16(x, scale, shift) || !wq || !out || N < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
+    if ((stride != 1 && stride != 2) || mvsnerf_conv2d_bf16_packed_elems(Cin, Cout, ksize) == 0) return MVSNERF_EUNSUPPORTED;
+    if ((cin_ld & 3) || cin_ld < Cin || !mvs_aligned16(wq)) return MVSNERF_EALIGN;
+    const ActSrc a{x, scale, shift}, b{nullptr, nullptr, nullptr};
+    const int P = ksize / 2, Ho = (H + 2 * P - ksize) / stride + 1, Wo = (W + 2 * P - ksize) / stride + 1;
+    const unsigned grid = (unsigned)mvsnerf_conv2d_bf16_tiles(N, H, W, ksize, stride);
+    const bool split = ksplit_of((int64_t)N * Ho * Wo);
+    hipStream_t st = (hipStream_t)stream;
+    const __bf16* w = reinterpret_cast<const __bf16*>(wq);
+#define MVS_C2(CIN, NT, S, K) do { if (split) conv_bf16_kernel<CIN, NT, S, 4, 1, K><<<grid, 256, 0, st>>>(a, b, cin_ld, N, H, W, w, Cout, out, N, Ho, Wo, stats_part, bias); \
+                                   else conv_bf16_kernel<CIN, NT, S, 1, 1, K><<<grid, 256, 0, st>>>(a, b, cin_ld, N, H, W, w, Cout, out, N, Ho, Wo, stats_part, bias); } while (0)
+    switch (((Cin * 100 + n_col_blocks(Cout)) * 10 + ksize) * 10 + stride) {
+        case ((4 * 100 + 1) * 10 + 3) * 10 + 1: MVS_C2(4, 1, 1, 3); break;        // conv0.0 (3 -> 8)
+        case ((8 * 100 + 1) * 10 + 3) * 10 + 1: MVS_C2(8, 1, 1, 3); break;        // conv0.1, and data gradients 8 -> 8 / 8 -> 4
+        case ((8 * 100 + 1) * 10 + 5) * 10 + 2: MVS_C2(8, 1, 2, 5); break;        // conv1.0 (8 -> 16)
+        case ((16 * 100 + 1) * 10 + 3) * 10 + 1: MVS_C2(16, 1, 1, 3); break;      // conv1.1, conv1.2 (+ data gradients)
+        case ((16 * 100 + 2) * 10 + 5) * 10 + 2: MVS_C2(16, 2, 2, 5); break;      // conv2.0 (16 -> 32)
+        case ((32 * 100 + 2) * 10 + 3) * 10 + 1: MVS_C2(32, 2, 1, 3); break;      // conv2.1, conv2.2 (+ data gradients)
+        case ((32 * 100 + 2) * 10 + 1) * 10 + 1: MVS_C2(32, 2, 1, 1); break;      // toplayer (+ data gradient)
+        default: return MVSNERF_EUNSUPPORTED;
+    }
+#undef MVS_C2
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }

@@ -2,25 +2,26 @@
 #pragma once
 #include "common.h"
 
-inline bool mvs_conv3d_bf16_shape_ok(int Cin, int Cout) { return (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 8 || Cout == 16 || Cout == 32 || Cout == 64); }
+inline bool mvs_conv3d_bf16_shape_ok(int Cin, int Cout) { return (Cin == 4 || Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 8 || Cout == 16 || Cout == 32 || Cout == 64); }
 
-inline size_t mvs_conv3d_bf16_elems(int Cin, int Cout, int transposed)
+// ntaps: 27 for the 3-D layers; k * k (1, 9, 25) for FeatureNet's 2-D layers (never transposed)
+inline size_t mvs_conv3d_bf16_elems(int Cin, int Cout, int transposed, int ntaps = 27)
 {
-    if (!mvs_conv3d_bf16_shape_ok(Cin, Cout)) return 0;
+    if (!mvs_conv3d_bf16_shape_ok(Cin, Cout) || ntaps < 1 || ntaps > 27) return 0;
     if (transposed) {                                             // four (pz, py) classes, both x parities in the columns; the instantiated shapes
-        if (!((Cin == 16 && Cout == 8) || (Cin == 32 && Cout == 16) || (Cin == 64 && Cout == 32))) return 0;
+        if (ntaps != 27 || !((Cin == 16 && Cout == 8) || (Cin == 32 && Cout == 16) || (Cin == 64 && Cout == 32))) return 0;
         return (size_t)(8 * Cin) / 32 * ((2 * Cout + 15) / 16) * 512 * 4;
     }
-    return (size_t)(27 * Cin + 31) / 32 * ((Cout + 15) / 16) * 512;
+    return (size_t)(ntaps * Cin + 31) / 32 * ((Cout + 15) / 16) * 512;
 }
 
 
 // element i of the fragment layout -> (tap, ci, co) of the weight it holds; false: a zero (k or column padding, a parity without a tap at this offset)
-__host__ __device__ inline bool mvs_conv3d_bf16_coords(int64_t i, int Cin, int Cout, int transposed, int& tap, int& ci, int& co)
+__host__ __device__ inline bool mvs_conv3d_bf16_coords(int64_t i, int Cin, int Cout, int transposed, int& tap, int& ci, int& co, int ntaps = 27)
 {
-    const int log = (Cin == 8 ? 3 : Cin == 16 ? 4 : Cin == 32 ? 5 : 6);
+    const int log = (Cin == 4 ? 2 : Cin == 8 ? 3 : Cin == 16 ? 4 : Cin == 32 ? 5 : 6);
     const int NT = transposed ? (2 * Cout + 15) / 16 : (Cout + 15) / 16;
-    const int ksn = transposed ? (8 * Cin) / 32 : (27 * Cin + 31) / 32;
+    const int ksn = transposed ? (8 * Cin) / 32 : (ntaps * Cin + 31) / 32;
     const int64_t per = (int64_t)ksn * NT * 64 * 8;
     const int cls = (int)(i / per);
     const int64_t r = i - cls * per;
@@ -28,7 +29,7 @@ __host__ __device__ inline bool mvs_conv3d_bf16_coords(int64_t i, int Cin, int C
     const int kb = ks * 32 + (lane >> 4) * 8 + j, t = kb >> log, col = nt * 16 + (lane & 15);
     ci = kb & (Cin - 1);
     tap = -1; co = col;
-    if (!transposed) { if (t < 27 && co < Cout) tap = t; }
+    if (!transposed) { if (t < ntaps && co < Cout) tap = t; }
     else {
         const int pz = cls >> 1, py = cls & 1, px = col / Cout;
         co = col - px * Cout;

@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(PackJobs J)
         if (i >= J.n_elems[j]) return;
         int tap, ci, co;
         float v = 0.f;
-        if (mvs_conv3d_bf16_coords(i, cip, cop, J.kind[j] == 4, tap, ci, co) && ci < J.ci_real[j] && co < J.co_real[j]) {
+        if (mvs_conv3d_bf16_coords(i, cip, cop, J.kind[j] == 4, tap, ci, co, ntaps) && ci < J.ci_real[j] && co < J.co_real[j]) {
             if (J.flip[j]) tap = ntaps - 1 - tap;
             v = J.w[j][(int64_t)ci * J.s_ci[j] + (int64_t)co * J.s_co[j] + tap];
         }
@@ -573,7 +573,7 @@ extern "C" int mvsnerf_pack_weights_multi(int n_jobs, const float* const* w, flo
         if (!w[j] || !dst[j] || q[0] < 0 || q[0] > 4 || q[1] < 1 || q[1] > 27 || q[2] < 1 || q[3] < 1 || q[4] < q[2] || q[5] < q[3]) return MVSNERF_EINVAL;
         size_t n_el = (size_t)q[1] * q[4] * q[5];
         if (q[0] >= 3) {
-            n_el = q[1] == 27 ? mvs_conv3d_bf16_elems(q[4], q[5], q[0] == 4) : 0;
+            n_el = mvs_conv3d_bf16_elems(q[4], q[5], q[0] == 4, q[1]);
             if (n_el == 0) return MVSNERF_EUNSUPPORTED;
         }
         if ((q[0] == 1 && (q[4] & 3)) || (q[0] == 2 && (q[4] & 7))) return MVSNERF_EINVAL;

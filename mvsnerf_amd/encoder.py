@@ -145,7 +145,7 @@ def _log_pack(pk, method, *args):
 
 
 class _PackedConv2d:
-    """Caches the [k*k][cin_pad][cout] re-layouts of a Conv2d weight (re-packed when it changes).
+    """Caches the [k*k][cin_pad][cout] re-layouts of a Conv2d weight (re-packed when it changes); get_bf16: the bf16 fragments (_get_bf16_2d).
     mode 'fwd': the layer itself; mode 'dgrad': the convolution computing its data gradient (channel roles swapped,
     taps mirrored for stride 1; the stride-2 layers use the gather-form kernel with un-mirrored taps)."""
 
@@ -153,6 +153,9 @@ class _PackedConv2d:
         self.conv, self.cache = conv, {}
         self.cout, self.cin, self.k = conv.weight.shape[0], conv.weight.shape[1], conv.weight.shape[2]
         self.cin_pad = (self.cin + 3) // 4 * 4
+
+    def get_bf16(self, mode="fwd"):
+        return _get_bf16_2d(self, mode)
 
     def get(self, mode="fwd"):
         w = self.conv.weight
@@ -173,14 +176,54 @@ class _PackedConv2d:
         return buf
 
 
-def _conv2d(src, dims_in, cin_ld, wbuf, cin_k, cout_k, ksize, stride, bias=None, want_stats=False):
+def _get_bf16_2d(pk, mode="fwd"):
+    """bf16 B fragments of a Conv2d (or of its stride-1 data gradient) for mvsnerf_conv2d_bf16_fwd; None when that shape has no such kernel."""
+    w = pk.conv.weight
+    kk = pk.k * pk.k
+    if mode == "fwd":
+        ci_real, co_real, ci_pad, co_pad, s_ci, s_co, flip = pk.cin, pk.cout, pk.cin_pad, pk.cout, kk, pk.cin * kk, 0
+    else:
+        if pk.conv.stride[0] != 1:
+            return None
+        ci_real, co_real, ci_pad, co_pad, s_ci, s_co, flip = pk.cout, pk.cin, pk.cout, pk.cin_pad, pk.cin * kk, kk, 1
+    lib = _lib.lib()
+    if co_pad < 8:                       # the data gradient towards the 3-channel images is never needed
+        return None
+    n = lib.mvsnerf_conv2d_bf16_packed_elems(ci_pad, co_pad, pk.k)
+    if n == 0:
+        return None
+    key = (w.data_ptr(), w._version, _lib.weights_epoch())
+    name = mode + "_bf16"
+    hit = pk.cache.get(name)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    buf = torch.empty(n, device=w.device, dtype=torch.bfloat16)
+    _pack(dev_f32(w.detach().contiguous(), "conv weight"), buf, 3, kk, ci_real, co_real, ci_pad, co_pad, s_ci, s_co, flip)
+    _log_pack(pk, "get_bf16", mode)
+    pk.cache[name] = (key, buf)
+    return buf
+
+
+def _conv2d(src, dims_in, cin_ld, wbuf, cin_k, cout_k, ksize, stride, bias=None, want_stats=False, packed=None, mode="fwd"):
     """2-D convolution kernel launch (padding k//2): input (N,H,W) with channel stride cin_ld -> raw (N,Ho,Wo,cout_k).
     want_stats: returns (raw, InPlaceABN partial sums | None) - the matrix-core layers leave them from their own launch."""
     N, H, W, _ = dims_in
     P = ksize // 2
     Ho, Wo = (H + 2 * P - ksize) // stride + 1, (W + 2 * P - ksize) // stride + 1
-    out = torch.empty((N, Ho, Wo, cout_k), device=wbuf.device, dtype=torch.float32)
+    dev = (src.x if isinstance(src, _Lazy) else src).device
+    out = torch.empty((N, Ho, Wo, cout_k), device=dev, dtype=torch.float32)
     lib = _lib.lib()
+    wq = _get_bf16_2d(packed, mode) if (_LAYER_BF16[0] and packed is not None) else None
+    if wq is not None:               # use_amp: FeatureNet on the bf16 matrix cores (csrc/conv3d_bf16.hip), statistics from the same launch
+        part, nblk = None, 0
+        if want_stats and bias is None and FUSED_ABN_STATS:
+            nblk = lib.mvsnerf_conv2d_bf16_tiles(N, H, W, ksize, stride)
+            part = torch.empty(nblk * 2 * cout_k, device=dev, dtype=torch.float32)
+        check(lib.mvsnerf_conv2d_bf16_fwd(*_ptrs(src), cin_k, cin_ld, N, H, W, wq.data_ptr(), 0 if bias is None else bias.data_ptr(), cout_k, ksize, stride,
+                                          out.data_ptr(), 0 if part is None else part.data_ptr(), stream_ptr()), "conv2d_bf16_fwd")
+        return (out, None if part is None else (part, nblk)) if want_stats else out
+    if callable(wbuf):
+        wbuf = wbuf()
     if want_stats and bias is None and FUSED_ABN_STATS:
         nblk = lib.mvsnerf_conv2d_mfma_tiles(cin_k, cout_k, N, H, W, ksize, stride)
         if nblk > 0:
@@ -207,7 +250,7 @@ class ConvBnReLU(nn.Module):
 
     def lazy(self, src, dims_in, cin_ld):
         pk = self._packed
-        raw, partials = _conv2d(src, dims_in, cin_ld, pk.get(), pk.cin_pad, pk.cout, self.k, self.stride, want_stats=True)
+        raw, partials = _conv2d(src, dims_in, cin_ld, pk.get, pk.cin_pad, pk.cout, self.k, self.stride, want_stats=True, packed=pk)
         N, H, W, C = raw.shape
         scale, shift, mean, invstd = _abn_stats(raw, N * H * W, self.bn, update_running=self.bn.training,
                                                 partials=partials if self.bn.training else None)
@@ -261,11 +304,12 @@ class FeatureNet(nn.Module):
         img, ld = _images_channel_last(x, 4)
         src, dims = img, (N, H, W, ld)
         lz = []
-        for lay in self._layers():
-            z = lay.lazy(src, dims, ld)
-            lz.append(z)
-            src, dims, ld = z, z.dims, z.dims[3]      # (materialising the activation here, as the 3-D up-blocks do, is 3 % slower)
-        top = _conv2d(src, dims, ld, self._top_packed.get(), 32, 32, 1, 1, bias=dev_f32_tensor(self.toplayer.bias))
+        with _layer_precision(ENCODER_PRECISION == "bf16" and BF16_LAYERS):      # use_amp: the 2-D layers on the bf16 matrix cores as well
+            for lay in self._layers():
+                z = lay.lazy(src, dims, ld)
+                lz.append(z)
+                src, dims, ld = z, z.dims, z.dims[3]      # (materialising the activation here, as the 3-D up-blocks do, is 3 % slower)
+            top = _conv2d(src, dims, ld, self._top_packed.get, 32, 32, 1, 1, bias=dev_f32_tensor(self.toplayer.bias), packed=self._top_packed)
         _flush_nbt()
         return (img, img.shape[3]), lz, top
 
@@ -331,10 +375,16 @@ class _FeatureNetFunction(torch.autograd.Function):
     def forward(ctx, x, net, *params):
         (img, ld), lz, top = net._run(x)
         ctx.net, ctx.img, ctx.ld, ctx.lz = net, img, ld, lz
+        ctx.layers_bf16 = ENCODER_PRECISION == "bf16" and BF16_LAYERS
         return top.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, g_out):
+        with _layer_precision(ctx.layers_bf16):
+            return _FeatureNetFunction._backward(ctx, g_out)
+
+    @staticmethod
+    def _backward(ctx, g_out):
         net, lz, lib = ctx.net, ctx.lz, _lib.lib()
         L = net._layers()
         g = g_out.permute(0, 2, 3, 1)
@@ -347,7 +397,7 @@ class _FeatureNetFunction(torch.autograd.Function):
         check(lib.mvsnerf_channel_sum(g.data_ptr(), N * h * w, 32, gb.data_ptr(), ws.data_ptr(), stream_ptr()), "channel_sum")
         sums = _PartialSums()
         gw_top = _wgrad2d(g, 32, last, 32, 32, (N, h, w), last.dims, 1, 1, tuple(net.toplayer.weight.shape), sums)
-        g_act = _conv2d(g, (N, h, w, 32), 32, net._top_packed.get("dgrad"), 32, 32, 1, 1)
+        g_act = _conv2d(g, (N, h, w, 32), 32, lambda: net._top_packed.get("dgrad"), 32, 32, 1, 1, packed=net._top_packed, mode="dgrad")
         grads = [None] * len(L)
         for i in range(len(L) - 1, -1, -1):
             lay, out_lz = L[i], lz[i]
@@ -362,7 +412,7 @@ class _FeatureNetFunction(torch.autograd.Function):
             if i == 0:
                 break
             if lay.stride == 1:
-                g_act = _conv2d(gx, out_lz.dims, pk.cout, pk.get("dgrad"), pk.cout, pk.cin, lay.k, 1)
+                g_act = _conv2d(gx, out_lz.dims, pk.cout, lambda: pk.get("dgrad"), pk.cout, pk.cin, lay.k, 1, packed=pk, mode="dgrad")
             else:
                 Nn, Ho, Wo, _ = out_lz.dims
                 Hi, Wi = x_dims[1], x_dims[2]

@@ -160,3 +160,81 @@ def test_use_amp_training_node_runs_every_layer_in_bf16_and_stays_close_to_fp32(
     record_err("bf16_node:volume", e_vol); record_err("bf16_node:d_feats", e_gf); record_err("bf16_node:worst_weight_grad", e_gw[worst])
     print(f"bf16 training node (all layers) vs fp32: volume {e_vol:.2e}, d feats {e_gf:.2e}, worst weight gradient {e_gw[worst]:.2e} ({worst})")
     assert 0 < e_vol < 3e-2 and e_gf < 0.3 and e_gw[worst] < 0.6
+
+
+# FeatureNet's 2-D layers (models.py:688-722) on the same kernels: (Cin, Cout, k, stride, N, H, W)
+LAYERS_2D = [(3, 8, 3, 1, 2, 20, 36), (8, 8, 3, 1, 3, 17, 23), (8, 16, 5, 2, 3, 24, 40), (16, 16, 3, 1, 2, 13, 21), (16, 32, 5, 2, 2, 22, 30),
+             (32, 32, 3, 1, 2, 9, 14), (16, 16, 3, 1, 3, 128, 160)]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,N,H,W", LAYERS_2D)
+def test_bf16_featurenet_layer_forward_and_dgrad_vs_float64(cin, cout, k, stride, N, H, W):
+    from mvsnerf_amd import encoder as E
+    torch.manual_seed(cin * 10 + k)
+    conv = nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False).to(DEV)
+    pk = E._PackedConv2d(conv)
+    g = torch.Generator(DEV).manual_seed(H * 7 + W)
+    x = torch.zeros((N, H, W, pk.cin_pad), device=DEV)
+    x[..., :cin] = torch.randn((N, H, W, cin), device=DEV, generator=g)
+    w64 = _bf(conv.weight.detach()).double()
+    with torch.no_grad(), E._layer_precision(True):
+        out, partials = E._conv2d(x, (N, H, W, pk.cin_pad), pk.cin_pad, pk.get, pk.cin_pad, cout, k, stride, want_stats=True, packed=pk)
+        assert "fwd_bf16" in pk.cache
+        ref = F.conv2d(_bf(x[..., :cin]).double().permute(0, 3, 1, 2), w64, stride=stride, padding=k // 2).permute(0, 2, 3, 1)
+        assert out.shape == ref.shape
+        scale, err = float(ref.abs().max()), float((out.double() - ref).abs().max())
+        record_err(f"bf16_layer2d_fwd:{cin}->{cout}k{k}s{stride}", err, scale=scale)
+        assert err < 3e-6 * scale, (err, scale)
+        part, nblk = partials
+        s = part.view(2, cout, nblk).double().sum(2)
+        o64 = out.double()
+        assert float((s[0] - o64.sum((0, 1, 2))).abs().max()) < 1e-6 * float(o64.abs().sum((0, 1, 2)).max())
+        assert float((s[1] - (o64 ** 2).sum((0, 1, 2))).abs().max()) < 1e-6 * float((o64 ** 2).sum((0, 1, 2)).max())
+        if stride == 1 and cin >= 8:
+            go = torch.randn(tuple(out.shape), device=DEV, generator=g)
+            gx = E._conv2d(go, tuple(out.shape), cout, lambda: pk.get("dgrad"), cout, cin, k, 1, packed=pk, mode="dgrad")
+            assert "dgrad_bf16" in pk.cache
+            refg = F.conv_transpose2d(_bf(go).double().permute(0, 3, 1, 2), w64, stride=1, padding=k // 2).permute(0, 2, 3, 1)
+            scale, err = float(refg.abs().max()), float((gx.double() - refg).abs().max())
+            record_err(f"bf16_layer2d_dgrad:{cin}->{cout}k{k}", err, scale=scale)
+            assert err < 3e-6 * scale, (err, scale)
+
+
+def test_bf16_toplayer_with_bias_and_whole_featurenet_vs_fp32():
+    """The biased 1x1 toplayer on the bf16 kernel, then FeatureNet end to end under encoder_precision('bf16') against the fp32 kernels:
+    forward within bf16 operand rounding, every layer (and every stride-1 data gradient) taken by the bf16 kernels, gradients close."""
+    from mvsnerf_amd import encoder as E, models
+    from tests.util import load_weights
+    torch.manual_seed(1)
+    top = nn.Conv2d(32, 32, 1).to(DEV)
+    pk = E._PackedConv2d(top)
+    g = torch.Generator(DEV).manual_seed(2)
+    x = torch.randn((2, 11, 19, 32), device=DEV, generator=g)
+    with torch.no_grad(), E._layer_precision(True):
+        out = E._conv2d(x, (2, 11, 19, 32), 32, pk.get, 32, 32, 1, 1, bias=top.bias.detach(), packed=pk)
+    ref = F.conv2d(_bf(x).double().permute(0, 3, 1, 2), _bf(top.weight.detach()).double(), top.bias.detach().double()).permute(0, 2, 3, 1)
+    assert float((out.double() - ref).abs().max()) < 3e-6 * float(ref.abs().max())
+    _, mvs_sd = load_weights()
+    imgs = torch.rand((3, 3, 128, 160), generator=torch.Generator().manual_seed(4)).to(DEV)
+    res = {}
+    for prec in ("fp32", "bf16"):
+        net = models.MVSNet()
+        net.load_state_dict(mvs_sd)
+        fn = net.feature.to(DEV).train()
+        with E.encoder_precision(prec):
+            f = fn(imgs)
+        gen = torch.Generator(DEV).manual_seed(5)
+        (f * torch.randn(f.shape, device=DEV, generator=gen)).sum().backward()          # outside the context, as in training_step
+        if prec == "bf16":
+            for lay in fn._layers():
+                assert "fwd_bf16" in lay._packed.cache, "a FeatureNet layer fell back to fp32"
+            assert "fwd_bf16" in fn._top_packed.cache and "dgrad_bf16" in fn._top_packed.cache
+            assert "dgrad_bf16" in fn.conv2[2]._packed.cache and "dgrad_bf16" in fn.conv0[1]._packed.cache
+        res[prec] = (f.detach(), {n: p.grad.detach() for n, p in fn.named_parameters()})
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-12))
+    e_f = rel(res["bf16"][0], res["fp32"][0])
+    e_g = {n: rel(res["bf16"][1][n], res["fp32"][1][n]) for n in res["fp32"][1]}
+    worst = max(e_g, key=e_g.get)
+    record_err("bf16_featurenet:features", e_f); record_err("bf16_featurenet:worst_grad", e_g[worst])
+    print(f"bf16 FeatureNet vs fp32: features {e_f:.2e}, worst gradient {e_g[worst]:.2e} ({worst})")
+    assert 0 < e_f < 3e-2 and e_g[worst] < 0.3
