@@ -268,6 +268,19 @@ int mvsnerf_conv3d_wgrad(const float* g1, const float* g1_scale, const float* g1
                          const float* x2, const float* x2_scale, const float* x2_shift, int B, int ldx,
                          int Do, int Ho, int Wo, int Di, int Hi, int Wi, int stride,
                          float* gw, float* workspace, void* stream);
+/* The same weight gradients with bf16 operands (use_amp; csrc/wgrad_bf16.hip): G and X are rounded to bf16 when they are staged, products
+ * accumulate in fp32 on v_mfma_f32_16x16x32_bf16, deterministic.  kz x k x k taps, padding k / 2 (kz / 2): (3, 3) with stride 1 | 2 for the 3-D
+ * layers, (1, 3) stride 1, (1, 5) stride 2 and (1, 1) for FeatureNet's 2-D layers (D = the images, not strided).  A, B multiples of 4, <= 64.
+ * workspace: mvsnerf_conv_wgrad_bf16_workspace_floats(A, B, kz, k); gw NULL leaves mvsnerf_conv_wgrad_bf16_parts(...) partial results at its
+ * start for mvsnerf_partial_sum_multi (0 parts: shape not built). */
+int mvsnerf_conv_wgrad_bf16_parts(int A, int B, int Do, int Ho, int Wo, int kz, int k, int stride);
+size_t mvsnerf_conv_wgrad_bf16_workspace_floats(int A, int B, int kz, int k);
+int mvsnerf_conv_wgrad_bf16(const float* g1, const float* g1_scale, const float* g1_shift,
+                            const float* g2, const float* g2_scale, const float* g2_shift, int A,
+                            const float* x1, const float* x1_scale, const float* x1_shift,
+                            const float* x2, const float* x2_scale, const float* x2_shift, int B, int ldx,
+                            int Do, int Ho, int Wo, int Di, int Hi, int Wi, int kz, int k, int stride,
+                            float* gw, float* workspace, void* stream);
 int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float* proj, const float* depth, int V, int C, int H, int W, int D, int pad,
                                    const float* g_cost, int CP, int with_img, float* g_feats_cl, void* stream);
 /* Every weight-gradient entry (conv3d_wgrad, conv3d_c8_blocked_wgrad, conv2d_wgrad) leaves per-workgroup partial results at the start of

@@ -115,6 +115,9 @@ SIGNATURES = {
     "mvsnerf_conv2d_bf16_packed_elems": (ctypes.c_size_t, [_c_i, _c_i, _c_i]),
     "mvsnerf_conv2d_bf16_tiles": (_c_i, [_c_i] * 5),
     "mvsnerf_conv2d_bf16_fwd": (_c_i, [_c_fp] * 3 + [_c_i] * 5 + [_c_fp, _c_fp] + [_c_i] * 3 + [_c_fp, _c_fp, _c_fp]),
+    "mvsnerf_conv_wgrad_bf16_parts": (_c_i, [_c_i] * 8),
+    "mvsnerf_conv_wgrad_bf16_workspace_floats": (ctypes.c_size_t, [_c_i] * 4),
+    "mvsnerf_conv_wgrad_bf16": (_c_i, [_c_fp] * 6 + [_c_i] + [_c_fp] * 6 + [_c_i] * 11 + [_c_fp, _c_fp, _c_fp]),
     "mvsnerf_conv3d_mfma_supported": (_c_i, [_c_i, _c_i, _c_i]),
     "mvsnerf_conv3d_pack_weights_mfma": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_fp]),
     "mvsnerf_conv3d_mfma_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),

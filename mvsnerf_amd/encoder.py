@@ -359,6 +359,16 @@ def _wgrad2d(gx, A, X, B, ldx, g_dims, x_dims, ksize, stride, shape, sums=None):
     """gW[a][b][tap] = sum_o G[o][a] X[o*stride - k//2 + tap][b]  (mvsnerf_conv2d_wgrad).  sums: a _PartialSums that finishes gw later."""
     lib = _lib.lib()
     gw = torch.empty(shape, device=gx.device, dtype=torch.float32)
+    if _LAYER_BF16[0] and BF16_WGRAD:
+        n_parts = lib.mvsnerf_conv_wgrad_bf16_parts(A, B, g_dims[0], g_dims[1], g_dims[2], 1, ksize, stride)
+        if n_parts > 0:             # use_amp: bf16 operands, v_mfma_f32_16x16x32_bf16 (csrc/wgrad_bf16.hip)
+            ws = torch.empty(lib.mvsnerf_conv_wgrad_bf16_workspace_floats(A, B, 1, ksize) if sums is None else n_parts * gw.numel(), device=gx.device, dtype=torch.float32)
+            check(lib.mvsnerf_conv_wgrad_bf16(gx.data_ptr(), 0, 0, 0, 0, 0, A, *_ptrs(X), 0, 0, 0, B, ldx, g_dims[0], g_dims[1], g_dims[2],
+                                              x_dims[0], x_dims[1], x_dims[2], 1, ksize, stride, 0 if sums is not None else gw.data_ptr(), ws.data_ptr(),
+                                              stream_ptr()), "conv_wgrad_bf16")
+            if sums is not None:
+                sums.add(ws, n_parts, gw)
+            return gw
     ws = torch.empty(lib.mvsnerf_conv2d_wgrad_workspace_floats(A, B, ksize), device=gx.device, dtype=torch.float32)
     check(lib.mvsnerf_conv2d_wgrad(gx.data_ptr(), A, *_ptrs(X), B, ldx, g_dims[0], g_dims[1], g_dims[2], x_dims[1], x_dims[2], ksize, stride,
                                    0 if sums is not None else gw.data_ptr(), ws.data_ptr(), stream_ptr()), "conv2d_wgrad")
@@ -640,6 +650,7 @@ def _ptrs(src):
     return src.data_ptr(), 0, 0
 
 
+BF16_WGRAD = True          # A/B switch: the weight gradients of those layers on the bf16 kernel as well (csrc/wgrad_bf16.hip)
 BF16_LAYERS = True         # A/B switch (scratch/r4): False keeps conv1 ... conv11 on the fp32 kernels under use_amp (round 3's behaviour)
 _LAYER_BF16 = [False]      # conv1 ... conv11 on the bf16 matrix cores (csrc/conv3d_bf16.hip): set for the extent of a forward / backward by _layer_precision
 
@@ -964,6 +975,16 @@ def _wgrad(G1, G2, A, X1, X2, B, ldx, g_dims, x_dims, stride, shape, sums=None):
     lib = _lib.lib()
     dev = (G1.x if isinstance(G1, _Lazy) else G1).device
     gw = torch.empty(shape, device=dev, dtype=torch.float32)
+    if _LAYER_BF16[0] and BF16_WGRAD:
+        n_parts = lib.mvsnerf_conv_wgrad_bf16_parts(A, B, g_dims[0], g_dims[1], g_dims[2], 3, 3, stride)
+        if n_parts > 0:             # use_amp: bf16 operands, v_mfma_f32_16x16x32_bf16 (csrc/wgrad_bf16.hip)
+            ws = torch.empty(lib.mvsnerf_conv_wgrad_bf16_workspace_floats(A, B, 3, 3) if sums is None else n_parts * gw.numel(), device=dev, dtype=torch.float32)
+            check(lib.mvsnerf_conv_wgrad_bf16(*_ptrs(G1), *_ptrs(G2), A, *_ptrs(X1), *_ptrs(X2), B, ldx, g_dims[0], g_dims[1], g_dims[2],
+                                              x_dims[0], x_dims[1], x_dims[2], 3, 3, stride, 0 if sums is not None else gw.data_ptr(), ws.data_ptr(),
+                                              stream_ptr()), "conv_wgrad_bf16")
+            if sums is not None:
+                sums.add(ws, n_parts, gw)
+            return gw
     ws = torch.empty(lib.mvsnerf_conv3d_wgrad_workspace_floats(A, B), device=dev, dtype=torch.float32)
     check(lib.mvsnerf_conv3d_wgrad(*_ptrs(G1), *_ptrs(G2), A, *_ptrs(X1), *_ptrs(X2), B, ldx, g_dims[0], g_dims[1], g_dims[2],
                                    x_dims[0], x_dims[1], x_dims[2], stride, 0 if sums is not None else gw.data_ptr(), ws.data_ptr(), stream_ptr()),

@@ -4,6 +4,8 @@ import sys, time, torch, os
 import os; ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); os.chdir(ROOT)
 import numpy as np
 from mvsnerf_amd import train, _lib, encoder
+if os.environ.get('MVS_BF16_WGRAD') == '0':
+    encoder.BF16_WGRAD = False
 if os.environ.get('MVS_BF16_LAYERS') == '0':
     encoder.BF16_LAYERS = False
 if os.environ.get('MVS_LIB'):
@@ -22,7 +24,7 @@ torch.manual_seed(0)
 system.fit_steps([batch] * 2, opt)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 system.fit_steps([batch] * steps, opt)
-torch.cuda.synchronize(); print("train step ms (%s, bf16 layers %s)" % ("use_amp" if amp else "fp32", encoder.BF16_LAYERS), (time.perf_counter() - t0) / steps * 1e3)
+torch.cuda.synchronize(); print("train step ms (%s, bf16 layers %s, bf16 wgrad %s)" % ("use_amp" if amp else "fp32", encoder.BF16_LAYERS, encoder.BF16_WGRAD), (time.perf_counter() - t0) / steps * 1e3)
 for rep in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     system.fit_steps([batch] * steps, opt)
