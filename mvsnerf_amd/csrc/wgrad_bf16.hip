@@ -30,18 +30,29 @@ __device__ __forceinline__ bf16x4 tr_read(const char* p)
     return __builtin_bit_cast(bf16x4, v);
 }
 
-// four channels c .. c + 3 (c + j < C real) of voxel `vox` of a lazily-activated (two-source) tensor with channel stride ld, as bf16
-__device__ __forceinline__ bf16x4 stage4(const ActSrc& s1, const ActSrc& s2, int64_t vox, int ld, int c, int C, bool in)
+// four channels c .. c + 3 of voxel `vox` of a lazily-activated (two-source) tensor with channel stride ld: raw loads (issued in batches so that
+// many are in flight), then activation, sum and the rounding to bf16
+struct Raw4 { f32x4 a, b; };
+__device__ __forceinline__ Raw4 stage_load(const ActSrc& s1, const ActSrc& s2, int64_t vox, int ld, int c, bool real)
 {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (in && c < C) {                                             // channel counts are multiples of 4: a quad is real or padding as a whole
-        v = *reinterpret_cast<const f32x4*>(s1.x + vox * ld + c);
+    Raw4 r;
+    r.a = f32x4{0.f, 0.f, 0.f, 0.f}; r.b = r.a;
+    if (real) {                                                   // channel counts are multiples of 4: a quad is real or padding as a whole
+        r.a = *reinterpret_cast<const f32x4*>(s1.x + vox * ld + c);
+        if (s2.x) r.b = *reinterpret_cast<const f32x4*>(s2.x + vox * ld + c);
+    }
+    return r;
+}
+__device__ __forceinline__ bf16x4 stage_finish(const ActSrc& s1, const ActSrc& s2, Raw4 r, int c, bool real)
+{
+    f32x4 v = r.a;
+    if (real) {
         if (s1.scale) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], s1.scale[c + j], s1.shift[c + j]);
         }
         if (s2.x) {
-            f32x4 t = *reinterpret_cast<const f32x4*>(s2.x + vox * ld + c);
+            f32x4 t = r.b;
             if (s2.scale) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) t[j] = act_apply(t[j], s2.scale[c + j], s2.shift[c + j]);
@@ -49,10 +60,10 @@ __device__ __forceinline__ bf16x4 stage4(const ActSrc& s1, const ActSrc& s2, int
             v += t;
         }
     }
-    bf16x4 r;
+    bf16x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = (__bf16)v[j];
-    return r;
+    for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
+    return o;
 }
 
 template <int S, int KZ, int K, int TOZ, int TOY>
@@ -91,21 +102,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ActSrc g1, ActSrc 
         const int ox0 = bx * TX, oy0 = by * TOY, oz0 = bz * TOZ;
         const int ix0 = ox0 * S - P, iy0 = oy0 * S - P, iz0 = oz0 * SZ - PZ;
         __syncthreads();                                          // everybody is done with the previous tile
-        // ---- stage G: item = (voxel, channel quad); consecutive threads -> consecutive 16 bytes of a voxel's 16-channel block
-#pragma unroll 4
-        for (int it = tid; it < NVO * 4; it += 256) {
-            const int v = it >> 2, c4 = (it & 3) * 4;
-            const int ox = ox0 + v % TX, oy = oy0 + (v / TX) % TOY, oz = oz0 + v / (TX * TOY);
-            const bool in = ox < Wo && oy < Ho && oz < Do;
-            *reinterpret_cast<bf16x4*>(gt + v * 32 + c4 * 2) = stage4(g1, g2, in ? ((int64_t)oz * Ho + oy) * Wo + ox : 0, A, a0 + c4, A, in);
+        // ---- stage G, then the X halo (the zero padding is not activated): item = (voxel, channel quad), consecutive threads -> consecutive
+        // 16 bytes of a voxel's 16-channel block; SB items per thread are loaded before the first is converted
+        constexpr int SB = 8;
+#pragma unroll 1
+        for (int it0 = tid; it0 < NVO * 4; it0 += 256 * SB) {
+            Raw4 raw[SB]; bool real[SB];
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int it = it0 + 256 * u, v = it >> 2, c4 = (it & 3) * 4;
+                const int ox = ox0 + v % TX, oy = oy0 + (v / TX) % TOY, oz = oz0 + v / (TX * TOY);
+                real[u] = it < NVO * 4 && ox < Wo && oy < Ho && oz < Do && a0 + c4 < A;
+                raw[u] = stage_load(g1, g2, real[u] ? ((int64_t)oz * Ho + oy) * Wo + ox : 0, A, a0 + c4, real[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int it = it0 + 256 * u;
+                if (it < NVO * 4) *reinterpret_cast<bf16x4*>(gt + (it >> 2) * 32 + (it & 3) * 8) = stage_finish(g1, g2, raw[u], a0 + (it & 3) * 4, real[u]);
+            }
         }
-        // ---- stage the X halo (the zero padding is not activated)
-#pragma unroll 4
-        for (int it = tid; it < NVH * 4; it += 256) {
-            const int v = it >> 2, c4 = (it & 3) * 4;
-            const int ix = ix0 + v % HX, iy = iy0 + (v / HX) % HY, iz = iz0 + v / (HX * HY);
-            const bool in = ix >= 0 && ix < Wi && iy >= 0 && iy < Hi && iz >= 0 && iz < Di;
-            *reinterpret_cast<bf16x4*>(xt + v * 32 + c4 * 2) = stage4(x1, x2, in ? ((int64_t)iz * Hi + iy) * Wi + ix : 0, ldx, b0 + c4, B, in);
+#pragma unroll 1
+        for (int it0 = tid; it0 < NVH * 4; it0 += 256 * SB) {
+            Raw4 raw[SB]; bool real[SB];
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int it = it0 + 256 * u, v = it >> 2, c4 = (it & 3) * 4;
+                const int ix = ix0 + v % HX, iy = iy0 + (v / HX) % HY, iz = iz0 + v / (HX * HY);
+                real[u] = it < NVH * 4 && ix >= 0 && ix < Wi && iy >= 0 && iy < Hi && iz >= 0 && iz < Di && b0 + c4 < B;
+                raw[u] = stage_load(x1, x2, real[u] ? ((int64_t)iz * Hi + iy) * Wi + ix : 0, ldx, b0 + c4, real[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int it = it0 + 256 * u;
+                if (it < NVH * 4) *reinterpret_cast<bf16x4*>(xt + (it >> 2) * 32 + (it & 3) * 8) = stage_finish(x1, x2, raw[u], b0 + (it & 3) * 4, real[u]);
+            }
         }
         __syncthreads();
         // ---- multiply: this wave's (z, y) rows of the tile
@@ -161,7 +191,7 @@ struct WgShape { int toz, toy; };
 __host__ inline bool wg_shape(int kz, int k, int stride, WgShape& s)
 {
     if (kz == 3 && k == 3 && stride == 1) { s = {4, 6}; return true; }
-    if (kz == 3 && k == 3 && stride == 2) { s = {4, 2}; return true; }
+    if (kz == 3 && k == 3 && stride == 2) { s = {2, 2}; return true; }
     if (kz == 1 && k == 3 && stride == 1) { s = {1, 8}; return true; }
     if (kz == 1 && k == 5 && stride == 2) { s = {1, 4}; return true; }
     if (kz == 1 && k == 1 && stride == 1) { s = {1, 8}; return true; }
@@ -218,7 +248,7 @@ extern "C" int mvsnerf_conv_wgrad_bf16(const float* g1, const float* g1_scale, c
         conv_wgrad_bf16_kernel<S_, KZ_, K_, TOZ_, TOY_><<<dim3(nr, NA * NB), 256, bytes, st>>>(G1, G2, A, X1, X2, B, ldx, Do, Ho, Wo, Di, Hi, Wi, nr, NB, workspace); \
     } while (0)
     if (kz == 3 && stride == 1) MVS_WG(0, 1, 3, 3, 4, 6);
-    else if (kz == 3) MVS_WG(1, 2, 3, 3, 4, 2);
+    else if (kz == 3) MVS_WG(1, 2, 3, 3, 2, 2);
     else if (k == 3) MVS_WG(2, 1, 1, 3, 1, 8);
     else if (k == 5) MVS_WG(3, 2, 1, 5, 1, 4);
     else MVS_WG(4, 1, 1, 1, 1, 8);
