@@ -283,6 +283,13 @@ int mvsnerf_conv_wgrad_bf16(const float* g1, const float* g1_scale, const float*
                             float* gw, float* workspace, void* stream);
 int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float* proj, const float* depth, int V, int C, int H, int W, int D, int pad,
                                    const float* g_cost, int CP, int with_img, float* g_feats_cl, void* stream);
+/* The same gradient with an ORDER-INDEPENDENT reduction: the source views' sums are accumulated in 64-bit fixed point (integer atomics commute;
+ * the scale is derived on the device from max |g_cost| * max |feats|, a contribution is rounded to 2^-36 of the largest possible one), then
+ * added to g_feats_cl.  Two runs - and N ranks against one - give bit-identical results; ~0.1 ms slower at config 3 (two extra passes).
+ * workspace_zeroed: mvsnerf_planesweep_costvar_bwd_det_workspace_words(V, C, H, W) int64 words, 8-byte aligned, zeroed before every call. */
+size_t mvsnerf_planesweep_costvar_bwd_det_workspace_words(int V, int C, int H, int W);
+int mvsnerf_planesweep_costvar_bwd_det(const float* feats_cl, const float* proj, const float* depth, int V, int C, int H, int W, int D, int pad,
+                                       const float* g_cost, int CP, int with_img, float* g_feats_cl, void* workspace_zeroed, void* stream);
 /* Every weight-gradient entry (conv3d_wgrad, conv3d_c8_blocked_wgrad, conv2d_wgrad) leaves per-workgroup partial results at the start of
  * its workspace and then reduces them (two small launches).  With gw == NULL the reduction is skipped: the caller collects the
  * (workspace, *_wgrad_parts(...) rows, A*B*taps floats per row, gw) of all layers of a backward pass and finishes them together with

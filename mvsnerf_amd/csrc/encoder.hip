@@ -1744,6 +1744,37 @@ __global__ __launch_bounds__(256) void planesweep_bwd_kernel(const float* __rest
 }
 
 
+// ---- helpers of the deterministic plane-sweep backward: largest magnitudes (float bits order like unsigned integers for x >= 0), the
+// fixed-point scale every thread derives from them, and the conversion back
+__global__ __launch_bounds__(256) void absmax_strided_kernel(const float* __restrict__ x, int64_t n_rows, int ld, int c0, int nc, unsigned* __restrict__ out)
+{
+    float m = 0.f;
+    const int64_t n = n_rows * nc;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / nc;
+        m = fmaxf(m, fabsf(x[r * ld + c0 + (int)(i - r * nc)]));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+__device__ __forceinline__ float psw_fix_scale(const unsigned* mx)
+{
+    const float b = __uint_as_float(mx[0]) * __uint_as_float(mx[1]);
+    if (!(b > 0.f) || !(b < 3.0e38f)) return 1.0f;
+    int e;
+    frexpf(b, &e);                                                    // b in [2^(e-1), 2^e)
+    return ldexpf(1.0f, max(-120, min(120, 36 - e)));
+}
+__global__ __launch_bounds__(256) void psw_fix_to_float_kernel(const long long* __restrict__ fix, int64_t n, float* __restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float inv = 1.0f / psw_fix_scale(reinterpret_cast<const unsigned*>(fix + n));
+    const long long v = fix[i];
+    if (v != 0) dst[i] += (float)((double)v * (double)inv);
+}
+
 // ---- plane-sweep backward, column form.  A thread owns ONE channel of ONE voxel column (x, y) and walks the depth planes itself.  Along
 // a column the sample point in a source view moves by the disparity step - a fraction of a pixel per plane for any rig the sweep is meant
 // for (0.07 px at config 2) - so the four tap PIXELS stay the same for many consecutive planes; only the bilinear weights change.  The
@@ -1756,10 +1787,16 @@ __global__ __launch_bounds__(256) void planesweep_bwd_kernel(const float* __rest
 //   Workgroup = NV = 8 consecutive columns of one row x 32 channels.  Geometry (7 divisions per voxel and view) is computed once per
 // voxel, DCH planes at a time: NV x NSRC x DCH items over the 256 threads -> LDS -> read back by the 32 channel lanes (broadcast reads).
 // The reference view's gradient of a pixel has exactly one column contributing: register sum over all planes, one plain read-add-write.
-template <int C, int NSRC>
+// FIX (the deterministic variant, mvsnerf_planesweep_costvar_bwd_det): the source views' sums go to 64-bit FIXED-POINT accumulators - integer
+// additions commute, so the result does not depend on the order in which the columns' atomics arrive (float atomics: last-bit differences
+// from run to run).  fix = {int64 [NSRC][H][W][C] | float bits of max |g_cost|, max |feat|}: a contribution is rounded to a multiple of
+// 2^-k with k = 36 - ceil(log2(max|g| * max|feat|)) (relative 2^-36 of the largest possible contribution: far below fp32's 2^-24) and
+// 2^24.3 voxels x 4 |g| |feat| 2^k stay below 2^63.
+template <int C, int NSRC, bool FIX>
 __global__ __launch_bounds__(256) void planesweep_bwd_columns_kernel(const float* __restrict__ feat, const float* __restrict__ proj,
                                                                      const float* __restrict__ depth, int H, int W, int D, int pad,
-                                                                     const float* __restrict__ g_cost, int CP, int c_var, float* __restrict__ g_feat)
+                                                                     const float* __restrict__ g_cost, int CP, int c_var, float* __restrict__ g_feat,
+                                                                     long long* __restrict__ fix)
 {
     static_assert(C == 32, "one lane per channel, 8 columns per workgroup");
     constexpr int NV = 8, DCH = 16, GI = 12;                          // columns per workgroup, planes per geometry batch, floats per item
@@ -1784,12 +1821,19 @@ __global__ __launch_bounds__(256) void planesweep_bwd_columns_kernel(const float
 #pragma unroll
         for (int k = 0; k < 4; ++k) { tap[vs][k] = 0.f; acc[vs][k] = 0.f; }
     }
+    float fix_scale = 1.0f;
+    if (FIX) fix_scale = psw_fix_scale(reinterpret_cast<const unsigned*>(fix + (int64_t)NSRC * H * W * C));
     auto send = [&](int vs) {
         float* gview = g_feat + (int64_t)(vs + 1) * H * W * C + c;
         const int o[4] = {cur[vs].x, cur[vs].y, cur[vs].z, cur[vs].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (acc[vs][k] != 0.f) { atomicAdd(gview + (o[k] >> 2), acc[vs][k]); acc[vs][k] = 0.f; }
+            if (acc[vs][k] != 0.f) {
+                if (FIX) atomicAdd(reinterpret_cast<unsigned long long*>(fix + (int64_t)vs * H * W * C + c + (o[k] >> 2)),
+                                   (unsigned long long)(long long)rintf(acc[vs][k] * fix_scale));
+                else atomicAdd(gview + (o[k] >> 2), acc[vs][k]);
+                acc[vs][k] = 0.f;
+            }
     };
     const float* gcol = g_cost + ((int64_t)y * Wp + x) * CP + c_var + c;
     const int64_t gplane = (int64_t)Hp * Wp * CP;
@@ -1865,17 +1909,28 @@ __global__ __launch_bounds__(256) void planesweep_bwd_columns_kernel(const float
 
 template <int NSRC>
 static int planesweep_bwd_columns_launch(const float* feat, const float* proj, const float* depth, int H, int W, int D, int pad, const float* g_cost,
-                                         int CP, int c_var, float* g_feat, hipStream_t st)
+                                         int CP, int c_var, float* g_feat, long long* fix, hipStream_t st)
 {
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
-    planesweep_bwd_columns_kernel<32, NSRC><<<(unsigned)(Hp * ((Wp + 7) / 8)), 256, 0, st>>>(feat, proj, depth, H, W, D, pad, g_cost, CP, c_var, g_feat);
+    const unsigned grid = (unsigned)(Hp * ((Wp + 7) / 8));
+    if (!fix) {
+        planesweep_bwd_columns_kernel<32, NSRC, false><<<grid, 256, 0, st>>>(feat, proj, depth, H, W, D, pad, g_cost, CP, c_var, g_feat, nullptr);
+        MVS_LAUNCH_CHECK();
+        return MVSNERF_OK;
+    }
+    const int64_t n = (int64_t)NSRC * H * W * 32;
+    unsigned* mx = reinterpret_cast<unsigned*>(fix + n);
+    absmax_strided_kernel<<<1024, 256, 0, st>>>(g_cost, (int64_t)D * Hp * Wp, CP, c_var, 32, mx);
+    absmax_strided_kernel<<<256, 256, 0, st>>>(feat, (int64_t)(NSRC + 1) * H * W, 32, 0, 32, mx + 1);
+    planesweep_bwd_columns_kernel<32, NSRC, true><<<grid, 256, 0, st>>>(feat, proj, depth, H, W, D, pad, g_cost, CP, c_var, g_feat, fix);
+    psw_fix_to_float_kernel<<<mvs_cdiv(n, 256), 256, 0, st>>>(fix, n, g_feat + (int64_t)H * W * 32);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }
 
 
-extern "C" int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float* proj, const float* depth, int V, int C, int H, int W, int D, int pad,
-                                              const float* g_cost, int CP, int with_img, float* g_feats_cl, void* stream)
+static int planesweep_costvar_bwd_impl(const float* feats_cl, const float* proj, const float* depth, int V, int C, int H, int W, int D, int pad,
+                                       const float* g_cost, int CP, int with_img, float* g_feats_cl, long long* fix, void* stream)
 {
     if (!feats_cl || !proj || !depth || !g_cost || !g_feats_cl || V < 1 || V > 8 || H < 2 || W < 2 || D < 1 || pad < 0) return MVSNERF_EINVAL;
     if (C != 32) return MVSNERF_EUNSUPPORTED;
@@ -1884,7 +1939,7 @@ extern "C" int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float
         hipStream_t st = (hipStream_t)stream;
         const int cv = with_img ? 3 * V : 0;
         switch (V - 1) {
-#define MVS_PBC(N) case N: return planesweep_bwd_columns_launch<N>(feats_cl, proj, depth, H, W, D, pad, g_cost, CP, cv, g_feats_cl, st)
+#define MVS_PBC(N) case N: return planesweep_bwd_columns_launch<N>(feats_cl, proj, depth, H, W, D, pad, g_cost, CP, cv, g_feats_cl, fix, st)
             MVS_PBC(1); MVS_PBC(2); MVS_PBC(3); MVS_PBC(4); MVS_PBC(5); MVS_PBC(6); MVS_PBC(7);
 #undef MVS_PBC
         }
@@ -1894,4 +1949,24 @@ extern "C" int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float
                                                                                     with_img ? 3 * V : 0, g_feats_cl);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
+}
+
+extern "C" int mvsnerf_planesweep_costvar_bwd(const float* feats_cl, const float* proj, const float* depth, int V, int C, int H, int W, int D, int pad,
+                                              const float* g_cost, int CP, int with_img, float* g_feats_cl, void* stream)
+{
+    return planesweep_costvar_bwd_impl(feats_cl, proj, depth, V, C, H, W, D, pad, g_cost, CP, with_img, g_feats_cl, nullptr, stream);
+}
+
+// int64 words of the deterministic variant's workspace (zeroed by the caller before every call)
+extern "C" size_t mvsnerf_planesweep_costvar_bwd_det_workspace_words(int V, int C, int H, int W)
+{
+    return V >= 1 && C == 32 && H >= 1 && W >= 1 ? (size_t)(V > 1 ? V - 1 : 0) * H * W * C + 1 : 0;
+}
+
+extern "C" int mvsnerf_planesweep_costvar_bwd_det(const float* feats_cl, const float* proj, const float* depth, int V, int C, int H, int W, int D, int pad,
+                                                  const float* g_cost, int CP, int with_img, float* g_feats_cl, void* workspace_zeroed, void* stream)
+{
+    if (!workspace_zeroed || ((uintptr_t)workspace_zeroed & 7)) return workspace_zeroed ? MVSNERF_EALIGN : MVSNERF_EINVAL;
+    return planesweep_costvar_bwd_impl(feats_cl, proj, depth, V, C, H, W, D, pad, g_cost, CP, with_img, g_feats_cl,
+                                       reinterpret_cast<long long*>(workspace_zeroed), stream);
 }

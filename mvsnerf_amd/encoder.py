@@ -1213,6 +1213,25 @@ def _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img, blocked=Fa
     return _cl_view_to_ncdhw(cost, n_ch), masks.unsqueeze(0), (feats_cl, proj, depth, (V, C, H, W, D, pad, CP, n_ch))
 
 
+PSW_BWD_DETERMINISTIC = False   # True: the plane sweep's feature gradient through 64-bit fixed-point accumulators (integer atomics commute: two
+                                # runs, or N ranks against one, agree bit for bit; ~0.1 ms slower).  Default: float atomics.
+
+
+def _planesweep_bwd(feats_cl, proj, depth, V, C, H, W, D, pad, g_cost, ld, with_img):
+    """d cost volume (variance channels) -> d feats_cl (V, H, W, C); reference: autograd through models.py:839-893 (homo_warp + variance)."""
+    lib = _lib.lib()
+    g_feats = torch.zeros((V, H, W, C), device=feats_cl.device, dtype=torch.float32)
+    if PSW_BWD_DETERMINISTIC:
+        ws = torch.zeros(lib.mvsnerf_planesweep_costvar_bwd_det_workspace_words(V, C, H, W), device=feats_cl.device, dtype=torch.int64)
+        check(lib.mvsnerf_planesweep_costvar_bwd_det(feats_cl.data_ptr(), proj.data_ptr(), depth.data_ptr(), V, C, H, W, D, pad,
+                                                     g_cost.data_ptr(), ld, with_img, g_feats.data_ptr(), ws.data_ptr(), stream_ptr()),
+              "planesweep_costvar_bwd_det")
+    else:
+        check(lib.mvsnerf_planesweep_costvar_bwd(feats_cl.data_ptr(), proj.data_ptr(), depth.data_ptr(), V, C, H, W, D, pad,
+                                                 g_cost.data_ptr(), ld, with_img, g_feats.data_ptr(), stream_ptr()), "planesweep_costvar_bwd")
+    return g_feats
+
+
 class _PlaneSweepFunction(torch.autograd.Function):
     """Plane sweep with the gradient of the variance channels w.r.t. the source feature maps (bilinear scatter)."""
 
@@ -1227,9 +1246,7 @@ class _PlaneSweepFunction(torch.autograd.Function):
     def backward(ctx, g_cost, g_masks):
         feats_cl, proj, depth, (V, C, H, W, D, pad, CP, n_ch) = ctx.saved
         buf, ld = _as_channel_last(g_cost, CP)
-        g_feats = torch.zeros((V, H, W, C), device=feats_cl.device, dtype=torch.float32)
-        check(_lib.lib().mvsnerf_planesweep_costvar_bwd(feats_cl.data_ptr(), proj.data_ptr(), depth.data_ptr(), V, C, H, W, D, pad,
-                                                        buf.data_ptr(), ld, int(ctx.with_img), g_feats.data_ptr(), stream_ptr()), "planesweep_costvar_bwd")
+        g_feats = _planesweep_bwd(feats_cl, proj, depth, V, C, H, W, D, pad, buf, ld, int(ctx.with_img))
         return g_feats.permute(0, 3, 1, 2).unsqueeze(0), None, None, None, None, None
 
 
@@ -1281,10 +1298,7 @@ class _SweepRegFunction(torch.autograd.Function):
             g_var, flat = _costreg_backward(net, lz, g_out, conv0_grads, sums)
         g_feats = None
         if g_var is not None:
-            g_feats_cl = torch.zeros((V, H, W, C), device=feats_cl.device, dtype=torch.float32)
-            check(lib.mvsnerf_planesweep_costvar_bwd(feats_cl.data_ptr(), proj.data_ptr(), depth.data_ptr(), V, C, H, W, D, pad,
-                                                     g_var.data_ptr(), C, 0, g_feats_cl.data_ptr(), stream_ptr()), "planesweep_costvar_bwd")
-            g_feats = g_feats_cl.permute(0, 3, 1, 2).unsqueeze(0)
+            g_feats = _planesweep_bwd(feats_cl, proj, depth, V, C, H, W, D, pad, g_var, C, 0).permute(0, 3, 1, 2).unsqueeze(0)
         return (g_feats, None, None, None, None, None, *flat)
 
 

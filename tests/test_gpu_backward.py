@@ -349,3 +349,71 @@ def test_planesweep_bwd_vs_float64_autograd(V, H, W, pad, D, with_img, bscale):
     err = float((gf.double() - gref).abs().max())
     print(f"[planesweep bwd V={V} {D}x{Hp}x{Wp}] {ms:.3f} ms; max err vs float64 autograd {err:.2e} (|g| max {scale:.1f})")
     assert scale > 0 and err < 2e-5 * scale
+
+
+@pytest.mark.parametrize("V,H,W,pad,D,with_img,bscale", [(3, 30, 41, 3, 10, True, 1.0), (3, 24, 33, 2, 37, False, 6.0), (4, 128, 160, 24, 128, False, 1.0)])
+def test_planesweep_bwd_deterministic_variant(V, H, W, pad, D, with_img, bscale):
+    """mvsnerf_planesweep_costvar_bwd_det (64-bit fixed-point accumulators): three runs are bit-identical, the result agrees
+    with the float-atomic kernel to the float atomics' own run-to-run noise, a gradient 1e6 times larger (another fixed-point scale) works
+    the same, and encoder.PSW_BWD_DETERMINISTIC routes the autograd node through it."""
+    from mvsnerf_amd import _lib, encoder
+    from mvsnerf_amd.ops import stream_ptr
+    from mvsnerf_amd.synth import make_rig
+    from tests.util import record_err
+    base = tuple(b * bscale for b in (0.0, 0.25, -0.25, 0.12, -0.12, 0.1, -0.3, 0.3, 0.2))
+    rig = make_rig(H * 4, W * 4, n_views=V + 1, seed=77, baselines=base[:V + 1], rot_deg=2.0, smooth=True)
+    proj = rig["proj_mats"][0, :V].contiguous().to(DEV)
+    nf = rig["near_fars"][0, 0]
+    depth = torch.linspace(float(nf[0]), float(nf[1]), D).to(DEV)
+    g = torch.Generator(DEV).manual_seed(V * 100 + D)
+    feats = torch.randn((V, H, W, 32), device=DEV, generator=g)
+    CP = (32 + 3 * V + 3) // 4 * 4 if with_img else 32
+    g_cost = torch.randn((D, H + 2 * pad, W + 2 * pad, CP), device=DEV, generator=g)
+    L = _lib.lib()
+    words = L.mvsnerf_planesweep_costvar_bwd_det_workspace_words(V, 32, H, W)
+    assert words == (V - 1) * H * W * 32 + 1
+
+    def det(gc):
+        gf = torch.zeros((V, H, W, 32), device=DEV)
+        ws = torch.zeros(words, device=DEV, dtype=torch.int64)
+        assert L.mvsnerf_planesweep_costvar_bwd_det(feats.data_ptr(), proj.data_ptr(), depth.data_ptr(), V, 32, H, W, D, pad, gc.data_ptr(), CP,
+                                                    int(with_img), gf.data_ptr(), ws.data_ptr(), stream_ptr()) == 0
+        return gf
+
+    def atomic(gc):
+        gf = torch.zeros((V, H, W, 32), device=DEV)
+        assert L.mvsnerf_planesweep_costvar_bwd(feats.data_ptr(), proj.data_ptr(), depth.data_ptr(), V, 32, H, W, D, pad, gc.data_ptr(), CP,
+                                                int(with_img), gf.data_ptr(), stream_ptr()) == 0
+        return gf
+
+    a = det(g_cost)
+    for _ in range(2):
+        assert torch.equal(det(g_cost), a), "two runs of the deterministic variant differ"
+    ref = atomic(g_cost)
+    scale = float(ref.abs().max())
+    err = float((a - ref).abs().max()) / scale
+    record_err(f"planesweep_bwd_det_vs_atomic:V{V}:D{D}", err, tol=3e-6)
+    assert scale > 0 and err < 3e-6, err                                  # the float atomics' summation-order noise
+    big = det(g_cost * 1.0e6)
+    assert torch.equal(det(g_cost * 1.0e6), big)
+    assert float((big / 1.0e6 - a).abs().max()) / scale < 3e-6
+    assert float(det(torch.zeros_like(g_cost)).abs().max()) == 0.0       # all-zero gradient: scale falls back to 1
+    # the autograd node
+    f0 = feats.permute(0, 3, 1, 2).unsqueeze(0).contiguous()
+    imgs = torch.rand((1, V, 3, H * 4, W * 4), device=DEV)
+    net = encoder.MVSNet().to(DEV)
+    outs = []
+    for flag in (True, True, False):
+        encoder.PSW_BWD_DETERMINISTIC = flag
+        try:
+            f = f0.clone().requires_grad_()
+            if with_img:
+                vol, _ = net.build_volume_costvar_img(imgs, f, proj[None], depth[None], pad)
+            else:
+                vol, _ = net.build_volume_costvar(f, proj[None], depth[None], pad)
+            (vol * vol).sum().backward()
+            outs.append(f.grad.clone())
+        finally:
+            encoder.PSW_BWD_DETERMINISTIC = False
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[0] - outs[2]).abs().max()) <= 3e-6 * float(outs[2].abs().max())

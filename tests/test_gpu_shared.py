@@ -65,7 +65,8 @@ def _worst(got, ref):
 
 def _rank_body(rank, world, port, q):
     import torch.distributed as dist
-    from mvsnerf_amd import distributed as D, train
+    from mvsnerf_amd import distributed as D, encoder, train
+    encoder.PSW_BWD_DETERMINISTIC = True          # the order-independent plane-sweep reduction: one source of run-to-run noise less in the comparisons
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
