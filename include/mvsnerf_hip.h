@@ -449,11 +449,14 @@ int mvsnerf_mlp_fwd_bf16(const void* packed_bf16, const float* packed_f32, int F
                          int64_t N, int S, int alpha_only, float* raw, void* stream);
 
 /* bf16 TRAINING (the reference's AMP switch, train_mvs_nerf_pl.py:317-318 `precision=16 if args.use_amp`; BASELINE config 3):
- *   mlp_fwd_bf16_train  = mlp_fwd_bf16 + the activation store of mvsnerf_mlp_fwd_train (fp32 slots: what THIS forward computed)
+ *   mlp_fwd_bf16_train  = mlp_fwd_bf16 + the activation store of mvsnerf_mlp_fwd_train as BF16 slots (same [tile][slot][lane] order, two
+ *                       bytes per element: `saved` needs mvsnerf_mlp_saved_floats(N*S) / 2 floats) - what the bf16 backward reads
  *   mlp_pack_bwd_bf16   W^T fragments for v_mfma_f32_32x32x16_bf16 (mvsnerf_mlp_packed_bwd_bf16_elems() 16-bit elements)
  *   mlp_bwd_bf16        mvsnerf_mlp_bwd with every GEMM of the backward pass (data gradient W^T products, weight-gradient point
  *                       contractions) on the bf16 matrix cores: operands rounded to bf16, fp32 accumulate; activation derivatives,
- *                       bias gradients and reductions fp32; gradients are returned in fp32 (fp32 master weights, fp32 all-reduce). */
+ *                       bias gradients and reductions fp32; gradients are returned in fp32 (fp32 master weights, fp32 all-reduce).
+ *                       `saved` must come from mvsnerf_mlp_fwd_bf16_train (bf16 slots); `gslots` holds bf16 slots as well
+ *                       (mvsnerf_mlp_gradslot_floats(N*S) / 2 floats).  As with autocast, what is kept for the backward pass is 16-bit. */
 int mvsnerf_mlp_fwd_bf16_train(const void* packed_bf16, const float* packed_f32, int F, const float* ndc, int ndc_stride,
                                const float* feat, int feat_stride, const float* dirs, int dirs_stride,
                                int64_t N, int S, float* raw, float* saved, void* stream);
@@ -651,7 +654,7 @@ typedef struct {
     float* dirs_tmp;                        /* [N][3] */
     float* input_feat;                      /* [N][S][8+4V] (output of rendering() too) */
     float* raw;                             /* [N][S][4] */
-    float* saved;                           /* mvsnerf_mlp_saved_floats(N*S) */
+    float* saved;                           /* mvsnerf_mlp_saved_floats(N*S) floats; half of that when bf16 (two-byte slots) */
     float* rgb_map; float* disp; float* acc; float* weights; float* depth; float* alpha;
     int vol_layout;                         /* memory order of `vol` (ABI v10); the gradient volume of mvsnerf_raymarch_bwd is DHWC in either case */
 } mvsnerf_raymarch_train_args;
@@ -663,7 +666,7 @@ typedef struct {
     int64_t N; int S; int white_bkgd;
     const float* g_rgb; const float* g_depth; const float* g_weights; const float* g_alpha;
     float* d_raw;                           /* scratch [N][S][4] */
-    float* gslots;                          /* scratch mvsnerf_mlp_gradslot_floats(N*S) */
+    float* gslots;                          /* scratch mvsnerf_mlp_gradslot_floats(N*S) floats; half of that when bf16 */
     float* d_feat; int n_feat_out;          /* scratch [N*S][n_feat_out]; 8, or F for a colour volume */
     float* const* gw; float* const* gb;     /* 11 weight / bias gradient tensors (nn.Linear layout) */
     const int* maps; float* workspace;      /* as mvsnerf_mlp_bwd */

@@ -1609,11 +1609,15 @@ extern "C" int mvsnerf_partial_sum_multi(int n_jobs, const float* const* partial
     if (n_jobs < 1 || n_jobs > MVS_PSUM_JOBS || !partial || !n_part || !n_out || !dst || !scratch) return MVSNERF_EINVAL;
     PsumJobs J;
     J.n = n_jobs;
+    J.vec4 = 0;
     int b1 = 0, b2 = 0;
     size_t off = 0;
     for (int j = 0; j < n_jobs; ++j) {
         if (!partial[j] || !dst[j] || n_part[j] < 1 || n_out[j] < 1) return MVSNERF_EINVAL;
-        const int gx = (int)((n_out[j] + 255) / 256);
+        // scratch + off stays 16-byte aligned as long as every job before this one was a vector job (slices * n_out multiples of 4)
+        const bool vec4 = (n_out[j] & 3) == 0 && mvs_aligned16(partial[j]) && mvs_aligned16(dst[j]) && mvs_aligned16(scratch + off);
+        if (vec4) J.vec4 |= 1u << j;
+        const int gx = mvs_psum_gx(n_out[j], vec4);
         const int chunk = n_part[j] <= MVS_RED_SLICES ? n_part[j] : (n_part[j] + MVS_RED_SLICES - 1) / MVS_RED_SLICES;
         const int slices = (n_part[j] + chunk - 1) / chunk;
         J.partial[j] = partial[j]; J.dst[j] = dst[j]; J.scratch[j] = scratch + off; J.n_out[j] = n_out[j];

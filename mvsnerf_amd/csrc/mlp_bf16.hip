@@ -106,8 +106,10 @@ __device__ __forceinline__ bf16x8 pack8(const float* v)
 }
 
 // SAVE (bf16 training forward, train_mvs_nerf_pl.py:317-318 `precision=16`): the operands the backward pass consumes are written in
-// the slot format of mlp_layout.h, in fp32 - exactly what the fp32 training forward stores, so that the weight-gradient kernels read
-// the same buffers in either precision.  What is stored is what this forward computed (bf16-rounded operands, fp32 accumulators).
+// the slot format of mlp_layout.h as BF16 values (same [tile][slot][lane] order, two bytes per element): the weight-gradient GEMMs
+// round them to bf16 when they load them anyway, and 0.64 GB of fp32 slots per 1024 x 128 batch made this kernel, the data-gradient
+// kernel and the weight-gradient kernels stream at the HBM rate (4.6 / 5.0 / 3.5 TB/s) instead of computing.  What autocast itself
+// saves for backward is 16-bit as well.
 template <bool ALPHA_ONLY, bool SAVE = false>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_bf16_kernel(
     const __bf16* __restrict__ wq, const float* __restrict__ packed_f32, int F, const float* __restrict__ ndc, int ndc_stride,
@@ -127,9 +129,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_bf16_kernel(
     const int64_t p_raw = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
     const bool live = p_raw < P;
     const int64_t p = live ? p_raw : P - 1;
-    float* sv = nullptr;
-    if (SAVE) sv = saved + ((int64_t)blockIdx.x * 4 + wave) * (SLOTS_SAVED * 64) + lane;
-    auto save = [&](int slot, float v) { if (SAVE) sv[slot * 64] = v; };
+    __bf16* sv = nullptr;
+    if (SAVE) sv = reinterpret_cast<__bf16*>(saved) + ((int64_t)blockIdx.x * 4 + wave) * (SLOTS_SAVED * 64) + lane;
+    auto save = [&](int slot, float v) { if (SAVE) sv[slot * 64] = (__bf16)v; };
 
     // slab 0 = pts_bias weights + layer 0 (contiguous in the packed buffer)
     slabb_dma(buf0, wq + L.featw, L.l1 - L.featw, wave, lane);

@@ -189,6 +189,9 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NBLK])
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
 }
 
+template <bool BF> struct SlotType { using type = float; };
+template <> struct SlotType<true> { using type = __bf16; };
+
 // BF: the transposed weights are bf16 fragments (mvsnerf_mlp_pack_bwd_bf16) and every W^T product runs on
 // v_mfma_f32_32x32x16_bf16 with the gradient operand rounded to bf16 (fp32 accumulate); everything else is unchanged fp32.
 template <bool BF>
@@ -216,8 +219,10 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     const int64_t p_raw = tile * 32 + (lane & 31);
     const bool live = p_raw < P;
-    const float* sv = saved + tile * (SLOTS_SAVED * 64) + lane;
-    float* gs = gslots + tile * (SLOTS_GRAD * 64) + lane;
+    // BF: both slot buffers hold bf16 elements (what mvsnerf_mlp_fwd_bf16_train stored; what the bf16 weight-gradient GEMMs read)
+    using slot_t = typename SlotType<BF>::type;
+    const slot_t* sv = reinterpret_cast<const slot_t*>(saved) + tile * (SLOTS_SAVED * 64) + lane;
+    slot_t* gs = reinterpret_cast<slot_t*>(gslots) + tile * (SLOTS_GRAD * 64) + lane;
 
     wdma(buf0, packed_bwd + L.views, L.n_views, wave, lane);                         // segment 0 -> buf0
     for (int i = tid; i < V_TOTAL; i += 256) vec[i] = packed_fwd[LF.vec + i];
@@ -229,11 +234,11 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
     const float gsg = o[3] > 0.0f ? g[3] : 0.0f;
     float hv[32];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) hv[q] = sv[(S_HV + q) * 64];
+    for (int q = 0; q < 32; ++q) hv[q] = (float)sv[(S_HV + q) * 64];
     wsync();                                                                           // vec + segment 0 visible
     wdma(buf1, packed_bwd + L.feat, L.n_act, wave, lane);                            // segment 1 -> buf1
-    gs[(G_G4 + 0) * 64] = half ? gz1 : gz0;
-    gs[(G_G4 + 1) * 64] = half ? gsg : gz2;
+    gs[(G_G4 + 0) * 64] = (slot_t)(half ? gz1 : gz0);
+    gs[(G_G4 + 1) * 64] = (slot_t)(half ? gsg : gz2);
 
     // grad wrt views_linears[0] pre-activation: ghv = Wr^T gz, masked by relu
     float gh[64];
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
         for (int q = 0; q < 32; ++q) {
             const float ghv = fmaf(wr[128 + q], gz2, fmaf(wr[64 + q], gz1, wr[q] * gz0));
             gh[q] = hv[q] > 0.0f ? ghv : 0.0f;
-            gs[(G_GPV + q) * 64] = gh[q];
+            gs[(G_GPV + q) * 64] = (slot_t)gh[q];
         }
     }
     // gF = views_linears[0][:, :128]^T gpv   (no gradient to the view direction input)
@@ -262,9 +267,9 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
         wsync();                                                                       // segment 1 landed; buf0 free
         wdma(buf0, packed_bwd + L.l5, L.n_act, wave, lane);                          // segment 2 -> buf0
 #pragma unroll
-        for (int q = 0; q < 64; ++q) gs[(G_GF + q) * 64] = gh[q];
+        for (int q = 0; q < 64; ++q) gs[(G_GF + q) * 64] = (slot_t)gh[q];
 #pragma unroll
-        for (int q = 0; q < 64; ++q) hq[q] = sv[(S_H + 5 * 64 + q) * 64];
+        for (int q = 0; q < 64; ++q) hq[q] = (float)sv[(S_H + 5 * 64 + q) * 64];
         zero_acc<4>(acc);
         if (BF) gemm_tb<8, 4>(buf1, acc, lane, gh);
         else gemm_t<16, 4>(buf1, acc, lane, [&](int t) { return gh[t]; });
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
     // pts_linears 5..0:  h_i = relu(p_i * b)  =>  gq = gh*[h_i>0], gp_i = gq*b, gb += gq*p_i = gq*h_i/b
     float bm[64], gbm[64];
 #pragma unroll
-    for (int q = 0; q < 64; ++q) { bm[q] = sv[(S_BM + q) * 64]; gbm[q] = 0.0f; }
+    for (int q = 0; q < 64; ++q) { bm[q] = (float)sv[(S_BM + q) * 64]; gbm[q] = 0.0f; }
 #pragma unroll 1
     for (int layer = 5; layer >= 0; --layer) {
 #pragma unroll
@@ -292,10 +297,10 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
         if (layer >= 2) wdma(nxt, packed_bwd + L.l5 + (size_t)(6 - layer) * L.n_act, L.n_act, wave, lane);
         else if (layer == 1) wdma(nxt, packed_bwd + L.bias, L.n_bias, wave, lane);
 #pragma unroll
-        for (int q = 0; q < 64; ++q) gs[(G_GP + layer * 64 + q) * 64] = gh[q];
+        for (int q = 0; q < 64; ++q) gs[(G_GP + layer * 64 + q) * 64] = (slot_t)gh[q];
         if (layer == 0) break;
 #pragma unroll
-        for (int q = 0; q < 64; ++q) hq[q] = sv[(S_H + (layer - 1) * 64 + q) * 64];
+        for (int q = 0; q < 64; ++q) hq[q] = (float)sv[(S_H + (layer - 1) * 64 + q) * 64];
         f32x16 acc[4];
         zero_acc<4>(acc);
         if (BF) gemm_tb<8, 4>(cur, acc, lane, gh);
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(
         for (int q = 0; q < 64; ++q) gh[q] = acc[q >> 4][q & 15];
     }
 #pragma unroll
-    for (int q = 0; q < 64; ++q) gs[(G_GBM + q) * 64] = gbm[q];
+    for (int q = 0; q < 64; ++q) gs[(G_GBM + q) * 64] = (slot_t)gbm[q];
     // grad wrt the first 8 feature columns (the trilinear volume features): gf = pts_bias^T gb ; the bias segment was
     // requested during layer 1 into buf1 and made visible by the barrier of layer 0
     {
@@ -333,7 +338,7 @@ struct WgradArgs {
     float* partial;      // [gridDim.x][RA][RB + 1]  (last column = row sums)
 };
 
-// BF: both operand rows are rounded to bf16 on load and the 32 points of a tile are contracted by two v_mfma_f32_32x32x16_bf16
+// BF: both slot buffers hold bf16 elements and the 32 points of a tile are contracted by two v_mfma_f32_32x32x16_bf16
 // (lane (i, kkh) holds points [16 kkh, 16 kkh + 16): MFMA m takes its points 8m..8m+7 - the same assignment for A and B).
 // Weight-gradient GEMMs of the SAME shape run as ONE launch (blockIdx.y = job): a GEMM alone is <= 256 workgroups of one wave per SIMD,
 // i.e. latency-bound; two workgroups of different layers per CU cover each other's waits (the registers allow two).
@@ -357,36 +362,51 @@ __global__ __launch_bounds__(64 * RA_BLOCKS) void mlp_wgrad_kernel(WgradJobs job
     // <= 256 workgroups of RA_BLOCKS waves - one wave per SIMD - so nothing else covers the ~2 us between a tile's request and its
     // arrival: without the prefetch every one of the 16 tiles of a workgroup paid that latency in full (50 us per 128 x 128 layer at
     // 1024 x 128 samples, 2.7 TB/s).
-    auto request = [&](int64_t tile, f32x4 (&a4)[4], f32x4 (&b4)[NBB][4]) {
-        const float* ap = w.A + tile * w.a_tile_stride + (int64_t)(w.a_slot + (arow >> 1)) * 64 + (arow & 1) * 32 + kkh * 16;
+    if constexpr (BF) {
+        // bf16 slots ([tile][slot][64] two-byte elements): a lane's 16 points of a row are 32 contiguous bytes = the two MFMA operands as stored
+        const __bf16* A16 = reinterpret_cast<const __bf16*>(w.A);
+        const __bf16* B16 = reinterpret_cast<const __bf16*>(w.B);
+        auto request = [&](int64_t tile, bf16x8 (&a8)[2], bf16x8 (&b8)[NBB][2]) {
+            const __bf16* ap = A16 + tile * w.a_tile_stride + (int64_t)(w.a_slot + (arow >> 1)) * 64 + (arow & 1) * 32 + kkh * 16;
+            a8[0] = *reinterpret_cast<const bf16x8*>(ap); a8[1] = *reinterpret_cast<const bf16x8*>(ap + 8);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) a4[k] = *reinterpret_cast<const f32x4*>(ap + k * 4);
-#pragma unroll
-        for (int bb = 0; bb < NBB; ++bb) {
-            const int slot = bb < w.b_nblk0 ? w.b_slot0 + bb * 16 : w.b_slot1 + (bb - w.b_nblk0) * 16;
-            const float* bp = w.B + tile * w.b_tile_stride + (int64_t)(slot + (i >> 1)) * 64 + (i & 1) * 32 + kkh * 16;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) b4[bb][k] = *reinterpret_cast<const f32x4*>(bp + k * 4);
-        }
-    };
-    auto contract = [&](const f32x4 (&a4)[4], const f32x4 (&b4)[NBB][4]) {
-        if constexpr (BF) {
-#pragma unroll
-            for (int s = 0; s < 16; ++s) rsum += a4[s >> 2][s & 3];                    // bias gradient: fp32 row sums
+            for (int bb = 0; bb < NBB; ++bb) {
+                const int slot = bb < w.b_nblk0 ? w.b_slot0 + bb * 16 : w.b_slot1 + (bb - w.b_nblk0) * 16;
+                const __bf16* bp = B16 + tile * w.b_tile_stride + (int64_t)(slot + (i >> 1)) * 64 + (i & 1) * 32 + kkh * 16;
+                b8[bb][0] = *reinterpret_cast<const bf16x8*>(bp); b8[bb][1] = *reinterpret_cast<const bf16x8*>(bp + 8);
+            }
+        };
+        auto contract = [&](const bf16x8 (&a8)[2], const bf16x8 (&b8)[NBB][2]) {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                bf16x8 av;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) av[j] = (__bf16)a4[2 * m + (j >> 2)][j & 3];
+                for (int j = 0; j < 8; ++j) rsum += (float)a8[m][j];                    // bias gradient: fp32 row sums
 #pragma unroll
-                for (int bb = 0; bb < NBB; ++bb) {
-                    bf16x8 bv;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) bv[j] = (__bf16)b4[bb][2 * m + (j >> 2)][j & 3];
-                    acc[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[bb], 0, 0, 0);
-                }
+                for (int bb = 0; bb < NBB; ++bb) acc[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[m], b8[bb][m], acc[bb], 0, 0, 0);
             }
-        } else {
+        };
+        bf16x8 a_e[2], b_e[NBB][2], a_o[2], b_o[NBB][2];                 // even / odd tiles of this workgroup's range
+        if (t0 < t1) request(t0, a_e, b_e);
+        for (int64_t tile = t0; tile < t1; tile += 2) {
+            if (tile + 1 < t1) request(tile + 1, a_o, b_o);
+            contract(a_e, b_e);
+            if (tile + 2 < t1) request(tile + 2, a_e, b_e);
+            if (tile + 1 < t1) contract(a_o, b_o);
+        }
+    } else {
+        auto request = [&](int64_t tile, f32x4 (&a4)[4], f32x4 (&b4)[NBB][4]) {
+            const float* ap = w.A + tile * w.a_tile_stride + (int64_t)(w.a_slot + (arow >> 1)) * 64 + (arow & 1) * 32 + kkh * 16;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a4[k] = *reinterpret_cast<const f32x4*>(ap + k * 4);
+#pragma unroll
+            for (int bb = 0; bb < NBB; ++bb) {
+                const int slot = bb < w.b_nblk0 ? w.b_slot0 + bb * 16 : w.b_slot1 + (bb - w.b_nblk0) * 16;
+                const float* bp = w.B + tile * w.b_tile_stride + (int64_t)(slot + (i >> 1)) * 64 + (i & 1) * 32 + kkh * 16;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) b4[bb][k] = *reinterpret_cast<const f32x4*>(bp + k * 4);
+            }
+        };
+        auto contract = [&](const f32x4 (&a4)[4], const f32x4 (&b4)[NBB][4]) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const float av = a4[s >> 2][s & 3];
@@ -394,15 +414,15 @@ __global__ __launch_bounds__(64 * RA_BLOCKS) void mlp_wgrad_kernel(WgradJobs job
 #pragma unroll
                 for (int bb = 0; bb < NBB; ++bb) acc[bb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b4[bb][s >> 2][s & 3], acc[bb], 0, 0, 0);
             }
+        };
+        f32x4 a_e[4], b_e[NBB][4], a_o[4], b_o[NBB][4];                  // even / odd tiles of this workgroup's range
+        if (t0 < t1) request(t0, a_e, b_e);
+        for (int64_t tile = t0; tile < t1; tile += 2) {
+            if (tile + 1 < t1) request(tile + 1, a_o, b_o);
+            contract(a_e, b_e);
+            if (tile + 2 < t1) request(tile + 2, a_e, b_e);
+            if (tile + 1 < t1) contract(a_o, b_o);
         }
-    };
-    f32x4 a_e[4], b_e[NBB][4], a_o[4], b_o[NBB][4];                  // even / odd tiles of this workgroup's range
-    if (t0 < t1) request(t0, a_e, b_e);
-    for (int64_t tile = t0; tile < t1; tile += 2) {
-        if (tile + 1 < t1) request(tile + 1, a_o, b_o);
-        contract(a_e, b_e);
-        if (tile + 2 < t1) request(tile + 2, a_e, b_e);
-        if (tile + 1 < t1) contract(a_o, b_o);
     }
     constexpr int RA = RA_BLOCKS * 32;
     float* out = w.partial + (int64_t)blockIdx.x * RA * (RB + 1);
@@ -494,7 +514,7 @@ extern "C" int mvsnerf_mlp_bwd(const float* packed_fwd, const float* packed_bwd,
 // bf16 backward (AMP-style): every GEMM of the backward pass - W^T products of the data gradient and the point contractions of
 // the weight gradients - on v_mfma_f32_32x32x16_bf16 with operands rounded to bf16 and fp32 accumulation; activation-function
 // derivatives, the multiplicative bias modulation, the bias gradients and the reductions stay fp32; the gradients come back fp32
-// (fp32 master weights, fp32 all-reduce).  packed_bwd_bf16: mvsnerf_mlp_pack_bwd_bf16.  `saved` may come from either training forward.
+// (fp32 master weights, fp32 all-reduce).  packed_bwd_bf16: mvsnerf_mlp_pack_bwd_bf16.  `saved`: the bf16 slots of mvsnerf_mlp_fwd_bf16_train.
 extern "C" int mvsnerf_mlp_bwd_bf16(const float* packed_fwd, const void* packed_bwd_bf16, int F,
                                     const float* raw, const float* d_raw, const float* saved, int64_t N, int S,
                                     float* gslots, float* d_feat, int n_feat_out, float* const gw[11], float* const gb[11],

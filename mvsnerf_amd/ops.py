@@ -624,7 +624,7 @@ class RayMarchFunction(torch.autograd.Function):
         f32 = dict(device=dev, dtype=torch.float32)
         feat = torch.empty((N, S, F), **f32)
         raw = torch.empty((N, S, 4), **f32)
-        saved = torch.empty(lib.mvsnerf_mlp_saved_floats(N * S), **f32)
+        saved = torch.empty(lib.mvsnerf_mlp_saved_floats(N * S) // (2 if bf16 else 1), **f32)      # bf16 mode: two-byte slots
         dirs = torch.empty((N, 3), **f32)
         rgb, disp, acc, depth = (torch.empty(sh, **f32) for sh in ((N, 3), (N,), (N,), (N,)))
         weights, alpha = torch.empty((N, S), **f32), torch.empty((N, S), **f32)
@@ -660,7 +660,7 @@ class RayMarchFunction(torch.autograd.Function):
         weights = [p.detach() for p in mlp_params[0::2]]
         packed_bwd = mlp_pack_bwd_bf16(weights, F) if bf16 else mlp_pack_bwd(weights, F)
         d_raw = torch.empty((N, S, 4), **f32)
-        gslots = torch.empty(lib.mvsnerf_mlp_gradslot_floats(N * S), **f32)
+        gslots = torch.empty(lib.mvsnerf_mlp_gradslot_floats(N * S) // (2 if bf16 else 1), **f32)
         ws = torch.empty(lib.mvsnerf_mlp_bwd_workspace_floats(), **f32)
         d_feat = torch.empty((N * S, C), **f32)         # C = 8: the volume features only; C = F: the colour volume is a parameter too
         # 22 gradient tensors of their own, zeroed by ONE multi-tensor launch.  (They used to be views of one zero-filled buffer: autograd's

@@ -206,6 +206,26 @@ class _BF16Linear(torch.autograd.Function):
         return gx, gw, g2.sum(0), None, None, None
 
 
+class _ModReLU16(torch.autograd.Function):
+    """h = relu(p * b) as the bf16 training kernels keep it for the backward pass: h and b are stored as bf16 slots (round 4: the fp32
+    slots made the three MLP training kernels HBM-bound), the mask comes from the stored h and the gradient of the multiplicative bias
+    is g * h / b on the stored values (mlp_bwd.hip, `gbm[q] += gq * (hq[q] / bm[q])`)."""
+
+    @staticmethod
+    def forward(ctx, p, b):
+        q = lambda t: t.to(torch.bfloat16).to(torch.float32)
+        h = torch.relu(p * b)
+        ctx.save_for_backward(q(h), q(b))
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        h, b = ctx.saved_tensors
+        on = h > 0
+        gq = torch.where(on, g, torch.zeros_like(g))
+        return gq * b, torch.where(on, gq * (h / b), torch.zeros_like(g))
+
+
 def _renderer_bf16_emulation(ndc, angle, feat, sd):
     """Renderer_ours (models.py:194-222) with the rounding of the bf16 training kernels: the nine wide layers are bf16 GEMMs in
     all three passes; the two heads (alpha_linear, rgb_linear) are fp32 dot products forward and in the data gradient, and go
@@ -217,7 +237,7 @@ def _renderer_bf16_emulation(ndc, angle, feat, sd):
     bias = big("pts_bias", feat)
     h = pts
     for i in range(6):
-        h = torch.relu(big(f"pts_linears.{i}", h) * bias)
+        h = _ModReLU16.apply(big(f"pts_linears.{i}", h), bias)
         if i == 4:
             h = torch.cat([pts, h], -1)
     alpha = torch.relu(head("alpha_linear", h))
