@@ -187,6 +187,139 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ActSrc a, ActSrc b, int 
     });
 }
 
+// ------------------------------------------------------------------------------------------------------------------ conv, LDS-tiled
+// The big layers (conv1: 8 -> 16 stride 2 on the full-resolution volume, conv2: 16 -> 16 at half resolution, and the data gradients that are the
+// same convolutions: conv2's own and conv11's) through LDS instead of 27 re-reads of every input voxel from L1 / L2 (each with its activation
+// and rounding): the direct-load kernel above spends 85 / 65 us per launch on 37 / 150 MB of input, i.e. it is bound by the 27-fold load +
+// activate + convert instruction stream, not by memory.  A workgroup walks a range of output tiles (TOZ x TOY x 32 voxels = 2 TOZ TOY M-tiles
+// of 16 along x, four or two per wave); the input halo of a tile is activated and rounded ONCE on its way into LDS as [voxel][CIN] bf16 rows,
+// and the A fragment of an MFMA is one 16-byte LDS read (eight channels of one tap of the lane's voxel).  The next tile's halo is requested
+// (buffer loads, 32-bit offsets, zeros past the end) before the current tile's MFMAs and lands in registers under them.  The weights of all
+// k-steps stay in registers (7 or 14 x 16 bytes per lane).  Same packed weights, same output, same InPlaceABN partial sums (slot = workgroup;
+// the slots the direct-load grid would have had beyond that are written as zeros, so the caller's slot count does not depend on the kernel).
+template <int CIN, int S, int TOZ, int TOY>
+struct TiledCfg {
+    static constexpr int TX = 32, HX = (TX - 1) * S + 3, HY = (TOY - 1) * S + 3, HZ = (TOZ - 1) * S + 3;
+    static constexpr int NVH = HX * HY * HZ, ROWB = CIN * 2, XQ = CIN / 4, NX = (NVH * XQ + 255) / 256;
+    static constexpr int LDS_BYTES = ((NVH * ROWB + 63) & ~63) + 64;
+    static constexpr int KS = (27 * CIN + 31) / 32;
+};
+
+template <int CIN, int S, int TOZ, int TOY>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_bf16_tiled_kernel(
+    ActSrc a, int ld, int Di, int Hi, int Wi, const __bf16* __restrict__ wq, float* __restrict__ out, int Do, int Ho, int Wo,
+    float* __restrict__ stats, int nslots)
+{
+    using C = TiledCfg<CIN, S, TOZ, TOY>;
+    constexpr int TX = C::TX, HX = C::HX, HY = C::HY, NVH = C::NVH, ROWB = C::ROWB, XQ = C::XQ, NX = C::NX, KS = C::KS, COUT = 16;
+    constexpr int MT_PER_WAVE = TOZ * TOY * 2 / 4;
+    static_assert(CIN == 8 || CIN == 16, "the layers with >= 0.5 M output voxels");
+    static_assert((TOZ * TOY * 2) % 4 == 0 && NX <= 32, "M-tiles divide among the four waves; one mask bit per prefetched quad");
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    char* xt = lds;                                               // [NVH][CIN] bf16
+    __shared__ float red[4][2][COUT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 15, kg = lane >> 4;
+    const int nbx = (Wo + TX - 1) / TX, nby = (Ho + TOY - 1) / TOY, nbz = (Do + TOZ - 1) / TOZ;
+    const int n_tiles = nbx * nby * nbz, n_ranges = gridDim.x;
+    const int t_begin = (int)((int64_t)n_tiles * blockIdx.x / n_ranges), t_end = (int)((int64_t)n_tiles * (blockIdx.x + 1) / n_ranges);
+    // weights of every k-step, and the LDS offset of this lane's tap in each
+    bf16x8 wreg[KS];
+    int toff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        wreg[ks] = reinterpret_cast<const bf16x8*>(wq)[ks * 64 + lane];
+        const int kb = ks * 32 + kg * 8, tap = CIN == 16 ? (kb >> 4) : (kb >> 3), c0 = CIN == 16 ? (kb & 15) : 0;
+        const int t = tap < 27 ? tap : 0;                         // the padding k-values multiply zero weights: any address will do
+        const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+        toff[ks] = ((dz * HY + dy) * HX + dx) * ROWB + c0 * 2;
+    }
+    // this thread's channel quad of every staged item, its activation
+    const int xq = (tid & (XQ - 1)) * 4;
+    f32x4 sc{1.f, 1.f, 1.f, 1.f}, sh{0.f, 0.f, 0.f, 0.f};
+    const bool act_on = a.scale != nullptr;
+    if (act_on) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sc[j] = a.scale[xq + j]; sh[j] = a.shift[xq + j]; }
+    }
+    typedef unsigned u32x4v __attribute__((__vector_size__(16)));
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)((int64_t)Di * Hi * Wi * ld * 4), 0x00020000);
+    f32x4 px[NX];
+    unsigned mx = 0;
+    auto prefetch = [&](int tile) {
+        const int bx = tile % nbx, by = (tile / nbx) % nby, bz = tile / (nbx * nby);
+        const int ix0 = bx * TX * S - 1, iy0 = by * TOY * S - 1, iz0 = bz * TOZ * S - 1;
+        mx = 0;
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int v = (tid + 256 * u) / XQ;
+            const int ix = ix0 + v % HX, iy = iy0 + (v / HX) % HY, iz = iz0 + v / (HX * HY);
+            const bool in = v < NVH && ix >= 0 && ix < Wi && iy >= 0 && iy < Hi && iz >= 0 && iz < Di;
+            const unsigned off = in ? (unsigned)(((iz * Hi + iy) * Wi + ix) * ld + xq) * 4u : 0xffffffffu;
+            px[u] = __builtin_bit_cast(f32x4, (u32x4v)__builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            mx |= (unsigned)in << u;
+        }
+    };
+    float s_sum = 0.f, q_sum = 0.f;                               // InPlaceABN partial sums of channel (lane & 15), rows 4 (lane >> 4) .. + 3 of every M-tile
+    if (t_begin < t_end) prefetch(t_begin);
+#pragma unroll 1
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int bx = tile % nbx, by = (tile / nbx) % nby, bz = tile / (nbx * nby);
+        const int ox0 = bx * TX, oy0 = by * TOY, oz0 = bz * TOZ;
+        __syncthreads();                                          // everybody is done with the previous tile
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int it = tid + 256 * u;
+            f32x4 v = px[u];
+            if (act_on && ((mx >> u) & 1)) {                     // the zero padding is padding of the ACTIVATED input
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], sc[j], sh[j]);
+            }
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
+            if (it < NVH * XQ) *reinterpret_cast<bf16x4*>(xt + it * 8) = o;
+        }
+        __syncthreads();
+        if (tile + 1 < t_end) prefetch(tile + 1);
+#pragma unroll
+        for (int q = 0; q < MT_PER_WAVE; ++q) {
+            const int mt = wave * MT_PER_WAVE + q, xh = mt & 1, row = mt >> 1, oy_l = row % TOY, oz_l = row / TOY;
+            const char* base = xt + ((oz_l * S * HY + oy_l * S) * HX + (xh * 16 + m) * S) * ROWB;
+            f32x4 acc{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(base + toff[ks]), wreg[ks], acc, 0, 0, 0);
+            // D: lane (n = lane & 15, g = lane >> 4): acc[r] = voxel 4 g + r of the M-tile, channel n
+            const int oz = oz0 + oz_l, oy = oy0 + oy_l;
+            if (oz < Do && oy < Ho) {
+                float* orow = out + (((int64_t)oz * Ho + oy) * Wo) * COUT + m;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ox = ox0 + xh * 16 + 4 * kg + r;
+                    if (ox < Wo) { const float v = acc[r]; orow[(int64_t)ox * COUT] = v; s_sum += v; q_sum = fmaf(v, v, q_sum); }
+                }
+            }
+        }
+    }
+    if (stats) {
+        s_sum += __shfl_xor(s_sum, 16); q_sum += __shfl_xor(q_sum, 16);
+        s_sum += __shfl_xor(s_sum, 32); q_sum += __shfl_xor(q_sum, 32);
+        if (kg == 0) { red[wave][0][m] = s_sum; red[wave][1][m] = q_sum; }
+        __syncthreads();
+        if (tid < 2 * COUT) {
+            const int which = tid / COUT, c = tid - which * COUT;
+            stats[abn_part_at(which, c, COUT, blockIdx.x, nslots)] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+        }
+        // the slots this grid does not own
+        for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < (int64_t)(nslots - (int)gridDim.x) * 2 * COUT; i += (int64_t)gridDim.x * 256) {
+            const int64_t slot = gridDim.x + i / (2 * COUT);
+            const int r = (int)(i % (2 * COUT));
+            stats[abn_part_at(r / COUT, r % COUT, COUT, slot, nslots)] = 0.f;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ transposed conv, stride 2
 template <int CIN, int NT>          // NT = 2 * Cout / 16 column blocks (both x parities)
 __global__ __launch_bounds__(256) void convT3d_k3s2_bf16_kernel(ActSrc a, ActSrc b, int Di, int Hi, int Wi, const __bf16* __restrict__ wq, int Cout,
@@ -272,6 +405,151 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_bf16_kernel(ActSrc a, ActSrc
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------ transposed conv 16 -> 8, LDS-tiled
+// conv11 (16 channels at half resolution -> 8 at full resolution, the skip sum conv2 + conv9 as a two-source input) and conv1's data gradient:
+// 0.59 M input positions, 150 MB of output.  Same M-tile / column / k enumeration and the same packed weights as convT3d_k3s2_bf16_kernel<16, 1>;
+// the input tile (TIZ x TIY x 32 positions + one more along each axis) is activated, summed and rounded once into LDS, an A fragment is one
+// 16-byte LDS read, the nine k-steps' weights stay in registers, the next tile's loads run under the MFMAs (94 -> see profiles/ us per launch).
+template <bool TWO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void convT3d_16to8_bf16_tiled_kernel(
+    ActSrc a, ActSrc b, int Di, int Hi, int Wi, const __bf16* __restrict__ wq, float* __restrict__ out, float* __restrict__ stats, int nslots)
+{
+    constexpr int CIN = 16, COUT = 8, TIZ = 2, TIY = 4, TX = 32, HX = TX + 1, HY = TIY + 1, HZ = TIZ + 1, NVH = HX * HY * HZ, ROWB = CIN * 2, XQ = 4;
+    constexpr int NX = (NVH * XQ + 255) / 256, MT_PER_WAVE = TIZ * TIY * 2 / 4, KSC = (8 * CIN) / 32, NKS = 9;
+    __shared__ __attribute__((aligned(1024))) char xt[(NVH * ROWB + 63) & ~63];
+    __shared__ float red[4][2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 15, kg = lane >> 4;
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    const int nbx = (Wi + TX - 1) / TX, nby = (Hi + TIY - 1) / TIY, nbz = (Di + TIZ - 1) / TIZ;
+    const int n_tiles = nbx * nby * nbz, n_ranges = gridDim.x;
+    const int t_begin = (int)((int64_t)n_tiles * blockIdx.x / n_ranges), t_end = (int)((int64_t)n_tiles * (blockIdx.x + 1) / n_ranges);
+    // the nine k-steps (classes (pz, py) = (0,0): 1, (0,1): 2, (1,0): 2, (1,1): 4): weights and this lane's tap offset in the LDS tile
+    bf16x8 wreg[NKS];
+    int toff[NKS];
+    {
+        int i = 0;
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) {
+            const int pz = cls >> 1, py = cls & 1, ks_n = ((1 + pz) * (1 + py) * 2 * CIN) / 32;
+#pragma unroll
+            for (int ks = 0; ks < ks_n; ++ks, ++i) {
+                wreg[i] = reinterpret_cast<const bf16x8*>(wq)[(cls * KSC + ks) * 64 + lane];
+                const int kb = ks * 32 + kg * 8, t = kb >> 4, c0 = kb & 15;
+                int bits = t;
+                const int sx = bits & 1; bits >>= 1;
+                const int sy = py ? (bits & 1) : 1; bits >>= py;
+                const int sz = pz ? (bits & 1) : 1;
+                toff[i] = (((sz ? 0 : 1) * HY + (sy ? 0 : 1)) * HX + (sx ? 0 : 1)) * ROWB + c0 * 2;
+            }
+        }
+    }
+    const int xq = (tid & (XQ - 1)) * 4;
+    f32x4 sc1{1.f, 1.f, 1.f, 1.f}, sh1{0.f, 0.f, 0.f, 0.f}, sc2 = sc1, sh2 = sh1;
+    const bool on1 = a.scale != nullptr, on2 = TWO && b.scale != nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (on1) { sc1[j] = a.scale[xq + j]; sh1[j] = a.shift[xq + j]; }
+        if (on2) { sc2[j] = b.scale[xq + j]; sh2[j] = b.shift[xq + j]; }
+    }
+    typedef unsigned u32x4v __attribute__((__vector_size__(16)));
+    const int bytes = (int)((int64_t)Di * Hi * Wi * CIN * 4);
+    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, bytes, 0x00020000);
+    const auto rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(TWO ? b.x : a.x), 0, bytes, 0x00020000);
+    f32x4 px[NX], py2[TWO ? NX : 1];
+    unsigned mx = 0;
+    auto prefetch = [&](int tile) {
+        const int bx = tile % nbx, by = (tile / nbx) % nby, bz = tile / (nbx * nby);
+        const int ix0 = bx * TX, iy0 = by * TIY, iz0 = bz * TIZ;
+        mx = 0;
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int v = (tid + 256 * u) / XQ;
+            const int ix = ix0 + v % HX, iy = iy0 + (v / HX) % HY, iz = iz0 + v / (HX * HY);
+            const bool in = v < NVH && ix < Wi && iy < Hi && iz < Di;
+            const unsigned off = in ? (unsigned)(((iz * Hi + iy) * Wi + ix) * CIN + xq) * 4u : 0xffffffffu;
+            px[u] = __builtin_bit_cast(f32x4, (u32x4v)__builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
+            if (TWO) py2[TWO ? u : 0] = __builtin_bit_cast(f32x4, (u32x4v)__builtin_amdgcn_raw_buffer_load_b128(rs2, off, 0, 0));
+            mx |= (unsigned)in << u;
+        }
+    };
+    float s_sum = 0.f, q_sum = 0.f;                               // column n = px * 8 + channel
+    if (t_begin < t_end) prefetch(t_begin);
+#pragma unroll 1
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int bx = tile % nbx, by = (tile / nbx) % nby, bz = tile / (nbx * nby);
+        const int ix0 = bx * TX, iy0 = by * TIY, iz0 = bz * TIZ;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int it = tid + 256 * u;
+            f32x4 v = px[u];
+            if ((mx >> u) & 1) {
+                if (on1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], sc1[j], sh1[j]);
+                }
+                if (TWO) {
+                    f32x4 t = py2[TWO ? u : 0];
+                    if (on2) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) t[j] = act_apply(t[j], sc2[j], sh2[j]);
+                    }
+                    v += t;
+                }
+            }
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
+            if (it < NVH * XQ) *reinterpret_cast<bf16x4*>(xt + it * 8) = o;
+        }
+        __syncthreads();
+        if (tile + 1 < t_end) prefetch(tile + 1);
+#pragma unroll
+        for (int q = 0; q < MT_PER_WAVE; ++q) {
+            const int mt = wave * MT_PER_WAVE + q, xh = mt & 1, row = mt >> 1, iy_l = row % TIY, iz_l = row / TIY;
+            const char* base = xt + ((iz_l * HY + iy_l) * HX + xh * 16 + m) * ROWB;
+            const int iz = iz0 + iz_l, iy = iy0 + iy_l;
+            const bool row_ok = iz < Di && iy < Hi;
+            float* orow = out + ((((int64_t)(2 * iz) * Ho + 2 * iy) * Wo) * COUT) + m;
+            int i = 0;
+#pragma unroll
+            for (int cls = 0; cls < 4; ++cls) {
+                const int pz = cls >> 1, py = cls & 1, ks_n = ((1 + pz) * (1 + py) * 2 * CIN) / 32;
+                f32x4 acc{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < ks_n; ++ks, ++i)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(base + toff[i]), wreg[i], acc, 0, 0, 0);
+                // D: lane (n = lane & 15, g = lane >> 4): acc[r] = position 4 g + r of the M-tile, column n = (x parity, channel): 16 contiguous floats
+                if (row_ok) {
+                    float* oc = orow + ((int64_t)pz * Ho + py) * Wo * COUT;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ix = ix0 + xh * 16 + 4 * kg + r;
+                        if (ix < Wi) { const float v = acc[r]; oc[(int64_t)ix * 2 * COUT] = v; s_sum += v; q_sum = fmaf(v, v, q_sum); }
+                    }
+                }
+            }
+        }
+    }
+    if (stats) {
+        s_sum += __shfl_xor(s_sum, 8); q_sum += __shfl_xor(q_sum, 8);          // the two x parities of a channel
+        s_sum += __shfl_xor(s_sum, 16); q_sum += __shfl_xor(q_sum, 16);
+        s_sum += __shfl_xor(s_sum, 32); q_sum += __shfl_xor(q_sum, 32);
+        if (kg == 0 && m < 8) { red[wave][0][m] = s_sum; red[wave][1][m] = q_sum; }
+        __syncthreads();
+        if (tid < 2 * COUT) {
+            const int which = tid / COUT, c = tid - which * COUT;
+            stats[abn_part_at(which, c, COUT, blockIdx.x, nslots)] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+        }
+        for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < (int64_t)(nslots - (int)gridDim.x) * 2 * COUT; i += (int64_t)gridDim.x * 256) {
+            const int64_t slot = gridDim.x + i / (2 * COUT);
+            const int r = (int)(i % (2 * COUT));
+            stats[abn_part_at(r / COUT, r % COUT, COUT, slot, nslots)] = 0.f;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ weight fragments
 // wp[27][Cin][Cout] fp32 (mvsnerf_conv3d_pack_weights: the generic layout of the layer or of its data gradient) -> bf16 B fragments.
 // conv:        wq[ks][nt][lane][8],  k = 32 ks + 8 (lane >> 4) + j = tap * Cin + ci, column 16 nt + (lane & 15) = output channel
@@ -337,6 +615,14 @@ extern "C" int mvsnerf_conv3d_bf16_fwd(const float* x1, const float* scale1, con
     hipStream_t st = (hipStream_t)stream;
     const __bf16* w = reinterpret_cast<const __bf16*>(wq);
     const bool split = ksplit_of((int64_t)Do * Ho * Wo);
+    // the LDS-tiled kernel: single-source 8 -> 16 stride 2 / 16 -> 16 stride 1 layers with at least 256 K output voxels, tensors below 2 GB
+    if (!x2 && Cout == 16 && !split && (int64_t)Do * Ho * Wo >= (1 << 18) && (int64_t)D * H * W * cin_ld * 4 < (1ll << 31) && (int)grid >= 512 &&
+        ((Cin == 16 && stride == 1) || (Cin == 8 && stride == 2))) {
+        if (Cin == 16) conv_bf16_tiled_kernel<16, 1, 2, 4><<<512, 256, TiledCfg<16, 1, 2, 4>::LDS_BYTES, st>>>(a, cin_ld, D, H, W, w, out, Do, Ho, Wo, stats_part, (int)grid);
+        else conv_bf16_tiled_kernel<8, 2, 2, 2><<<512, 256, TiledCfg<8, 2, 2, 2>::LDS_BYTES, st>>>(a, cin_ld, D, H, W, w, out, Do, Ho, Wo, stats_part, (int)grid);
+        MVS_LAUNCH_CHECK();
+        return MVSNERF_OK;
+    }
 #define MVS_C16(CIN, NT, S) do { if (split) conv_bf16_kernel<CIN, NT, S, 4, 3, 3><<<grid, 256, 0, st>>>(a, b, cin_ld, D, H, W, w, Cout, out, Do, Ho, Wo, stats_part, nullptr); \
                                  else conv_bf16_kernel<CIN, NT, S, 1, 3, 3><<<grid, 256, 0, st>>>(a, b, cin_ld, D, H, W, w, Cout, out, Do, Ho, Wo, stats_part, nullptr); } while (0)
     switch ((Cin * 100 + n_col_blocks(Cout)) * 10 + stride) {
@@ -367,6 +653,12 @@ extern "C" int mvsnerf_conv_transpose3d_bf16_fwd(const float* x1, const float* s
     const unsigned grid = (unsigned)(((int64_t)D * H * W + 63) / 64);
     hipStream_t st = (hipStream_t)stream;
     const __bf16* w = reinterpret_cast<const __bf16*>(wq);
+    if (Cin == 16 && Cout == 8 && (int)grid >= 512 && (int64_t)D * H * W >= (1 << 18) && (int64_t)D * H * W * 16 * 4 < (1ll << 31)) {   // the LDS-tiled kernel
+        if (x2) convT3d_16to8_bf16_tiled_kernel<true><<<512, 256, 0, st>>>(a, b, D, H, W, w, out, stats_part, (int)grid);
+        else convT3d_16to8_bf16_tiled_kernel<false><<<512, 256, 0, st>>>(a, b, D, H, W, w, out, stats_part, (int)grid);
+        MVS_LAUNCH_CHECK();
+        return MVSNERF_OK;
+    }
 #define MVS_T16(CIN, NT) convT3d_k3s2_bf16_kernel<CIN, NT><<<grid, 256, 0, st>>>(a, b, D, H, W, w, Cout, out, stats_part)
     switch (Cin * 100 + Cout) {
         case 16 * 100 + 8: MVS_T16(16, 1); break;           // conv11, data gradient of conv1

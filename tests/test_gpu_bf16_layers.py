@@ -31,6 +31,10 @@ LAYERS = [
     (32, 16, 2, True, (6, 7, 9)),         # conv9
     (16, 8, 2, True, (8, 12, 20)),        # conv11
     (16, 8, 2, True, (24, 40, 48)),       # conv11, many tiles
+    # >= 256 K output voxels: the LDS-tiled kernel (conv_bf16_tiled_kernel) - forward of conv1 / conv2, data gradient of conv2 / conv11; ragged tiles
+    (8, 16, 2, False, (96, 130, 172)),    # conv1 (tiled forward)
+    (16, 16, 1, False, (50, 70, 78)),     # conv2 (tiled forward and data gradient)
+    (16, 8, 2, True, (48, 65, 86)),       # conv11 (tiled data gradient)
 ]
 
 
@@ -122,6 +126,51 @@ def test_bf16_layer_with_lazy_and_two_source_input():
         scale = float(r.abs().max())
         record_err(f"bf16_layer_lazy:{tag}", float(d.max()), scale=scale)
         assert float(d.max()) < 4e-3 * scale and float((d > 1e-5 * scale).double().mean()) < 0.02
+
+
+def test_bf16_tiled_layers_with_lazy_input_match_the_direct_load_kernel():
+    """conv_bf16_tiled_kernel (the layers with >= 256 K output voxels) applies the pending InPlaceABN once per staged voxel; the direct-load
+    kernel applies it per tap.  Same operands, same fp32 accumulation order per k-step: the two must agree to fp32 summation noise.  The direct-load
+    result comes from a second source that is all zeros with identity activation (two-source inputs never take the tiled kernel)."""
+    from mvsnerf_amd import encoder as E
+    g = torch.Generator(DEV).manual_seed(11)
+    for cin, stride, dims in ((16, 1, (50, 70, 78)), (8, 2, (96, 130, 172))):
+        D, H, W = dims
+        conv = _layer(cin, 16, stride, False, 40 + cin)
+        pk = E._PackedConv(conv, False)
+        x = torch.randn((D, H, W, cin), device=DEV, generator=g)
+        sc, sh = torch.rand(cin, device=DEV, generator=g) + 0.5, torch.randn(cin, device=DEV, generator=g) * 0.3
+        lz = E._Lazy(x, sc, sh, (D, H, W, cin))
+        zero = torch.zeros_like(x)
+        with torch.no_grad(), E._layer_precision(True):
+            tiled, (part, nblk) = E._conv(lz, None, (D, H, W, cin), cin, pk.get, cin, 16, stride, packed=pk, want_stats=True)
+            direct, (part_d, nblk_d) = E._conv(lz, zero, (D, H, W, cin), cin, pk.get, cin, 16, stride, packed=pk, want_stats=True)
+        scale = float(direct.abs().max())
+        err = float((tiled - direct).abs().max())
+        record_err(f"bf16_tiled_vs_direct:{cin}->16s{stride}", err, scale=scale)
+        assert err < 2e-6 * scale, (err, scale)
+        assert nblk == nblk_d
+        s_t, s_d = part.view(2, 16, nblk).double().sum(2), part_d.view(2, 16, nblk).double().sum(2)
+        assert float((s_t - s_d).abs().max()) < 1e-6 * float(s_d.abs().max())
+    # the tiled transposed layer (conv11) with its two lazily-activated sources (the skip sum), against float64 on the rounded sum
+    D, H, W, cin, cout = 48, 65, 86, 16, 8
+    conv = _layer(cin, cout, 2, True, 77)
+    pk = E._PackedConv(conv, True)
+    x1, x2 = torch.randn((D, H, W, cin), device=DEV, generator=g), torch.randn((D, H, W, cin), device=DEV, generator=g)
+    sc1, sh1 = torch.rand(cin, device=DEV, generator=g) + 0.5, torch.randn(cin, device=DEV, generator=g) * 0.3
+    sc2, sh2 = torch.rand(cin, device=DEV, generator=g) + 0.5, torch.randn(cin, device=DEV, generator=g) * 0.3
+    act = lambda x, sc, sh: F.leaky_relu(torch.addcmul(sh, x, sc), 0.01)
+    with torch.no_grad(), E._layer_precision(True):
+        out, (part, nblk) = E._conv_t(E._Lazy(x1, sc1, sh1, (D, H, W, cin)), E._Lazy(x2, sc2, sh2, (D, H, W, cin)), (D, H, W, cin), pk.get, cin, cout,
+                                      packed=pk, want_stats=True)
+        ref = F.conv_transpose3d(_bf(act(x1, sc1, sh1) + act(x2, sc2, sh2)).double().permute(3, 0, 1, 2)[None], _bf(conv.weight.detach()).double(),
+                                 stride=2, padding=1, output_padding=1)[0].permute(1, 2, 3, 0)
+    d = (out.double() - ref).abs()
+    scale = float(ref.abs().max())
+    record_err("bf16_tiled_convT_two_lazy", float(d.max()), scale=scale)
+    assert float(d.max()) < 4e-3 * scale and float((d > 1e-5 * scale).double().mean()) < 0.02     # one fma vs two roundings: see the test above
+    s = part.view(2, cout, nblk).double().sum(2)
+    assert float((s[0] - out.double().sum((0, 1, 2))).abs().max()) < 1e-6 * float(out.double().abs().sum((0, 1, 2)).max())
 
 
 def test_use_amp_training_node_runs_every_layer_in_bf16_and_stays_close_to_fp32():
