@@ -38,7 +38,7 @@ COL_BYTES_PER_SAMPLE = 204        # 3 views x 48 B + 12 B + 48 B out
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
 PEAK_16BIT_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16 matrix peak (v_mfma_f32_32x32x16_{bf16,f16})
-PMC_FILE = "profiles/r03_pmc_summary.json"
+PMC_FILE = "profiles/r04_pmc_summary.json"
 
 
 def csrc_sha16():
@@ -665,20 +665,21 @@ def main():
             torch.manual_seed(0)
             system.fit_steps([batch] * 3, opt)
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            losses = system.fit_steps([batch] * 5, opt)
-            torch.cuda.synchronize(); tdt = (time.perf_counter() - t0) / 5
+            losses = system.fit_steps([batch] * 10, opt)
+            torch.cuda.synchronize(); tdt = (time.perf_counter() - t0) / 10
             extras["train_step"] = {"ms": round(tdt * 1e3, 2), "rays_per_s": round(N_RAYS / tdt, 1), "loss_last": round(losses[-1], 5),
-                                    "note": "MVSSystem.training_step fwd+bwd (HIP) + Adam (torch), encoder incl. FeatureNet on HIP, 1024x128, fp32"}
+                                    "note": "MVSSystem.training_step fwd+bwd (HIP) + Adam (torch), encoder incl. FeatureNet on HIP, 1024x128, fp32; 3 warm + 10 timed steps"}
             # (ii-b) the same step with args.use_amp (BASELINE config 3 "bf16"): MLP forward/backward GEMMs on bf16 MFMA
             system.args.use_amp = True
-            system.fit_steps([batch] * 2, opt)
+            system.fit_steps([batch] * 3, opt)
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            losses_b = system.fit_steps([batch] * 5, opt)
-            torch.cuda.synchronize(); bdt_t = (time.perf_counter() - t0) / 5
+            losses_b = system.fit_steps([batch] * 10, opt)
+            torch.cuda.synchronize(); bdt_t = (time.perf_counter() - t0) / 10
             system.args.use_amp = False
             extras["train_step_bf16"] = {"ms": round(bdt_t * 1e3, 2), "rays_per_s": round(N_RAYS / bdt_t, 1), "loss_last": round(losses_b[-1], 5),
-                                         "note": "args.use_amp: ray-march MLP on v_mfma_f32_32x32x16_bf16 (forward with activation store, dgrad, wgrad), fp32 "
-                                                 "accumulation / master weights / gradients; encoder kernels fp32"}
+                                         "note": "args.use_amp (BASELINE config 3 'bf16'): ray-march MLP on v_mfma_f32_32x32x16_bf16 (forward with a 16-bit activation store, dgrad, "
+                                                 "wgrad), conv0 .. conv11 and FeatureNet forward / data gradient / weight gradient on v_mfma_f32_16x16x32_bf16; fp32 accumulation, "
+                                                 "master weights, gradients, InPlaceABN statistics; the plane sweep's arithmetic fp32; 3 warm + 10 timed steps"}
         if not a.no_extras and world == 1:
             import gc
             import math
