@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 4, call 21: volume-gradient scatter with the shared corners of consecutive samples merged in registers
+cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_backward.py tests/test_gpu_train.py tests/test_gpu_raymarch.py -q --tb=short -p no:cacheprovider -x > gpurun_out/c21_tests.log 2>&1; echo "tests rc $?" | tee -a gpurun_out/c21_tests.log
+tail -6 gpurun_out/c21_tests.log
+timeout 300 python scratch/r3/train_prof.py amp 10 2>&1 | grep -v amdgpu.ids | tee gpurun_out/c21_ab.txt
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/c21_prof" -o amp -- python "$GRAFT_REPO_ROOT/scratch/r3/train_prof.py" amp 4 > "$GRAFT_REPO_ROOT/gpurun_out/c21_prof.log" 2>&1; echo "prof rc $?")
+grep "volume_sample" gpurun_out/c21_prof/amp_kernel_stats.csv | cut -c1-200
