@@ -312,7 +312,7 @@ def multi_gpu_legs(dev, rank, world, train_steps=5):
         if not in_sync:
             raise SystemExit(f"rank {rank}: parameters diverged across ranks after {mode}-sharded steps")
         rays = N_RAYS * (world if mode == "scene" else 1)
-        out[f"train_step_dp_{mode}" + ("_bf16" if amp else "")] = {"ms": round(dt / train_steps * 1e3, 2), "arithmetic": "use_amp: MLP and conv0 on bf16 MFMA, fp32 accumulate / master weights / gradients" if amp else "fp32 MFMA", "rays_per_s": round(rays * train_steps / dt, 1), "n_ranks": world,
+        out[f"train_step_dp_{mode}" + ("_bf16" if amp else "")] = {"ms": round(dt / train_steps * 1e3, 2), "arithmetic": "use_amp: MLP, conv0 .. conv11 and FeatureNet on bf16 MFMA, fp32 accumulate / master weights / gradients" if amp else "fp32 MFMA", "rays_per_s": round(rays * train_steps / dt, 1), "n_ranks": world,
                                         "global_rays_per_step": rays, "params_in_sync": in_sync, "loss_last_rank0": round(losses[-1], 5),
                                         "scaling": "strong (same 1024-ray step, encoder replicated)" if mode == "ray" else "weak (one scene + 1024 rays per rank)",
                                         "note": "fit_steps: training_step fwd+bwd (HIP) + one flat fp32 all-reduce of all gradients (RCCL) + Adam"}

@@ -22,10 +22,11 @@ Nothing here has run on more than one GPU (the dev boxes have one): every multi-
 tests, UNMEASURED on hardware.
 
 `args.use_amp` (the reference's `precision=16 if args.use_amp`, train_mvs_nerf_pl.py:317-318; BASELINE config 3 "bf16"): the ray-march MLP
-trains on v_mfma_f32_32x32x16_bf16 - forward with activation store, data- and weight-gradient GEMMs - and conv0 of CostRegNet (74.5 % of
-the encoder's FLOPs) on v_mfma_f32_16x16x32_bf16 from a bf16 cost volume (forward, data and weight gradient: csrc/conv_bf16.hip), with fp32
-accumulation, fp32 master weights and an fp32 gradient all-reduce.  FeatureNet, the plane sweep's arithmetic, InPlaceABN and the other
-nine 3-D layers keep their fp32 kernels.
+trains on v_mfma_f32_32x32x16_bf16 - forward with a 16-bit activation store, data- and weight-gradient GEMMs - and the encoder on
+v_mfma_f32_16x16x32_bf16: conv0 of CostRegNet (74.5 % of the encoder's FLOPs) from a bf16 cost volume (csrc/conv_bf16.hip), conv1 .. conv11 and
+FeatureNet from their fp32 activations rounded on load (csrc/conv3d_bf16.hip, csrc/wgrad_bf16.hip) - forward, data and weight gradients alike -
+with fp32 accumulation, fp32 master weights and an fp32 gradient all-reduce.  The plane sweep's arithmetic and InPlaceABN (statistics,
+normalisation, its backward) stay fp32, as autocast keeps grid_sample and batch norm.
 """
 import os
 
@@ -150,7 +151,7 @@ class MVSSystem(_ModuleShim):
 
         nv = self.n_views
         from . import encoder as _enc
-        with _enc.encoder_precision("bf16" if getattr(args, "use_amp", False) else _enc.ENCODER_PRECISION):   # :317-318 precision=16: conv0 on bf16
+        with _enc.encoder_precision("bf16" if getattr(args, "use_amp", False) else _enc.ENCODER_PRECISION):   # :317-318 precision=16: conv0 .. conv11 and FeatureNet on bf16
             volume_feature, _, _ = self.MVSNet(imgs[:, :nv], proj_mats[:, :nv], near_fars[0, 0], pad=args.pad)      # :113
         imgs = self.unpreprocess(imgs)
         N_rays, N_samples = args.batch_size, args.N_samples
@@ -162,7 +163,7 @@ class MVSSystem(_ModuleShim):
             (rays_pts, rays_dir, target_s, rays_NDC, depth_candidates, rays_depth, rays_o), loss_scale = D.shard_ray_batch(
                 (rays_pts, rays_dir, target_s, rays_NDC, depth_candidates, rays_depth, rays_o), N_rays)     # rays_o is (3, N): sliced in dim 1
         # --use_amp (train_mvs_nerf_pl.py:317-318 `precision=16`): the MLP's forward / backward GEMMs on the bf16 matrix cores with
-        # fp32 accumulation, master weights and gradients; the encoder kernels stay fp32 (module docstring)
+        # fp32 accumulation, master weights and gradients; the encoder runs its bf16 kernels under the context above (encoder.py)
         with ops.mlp_precision("bf16" if getattr(args, "use_amp", False) else ops.MLP_PRECISION):
             rgb, disp, acc, depth_pred, alpha, ret = rendering(args, pose_ref, rays_pts, rays_NDC, depth_candidates, rays_o, rays_dir,
                                                                volume_feature, imgs[:, :-1], img_feat=None, **self.render_kwargs_train)   # :123
