@@ -559,6 +559,14 @@ int mvsnerf_mlp_fwd_split(const void* packed_split, const float* packed_f32, int
                           const float* feat, int feat_stride, const float* dirs, int dirs_stride,
                           int64_t N, int S, int alpha_only, float* raw, void* stream);
 
+/* ---- the optimizer step (train_mvs_nerf_pl.py:84-88: torch.optim.Adam, betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad) ----
+ * One Adam update of n fp32 tensors in ONE launch per 84 tensors (host arrays of device pointers; contiguous tensors; tensors whose size is a multiple of
+ * four must be 16-byte aligned):  m += (1 - beta1)(g - m);  v = beta2 v + (1 - beta2) g^2;  p -= step_size * m / (sqrt(v) / bc2_sqrt + eps)  with
+ * step_size = lr / (1 - beta1^step) and bc2_sqrt = sqrt(1 - beta2^step) computed by the caller.  torch's fused Adam needs three ~25 us launches for
+ * the 78 tensors of the generalizable step; mvsnerf_amd.optim.Adam (a torch.optim.Adam subclass, same state_dict) calls this instead. */
+int mvsnerf_adam_step_multi(int n, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* numel,
+                            double step_size, double beta1, double beta2, double eps, double bc2_sqrt, void* stream);
+
 /* ---- Guarded 16-bit sequences (ABI v10) ----
  * The two-piece fp16 kernels ("fp16x3": the MLP above, conv0 of CostRegNet below) give fp32-grade results at 2-2.5x the fp32-MFMA rate, but an
  * fp16 piece cannot hold more than 65504: a value outside that range saturates.  A GUARDED sequence makes them safe to use by default without a

@@ -153,6 +153,8 @@ SIGNATURES = {
     "mvsnerf_conv3d_wgrad_workspace_floats": (ctypes.c_size_t, [_c_i, _c_i]),
     "mvsnerf_conv3d_wgrad": (_c_i, [_c_fp] * 6 + [_c_i] + [_c_fp] * 6 + [_c_i] * 9 + [_c_fp, _c_fp, _c_fp]),
     "mvsnerf_planesweep_costvar_bwd": (_c_i, [_c_fp, _c_fp, _c_fp] + [_c_i] * 6 + [_c_fp, _c_i, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_adam_step_multi": (_c_i, [_c_i, ctypes.POINTER(_c_fp), ctypes.POINTER(_c_fp), ctypes.POINTER(_c_fp), ctypes.POINTER(_c_fp), ctypes.POINTER(ctypes.c_int64)]
+                                + [ctypes.c_double] * 5 + [_c_fp]),
     "mvsnerf_planesweep_costvar_bwd_det_workspace_words": (ctypes.c_size_t, [_c_i] * 4),
     "mvsnerf_planesweep_costvar_bwd_det": (_c_i, [_c_fp, _c_fp, _c_fp] + [_c_i] * 6 + [_c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_conv2d_pack_weights": (_c_i, [_c_fp] + [_c_i] * 8 + [_c_fp, _c_fp]),

@@ -194,6 +194,50 @@ def test_fused_optimizer_updates_are_seen_by_the_packed_weight_caches():
     assert not torch.equal(p0, p1) and not torch.equal(c0, c1)
 
 
+def test_one_launch_adam_matches_torch_adam_and_keeps_its_interfaces():
+    """mvsnerf_amd.optim.Adam (csrc/adam.hip: the whole step's tensors in one launch) against torch.optim.Adam on the same gradients: parameters and
+    both moments after six steps with a changing learning rate (a scheduler acts on param_groups), odd tensor sizes, a parameter without a gradient;
+    the state_dict loads into torch.optim.Adam and back; the optimizer-step post hook (what the packed-weight caches key on) fires."""
+    from mvsnerf_amd import _lib, models
+    from mvsnerf_amd.optim import Adam
+    from tests.util import record_err
+    g = torch.Generator(DEV).manual_seed(5)
+    shapes = [(128, 63), (128,), (8, 41, 3, 3, 3), (7,), (1,), (33, 5), (64, 64, 27), (3, 1031)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(sh, device=DEV, generator=torch.Generator(DEV).manual_seed(i))) for i, sh in enumerate(shapes)] + \
+                 [torch.nn.Parameter(torch.zeros(5, device=DEV))]                      # never receives a gradient
+    pa, pb = mk(), mk()
+    oa, ob = Adam(pa, lr=5e-4, betas=(0.9, 0.999)), torch.optim.Adam(pb, lr=5e-4, betas=(0.9, 0.999))
+    sa = torch.optim.lr_scheduler.CosineAnnealingLR(oa, T_max=6, eta_min=1e-7)
+    sb = torch.optim.lr_scheduler.CosineAnnealingLR(ob, T_max=6, eta_min=1e-7)
+    e0 = _lib.weights_epoch()
+    for step in range(6):
+        for a, b in zip(pa[:-1], pb[:-1]):
+            gr = torch.randn(a.shape, device=DEV, generator=g) * (10.0 ** (step - 3))       # gradients over six decades
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step(); sa.step(); sb.step()
+    assert _lib.weights_epoch() > e0
+    worst = 0.0
+    for a, b in zip(pa, pb):
+        worst = max(worst, float((a.detach() - b.detach()).abs().max()) / max(float(b.detach().abs().max()), 1e-12))
+        for k in ("exp_avg", "exp_avg_sq"):
+            if b in ob.state:
+                worst = max(worst, float((oa.state[a][k] - ob.state[b][k]).abs().max()) / max(float(ob.state[b][k].abs().max()), 1e-30))
+    record_err("adam_vs_torch_adam", worst, tol=2e-6)
+    assert worst < 2e-6, worst
+    assert torch.equal(pa[-1], torch.zeros(5, device=DEV)) and pa[-1] not in oa.state
+    sd = oa.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 6.0
+    oc = torch.optim.Adam(mk(), lr=1e-3)
+    oc.load_state_dict(sd)                                   # torch's Adam takes the state as it is
+    od = Adam(mk(), lr=1e-3)
+    od.load_state_dict(ob.state_dict())                      # and the other way round
+    assert float(od.state_dict()["state"][0]["step"]) == 6.0
+    # the training systems use it
+    from mvsnerf_amd import train
+    sysm = train.MVSSystem(train.default_args(pad=4, batch_size=64, N_samples=16), n_depth_planes=16).to(DEV)
+    assert isinstance(sysm.configure_optimizers()[0][0], Adam)
+
+
 def test_finetune_five_source_views_bf16():
     """BASELINE config 4 names 5 source views and the bf16 MLP: `args.n_views = 5` (47-channel cost volume, feat_dim 28) through
     MVSSystemFinetune - the reference hard-wires 8 + 3*4 (train_mvs_nerf_finetuning_pl.py:39)."""
