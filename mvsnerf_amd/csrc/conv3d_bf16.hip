@@ -197,21 +197,22 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ActSrc a, ActSrc b, int 
 // (buffer loads, 32-bit offsets, zeros past the end) before the current tile's MFMAs and lands in registers under them.  The weights of all
 // k-steps stay in registers (7 or 14 x 16 bytes per lane).  Same packed weights, same output, same InPlaceABN partial sums (slot = workgroup;
 // the slots the direct-load grid would have had beyond that are written as zeros, so the caller's slot count does not depend on the kernel).
-template <int CIN, int S, int TOZ, int TOY>
+// KZ = 1: FeatureNet's full- and half-resolution 3 x 3 layers (models.py:688-722; the images are z, without halo or stride); Cout = 8 or 16 (one column block).
+template <int CIN, int S, int TOZ, int TOY, int KZ = 3>
 struct TiledCfg {
-    static constexpr int TX = 32, HX = (TX - 1) * S + 3, HY = (TOY - 1) * S + 3, HZ = (TOZ - 1) * S + 3;
+    static constexpr int TX = 32, HX = (TX - 1) * S + 3, HY = (TOY - 1) * S + 3, HZ = KZ == 3 ? (TOZ - 1) * S + 3 : TOZ, SZ = KZ == 3 ? S : 1;
     static constexpr int NVH = HX * HY * HZ, ROWB = CIN * 2, XQ = CIN / 4, NX = (NVH * XQ + 255) / 256;
     static constexpr int LDS_BYTES = ((NVH * ROWB + 63) & ~63) + 64;
-    static constexpr int KS = (27 * CIN + 31) / 32;
+    static constexpr int NTAP = KZ * 9, KS = (NTAP * CIN + 31) / 32;
 };
 
-template <int CIN, int S, int TOZ, int TOY>
+template <int CIN, int S, int TOZ, int TOY, int KZ = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_bf16_tiled_kernel(
-    ActSrc a, int ld, int Di, int Hi, int Wi, const __bf16* __restrict__ wq, float* __restrict__ out, int Do, int Ho, int Wo,
+    ActSrc a, int ld, int Di, int Hi, int Wi, const __bf16* __restrict__ wq, int Cout, float* __restrict__ out, int Do, int Ho, int Wo,
     float* __restrict__ stats, int nslots)
 {
-    using C = TiledCfg<CIN, S, TOZ, TOY>;
-    constexpr int TX = C::TX, HX = C::HX, HY = C::HY, NVH = C::NVH, ROWB = C::ROWB, XQ = C::XQ, NX = C::NX, KS = C::KS, COUT = 16;
+    using C = TiledCfg<CIN, S, TOZ, TOY, KZ>;
+    constexpr int TX = C::TX, HX = C::HX, HY = C::HY, NVH = C::NVH, ROWB = C::ROWB, XQ = C::XQ, NX = C::NX, KS = C::KS, NTAP = C::NTAP, SZ = C::SZ, COUT = 16;
     constexpr int MT_PER_WAVE = TOZ * TOY * 2 / 4;
     static_assert(CIN == 8 || CIN == 16, "the layers with >= 0.5 M output voxels");
     static_assert((TOZ * TOY * 2) % 4 == 0 && NX <= 32, "M-tiles divide among the four waves; one mask bit per prefetched quad");
@@ -229,8 +230,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     for (int ks = 0; ks < KS; ++ks) {
         wreg[ks] = reinterpret_cast<const bf16x8*>(wq)[ks * 64 + lane];
         const int kb = ks * 32 + kg * 8, tap = CIN == 16 ? (kb >> 4) : (kb >> 3), c0 = CIN == 16 ? (kb & 15) : 0;
-        const int t = tap < 27 ? tap : 0;                         // the padding k-values multiply zero weights: any address will do
-        const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+        const int t = tap < NTAP ? tap : 0;                       // the padding k-values multiply zero weights: any address will do
+        const int dz = KZ == 3 ? t / 9 : 0, dy = (t / 3) % 3, dx = t % 3;
         toff[ks] = ((dz * HY + dy) * HX + dx) * ROWB + c0 * 2;
     }
     // this thread's channel quad of every staged item, its activation
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     unsigned mx = 0;
     auto prefetch = [&](int tile) {
         const int bx = tile % nbx, by = (tile / nbx) % nby, bz = tile / (nbx * nby);
-        const int ix0 = bx * TX * S - 1, iy0 = by * TOY * S - 1, iz0 = bz * TOZ * S - 1;
+        const int ix0 = bx * TX * S - 1, iy0 = by * TOY * S - 1, iz0 = KZ == 3 ? bz * TOZ * S - 1 : bz * TOZ;
         mx = 0;
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
@@ -285,19 +286,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
         for (int q = 0; q < MT_PER_WAVE; ++q) {
             const int mt = wave * MT_PER_WAVE + q, xh = mt & 1, row = mt >> 1, oy_l = row % TOY, oz_l = row / TOY;
-            const char* base = xt + ((oz_l * S * HY + oy_l * S) * HX + (xh * 16 + m) * S) * ROWB;
+            const char* base = xt + ((oz_l * SZ * HY + oy_l * S) * HX + (xh * 16 + m) * S) * ROWB;
             f32x4 acc{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(base + toff[ks]), wreg[ks], acc, 0, 0, 0);
             // D: lane (n = lane & 15, g = lane >> 4): acc[r] = voxel 4 g + r of the M-tile, channel n
             const int oz = oz0 + oz_l, oy = oy0 + oy_l;
-            if (oz < Do && oy < Ho) {
-                float* orow = out + (((int64_t)oz * Ho + oy) * Wo) * COUT + m;
+            if (oz < Do && oy < Ho && m < Cout) {
+                float* orow = out + (((int64_t)oz * Ho + oy) * Wo) * Cout + m;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ox = ox0 + xh * 16 + 4 * kg + r;
-                    if (ox < Wo) { const float v = acc[r]; orow[(int64_t)ox * COUT] = v; s_sum += v; q_sum = fmaf(v, v, q_sum); }
+                    if (ox < Wo) { const float v = acc[r]; orow[(int64_t)ox * Cout] = v; s_sum += v; q_sum = fmaf(v, v, q_sum); }
                 }
             }
         }
@@ -307,15 +308,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         s_sum += __shfl_xor(s_sum, 32); q_sum += __shfl_xor(q_sum, 32);
         if (kg == 0) { red[wave][0][m] = s_sum; red[wave][1][m] = q_sum; }
         __syncthreads();
-        if (tid < 2 * COUT) {
-            const int which = tid / COUT, c = tid - which * COUT;
-            stats[abn_part_at(which, c, COUT, blockIdx.x, nslots)] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+        if (tid < 2 * Cout) {
+            const int which = tid / Cout, c = tid - which * Cout;
+            stats[abn_part_at(which, c, Cout, blockIdx.x, nslots)] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
         }
         // the slots this grid does not own
-        for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < (int64_t)(nslots - (int)gridDim.x) * 2 * COUT; i += (int64_t)gridDim.x * 256) {
-            const int64_t slot = gridDim.x + i / (2 * COUT);
-            const int r = (int)(i % (2 * COUT));
-            stats[abn_part_at(r / COUT, r % COUT, COUT, slot, nslots)] = 0.f;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < (int64_t)(nslots - (int)gridDim.x) * 2 * Cout; i += (int64_t)gridDim.x * 256) {
+            const int64_t slot = gridDim.x + i / (2 * Cout);
+            const int r = (int)(i % (2 * Cout));
+            stats[abn_part_at(r / Cout, r % Cout, Cout, slot, nslots)] = 0.f;
         }
     }
 }
@@ -618,8 +619,8 @@ extern "C" int mvsnerf_conv3d_bf16_fwd(const float* x1, const float* scale1, con
     // the LDS-tiled kernel: single-source 8 -> 16 stride 2 / 16 -> 16 stride 1 layers with at least 256 K output voxels, tensors below 2 GB
     if (!x2 && Cout == 16 && !split && (int64_t)Do * Ho * Wo >= (1 << 18) && (int64_t)D * H * W * cin_ld * 4 < (1ll << 31) && (int)grid >= 512 &&
         ((Cin == 16 && stride == 1) || (Cin == 8 && stride == 2))) {
-        if (Cin == 16) conv_bf16_tiled_kernel<16, 1, 2, 4><<<512, 256, TiledCfg<16, 1, 2, 4>::LDS_BYTES, st>>>(a, cin_ld, D, H, W, w, out, Do, Ho, Wo, stats_part, (int)grid);
-        else conv_bf16_tiled_kernel<8, 2, 2, 2><<<512, 256, TiledCfg<8, 2, 2, 2>::LDS_BYTES, st>>>(a, cin_ld, D, H, W, w, out, Do, Ho, Wo, stats_part, (int)grid);
+        if (Cin == 16) conv_bf16_tiled_kernel<16, 1, 2, 4><<<512, 256, TiledCfg<16, 1, 2, 4>::LDS_BYTES, st>>>(a, cin_ld, D, H, W, w, Cout, out, Do, Ho, Wo, stats_part, (int)grid);
+        else conv_bf16_tiled_kernel<8, 2, 2, 2><<<512, 256, TiledCfg<8, 2, 2, 2>::LDS_BYTES, st>>>(a, cin_ld, D, H, W, w, Cout, out, Do, Ho, Wo, stats_part, (int)grid);
         MVS_LAUNCH_CHECK();
         return MVSNERF_OK;
     }
@@ -706,6 +707,14 @@ extern "C" int mvsnerf_conv2d_bf16_fwd(const float* x, const float* scale, const
     const bool split = ksplit_of((int64_t)N * Ho * Wo);
     hipStream_t st = (hipStream_t)stream;
     const __bf16* w = reinterpret_cast<const __bf16*>(wq);
+    // the LDS-tiled kernel: 3 x 3 stride-1 layers with 8 or 16 input channels, one column block, no bias, at least 128 K pixels, tensors below 2 GB
+    if (ksize == 3 && stride == 1 && !bias && (Cin == 8 || Cin == 16) && Cout <= 16 && !split && (int64_t)N * Ho * Wo >= (1 << 17) && (int)grid >= 1024 &&
+        (int64_t)N * H * W * cin_ld * 4 < (1ll << 31)) {
+        if (Cin == 8) conv_bf16_tiled_kernel<8, 1, 1, 16, 1><<<1024, 256, TiledCfg<8, 1, 1, 16, 1>::LDS_BYTES, st>>>(a, cin_ld, N, H, W, w, Cout, out, N, Ho, Wo, stats_part, (int)grid);
+        else conv_bf16_tiled_kernel<16, 1, 1, 8, 1><<<768, 256, TiledCfg<16, 1, 1, 8, 1>::LDS_BYTES, st>>>(a, cin_ld, N, H, W, w, Cout, out, N, Ho, Wo, stats_part, (int)grid);
+        MVS_LAUNCH_CHECK();
+        return MVSNERF_OK;
+    }
 #define MVS_C2(CIN, NT, S, K) do { if (split) conv_bf16_kernel<CIN, NT, S, 4, 1, K><<<grid, 256, 0, st>>>(a, b, cin_ld, N, H, W, w, Cout, out, N, Ho, Wo, stats_part, bias); \
                                    else conv_bf16_kernel<CIN, NT, S, 1, 1, K><<<grid, 256, 0, st>>>(a, b, cin_ld, N, H, W, w, Cout, out, N, Ho, Wo, stats_part, bias); } while (0)
     switch (((Cin * 100 + n_col_blocks(Cout)) * 10 + ksize) * 10 + stride) {

@@ -213,7 +213,9 @@ def test_use_amp_training_node_runs_every_layer_in_bf16_and_stays_close_to_fp32(
 
 # FeatureNet's 2-D layers (models.py:688-722) on the same kernels: (Cin, Cout, k, stride, N, H, W)
 LAYERS_2D = [(3, 8, 3, 1, 2, 20, 36), (8, 8, 3, 1, 3, 17, 23), (8, 16, 5, 2, 3, 24, 40), (16, 16, 3, 1, 2, 13, 21), (16, 32, 5, 2, 2, 22, 30),
-             (32, 32, 3, 1, 2, 9, 14), (16, 16, 3, 1, 3, 128, 160)]
+             (32, 32, 3, 1, 2, 9, 14), (16, 16, 3, 1, 3, 128, 160),
+             # >= 128 K pixels: the LDS-tiled kernel (conv_bf16_tiled_kernel<.., KZ = 1>) forward and data gradient, ragged tiles
+             (8, 8, 3, 1, 2, 301, 450), (16, 16, 3, 1, 3, 261, 340), (16, 16, 3, 1, 3, 256, 320)]
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,N,H,W", LAYERS_2D)
