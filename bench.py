@@ -666,12 +666,19 @@ def main():
             def timed_steps():
                 """3 warm steps, then 3 x 10 timed steps; the best 10-step mean is reported next to all three (a fresh box ramps its clocks for
                 the first hundred launches or so, and a 10-step loop is ~50-85 ms)."""
+                import gc
                 system.fit_steps([batch] * 3, opt)
                 reps, last = [], None
-                for _ in range(3):
-                    torch.cuda.synchronize(); t0 = time.perf_counter()
-                    last = system.fit_steps([batch] * 10, opt)
-                    torch.cuda.synchronize(); reps.append((time.perf_counter() - t0) / 10)
+                gc_on = gc.isenabled()
+                gc.collect(); gc.disable()                 # as in mlp_mode below: a generation-2 collection of this process costs ~0.1 s = 10 ms per step of a 10-step loop
+                try:
+                    for _ in range(3):
+                        torch.cuda.synchronize(); t0 = time.perf_counter()
+                        last = system.fit_steps([batch] * 10, opt)
+                        torch.cuda.synchronize(); reps.append((time.perf_counter() - t0) / 10)
+                finally:
+                    if gc_on:
+                        gc.enable()
                 return min(reps), reps, last
             tdt, t_all, losses = timed_steps()
             extras["train_step"] = {"ms": round(tdt * 1e3, 2), "ms_all_reps": [round(x * 1e3, 2) for x in t_all], "rays_per_s": round(N_RAYS / tdt, 1), "loss_last": round(losses[-1], 5),
