@@ -76,10 +76,18 @@ def _rank_body(rank, world, port, q):
         # ---- tile-parallel frame
         batch = train.batch_to_device(train.synthetic_batch(H, W, seed=7, rot_deg=2.0), dev)
         sysm = _system(dev, "ray")
+        from mvsnerf_amd import ops
+        fb0 = ops.guard_fallbacks()
         rgb, depth = sysm.render_view(batch, batch_rays=256)
+        fb1 = ops.guard_fallbacks()
         with D.single_rank():
             rgb1, depth1 = sysm.render_view(batch, batch_rays=256)
+        fb2 = ops.guard_fallbacks()
         res["frame_equal"] = bool(torch.equal(rgb, rgb1) and torch.equal(depth, depth1))
+        # diagnostics for a mismatch: how far apart, where, and whether a guarded sequence fell back to fp32 in one of the two frames
+        res["frame_max_diff"] = (float((rgb - rgb1).abs().max()), float((depth - depth1).abs().max()))
+        res["frame_diff_pixels"] = int(((rgb - rgb1).abs().amax(-1) > 0).sum())
+        res["guard_fallbacks"] = (fb1 - fb0, fb2 - fb1)
         # ---- ray-sharded DP: same draw on both ranks, each renders its half; all-reduced gradients == 1-rank gradients of the whole batch
         g2 = _grads_of(sysm, batch, 11, True)
         with D.single_rank():
@@ -180,6 +188,10 @@ def test_bench_shared_gpu_dry_run():
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shared-gpu-dry-run"],
                        capture_output=True, text=True, env=env, timeout=900)
+    if p.returncode != 0:                                   # the assertion message is truncated by pytest: keep the whole text where a gpurun call merges it back
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "shared_dry_run_failure.txt"), "w") as f:
+            f.write(p.stdout + "\n==== stderr ====\n" + p.stderr)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
