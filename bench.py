@@ -294,8 +294,9 @@ def multi_gpu_legs(dev, rank, world, train_steps=5, shared_gpu=False):
                           f"{int(torch.isnan(rgb).sum())} / {int(torch.isnan(rgb1).sum())}, differing pixels {int(bad.sum())} of {bad.numel()}, max |d depth| "
                           f"{float(torch.nan_to_num((depth - depth1).abs(), nan=-1.0).max()):.3e}, guard fallbacks so far {ops.guard_fallbacks()}")
     if not same:
-        # with one process per GPU this has never been observed and is fatal; several processes on ONE GPU (the dry run) see about one scene encode in sixty
-        # with 2-4 different cost-volume voxels: the dry run repeats the comparison up to three times and reports every mismatch
+        # with one process per GPU this has never been observed and is fatal; several processes on ONE GPU (the dry run) used to see about one scene encode
+        # in sixty differ (packed fp32 arithmetic of the plane sweep next to the other rank's 16-bit MFMA waves: csrc/planesweep.hip, fixed in round 4);
+        # the dry run still repeats the comparison up to three times and reports every mismatch
         raise SystemExit("tile-parallel frame differs from the single-rank frame: " + " | ".join(mismatches))
     out["frame_tile_parallel"] = {"seconds": round(dt, 4), "rays_per_s_incl_encode": round(H_IMG * W_IMG / dt, 1), "n_ranks": world,
                                   "equals_single_rank_frame": same, "frame_comparisons_repeated": mismatches,

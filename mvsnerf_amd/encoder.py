@@ -1,5 +1,5 @@
 """Scene encoder (L1a) of the reference's models.py on libmvsnerf_hip.so: FeatureNet (2-D CNN, csrc/featnet.hip),
-plane-sweep variance cost volume and CostRegNet (csrc/encoder.hip) - no ATen/MIOpen compute between images and volume.
+plane-sweep variance cost volume (csrc/planesweep.hip) and CostRegNet (csrc/encoder.hip) - no ATen/MIOpen compute between images and volume.
 
 Same class / sub-module / parameter names as the reference (models.py:661-932) so that
 `network_mvs_state_dict` of a reference checkpoint loads unchanged.

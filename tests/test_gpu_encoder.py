@@ -35,7 +35,7 @@ def test_golden_sweep(name, mvs):
     with torch.no_grad():
         warped, grid = U.homo_warp(g["ref_feats"][:, 1], g["proj_mats"][:, 1], g["depth_values"], pad=pad)
         assert grid.shape == c["ref_grid_v1"].shape
-        # homo_warp / the plane sweep follow the CPU reference's fp32 arithmetic operation for operation (encoder.hip): the reference-generated
+        # homo_warp / the plane sweep follow the CPU reference's fp32 arithmetic operation for operation (planesweep.hip): the reference-generated
         # fixtures are reproduced exactly (measured 0.0; equality up to the sign of zero, hence `==` on values rather than on bits)
         assert bool((grid.cpu() == c["ref_grid_v1"]).all()), f"grid {maxabs(grid.cpu(), c['ref_grid_v1'])}"
         assert bool((warped.cpu() == c["ref_warped_v1"]).all()), f"warped {maxabs(warped.cpu(), c['ref_warped_v1'])}"

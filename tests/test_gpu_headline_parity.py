@@ -105,7 +105,7 @@ def test_stage_isolated(scene, mvs):
         e_rgbch, e_var = float(err[:, :9].max()), float(err[:, 9:].max())
         _record("planesweep_rgb_channels_max_abs_err", e_rgbch)
         _record("planesweep_variance_max_abs_err", e_var)
-        # the sweep follows the CPU reference operation for operation (encoder.hip planesweep_kernel): count the values whose BITS differ
+        # the sweep follows the CPU reference operation for operation (planesweep.hip planesweep_kernel): count the values whose BITS differ
         n_bits = int((cost.cpu().view(torch.int32) != s["cost_ref"].view(torch.int32)).masked_fill_(bad.expand_as(err), False).sum())
         _record("planesweep_values_with_different_bits_of_%d" % cost.numel(), n_bits)
         e_var64 = float((cost.cpu()[:, 9:] - s["cvar64"]).abs().masked_fill_(bad.expand(-1, 32, -1, -1, -1), 0).max())
