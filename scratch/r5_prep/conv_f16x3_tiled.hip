@@ -1,0 +1,231 @@
+// PROTOTYPE for round 5 (not part of libmvsnerf_hip.so; built by scratch/r5_prep/build.sh into its own library, driven by scratch/r5_prep/check.py).
+//
+// conv1 (8 -> 16, stride 2, full resolution) and conv2 (16 -> 16, stride 1, half resolution) of CostRegNet (models.py:725-769) with fp32-GRADE results
+// from the fp16 matrix cores, for the no-grad scene encode, where they still run on the round-2 fp32 kernels (0.107 / 0.119 ms of the 1.78 ms encode;
+// their bf16 forms take 0.047 / 0.034 ms): csrc/conv3d_bf16.hip's LDS-tiled kernel (conv_bf16_tiled_kernel: halo activated ONCE on its way into LDS, weights
+// of every k-step in registers, next tile's halo prefetched under the MFMAs) with the two-piece operand split of csrc/conv_f16x3.hip:
+//     x = x0 + x1,  x0 = fp16(x 2^4), x1 = fp16(x 2^4 - x0);   w likewise with 2^8;   x w 2^12 ~= x1 w0 + x0 w1 + x0 w0   (dropped: x1 w1 <= 2^-22 |x w|)
+// three v_mfma_f32_16x16x32_f16 per product, fp32 accumulation, the power-of-two scales taken out of the accumulator exactly.  The scales keep the SECOND
+// pieces of ordinary activations (|x| ~ 1e-3 .. 50 after InPlaceABN) and weights (~1e-2 .. 1) out of fp16's subnormals.  Range: |x| < 4094, |w| < 255; a
+// value beyond sets *guard (the shipped guarded sequences then re-run the layer on the fp32 kernel; not wired here).
+// KZ = 1: FeatureNet's 3 x 3 layers of 8 / 16 channels (images as z), as in the bf16 kernel.
+#include "common.h"
+#include "act.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr float X_SCALE = 16.0f, W_SCALE = 256.0f, OUT_SCALE = 1.0f / (16.0f * 256.0f);
+
+template <int CIN, int S, int TOZ, int TOY, int KZ = 3>
+struct TiledCfgH {
+    static constexpr int TX = 32, HX = (TX - 1) * S + 3, HY = (TOY - 1) * S + 3, HZ = KZ == 3 ? (TOZ - 1) * S + 3 : TOZ, SZ = KZ == 3 ? S : 1;
+    static constexpr int NVH = HX * HY * HZ, ROWB = CIN * 2, XQ = CIN / 4, NX = (NVH * XQ + 255) / 256;
+    static constexpr int PLANE = (NVH * ROWB + 63) & ~63;              // bytes of one piece plane [voxel][CIN] fp16
+    static constexpr int NTAP = KZ * 9, KS = (NTAP * CIN + 31) / 32;
+    static constexpr bool W_IN_REGS = CIN == 8;                      // first weight pieces in registers (7 x 16 B per lane); with 16 channels (14 x 16 B) both pieces
+                                                                     // live in LDS: in registers the kernel needs more than the 256 VGPRs of two waves per SIMD and spills
+    static constexpr int LDS_BYTES = 2 * PLANE + (W_IN_REGS ? 1 : 2) * KS * 1024 + 64;
+};
+
+template <int CIN, int S, int TOZ, int TOY, int KZ = 3>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_f16x3_tiled_kernel(
+    ActSrc a, int ld, int Di, int Hi, int Wi, const _Float16* __restrict__ wq, int Cout, float* __restrict__ out, int Do, int Ho, int Wo,
+    float* __restrict__ stats, int nslots, int* __restrict__ guard)
+{
+    using C = TiledCfgH<CIN, S, TOZ, TOY, KZ>;
+    constexpr int TX = C::TX, HX = C::HX, HY = C::HY, NVH = C::NVH, ROWB = C::ROWB, XQ = C::XQ, NX = C::NX, KS = C::KS, NTAP = C::NTAP, SZ = C::SZ, PLANE = C::PLANE, COUT = 16;
+    constexpr int MT_PER_WAVE = TOZ * TOY * 2 / 4;
+    static_assert(CIN == 8 || CIN == 16, "the layers with >= 0.5 M output voxels");
+    static_assert((TOZ * TOY * 2) % 4 == 0 && NX <= 32, "M-tiles divide among the four waves; one mask bit per prefetched quad");
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    char* xt = lds;                                               // hi plane [NVH][CIN] fp16, lo plane at + PLANE
+    __shared__ float red[4][2][COUT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 15, kg = lane >> 4;
+    const int nbx = (Wo + TX - 1) / TX, nby = (Ho + TOY - 1) / TOY, nbz = (Do + TOZ - 1) / TOZ;
+    const int n_tiles = nbx * nby * nbz, n_ranges = gridDim.x;
+    const int t_begin = (int)((int64_t)n_tiles * blockIdx.x / n_ranges), t_end = (int)((int64_t)n_tiles * (blockIdx.x + 1) / n_ranges);
+    // the weights of every k-step (wq[piece][ks][lane][8]): first pieces in registers, second pieces in LDS (both in registers: 256 VGPRs and spills
+    // at two waves per SIMD); and the LDS offset of this lane's tap in each k-step
+    constexpr bool WR = C::W_IN_REGS;
+    f16x8 w_hi[WR ? KS : 1];
+    f16x8* wl = reinterpret_cast<f16x8*>(lds + 2 * PLANE);          // [ks][lane] second pieces, then (16 channels) [ks][lane] first pieces
+    int toff[KS];
+    for (int i = tid; i < KS * 64; i += 256) {
+        wl[i] = reinterpret_cast<const f16x8*>(wq)[KS * 64 + i];
+        if (!WR) wl[KS * 64 + i] = reinterpret_cast<const f16x8*>(wq)[i];
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (WR) w_hi[ks] = reinterpret_cast<const f16x8*>(wq)[ks * 64 + lane];
+        const int kb = ks * 32 + kg * 8, tap = CIN == 16 ? (kb >> 4) : (kb >> 3), c0 = CIN == 16 ? (kb & 15) : 0;
+        const int t = tap < NTAP ? tap : 0;                       // the padding k-values multiply zero weights: any address will do
+        const int dz = KZ == 3 ? t / 9 : 0, dy = (t / 3) % 3, dx = t % 3;
+        toff[ks] = ((dz * HY + dy) * HX + dx) * ROWB + c0 * 2;
+    }
+    if (guard && blockIdx.x == 0 && tid == 0 && (float)wq[(size_t)2 * KS * 512] != 0.0f) guard[0] = 1;      // status word behind the weights: one was clamped at pack time
+    // this thread's channel quad of every staged item, its activation
+    const int xq = (tid & (XQ - 1)) * 4;
+    f32x4 sc{1.f, 1.f, 1.f, 1.f}, sh{0.f, 0.f, 0.f, 0.f};
+    const bool act_on = a.scale != nullptr;
+    if (act_on) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sc[j] = a.scale[xq + j]; sh[j] = a.shift[xq + j]; }
+    }
+    typedef unsigned u32x4v __attribute__((__vector_size__(16)));
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)((int64_t)Di * Hi * Wi * ld * 4), 0x00020000);
+    f32x4 px[NX];
+    unsigned mx = 0;
+    auto prefetch = [&](int tile) {
+        const int bx = tile % nbx, by = (tile / nbx) % nby, bz = tile / (nbx * nby);
+        const int ix0 = bx * TX * S - 1, iy0 = by * TOY * S - 1, iz0 = KZ == 3 ? bz * TOZ * S - 1 : bz * TOZ;
+        mx = 0;
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int v = (tid + 256 * u) / XQ;
+            const int ix = ix0 + v % HX, iy = iy0 + (v / HX) % HY, iz = iz0 + v / (HX * HY);
+            const bool in = v < NVH && ix >= 0 && ix < Wi && iy >= 0 && iy < Hi && iz >= 0 && iz < Di;
+            const unsigned off = in ? (unsigned)(((iz * Hi + iy) * Wi + ix) * ld + xq) * 4u : 0xffffffffu;
+            px[u] = __builtin_bit_cast(f32x4, (u32x4v)__builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            mx |= (unsigned)in << u;
+        }
+    };
+    float s_sum = 0.f, q_sum = 0.f;                               // InPlaceABN partial sums of channel (lane & 15), rows 4 (lane >> 4) .. + 3 of every M-tile
+    float big = 0.f;                                              // largest |x 2^4| this thread staged
+    if (t_begin < t_end) prefetch(t_begin);
+#pragma unroll 1
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int bx = tile % nbx, by = (tile / nbx) % nby, bz = tile / (nbx * nby);
+        const int ox0 = bx * TX, oy0 = by * TOY, oz0 = bz * TOZ;
+        __syncthreads();                                          // everybody is done with the previous tile
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int it = tid + 256 * u;
+            f32x4 v = px[u];
+            if (act_on && ((mx >> u) & 1)) {                     // the zero padding is padding of the ACTIVATED input
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], sc[j], sh[j]);
+            }
+            f16x4 h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xs = v[j] * X_SCALE;
+                big = fmaxf(big, fabsf(xs));
+                const float c = fminf(fmaxf(xs, -65504.0f), 65504.0f);
+                const _Float16 p0 = (_Float16)c;
+                h[j] = p0; l[j] = (_Float16)(c - (float)p0);
+            }
+            if (it < NVH * XQ) { *reinterpret_cast<f16x4*>(xt + it * 8) = h; *reinterpret_cast<f16x4*>(xt + PLANE + it * 8) = l; }
+        }
+        __syncthreads();
+        if (tile + 1 < t_end) prefetch(tile + 1);
+        const char* base[MT_PER_WAVE];
+        f32x4 acc[MT_PER_WAVE];
+#pragma unroll
+        for (int q = 0; q < MT_PER_WAVE; ++q) {
+            const int mt = wave * MT_PER_WAVE + q, xh = mt & 1, row = mt >> 1, oy_l = row % TOY, oz_l = row / TOY;
+            base[q] = xt + ((oz_l * SZ * HY + oy_l * S) * HX + (xh * 16 + m) * S) * ROWB;
+            acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 w_lo = wl[ks * 64 + lane];
+            const f16x8 w_h = WR ? w_hi[ks] : wl[(KS + ks) * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < MT_PER_WAVE; ++q) {               // the small products first
+                const f16x8 a_hi = *reinterpret_cast<const f16x8*>(base[q] + toff[ks]), a_lo = *reinterpret_cast<const f16x8*>(base[q] + PLANE + toff[ks]);
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, w_h, acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, w_lo, acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, w_h, acc[q], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < MT_PER_WAVE; ++q) {
+            // D: lane (n = lane & 15, g = lane >> 4): acc[r] = voxel 4 g + r of the M-tile, channel n
+            const int mt = wave * MT_PER_WAVE + q, xh = mt & 1, row = mt >> 1, oy_l = row % TOY, oz_l = row / TOY;
+            const int oz = oz0 + oz_l, oy = oy0 + oy_l;
+            if (oz < Do && oy < Ho && m < Cout) {
+                float* orow = out + (((int64_t)oz * Ho + oy) * Wo) * Cout + m;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ox = ox0 + xh * 16 + 4 * kg + r;
+                    if (ox < Wo) { const float v = acc[q][r] * OUT_SCALE; orow[(int64_t)ox * Cout] = v; s_sum += v; q_sum = fmaf(v, v, q_sum); }
+                }
+            }
+        }
+    }
+    if (guard && big > 65504.0f) guard[0] = 1;
+    if (stats) {
+        s_sum += __shfl_xor(s_sum, 16); q_sum += __shfl_xor(q_sum, 16);
+        s_sum += __shfl_xor(s_sum, 32); q_sum += __shfl_xor(q_sum, 32);
+        if (kg == 0) { red[wave][0][m] = s_sum; red[wave][1][m] = q_sum; }
+        __syncthreads();
+        if (tid < 2 * Cout) {
+            const int which = tid / Cout, c = tid - which * Cout;
+            stats[abn_part_at(which, c, Cout, blockIdx.x, nslots)] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+        }
+        for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < (int64_t)(nslots - (int)gridDim.x) * 2 * Cout; i += (int64_t)gridDim.x * 256) {   // the slots this grid does not own
+            const int64_t slot = gridDim.x + i / (2 * Cout);
+            const int r = (int)(i % (2 * Cout));
+            stats[abn_part_at(r / Cout, r % Cout, Cout, slot, nslots)] = 0.f;
+        }
+    }
+}
+
+// nn weight w[Cout][Cin][ntaps] (fp32) -> wq[piece hi | lo][ks][lane][8] fp16 pieces of w * 2^8: the B fragments (k = 32 ks + 8 (lane >> 4) + j = tap * Cin + ci,
+// column lane & 15 = output channel), then 8 status elements ([0] != 0: a weight left fp16's range)
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, int Cin, int Cout, int ntaps, int KS, _Float16* __restrict__ wq)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= KS * 512) return;
+    const int j = i & 7, lane = (i >> 3) & 63, ks = i >> 9;
+    const int kb = ks * 32 + (lane >> 4) * 8 + j, log = Cin == 8 ? 3 : 4, tap = kb >> log, ci = kb & (Cin - 1), co = lane & 15;
+    float v = 0.0f;
+    if (tap < ntaps && co < Cout) v = w[((int64_t)co * Cin + ci) * ntaps + tap] * W_SCALE;
+    if (!(fabsf(v) <= 65504.0f)) wq[(size_t)2 * KS * 512] = (_Float16)1.0f;
+    v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+    const _Float16 hi = (_Float16)v;
+    wq[i] = hi;
+    wq[(size_t)KS * 512 + i] = (_Float16)(v - (float)hi);
+}
+
+}  // namespace
+
+extern "C" size_t r5_conv_f16x3_tiled_packed_elems(int Cin, int ntaps) { return (size_t)2 * ((ntaps * Cin + 31) / 32) * 512 + 8; }
+
+extern "C" int r5_conv_f16x3_tiled_pack(const float* w, int Cin, int Cout, int ntaps, void* wq, void* stream)
+{
+    if (!w || !wq || (Cin != 8 && Cin != 16) || Cout < 1 || Cout > 16 || (ntaps != 27 && ntaps != 9)) return MVSNERF_EINVAL;
+    const int KS = (ntaps * Cin + 31) / 32;
+    hipError_t e = hipMemsetAsync(reinterpret_cast<_Float16*>(wq) + (size_t)2 * KS * 512, 0, 8 * sizeof(_Float16), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    pack_kernel<<<mvs_cdiv((int64_t)KS * 512, 256), 256, 0, (hipStream_t)stream>>>(w, Cin, Cout, ntaps, KS, reinterpret_cast<_Float16*>(wq));
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// x: [D][H][W][cin_ld] fp32 raw + pending InPlaceABN (scale / shift may be null), k3 p1; out [Do][Ho][Wo][Cout] fp32; stats_part: nslots >= grid slots or null
+extern "C" int r5_conv_f16x3_tiled_fwd(const float* x, const float* scale, const float* shift, int Cin, int cin_ld, int D, int H, int W, const void* wq, int Cout,
+                                       int stride, float* out, float* stats_part, int nslots, int* guard, int grid, void* stream)
+{
+    if (!x || !wq || !out || D < 1 || H < 1 || W < 1 || grid < 1) return MVSNERF_EINVAL;
+    if ((int64_t)D * H * W * cin_ld * 4 >= (1ll << 31)) return MVSNERF_EUNSUPPORTED;
+    const ActSrc a{x, scale, shift};
+    const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    hipStream_t st = (hipStream_t)stream;
+    const _Float16* w = reinterpret_cast<const _Float16*>(wq);
+    static unsigned long long cap16 = 0, cap8 = 0;
+    if (Cin == 16 && stride == 1 && Cout <= 16) {
+        using Cfg = TiledCfgH<16, 1, 2, 4>;
+        if (int rc = mvs_raise_lds_cap(reinterpret_cast<const void*>(conv_f16x3_tiled_kernel<16, 1, 2, 4>), Cfg::LDS_BYTES, &cap16)) return rc;
+        conv_f16x3_tiled_kernel<16, 1, 2, 4><<<grid, 256, Cfg::LDS_BYTES, st>>>(a, cin_ld, D, H, W, w, Cout, out, Do, Ho, Wo, stats_part, nslots, guard);
+    } else if (Cin == 8 && stride == 2 && Cout <= 16) {
+        using Cfg = TiledCfgH<8, 2, 2, 2>;
+        if (int rc = mvs_raise_lds_cap(reinterpret_cast<const void*>(conv_f16x3_tiled_kernel<8, 2, 2, 2>), Cfg::LDS_BYTES, &cap8)) return rc;
+        conv_f16x3_tiled_kernel<8, 2, 2, 2><<<grid, 256, Cfg::LDS_BYTES, st>>>(a, cin_ld, D, H, W, w, Cout, out, Do, Ho, Wo, stats_part, nslots, guard);
+    } else return MVSNERF_EUNSUPPORTED;
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
