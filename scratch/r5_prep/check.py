@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 import torch
 import torch.nn.functional as F
 
-L = ctypes.CDLL(os.path.join(ROOT, "scratch", "r5_prep", "libr5.so"))
+L = ctypes.CDLL(os.path.join(ROOT, "scratch", "r5_prep", os.environ.get("R5_LIB", "libr5.so")))
 vp, i32 = ctypes.c_void_p, ctypes.c_int
 L.r5_conv_f16x3_tiled_packed_elems.restype = ctypes.c_size_t
 L.r5_conv_f16x3_tiled_packed_elems.argtypes = [i32, i32]
@@ -67,6 +67,12 @@ def run(Cin, Cout, stride, dims, seed, lazy=True, grid=512, scale_x=1.0):
     return e16, e32
 
 
+if os.environ.get("R5_GRIDS"):                   # timing only: the two encode shapes at several grid sizes
+    for gsz in [int(t) for t in os.environ["R5_GRIDS"].split(",")]:
+        print("grid", gsz)
+        run(16, 16, 1, (64, 88, 104), 3, grid=gsz)
+        run(8, 16, 2, (128, 176, 208), 4, grid=gsz)
+    sys.exit(0)
 run(16, 16, 1, (8, 12, 40), 1)                    # small, ragged against the 2 x 4 x 32 tile
 run(8, 16, 2, (10, 14, 70), 2)
 run(16, 16, 1, (64, 88, 104), 3)                  # conv2 of the config-2 encode

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     const bool act_on = a.scale != nullptr;
     if (act_on) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { sc[j] = a.scale[xq + j]; sh[j] = a.shift[xq + j]; }
+        for (int j = 0; j < 4; ++j) { sc[j] = a.scale[xq + j] * X_SCALE; sh[j] = a.shift[xq + j] * X_SCALE; }
     }
     typedef unsigned u32x4v __attribute__((__vector_size__(16)));
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)((int64_t)Di * Hi * Wi * ld * 4), 0x00020000);
@@ -93,7 +93,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         }
     };
     float s_sum = 0.f, q_sum = 0.f;                               // InPlaceABN partial sums of channel (lane & 15), rows 4 (lane >> 4) .. + 3 of every M-tile
-    float big = 0.f;                                              // largest |x 2^4| this thread staged
     if (t_begin < t_end) prefetch(t_begin);
 #pragma unroll 1
     for (int tile = t_begin; tile < t_end; ++tile) {
@@ -104,18 +103,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         for (int u = 0; u < NX; ++u) {
             const int it = tid + 256 * u;
             f32x4 v = px[u];
-            if (act_on && ((mx >> u) & 1)) {                     // the zero padding is padding of the ACTIVATED input
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], sc[j], sh[j]);
-            }
             f16x4 h, l;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float xs = v[j] * X_SCALE;
-                big = fmaxf(big, fabsf(xs));
-                const float c = fminf(fmaxf(xs, -65504.0f), 65504.0f);
-                const _Float16 p0 = (_Float16)c;
-                h[j] = p0; l[j] = (_Float16)(c - (float)p0);
+                // x 2^4 with the pending activation: leaky(16 y) = 16 leaky(y) and fma(x, 16 sc, 16 sh) = 16 fma(x, sc, sh) exactly, so the scale rides in sc / sh;
+                // leaky(y) = max(y, 0.01 y).  The zero padding is padding of the ACTIVATED input.  No clamp: a value beyond fp16 becomes inf, its second piece
+                // -inf, every output it touches NaN - which the partial sums carry to the guard below (7 operations per value instead of 12).
+                float xs = act_on ? fmaf(v[j], sc[j], sh[j]) : v[j] * X_SCALE;
+                if (act_on) xs = fmaxf(xs, 0.01f * xs);
+                if (!((mx >> u) & 1)) xs = 0.0f;
+                const _Float16 p0 = (_Float16)xs;
+                h[j] = p0; l[j] = (_Float16)(xs - (float)p0);
             }
             if (it < NVH * XQ) { *reinterpret_cast<f16x4*>(xt + it * 8) = h; *reinterpret_cast<f16x4*>(xt + PLANE + it * 8) = l; }
         }
@@ -133,6 +131,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         for (int ks = 0; ks < KS; ++ks) {
             const f16x8 w_lo = wl[ks * 64 + lane];
             const f16x8 w_h = WR ? w_hi[ks] : wl[(KS + ks) * 64 + lane];
+#ifdef R5_PIECE_MAJOR                                             // variant: the three piece products as three passes over the M-tiles (four independent MFMAs between dependent ones)
+            f16x8 a_hi[MT_PER_WAVE], a_lo[MT_PER_WAVE];
+#pragma unroll
+            for (int q = 0; q < MT_PER_WAVE; ++q) { a_hi[q] = *reinterpret_cast<const f16x8*>(base[q] + toff[ks]); a_lo[q] = *reinterpret_cast<const f16x8*>(base[q] + PLANE + toff[ks]); }
+#pragma unroll
+            for (int q = 0; q < MT_PER_WAVE; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[q], w_h, acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < MT_PER_WAVE; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[q], w_lo, acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < MT_PER_WAVE; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[q], w_h, acc[q], 0, 0, 0);
+#else
 #pragma unroll
             for (int q = 0; q < MT_PER_WAVE; ++q) {               // the small products first
                 const f16x8 a_hi = *reinterpret_cast<const f16x8*>(base[q] + toff[ks]), a_lo = *reinterpret_cast<const f16x8*>(base[q] + PLANE + toff[ks]);
@@ -140,6 +149,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
                 acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, w_lo, acc[q], 0, 0, 0);
                 acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, w_h, acc[q], 0, 0, 0);
             }
+#endif
         }
 #pragma unroll
         for (int q = 0; q < MT_PER_WAVE; ++q) {
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             }
         }
     }
-    if (guard && big > 65504.0f) guard[0] = 1;
+    if (guard && !(fabsf(q_sum) <= 3.0e38f)) guard[0] = 1;         // an operand left fp16's range (or the input held a NaN / inf): outputs are NaN there
     if (stats) {
         s_sum += __shfl_xor(s_sum, 16); q_sum += __shfl_xor(q_sum, 16);
         s_sum += __shfl_xor(s_sum, 32); q_sum += __shfl_xor(q_sum, 32);
