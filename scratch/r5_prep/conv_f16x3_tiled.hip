@@ -127,6 +127,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             base[q] = xt + ((oz_l * SZ * HY + oy_l * S) * HX + (xh * 16 + m) * S) * ROWB;
             acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+#ifdef R5_PIPELINED
+        // Software-pipelined MFMA phase: the fragments of k-step ks + 1 are requested (second register set) before the MFMAs of ks, whose three piece products run as three
+        // passes over the M-tiles (independent accumulators next to each other); sched_barrier fences keep the scheduler from sinking the reads back to their uses (sched_group_barrier alone did not).
+        // (What the compiler does on its own - 4 reads, wait, 3 dependent MFMAs per (k-step, M-tile) - costs ~250 cycles per MFMA: NOTES.md.)
+        {
+            f16x8 ah[2][MT_PER_WAVE], al[2][MT_PER_WAVE], wh[2], wlo[2];
+            auto load_k = [&](int ks, int b) {
+                wlo[b] = wl[ks * 64 + lane];
+                wh[b] = WR ? w_hi[WR ? ks : 0] : wl[(KS + ks) * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < MT_PER_WAVE; ++q) {
+                    ah[b][q] = *reinterpret_cast<const f16x8*>(base[q] + toff[ks]);
+                    al[b][q] = *reinterpret_cast<const f16x8*>(base[q] + PLANE + toff[ks]);
+                }
+            };
+            load_k(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int b = ks & 1;
+                if (ks + 1 < KS) load_k(ks + 1, b ^ 1);
+                __builtin_amdgcn_sched_barrier(0);                                       // all reads of the next k-step are issued before the MFMAs of this one ...
+#pragma unroll
+                for (int q = 0; q < MT_PER_WAVE; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[b][q], wh[b], acc[q], 0, 0, 0);     // the small products first
+#pragma unroll
+                for (int q = 0; q < MT_PER_WAVE; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b][q], wlo[b], acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < MT_PER_WAVE; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b][q], wh[b], acc[q], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);                                       // ... and nothing moves across: the reads stay a whole k-step ahead
+            }
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const f16x8 w_lo = wl[ks * 64 + lane];
@@ -151,6 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             }
 #endif
         }
+#endif
 #pragma unroll
         for (int q = 0; q < MT_PER_WAVE; ++q) {
             // D: lane (n = lane & 15, g = lane >> 4): acc[r] = voxel 4 g + r of the M-tile, channel n
