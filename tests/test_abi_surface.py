@@ -51,3 +51,24 @@ def test_product_path_does_not_import_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(root, f)).read()
                 assert "oracle" not in txt.replace("# oracle", ""), f"{f} mentions the oracle"
+
+
+def test_plane_sweep_code_object_has_no_packed_fp32_arithmetic():
+    """csrc/planesweep.hip must be built without packed fp32 instructions: next to 16-bit MFMA waves of another stream or process they computed wrong lanes
+    (tests/test_gpu_costream.py is the GPU side).  The Makefile carries the flag and greps the code object; this compiles the file to ISA with
+    the Makefile's own flags (hipcc cross-compiles without a GPU) and looks again."""
+    csrc = os.path.join(ROOT, "mvsnerf_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    rule = mk[mk.index("build/planesweep.o:"):]
+    assert "-fno-slp-vectorize" in rule.split("\n\n")[0], "the plane sweep's build rule lost -fno-slp-vectorize"
+    flags = re.search(r"^FLAGS\s*=\s*(.*)$", mk, flags=re.M).group(1).replace("$(ARCH)", "gfx950").split()
+    out = os.path.join(csrc, "build", "planesweep_check.s")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    r = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), *flags, "-fno-slp-vectorize", "-S", "--cuda-device-only",
+                        os.path.join(csrc, "planesweep.hip"), "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    isa = open(out).read()
+    os.remove(out)
+    assert "planesweep_kernel" in isa and "planesweep_if_kernel" in isa
+    packed = re.findall(r"\bv_pk_\w+_f32\b", isa)
+    assert not packed, f"{len(packed)} packed fp32 instructions in the plane sweep's code object: {sorted(set(packed))}"
