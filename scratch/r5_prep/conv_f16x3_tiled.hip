@@ -78,6 +78,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)((int64_t)Di * Hi * Wi * ld * 4), 0x00020000);
     f32x4 px[NX];
     unsigned mx = 0;
+#ifdef R5_HOIST
+    // Tile-independent half of the prefetch addressing, once per thread: item u = halo voxel (vx, vy, vz) and its byte offset inside the halo box.  (Inside the tile loop
+    // the divisions by HX / HY and the three 32-bit multiplies per item were ~200 quarter-rate integer instructions per tile and wave: the ablation of NOTES.md.)
+    int loff[NX];
+    unsigned vxyz[NX];                                            // vx | vy << 16 | vz << 24; vx = 0x3fff for the items past the halo (never inside the volume)
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+        const int v = (tid + 256 * u) / XQ;
+        const int vx = v % HX, vy = (v / HX) % HY, vz = v / (HX * HY);
+        loff[u] = (((vz * Hi + vy) * Wi + vx) * ld) * 4;
+        vxyz[u] = v < NVH ? (unsigned)vx | ((unsigned)vy << 16) | ((unsigned)vz << 24) : 0x3fffu;
+    }
+    auto prefetch = [&](int tile) {
+        const int bx = tile % nbx, by = (tile / nbx) % nby, bz = tile / (nbx * nby);
+        const int ix0 = bx * TX * S - 1, iy0 = by * TOY * S - 1, iz0 = KZ == 3 ? bz * TOZ * S - 1 : bz * TOZ;
+        const int base = (((iz0 * Hi + iy0) * Wi + ix0) * ld + xq) * 4;       // may be negative (halo origin -1); base + loff is not for a voxel inside the volume
+        mx = 0;
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const unsigned c = vxyz[u];
+            const bool in = (unsigned)(ix0 + (int)(c & 0xffffu)) < (unsigned)Wi && (unsigned)(iy0 + (int)((c >> 16) & 0xffu)) < (unsigned)Hi && (unsigned)(iz0 + (int)(c >> 24)) < (unsigned)Di;
+            const unsigned off = in ? (unsigned)(base + loff[u]) : 0xffffffffu;
+#ifdef R5_NO_PREFETCH
+            px[u] = f32x4{0.f, 0.f, 0.f, 0.f}; (void)off;
+#else
+            px[u] = __builtin_bit_cast(f32x4, (u32x4v)__builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+#endif
+            mx |= (unsigned)in << u;
+        }
+    };
+#else
     auto prefetch = [&](int tile) {
         const int bx = tile % nbx, by = (tile / nbx) % nby, bz = tile / (nbx * nby);
         const int ix0 = bx * TX * S - 1, iy0 = by * TOY * S - 1, iz0 = KZ == 3 ? bz * TOZ * S - 1 : bz * TOZ;
@@ -88,10 +119,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             const int ix = ix0 + v % HX, iy = iy0 + (v / HX) % HY, iz = iz0 + v / (HX * HY);
             const bool in = v < NVH && ix >= 0 && ix < Wi && iy >= 0 && iy < Hi && iz >= 0 && iz < Di;
             const unsigned off = in ? (unsigned)(((iz * Hi + iy) * Wi + ix) * ld + xq) * 4u : 0xffffffffu;
+#ifdef R5_NO_PREFETCH                                             // phase ablation: no global loads (the staged values are zeros)
+            px[u] = f32x4{0.f, 0.f, 0.f, 0.f}; (void)off;
+#else
             px[u] = __builtin_bit_cast(f32x4, (u32x4v)__builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+#endif
             mx |= (unsigned)in << u;
         }
     };
+#endif
     float s_sum = 0.f, q_sum = 0.f;                               // InPlaceABN partial sums of channel (lane & 15), rows 4 (lane >> 4) .. + 3 of every M-tile
     if (t_begin < t_end) prefetch(t_begin);
 #pragma unroll 1
@@ -99,6 +135,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         const int bx = tile % nbx, by = (tile / nbx) % nby, bz = tile / (nbx * nby);
         const int ox0 = bx * TX, oy0 = by * TOY, oz0 = bz * TOZ;
         __syncthreads();                                          // everybody is done with the previous tile
+#ifndef R5_NO_STAGE                                               // phase ablation: no activation / split / LDS stores
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
             const int it = tid + 256 * u;
@@ -117,6 +154,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             }
             if (it < NVH * XQ) { *reinterpret_cast<f16x4*>(xt + it * 8) = h; *reinterpret_cast<f16x4*>(xt + PLANE + it * 8) = l; }
         }
+#endif
         __syncthreads();
         if (tile + 1 < t_end) prefetch(tile + 1);
         const char* base[MT_PER_WAVE];
@@ -127,7 +165,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             base[q] = xt + ((oz_l * SZ * HY + oy_l * S) * HX + (xh * 16 + m) * S) * ROWB;
             acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-#ifdef R5_PIPELINED
+#ifdef R5_NO_MFMA                                                 // phase ablation: no LDS reads, no MFMAs (zeros are stored)
+#elif defined(R5_PIPELINED)
         // Software-pipelined MFMA phase: the fragments of k-step ks + 1 are requested (second register set) before the MFMAs of ks, whose three piece products run as three
         // passes over the M-tiles (independent accumulators next to each other); sched_barrier fences keep the scheduler from sinking the reads back to their uses (sched_group_barrier alone did not).
         // (What the compiler does on its own - 4 reads, wait, 3 dependent MFMAs per (k-step, M-tile) - costs ~250 cycles per MFMA: NOTES.md.)
