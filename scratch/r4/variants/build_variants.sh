@@ -2,6 +2,9 @@
 # Variant libraries for the shared-GPU probes: the product objects with ONE source swapped for a variant.  usage: build_variants.sh
 set -e
 cd "$(dirname "$0")"
+# encoder_variant.hip is generated (the encoder.hip of the revision before the sweep moved + the variant macros); the variant libraries then hold the OLD sweep
+# twice (this object and the product's planesweep.o) - link against objects of that revision, or use build_sweep_variants.sh for variants of the current sweep
+[ -f encoder_variant.hip ] || python make_encoder_variant.py
 C=../../../mvsnerf_amd/csrc
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-pass-failed -I$C -I../../../include"
 OTHERS=$(ls $C/build/*.o | grep -v encoder.o)
