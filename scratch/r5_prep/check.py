@@ -27,7 +27,7 @@ def run(Cin, Cout, stride, dims, seed, lazy=True, grid=512, scale_x=1.0):
     assert L.r5_conv_f16x3_tiled_pack(w.data_ptr(), Cin, Cout, 27, pk.data_ptr(), st()) == 0
     Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
     out = torch.full((Do, Ho, Wo, Cout), float("nan"), device=dev)
-    nslots = grid + 3
+    nslots = abs(grid) + 3
     part = torch.full((2 * Cout * nslots,), float("nan"), device=dev)
     guard = torch.zeros(4, device=dev, dtype=torch.int32)
     call = lambda: L.r5_conv_f16x3_tiled_fwd(x.data_ptr(), sc.data_ptr() if lazy else None, sh.data_ptr() if lazy else None, Cin, Cin, D, H, W, pk.data_ptr(), Cout,
@@ -68,7 +68,7 @@ def run(Cin, Cout, stride, dims, seed, lazy=True, grid=512, scale_x=1.0):
 
 
 if os.environ.get("R5_GRIDS"):                   # timing only: the two encode shapes at several grid sizes
-    for gsz in [int(t) for t in os.environ["R5_GRIDS"].split(",")]:
+    for gsz in [int(t) for t in os.environ["R5_GRIDS"].split(",")]:          # a negative size selects the 16-wide tiles
         print("grid", gsz)
         run(16, 16, 1, (64, 88, 104), 3, grid=gsz)
         run(8, 16, 2, (128, 176, 208), 4, grid=gsz)

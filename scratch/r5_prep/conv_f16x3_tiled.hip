@@ -19,9 +19,9 @@ namespace {
 
 constexpr float X_SCALE = 16.0f, W_SCALE = 256.0f, OUT_SCALE = 1.0f / (16.0f * 256.0f);
 
-template <int CIN, int S, int TOZ, int TOY, int KZ = 3>
+template <int CIN, int S, int TOZ, int TOY, int KZ = 3, int TXP = 32>
 struct TiledCfgH {
-    static constexpr int TX = 32, HX = (TX - 1) * S + 3, HY = (TOY - 1) * S + 3, HZ = KZ == 3 ? (TOZ - 1) * S + 3 : TOZ, SZ = KZ == 3 ? S : 1;
+    static constexpr int TX = TXP, HX = (TX - 1) * S + 3, HY = (TOY - 1) * S + 3, HZ = KZ == 3 ? (TOZ - 1) * S + 3 : TOZ, SZ = KZ == 3 ? S : 1;
     static constexpr int NVH = HX * HY * HZ, ROWB = CIN * 2, XQ = CIN / 4, NX = (NVH * XQ + 255) / 256;
     static constexpr int PLANE = (NVH * ROWB + 63) & ~63;              // bytes of one piece plane [voxel][CIN] fp16
     static constexpr int NTAP = KZ * 9, KS = (NTAP * CIN + 31) / 32;
@@ -30,16 +30,17 @@ struct TiledCfgH {
     static constexpr int LDS_BYTES = 2 * PLANE + (W_IN_REGS ? 1 : 2) * KS * 1024 + 64;
 };
 
-template <int CIN, int S, int TOZ, int TOY, int KZ = 3>
+template <int CIN, int S, int TOZ, int TOY, int KZ = 3, int TXP = 32>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_f16x3_tiled_kernel(
     ActSrc a, int ld, int Di, int Hi, int Wi, const _Float16* __restrict__ wq, int Cout, float* __restrict__ out, int Do, int Ho, int Wo,
     float* __restrict__ stats, int nslots, int* __restrict__ guard)
 {
-    using C = TiledCfgH<CIN, S, TOZ, TOY, KZ>;
+    using C = TiledCfgH<CIN, S, TOZ, TOY, KZ, TXP>;
     constexpr int TX = C::TX, HX = C::HX, HY = C::HY, NVH = C::NVH, ROWB = C::ROWB, XQ = C::XQ, NX = C::NX, KS = C::KS, NTAP = C::NTAP, SZ = C::SZ, PLANE = C::PLANE, COUT = 16;
-    constexpr int MT_PER_WAVE = TOZ * TOY * 2 / 4;
+    constexpr int XT = TX / 16;                                   // M-tiles (16 voxels along x) per tile row: 2, or 1 for the 16-wide tiles (rows of 104 voxels: 93 % instead of 81 % used)
+    constexpr int MT_PER_WAVE = TOZ * TOY * XT / 4;
     static_assert(CIN == 8 || CIN == 16, "the layers with >= 0.5 M output voxels");
-    static_assert((TOZ * TOY * 2) % 4 == 0 && NX <= 32, "M-tiles divide among the four waves; one mask bit per prefetched quad");
+    static_assert((TX == 16 || TX == 32) && (TOZ * TOY * XT) % 4 == 0 && NX <= 32, "M-tiles divide among the four waves; one mask bit per prefetched quad");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     char* xt = lds;                                               // hi plane [NVH][CIN] fp16, lo plane at + PLANE
     __shared__ float red[4][2][COUT];
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         f32x4 acc[MT_PER_WAVE];
 #pragma unroll
         for (int q = 0; q < MT_PER_WAVE; ++q) {
-            const int mt = wave * MT_PER_WAVE + q, xh = mt & 1, row = mt >> 1, oy_l = row % TOY, oz_l = row / TOY;
+            const int mt = wave * MT_PER_WAVE + q, xh = mt % XT, row = mt / XT, oy_l = row % TOY, oz_l = row / TOY;
             base[q] = xt + ((oz_l * SZ * HY + oy_l * S) * HX + (xh * 16 + m) * S) * ROWB;
             acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
         for (int q = 0; q < MT_PER_WAVE; ++q) {
             // D: lane (n = lane & 15, g = lane >> 4): acc[r] = voxel 4 g + r of the M-tile, channel n
-            const int mt = wave * MT_PER_WAVE + q, xh = mt & 1, row = mt >> 1, oy_l = row % TOY, oz_l = row / TOY;
+            const int mt = wave * MT_PER_WAVE + q, xh = mt % XT, row = mt / XT, oy_l = row % TOY, oz_l = row / TOY;
             const int oz = oz0 + oz_l, oy = oy0 + oy_l;
             if (oz < Do && oy < Ho && m < Cout) {
                 float* orow = out + (((int64_t)oz * Ho + oy) * Wo) * Cout + m;
@@ -291,14 +292,25 @@ extern "C" int r5_conv_f16x3_tiled_pack(const float* w, int Cin, int Cout, int n
 extern "C" int r5_conv_f16x3_tiled_fwd(const float* x, const float* scale, const float* shift, int Cin, int cin_ld, int D, int H, int W, const void* wq, int Cout,
                                        int stride, float* out, float* stats_part, int nslots, int* guard, int grid, void* stream)
 {
-    if (!x || !wq || !out || D < 1 || H < 1 || W < 1 || grid < 1) return MVSNERF_EINVAL;
+    const bool narrow = grid < 0;                                 // grid < 0: the 16-wide tiles (16 x 8 x 2 / 16 x 4 x 2 outputs), |grid| workgroups
+    if (narrow) grid = -grid;
+    if (!x || !wq || !out || D < 1 || H < 1 || W < 1 || grid == 0) return MVSNERF_EINVAL;
     if ((int64_t)D * H * W * cin_ld * 4 >= (1ll << 31)) return MVSNERF_EUNSUPPORTED;
     const ActSrc a{x, scale, shift};
     const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     hipStream_t st = (hipStream_t)stream;
     const _Float16* w = reinterpret_cast<const _Float16*>(wq);
     static unsigned long long cap16 = 0, cap8 = 0;
-    if (Cin == 16 && stride == 1 && Cout <= 16) {
+    static unsigned long long cap16n = 0, cap8n = 0;
+    if (narrow && Cin == 16 && stride == 1 && Cout <= 16) {
+        using Cfg = TiledCfgH<16, 1, 2, 8, 3, 16>;
+        if (int rc = mvs_raise_lds_cap(reinterpret_cast<const void*>(conv_f16x3_tiled_kernel<16, 1, 2, 8, 3, 16>), Cfg::LDS_BYTES, &cap16n)) return rc;
+        conv_f16x3_tiled_kernel<16, 1, 2, 8, 3, 16><<<grid, 256, Cfg::LDS_BYTES, st>>>(a, cin_ld, D, H, W, w, Cout, out, Do, Ho, Wo, stats_part, nslots, guard);
+    } else if (narrow && Cin == 8 && stride == 2 && Cout <= 16) {
+        using Cfg = TiledCfgH<8, 2, 2, 4, 3, 16>;
+        if (int rc = mvs_raise_lds_cap(reinterpret_cast<const void*>(conv_f16x3_tiled_kernel<8, 2, 2, 4, 3, 16>), Cfg::LDS_BYTES, &cap8n)) return rc;
+        conv_f16x3_tiled_kernel<8, 2, 2, 4, 3, 16><<<grid, 256, Cfg::LDS_BYTES, st>>>(a, cin_ld, D, H, W, w, Cout, out, Do, Ho, Wo, stats_part, nslots, guard);
+    } else if (Cin == 16 && stride == 1 && Cout <= 16) {
         using Cfg = TiledCfgH<16, 1, 2, 4>;
         if (int rc = mvs_raise_lds_cap(reinterpret_cast<const void*>(conv_f16x3_tiled_kernel<16, 1, 2, 4>), Cfg::LDS_BYTES, &cap16)) return rc;
         conv_f16x3_tiled_kernel<16, 1, 2, 4><<<grid, 256, Cfg::LDS_BYTES, st>>>(a, cin_ld, D, H, W, w, Cout, out, Do, Ho, Wo, stats_part, nslots, guard);
