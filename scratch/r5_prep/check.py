@@ -79,3 +79,8 @@ run(16, 16, 1, (64, 88, 104), 3)                  # conv2 of the config-2 encode
 run(8, 16, 2, (128, 176, 208), 4)                 # conv1
 run(16, 8, 1, (64, 88, 104), 5, lazy=False)       # 8 output channels (half of the columns idle), no pending activation
 run(16, 16, 1, (16, 24, 64), 6, scale_x=5000.0)   # |x 2^4| beyond fp16: the guard must trip
+# the 16-wide tiles (negative grid): correctness at ragged and full shapes, then their time
+run(16, 16, 1, (8, 12, 40), 1, grid=-64)
+run(8, 16, 2, (10, 14, 70), 2, grid=-64)
+run(16, 16, 1, (64, 88, 104), 3, grid=-512)
+run(8, 16, 2, (128, 176, 208), 4, grid=-512)
