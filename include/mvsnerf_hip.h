@@ -575,6 +575,10 @@ int mvsnerf_adam_step_multi(int n, float* const* p, const float* const* g, float
  * stage are enqueued right behind them PREDICATED on guard[0] (they leave at once when it is 0, and overwrite the results when it is set); the
  * last kernel of the sequence counts the event in guard[1] and re-arms guard[0] = 0.  The caller reads results that are the fp32 kernels'
  * whenever the 16-bit ones were out of range, and may read guard[1] (number of sequences that fell back) whenever it synchronises anyway.
+ * ONE GUARD BUFFER PER STREAM: guard[0] is armed, read and re-armed in stream order only (guard[1] += 1 is a plain store of the last kernel), so
+ * sequences enqueued on different streams - or by different host threads - must be given different buffers; sharing one lets stream B re-arm the
+ * word between stream A's 16-bit kernel setting it and A's predicated fp32 kernel reading it.  mvsnerf_amd.ops.guard_words() keeps one buffer per
+ * (device, stream) for that reason.
  *   - mvsnerf_raymarch_fwd / mvsnerf_render_pixels_fwd: args.guard with n_split = MVSNERF_SPLIT_FP16 (gather -> fp16x3 MLP -> predicated fp32-MFMA
  *     MLP -> compositing, which also re-arms the guard);
  *   - mvsnerf_mlp_fwd_guarded: the stand-alone network query (run_network_mvs, renderer.py:42-63; alpha_only = forward_alpha);

@@ -1,6 +1,7 @@
 """Python faces of the C-ABI entry points (include/mvsnerf_hip.h).  Tensors in, tensors out;
 all arithmetic happens in libmvsnerf_hip.so.  No fallbacks."""
 import ctypes
+import weakref
 
 import torch
 
@@ -55,10 +56,13 @@ def channels_last_volume(volume_feature):
     depth-fastest vol[y][x][d][c] our MVSNet emits; otherwise one HIP transpose to vol[d][y][x][c], cached on (storage, version)."""
     v = volume_feature
     hit = _cl_cache.get("last")          # the same tensor object, unmodified, as in the previous call (a render loop): ~0.3 us instead of ~6
-    if hit is not None and hit[0] is v and hit[1] == (v._version, _lib.weights_epoch()):
+    if hit is not None and hit[0]() is v and hit[1] == (v._version, _lib.weights_epoch()):
         return hit[2]
     out = _channels_last_volume(v)
-    _cl_cache["last"] = (v, (v._version, _lib.weights_epoch()), out)
+    # a WEAK reference to the tensor object: an encoder output still carries its grad_fn, and a module-level strong reference would keep the whole
+    # encoder graph (its saved activations, GB-scale at config 2/3) alive until the next call.  `out` (a no-grad view or a transposed copy) keeps
+    # only the volume's own storage; RayMarchFunction.backward drops the entry.
+    _cl_cache["last"] = (weakref.ref(v), (v._version, _lib.weights_epoch()), out.detach())
     return out
 
 
@@ -364,21 +368,30 @@ _guards = {}
 
 
 def guard_words(device=None):
-    """The guard words of this device's guarded 16-bit sequences: int32[4] = {tripped (re-armed by every sequence), sequences that fell back
-    to the fp32 kernels so far, 0, 0}; allocated once per device, owned here (the library allocates nothing)."""
+    """The guard words of the guarded 16-bit sequences enqueued on (this device, the CURRENT stream): int32[4] = {tripped (re-armed by every
+    sequence), sequences that fell back to the fp32 kernels so far, 0, 0}.  One buffer per (device, stream), allocated once and owned here (the
+    library allocates nothing): a sequence arms, reads and re-arms word 0 in STREAM order only, so two streams (or two host threads on their own
+    streams) must never share a buffer - stream B's consume kernel could re-arm the word between stream A's fp16 kernel tripping it and A's
+    predicated fp32 kernel reading it (include/mvsnerf_hip.h, "guarded 16-bit sequences": one guard buffer per stream)."""
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
     if idx is None:
         idx = torch.cuda.current_device()
-    g = _guards.get(idx)
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    g = _guards.get(key)
     if g is None:
-        g = _guards[idx] = torch.zeros(4, device=torch.device("cuda", idx), dtype=torch.int32)
+        with torch.cuda.device(idx):
+            g = _guards[key] = torch.zeros(4, device=torch.device("cuda", idx), dtype=torch.int32)
     return g
 
 
 def guard_fallbacks(device=None):
-    """Number of guarded sequences (ray-march batches, network queries, scene encodes) whose fp32 kernels had to take over because a value
-    left fp16's range.  Reading it synchronises - it is for tests and reports, the hot path never looks at it."""
-    return int(guard_words(device)[1].item())
+    """Number of guarded sequences (ray-march batches, network queries, scene encodes) on this device - all streams - whose fp32 kernels had to
+    take over because a value left fp16's range.  Reading it synchronises - it is for tests and reports, the hot path never looks at it."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    torch.cuda.synchronize(idx)
+    return sum(int(g[1].item()) for (d, _), g in list(_guards.items()) if d == idx)
 
 
 def mlp_pack_split(weights, F, n_split):
@@ -651,6 +664,7 @@ class RayMarchFunction(torch.autograd.Function):
         """The weight re-pack for the transposed products + ONE FFI call (mvsnerf_raymarch_bwd): compositing backward -> MLP data and
         weight gradients -> trilinear scatter into the volume gradient."""
         lib = _lib.lib()
+        _cl_cache.pop("last", None)              # do not keep the step's volume storage past its backward (channels_last_volume)
         rays_ndc, z_vals, raw, saved, packed, *mlp_params = ctx.saved_tensors
         vshape, (D, H, W, C), N, S, F, white, bf16, dp_samples = ctx.meta
         dev = raw.device

@@ -50,3 +50,72 @@ def test_plane_sweep_next_to_16bit_mfma_waves_of_a_second_stream(blocked):
         bad = int(torch.stack(flags).sum())
         torch.cuda.synchronize()
     assert bad == 0, f"{bad} of {n_iter} plane sweeps differ from the quiet result while 16-bit MFMA waves of a second stream share the GPU"
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_training_step_gradients_next_to_16bit_mfma_waves_of_a_second_stream(amp):
+    """VERDICT r4 1(e) / ADVICE r4: the TRAINING kernels (plane-sweep backward, conv / MLP data and weight gradients, InPlaceABN backward,
+    compositing backward, trilinear scatter) next to the same aggressor.  Their floating-point atomics make two runs differ in the last
+    bits even on a quiet GPU, so the comparison is not bit for bit: every gradient of a step taken while the fp16x3 conv0 runs on a second
+    stream against the same step on a quiet GPU, at 1e-6 of the tensor's maximum (+ the quiet run-to-run spread, measured here), with the
+    plane sweep's DETERMINISTIC backward (64-bit fixed-point accumulators) so that the sweep's gradient itself is comparable bit for bit.
+    A wrong-lanes event of the kind the forward sweep had (lanes 48..63 of one accumulator) is ~1e-1 of a tensor's maximum."""
+    from mvsnerf_amd import _lib, train, ops
+    from mvsnerf_amd import encoder as E
+    from mvsnerf_amd.ops import stream_ptr
+    from tests.test_gpu_bf16_encoder import _sweep_inputs
+    from tests.test_gpu_train import _system
+    from tests.util import record_err
+    L = _lib.lib()
+    # the aggressor of the test above: fp16x3 conv0 at config-2 size on a side stream (9 k workgroups of 16-bit MFMA waves, ~0.45 ms each)
+    V, H, W, D, pad = 3, 128, 160, 128, 24
+    imgs, feats, proj, dv = _sweep_inputs(V, H, W, D, pad, seed=5)
+    cin = 3 * V + 32
+    with torch.no_grad():
+        c16 = E._plane_sweep(imgs, feats, proj, dv, pad, True, blocked="fp16x2")[0]
+        Dp, Hp, Wp = c16.dims
+        w = torch.randn((8, cin, 3, 3, 3), device=DEV, generator=torch.Generator(DEV).manual_seed(1)) * 0.1
+        pk = torch.empty(L.mvsnerf_conv0_f16x3_packed_elems(cin), device=DEV, dtype=torch.float16)
+        assert L.mvsnerf_conv0_f16x3_pack(w.data_ptr(), cin, pk.data_ptr(), stream_ptr()) == 0
+        raw = torch.empty((Dp, Hp, Wp, 8), device=DEV)
+    # the victim: one training step (BASELINE config 3's code path) at a size whose kernels take ~2 ms
+    sys_, args, _, _ = _system(8, 512, 64, 32)
+    args.use_amp = amp
+    batch = train.synthetic_batch(128, 160, seed=3, rot_deg=2.0, smooth=True)
+    params = [(n, p) for n, p in list(sys_.render_kwargs_train["network_fn"].named_parameters()) + list(sys_.MVSNet.named_parameters())]
+
+    def grads(aggress):
+        for _, p in params:
+            p.grad = None
+        torch.manual_seed(11)
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        if aggress:
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(aggress):
+                    assert L.mvsnerf_conv0_f16x3_fwd(c16.buf.data_ptr(), cin, Dp, Hp, Wp, pk.data_ptr(), raw.data_ptr(), 0, stream_ptr()) == 0
+        out = sys_.training_step(batch, 0)          # args.use_amp selects the bf16 kernels inside (train_mvs_nerf_pl.py:317-318)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        return float(out["loss"].detach()), {n: p.grad.detach().clone() for n, p in params}
+
+    prev = E.PSW_BWD_DETERMINISTIC
+    E.PSW_BWD_DETERMINISTIC = True
+    try:
+        l0, g0 = grads(0)
+        l1, g1 = grads(0)                       # quiet run-to-run spread (floating-point atomics)
+        spread = {n: float((g0[n] - g1[n]).abs().max()) / max(float(g0[n].abs().max()), 1e-30) for n in g0}
+        worst, worst_name = 0.0, None
+        for it in range(6):
+            l2, g2 = grads(12)                  # ~5 ms of 16-bit MFMA waves covering the step
+            assert abs(l2 - l0) <= 1e-6 * max(1.0, abs(l0)), (l2, l0)
+            for n in g0:
+                e = float((g0[n] - g2[n]).abs().max()) / max(float(g0[n].abs().max()), 1e-30)
+                if e - 2 * spread[n] > worst:
+                    worst, worst_name = e - 2 * spread[n], n
+    finally:
+        E.PSW_BWD_DETERMINISTIC = prev
+    record_err(f"costream_training_gradients_amp{int(amp)}:worst_rel_beyond_quiet_spread", worst, tol=1e-6)
+    print(f"co-stream training step (use_amp={amp}): worst gradient deviation beyond twice the quiet spread {worst:.2e} ({worst_name}); "
+          f"largest quiet spread {max(spread.values()):.2e}")
+    assert worst < 1e-6, (worst, worst_name)

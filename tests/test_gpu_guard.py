@@ -216,3 +216,43 @@ def test_rendering_batched_equals_per_batch_rendering(net20):
         for a, b in zip(one, many):
             for x, y in zip(a[:5], b[:5]):
                 assert torch.equal(x, y)
+
+
+def test_two_streams_do_not_share_a_guard_buffer(net20):
+    """guard[0] is armed / read / re-armed in stream order only, so two streams need two buffers (ops.guard_words() is keyed on
+    (device, stream)).  Stream A queries an out-of-range network, stream B an in-range one, enqueued alternately so their kernels overlap: every
+    A result must be the fp32 kernel's bits (never a saturated fp16 one), every B result the fp16x3 kernel's, and the fallbacks are counted
+    per sequence."""
+    from mvsnerf_amd import ops
+    big = copy.deepcopy(net20)
+    with torch.no_grad():
+        big.nerf.pts_linears[1].weight.mul_(3e4)
+    big.invalidate_packed()
+    ba, bb = _batch(n_rays=512, n_samples=64, seed=7), _batch(n_rays=512, n_samples=64, seed=8)
+    want_a, _ = _query(big, "fp32", *ba)
+    want_b, _ = _query(net20, "fp16x3", *bb)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(sa):
+        ga = ops.guard_words()
+    with torch.cuda.stream(sb):
+        gb = ops.guard_words()
+    assert ga.data_ptr() != gb.data_ptr() and ga.data_ptr() != ops.guard_words().data_ptr()
+    before = ops.guard_fallbacks()
+    outs_a, outs_b = [], []
+    rounds = 12
+    with ops.mlp_precision("auto"), torch.no_grad():
+        big.nerf.packed_split(20, ops.N_SPLIT["fp16x3"]), net20.nerf.packed_split(20, ops.N_SPLIT["fp16x3"])      # pack on the default stream first
+        torch.cuda.synchronize()
+        for _ in range(rounds):
+            with torch.cuda.stream(sa):
+                outs_a.append(big.nerf.query(ba[0], ba[1], ba[2], 512, 64))
+            with torch.cuda.stream(sb):
+                outs_b.append(net20.nerf.query(bb[0], bb[1], bb[2], 512, 64))
+    torch.cuda.synchronize()
+    assert ops.guard_fallbacks() == before + rounds
+    assert int(ga[1].item()) >= rounds and int(ga[0].item()) == 0 and int(gb[0].item()) == 0
+    for o in outs_a:
+        assert torch.equal(o, want_a)
+    for o in outs_b:
+        assert torch.equal(o, want_b)

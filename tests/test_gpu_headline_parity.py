@@ -124,10 +124,21 @@ def test_stage_isolated(scene, mvs):
     assert e_vol < TOL_VOL_ISOLATED
 
 
-def test_chained_images_to_rgb(scene, mvs):
-    """images -> FeatureNet -> plane sweep -> CostRegNet -> 1024x128 ray march, all on the HIP path, vs. all on the oracle."""
+@pytest.mark.parametrize("mode", ["fp32", "auto"])
+def test_chained_images_to_rgb(scene, mvs, mode):
+    """images -> FeatureNet -> plane sweep -> CostRegNet -> 1024x128 ray march, all on the HIP path, vs. all on the oracle.
+    mode "fp32": fp32-MFMA conv0 + mlp_fwd_pipe_kernel (the arithmetic of bench.py's headline line); "auto": the library default of
+    no-grad work (guarded fp16x3 conv0 and MLP).  Both own the same bounds; records are keyed "<mode>:<name>"."""
+    from mvsnerf_amd import models, renderer as R, ops, encoder
+    import types
+    with ops.mlp_precision(mode), encoder.encoder_precision(mode):
+        _chained(scene, mvs, mode)
+
+
+def _chained(scene, mvs, mode):
     from mvsnerf_amd import models, renderer as R
     import types
+    _record = lambda k, v: globals()["_record"](f"{mode}:{k}", v)
     s = scene
     pts, dirs, ndc, z, ro = s["rays"]
     ref = s["ref"]

@@ -102,6 +102,17 @@ def _rank_body(rank, world, port, q):
         with D.single_rank():
             g1 = _grads_of(sysm, batch, 11, False)
         res["ray_grad_err"] = _worst(g2, g1)
+        # ---- the same under args.use_amp = BASELINE config 3 as worded ("bf16, ray-sharded DP"): MLP, conv0 .. conv11 and FeatureNet on the bf16 matrix
+        # cores; every rank rounds the same operands the same way, so N-rank == 1-rank holds to the fp32 summation-order tolerance here too
+        sysm.args.use_amp = True
+        try:
+            g2b = _grads_of(sysm, batch, 11, True)
+            with D.single_rank():
+                g1b = _grads_of(sysm, batch, 11, False)
+        finally:
+            sysm.args.use_amp = False
+        res["ray_amp_grad_err"] = _worst(g2b, g1b)
+        res["ray_amp_differs_from_fp32"] = _worst(g1b, g1) > 1e-4         # the bf16 kernels really ran
         # ---- scene-sharded DP: rank r renders scene r with its own draw; all-reduced gradients == mean of the two 1-rank gradients
         scenes = [train.batch_to_device(train.synthetic_batch(H, W, seed=20 + j, rot_deg=2.0), dev) for j in range(world)]
         sm = _system(dev, "scene")
@@ -185,7 +196,8 @@ def test_two_ranks_on_one_gpu():
         if len(r["frame_attempts"]) > 1:
             print(f"rank {rank}: NOTE - {len(r['frame_attempts']) - 1} frame comparison(s) had to be repeated: {r['frame_attempts'][:-1]}")
             record_err(f"shared_gpu:frame_retries:rank{rank}", float(len(r["frame_attempts"]) - 1), tol=2.0)
-        for k in ("ray_grad_err", "scene_grad_err", "finetune_grad_err"):
+        assert r["ray_amp_differs_from_fp32"], "use_amp gradients equal the fp32 ones: the bf16 kernels did not run"
+        for k in ("ray_grad_err", "ray_amp_grad_err", "scene_grad_err", "finetune_grad_err"):
             record_err(f"shared_gpu:{k}:rank{rank}", r[k], tol=GRAD_TOL)
             assert r[k] < GRAD_TOL, f"rank {rank}: {k} = {r[k]}"
         assert r["ray_in_sync"] and r["scene_in_sync"], f"rank {rank}: parameters diverged"
@@ -212,5 +224,6 @@ def test_bench_shared_gpu_dry_run():
     m = d["multi_gpu"]
     assert m["world_size"] == 2 and m["measured_on_hardware"] is False
     assert m["frame_tile_parallel"]["equals_single_rank_frame"] is True
+    assert m["frame_tile_parallel_config5"]["equals_single_rank_frame"] is True and m["frame_tile_parallel_config5"]["n_ranks"] == 2
     for k in ("train_step_dp_scene", "train_step_dp_scene_bf16", "train_step_dp_ray", "train_step_dp_ray_bf16"):
         assert m[k]["params_in_sync"] is True and m[k]["n_ranks"] == 2

@@ -238,6 +238,54 @@ def test_one_launch_adam_matches_torch_adam_and_keeps_its_interfaces():
     assert isinstance(sysm.configure_optimizers()[0][0], Adam)
 
 
+def test_one_launch_adam_with_intermittent_gradients_and_mixed_step_counts():
+    """a parameter that receives a gradient only now and then (zero_grad(set_to_none=True) is the default) takes fewer steps than its
+    group; torch.optim.Adam keeps a step count per parameter, and so must the one-launch form (buckets by count, one launch per bucket).  Also a
+    loaded torch.optim.Adam state whose parameters have different counts."""
+    from mvsnerf_amd.optim import Adam
+    from tests.util import record_err
+    shapes = [(64, 20), (64,), (5, 7, 3), (129,)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(sh, device=DEV, generator=torch.Generator(DEV).manual_seed(i))) for i, sh in enumerate(shapes)]
+    pa, pb = mk(), mk()
+    oa, ob = Adam(pa, lr=1e-3), torch.optim.Adam(pb, lr=1e-3)
+    g = torch.Generator(DEV).manual_seed(9)
+    # which parameters have a gradient at each step: B (index 1) skips step 2, D (index 3) appears at step 3 only, all at the end
+    plan = [(0, 1, 2), (0, 2), (0, 1, 2, 3), (1,), (0, 1, 2, 3), (0, 1, 2, 3)]
+
+    def run(plan, pa, pb, oa, ob):
+        for have in plan:
+            oa.zero_grad(set_to_none=True); ob.zero_grad(set_to_none=True)
+            for i in have:
+                gr = torch.randn(pa[i].shape, device=DEV, generator=g)
+                pa[i].grad, pb[i].grad = gr.clone(), gr.clone()
+            oa.step(); ob.step()
+
+    def worst(pa, pb, oa, ob):
+        w = 0.0
+        for a, b in zip(pa, pb):
+            w = max(w, float((a.detach() - b.detach()).abs().max()) / float(b.detach().abs().max()))
+            assert float(oa.state[a]["step"]) == float(ob.state[b]["step"])
+            for k in ("exp_avg", "exp_avg_sq"):
+                w = max(w, float((oa.state[a][k] - ob.state[b][k]).abs().max()) / max(float(ob.state[b][k].abs().max()), 1e-30))
+        return w
+
+    run(plan, pa, pb, oa, ob)
+    w = worst(pa, pb, oa, ob)
+    record_err("adam_intermittent_vs_torch_adam", w, tol=2e-6)
+    assert w < 2e-6, w
+    assert [float(oa.state[p]["step"]) for p in pa] == [5.0, 5.0, 5.0, 3.0]
+    # a torch.optim.Adam state with differing per-parameter counts loads and continues identically
+    pc, pd = mk(), mk()
+    oc, od = Adam(pc, lr=1e-3), torch.optim.Adam(pd, lr=1e-3)
+    with torch.no_grad():
+        for c, d, b in zip(pc, pd, pb):
+            c.copy_(b); d.copy_(b)
+    oc.load_state_dict(ob.state_dict()); od.load_state_dict(ob.state_dict())
+    run([(0, 1, 2, 3), (0, 3)], pc, pd, oc, od)
+    w = worst(pc, pd, oc, od)
+    assert w < 2e-6, w
+
+
 def test_finetune_five_source_views_bf16():
     """BASELINE config 4 names 5 source views and the bf16 MLP: `args.n_views = 5` (47-channel cost volume, feat_dim 28) through
     MVSSystemFinetune - the reference hard-wires 8 + 3*4 (train_mvs_nerf_finetuning_pl.py:39)."""
