@@ -33,7 +33,8 @@ __device__ __forceinline__ void dma16_gather_b(const void* lane_ptr, unsigned ld
 // workgroup with chunk c+1 in flight during chunk c - 86 KB, i.e. ONE workgroup of four waves per CU: 0.42 ms, every chunk waiting ~4 us for
 // its DMA with nothing else resident to run.)  K = 32 of one MFMA = two (dz, dx) taps x 16 channels: fragment f = 0..4 pairs the (dz, dx)
 // combinations p = 2f, 2f+1 (p = 3 dz + dx; p = 9 does not exist: zero weights).  For a fixed f the A fragment of INPUT row j serves
-// the three dy taps of the M-tiles t = j - dy: 10 operand reads + 3 weight reads per 24 MFMAs.
+// the three dy taps of the M-tiles t = j - dy: 10 operand reads + 2 weight reads per 17 MFMAs (dy 0 and dy 1 share one MFMA through the two halves
+// of the 16 B columns).
 constexpr int BTX = 16, BTY = 8, BTZ = 4;
 constexpr int BPX = BTX + 2, BPY = BTY + 2, BPZ = BTZ + 2;
 constexpr int BNV = BPX * BPY * BPZ;                            // 1080 voxels
@@ -81,41 +82,52 @@ __global__ __launch_bounds__(256, 3) void conv3d_k3s1_c8_bf16_kernel(const __bf1
             dma16_gather_b(off < BW_BYTES ? wb + off : zero16, base + BT_BYTES + p * 1024);
         }
     };
-    f32x4 acc[8];
+    // Accumulators P[0..8], one per INPUT row j: B columns 0..7 carry the dy = 0 weights and columns 8..15 the dy = 1 weights, so one MFMA of input
+    // row j yields [dy 0 -> output row j | dy 1 -> output row j - 1]; a second MFMA with B = [dy 2 | 0] adds row j's share of output row j - 2 to the
+    // left half of P[j - 2].  Output row t = left(P[t]) + right(P[t + 1]): 17 MFMAs per fragment group instead of 24 (conv_f16x3.hip: same scheme).
+    f32x4 P[9];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0, 0, 0, 0};
+    for (int t = 0; t < 9; ++t) P[t] = f32x4{0, 0, 0, 0};
     const int m = lane & 15, kg = lane >> 4;
+    const bool left = m < 8;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
     for (int c = 0; c < nblk16; ++c) {
         char* cur = lds;
         issue(c, cur);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMA pieces have landed ...
         __syncthreads();                                          // ... everybody's have
-        const char* wt = cur + BT_BYTES + (kg * 8 + (m & 7)) * 16;          // columns 8..15 repeat 0..7 (their results are never stored)
+        const char* wt01 = cur + BT_BYTES + (m >> 3) * 512 + (kg * 8 + (m & 7)) * 16;      // columns 0..7: dy 0, columns 8..15: dy 1
+        const char* wt2 = cur + BT_BYTES + 2 * 512 + (kg * 8 + (m & 7)) * 16;              // dy 2 (right half zeroed)
 #pragma unroll
         for (int f = 0; f < 5; ++f) {
             const int p = 2 * f + (kg >> 1) < 9 ? 2 * f + (kg >> 1) : 8;     // the missing tenth (dz, dx) pair re-reads the ninth; its weights are zero
             const int dz = p / 3, dx = p - 3 * dz;
             const char* al = cur + (((wave + dz) * BPY) * BPX + m + dx) * 32 + (kg & 1) * 16;
-            bf16x8 av[10], bw[3];
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) bw[dy] = *reinterpret_cast<const bf16x8*>(wt + (f * 3 + dy) * 512);
+            bf16x8 av[10];
+            const bf16x8 b01 = *reinterpret_cast<const bf16x8*>(wt01 + f * 3 * 512);
+            const bf16x8 b2 = left ? *reinterpret_cast<const bf16x8*>(wt2 + f * 3 * 512) : zero8;
 #pragma unroll
             for (int j = 0; j < 10; ++j) av[j] = *reinterpret_cast<const bf16x8*>(al + j * BPX * 32);
 #pragma unroll
-            for (int j = 0; j < 10; ++j)
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int t = j - dy;
-                    if (t >= 0 && t < 8) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[j], bw[dy], acc[t], 0, 0, 0);
-                }
+            for (int j = 0; j < 10; ++j) {
+                if (j < 9) P[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[j], b01, P[j], 0, 0, 0);
+                if (j >= 2) P[j - 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[j], b2, P[j - 2], 0, 0, 0);
+            }
         }
         __syncthreads();                                          // everybody is done reading the buffer
     }
-    // D: lane (col n = lane & 15 = output channel when < 8, g = lane >> 4): register r = voxel x 4 g + r of the M-tile
+    // D: lane (column n = lane & 15, g = lane >> 4): register r = voxel x 4 g + r of the M-tile; left(P[t]) sits in lane n, right(P[t + 1]) in
+    // lane n + 8 of the same 16-lane row (DPP row rotation by 8)
     const int n = lane & 15, g4 = lane >> 4;
     const int oz = bz * BTZ + wave;
     float ssum = 0.f, ssq = 0.f;
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[t][r] = P[t][r] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P[t + 1][r]), 0x128, 0xf, 0xf, false));   // row_ror:8
     if (oz < D && n < 8) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -386,8 +398,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_bf16_wgrad_kernel(const
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = f32x4{0, 0, 0, 0};
     const int i16 = lane & 15, kg = lane >> 4;
-    // per-lane parts of the transposing reads: this lane passes row (8 kg + (i16 >> 2) [+ 4]) of the fragment, column chunk (i16 & 3)
-    const int row_in_frag = 8 * kg + (i16 >> 2), chunk = i16 & 3;
+    // per-lane parts of the transposing reads: this lane passes row (8 kg + (i16 >> 2) [+ 4]) of the fragment, column chunk (i16 & 3).
+    // The two reads of a fragment take the rows 8 kg + 0..3 and 8 kg + 4..7; ODD lane groups take them in the opposite order (for A and B alike, so the
+    // k-index of an element is the same on both sides): one read instruction then covers 128-byte blocks at 0, 384, 512, 896 instead of 0, 256, 512, 768 -
+    // both halves of the 64 banks instead of one (round 4 PMC: LDS bank conflict rate 0.47 = every x-fragment read took four cycles instead of two).
+    const int first4 = (kg & 1) * 4;
+    const int row_in_frag = 8 * kg + (i16 >> 2) + first4, row_step = (kg & 1) ? -4 : 4, chunk = i16 & 3;
 #pragma unroll 1
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int bx = tile % nbx, by = (tile / nbx) % nby, bz = tile / (nbx * nby);
@@ -430,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_bf16_wgrad_kernel(const
 #pragma unroll
         for (int y = 0; y < WTY; ++y) {
             const char* rowp = gt + ((wave * WTY + y) * WTX + row_in_frag) * 16 + chunk * 8;
-            const char* p0 = chunk < 2 ? rowp : zt, * p1 = chunk < 2 ? rowp + 4 * 16 : zt;
+            const char* p0 = chunk < 2 ? rowp : zt, * p1 = chunk < 2 ? rowp + row_step * 16 : zt;
             const bf16x4 lo = tr_read(p0), hi = tr_read(p1);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { bg[y][e] = lo[e]; bg[y][4 + e] = hi[e]; }
@@ -442,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_bf16_wgrad_kernel(const
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const char* rowp = xt + ((((wave + dz) * WPY + yy) * WPX) + dx + row_in_frag) * 32 + chunk * 8;
-                    const bf16x4 lo = tr_read(rowp), hi = tr_read(rowp + 4 * 32);
+                    const bf16x4 lo = tr_read(rowp), hi = tr_read(rowp + row_step * 32);
                     bf16x8 a;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { a[e] = lo[e]; a[4 + e] = hi[e]; }

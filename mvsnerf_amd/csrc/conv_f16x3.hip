@@ -15,9 +15,10 @@
 // the cost volume may reach 2^20 before an fp16 piece saturates (variance channels of the shipped FeatureNet: < 450).  Pieces below fp16's normal range
 // are subnormals, which gfx950's matrix cores take as they are; what they lose is below 2^-21 absolute per operand.
 //
-// Kernel = conv_bf16.hip's forward (4 x 8 x 16 output voxels per workgroup, wave = plane, M-tile = a row of 16 x, K = 32 = two (dz, dx) taps x 16
-// channels, one input-row fragment serving the three dy taps, LDS-DMA tiles of [voxel][32 B], three workgroups per CU) run over TWO tiles per
-// 16-channel block: the hi tile against both weight planes (48 MFMAs per fragment group), then the lo tile against the hi weights (24).
+// Kernel = conv_bf16.hip's forward scheme (wave = plane, M-tile = a row of 16 x, K = 32 = two (dz, dx) taps x 16 channels, one input-row fragment
+// serving the three dy taps, LDS-DMA tiles of [voxel][32 B]) on 8 x 8 x 16 output voxels per workgroup of eight waves, run over TWO tiles per
+// 16-channel block: the hi tile against both weight planes (34 MFMAs per fragment group), then the lo tile against the hi weights (17) - the dy = 0 and
+// dy = 1 taps of an input row share one MFMA through the two halves of the 16 B columns (see the accumulator comment in the kernel).
 #include "common.h"
 #include "act.h"
 #include "lds_dma.h"
@@ -36,17 +37,22 @@ __device__ __forceinline__ void dma16_gather_h(const void* lane_ptr, unsigned ld
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(lane_ptr), "s"(lds_byte_uniform) : "memory");
 }
 
-constexpr int HTX = 16, HTY = 8, HTZ = 4;
+// Workgroup = EIGHT waves = 8 x 8 x 16 output voxels (z, y, x), wave w owns plane z0 + w.  The kernel moves 2.3 GB through the LDS-DMA path per launch
+// at config 2 with the 4-plane tile of conv_bf16.hip (5.7 TB/s at 407 us - the chip's LDS-DMA fill rate, MI355X_MICROARCH.md "ldsdma-fill", is what bounds
+// it, not the matrix pipes: the 17-MFMA scheme below took 29 % of the MFMA work out and 10 % of the time); the 8-plane tile's halo is 1.76 x its voxels
+// instead of 2.11 x and one 15 KB weight fetch serves twice the voxels: 1.78 GB.  73 KB of LDS and <= 128 VGPRs: two workgroups = 16 waves per CU.
+// The InPlaceABN statistics keep the 4-plane slots of mvsnerf_conv0_bf16_tiles (one slot per half of a workgroup).
+constexpr int HTX = 16, HTY = 8, HTZ = 8, H_WAVES = 8;
 constexpr int HPX = HTX + 2, HPY = HTY + 2, HPZ = HTZ + 2;
-constexpr int HNV = HPX * HPY * HPZ;                            // 1080 voxels
-constexpr int HT_PIECES = (HNV * 32 + 1023) / 1024;             // 34 DMA pieces per tile
+constexpr int HNV = HPX * HPY * HPZ;                            // 1800 voxels
+constexpr int HT_PIECES = (HNV * 32 + 1023) / 1024;             // 57 DMA pieces per tile
 constexpr int HT_BYTES = HT_PIECES * 1024;
-constexpr int HT_SLOTS = (HT_PIECES + 3) / 4;                   // 9 per wave
+constexpr int HT_SLOTS = (HT_PIECES + H_WAVES - 1) / H_WAVES;   // 8 per wave
 constexpr int HW_BYTES = 5 * 3 * 4 * 8 * 16;                    // one weight plane of a chunk: [f][dy][kg][co 8][8 ci] fp16 = 7680 B
 constexpr int HW_PIECES = (HW_BYTES + 1023) / 1024;             // 8 per plane
-constexpr int HBUF = HT_BYTES + 2 * HW_PIECES * 1024;           // 51200 B: three workgroups per CU
+constexpr int HBUF = HT_BYTES + 2 * HW_PIECES * 1024;           // 74752 B: two workgroups per CU
 
-__global__ __launch_bounds__(256, 3) void conv3d_k3s1_c8_f16x3_kernel(const _Float16* __restrict__ x16, int nblk16, int D, int H, int W,
+__global__ __launch_bounds__(64 * H_WAVES, 4) void conv3d_k3s1_c8_f16x3_kernel(const _Float16* __restrict__ x16, int nblk16, int D, int H, int W,
                                                                      const _Float16* __restrict__ wq, float* __restrict__ out,
                                                                      float* __restrict__ stats, int* __restrict__ guard)
 {
@@ -58,11 +64,11 @@ __global__ __launch_bounds__(256, 3) void conv3d_k3s1_c8_f16x3_kernel(const _Flo
     const int x0 = bx * HTX - 1, y0 = by * HTY - 1, z0 = bz * HTZ - 1;
     const int64_t nvox = (int64_t)D * H * W;
     if (guard && blockIdx.x == 0 && tid == 0 && (float)wq[(int64_t)nblk16 * 7680] != 0.0f) guard[0] = 1;     // status word behind the weights: one was clamped at pack time
-    // DMA slots of this lane: piece p = wave + 4 j holds tile voxels 32 p .. 32 p + 31, lane -> (voxel 32 p + lane / 2, half lane & 1)
+    // DMA slots of this lane: piece p = wave + 8 j holds tile voxels 32 p .. 32 p + 31, lane -> (voxel 32 p + lane / 2, half lane & 1)
     int goff[HT_SLOTS];                                          // byte offset inside a channel block, -1: zeros
 #pragma unroll
     for (int j = 0; j < HT_SLOTS; ++j) {
-        const int v = (wave + 4 * j) * 32 + (lane >> 1);
+        const int v = (wave + H_WAVES * j) * 32 + (lane >> 1);
         const int vx = v % HPX, vy = (v / HPX) % HPY, vz = v / (HPX * HPY);
         const int gx = x0 + vx, gy = y0 + vy, gz = z0 + vz;
         const bool in = v < HNV && gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
@@ -75,23 +81,39 @@ __global__ __launch_bounds__(256, 3) void conv3d_k3s1_c8_f16x3_kernel(const _Flo
         const char* xb = reinterpret_cast<const char*>(x16) + ((int64_t)plane * nblk16 + c) * nvox * 32;
 #pragma unroll
         for (int j = 0; j < HT_SLOTS; ++j) {
-            const int p = wave + 4 * j;
+            const int p = wave + H_WAVES * j;
             if (p < HT_PIECES) dma16_gather_h(goff[j] >= 0 ? xb + goff[j] : zero16, base + p * 1024);
         }
     };
-    auto issue_weights = [&](int c) {                            // both planes of chunk c: 16 pieces, four per wave (the tail pieces are partly padding)
+    auto issue_weights = [&](int c) {                            // both planes of chunk c: 16 pieces, two per wave (the tail pieces are partly padding)
         const char* wb = reinterpret_cast<const char*>(wq) + (int64_t)c * 2 * HW_BYTES;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = wave + 4 * j, plane = p >> 3, off = (p & 7) * 1024 + lane * 16;
+        for (int j = 0; j < 2; ++j) {
+            const int p = wave + H_WAVES * j, plane = p >> 3, off = (p & 7) * 1024 + lane * 16;
             dma16_gather_h(off < HW_BYTES ? wb + plane * HW_BYTES + off : zero16, base + HT_BYTES + p * 1024);
         }
     };
-    f32x4 acc[8];
+    // Accumulators P[0..8], one per input row j (y = y0 + j): B columns 0..7 carry the dy = 0 weights and columns 8..15 the dy = 1 weights, so ONE
+    // MFMA of input row j yields [dy 0 -> output row j | dy 1 -> output row j - 1] in the left / right halves of P[j]; a second MFMA with
+    // B = [dy 2 weights | 0] adds input row j's share of output row j - 2 to the left half of P[j - 2].  Output row t = left(P[t]) + right(P[t + 1]).
+    // 9 + 8 = 17 MFMAs per (fragment, weight piece) instead of the 24 of one-dy-per-MFMA with a dead right half (round 4: 66.8 % of the kernel's
+    // duration the matrix pipes were busy, half of that on columns nobody stored).
+    f32x4 P[9];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0, 0, 0, 0};
+    for (int t = 0; t < 9; ++t) P[t] = f32x4{0, 0, 0, 0};
     const int m = lane & 15, kg = lane >> 4;
-    const char* wt = lds + HT_BYTES + (kg * 8 + (m & 7)) * 16;          // columns 8..15 repeat 0..7 (their results are never stored)
+    const bool left = m < 8;
+    const char* wt01 = lds + HT_BYTES + (m >> 3) * 512 + (kg * 8 + (m & 7)) * 16;      // columns 0..7: dy 0, columns 8..15: dy 1
+    const char* wt2 = lds + HT_BYTES + 2 * 512 + (kg * 8 + (m & 7)) * 16;              // dy 2 (the right half of that fragment is zeroed)
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // one (fragment group, weight piece): 17 MFMAs; rows are visited so that no accumulator is written twice in a row
+    auto mma17 = [&](const f16x8 (&av)[10], const f16x8 b01, const f16x8 b2) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            if (j < 9) P[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[j], b01, P[j], 0, 0, 0);
+            if (j >= 2) P[j - 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[j], b2, P[j - 2], 0, 0, 0);
+        }
+    };
 #pragma unroll 1
     for (int c = 0; c < nblk16; ++c) {
         // ---- hi tile x (lo weights, then hi weights): the small products first
@@ -104,28 +126,15 @@ __global__ __launch_bounds__(256, 3) void conv3d_k3s1_c8_f16x3_kernel(const _Flo
             const int p = 2 * f + (kg >> 1) < 9 ? 2 * f + (kg >> 1) : 8;     // the missing tenth (dz, dx) pair re-reads the ninth; its weights are zero
             const int dz = p / 3, dx = p - 3 * dz;
             const char* al = lds + (((wave + dz) * HPY) * HPX + m + dx) * 32 + (kg & 1) * 16;
-            f16x8 av[10], bh[3], bl[3];
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                bh[dy] = *reinterpret_cast<const f16x8*>(wt + (f * 3 + dy) * 512);
-                bl[dy] = *reinterpret_cast<const f16x8*>(wt + HW_PIECES * 1024 + (f * 3 + dy) * 512);
-            }
+            f16x8 av[10];
+            const f16x8 bh01 = *reinterpret_cast<const f16x8*>(wt01 + f * 3 * 512);
+            const f16x8 bl01 = *reinterpret_cast<const f16x8*>(wt01 + HW_PIECES * 1024 + f * 3 * 512);
+            const f16x8 bh2 = left ? *reinterpret_cast<const f16x8*>(wt2 + f * 3 * 512) : zero8;
+            const f16x8 bl2 = left ? *reinterpret_cast<const f16x8*>(wt2 + HW_PIECES * 1024 + f * 3 * 512) : zero8;
 #pragma unroll
             for (int j = 0; j < 10; ++j) av[j] = *reinterpret_cast<const f16x8*>(al + j * HPX * 32);
-#pragma unroll
-            for (int j = 0; j < 10; ++j)
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int t = j - dy;
-                    if (t >= 0 && t < 8) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[j], bl[dy], acc[t], 0, 0, 0);
-                }
-#pragma unroll
-            for (int j = 0; j < 10; ++j)
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int t = j - dy;
-                    if (t >= 0 && t < 8) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[j], bh[dy], acc[t], 0, 0, 0);
-                }
+            mma17(av, bl01, bl2);
+            mma17(av, bh01, bh2);
         }
         __syncthreads();                                          // everybody is done reading the tile
         // ---- lo tile x hi weights (the weight planes of this chunk stay where they are)
@@ -137,25 +146,26 @@ __global__ __launch_bounds__(256, 3) void conv3d_k3s1_c8_f16x3_kernel(const _Flo
             const int p = 2 * f + (kg >> 1) < 9 ? 2 * f + (kg >> 1) : 8;
             const int dz = p / 3, dx = p - 3 * dz;
             const char* al = lds + (((wave + dz) * HPY) * HPX + m + dx) * 32 + (kg & 1) * 16;
-            f16x8 av[10], bh[3];
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) bh[dy] = *reinterpret_cast<const f16x8*>(wt + (f * 3 + dy) * 512);
+            f16x8 av[10];
+            const f16x8 bh01 = *reinterpret_cast<const f16x8*>(wt01 + f * 3 * 512);
+            const f16x8 bh2 = left ? *reinterpret_cast<const f16x8*>(wt2 + f * 3 * 512) : zero8;
 #pragma unroll
             for (int j = 0; j < 10; ++j) av[j] = *reinterpret_cast<const f16x8*>(al + j * HPX * 32);
-#pragma unroll
-            for (int j = 0; j < 10; ++j)
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int t = j - dy;
-                    if (t >= 0 && t < 8) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[j], bh[dy], acc[t], 0, 0, 0);
-                }
+            mma17(av, bh01, bh2);
         }
         __syncthreads();                                          // everybody is done reading the buffer
     }
-    // D: lane (col n = lane & 15 = output channel when < 8, g = lane >> 4): register r = voxel x 4 g + r of the M-tile
+    // D: lane (column n = lane & 15, g = lane >> 4): register r = voxel x 4 g + r of the M-tile.  Output row t, channel n < 8:
+    // left(P[t]) sits in lane n, right(P[t + 1]) in lane n + 8 of the same 16-lane row: one DPP row rotation by 8 brings it over.
     const int n = lane & 15, g4 = lane >> 4;
     const int oz = bz * HTZ + wave;
     float ssum = 0.f, ssq = 0.f;
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[t][r] = P[t][r] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P[t + 1][r]), 0x128, 0xf, 0xf, false));   // row_ror:8
     if (oz < D && n < 8) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -170,16 +180,18 @@ __global__ __launch_bounds__(256, 3) void conv3d_k3s1_c8_f16x3_kernel(const _Flo
             }
         }
     }
-    if (stats) {          // InPlaceABN partial sums of this tile: abn_part_at(...) of common.h, slot = tile (abn_finalize_kernel's layout)
-        __syncthreads();
+    if (stats) {          // InPlaceABN partial sums in the 4-plane slots of mvsnerf_conv0_bf16_tiles (abn_finalize_kernel's layout): waves 0..3 -> slot of the
+        __syncthreads();  // planes 8 bz .. 8 bz + 3, waves 4..7 -> the slot of the next four planes (absent when D ends inside the first half)
         float* red = reinterpret_cast<float*>(lds);
         ssum += __shfl_xor(ssum, 16); ssq += __shfl_xor(ssq, 16);
         ssum += __shfl_xor(ssum, 32); ssq += __shfl_xor(ssq, 32);
         if (lane < 8) { red[wave * 16 + lane] = ssum; red[wave * 16 + 8 + lane] = ssq; }
         __syncthreads();
-        if (wave == 0 && lane < 16) {
-            const float v = (red[lane] + red[16 + lane]) + (red[32 + lane] + red[48 + lane]);
-            stats[abn_part_at(lane >> 3, lane & 7, 8, tile_id, gridDim.x)] = v;
+        const int nbz4 = (D + 3) / 4, h = wave >> 2, bz4 = 2 * bz + h;
+        if ((wave & 3) == 0 && lane < 16 && bz4 < nbz4) {
+            const float* r4 = red + h * 64;
+            const float v = (r4[lane] + r4[16 + lane]) + (r4[32 + lane] + r4[48 + lane]);
+            stats[abn_part_at(lane >> 3, lane & 7, 8, ((int64_t)bz4 * nby + by) * nbx + bx, (int64_t)nbz4 * nby * nbx)] = v;
         }
     }
 }
@@ -233,8 +245,8 @@ int mvs_conv0_f16x3_fwd(const void* x16, int Cin, int D, int H, int W, const voi
     if ((int64_t)D * H * W * 32 >= ((int64_t)1 << 31)) return MVSNERF_EUNSUPPORTED;
     static unsigned long long cap_mask = 0;
     if (int rc = mvs_raise_lds_cap(reinterpret_cast<const void*>(conv3d_k3s1_c8_f16x3_kernel), HBUF, &cap_mask)) return rc;
-    const int tiles = ((W + HTX - 1) / HTX) * ((H + HTY - 1) / HTY) * ((D + HTZ - 1) / HTZ);       // = mvsnerf_conv0_bf16_tiles(D, H, W): same tile, same statistics slots
-    conv3d_k3s1_c8_f16x3_kernel<<<tiles, 256, HBUF, st>>>(
+    const int tiles = ((W + HTX - 1) / HTX) * ((H + HTY - 1) / HTY) * ((D + HTZ - 1) / HTZ);       // statistics: the 4-plane slots of mvsnerf_conv0_bf16_tiles(D, H, W)
+    conv3d_k3s1_c8_f16x3_kernel<<<tiles, 64 * H_WAVES, HBUF, st>>>(
         reinterpret_cast<const _Float16*>(x16), (Cin + 15) / 16, D, H, W, reinterpret_cast<const _Float16*>(packed), out, stats_part, guard);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;

@@ -228,9 +228,14 @@ def test_two_streams_do_not_share_a_guard_buffer(net20):
     with torch.no_grad():
         big.nerf.pts_linears[1].weight.mul_(3e4)
     big.invalidate_packed()
-    ba, bb = _batch(n_rays=512, n_samples=64, seed=7), _batch(n_rays=512, n_samples=64, seed=8)
+    # (B's features are scaled down: with 32 768 unit-normal feature vectors - far outside what the encoder produces - the multiplicative modulation of
+    # six layers does push a few activations of the SHIPPED network past 65504, and B would fall back legitimately, as it did in the first run of this test)
+    ba, bb = _batch(n_rays=512, n_samples=64, seed=7), _batch(n_rays=512, n_samples=64, seed=8, feat_scale=0.25)
     want_a, _ = _query(big, "fp32", *ba)
     want_b, _ = _query(net20, "fp16x3", *bb)
+    n0 = ops.guard_fallbacks()
+    alone_b, _ = _query(net20, "auto", *bb)
+    assert ops.guard_fallbacks() == n0 and torch.equal(alone_b, want_b), "B's batch must be in range on its own"
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
     torch.cuda.synchronize()
     with torch.cuda.stream(sa):
@@ -250,9 +255,11 @@ def test_two_streams_do_not_share_a_guard_buffer(net20):
             with torch.cuda.stream(sb):
                 outs_b.append(net20.nerf.query(bb[0], bb[1], bb[2], 512, 64))
     torch.cuda.synchronize()
+    na, nb = int(ga[1].item()), int(gb[1].item())
+    ok_a, ok_b = [bool(torch.equal(o, want_a)) for o in outs_a], [bool(torch.equal(o, want_b)) for o in outs_b]
+    info = f"fallbacks counted on stream A {na} (expected {rounds}), on stream B {nb} (expected 0); A results equal the fp32 kernel's: {ok_a}; B results equal the fp16x3 kernel's: {ok_b}"
+    print("two guarded streams:", info)
+    assert na == rounds and nb == 0, info
     assert ops.guard_fallbacks() == before + rounds
-    assert int(ga[1].item()) >= rounds and int(ga[0].item()) == 0 and int(gb[0].item()) == 0
-    for o in outs_a:
-        assert torch.equal(o, want_a)
-    for o in outs_b:
-        assert torch.equal(o, want_b)
+    assert int(ga[0].item()) == 0 and int(gb[0].item()) == 0
+    assert all(ok_a) and all(ok_b), info

@@ -23,6 +23,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 H, W, PAD, S, NR = 64, 96, 4, 16, 256
 GRAD_TOL = 1e-4
+AMP_L2_TOL = 5e-2          # use_amp: relative L2 distance of the whole gradient vector (see _rank_body); a wrong shard or a missing all-reduce is O(1)
 
 
 def _free_port():
@@ -111,7 +112,14 @@ def _rank_body(rank, world, port, q):
                 g1b = _grads_of(sysm, batch, 11, False)
         finally:
             sysm.args.use_amp = False
-        res["ray_amp_grad_err"] = _worst(g2b, g1b)
+        # bf16 arithmetic is chaotic in the last bits of its inputs: the two ranks' partial volume gradients are summed in another order than one rank's
+        # atomics, a last-bit difference there occasionally flips a rounding to bf16 (2^-8 of that operand) and the flip grows through the 14 layers of the
+        # encoder backward (profiles/r05_costream_ab.txt: 2.5e-3 on FeatureNet's gradients from ONE process re-running the same step) - so under use_amp
+        # "N ranks == 1 rank" is asked of the gradient VECTOR (relative L2 distance over all parameters), not of every tensor's maximum
+        num = sum(float(((a - b).double() ** 2).sum()) for a, b in zip(g2b, g1b) if a is not None)
+        den = sum(float((b.double() ** 2).sum()) for b in g1b if b is not None)
+        res["ray_amp_grad_err"] = (num / den) ** 0.5
+        res["ray_amp_grad_err_max_norm"] = _worst(g2b, g1b)
         res["ray_amp_differs_from_fp32"] = _worst(g1b, g1) > 1e-4         # the bf16 kernels really ran
         # ---- scene-sharded DP: rank r renders scene r with its own draw; all-reduced gradients == mean of the two 1-rank gradients
         scenes = [train.batch_to_device(train.synthetic_batch(H, W, seed=20 + j, rot_deg=2.0), dev) for j in range(world)]
@@ -197,7 +205,10 @@ def test_two_ranks_on_one_gpu():
             print(f"rank {rank}: NOTE - {len(r['frame_attempts']) - 1} frame comparison(s) had to be repeated: {r['frame_attempts'][:-1]}")
             record_err(f"shared_gpu:frame_retries:rank{rank}", float(len(r["frame_attempts"]) - 1), tol=2.0)
         assert r["ray_amp_differs_from_fp32"], "use_amp gradients equal the fp32 ones: the bf16 kernels did not run"
-        for k in ("ray_grad_err", "ray_amp_grad_err", "scene_grad_err", "finetune_grad_err"):
+        record_err(f"shared_gpu:ray_amp_grad_err:rank{rank}", r["ray_amp_grad_err"], tol=AMP_L2_TOL)
+        record_err(f"shared_gpu:ray_amp_grad_err_max_norm:rank{rank}", r["ray_amp_grad_err_max_norm"], tol=1.0)
+        assert r["ray_amp_grad_err"] < AMP_L2_TOL, f"rank {rank}: use_amp ray-DP gradients, relative L2 distance to the 1-rank gradients {r['ray_amp_grad_err']}"
+        for k in ("ray_grad_err", "scene_grad_err", "finetune_grad_err"):
             record_err(f"shared_gpu:{k}:rank{rank}", r[k], tol=GRAD_TOL)
             assert r[k] < GRAD_TOL, f"rank {rank}: {k} = {r[k]}"
         assert r["ray_in_sync"] and r["scene_in_sync"], f"rank {rank}: parameters diverged"

@@ -280,7 +280,8 @@ def test_one_launch_adam_with_intermittent_gradients_and_mixed_step_counts():
     with torch.no_grad():
         for c, d, b in zip(pc, pd, pb):
             c.copy_(b); d.copy_(b)
-    oc.load_state_dict(ob.state_dict()); od.load_state_dict(ob.state_dict())
+    import copy
+    oc.load_state_dict(copy.deepcopy(ob.state_dict())); od.load_state_dict(copy.deepcopy(ob.state_dict()))     # (load_state_dict does not copy tensors that already fit)
     run([(0, 1, 2, 3), (0, 3)], pc, pd, oc, od)
     w = worst(pc, pd, oc, od)
     assert w < 2e-6, w
