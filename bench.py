@@ -1027,6 +1027,51 @@ def main():
                     e["max_abs_rgb_err_vs_cpu_oracle"] = float((gx[0].cpu() - o[0]).abs().max())
                 extras[("guarded_default" if mode == "auto" else mode) + "_mlp_mode"] = e
         if not a.no_extras and world == 1:
+            # (v-b) what a TRIPPED guard costs (VERDICT r4 hygiene): the same step / encode with operands that leave fp16's range, so that every guarded
+            # sequence runs its fp16 kernels AND the predicated fp32 kernels behind them (mlp_fwd_pipe_if_kernel, fp32 plane sweep + fp32-MFMA conv0)
+            import copy
+            try:
+                big = copy.deepcopy(net)
+                with torch.no_grad():
+                    big.nerf.pts_linears[1].weight.mul_(3e4)                     # h1 ~ 1e5: beyond fp16 in the layer epilogue
+                big.invalidate_packed()
+                def step_big(i):
+                    pts, ndc, z, ro, rdir = batches[i % n_batches]
+                    return renderer.rendering(args, pose, pts, ndc, z, ro, rdir, vol, src, network_fn=big, network_query_fn=qfn)
+                fb0 = ops.guard_fallbacks()
+                with torch.no_grad(), ops.mlp_precision("auto"):
+                    for i in range(10):
+                        step_big(i)
+                    torch.cuda.synchronize(); g0 = time.perf_counter()
+                    for i in range(100):
+                        step_big(i)
+                    torch.cuda.synchronize(); gdt = (time.perf_counter() - g0) / 100
+                fb1 = ops.guard_fallbacks()
+                trip = {"mlp": {"ms_per_step": round(gdt * 1e3, 4), "rays_per_s": round(N_RAYS / gdt, 1), "fallbacks_in_110_steps": fb1 - fb0,
+                                "note": "rendering() in the default mode with a network whose activations leave fp16's range: fp16x3 kernel + the fp32-MFMA kernel "
+                                        "(mlp_fwd_pipe_if_kernel: 9-16 spilled VGPRs) on every batch; compare extras.guarded_default_mlp_mode.ms_per_step (untripped) and ms_per_step (fp32 alone)"}}
+                del big
+                if enc_ready:
+                    import numpy as np
+                    zz = np.load(os.path.join(ROOT, "tests", "golden", "mvsnerf_v0_weights.npz"))
+                    mv = models.MVSNet().to(dev)
+                    mv.load_state_dict({k[4:]: torch.from_numpy(zz[k]) for k in zz.files if k.startswith("mvs/")})
+                    mv.train()
+                    with torch.no_grad():
+                        mv.cost_reg_2.conv0.conv.weight.mul_(1e6)               # weights that do not fit an fp16 piece: the pack sets the status word, every encode falls back
+                    mv.invalidate_packed()
+                    ei, ep, en = rig["images"][:, :3].to(dev), rig["proj_mats"][:, :3].to(dev), rig["near_fars"][0, 0].to(dev)
+                    fb0 = ops.guard_fallbacks()
+                    with torch.no_grad():
+                        trip["encode"] = {"ms": round(_ms_events(lambda: mv(ei, ep, en, pad=PAD), iters=6, warm=2), 3)}
+                    trip["encode"]["fallbacks_in_8_encodes"] = ops.guard_fallbacks() - fb0
+                    trip["encode"]["note"] = ("MVSNet.forward in the default mode with conv0 weights outside fp16's range: two-piece sweep + fp16x3 conv0 AND the fp32 sweep + fp32-MFMA "
+                                              "conv0 + statistics pass behind them; compare encode_ms.forward_free_running (untripped) and encode_ms_fp32_conv0 (fp32 alone)")
+                    del mv
+                extras["guard_tripped"] = trip
+            except Exception as ex:                                # a diagnostic leg must not take the headline line down
+                extras["guard_tripped"] = {"error": repr(ex)}
+        if not a.no_extras and world == 1:
             # (vi) BASELINE configs 4 and 5 at their own shapes (single-GPU forms): encode / frame / fine-tune step timings + same-volume parity vs the CPU oracle
             try:
                 extras.update(config45_legs(dev, with_oracle=a.cpu_batches > 0))

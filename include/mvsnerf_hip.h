@@ -582,6 +582,7 @@ int mvsnerf_adam_step_multi(int n, float* const* p, const float* const* g, float
  *   - mvsnerf_raymarch_fwd / mvsnerf_render_pixels_fwd: args.guard with n_split = MVSNERF_SPLIT_FP16 (gather -> fp16x3 MLP -> predicated fp32-MFMA
  *     MLP -> compositing, which also re-arms the guard);
  *   - mvsnerf_mlp_fwd_guarded: the stand-alone network query (run_network_mvs, renderer.py:42-63; alpha_only = forward_alpha);
+ *   - mvsnerf_conv3d_f16x3_guarded_fwd (scene encode, conv1 / conv2; ABI v11);
  *   - mvsnerf_sweep_conv0_guarded_fwd (scene encode): two-piece plane sweep -> fp16x3 conv0 -> predicated {fp32 plane sweep in channel blocks,
  *     fp32-MFMA conv0, InPlaceABN partial sums} -> re-arm.  `cost32` (the fp32 hand-off, (CP/4) * D*Hp*Wp * 4 floats) is scratch that is only
  *     written when the guard trips.  stats_part: mvsnerf_conv0_bf16_tiles(D, Hp, Wp) slots x 16 floats in either case. */
@@ -603,6 +604,28 @@ typedef struct {
     int* guard;
 } mvsnerf_sweep_conv0_args;
 int mvsnerf_sweep_conv0_guarded_fwd(const mvsnerf_sweep_conv0_args* a, void* stream);
+
+/* ---- conv1 / conv2 of CostRegNet on the fp16 matrix cores with fp32-grade results (ABI v11; models.py:743-746 `conv1 = ConvBnReLU3D(8, 16, stride=2)`,
+ * `conv2 = ConvBnReLU3D(16, 16)`, called at models.py:757-758) - what a no-grad encode runs for these two layers from 256 K output voxels on.
+ * Two fp16 pieces per operand (activations x 2^4, weights x 2^8, exact), x1 w0 + x0 w1 + x0 w0 on v_mfma_f32_16x16x32_f16, fp32 accumulation
+ * (csrc/conv_f16x3_tiled.hip).  Shapes: (Cin 8, stride 2) and (Cin 16, stride 1), Cout <= 16 (mvsnerf_conv3d_f16x3_supported).
+ *   x: [D][H][W][cin_ld] fp32 RAW output of the previous layer with its pending InPlaceABN (scale, shift; both NULL: x is taken as it is);
+ *   out: [Do][Ho][Wo][Cout] fp32 raw; stats_part: NULL or 2 * Cout * mvsnerf_conv3d_f16x3_slots() floats for mvsnerf_abn_finalize (n_blocks = slots).
+ *   mvsnerf_conv3d_f16x3_pack: nn.Conv3d weight w[Cout][Cin][3][3][3] -> mvsnerf_conv3d_f16x3_packed_elems(Cin) fp16 elements (16-byte aligned);
+ *   a weight outside fp16's range is recorded in a status tail and reported through the guard by the kernel.
+ *   mvsnerf_conv3d_f16x3_fwd: the UNGUARDED kernel (an operand beyond |x| < 4094 leaves NaNs in the outputs it touches).
+ *   mvsnerf_conv3d_f16x3_guarded_fwd: the guarded sequence (see "Guarded 16-bit sequences"): the kernel above sets guard[0] when an operand left the
+ *   range, the layer's fp32 kernel (w_f32: mvsnerf_conv3d_pack_weights_mfma layout for Cin 8, mvsnerf_conv3d_pack_weights layout for Cin 16) and a
+ *   statistics pass run behind it predicated on that word; consume != 0 counts the event in guard[1] and re-arms guard[0] at the end. */
+int mvsnerf_conv3d_f16x3_supported(int Cin, int Cout, int stride);
+int mvsnerf_conv3d_f16x3_slots(void);
+size_t mvsnerf_conv3d_f16x3_packed_elems(int Cin);
+int mvsnerf_conv3d_f16x3_pack(const float* w, int Cin, int Cout, void* packed, void* stream);
+int mvsnerf_conv3d_f16x3_fwd(const float* x, const float* scale, const float* shift, int Cin, int cin_ld, int D, int H, int W, const void* packed, int Cout,
+                             int stride, float* out, float* stats_part, void* stream);
+int mvsnerf_conv3d_f16x3_guarded_fwd(const float* x, const float* scale, const float* shift, int Cin, int cin_ld, int D, int H, int W,
+                                     const void* w_f16x3, const float* w_f32, int Cout, int stride, float* out, float* stats_part,
+                                     int* guard, int consume, void* stream);
 
 /* ---- importance sampling of the fine-tuning option --use_density_volume ----
  * sample_pdf (data/ray_utils.py:96-139): bins[N][n_bins] ascending, weights[N][n_bins-1], u[N][n_importance] uniform draws

@@ -190,6 +190,12 @@ SIGNATURES = {
     "mvsnerf_mlp_fwd_split": (_c_i, [_c_fp, _c_fp, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp]),
     "mvsnerf_mlp_fwd_guarded": (_c_i, [_c_fp, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_sweep_conv0_guarded_fwd": (_c_i, [ctypes.POINTER(SweepConv0Args), _c_fp]),
+    "mvsnerf_conv3d_f16x3_supported": (_c_i, [_c_i, _c_i, _c_i]),
+    "mvsnerf_conv3d_f16x3_slots": (_c_i, []),
+    "mvsnerf_conv3d_f16x3_packed_elems": (ctypes.c_size_t, [_c_i]),
+    "mvsnerf_conv3d_f16x3_pack": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_conv3d_f16x3_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_fp]),
+    "mvsnerf_conv3d_f16x3_guarded_fwd": (_c_i, [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_i, _c_fp]),
     "mvsnerf_mlp_packed_bf16_elems": (ctypes.c_size_t, [_c_i]),
     "mvsnerf_mlp_pack_bf16": (_c_i, [ctypes.POINTER(_c_fp), _c_i, _c_fp, _c_fp]),
     "mvsnerf_mlp_fwd_bf16": (_c_i, [_c_fp, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp]),

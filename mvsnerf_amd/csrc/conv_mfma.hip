@@ -896,8 +896,10 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_c16to8_mfma4_kernel(ActSrc x
 // re-read of the input is served by L1/L2.  Leaves the InPlaceABN partial sums of its 32-voxel tiles when asked.
 template <int CIN, int S>
 __global__ __launch_bounds__(256) void conv3d_k3_mfma16_kernel(ActSrc a, int ld, int Di, int Hi, int Wi, const float* __restrict__ w32,
-                                                              float* __restrict__ out, int Do, int Ho, int Wo, float* __restrict__ stats)
+                                                              float* __restrict__ out, int Do, int Ho, int Wo, float* __restrict__ stats,
+                                                              const int* __restrict__ run_if = nullptr)
 {
+    if (run_if && *run_if == 0) return;                          // fp32 half of a guarded sequence (mvsnerf_conv3d_f16x3_guarded_fwd)
     constexpr int COUT = 16, CPL = CIN / 4, CB8 = CIN / 8;
     static_assert(CIN == 8 || CIN == 16, "8 or 16 input channels");
     typedef float fcpl __attribute__((ext_vector_type(CPL)));
@@ -970,15 +972,16 @@ int mvs_conv3d_mfma32_tiles(int D, int H, int W, int stride)
 }
 
 int mvs_conv3d_mfma32(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int D, int H, int W, const float* w32, int Cout, int stride,
-                      float* out, float* stats, hipStream_t st)
+                      float* out, float* stats, hipStream_t st, const int* run_if)
 {
+    if (run_if && !(Cin == 8 && Cout == 16 && stride == 2)) return MVSNERF_EUNSUPPORTED;      // predication: conv1's kernel only
     if (b.x || (cin_ld & 3)) return MVSNERF_EUNSUPPORTED;
     const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const unsigned grid = mvs_cdiv((int64_t)Do * Ho * Wo, 32);
 #define MVS_M32(CIN, COUT, S) conv3d_k3_mfma32_kernel<CIN, COUT, S><<<grid, 512, 0, st>>>(a, cin_ld, D, H, W, w32, out, Do, Ho, Wo, stats)
     const unsigned grid16 = (grid + 3) / 4;
     switch (Cin * 1000 + Cout * 10 + stride) {
-        case 8 * 1000 + 16 * 10 + 2:  conv3d_k3_mfma16_kernel<8, 2><<<grid16, 256, 0, st>>>(a, cin_ld, D, H, W, w32, out, Do, Ho, Wo, stats); break;    // conv1
+        case 8 * 1000 + 16 * 10 + 2:  conv3d_k3_mfma16_kernel<8, 2><<<grid16, 256, 0, st>>>(a, cin_ld, D, H, W, w32, out, Do, Ho, Wo, stats, run_if); break;    // conv1
         case 16 * 1000 + 32 * 10 + 2: MVS_M32(16, 32, 2); break;     // conv3 (and the data gradient of conv9)
         case 32 * 1000 + 32 * 10 + 1: MVS_M32(32, 32, 1); break;     // conv4 (and its data gradient)
         case 32 * 1000 + 64 * 10 + 2: MVS_M32(32, 64, 2); break;     // conv5 (and the data gradient of conv7)

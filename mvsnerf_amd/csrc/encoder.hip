@@ -342,8 +342,9 @@ __device__ __forceinline__ void conv_tile_chunk(const ActSrc& a, const ActSrc& b
 template <int CIN, int CT, int COUT>
 __global__ __launch_bounds__(256) void conv3d_k3s1_tiled_kernel(ActSrc a, ActSrc b, int ld, int D, int H, int W,
                                                                const float* __restrict__ wp, float* __restrict__ out, int swz,
-                                                               float* __restrict__ stats = nullptr)
+                                                               float* __restrict__ stats = nullptr, const int* __restrict__ run_if = nullptr)
 {
+    if (run_if && *run_if == 0) return;                          // fp32 half of a guarded sequence (mvsnerf_conv3d_f16x3_guarded_fwd)
     __shared__ __attribute__((aligned(16))) float tile[600 * 12];
     const int nbx = (W + 7) / 8, nby = (H + 7) / 8;
     const int tile_id = swz ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;   // halo neighbours share an XCD's L2
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_kernel(ActSrc a, ActSrc b, i
 int mvs_conv3d_c8_mfma(const ActSrc& a, const ActSrc& b, int Cin, int cin_real, int cin_ld, int D, int H, int W, const float* wpacked, float* out,
                        int xcd, hipStream_t st);
 int mvs_conv3d_mfma32(const ActSrc& a, const ActSrc& b, int Cin, int cin_ld, int D, int H, int W, const float* w32, int Cout, int stride,
-                      float* out, float* stats, hipStream_t st);
+                      float* out, float* stats, hipStream_t st, const int* run_if = nullptr);
 int mvs_conv3d_mfma32_tiles(int D, int H, int W, int stride);
 bool mvs_conv3d_mfma32_supported(int Cin, int Cout, int stride);
 int mvs_conv_w32_repack(const float* wpacked, float* w32, int Cin, int Cout, hipStream_t st);
@@ -805,6 +806,42 @@ extern "C" int mvsnerf_sweep_conv0_guarded_fwd(const mvsnerf_sweep_conv0_args* a
     }
     // 3. count the event, re-arm
     return mvs_guard_consume(a->guard, st);
+}
+
+// conv1 / conv2 of a no-grad encode as a guarded sequence (include/mvsnerf_hip.h): the fp16x3 LDS-tiled kernel (conv_f16x3_tiled.hip) reporting through guard[0],
+// then the layer's fp32 kernel and a statistics pass over its output, both predicated on that word (they cost a launch when it is clear, recompute the
+// layer - the same out, the same stats_part slots - when it is set).  consume != 0: count the event in guard[1] and re-arm guard[0] (the LAST guarded
+// layer of the encode passes 1; earlier ones may pass 0: a set guard then also makes the later layers take their fp32 kernels, which is harmless).
+int mvs_conv3d_f16x3_tiled_fwd(const float* x, const float* scale, const float* shift, int Cin, int cin_ld, int D, int H, int W, const void* wq, int Cout,
+                               int stride, float* out, float* stats_part, int* guard, hipStream_t st);                     // conv_f16x3_tiled.hip
+extern "C" int mvsnerf_conv3d_f16x3_slots(void);
+
+extern "C" int mvsnerf_conv3d_f16x3_guarded_fwd(const float* x, const float* scale, const float* shift, int Cin, int cin_ld, int D, int H, int W,
+                                                const void* w_f16x3, const float* w_f32, int Cout, int stride, float* out, float* stats_part,
+                                                int* guard, int consume, void* stream)
+{
+    if (!act_ok(x, scale, shift) || !w_f16x3 || !w_f32 || !out || !guard || D < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
+    if (Cout != 16 || !((Cin == 8 && stride == 2) || (Cin == 16 && stride == 1))) return MVSNERF_EUNSUPPORTED;
+    if ((cin_ld & 3) || cin_ld < Cin || !mvs_aligned16(out)) return MVSNERF_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    // 1. fp16x3; the guard is set from the (NaN) partial sums, so the statistics are always computed
+    if ((rc = mvs_conv3d_f16x3_tiled_fwd(x, scale, shift, Cin, cin_ld, D, H, W, w_f16x3, Cout, stride, out, stats_part, guard, st))) return rc;
+    // 2. the fp32 kernel of the layer, predicated: conv1 = conv3d_k3_mfma16_kernel<8, 2> (w_f32: mvsnerf_conv3d_pack_weights_mfma layout),
+    //    conv2 = conv3d_k3s1_tiled_kernel<16, 16, 16> (w_f32: mvsnerf_conv3d_pack_weights layout)
+    const ActSrc a{x, scale, shift}, b{nullptr, nullptr, nullptr};
+    if (Cin == 8) {
+        if ((rc = mvs_conv3d_mfma32(a, b, Cin, cin_ld, D, H, W, w_f32, Cout, stride, out, nullptr, st, guard))) return rc;
+    } else {
+        conv3d_k3s1_tiled_kernel<16, 16, 16><<<dim3((unsigned)mvsnerf_conv3d_tiled_tiles(D, H, W), 1), 256, 0, st>>>(a, b, cin_ld, D, H, W, w_f32, out, g_conv_xcd, nullptr, guard);
+        MVS_LAUNCH_CHECK();
+    }
+    if (stats_part) {
+        const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+        abn_partial_kernel<16><<<mvsnerf_conv3d_f16x3_slots(), 256, 0, st>>>(out, (int64_t)Do * Ho * Wo, stats_part, guard);
+        MVS_LAUNCH_CHECK();
+    }
+    return consume ? mvs_guard_consume(guard, st) : MVSNERF_OK;
 }
 
 // out = leaky(x1*scale1+shift1) [+ leaky(x2*scale2+shift2)]  (materialises an activated tensor, e.g. the final

@@ -529,6 +529,20 @@ class _PackedConv:
         self.cache["dgrad_slice"] = (key, buf)
         return buf
 
+    def get_f16x3(self):
+        """Two-piece fp16 B fragments of the layer's own weights for csrc/conv_f16x3_tiled.hip (conv1 / conv2 of a no-grad encode):
+        mvsnerf_conv3d_f16x3_pack, cached like every other layout."""
+        w = self.conv.weight
+        key = (w.data_ptr(), w._version, _lib.weights_epoch())
+        hit = self.cache.get("f16x3t")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        lib = _lib.lib()
+        buf = torch.empty(lib.mvsnerf_conv3d_f16x3_packed_elems(self.cin), device=w.device, dtype=torch.float16)
+        check(lib.mvsnerf_conv3d_f16x3_pack(dev_f32(w.detach().contiguous(), "conv weight"), self.cin, self.cout, buf.data_ptr(), stream_ptr()), "conv3d_f16x3_pack")
+        self.cache["f16x3t"] = (key, buf)
+        return buf
+
     def get_mfma(self, mode="fwd"):
         """[tap][ci/8][co][8] layout of get(mode)'s weights for the matrix-core kernels of the 32/64-channel layers."""
         return self._cached(mode + "_m32", 2, mode, "get_mfma", mode)
@@ -655,6 +669,25 @@ BF16_LAYERS = True         # A/B switch (scratch/r4): False keeps conv1 ... conv
 _LAYER_BF16 = [False]      # conv1 ... conv11 on the bf16 matrix cores (csrc/conv3d_bf16.hip): set for the extent of a forward / backward by _layer_precision
 
 
+F16X3_LAYERS = True        # A/B switch: conv1 / conv2 of a no-grad "auto" encode on the guarded fp16x3 LDS-tiled kernel (csrc/conv_f16x3_tiled.hip)
+F16X3_MIN_VOXELS = 262144  # ... from this many OUTPUT voxels on (below, the layer is a few microseconds on any kernel and the persistent grid of 512 workgroups is mostly idle)
+_LAYER_F16X3 = [None]      # None, or "guarded" / "plain" for the extent of CostRegNet._run (set by _layers_f16x3)
+
+
+class _layers_f16x3:
+    """conv1 / conv2 on the two-piece fp16 kernel for the enclosed launches: "guarded" (the no-grad default: the layer's fp32 kernel is enqueued
+    behind it, predicated on the guard word) or "plain" (encoder_precision("fp16x3"): the kernel alone; NaNs where an operand left fp16's range)."""
+
+    def __init__(self, how):
+        self.how = how if F16X3_LAYERS else None
+
+    def __enter__(self):
+        self.prev, _LAYER_F16X3[0] = _LAYER_F16X3[0], self.how
+
+    def __exit__(self, *exc):
+        _LAYER_F16X3[0] = self.prev
+
+
 class _layer_precision:
     """The arithmetic of the 3-D layers behind conv0 for the enclosed launches: bf16 operands (use_amp, encoder_precision("bf16")) or fp32.
     A backward pass re-enters it with what its forward ran (the `with encoder_precision(...)` of the caller is long gone by then)."""
@@ -687,6 +720,23 @@ def _conv(src1, src2, dims_in, cin_ld, wbuf, cin_k, cout_k, stride, packed=None,
         check(lib.mvsnerf_conv3d_bf16_fwd(*_ptrs(src1), *_ptrs(src2), cin_k, cin_ld, D, H, W, wq.data_ptr(), cout_k, stride, out.data_ptr(),
                                           0 if part is None else part.data_ptr(), stream_ptr()), "conv3d_bf16_fwd")
         return out if want_stats is None else (out, None if part is None else (part, nblk))
+    how = _LAYER_F16X3[0]
+    if (how is not None and packed is not None and src2 is None and mode == "fwd" and want_stats and FUSED_ABN_STATS and cout_k == 16
+            and (cin_k, stride) in ((8, 2), (16, 1)) and Do * Ho * Wo >= F16X3_MIN_VOXELS):
+        # conv1 / conv2 of a no-grad encode: fp32-grade results from the fp16 matrix cores (52 / 43 us instead of 107 / 120 at config 2)
+        lib = _lib.lib()
+        x, sc, sh = _ptrs(src1)
+        nblk = lib.mvsnerf_conv3d_f16x3_slots()
+        part = torch.empty(nblk * 2 * cout_k, device=out.device, dtype=torch.float32)
+        if how == "guarded":
+            w32 = packed.get_mfma("fwd") if cin_k == 8 else (wbuf() if callable(wbuf) else wbuf)      # the layouts of the layer's fp32 kernels
+            check(lib.mvsnerf_conv3d_f16x3_guarded_fwd(x, sc, sh, cin_k, cin_ld, D, H, W, packed.get_f16x3().data_ptr(), w32.data_ptr(), cout_k, stride,
+                                                       out.data_ptr(), part.data_ptr(), ops.guard_words(out.device).data_ptr(), 1, stream_ptr()),
+                  "conv3d_f16x3_guarded_fwd")
+        else:
+            check(lib.mvsnerf_conv3d_f16x3_fwd(x, sc, sh, cin_k, cin_ld, D, H, W, packed.get_f16x3().data_ptr(), cout_k, stride, out.data_ptr(),
+                                               part.data_ptr(), stream_ptr()), "conv3d_f16x3_fwd")
+        return out, (part, nblk)
     if packed is not None and src2 is None and _lib.lib().mvsnerf_conv3d_mfma_supported(cin_k, cout_k, stride):
         lib = _lib.lib()
         x, sc, sh = _ptrs(src1)
@@ -874,6 +924,8 @@ class CostRegNet(nn.Module):
             _, C, D, H, W = x.shape
         if D % 8 or H % 8 or W % 8:
             raise RuntimeError(f"CostRegNet needs D,h,w divisible by 8 (three stride-2 stages), got {(D, H, W)}")
+        # the hand-off says which encode this is: _Conv0Done = the guarded no-grad default, two fp16 planes = encoder_precision("fp16x3")
+        f16 = "guarded" if isinstance(x, _Conv0Done) else ("plain" if isinstance(x, _BlockedCostH2) else None)
         if isinstance(x, _Conv0Done):          # conv0 already ran inside the guarded encode head (_plane_sweep, blocked="guarded")
             raw = x.buf
             scale, shift, mean, invstd = _abn_stats(raw, D * H * W, self.conv0.bn, update_running=self.conv0.bn.training,
@@ -921,7 +973,7 @@ class CostRegNet(nn.Module):
         else:
             buf, ld = _as_channel_last(x, self.conv0._packed_cin_pad())
             c0 = self.conv0.lazy(buf, (D, H, W, ld), ld)
-        with _layer_precision(ENCODER_PRECISION == "bf16" and BF16_LAYERS):     # use_amp: conv1 ... conv11 on the bf16 matrix cores as well (csrc/conv3d_bf16.hip)
+        with _layer_precision(ENCODER_PRECISION == "bf16" and BF16_LAYERS), _layers_f16x3(f16):     # use_amp: conv1 ... conv11 on the bf16 matrix cores as well (csrc/conv3d_bf16.hip)
             c1 = self.conv1.lazy(c0, c0.dims, 8)
             c2 = self.conv2.lazy(c1, c1.dims, 16)
             c3 = self.conv3.lazy(c2, c2.dims, 16)

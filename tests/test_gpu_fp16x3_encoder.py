@@ -118,3 +118,93 @@ def test_encode_fp16x3_vs_fp32_path_and_oracle():
     assert e16 < 2 * e32 + 5e-6 and d < 2 * e32 + 5e-6
     with pytest.raises(ValueError):
         E.encoder_precision("fp8")
+
+
+# ------------------------------------------------------------------ conv1 / conv2 on the two-piece fp16 LDS-tiled kernel (csrc/conv_f16x3_tiled.hip)
+def _conv12_case(cin, stride, dims, seed, lazy=True, scale_x=1.0):
+    D, H, W = dims
+    g = torch.Generator(DEV).manual_seed(seed)
+    x = torch.randn((D, H, W, cin), device=DEV, generator=g) * scale_x
+    sc = (torch.rand(cin, device=DEV, generator=g) + 0.5) if lazy else None
+    sh = (torch.randn(cin, device=DEV, generator=g) * 0.3) if lazy else None
+    w = torch.randn((16, cin, 3, 3, 3), device=DEV, generator=g) * 0.1
+    return x, sc, sh, w
+
+
+@pytest.mark.parametrize("cin,stride,dims", [(16, 1, (8, 12, 40)), (8, 2, (10, 14, 70)), (16, 1, (8, 12, 64)), (8, 2, (10, 14, 128)), (16, 1, (5, 9, 33)),
+                                             (16, 1, (64, 88, 104)), (8, 2, (128, 176, 208))])
+def test_conv12_f16x3_tiled_vs_float64(cin, stride, dims):
+    """conv2 (16 -> 16) / conv1 (8 -> 16, stride 2) of CostRegNet (models.py:743-746) on three v_mfma_f32_16x16x32_f16 per product against the float64
+    convolution of the same fp32 operands (pending InPlaceABN applied in float64), with torch's own fp32 convolution as the yardstick for "fp32 grade";
+    32-wide and 16-wide tiles (rows of 40 / 35 / 104 / 17 voxels take the narrow ones), ragged edges, the two config-2 shapes (timed), the InPlaceABN partial sums."""
+    import torch.nn.functional as F
+    from mvsnerf_amd import _lib
+    from mvsnerf_amd.ops import stream_ptr
+    L = _lib.lib()
+    D, H, W = dims
+    x, sc, sh, w = _conv12_case(cin, stride, dims, cin * 7 + D)
+    pk = torch.zeros(L.mvsnerf_conv3d_f16x3_packed_elems(cin), device=DEV, dtype=torch.float16)
+    assert L.mvsnerf_conv3d_f16x3_pack(w.data_ptr(), cin, 16, pk.data_ptr(), stream_ptr()) == 0
+    Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.full((Do, Ho, Wo, 16), float("nan"), device=DEV)
+    nslots = L.mvsnerf_conv3d_f16x3_slots()
+    part = torch.full((2 * 16 * nslots,), float("nan"), device=DEV)
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        assert L.mvsnerf_conv3d_f16x3_fwd(x.data_ptr(), sc.data_ptr(), sh.data_ptr(), cin, cin, D, H, W, pk.data_ptr(), 16, stride, out.data_ptr(), part.data_ptr(), stream_ptr()) == 0
+        e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3
+    xa = x.double() * sc.double() + sh.double()
+    xa = torch.where(xa > 0, xa, 0.01 * xa)
+    zo = min(Do, 16 if stride == 1 else 8)                    # float64 on a slab of the first planes (the fp64 convolution is an im2col fallback)
+    zs = min(D, zo * stride + 1)
+    xin = xa[:zs].permute(3, 0, 1, 2)[None]
+    ref = F.conv3d(xin, w.double(), stride=stride, padding=1)[0].permute(1, 2, 3, 0)[:zo]
+    y32 = F.conv3d(xin.float(), w, stride=stride, padding=1)[0].permute(1, 2, 3, 0)[:zo]
+    top = float(ref.abs().max())
+    e16, e32 = float((out[:zo].double() - ref).abs().max()) / top, float((y32.double() - ref).abs().max()) / top
+    record_err(f"conv12_f16x3_{cin}s{stride}_{D}x{H}x{W}", e16 * top, scale=top)
+    print(f"[conv f16x3 tiled cin={cin} s={stride} {D}x{H}x{W}] {us:.1f} us; err / max|ref|: fp16x3 {e16:.2e}, torch fp32 {e32:.2e}")
+    assert bool(torch.isfinite(out).all())
+    assert e16 < 2.5e-6 and e16 < 3 * e32 + 5e-7, (e16, e32)          # measured 2.3e-7 .. 5.8e-7 where torch's fp32 convolution is 3.5e-7 .. 9.1e-7
+    ps = part.view(2, 16, nslots).double()
+    o64 = out.double()
+    assert float((ps[0].sum(1) - o64.sum((0, 1, 2))).abs().max()) < 1e-6 * float(o64.abs().sum((0, 1, 2)).max())
+    assert float((ps[1].sum(1) - (o64 ** 2).sum((0, 1, 2))).abs().max()) < 1e-6 * float((o64 ** 2).sum((0, 1, 2)).max())
+
+
+@pytest.mark.parametrize("cin,stride,dims", [(16, 1, (16, 24, 64)), (8, 2, (16, 24, 70))])
+def test_conv12_guarded_sequence(cin, stride, dims, monkeypatch):
+    """mvsnerf_conv3d_f16x3_guarded_fwd through encoder._conv, as CostRegNet._run issues it for a no-grad encode: in range the result IS the fp16 kernel's
+    and no fallback is counted; with activations beyond fp16's range (|x 2^4| > 65504) the result is the layer's fp32 kernel's, bit for bit, the statistics
+    are those of that result, the fallback is counted and the guard re-armed."""
+    import torch.nn as nn
+    from mvsnerf_amd import encoder as E, ops
+    monkeypatch.setattr(E, "F16X3_MIN_VOXELS", 0)
+    D, H, W = dims
+    torch.manual_seed(cin)
+    conv = nn.Conv3d(cin, 16, 3, stride=stride, padding=1, bias=False).to(DEV)
+    pk = E._PackedConv(conv, False)
+    for scale_x, trips in ((1.0, 0), (5000.0, 1)):
+        x, sc, sh, _ = _conv12_case(cin, stride, dims, 3, scale_x=scale_x)
+        lz = E._Lazy(x, sc, sh, (D, H, W, cin))
+        with torch.no_grad():
+            ref, ref_part = E._conv(lz, None, (D, H, W, cin), cin, pk.get, cin, 16, stride, packed=pk, want_stats=True)           # the fp32 kernel of the layer
+            with E._layers_f16x3("plain"):
+                plain, _ = E._conv(lz, None, (D, H, W, cin), cin, pk.get, cin, 16, stride, packed=pk, want_stats=True)
+            before = ops.guard_fallbacks()
+            with E._layers_f16x3("guarded"):
+                got, (part, nblk) = E._conv(lz, None, (D, H, W, cin), cin, pk.get, cin, 16, stride, packed=pk, want_stats=True)
+            n_fb = ops.guard_fallbacks() - before
+        assert n_fb == trips and int(ops.guard_words()[0].item()) == 0
+        if trips:
+            assert torch.equal(got, ref) and not bool(torch.isfinite(plain).all())            # the fp32 kernel's bits; the unguarded kernel left NaNs
+        else:
+            assert torch.equal(got, plain)
+            e = float((got - ref).abs().max()) / float(ref.abs().max())
+            assert e < 5e-6, e                                                                 # two fp32-grade results of the same layer
+        s = part.view(2, 16, nblk).double().sum(2)
+        o64 = got.double()
+        assert float((s[0] - o64.sum((0, 1, 2))).abs().max()) < 1e-6 * float(o64.abs().sum((0, 1, 2)).max())
+        assert float((s[1] - (o64 ** 2).sum((0, 1, 2))).abs().max()) < 1e-6 * float((o64 ** 2).sum((0, 1, 2)).max())
