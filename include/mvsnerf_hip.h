@@ -575,6 +575,10 @@ int mvsnerf_adam_step_multi(int n, float* const* p, const float* const* g, float
  * stage are enqueued right behind them PREDICATED on guard[0] (they leave at once when it is 0, and overwrite the results when it is set); the
  * last kernel of the sequence counts the event in guard[1] and re-arms guard[0] = 0.  The caller reads results that are the fp32 kernels'
  * whenever the 16-bit ones were out of range, and may read guard[1] (number of sequences that fell back) whenever it synchronises anyway.
+ * What trips the guard (ABI v11): (a) RANGE - an operand, weight or layer output beyond what an fp16 piece holds after the kernel's scaling; (b) the MLP kernel
+ * also reports a layer whose inputs are ALL small: a second piece below 2^-14 is a subnormal with an absolute resolution of 2^-24, so when the largest
+ * activation a layer hands on (over a wave's 32 points) is non-zero and below 2^-7 its products carry more than 2^-18 of the layer's scale and the batch is
+ * re-run in fp32 (a network with hidden activations 1e-4 of the shipped one's falls back; at 1e-2 it does not and stays within 1.5e-5 of the oracle).
  * ONE GUARD BUFFER PER STREAM: guard[0] is armed, read and re-armed in stream order only (guard[1] += 1 is a plain store of the last kernel), so
  * sequences enqueued on different streams - or by different host threads - must be given different buffers; sharing one lets stream B re-arm the
  * word between stream A's 16-bit kernel setting it and A's predicated fp32 kernel reading it.  mvsnerf_amd.ops.guard_words() keeps one buffer per

@@ -202,9 +202,20 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
     float gmax = 0.0f;
 #pragma unroll
     for (int i = 0; i < 24; ++i) gmax = fmaxf(gmax, fabsf(fv[i]));
+    // ... and the other end of fp16: a second piece below 2^-14 is a subnormal (absolute resolution 2^-24), so an operand x carries an absolute error of up
+    // to 2^-25 whatever its size - fp32 grade only while the layer's inputs are not ALL small.  `tiny` is set when the largest activation a layer hands on,
+    // taken over the wave's 32 points, is non-zero and below 2^-7 (the layer's products then carry > 2^-18 of its scale): reported like an overflow, the
+    // fp32 kernel takes the batch (a network whose hidden activations are 1e-4 of the shipped one's: tests/test_gpu_fp16x3.py).
+    bool tiny = false;
+    auto layer_scale = [&](float lmax) {                          // lmax: the largest |activation| among this lane's 64 values of the layer
+        gmax = fmaxf(gmax, lmax);
+        // wave-uniform, two compares and no cross-lane traffic: no lane reaches 2^-7, some lane is above zero (a wave-level max by six shuffles per
+        // layer cost 3.8 % of the kernel: they sit in the epilogue, the part of a layer nothing overlaps)
+        tiny = tiny || (__ballot(lmax >= SA * 0.0078125f) == 0 && __ballot(lmax > 0.0f) != 0);
+    };
     auto report = [&]() {
         if (guard) {
-            if (gmax > H_MAX) guard[0] = 1;
+            if (gmax > H_MAX || tiny) guard[0] = 1;
             if (blockIdx.x == 0 && tid == 0 && (float)wq[L.total] != 0.0f) guard[0] = 1;      // a weight was clamped at pack time
         }
     };
@@ -227,6 +238,7 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
     };
     // epilogue of a modulated ReLU layer; the clamp only matters where fp16 would overflow
     auto finish = [&](f32x16 (&acc)[4]) {
+        float lmax = 0.0f;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             float v8[8];
@@ -234,11 +246,12 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
             for (int j = 0; j < 8; ++j) {
                 const int q = 8 * s + j;
                 const float x = acc[q >> 4][q & 15] * bias[q];
-                gmax = fmaxf(gmax, x);
+                lmax = fmaxf(lmax, x);
                 v8[j] = __builtin_amdgcn_fmed3f(x, 0.0f, H_MAX);
             }
             put(s, v8);
         }
+        layer_scale(lmax);
     };
 
     slab_sync();
@@ -298,7 +311,7 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
         H3_STAMP();
         // alpha_linear on the fp32 activations (before they are split), then the split for feature_linear
         const float* wa = vec + V_WA + half * 64;
-        float part = 0.0f;
+        float part = 0.0f, lmax = 0.0f;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             float v8[8];
@@ -306,12 +319,13 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
             for (int j = 0; j < 8; ++j) {
                 const int q = 8 * s + j;
                 const float x = acc[q >> 4][q & 15] * bias[q];
-                gmax = fmaxf(gmax, x);
+                lmax = fmaxf(lmax, x);
                 v8[j] = __builtin_amdgcn_fmed3f(x, 0.0f, H_MAX);
                 part = fmaf(wa[q], v8[j], part);
             }
             if (!ALPHA_ONLY) put(s, v8);
         }
+        if (ALPHA_ONLY) gmax = fmaxf(gmax, lmax); else layer_scale(lmax);      // (the sigma head reads these values in fp32: only feature_linear splits them)
         part += __shfl_xor(part, 32);
         sigma = fmaxf(fmaf(part, 1.0f / SA, vec[V_BA]), 0.0f);
         H3_STAMP();
@@ -329,6 +343,7 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
         init_acc_b<4>(acc, vec + V_FEAT + half * 64);
         gemm_h<B_ACT_STEPS, 4>(buf1, buf1 + ACT_PLANE * 2, acc, lane, act);
         H3_STAMP();
+        float lmax = 0.0f;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             float v8[8];
@@ -336,11 +351,12 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
             for (int j = 0; j < 8; ++j) {
                 const int q = 8 * s + j;
                 const float x = acc[q >> 4][q & 15] * (1.0f / SW);
-                gmax = fmaxf(gmax, fabsf(x));
+                lmax = fmaxf(lmax, fabsf(x));
                 v8[j] = __builtin_amdgcn_fmed3f(x, -H_MAX, H_MAX);
             }
             put(s, v8);
         }
+        layer_scale(lmax);
     }
     report();
     {   // views_linears[0] + rgb head

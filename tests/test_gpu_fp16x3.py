@@ -168,3 +168,43 @@ def test_fp16x3_frame_render_matches_the_fp32_frame(net20):
     e = float((a["rgb"] - b["rgb"]).abs().max())
     record_err("fp16x3_frame:rgb_vs_fp32_kernel", e)
     assert e < 9e-6 and float((a["depth"] - b["depth"]).abs().max()) < 5e-5          # measured 1.8e-6
+
+
+@pytest.mark.parametrize("s", [1e-2, 1e-4])
+def test_small_activations_keep_their_lo_pieces(net20, s):
+    """the guard of the default path trips on RANGE only; what it accepts silently is the floor of the second fp16 pieces.  A network
+    whose hidden activations are s times the shipped ones but whose outputs are the same function (pts_linears are positively homogeneous in h: scale layer 0,
+    the PE columns of layer 5 and the later biases by s, the two heads by 1 / s) must still come out fp32-grade: at s = 1e-2 the lo pieces of the activations
+    are fp16 subnormals (spacing 6e-8 against values of ~5e-6), at s = 1e-4 they are below the subnormal spacing altogether and the kernel computes with the hi
+    pieces alone (11 bits) - THAT must show up as a fallback or as an error this test catches, never as a silent 5e-4."""
+    import copy
+    from mvsnerf_amd import ops
+    from oracle import mvsnerf_oracle as O
+    net = copy.deepcopy(net20)
+    with torch.no_grad():
+        n = net.nerf
+        n.pts_linears[0].weight.mul_(s); n.pts_linears[0].bias.mul_(s)
+        for l in range(1, 6):
+            n.pts_linears[l].bias.mul_(s)
+        n.pts_linears[5].weight[:, :63].mul_(s)                   # layer 5 sees cat([pts_embedding, h]) (models.py:204-205): the embedding columns
+        n.alpha_linear.weight.mul_(1.0 / s)
+        n.feature_linear.weight.mul_(1.0 / s)
+    net.invalidate_packed()
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(11)
+    n_rays, n_samples = 64, 32
+    ndc = torch.rand((n_rays, n_samples, 3), generator=g)
+    feat = torch.randn((n_rays, n_samples, 20), generator=g) * 0.3
+    dirs = torch.nn.functional.normalize(torch.randn((n_rays, 3), generator=g), dim=-1)
+    ref = O.run_network_mvs(ndc, dirs, feat, sd)
+    fb0 = ops.guard_fallbacks()
+    with ops.mlp_precision("auto"), torch.no_grad():
+        raw = net.nerf.query(ndc.to(DEV), feat.to(DEV), dirs.to(DEV), n_rays, n_samples).cpu().view(n_rays, n_samples, 4)
+    fell_back = ops.guard_fallbacks() - fb0
+    with ops.mlp_precision("fp32"), torch.no_grad():
+        raw32 = net.nerf.query(ndc.to(DEV), feat.to(DEV), dirs.to(DEV), n_rays, n_samples).cpu().view(n_rays, n_samples, 4)
+    scale = float(ref[..., 3].abs().max())
+    e, e32 = float((raw[..., 3] - ref[..., 3]).abs().max()), float((raw32[..., 3] - ref[..., 3]).abs().max())
+    record_err(f"fp16x3_small_activations_{s:g}:sigma", e, scale=scale)
+    print(f"activations x {s:g}: default-path sigma err {e:.2e} (fp32 kernel {e32:.2e}; |sigma| max {scale:.2f}); fallbacks {fell_back}")
+    assert e < 1e-4 * max(1.0, scale) and e < 10 * e32 + 2e-5 * max(1.0, scale), (e, e32, fell_back)
