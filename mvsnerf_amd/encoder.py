@@ -672,6 +672,7 @@ _LAYER_BF16 = [False]      # conv1 ... conv11 on the bf16 matrix cores (csrc/con
 F16X3_LAYERS = True        # A/B switch: conv1 / conv2 of a no-grad "auto" encode on the guarded fp16x3 LDS-tiled kernel (csrc/conv_f16x3_tiled.hip)
 F16X3_MIN_VOXELS = 262144  # ... from this many OUTPUT voxels on (below, the layer is a few microseconds on any kernel and the persistent grid of 512 workgroups is mostly idle)
 _LAYER_F16X3 = [None]      # None, or "guarded" / "plain" for the extent of CostRegNet._run (set by _layers_f16x3)
+_F16X3_CONSUME = [1]       # 0 while conv1 runs inside CostRegNet._run: conv2 (same output size, hence guarded as well) counts / re-arms for both
 
 
 class _layers_f16x3:
@@ -731,7 +732,7 @@ def _conv(src1, src2, dims_in, cin_ld, wbuf, cin_k, cout_k, stride, packed=None,
         if how == "guarded":
             w32 = packed.get_mfma("fwd") if cin_k == 8 else (wbuf() if callable(wbuf) else wbuf)      # the layouts of the layer's fp32 kernels
             check(lib.mvsnerf_conv3d_f16x3_guarded_fwd(x, sc, sh, cin_k, cin_ld, D, H, W, packed.get_f16x3().data_ptr(), w32.data_ptr(), cout_k, stride,
-                                                       out.data_ptr(), part.data_ptr(), ops.guard_words(out.device).data_ptr(), 1, stream_ptr()),
+                                                       out.data_ptr(), part.data_ptr(), ops.guard_words(out.device).data_ptr(), _F16X3_CONSUME[0], stream_ptr()),
                   "conv3d_f16x3_guarded_fwd")
         else:
             check(lib.mvsnerf_conv3d_f16x3_fwd(x, sc, sh, cin_k, cin_ld, D, H, W, packed.get_f16x3().data_ptr(), cout_k, stride, out.data_ptr(),
@@ -974,7 +975,13 @@ class CostRegNet(nn.Module):
             buf, ld = _as_channel_last(x, self.conv0._packed_cin_pad())
             c0 = self.conv0.lazy(buf, (D, H, W, ld), ld)
         with _layer_precision(ENCODER_PRECISION == "bf16" and BF16_LAYERS), _layers_f16x3(f16):     # use_amp: conv1 ... conv11 on the bf16 matrix cores as well (csrc/conv3d_bf16.hip)
-            c1 = self.conv1.lazy(c0, c0.dims, 8)
+            # one guard_consume launch for the conv1 + conv2 pair when conv2 is sure to run guarded as well (same output size, both layers in batch-statistics
+            # mode): a guard set by conv1 then also makes conv2 take its fp32 kernel, and conv2's sequence counts the event and re-arms
+            _F16X3_CONSUME[0] = 0 if (f16 == "guarded" and self.conv1.bn.training and self.conv2.bn.training and FUSED_ABN_STATS) else 1
+            try:
+                c1 = self.conv1.lazy(c0, c0.dims, 8)
+            finally:
+                _F16X3_CONSUME[0] = 1
             c2 = self.conv2.lazy(c1, c1.dims, 16)
             c3 = self.conv3.lazy(c2, c2.dims, 16)
             c4 = self.conv4.lazy(c3, c3.dims, 32)
