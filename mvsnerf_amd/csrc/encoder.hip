@@ -1118,8 +1118,16 @@ __device__ __forceinline__ G8 wg_load_g(const ActSrc& g1, const ActSrc& g2, cons
     return g;
 }
 
+// Built without packed fp32 instructions: with them the compiler broadcasts w[k] through `v_pk_fma_f32 ... op_sel:[0,1,0]` (the high half of src1 feeding
+// the low result), the one packed form that returns wrong values in lanes 48-63 while the fp16x3 conv0 runs on another stream
+// (profiles/r05_pk_fma_opsel_reproducer.txt).  csrc/check_isa.sh fails the build if that form shows up in any code object of the library.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MVS_NO_PACKED_FP32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define MVS_NO_PACKED_FP32                                  // the host pass does not know the device feature
+#endif
 template <int S>
-__global__ __launch_bounds__(256) void conv3d_wgrad_rows_kernel(ActSrc g1, ActSrc g2, int A, ActSrc x1, ActSrc x2, int B, int ldx,
+__global__ __launch_bounds__(256) MVS_NO_PACKED_FP32 void conv3d_wgrad_rows_kernel(ActSrc g1, ActSrc g2, int A, ActSrc x1, ActSrc x2, int B, int ldx,
                                                                int Do, int Ho, int Wo, int Di, int Hi, int Wi, int nb4, int R,
                                                                float* __restrict__ partial)
 {

@@ -72,3 +72,15 @@ def test_plane_sweep_code_object_has_no_packed_fp32_arithmetic():
     assert "planesweep_kernel" in isa and "planesweep_if_kernel" in isa
     packed = re.findall(r"\bv_pk_\w+_f32\b", isa)
     assert not packed, f"{len(packed)} packed fp32 instructions in the plane sweep's code object: {sorted(set(packed))}"
+
+
+def test_no_code_object_selects_the_high_half_of_src1_in_packed_fp32():
+    """`v_pk_{fma,mul,add}_f32 ... op_sel:[x,1...]` (src1's high half feeding the low result) is the packed fp32 form that returned wrong values in lanes
+    48-63 next to the fp16x3 conv0 of another stream (scratch/r5/pk_probe.hip, profiles/r05_pk_fma_opsel_reproducer.txt); the compiler picks the form, so
+    the shipped bits are disassembled: csrc/check_isa.sh, which the Makefile also runs after linking."""
+    csrc = os.path.join(ROOT, "mvsnerf_amd", "csrc")
+    assert "check_isa.sh $@" in open(os.path.join(csrc, "Makefile")).read(), "the link rule lost its ISA check"
+    r = subprocess.run(["sh", os.path.join(csrc, "check_isa.sh"), _lib.LIB_PATH, os.path.join(csrc, "build", "isa_test")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    n = int(re.search(r"check_isa: (\d+) code objects", r.stdout).group(1))
+    assert n >= 18, r.stdout
