@@ -1,4 +1,7 @@
-"""scratch/r5/pk_probe.hip on a GPU box: the packed-vs-scalar recurrence quiet, next to the fp16x3 conv0 (16-bit MFMA) on a second stream, and next to the fp32-MFMA MLP kernel."""
+"""scratch/r5/pk_probe.hip on a GPU box: the packed-vs-scalar recurrence of every packed fp32 form, quiet and next to one aggressor kernel on a second stream
+(fp16x3 conv0, fp32 / bf16 / fp16x3 MLP).  Result: profiles/r05_pk_fma_opsel_reproducer.txt.
+Build (here, cross-compiled):  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared scratch/r5/pk_probe.hip -o scratch/r5/libpk_probe.so
+Run:  gpurun -- 'python scratch/r5/pk_probe.py'  (about 15 s of GPU time)"""
 import ctypes, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); os.chdir(ROOT)
 from mvsnerf_amd import _lib
