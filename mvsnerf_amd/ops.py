@@ -539,10 +539,12 @@ def render_pixels(vol_cl, imgs, w2cs, intrinsics, packed, H, W, K_tgt, c2w_tgt, 
     f32 = dict(device=dev, dtype=torch.float32)
     B = int(min(batch_rays, max(n, 1)))
     ws_n = lib.mvsnerf_render_workspace_floats(B, N_samples, V)
-    key = (ws_n, str(dev))
+    # one workspace per (size, device, STREAM): two streams rendering on one device must not share intermediates (same reason as guard_words)
+    key = (ws_n, dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
     ws = _render_ws.get(key)
     if ws is None:
-        _render_ws.clear()
+        while len(_render_ws) >= 4:
+            _render_ws.pop(next(iter(_render_ws)))
         ws = _render_ws[key] = torch.empty(ws_n, **f32)
     out = {"rgb": torch.empty((n, 3), **f32)}
     for k in ("depth", "acc", "disp"):

@@ -55,7 +55,7 @@ def test_product_path_does_not_import_oracle():
 
 def test_plane_sweep_code_object_has_no_packed_fp32_arithmetic():
     """csrc/planesweep.hip must be built without packed fp32 instructions: next to 16-bit MFMA waves of another stream or process they computed wrong lanes
-    (DESIGN.md section 9, tests/test_gpu_costream.py is the GPU side).  The Makefile carries the flag and greps the code object; this compiles the file to ISA with
+    (DESIGN.md section 8, tests/test_gpu_costream.py is the GPU side).  The Makefile carries the flag and greps the code object; this compiles the file to ISA with
     the Makefile's own flags (hipcc cross-compiles without a GPU) and looks again."""
     csrc = os.path.join(ROOT, "mvsnerf_amd", "csrc")
     mk = open(os.path.join(csrc, "Makefile")).read()

@@ -137,6 +137,40 @@ def test_guarded_rendering_and_frame_render(net20):
             assert torch.equal(d[k], want[k]), k
 
 
+def test_two_streams_do_not_share_a_render_workspace(net20):
+    """The intermediates of mvsnerf_render_pixels_fwd (rays, gathered features, MLP outputs of a sub-batch) live in a workspace the Python layer keeps
+    between calls; like the guard words it is per (device, stream).  Two streams render different pixel ranges of the same view, enqueued alternately so
+    that their sub-batches overlap: every result must equal the single-stream render of its range, bit for bit."""
+    from mvsnerf_amd import ops
+    from mvsnerf_amd.synth import make_rig, pose_ref_of
+    g = torch.Generator().manual_seed(3)
+    H, W, S, pad = 48, 64, 24, 4
+    rig = make_rig(H, W, seed=11, rot_deg=2.0, smooth=True)
+    pd = {k: v.to(DEV) for k, v in pose_ref_of(rig).items()}
+    vol_cl = ops.channels_last_volume(torch.randn((1, 8, 16, H // 4 + 2 * pad, W // 4 + 2 * pad), generator=g).to(DEV))
+    im = rig["images_raw"][0, :3].to(DEV)
+    args = (vol_cl, im, pd["w2cs"][:3].contiguous(), pd["intrinsics"][:3].contiguous(), net20.packed(20), H, W, pd["intrinsics"][-1], pd["c2ws"][-1],
+            pd["intrinsics"][-1], pd["w2cs"][0], pd["near_fars"][-1], pd["near_fars"][0], S)
+    ranges = (dict(first_pixel=0, n_pixels=1536), dict(first_pixel=1536, n_pixels=1536))
+    common = dict(pad=pad, batch_rays=512, want=("depth",))
+    with torch.no_grad(), ops.mlp_precision("auto"):
+        alt = net20.packed_alt(20)                                     # packed on the default stream, before the side streams start
+        want = [ops.render_pixels(*args, **alt, **r, **common) for r in ranges]
+        torch.cuda.synchronize()
+        streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        got = ([], [])
+        for _ in range(8):
+            for k in (0, 1):
+                with torch.cuda.stream(streams[k]):              # packed_alt here: the weights are cached, the guard words are this stream's
+                    got[k].append(ops.render_pixels(*args, **net20.packed_alt(20), **ranges[k], **common))
+        torch.cuda.synchronize()
+    keys = {key for key in ops._render_ws}
+    assert len({key[2] for key in keys}) >= 2, "one workspace per stream expected"
+    for k in (0, 1):
+        for d in got[k]:
+            assert torch.equal(d["rgb"], want[k]["rgb"]) and torch.equal(d["depth"], want[k]["depth"])
+
+
 def test_out_of_range_scene_encode_returns_the_fp32_volume():
     """`a scene scaled so that variance channels exceed 2^20`.  FeatureNet's last layer (1x1 `toplayer`, no norm) is scaled by
     2000: features x 2000, variance channels x 4e6 (beyond 2^20 * 16 ... 1e9).  The default no-grad encode must return what the fp32 kernels
