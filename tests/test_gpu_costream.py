@@ -6,6 +6,7 @@ SIMD - 192 of 192 sweeps with the conv0 running on a second stream of the same p
 kernels apart).  Compiled without packed fp32 arithmetic (planesweep.hip is built with -fno-slp-vectorize) it is bit-identical and never differs.
 This test is that two-stream experiment: it fails on every iteration if the packed instructions come back."""
 import pytest
+import os
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -59,6 +60,19 @@ def _aggressor():
     from mvsnerf_amd import encoder as E
     from mvsnerf_amd.ops import stream_ptr
     from tests.test_gpu_bf16_encoder import _sweep_inputs
+    hog = os.environ.get("MVSNERF_TEST_MFMA_HOG")
+    if hog:
+        # the distilled trigger instead (scratch/r5/pk_hog.hip built as a shared object: waves that only spin on v_mfma_f32_16x16x32_f16, four per SIMD) -
+        # three to four orders of magnitude more wrong results in a vulnerable victim than the conv0 (profiles/r05_pk_fma_opsel_reproducer.txt)
+        import ctypes
+        Hg = ctypes.CDLL(os.path.abspath(hog))
+        Hg.pk_hog_launch.argtypes = [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_void_p]
+        sink = torch.zeros(4, device=DEV)
+
+        def run_hog(n):
+            for _ in range(n):
+                assert Hg.pk_hog_launch(32, 2, 4096, 1, 0, 1000, sink.data_ptr(), stream_ptr()) == 0
+        return run_hog
     L = _lib.lib()
     V, H, W, D, pad = 3, 128, 160, 128, 24
     imgs, feats, proj, dv = _sweep_inputs(V, H, W, D, pad, seed=5)
