@@ -1039,7 +1039,7 @@ def main():
             try:
                 big = copy.deepcopy(net)
                 with torch.no_grad():
-                    big.nerf.pts_linears[1].weight.mul_(3e4)                     # h1 ~ 1e5: beyond fp16 in the layer epilogue
+                    big.nerf.pts_linears[1].weight[0, 0] = float("inf")          # round 6: only a non-finite weight / value still trips the MLP's guard (exponent management)
                 big.invalidate_packed()
                 def step_big(i):
                     pts, ndc, z, ro, rdir = batches[i % n_batches]
@@ -1054,7 +1054,7 @@ def main():
                     torch.cuda.synchronize(); gdt = (time.perf_counter() - g0) / 100
                 fb1 = ops.guard_fallbacks()
                 trip = {"mlp": {"ms_per_step": round(gdt * 1e3, 4), "rays_per_s": round(N_RAYS / gdt, 1), "fallbacks_in_110_steps": fb1 - fb0,
-                                "note": "rendering() in the default mode with a network whose activations leave fp16's range: fp16x3 kernel + the fp32-MFMA kernel "
+                                "note": "rendering() in the default mode with a network that holds a non-finite weight (all that still trips the MLP's guard): fp16x3 kernel + the fp32-MFMA kernel "
                                         "(mlp_fwd_pipe_if_kernel: 9-16 spilled VGPRs) on every batch; compare extras.guarded_default_mlp_mode.ms_per_step (untripped) and ms_per_step (fp32 alone)"}}
                 del big
                 if enc_ready:

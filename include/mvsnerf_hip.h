@@ -549,9 +549,10 @@ int mvsnerf_raymarch_fwd_batched(const mvsnerf_raymarch_args* a, int K, void* st
  *
  * n_split = MVSNERF_SPLIT_FP16 ("fp16x3", mlp_f16x3.hip): TWO FP16 pieces per operand, both rounded to nearest, and the three piece products
  * a0*w0 + a0*w1 + a1*w0 on v_mfma_f32_32x32x16_f16.  fp16 carries 11 significant bits, so two pieces hold 22 and what is dropped is
- * <= 2^-22 of a product - fp32-grade like n_split = 3, at half the matrix-core work - in exchange for fp16's RANGE: operands above 65504
- * saturate, lo pieces of operands below 2^-3 are fp16 subnormals (kept by gfx950's matrix cores).  The shipped network's activations
- * stay below 200; a network that leaves the window wants n_split = 3. */
+ * <= 2^-22 of a product - fp32-grade like n_split = 3, at half the matrix-core work.  fp16's five exponent bits are handled inside (ABI v12):
+ * every K-block of the weights is stored with an exact power-of-two scale chosen at pack time, every point's activations are re-scaled by a power
+ * of two whenever their largest magnitude leaves [2^-3, 2^12]; the scales are carried through the layers and divided out in the two heads.  Only a
+ * non-finite weight or value is beyond the kernel (reported through the guard of the guarded sequences below). */
 #define MVSNERF_SPLIT_FP16 18
 size_t mvsnerf_mlp_packed_split_elems(int F, int n_split);
 int mvsnerf_mlp_pack_split(const float* const w[11], int F, int n_split, void* packed_split, void* stream);
@@ -575,10 +576,10 @@ int mvsnerf_adam_step_multi(int n, float* const* p, const float* const* g, float
  * stage are enqueued right behind them PREDICATED on guard[0] (they leave at once when it is 0, and overwrite the results when it is set); the
  * last kernel of the sequence counts the event in guard[1] and re-arms guard[0] = 0.  The caller reads results that are the fp32 kernels'
  * whenever the 16-bit ones were out of range, and may read guard[1] (number of sequences that fell back) whenever it synchronises anyway.
- * What trips the guard (ABI v11): (a) RANGE - an operand, weight or layer output beyond what an fp16 piece holds after the kernel's scaling; (b) the MLP kernel
- * also reports a layer whose inputs are ALL small: a second piece below 2^-14 is a subnormal with an absolute resolution of 2^-24, so when the largest
- * activation a layer hands on (over a wave's 32 points) is non-zero and below 2^-7 its products carry more than 2^-18 of the layer's scale and the batch is
- * re-run in fp32 (a network with hidden activations 1e-4 of the shipped one's falls back; at 1e-2 it does not and stays within 1.5e-5 of the oracle).
+ * What trips the guard: the conv kernels report RANGE - an operand, weight or layer output beyond what an fp16 piece holds after the kernel's scaling.  The
+ * MLP kernel (ABI v12) manages exponents itself (see MVSNERF_SPLIT_FP16 above) and reports only a non-finite weight (status tail of the pack) or value:
+ * a network with hidden activations 1e-4 or 1e+5 times the shipped one's stays on the fp16 kernel and within 2e-6 of the oracle
+ * (through ABI v11 both were re-run in fp32: Kaiming-initialised networks paid for both kernels on every batch).
  * ONE GUARD BUFFER PER STREAM: guard[0] is armed, read and re-armed in stream order only (guard[1] += 1 is a plain store of the last kernel), so
  * sequences enqueued on different streams - or by different host threads - must be given different buffers; sharing one lets stream B re-arm the
  * word between stream A's 16-bit kernel setting it and A's predicated fp32 kernel reading it.  mvsnerf_amd.ops.guard_words() keeps one buffer per

@@ -42,7 +42,38 @@ __device__ __forceinline__ void init_acc_b(f32x16 (&acc)[NBLK], const float* __r
         }
 }
 
-__device__ __forceinline__ float pe_sc(float x, int want_cos)      // same routine as mlp.hip
+// sin / cos of x * 2^f (Embedder, models.py:47-51) on the transcendental unit.  v_sin_f32 takes REVOLUTIONS and is good to 1.25e-7 absolute over a period
+// (scratch/r6/sin_probe.hip, pe_probe.hip; the polynomial routine of mlp.hip: ~22 instructions per value, this: 7); what matters is the range reduction, done exactly:
+// u = x / (2 pi) is kept as an unevaluated sum hi + lo (two-constant product with the rounding error of the first recovered by FMA: ~45 bits), hi * 2^f is exact,
+// its fractional part is exact, and lo * 2^f joins by one FMA - the argument of v_sin_f32 is off by half an ulp of a number below one (1.5e-8 revolutions).
+// |x| is clamped to 2^15 (beyond it 2^9 x / 2 pi has no fraction bits).
+struct PeArg { float hi, lo; };
+__device__ __forceinline__ PeArg pe_arg(float x)
+{
+#pragma clang fp contract(off)      // hi must be the ROUNDED product: a fused x * (C_HI * 2^f) + 1/4 downstream would count its rounding error twice (4.8e-5 at f = 9)
+    x = fminf(fmaxf(x, -32768.0f), 32768.0f);
+    constexpr float C_HI = 0x1.45f306p-3f, C_LO = 0x1.b9391p-28f;          // 1 / (2 pi) = C_HI + C_LO + O(2^-52)
+    PeArg a;
+    a.hi = x * C_HI;
+    asm("" : "+v"(a.hi));                                                    // (and opaque, so that no later pass re-derives it from x)
+    a.lo = __builtin_fmaf(x, C_LO, __builtin_fmaf(x, C_HI, -a.hi));
+    return a;
+}
+__device__ __forceinline__ float pe_sc(PeArg a, int f, int want_cos)
+{
+#pragma clang fp contract(off)
+    const float two_f = (float)(1 << f);
+    const float t = a.hi * two_f;                                            // exact
+    const float fr = t - __builtin_rintf(t);                                 // exact, in [-0.5, 0.5]: where v_sin_f32 is at its best (1.7e-7; on [0.5, 1): 4e-7)
+    const float r = __builtin_fmaf(a.lo, two_f, fr);
+    // cos(2 pi r) = sin(2 pi (1/4 - |r|)), again inside [-1/4, 1/4].  (Adding the quarter turn BEFORE the reduction - t + 1/4 - is not exact where the sum crosses a
+    // power of two: 4.8e-5 at f = 9, scratch/r6/pe_probe.hip.)
+    return __builtin_amdgcn_sinf(want_cos ? 0.25f - __builtin_fabsf(r) : r);
+}
+
+// the polynomial routine of mlp.hip (rounds 1-5): what the bf16 kernels keep (their parity test pins them to a torch emulation of bf16 rounding within 2e-3,
+// and one rounding boundary crossed by a 1e-7 difference in an input moves an output by more)
+__device__ __forceinline__ float pe_sc_poly(float x, int want_cos)
 {
     x = fminf(fmaxf(x, -65536.0f), 65536.0f);
     const float k = rintf(x * 0.63661977236758134f);
@@ -57,13 +88,18 @@ __device__ __forceinline__ float pe_sc(float x, int want_cos)      // same routi
     return (q & 2) ? -v : v;
 }
 
-__device__ __forceinline__ float pe_op(int t, int half, float px, float py, float pz)
+// operand t of the lane half: t = 0: (x, y), 1: (z, 0), t >= 2: (sin, cos) of coordinate (t - 2) % 3 at frequency 2^((t - 2) / 3)
+template <bool HW_SIN>
+__device__ __forceinline__ float pe_op_t(int t, int half, float px, float py, float pz)
 {
     if (t == 0) return half ? py : px;
     if (t == 1) return half ? 0.0f : pz;
     const int j = t - 2, f = j / 3, c = j - 3 * f;
-    return pe_sc((c == 0 ? px : c == 1 ? py : pz) * (float)(1 << f), half);
+    const float x = c == 0 ? px : c == 1 ? py : pz;
+    return HW_SIN ? pe_sc(pe_arg(x), f, half) : pe_sc_poly(x * (float)(1 << f), half);
 }
+__device__ __forceinline__ float pe_op(int t, int half, float px, float py, float pz) { return pe_op_t<false>(t, half, px, py, pz); }
+__device__ __forceinline__ float pe_op_hw(int t, int half, float px, float py, float pz) { return pe_op_t<true>(t, half, px, py, pz); }
 
 }  // namespace mlp
 

@@ -3,7 +3,7 @@
 // ATen launches).
 #include "common.h"
 
-extern "C" int mvsnerf_abi_version(void) { return 11; }
+extern "C" int mvsnerf_abi_version(void) { return 12; }
 
 // internal pieces of the guarded 16-bit sequences (include/mvsnerf_hip.h)
 int mvs_mlp_f16x3_fwd(const void* packed_h, const float* packed_f32, int F, const float* ndc, int ndc_stride, const float* feat, int feat_stride,

@@ -323,10 +323,11 @@ _MODES = ("auto", "fp32", "bf16", "bf16x3", "bf16x6", "fp16x3")
 def set_mlp_precision(mode):
     """Select the matrix-core arithmetic of the MLP:
       "auto"    (default) a step that needs gradients runs "fp32"; a no-grad rendering / network query runs the GUARDED fp16x3 sequence:
-                the two-piece fp16 kernel (fp32-grade results, 2.5x the fp32-MFMA rate) reports any operand outside fp16's range through
-                a device-side guard word, and the fp32-MFMA kernel enqueued right behind it - predicated on that word - recomputes the
-                batch when it is set.  No host synchronisation, results never saturate (include/mvsnerf_hip.h, "guarded 16-bit
-                sequences"); ops.guard_fallbacks() tells how often the fp32 kernel had to step in.
+                the two-piece fp16 kernel (fp32-grade results, 2.5x the fp32-MFMA rate; operands and weights carry exact power-of-two
+                scales, so fp16's exponent range is not a limit) reports what it cannot represent - a non-finite weight or value -
+                through a device-side guard word, and the fp32-MFMA kernel enqueued right behind it - predicated on that word -
+                recomputes the batch when it is set.  No host synchronisation (include/mvsnerf_hip.h, "guarded 16-bit sequences");
+                ops.guard_fallbacks() tells how often the fp32 kernel had to step in.
       "fp32"    v_mfma_f32_32x32x2_f32 everywhere (the arithmetic of bench.py's headline and of the parity tests that pin the fp32 kernel)
       "bf16"    v_mfma_f32_32x32x16_bf16, operands rounded to bf16 (BASELINE configs 3/4; ~1e-2 errors); in training this is the
                 reference's AMP switch (train_mvs_nerf_pl.py:317-318): forward, data- and weight-gradient GEMMs on bf16 operands
@@ -334,7 +335,7 @@ def set_mlp_precision(mode):
       (the split modes below are inference-only)
       "bf16x6"  split-bf16 fp32 emulation: operands as 3 bf16 pieces, 6 bf16 MFMAs per product (fp32-grade results, fp32's range)
       "bf16x3"  2 bf16 pieces, 3 MFMAs (~1e-5 relative)
-      "fp16x3"  the UNGUARDED two-piece fp16 kernel alone: operands above 65504 saturate (csrc/mlp_f16x3.hip)"""
+      "fp16x3"  the UNGUARDED two-piece fp16 kernel alone (csrc/mlp_f16x3.hip)"""
     global MLP_PRECISION
     if mode not in _MODES:
         raise ValueError(f"mlp precision must be one of {_MODES}")

@@ -25,7 +25,7 @@ def test_library_builds_and_exports_header_symbols():
     missing = [n for n in names if not hasattr(l, n)]
     assert not missing, f"declared in the header but not exported: {missing}"
     assert sorted(_lib.SIGNATURES) == names, (set(names) ^ set(_lib.SIGNATURES))
-    assert _lib.lib().mvsnerf_abi_version() == 11
+    assert _lib.lib().mvsnerf_abi_version() == 12
     # the dynamic symbol table is the header and nothing else (csrc/exports.map): no kernel host stubs, no C++-mangled helpers, no
     # A/B switches or diagnostics state
     exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout

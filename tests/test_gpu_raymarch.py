@@ -47,7 +47,7 @@ def _args(**kw):
 def test_library_loaded_is_in_tree():
     from mvsnerf_amd import _lib
     l = _lib.lib()
-    assert l.mvsnerf_abi_version() == 11
+    assert l.mvsnerf_abi_version() == 12
     assert "mvsnerf_amd/lib/libmvsnerf_hip.so" in open("/proc/self/maps").read()
 
 
