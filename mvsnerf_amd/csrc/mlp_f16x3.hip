@@ -32,6 +32,7 @@
 // this chip (the same loop on zeros: 2.40; the clock drops from 2.4 to ~1.6 GHz at unchanged cycles per instruction), with this kernel's ds_reads and VALU beside
 // it 1.43-1.46: 0.57-0.63 of the nominal 2.5 PFLOP/s is the ceiling of ANY fp16 matrix kernel on real data here, and re-arranging who stalls when (rounds 3-5: anti-phase
 // wave groups, block groupings, priorities; round 6: a stall-free software-pipelined stream) moves cycles but not joules.
+#include <type_traits>
 #include "common.h"
 #include "lds_dma.h"
 #include "mlp_layout.h"
@@ -315,9 +316,9 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
 #endif
     H3_STAMP();                                   // 0: wave start
 
-    // slab 0 = pts_bias weights + layer 0 (contiguous in the packed buffer) -> buf0, layer 1 -> buf1: both buffers are free
+    // slab 0 = pts_bias weights + layer 0 (contiguous in the packed buffer) -> buf0.  (Layer 1's slab follows behind the first barrier: every workgroup of the
+    // launch asks the L2 for the same bytes at the same moment, and the wait for slab 0 is the longest single wait of a wave's life.)
     slab_dma(buf0, wq + L.s0, L.l1 - L.s0, wave, lane);
-    slab_dma(buf1, wq + L.l1, 2 * ACT_PLANE, wave, lane);
     // The two waves of a SIMD share one matrix pipe and the OLDER one (waves 0..3 of the workgroup, dispatched first; priority 1 makes it explicit) wins every
     // arbitration between two matrix streams (a wave raises its priority for the length of a GEMM, so that a matrix stream also beats the partner's epilogue): measured, the pair runs its GEMMs one after the other (profiles/r06_mlp_f16x3_census.txt).  The layer barrier is therefore placed differently
     // for the two: an older wave runs [GEMM, epilogue, barrier], a younger one [GEMM, barrier, epilogue] - the barrier falls when the younger wave's GEMM ends, the
@@ -423,9 +424,9 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
         BP fb[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) fb[s] = split8h(fv + 8 * s);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                              // this wave's pieces of slab 0 (layer 1's eight are behind them)
-        __syncthreads();                                                              // slab 0 and the vectors have landed
+        slab_sync();                                                                  // slab 0 and the vectors have landed
         H3_STAMP();
+        slab_dma(buf1, wq + L.l1, 2 * ACT_PLANE, wave, lane);                         // layer 1 -> buf1
         init_acc_b<4>(acc, vec + V_BIASG + half * 64);
         if (scaled) {
             const float fa = pow2f(k + kwb);
@@ -476,31 +477,37 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
         H3_STAMP();
     }
     // layers 1..4: slabs alternate buf1, buf0, buf1, buf0; behind layer l's GEMM its buffer takes the slab after next (layer l + 2; layer 5's encoding part;
-    // layer 5's h part)
-#pragma unroll 1
-    for (int layer = 1; layer <= 4; ++layer) {
+    // layer 5's h part).  Layer 4 is peeled off the rolled loop: behind its GEMM the encoding comes back from the stash (inside the loop its 32 registers would be
+    // live through every iteration).
+    auto hidden_layer = [&](int layer, auto last) {
+        constexpr bool LAST = decltype(last)::value;
         char* cur = (layer & 1) ? buf1 : buf0;
         auto refill = [&]() {
             slab_sync();
-            if (layer < 3) slab_dma(cur, wq + L.l1 + (size_t)(layer + 1) * 2 * ACT_PLANE, 2 * ACT_PLANE, wave, lane);
+            if (LAST) slab_dma(cur, wq + L.l5b, 2 * ACT_PLANE, wave, lane);
             else if (layer == 3) slab_dma(cur, wq + L.l5a, 2 * PE_PLANE, wave, lane);
-            else slab_dma(cur, wq + L.l5b, 2 * ACT_PLANE, wave, lane);
+            else slab_dma(cur, wq + L.l1 + (size_t)(layer + 1) * 2 * ACT_PLANE, 2 * ACT_PLANE, wave, lane);
         };
         gemm_h<B_ACT_STEPS, 4>(cur, cur + ACT_PLANE * 2, acc, lane, first, act);
         H3_STAMP();
+        if (LAST) {                                                                   // the encoding comes back while the epilogue runs
+#pragma unroll
+            for (int s = 0; s < B_PE_STEPS; ++s) { pe[s].hi = pe_stash[2 * s]; pe[s].lo = pe_stash[2 * s + 1]; }
+        }
         if (young) refill();
         inherit(kw(SEG_L1 + layer - 1));
-        condition(finish(acc), layer == 4, kw(SEG_L5B) - kw(SEG_L5A));              // layer 5's K-vector = [encoding | h4]
-        init_acc4(acc, vec + V_L0 + 128 * (layer + 1) + half * 64, layer < 4 ? kw(SEG_L1 + layer) : kw(SEG_L5B));
-        if (layer < 4) first = split8h(h);
+        condition(finish(acc), LAST, kw(SEG_L5B) - kw(SEG_L5A));                     // layer 5's K-vector = [encoding | h4]
+        init_acc4(acc, vec + V_L0 + 128 * (layer + 1) + half * 64, LAST ? kw(SEG_L5B) : kw(SEG_L1 + layer));
+        if (!LAST) first = split8h(h);
         H3_STAMP();
         if (!young) refill();
         H3_STAMP();
-    }
+    };
+#pragma unroll 1
+    for (int layer = 1; layer <= 3; ++layer) hidden_layer(layer, std::false_type());
+    hidden_layer(4, std::true_type());
     float sigma;
     {   // layer 5 on cat([pts, h4]): L5a in buf1, L5b in buf0
-#pragma unroll
-        for (int s = 0; s < B_PE_STEPS; ++s) { pe[s].hi = pe_stash[2 * s]; pe[s].lo = pe_stash[2 * s + 1]; }
         // the encoding enters times sc * 2^(kw5b - kw5a) - its own weights carry 2^kw5a, the accumulators 2^kw5b: exact on the fp16 pieces while that exponent
         // is fp16's (condition(.., true, ..) keeps it inside the window or below it; far below, the encoding's share of the sum is below fp32's resolution anyway)
         const int kw5 = kw(SEG_L5B), pe_exp = lsc + kw5 - kw(SEG_L5A);
