@@ -3,7 +3,7 @@
 # Fails if any gfx950 code object bundled in the library holds `v_pk_{fma,mul,add}_f32 ... op_sel:[x,1...]`: src1's HIGH half feeding the LOW result.
 # That operand select is the one packed fp32 form measured to return wrong values (lanes 48-63 only) while ANOTHER wave of the same SIMD issues
 # v_mfma_f32_16x16x32_{f16,bf16} - from another stream or process; no other matrix shape does it; the unselected forms, op_sel on
-# src0 / src2, op_sel_hi and neg are clean (scratch/r5/pk_probe.hip + pk_hog.hip, profiles/r05_pk_fma_opsel_reproducer.txt).  The compiler picks the form, so the
+# src0 / src2, op_sel_hi and neg are clean (scratch/keep/pk_probe.hip + pk_hog.hip, profiles/r05_pk_fma_opsel_reproducer.txt).  The compiler picks the form, so the
 # check is on the shipped bits.
 set -e
 LIB="$1"; DIR="$2"

@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "../../include/mvsnerf_hip.h"
+#include "../../include/mvsnerf_hip_internal.h"      // (includes the stable tier, mvsnerf_hip.h)
 
 #define MVS_LAUNCH_CHECK()                                  \
     do {                                                    \

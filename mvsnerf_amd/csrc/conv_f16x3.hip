@@ -7,7 +7,7 @@
 //     x = x0 + x1 (+ 2^-22 |x|),  x0 = fp16(x), x1 = fp16(x - x0);   w likewise;      x * w ~= x0*w0 + x0*w1 + x1*w0      (dropped: x1*w1 <= 2^-22 |x w|)
 //
 // Three v_mfma_f32_16x16x32_f16 per product, exact piece products, fp32 accumulation.  Evaluated on the CPU first, at config 2 with the shipped
-// weights (scratch/r3/conv0_f16x3_numerics.py, piece convolutions in float64): the raw conv0 output is 1.1e-4 from the float64 convolution (of values up
+// weights (scratch/keep/conv0_f16x3_numerics.py, piece convolutions in float64): the raw conv0 output is 1.1e-4 from the float64 convolution (of values up
 // to 2215) where the fp32 reference path (oneDNN) is 1.3e-3; the neural volume built on it is 5.7e-6 from the fp32 oracle's - what a conv0 evaluated
 // EXACTLY differs from it (5.3e-6): the split is below the noise of an fp32 summation order.
 //

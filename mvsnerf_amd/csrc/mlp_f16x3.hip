@@ -8,7 +8,7 @@
 //     a = a0 + a1 + r,   a0 = fp16(a),  a1 = fp16(a - a0),   |r| <= 2^-22 |a|      (fp16 carries 11 significant bits; a - a0 is exact)
 //     a * w  ~=  a0*w0 + a0*w1 + a1*w0                                              (dropped: a1*w1 <= 2^-22 |a*w|)
 // The piece products are exact in fp32 and the matrix core accumulates them in fp32, so a product is off by ~3 * 2^-22 - the same order as
-// the roundings of an fp32 kernel (scratch/r3/f16x3_numerics.py on the shipped weights: sigma 2.4e-6 from the float64 result, the torch
+// the roundings of an fp32 kernel (scratch/keep/f16x3_numerics.py on the shipped weights: sigma 2.4e-6 from the float64 result, the torch
 // fp32 path 2.9e-6, the two-piece BF16 split 1.2e-4).  The three-piece bf16 split of mlp_bf16.hip ("bf16x6") needs six instructions of the
 // same rate for that.
 //
@@ -184,7 +184,7 @@ __device__ __forceinline__ BP split8h(const float* v8)
     return r;
 }
 
-// DEV probe (scratch/r3/build_variant.sh; never defined in the product build): -DH3_NO_DMA fetches no weight slab at all (garbage results) - the
+// DEV probe (scratch/r6/build_variant.sh; never defined in the product build): -DH3_NO_DMA fetches no weight slab at all (garbage results) - the
 // floor of MFMA + VALU + barriers.  Measured without effect and removed: per-workgroup rotation of the piece order, non-temporal DMA loads.
 __device__ __forceinline__ void slab_dma(char* __restrict__ dst, const _Float16* __restrict__ src, size_t n_elems, int wave, int lane)
 {
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
     constexpr size_t ACT_PLANE = (size_t)B_ACT_STEPS * 4 * 512, PE_PLANE = (size_t)B_PE_STEPS * 4 * 512;     // fp16 elements of one plane
     constexpr size_t VIEW_PLANE = (size_t)B_VIEW_STEPS * 2 * 512;
     const size_t feat_plane = b_seg(L.fsteps, 4);
-#ifdef H3_CENSUS      // DEV probe: shader-clock stamps of this wave's phases, 32 per tile, behind the results (scratch/r3/h3_census.py allocates them)
+#ifdef H3_CENSUS      // DEV probe: shader-clock stamps of this wave's phases, 32 per tile, behind the results (scratch/r6/h3_census.py allocates them)
     unsigned* cen = reinterpret_cast<unsigned*>(raw + P * (ALPHA_ONLY ? 1 : 4)) + ((int64_t)blockIdx.x * H3_WAVES + wave) * 32;
     int cen_i = 0;
 #define H3_STAMP() do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if (lane == 0 && cen_i < 32) cen[cen_i] = (unsigned)t__; ++cen_i; } while (0)

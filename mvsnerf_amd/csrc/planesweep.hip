@@ -52,7 +52,7 @@ __device__ __forceinline__ void planesweep_tile(
                                         // 3: two fp16 pieces of x / 16 in that layout (mvsnerf_planesweep_costvar_f16x2_fwd)
     int* __restrict__ guard)            // blocked 3 in a guarded sequence (include/mvsnerf_hip.h): guard[0] = 1 when a value did not fit an fp16 piece
 {
-    // fp32 arithmetic of the CPU reference path, operation for operation (scratch/r3/cpu_arith_probe.py, cpu_var_probe.py compare candidate
+    // fp32 arithmetic of the CPU reference path, operation for operation (scratch/keep/cpu_arith_probe.py, cpu_var_probe.py compare candidate
     // formulas with reference-generated fixtures BIT FOR BIT): the projection is a k-ordered fma chain (sgemm), grid_sample's blend is
     // fma(se, w_se, fma(sw, w_sw, fma(ne, w_ne, nw * w_nw))), and everything in models.py:879-890 is one ATen op per rounding
     // (x**2, +, *count, -): no contraction anywhere else.

@@ -98,7 +98,7 @@ __device__ __forceinline__ void dir_feature_of(const float* __restrict__ d3, con
 
 
 // Fold of the eight trilinear terms in the arithmetic of ATen's 5-D grid_sample on the CPU (the reference path the oracle runs; pinned bit for
-// bit by scratch/r3/cpu_lookup_probe.py against the reference-generated fixtures): every term v * w is ROUNDED (no fma), w = (wx * wy) * wz,
+// bit by scratch/keep/cpu_lookup_probe.py against the reference-generated fixtures): every term v * w is ROUNDED (no fma), w = (wx * wy) * wz,
 // and the terms are added one after the other in the order (z0,y0,x0), (z0,y0,x1), (z0,y1,x0), (z0,y1,x1), (z1,...) starting from 0.
 // Lane layout of the gather kernels: a lane holds the four (z, y) products of ONE x corner (k = 2 zc + yc), its partner two lanes further
 // in the quad holds the other corner's.  The x0 lane adds its own product, then the partner's (one DPP quad swap each); the x1 lane runs the

@@ -108,7 +108,7 @@ def _sgemm_k3(R, X):
     pin: per output element the k-ordered chain  r0*x0 -> fma(r1, x1, .) -> fma(r2, x2, .)  (Intel MKL sgemm on the Xeon that ran
     oracle/gen_golden.py; tests/test_oracle_golden.py compares the resulting sampling grid with the reference-generated one BIT FOR BIT).
     The bits of `R @ X` itself depend on the host's BLAS code path - on the GPU box's AMD EPYC the same MKL rounds the two products and
-    the sums separately, 8 % of the grid values of a rotated view then differ in the last bit (scratch/r3/grid_bits_gpu.py,
+    the sums separately, 8 % of the grid values of a rotated view then differ in the last bit (scratch/keep/grid_bits_gpu.py,
     gpurun_out/r3_grid_bits.txt) - so the oracle spells the pinned arithmetic out instead of inheriting whatever the host it runs on does.
     float64 mode (`precision`): a plain matmul."""
     if R.dtype != torch.float32:
@@ -121,7 +121,7 @@ def _sgemm_k3(R, X):
 def _rows_times_mat3_t(p, M):
     """p (n,3) @ M(3,3).t() in the pinned arithmetic of the authoring host's sgemm (see _sgemm_k3): out[:, j] =
     fma(p2, M[j,2], fma(p1, M[j,1], p0 * M[j,0])).  tests/test_oracle_golden.py: the reference-generated NDC coordinates
-    (utils.py:124,128 inside build_rays) are reproduced bit for bit; scratch/r3/cpu_lookup_probe.py lists the alternatives that are not."""
+    (utils.py:124,128 inside build_rays) are reproduced bit for bit; scratch/keep/cpu_lookup_probe.py lists the alternatives that are not."""
     if p.dtype != torch.float32 or M.dtype != torch.float32:
         return p @ M.t()
     cols = []

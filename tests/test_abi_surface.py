@@ -1,5 +1,5 @@
-"""CPU-only: the C-ABI library builds/loads, exports every symbol include/mvsnerf_hip.h declares, and the ctypes
-table binds exactly that set.  No compute calls (no GPU here)."""
+"""CPU-only: the C-ABI library builds/loads, exports every symbol the two headers (include/mvsnerf_hip.h = the stable tier,
+include/mvsnerf_hip_internal.h = the internal one) declare, the stable tier is the frozen list below, and the ctypes table binds exactly that set.  No compute calls (no GPU here)."""
 import ctypes
 import os
 import re
@@ -10,10 +10,43 @@ from mvsnerf_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "mvsnerf_hip.h")).read()
+def _declared_in(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(mvsnerf_[a-z0-9_]+)\s*\(", src)))
+
+
+def _declared():
+    """every export = the stable tier (mvsnerf_hip.h) + the internal tier (mvsnerf_hip_internal.h)"""
+    return sorted(set(_declared_in("mvsnerf_hip.h")) | set(_declared_in("mvsnerf_hip_internal.h")))
+
+
+# The STABLE tier, frozen at ABI 12 (VERDICT r5 next 7): the stage-level surface of SURVEY.md 8(b).  Adding, removing or re-typing an entry of this list is an
+# ABI bump; the internal tier (per-shape kernels, *_tiles / *_parts / *_packed_elems queries, layout variants) may change freely.
+STABLE_ABI_12 = """
+abi_version ncdhw_to_ndhwc ndhwc_to_ncdhw nchw_to_nhwc resize_bilinear
+planesweep_costvar_fwd planesweep_costvar_bwd planesweep_costvar_bwd_det_workspace_words planesweep_costvar_bwd_det homo_warp_fwd
+conv3d_pack_weights conv3d_fwd conv_transpose3d_fwd abn_workspace_floats abn_stats abn_apply_add abn_apply_add_hwdc abn_bwd
+conv3d_wgrad_workspace_floats conv3d_wgrad conv2d_pack_weights conv2d_fwd conv2d_wgrad_workspace_floats conv2d_wgrad channel_sum_workspace_floats channel_sum
+raygen_fwd raygen_train_fwd volume_sample_fwd volume_sample_bwd color_sample_fwd color_feat_sample_fwd dir_feature_fwd gather_fwd posenc_fwd
+mlp_packed_floats mlp_pack mlp_fwd mlp_packed_bf16_elems mlp_pack_bf16 mlp_fwd_bf16 mlp_fwd_bf16_train mlp_packed_bwd_bf16_elems mlp_pack_bwd_bf16 mlp_bwd_bf16
+mlp_saved_floats mlp_gradslot_floats mlp_packed_bwd_floats mlp_bwd_workspace_floats mlp_pack_bwd mlp_fwd_train mlp_bwd
+mlp_packed_split_elems mlp_pack_split mlp_fwd_split mlp_fwd_guarded
+composite_fwd composite_bwd raymarch_fwd raymarch_fwd_batched raymarch_train_fwd raymarch_bwd render_workspace_floats render_pixels_fwd
+adam_step_multi sample_pdf_fwd ray_marcher_fine_fwd ray_points_fwd
+""".split()
+
+
+def test_stable_tier_is_frozen():
+    stable = _declared_in("mvsnerf_hip.h")
+    assert stable == sorted("mvsnerf_" + n for n in STABLE_ABI_12), sorted(set(stable) ^ {"mvsnerf_" + n for n in STABLE_ABI_12})
+    internal = _declared_in("mvsnerf_hip_internal.h")
+    assert not set(stable) & set(internal)                       # an entry lives in exactly one tier
+    # the stable header stands alone (a maintainer includes only it); the internal one pulls it in
+    for h in ("mvsnerf_hip.h", "mvsnerf_hip_internal.h"):
+        r = subprocess.run(["gcc", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", h)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    assert "mvsnerf_hip_internal.h" not in open(os.path.join(ROOT, "include", "mvsnerf_hip.h")).read().split("*/", 1)[1]
 
 
 def test_library_builds_and_exports_header_symbols():
@@ -76,7 +109,7 @@ def test_plane_sweep_code_object_has_no_packed_fp32_arithmetic():
 
 def test_no_code_object_selects_the_high_half_of_src1_in_packed_fp32():
     """`v_pk_{fma,mul,add}_f32 ... op_sel:[x,1...]` (src1's high half feeding the low result) is the packed fp32 form that returned wrong values in lanes
-    48-63 next to the fp16x3 conv0 of another stream (scratch/r5/pk_probe.hip, profiles/r05_pk_fma_opsel_reproducer.txt); the compiler picks the form, so
+    48-63 next to the fp16x3 conv0 of another stream (scratch/keep/pk_probe.hip, profiles/r05_pk_fma_opsel_reproducer.txt); the compiler picks the form, so
     the shipped bits are disassembled: csrc/check_isa.sh, which the Makefile also runs after linking."""
     csrc = os.path.join(ROOT, "mvsnerf_amd", "csrc")
     assert "check_isa.sh $@" in open(os.path.join(csrc, "Makefile")).read(), "the link rule lost its ISA check"

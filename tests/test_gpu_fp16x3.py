@@ -1,6 +1,6 @@
 """Opt-in "fp16x3" MLP (csrc/mlp_f16x3.hip; ops.set_mlp_precision("fp16x3")): every fp32 operand of the Renderer_ours GEMMs
 (reference models.py:194-222) as two fp16 pieces, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulation and epilogues.
-The claim is fp32-GRADE results (two fp16 pieces carry 22 bits; scratch/r3/f16x3_numerics.py), so the bounds here are the fp32
+The claim is fp32-GRADE results (two fp16 pieces carry 22 bits; scratch/keep/f16x3_numerics.py), so the bounds here are the fp32
 kernel's (tests/test_gpu_raymarch.py), not a reduced-precision tolerance: north_star's 1e-4 with the margin measured on the GPU."""
 import numpy as np
 import pytest
@@ -49,7 +49,7 @@ def _render(net, mode, n_samples, pose, pts, ndc, z, ro, dirs, vol, imgs):
 def test_fp16x3_config2_vs_oracle_is_fp32_grade(net20):
     """1024 rays x 128 samples at BASELINE config 2's shapes (3 views 512x640, volume 128x176x208), shipped weights: the fp16x3 kernel
     against the CPU oracle AND against the fp32-MFMA kernel on identical inputs.  A matrix core that flushed fp16 subnormals (40 % of the
-    lo pieces are subnormal) would show up here as an error of ~7e-3 (scratch/r3/f16x3_numerics.py)."""
+    lo pieces are subnormal) would show up here as an error of ~7e-3 (scratch/keep/f16x3_numerics.py)."""
     from oracle import mvsnerf_oracle as O
     from tests.test_gpu_raymarch import _config2_inputs
     rig, pose, vol, pts, dirs, ndc, z, ro = _config2_inputs()
