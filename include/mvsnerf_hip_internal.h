@@ -199,6 +199,10 @@ int mvsnerf_sweep_conv0_guarded_fwd(const mvsnerf_sweep_conv0_args* a, void* str
  *   mvsnerf_conv3d_f16x3_pack: nn.Conv3d weight w[Cout][Cin][3][3][3] -> mvsnerf_conv3d_f16x3_packed_elems(Cin) fp16 elements (16-byte aligned);
  *   a weight outside fp16's range is recorded in a status tail and reported through the guard by the kernel.
  *   mvsnerf_conv3d_f16x3_fwd: the UNGUARDED kernel (an operand beyond |x| < 4094 leaves NaNs in the outputs it touches).
+ *   The other end of fp16 is NOT reported by these kernels: activated inputs that are ALL below ~2^-7, or weights below 2^-11, put the second
+ *   pieces into fp16's subnormals and the result silently drops from fp32 grade towards 2^-11 + log2(largest |x|) bits.  The layers this serves (conv1 / conv2
+ *   behind an InPlaceABN: unit-variance inputs, |w| ~ 1e-2 .. 1) are four to seven binary orders above that floor; a caller with other data uses the fp32 entry.
+ *   (The MLP kernel manages both ends itself since ABI v12; the same per-tile power-of-two scale would work here and is not built.)
  *   mvsnerf_conv3d_f16x3_guarded_fwd: the guarded sequence (see "Guarded 16-bit sequences"): the kernel above sets guard[0] when an operand left the
  *   range, the layer's fp32 kernel (w_f32: mvsnerf_conv3d_pack_weights_mfma layout for Cin 8, mvsnerf_conv3d_pack_weights layout for Cin 16) and a
  *   statistics pass run behind it predicated on that word; consume != 0 counts the event in guard[1] and re-arms guard[0] at the end. */

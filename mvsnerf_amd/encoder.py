@@ -664,15 +664,31 @@ def _ptrs(src):
     return src.data_ptr(), 0, 0
 
 
+class _ThreadCell:
+    """A one-slot cell, one value per host thread: cell[0] reads / writes THIS thread's value (default for a thread that never set it).  The per-launch
+    precision switches below are set for the extent of a forward / backward by context managers; two host threads on their own streams (supported: guard
+    words and workspaces are per stream) must not see each other's (thread A's `_F16X3_CONSUME[0] = 0` leaking into thread B's conv2 launch)."""
+
+    def __init__(self, default):
+        import threading
+        self._tls, self._default = threading.local(), default
+
+    def __getitem__(self, i):
+        return getattr(self._tls, "v", self._default)
+
+    def __setitem__(self, i, value):
+        self._tls.v = value
+
+
 BF16_WGRAD = True          # A/B switch: the weight gradients of those layers on the bf16 kernel as well (csrc/wgrad_bf16.hip)
 BF16_LAYERS = True         # A/B switch (scratch/r4): False keeps conv1 ... conv11 on the fp32 kernels under use_amp (round 3's behaviour)
-_LAYER_BF16 = [False]      # conv1 ... conv11 on the bf16 matrix cores (csrc/conv3d_bf16.hip): set for the extent of a forward / backward by _layer_precision
+_LAYER_BF16 = _ThreadCell(False)      # conv1 ... conv11 on the bf16 matrix cores (csrc/conv3d_bf16.hip): set for the extent of a forward / backward by _layer_precision
 
 
 F16X3_LAYERS = True        # A/B switch: conv1 / conv2 of a no-grad "auto" encode on the guarded fp16x3 LDS-tiled kernel (csrc/conv_f16x3_tiled.hip)
 F16X3_MIN_VOXELS = 262144  # ... from this many OUTPUT voxels on (below, the layer is a few microseconds on any kernel and the persistent grid of 512 workgroups is mostly idle)
-_LAYER_F16X3 = [None]      # None, or "guarded" / "plain" for the extent of CostRegNet._run (set by _layers_f16x3)
-_F16X3_CONSUME = [1]       # 0 while conv1 runs inside CostRegNet._run: conv2 (same output size, hence guarded as well) counts / re-arms for both
+_LAYER_F16X3 = _ThreadCell(None)      # None, or "guarded" / "plain" for the extent of CostRegNet._run (set by _layers_f16x3)
+_F16X3_CONSUME = _ThreadCell(1)       # 0 while conv1 runs inside CostRegNet._run: conv2 (same output size, hence guarded as well) counts / re-arms for both
 
 
 class _layers_f16x3:

@@ -252,6 +252,7 @@ class RefVolume(nn.Module):
         self.feat_volume = nn.Parameter(volume.contiguous(memory_format=torch.channels_last_3d))
 
     def forward(self, ray_coordinate_ref):
+        ops._need_no_grad(self.feat_volume, op="RefVolume.forward (volume_sample)")      # checked on the parameter itself: the view below is always detached
         vol_cl = ops.channels_last_volume(self.feat_volume)
         ndc = ray_coordinate_ref.to(vol_cl.device, torch.float32).contiguous()
         return ops.volume_sample(vol_cl, ndc).squeeze()

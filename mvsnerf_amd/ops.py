@@ -62,7 +62,10 @@ def channels_last_volume(volume_feature):
     # a WEAK reference to the tensor object: an encoder output still carries its grad_fn, and a module-level strong reference would keep the whole
     # encoder graph (its saved activations, GB-scale at config 2/3) alive until the next call.  `out` (a no-grad view or a transposed copy) keeps
     # only the volume's own storage; RayMarchFunction.backward drops the entry.
-    _cl_cache["last"] = (weakref.ref(v), (v._version, _lib.weights_epoch()), out.detach())
+    # The DETACHED view is what is cached AND returned (a miss used to return the view with its grad_fn, a hit the detached one - whether a stand-alone
+    # op saw a gradient-requiring volume depended on the cache).  The differentiable paths take the volume tensor itself (RayMarchFunction), never this view.
+    out = out.detach()
+    _cl_cache["last"] = (weakref.ref(v), (v._version, _lib.weights_epoch()), out)
     return out
 
 

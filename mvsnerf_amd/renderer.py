@@ -71,6 +71,7 @@ def gen_pts_feats(imgs, volume_feature, rays_pts, pose_ref, rays_ndc, feat_dim, 
     """renderer.py:124-136: [8 volume channels | V x (r,g,b,mask)] written in place into one (N,S,feat_dim) tensor."""
     from .models import RefVolume
     vol = volume_feature.feat_volume if isinstance(volume_feature, RefVolume) else volume_feature
+    ops._need_no_grad(vol, op="gen_pts_feats (gather)")                                  # on the caller's tensor: the channel-last view is always detached
     vol_cl = ops.channels_last_volume(vol)
     if use_color_volume:
         # renderer.py:134-135 (--use_color_volume fine-tuning): the colours were projected into the volume once

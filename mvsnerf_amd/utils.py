@@ -205,6 +205,7 @@ def index_point_feature(volume_feature, ray_coordinate_ref, chunk=-1):
     """utils.py:357-383: trilinear lookup of the (1,C,D,h,w) volume at NDC (x,y,z) in [0,1].
     Returns (N_rays, N_samples, C) (squeezed like the reference).  `chunk` is accepted and ignored:
     the kernel never materialises anything chunk-sized."""
+    ops._need_no_grad(volume_feature, op="index_point_feature (volume_sample)")         # on the caller's tensor: the channel-last view is always detached
     vol_cl = ops.channels_last_volume(volume_feature)
     ndc = ray_coordinate_ref.to(vol_cl.device, torch.float32).contiguous()
     return ops.volume_sample(vol_cl, ndc).squeeze()
