@@ -83,18 +83,30 @@ __device__ __forceinline__ void slabb_sync()
     __syncthreads();
 }
 
+// acc[nb] += W[block nb] * act over STEPS k-steps of 16: one weight fragment (ds_read_b128) per matrix instruction.  The stream is laid out by hand
+// (sched_barrier around every matrix instruction) like the fp16x3 kernel's: the fragment an instruction needs was requested B_AHEAD instructions earlier
+// (round 5's compiler-scheduled loop waited for every fragment right after asking for it: 2 650 cycles per 32-instruction layer, profiles/r06_mlp_bf16_census.txt),
+// the gap behind every instruction carries one read.
+constexpr int B_AHEAD = 3;
 template <int STEPS, int NBLK, typename BFN>
 __device__ __forceinline__ void gemm_b(const char* __restrict__ w, f32x16 (&acc)[NBLK], int lane, BFN bfn)
 {
+    constexpr int N = STEPS * NBLK, D = B_AHEAD;
+    const bf16x8* __restrict__ fw = reinterpret_cast<const bf16x8*>(w) + lane;
+    bf16x8 a[D + 1];
 #pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-        const bf16x8 b = bfn(s);
+    for (int i = 0; i < D && i < N; ++i) a[i] = fw[i * 64];
+    __builtin_amdgcn_s_setprio(1);                // a matrix stream beats the other wave's epilogue (and, between two matrix streams, the older wave wins)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int nb = 0; nb < NBLK; ++nb) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(w + ((s * NBLK + nb) * 64 + lane) * 16);
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nb], 0, 0, 0);
-        }
+    for (int i = 0; i < N; ++i) {
+        const int s = i / NBLK, nb = i % NBLK;
+        if (i + D < N) a[(i + D) % (D + 1)] = fw[(i + D) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % (D + 1)], bfn(s), acc[nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    __builtin_amdgcn_s_setprio(0);
 }
 
 __device__ __forceinline__ bf16x8 pack8(const float* v)
@@ -129,6 +141,14 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_bf16_kernel(
     const int64_t p_raw = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
     const bool live = p_raw < P;
     const int64_t p = live ? p_raw : P - 1;
+#ifdef BF_CENSUS      // DEV probe: shader-clock stamps of this wave's phases, 32 per tile, behind the results (scratch/r6/bf_census.py allocates them)
+    unsigned* cen = reinterpret_cast<unsigned*>(raw + P * (ALPHA_ONLY ? 1 : 4)) + ((int64_t)blockIdx.x * 4 + wave) * 32;
+    int cen_i = 0;
+#define BF_STAMP() do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if (lane == 0 && cen_i < 32) cen[cen_i] = (unsigned)t__; ++cen_i; } while (0)
+#else
+#define BF_STAMP() do {} while (0)
+#endif
+    BF_STAMP();
     __bf16* sv = nullptr;
     if (SAVE) sv = reinterpret_cast<__bf16*>(saved) + ((int64_t)blockIdx.x * 4 + wave) * (SLOTS_SAVED * 64) + lane;
     auto save = [&](int slot, float v) { if (SAVE) sv[slot * 64] = (__bf16)v; };
@@ -140,50 +160,78 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_bf16_kernel(
     float fv[24];                                 // F/2 <= 20 feature operands of this lane half (the store keeps the first 16: F <= 32 when training)
     {
         const float* fp = feat + p * feat_stride + half * (F / 2);
+        // (the compiler turns this into one scalar branch + one load per element; issuing all 24 unconditionally - padding slots re-reading element 0 - measured
+        // SLOWER, 34.4 -> 41.9 us in the bf16 kernel: a 64-lane dword load at an 80-byte stride is ~20 cache lines per instruction, the address unit is what waits)
 #pragma unroll
         for (int i = 0; i < 24; ++i) fv[i] = i < F / 2 ? fp[i] : 0.0f;
     }
-    bf16x8 pe8[B_PE_STEPS];                      // positional-encoding operands (reused by layer 5)
+    // the view direction of the point's ray: asked for HERE, used by the last GEMM (loaded there its latency sat in front of the rgb head: ~1 000 cycles per wave)
+    float dl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!ALPHA_ONLY) {
+        const int64_t ray = p / S;
+        dl[0] = half ? dirs[ray * dirs_stride + 1] : dirs[ray * dirs_stride + 0];
+        dl[1] = half ? 0.0f : dirs[ray * dirs_stride + 2];
+    }
+    bf16x8 pe8[B_PE_STEPS];                      // positional-encoding operands (layer 0, reused by layer 5); computed BEHIND the pts_bias GEMM
+    bf16x8 fb8[3];                                // the feature operands
 #pragma unroll
-    for (int s = 0; s < B_PE_STEPS; ++s) {
-        float t8[8];
+    for (int s = 0; s < 3; ++s) fb8[s] = pack8(fv + 8 * s);
+    if (SAVE) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) t8[j] = pe_op(8 * s + j, half, px, py, pz);
-        pe8[s] = pack8(t8);
+        for (int t = 0; t < 16; ++t) save(S_FV + t, fv[t]);
     }
     float bias[64];
-    bf16x8 hb[8];
-    float hf[64];                                 // fp32 copy of the current activations (epilogue scratch / heads)
-    auto to_b = [&]() {
+    bf16x8 hb[8];                                 // the current activations as bf16 B operands (k-step s = values 8s .. 8s+7 of the lane)
+    // epilogue of a layer: v = act(acc [* bias]) goes straight into hb, eight values at a time (no fp32 copy of the layer lives on: with the hand-laid GEMM stream
+    // the epilogue no longer overlaps the GEMM of the SAME wave - the other workgroup's wave on the SIMD does - and 64 more live registers spilled)
+    auto finish_b = [&](f32x16 (&acc)[4], bool modulated_relu, int save_slot, const float* head_w, float& head_sum) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) hb[s] = pack8(hf + 8 * s);
+        for (int s = 0; s < 8; ++s) {
+            float v8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int q = 8 * s + j;
+                const float x = acc[q >> 4][q & 15];
+                v8[j] = modulated_relu ? fmaxf(x * bias[q], 0.0f) : x;
+                save(save_slot + q, v8[j]);
+                if (head_w) head_sum = fmaf(head_w[q], v8[j], head_sum);
+            }
+            hb[s] = pack8(v8);
+        }
     };
+    float no_head = 0.0f;
 
     slabb_sync();
+    BF_STAMP();
     slabb_dma(buf1, wq + L.l1, b_seg(B_ACT_STEPS, 4), wave, lane);
     {   // bias = pts_bias(feat)
         f32x16 acc[4];
         init_acc_b<4>(acc, vec + V_BIASG + half * 64);
-        auto fb = [&](int s) { return pack8(fv + 8 * s); };
+        auto fb = [&](int s) { return fb8[s]; };
         if (L.fsteps == 1) gemm_b<1, 4>(buf0, acc, lane, fb);
         else if (L.fsteps == 2) gemm_b<2, 4>(buf0, acc, lane, fb);
         else gemm_b<3, 4>(buf0, acc, lane, fb);
+        BF_STAMP();
 #pragma unroll
         for (int q = 0; q < 64; ++q) { bias[q] = acc[q >> 4][q & 15]; save(S_BM + q, bias[q]); }
-        if (SAVE) {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) save(S_FV + t, fv[t]);
-#pragma unroll
-            for (int t = 0; t < PE_STEPS; ++t) save(S_E + t, pe_op(t, half, px, py, pz));
-        }
     }
+    // the encoding (transcendental unit, exact range reduction: mlp_b16_dev.h), between the first two GEMMs: it runs beside the matrix work of the other
+    // workgroup's wave on this SIMD (in front of the first barrier it measured 1 us slower)
+#pragma unroll
+    for (int s = 0; s < B_PE_STEPS; ++s) {
+        float t8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { t8[j] = pe_op_hw(8 * s + j, half, px, py, pz); save(S_E + 8 * s + j, t8[j]); }
+        pe8[s] = pack8(t8);
+    }
+
     {   // layer 0
         f32x16 acc[4];
         init_acc_b<4>(acc, vec + V_L0 + half * 64);
         gemm_b<B_PE_STEPS, 4>(buf0 + b_seg(L.fsteps, 4) * 2, acc, lane, [&](int s) { return pe8[s]; });
-#pragma unroll
-        for (int q = 0; q < 64; ++q) { hf[q] = fmaxf(acc[q >> 4][q & 15] * bias[q], 0.0f); save(S_H + q, hf[q]); }
-        to_b();
+        BF_STAMP();
+        finish_b(acc, true, S_H, nullptr, no_head);
+        BF_STAMP();
     }
     // layers 1..4: slabs alternate buf1, buf0, buf1, buf0
 #pragma unroll 1
@@ -191,34 +239,35 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_bf16_kernel(
         char* cur = (layer & 1) ? buf1 : buf0;
         char* nxt = (layer & 1) ? buf0 : buf1;
         slabb_sync();
+        BF_STAMP();
         if (layer < 4) slabb_dma(nxt, wq + L.l1 + (size_t)layer * b_seg(B_ACT_STEPS, 4), b_seg(B_ACT_STEPS, 4), wave, lane);
         else slabb_dma(nxt, wq + L.l5a, b_seg(B_PE_STEPS, 4), wave, lane);           // after layer 4 (in buf0): L5a -> buf1
         f32x16 acc[4];
         init_acc_b<4>(acc, vec + V_L0 + 128 * layer + half * 64);
         gemm_b<B_ACT_STEPS, 4>(cur, acc, lane, [&](int s) { return hb[s]; });
-#pragma unroll
-        for (int q = 0; q < 64; ++q) { hf[q] = fmaxf(acc[q >> 4][q & 15] * bias[q], 0.0f); save(S_H + layer * 64 + q, hf[q]); }
-        to_b();
+        BF_STAMP();
+        finish_b(acc, true, S_H + layer * 64, nullptr, no_head);
+        BF_STAMP();
     }
     float sigma;
     {   // layer 5 on cat([pts, h4]): L5a in buf1, L5b -> buf0
         f32x16 acc[4];
         slabb_sync();
+        BF_STAMP();
         slabb_dma(buf0, wq + L.l5b, b_seg(B_ACT_STEPS, 4), wave, lane);
         init_acc_b<4>(acc, vec + V_L0 + 128 * 5 + half * 64);
         gemm_b<B_PE_STEPS, 4>(buf1, acc, lane, [&](int s) { return pe8[s]; });
+        BF_STAMP();
         slabb_sync();
+        BF_STAMP();
         if (!ALPHA_ONLY) slabb_dma(buf1, wq + L.feat, b_seg(B_ACT_STEPS, 4), wave, lane);
         gemm_b<B_ACT_STEPS, 4>(buf0, acc, lane, [&](int s) { return hb[s]; });
-#pragma unroll
-        for (int q = 0; q < 64; ++q) { hf[q] = fmaxf(acc[q >> 4][q & 15] * bias[q], 0.0f); save(S_H + 5 * 64 + q, hf[q]); }
-        const float* wa = vec + V_WA + half * 64;
+        BF_STAMP();
         float part = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 64; ++q) part = fmaf(wa[q], hf[q], part);
+        finish_b(acc, true, S_H + 5 * 64, vec + V_WA + half * 64, part);       // alpha_linear on the fp32 activations, as they are produced
         part += __shfl_xor(part, 32);
         sigma = fmaxf(part + vec[V_BA], 0.0f);
-        to_b();
+        BF_STAMP();
     }
     if (ALPHA_ONLY) {
         if (live && half == 0) raw[p_raw] = sigma;
@@ -227,23 +276,21 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_bf16_kernel(
     {   // feature_linear (buf1), then views -> buf0
         f32x16 acc[4];
         slabb_sync();
+        BF_STAMP();
         slabb_dma(buf0, wq + L.views, b_seg(B_VIEW_STEPS, 2), wave, lane);
         init_acc_b<4>(acc, vec + V_FEAT + half * 64);
         gemm_b<B_ACT_STEPS, 4>(buf1, acc, lane, [&](int s) { return hb[s]; });
-#pragma unroll
-        for (int q = 0; q < 64; ++q) { hf[q] = acc[q >> 4][q & 15]; save(S_FE + q, hf[q]); }
-        to_b();
+        BF_STAMP();
+        finish_b(acc, false, S_FE, nullptr, no_head);
     }
     {   // views_linears[0] + rgb head
-        const int64_t ray = p / S;
-        float dl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        dl[0] = half ? dirs[ray * dirs_stride + 1] : dirs[ray * dirs_stride + 0];
-        dl[1] = half ? 0.0f : dirs[ray * dirs_stride + 2];
         const bf16x8 d8 = pack8(dl);
         f32x16 acc[2];
         slabb_sync();
+        BF_STAMP();
         init_acc_b<2>(acc, vec + V_VIEWS + half * 32);
         gemm_b<B_VIEW_STEPS, 2>(buf0, acc, lane, [&](int s) { return s < 8 ? hb[s < 8 ? s : 0] : d8; });
+        BF_STAMP();
         if (SAVE) {
 #pragma unroll
             for (int q = 0; q < 32; ++q) save(S_HV + q, fmaxf(acc[q >> 4][q & 15], 0.0f));
@@ -261,7 +308,190 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_bf16_kernel(
             rgb[c] = 1.0f / (1.0f + expf(-(part + vec[V_BR + c])));
         }
         if (live && half == 0) *reinterpret_cast<f32x4*>(raw + p_raw * 4) = f32x4{rgb[0], rgb[1], rgb[2], sigma};
+        BF_STAMP();
     }
+}
+
+
+// ------------------------------------------------------------------------------------------ inference kernel (round 6)
+// The same arithmetic with EIGHT waves (256 points) per workgroup and the layer barriers of the fp16x3 kernel (mlp_f16x3.hip): the two waves of a SIMD run
+// their GEMMs one after the other anyway (the older wins the matrix pipe), so an older wave (0..3) runs [GEMM, epilogue, barrier] and a younger one
+// [GEMM, barrier, epilogue]: the barrier falls when the younger wave's GEMM ends, the older wave starts the next layer at once, and each wave's epilogue - here
+// HALF a layer's time, a bf16 layer being 32 matrix instructions against ~200 VALU - runs beside its partner's GEMM instead of in front of its own.  One slab
+// serves 256 points (half the weight bytes per point of the 4-wave kernel above, which stays for the training forward with its activation store).
+constexpr int BP_WAVES = 8;
+constexpr int BP_THREADS = 64 * BP_WAVES;
+
+__device__ __forceinline__ void slabp_dma(char* __restrict__ dst, const __bf16* __restrict__ src, size_t n_elems, int wave, int lane)
+{
+    lds_dma<BP_WAVES>(dst, src, (int)(n_elems >> 9), wave, lane);
+}
+
+template <bool ALPHA_ONLY>
+__global__ __launch_bounds__(BP_THREADS) void mlp_fwd_bf16_pair_kernel(
+    const __bf16* __restrict__ wq, const float* __restrict__ packed_f32, int F, const float* __restrict__ ndc, int ndc_stride,
+    const float* __restrict__ feat, int feat_stride, const float* __restrict__ dirs, int dirs_stride,
+    int64_t P, int S, float* __restrict__ raw)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_b[];
+    char* buf0 = lds_b;
+    char* buf1 = lds_b + SLABB_BYTES;
+    float* vec = reinterpret_cast<float*>(lds_b + 2 * SLABB_BYTES);
+    const LayoutB L = layout_b(F);
+    const Layout LF = layout(F);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const bool young = wave >= BP_WAVES / 2;
+    const int64_t p_raw = ((int64_t)blockIdx.x * BP_WAVES + wave) * 32 + (lane & 31);
+    const bool live = p_raw < P;
+    const int64_t p = live ? p_raw : P - 1;
+    constexpr size_t ACT = (size_t)B_ACT_STEPS * 4 * 512, PEW = (size_t)B_PE_STEPS * 4 * 512;      // bf16 elements of a slab
+#ifdef BF_CENSUS      // DEV probe: shader-clock stamps of this wave's phases, 32 per tile, behind the results (scratch/r6/bf_census.py)
+    unsigned* cen = reinterpret_cast<unsigned*>(raw + P * (ALPHA_ONLY ? 1 : 4)) + ((int64_t)blockIdx.x * BP_WAVES + wave) * 32;
+    int cen_i = 0;
+#define BP_STAMP() do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if (lane == 0 && cen_i < 32) cen[cen_i] = (unsigned)t__; ++cen_i; } while (0)
+#else
+#define BP_STAMP() do {} while (0)
+#endif
+    BP_STAMP();
+
+    slabp_dma(buf0, wq + L.featw, L.l1 - L.featw, wave, lane);                       // slab 0 = pts_bias weights + layer 0
+    for (int i = tid; i < V_TOTAL; i += BP_THREADS) vec[i] = packed_f32[LF.vec + i];
+    const float px = ndc[p * ndc_stride + 0], py = ndc[p * ndc_stride + 1], pz = ndc[p * ndc_stride + 2];
+    float dl[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                           // the view direction: asked for here, used by the last GEMM
+    if (!ALPHA_ONLY) {
+        const int64_t ray = p / S;
+        dl[0] = half ? dirs[ray * dirs_stride + 1] : dirs[ray * dirs_stride + 0];
+        dl[1] = half ? 0.0f : dirs[ray * dirs_stride + 2];
+    }
+    bf16x8 fb8[3];
+    {
+        float fv[24];
+        const float* fp = feat + p * feat_stride + half * (F / 2);
+        // (the compiler turns this into one scalar branch + one load per element; issuing all 24 unconditionally - padding slots re-reading element 0 - measured
+        // SLOWER, 34.4 -> 41.9 us in the bf16 kernel: a 64-lane dword load at an 80-byte stride is ~20 cache lines per instruction, the address unit is what waits)
+#pragma unroll
+        for (int i = 0; i < 24; ++i) fv[i] = i < F / 2 ? fp[i] : 0.0f;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) fb8[s] = pack8(fv + 8 * s);
+    }
+    float bias[64];
+    bf16x8 hb[8], pe8[B_PE_STEPS];
+    f32x16 acc[4];
+    auto finish_b = [&](bool modulated_relu, const float* head_w, float& head_sum) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float v8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int q = 8 * s + j;
+                const float x = acc[q >> 4][q & 15];
+                v8[j] = modulated_relu ? fmaxf(x * bias[q], 0.0f) : x;
+                if (head_w) head_sum = fmaf(head_w[q], v8[j], head_sum);
+            }
+            hb[s] = pack8(v8);
+        }
+    };
+    float no_head = 0.0f;
+    auto act = [&](int s) { return hb[s]; };
+    auto enc = [&](int s) { return pe8[s]; };
+
+    slabb_sync();
+    BP_STAMP();
+    slabp_dma(buf1, wq + L.l1, ACT, wave, lane);                                     // layer 1 -> buf1
+    {   // bias = pts_bias(feat)
+        init_acc_b<4>(acc, vec + V_BIASG + half * 64);
+        auto fb = [&](int s) { return fb8[s]; };
+        if (L.fsteps == 1) gemm_b<1, 4>(buf0, acc, lane, fb);
+        else if (L.fsteps == 2) gemm_b<2, 4>(buf0, acc, lane, fb);
+        else gemm_b<3, 4>(buf0, acc, lane, fb);
+        BP_STAMP();
+#pragma unroll
+        for (int q = 0; q < 64; ++q) bias[q] = acc[q >> 4][q & 15];
+    }
+#pragma unroll
+    for (int s = 0; s < B_PE_STEPS; ++s) {                                            // the encoding (transcendental unit), beside the partner's matrix work
+        float t8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t8[j] = pe_op_hw(8 * s + j, half, px, py, pz);
+        pe8[s] = pack8(t8);
+    }
+    init_acc_b<4>(acc, vec + V_L0 + half * 64);
+    gemm_b<B_PE_STEPS, 4>(buf0 + b_seg(L.fsteps, 4) * 2, acc, lane, enc);           // layer 0 (same slab)
+    BP_STAMP();
+    // behind the GEMM in buffer X, X takes the slab after next
+    if (young) { slabb_sync(); slabp_dma(buf0, wq + L.l1 + ACT, ACT, wave, lane); }
+    finish_b(true, nullptr, no_head);
+    init_acc_b<4>(acc, vec + V_L0 + 128 + half * 64);
+    BP_STAMP();
+    if (!young) { slabb_sync(); slabp_dma(buf0, wq + L.l1 + ACT, ACT, wave, lane); }
+    BP_STAMP();
+#pragma unroll 1
+    for (int layer = 1; layer <= 4; ++layer) {
+        char* cur = (layer & 1) ? buf1 : buf0;
+        auto refill = [&]() {
+            slabb_sync();
+            if (layer < 3) slabp_dma(cur, wq + L.l1 + (size_t)(layer + 1) * ACT, ACT, wave, lane);
+            else if (layer == 3) slabp_dma(cur, wq + L.l5a, PEW, wave, lane);
+            else slabp_dma(cur, wq + L.l5b, ACT, wave, lane);
+        };
+        gemm_b<B_ACT_STEPS, 4>(cur, acc, lane, act);
+        BP_STAMP();
+        if (young) refill();
+        finish_b(true, nullptr, no_head);
+        init_acc_b<4>(acc, vec + V_L0 + 128 * (layer + 1) + half * 64);
+        BP_STAMP();
+        if (!young) refill();
+        BP_STAMP();
+    }
+    float sigma;
+    {   // layer 5 on cat([pts, h4]): L5a in buf1, L5b in buf0
+        gemm_b<B_PE_STEPS, 4>(buf1, acc, lane, enc);
+        BP_STAMP();
+        slabb_sync();
+        BP_STAMP();
+        if (!ALPHA_ONLY) slabp_dma(buf1, wq + L.feat, ACT, wave, lane);
+        gemm_b<B_ACT_STEPS, 4>(buf0, acc, lane, act);
+        BP_STAMP();
+        if (!ALPHA_ONLY && young) { slabb_sync(); slabp_dma(buf0, wq + L.views, b_seg(B_VIEW_STEPS, 2), wave, lane); }
+        float part = 0.0f;
+        finish_b(true, vec + V_WA + half * 64, part);                                 // alpha_linear on the fp32 activations, as they are produced
+        part += __shfl_xor(part, 32);
+        sigma = fmaxf(part + vec[V_BA], 0.0f);
+        if (!ALPHA_ONLY) init_acc_b<4>(acc, vec + V_FEAT + half * 64);
+        BP_STAMP();
+        if (!ALPHA_ONLY && !young) { slabb_sync(); slabp_dma(buf0, wq + L.views, b_seg(B_VIEW_STEPS, 2), wave, lane); }
+        BP_STAMP();
+    }
+    if (ALPHA_ONLY) {
+        if (live && half == 0) raw[p_raw] = sigma;
+        return;
+    }
+    gemm_b<B_ACT_STEPS, 4>(buf1, acc, lane, act);                                     // feature_linear (no activation)
+    BP_STAMP();
+    if (young) slabb_sync();
+    finish_b(false, nullptr, no_head);
+    const bf16x8 d8 = pack8(dl);
+    f32x16 av[2];
+    init_acc_b<2>(av, vec + V_VIEWS + half * 32);
+    BP_STAMP();
+    if (!young) slabb_sync();
+    BP_STAMP();
+    gemm_b<B_VIEW_STEPS, 2>(buf0, av, lane, [&](int s) { return s < 8 ? hb[s < 8 ? s : 0] : d8; });
+    BP_STAMP();
+    float rgb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* wr = vec + V_WR + c * 64 + half * 32;
+        float part = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) part = fmaf(wr[q], fmaxf(av[q >> 4][q & 15], 0.0f), part);
+        part += __shfl_xor(part, 32);
+        rgb[c] = 1.0f / (1.0f + expf(-(part + vec[V_BR + c])));
+    }
+    if (live && half == 0) *reinterpret_cast<f32x4*>(raw + p_raw * 4) = f32x4{rgb[0], rgb[1], rgb[2], sigma};
+    BP_STAMP();
 }
 
 
@@ -742,13 +972,14 @@ extern "C" int mvsnerf_mlp_fwd_bf16(const void* packed_bf16, const float* packed
     if (P == 0) return MVSNERF_OK;
     hipStream_t st = (hipStream_t)stream;
     static unsigned long long cap_a = 0, cap_b = 0;         // per-device bit masks (common.h)
-    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_bf16_kernel<false>), (int)(B_LDS_BYTES), &cap_a)) return rc_;
-    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_bf16_kernel<true>), (int)(B_LDS_BYTES), &cap_b)) return rc_;
+    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_bf16_pair_kernel<false>), (int)(B_LDS_BYTES), &cap_a)) return rc_;
+    if (int rc_ = mvs_raise_lds_cap(reinterpret_cast<const void*>(mlp_fwd_bf16_pair_kernel<true>), (int)(B_LDS_BYTES), &cap_b)) return rc_;
     const __bf16* wq = reinterpret_cast<const __bf16*>(packed_bf16);
+    const unsigned grid = mvs_cdiv(P, 32 * BP_WAVES);
     if (alpha_only)
-        mlp_fwd_bf16_kernel<true><<<mvs_cdiv(P, 128), 256, B_LDS_BYTES, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
+        mlp_fwd_bf16_pair_kernel<true><<<grid, BP_THREADS, B_LDS_BYTES, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
     else
-        mlp_fwd_bf16_kernel<false><<<mvs_cdiv(P, 128), 256, B_LDS_BYTES, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
+        mlp_fwd_bf16_pair_kernel<false><<<grid, BP_THREADS, B_LDS_BYTES, st>>>(wq, packed_f32, F, ndc, ndc_stride, feat, feat_stride, dirs, dirs_stride, P, S, raw);
     MVS_LAUNCH_CHECK();
     return MVSNERF_OK;
 }

@@ -326,9 +326,18 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
     const bool young = wave >= H3_WAVES / 2;
     for (int i = tid; i < V_TOTAL; i += H3_THREADS) vec[i] = packed_f32[LF.vec + i];
     const float px = ndc[p * ndc_stride + 0], py = ndc[p * ndc_stride + 1], pz = ndc[p * ndc_stride + 2];
+    // the view direction of the point's ray: asked for HERE, used by the last GEMM (loaded there, its latency sat in front of that GEMM)
+    float dir0 = 0.0f, dir1 = 0.0f;
+    if (!ALPHA_ONLY) {
+        const int64_t ray = p / S;
+        dir0 = half ? dirs[ray * dirs_stride + 1] : dirs[ray * dirs_stride + 0];
+        dir1 = half ? 0.0f : dirs[ray * dirs_stride + 2];
+    }
     float fv[24];                                 // F/2 <= 20 feature operands of this lane half
     {
         const float* fp = feat + p * feat_stride + half * (F / 2);
+        // (the compiler turns this into one scalar branch + one load per element; issuing all 24 unconditionally - padding slots re-reading element 0 - measured
+        // SLOWER, 34.4 -> 41.9 us in the bf16 kernel: a 64-lane dword load at an 80-byte stride is ~20 cache lines per instruction, the address unit is what waits)
 #pragma unroll
         for (int i = 0; i < 24; ++i) fv[i] = i < F / 2 ? fp[i] : 0.0f;
     }
@@ -579,12 +588,11 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
     report();
     const int64_t q_raw = point_again();
     {   // views_linears[0] + rgb head
-        const int64_t ray = (q_raw < P ? q_raw : P - 1) / S;
         float dl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const int kwv = kw(SEG_VF);
         const float dsc = pow2f(lsc + kwv - kw(SEG_VD));       // the direction's own weights carry 2^kw(SEG_VD), the accumulators 2^kwv
-        dl[0] = (half ? dirs[ray * dirs_stride + 1] : dirs[ray * dirs_stride + 0]) * dsc;
-        dl[1] = half ? 0.0f : dirs[ray * dirs_stride + 2] * dsc;
+        dl[0] = dir0 * dsc;
+        dl[1] = dir1 * dsc;
         BP d8[1];
         d8[0] = split8h(dl);
         init_acc_b<2>(av, vec + V_VIEWS + half * 32);
