@@ -279,7 +279,7 @@ def main():
                     pbm = net.packed_bf16(F)
                     k_mode = lambda: lib.mvsnerf_mlp_fwd_bf16(pbm.data_ptr(), packed.data_ptr(), F, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3,
                                                               N_RAYS, N_SAMPLES, 0, raw.data_ptr(), st().cuda_stream)
-                    kname = "mlp_fwd_bf16_kernel"
+                    kname = "mlp_fwd_bf16_pair_kernel"
                 else:
                     psm, nsm = net.packed_split(F, ops.N_SPLIT[a.mlp_precision])
                     k_mode = lambda: lib.mvsnerf_mlp_fwd_split(psm.data_ptr(), packed.data_ptr(), F, nsm, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3,

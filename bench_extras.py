@@ -274,7 +274,7 @@ def config45_legs(dev, with_oracle=True):
         t_b = event_time(lambda: lib.mvsnerf_mlp_fwd_bf16(pb.data_ptr(), packed.data_ptr(), F, rays[1].data_ptr(), 3, feat.data_ptr(), F, dirs_g.data_ptr(), 3,
                                                           N_RAYS, S, 0, raw.data_ptr(), st().cuda_stream), 100)
         tfb = flop_per_sample * N_RAYS * S / (t_b * 1e-3) / 1e12
-        c4["mlp_kernel_roofline"] = {"kernel": "mlp_fwd_bf16_kernel", "bound": "mfma", "achieved": round(tfb, 1), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
+        c4["mlp_kernel_roofline"] = {"kernel": "mlp_fwd_bf16_pair_kernel", "bound": "mfma", "achieved": round(tfb, 1), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
                                      "frac": round(tfb / PEAK_16BIT_MFMA_TFLOPS, 4), "avg_launch_ms": round(t_b, 4), "flop_per_sample": flop_per_sample,
                                      "note": "one 1024 x 128 launch at feat_dim 28, HIP events; v_mfma_f32_32x32x16_bf16, fp32 accumulate"}
         # parity of a 1024-ray batch on the GPU-built volume: default (guarded fp16x3) and bf16 MLP against the CPU oracle

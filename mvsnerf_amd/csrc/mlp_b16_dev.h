@@ -101,6 +101,40 @@ __device__ __forceinline__ float pe_op_t(int t, int half, float px, float py, fl
 __device__ __forceinline__ float pe_op(int t, int half, float px, float py, float pz) { return pe_op_t<false>(t, half, px, py, pz); }
 __device__ __forceinline__ float pe_op_hw(int t, int half, float px, float py, float pz) { return pe_op_t<true>(t, half, px, py, pz); }
 
+// v_sin_f32 is a transcendental: an instruction that consumes its result needs one wait state, which the compiler inserts for the instructions it knows - not for
+// the ones inside an asm statement.  Call this between pe_op_hw() values and an asm that reads them (first fp16x3 version: wrong pieces wherever a v_cvt_pk followed
+// its v_sin directly; sigma off by 1e-4).
+__device__ __forceinline__ void trans_fence8(float (&t)[8])
+{
+    asm volatile("s_nop 0" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+}
+
+// A wave's feature operands (32 points x F floats, the lane (m, half) wants columns [half F/2, (half + 1) F/2) of point m) fetched as WHOLE 16-byte vectors
+// - the block is contiguous when feat_stride == F - through a wave-private LDS stage of 32 * F * 4 bytes, instead of F / 2 dword loads per lane at an 80-byte
+// stride (~20 cache lines per wave-instruction, one scalar branch + wait per element as the compiler lays them out: the longest stretch of a wave's prologue).
+// Returns false - nothing touched - when the block is not contiguous / aligned / fully inside the tensor or F > 32; the caller then loads per lane.
+template <int MAXV>
+__device__ __forceinline__ bool stage_features(float (&fv)[MAXV], const float* __restrict__ feat, int feat_stride, int F, int64_t first_point, int64_t P,
+                                               char* __restrict__ stage, int lane)
+{
+    if (feat_stride != F || F > 32 || first_point + 32 > P || ((reinterpret_cast<uintptr_t>(feat) | (uintptr_t)(first_point * F * 4)) & 15)) return false;
+    const f32x4* __restrict__ g = reinterpret_cast<const f32x4*>(feat + first_point * F);
+    f32x4* __restrict__ st4 = reinterpret_cast<f32x4*>(stage);
+    const int n4 = 8 * F;                                                     // 16-byte vectors of the block (<= 256)
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = k * 64 + lane; v[k] = g[i < n4 ? i : 0]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = k * 64 + lane; if (i < n4) st4[i] = v[k]; }
+    const float* __restrict__ mine = reinterpret_cast<const float*>(stage) + (lane & 31) * F + (lane >> 5) * (F / 2);
+    const int n_half = F / 2;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) fv[i] = mine[i < n_half ? i : 0];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) fv[i] = i < n_half ? fv[i] : 0.0f;
+    return true;
+}
+
 }  // namespace mlp
 
 // mlp_f16x3.hip: the two-piece fp16 split behind mvsnerf_mlp_{packed_split_elems, pack_split, fwd_split}(n_split = MVSNERF_SPLIT_FP16)

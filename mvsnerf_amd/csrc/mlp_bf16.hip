@@ -89,14 +89,18 @@ __device__ __forceinline__ void slabb_sync()
 // the gap behind every instruction carries one read.
 constexpr int B_AHEAD = 3;
 template <int STEPS, int NBLK, typename BFN>
-__device__ __forceinline__ void gemm_b(const char* __restrict__ w, f32x16 (&acc)[NBLK], int lane, BFN bfn)
+__device__ __forceinline__ void gemm_b(const char* __restrict__ w, f32x16 (&acc)[NBLK], int lane, BFN bfn, bool high = false)
 {
     constexpr int N = STEPS * NBLK, D = B_AHEAD;
     const bf16x8* __restrict__ fw = reinterpret_cast<const bf16x8*>(w) + lane;
     bf16x8 a[D + 1];
 #pragma unroll
     for (int i = 0; i < D && i < N; ++i) a[i] = fw[i * 64];
-    __builtin_amdgcn_s_setprio(1);                // a matrix stream beats the other wave's epilogue (and, between two matrix streams, the older wave wins)
+    // a matrix stream beats the other wave's epilogue (priority 0); two matrix streams of equal priority share the pipe about evenly (measured: 64 cycles per
+    // instruction for BOTH waves of a SIMD)
+    // (measured: priority 2 for the older waves of the 8-wave kernel - strictly sequential GEMMs - is 3 % SLOWER than equal priorities: `high` is accepted and unused)
+    (void)high;
+    __builtin_amdgcn_s_setprio(1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -109,12 +113,19 @@ __device__ __forceinline__ void gemm_b(const char* __restrict__ w, f32x16 (&acc)
     __builtin_amdgcn_s_setprio(0);
 }
 
+// eight fp32 values -> bf16 (round to nearest even), two per v_cvt_pk_bf16_f32 (written element by element the compiler converts each value alone and merges
+// pairs with v_perm_b32: twelve instructions instead of four)
 __device__ __forceinline__ bf16x8 pack8(const float* v)
 {
-    bf16x8 r;
+    typedef unsigned u32x4_b __attribute__((ext_vector_type(4)));
+    u32x4_b r;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (__bf16)v[j];
-    return r;
+    for (int j = 0; j < 4; ++j) {
+        unsigned t;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(t) : "v"(v[2 * j]), "v"(v[2 * j + 1]));
+        r[j] = t;
+    }
+    return __builtin_bit_cast(bf16x8, r);
 }
 
 // SAVE (bf16 training forward, train_mvs_nerf_pl.py:317-318 `precision=16`): the operands the backward pass consumes are written in
@@ -222,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_bf16_kernel(
         float t8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { t8[j] = pe_op_hw(8 * s + j, half, px, py, pz); save(S_E + 8 * s + j, t8[j]); }
+        trans_fence8(t8);
         pe8[s] = pack8(t8);
     }
 
@@ -314,12 +326,16 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_bf16_kernel(
 
 
 // ------------------------------------------------------------------------------------------ inference kernel (round 6)
-// The same arithmetic with EIGHT waves (256 points) per workgroup and the layer barriers of the fp16x3 kernel (mlp_f16x3.hip): the two waves of a SIMD run
-// their GEMMs one after the other anyway (the older wins the matrix pipe), so an older wave (0..3) runs [GEMM, epilogue, barrier] and a younger one
-// [GEMM, barrier, epilogue]: the barrier falls when the younger wave's GEMM ends, the older wave starts the next layer at once, and each wave's epilogue - here
-// HALF a layer's time, a bf16 layer being 32 matrix instructions against ~200 VALU - runs beside its partner's GEMM instead of in front of its own.  One slab
-// serves 256 points (half the weight bytes per point of the 4-wave kernel above, which stays for the training forward with its activation store).
-constexpr int BP_WAVES = 8;
+// The same arithmetic with EIGHT waves (256 points) per workgroup - one slab serves twice the points of the 4-wave kernel above, which stays for the training
+// forward with its activation store - and NO separate epilogue: a bf16 layer is 32 matrix instructions against ~200 VALU of finishing (modulation, ReLU,
+// conversion), and the two waves of a SIMD run both phases together (census: GEMMs at 64 cycles per instruction each, then both epilogues, then the barrier:
+// 3 700 cycles per layer for 2 048 of matrix work).  Here the finishing of layer l is done INSIDE the GEMM of layer l + 1: the B operand of k-step s is
+// act(acc_l[8s .. 8s+7]) converted in the gaps behind the matrix instructions of k-step s - 1, straight from the previous layer's accumulators, which stay live
+// (two accumulator sets alternate; the bf16 copy of the activations and the fp32 scratch of the 4-wave kernel are gone).
+#ifndef BP_WAVES_N
+#define BP_WAVES_N 8
+#endif
+constexpr int BP_WAVES = BP_WAVES_N;             // 8: one workgroup per CU; 4: two (DEV: -DBP_WAVES_N=4)
 constexpr int BP_THREADS = 64 * BP_WAVES;
 
 __device__ __forceinline__ void slabp_dma(char* __restrict__ dst, const __bf16* __restrict__ src, size_t n_elems, int wave, int lane)
@@ -327,8 +343,54 @@ __device__ __forceinline__ void slabp_dma(char* __restrict__ dst, const __bf16* 
     lds_dma<BP_WAVES>(dst, src, (int)(n_elems >> 9), wave, lane);
 }
 
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b)
+{
+    unsigned t;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(t) : "v"(a), "v"(b));
+    return t;
+}
+
+// acc[nb] += W[block nb] * B over STEPS k-steps.  B of k-step 0 = `first`; B of k-step s + 1 is produced pair by pair by next(s + 1, pair) -> packed bf16 pair,
+// in the gaps behind the matrix instructions of k-step s (pairs 0, 1 behind the first, 2 behind the second, 3 behind the third: the last conversion is a matrix
+// instruction and a ds_read away from its reader - the compiler does not know the asm writes a VGPR a matrix instruction reads).
+template <int STEPS, int NBLK, typename NEXT>
+__device__ __forceinline__ void gemm_bf(const char* __restrict__ w, f32x16 (&acc)[NBLK], int lane, bf16x8 first, NEXT next)
+{
+    typedef unsigned u32x4_b __attribute__((ext_vector_type(4)));
+    constexpr int N = STEPS * NBLK, D = B_AHEAD;
+    const bf16x8* __restrict__ fw = reinterpret_cast<const bf16x8*>(w) + lane;
+    bf16x8 a[D + 1];
+    u32x4_b b[2];
+    b[0] = __builtin_bit_cast(u32x4_b, first);
+#pragma unroll
+    for (int i = 0; i < D && i < N; ++i) a[i] = fw[i * 64];
+    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int s = i / NBLK, nb = i % NBLK;
+        if (i + D < N) a[(i + D) % (D + 1)] = fw[(i + D) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % (D + 1)], __builtin_bit_cast(bf16x8, b[s & 1]), acc[nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < STEPS) {
+            u32x4_b& n = b[(s + 1) & 1];
+            if (NBLK == 4) {
+                if (nb == 0) { n[0] = next(s + 1, 0); n[1] = next(s + 1, 1); }
+                else if (nb == 1) n[2] = next(s + 1, 2);
+                else if (nb == 2) n[3] = next(s + 1, 3);
+            } else if (nb == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) n[j] = next(s + 1, j);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
 template <bool ALPHA_ONLY>
-__global__ __launch_bounds__(BP_THREADS) void mlp_fwd_bf16_pair_kernel(
+__global__ __launch_bounds__(BP_THREADS, BP_WAVES == 4 ? 2 : 1) void mlp_fwd_bf16_pair_kernel(
     const __bf16* __restrict__ wq, const float* __restrict__ packed_f32, int F, const float* __restrict__ ndc, int ndc_stride,
     const float* __restrict__ feat, int feat_stride, const float* __restrict__ dirs, int dirs_stride,
     int64_t P, int S, float* __restrict__ raw)
@@ -342,144 +404,126 @@ __global__ __launch_bounds__(BP_THREADS) void mlp_fwd_bf16_pair_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
-    const bool young = wave >= BP_WAVES / 2;
     const int64_t p_raw = ((int64_t)blockIdx.x * BP_WAVES + wave) * 32 + (lane & 31);
     const bool live = p_raw < P;
     const int64_t p = live ? p_raw : P - 1;
     constexpr size_t ACT = (size_t)B_ACT_STEPS * 4 * 512, PEW = (size_t)B_PE_STEPS * 4 * 512;      // bf16 elements of a slab
-#ifdef BF_CENSUS      // DEV probe: shader-clock stamps of this wave's phases, 32 per tile, behind the results (scratch/r6/bf_census.py)
-    unsigned* cen = reinterpret_cast<unsigned*>(raw + P * (ALPHA_ONLY ? 1 : 4)) + ((int64_t)blockIdx.x * BP_WAVES + wave) * 32;
-    int cen_i = 0;
-#define BP_STAMP() do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if (lane == 0 && cen_i < 32) cen[cen_i] = (unsigned)t__; ++cen_i; } while (0)
-#else
-#define BP_STAMP() do {} while (0)
-#endif
-    BP_STAMP();
 
     slabp_dma(buf0, wq + L.featw, L.l1 - L.featw, wave, lane);                       // slab 0 = pts_bias weights + layer 0
     for (int i = tid; i < V_TOTAL; i += BP_THREADS) vec[i] = packed_f32[LF.vec + i];
     const float px = ndc[p * ndc_stride + 0], py = ndc[p * ndc_stride + 1], pz = ndc[p * ndc_stride + 2];
-    float dl[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                           // the view direction: asked for here, used by the last GEMM
+    float dl0 = 0.0f, dl1 = 0.0f;                                                     // the view direction: asked for here, used by the last GEMM
     if (!ALPHA_ONLY) {
         const int64_t ray = p / S;
-        dl[0] = half ? dirs[ray * dirs_stride + 1] : dirs[ray * dirs_stride + 0];
-        dl[1] = half ? 0.0f : dirs[ray * dirs_stride + 2];
+        dl0 = half ? dirs[ray * dirs_stride + 1] : dirs[ray * dirs_stride + 0];
+        dl1 = half ? 0.0f : dirs[ray * dirs_stride + 2];
     }
     bf16x8 fb8[3];
     {
         float fv[24];
-        const float* fp = feat + p * feat_stride + half * (F / 2);
-        // (the compiler turns this into one scalar branch + one load per element; issuing all 24 unconditionally - padding slots re-reading element 0 - measured
-        // SLOWER, 34.4 -> 41.9 us in the bf16 kernel: a 64-lane dword load at an 80-byte stride is ~20 cache lines per instruction, the address unit is what waits)
+        // (buf1 is idle until layer 1's slab is asked for behind the first barrier: 4 KB of it per wave stage the features)
+        if (!stage_features(fv, feat, feat_stride, F, ((int64_t)blockIdx.x * BP_WAVES + wave) * 32, P, buf1 + wave * 4096, lane)) {
+            const float* fp = feat + p * feat_stride + half * (F / 2);
 #pragma unroll
-        for (int i = 0; i < 24; ++i) fv[i] = i < F / 2 ? fp[i] : 0.0f;
+            for (int i = 0; i < 24; ++i) fv[i] = i < F / 2 ? fp[i] : 0.0f;
+        }
 #pragma unroll
         for (int s = 0; s < 3; ++s) fb8[s] = pack8(fv + 8 * s);
     }
     float bias[64];
-    bf16x8 hb[8], pe8[B_PE_STEPS];
-    f32x16 acc[4];
-    auto finish_b = [&](bool modulated_relu, const float* head_w, float& head_sum) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            float v8[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int q = 8 * s + j;
-                const float x = acc[q >> 4][q & 15];
-                v8[j] = modulated_relu ? fmaxf(x * bias[q], 0.0f) : x;
-                if (head_w) head_sum = fmaf(head_w[q], v8[j], head_sum);
-            }
-            hb[s] = pack8(v8);
-        }
+    bf16x8 pe8[B_PE_STEPS];
+    f32x16 accA[4], accB[4];
+    // operand pairs for gemm_bf: precomputed (features, encoding) or finished on the fly from the previous layer's accumulators
+    auto from8 = [&](const bf16x8* arr) { return [arr](int s, int j) { return __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, arr[s])[j]; }; };
+    auto relu_of = [&](f32x16 (&prev)[4]) {
+        return [&](int s, int j) {
+            const int q = 8 * s + 2 * j;
+            return cvt_pk_bf16(fmaxf(prev[q >> 4][q & 15] * bias[q], 0.0f), fmaxf(prev[(q + 1) >> 4][(q + 1) & 15] * bias[q + 1], 0.0f));
+        };
     };
-    float no_head = 0.0f;
-    auto act = [&](int s) { return hb[s]; };
-    auto enc = [&](int s) { return pe8[s]; };
+    auto first_relu = [&](f32x16 (&prev)[4]) {
+        float v8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = fmaxf(prev[0][j] * bias[j], 0.0f);
+        return pack8(v8);
+    };
 
     slabb_sync();
-    BP_STAMP();
     slabp_dma(buf1, wq + L.l1, ACT, wave, lane);                                     // layer 1 -> buf1
     {   // bias = pts_bias(feat)
-        init_acc_b<4>(acc, vec + V_BIASG + half * 64);
-        auto fb = [&](int s) { return fb8[s]; };
-        if (L.fsteps == 1) gemm_b<1, 4>(buf0, acc, lane, fb);
-        else if (L.fsteps == 2) gemm_b<2, 4>(buf0, acc, lane, fb);
-        else gemm_b<3, 4>(buf0, acc, lane, fb);
-        BP_STAMP();
+        init_acc_b<4>(accA, vec + V_BIASG + half * 64);
+        if (L.fsteps == 1) gemm_bf<1, 4>(buf0, accA, lane, fb8[0], from8(fb8));
+        else if (L.fsteps == 2) gemm_bf<2, 4>(buf0, accA, lane, fb8[0], from8(fb8));
+        else gemm_bf<3, 4>(buf0, accA, lane, fb8[0], from8(fb8));
 #pragma unroll
-        for (int q = 0; q < 64; ++q) bias[q] = acc[q >> 4][q & 15];
+        for (int q = 0; q < 64; ++q) bias[q] = accA[q >> 4][q & 15];
     }
 #pragma unroll
-    for (int s = 0; s < B_PE_STEPS; ++s) {                                            // the encoding (transcendental unit), beside the partner's matrix work
+    for (int s = 0; s < B_PE_STEPS; ++s) {                                            // the encoding (transcendental unit)
         float t8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) t8[j] = pe_op_hw(8 * s + j, half, px, py, pz);
+        trans_fence8(t8);
         pe8[s] = pack8(t8);
     }
-    init_acc_b<4>(acc, vec + V_L0 + half * 64);
-    gemm_b<B_PE_STEPS, 4>(buf0 + b_seg(L.fsteps, 4) * 2, acc, lane, enc);           // layer 0 (same slab)
-    BP_STAMP();
-    // behind the GEMM in buffer X, X takes the slab after next
-    if (young) { slabb_sync(); slabp_dma(buf0, wq + L.l1 + ACT, ACT, wave, lane); }
-    finish_b(true, nullptr, no_head);
-    init_acc_b<4>(acc, vec + V_L0 + 128 + half * 64);
-    BP_STAMP();
-    if (!young) { slabb_sync(); slabp_dma(buf0, wq + L.l1 + ACT, ACT, wave, lane); }
-    BP_STAMP();
-#pragma unroll 1
-    for (int layer = 1; layer <= 4; ++layer) {
-        char* cur = (layer & 1) ? buf1 : buf0;
-        auto refill = [&]() {
-            slabb_sync();
-            if (layer < 3) slabp_dma(cur, wq + L.l1 + (size_t)(layer + 1) * ACT, ACT, wave, lane);
-            else if (layer == 3) slabp_dma(cur, wq + L.l5a, PEW, wave, lane);
-            else slabp_dma(cur, wq + L.l5b, ACT, wave, lane);
-        };
-        gemm_b<B_ACT_STEPS, 4>(cur, acc, lane, act);
-        BP_STAMP();
-        if (young) refill();
-        finish_b(true, nullptr, no_head);
-        init_acc_b<4>(acc, vec + V_L0 + 128 * (layer + 1) + half * 64);
-        BP_STAMP();
-        if (!young) refill();
-        BP_STAMP();
-    }
+    init_acc_b<4>(accA, vec + V_L0 + half * 64);
+    gemm_bf<B_PE_STEPS, 4>(buf0 + b_seg(L.fsteps, 4) * 2, accA, lane, pe8[0], from8(pe8));      // layer 0 (same slab) -> A
+    // layers 1..4: layer l reads the finished values of the other accumulator set; behind the GEMM in buffer X, X takes the slab after next
+    bf16x8 first;
+#define BP_LAYER(LAYER, CUR, PREV, NEXT_DMA)                                                                  \
+    init_acc_b<4>(CUR, vec + V_L0 + 128 * (LAYER) + half * 64);                                               \
+    first = first_relu(PREV);                                                                                 \
+    slabb_sync();                                                                                             \
+    NEXT_DMA;                                                                                                 \
+    gemm_bf<B_ACT_STEPS, 4>(((LAYER) & 1) ? buf1 : buf0, CUR, lane, first, relu_of(PREV));
+    BP_LAYER(1, accB, accA, slabp_dma(buf0, wq + L.l1 + 1 * ACT, ACT, wave, lane))              // layer 2 -> buf0
+    BP_LAYER(2, accA, accB, slabp_dma(buf1, wq + L.l1 + 2 * ACT, ACT, wave, lane))              // layer 3 -> buf1
+    BP_LAYER(3, accB, accA, slabp_dma(buf0, wq + L.l1 + 3 * ACT, ACT, wave, lane))              // layer 4 -> buf0
+    BP_LAYER(4, accA, accB, slabp_dma(buf1, wq + L.l5a, PEW, wave, lane))                       // layer 5, encoding part -> buf1
+#undef BP_LAYER
+    // layer 5 on cat([pts, h4]) -> B: encoding part (buf1), then the h4 part (buf0) finished from A
+    init_acc_b<4>(accB, vec + V_L0 + 128 * 5 + half * 64);
+    first = first_relu(accA);
+    slabb_sync();
+    slabp_dma(buf0, wq + L.l5b, ACT, wave, lane);
+    gemm_bf<B_PE_STEPS, 4>(buf1, accB, lane, pe8[0], from8(pe8));
+    slabb_sync();
+    if (!ALPHA_ONLY) slabp_dma(buf1, wq + L.feat, ACT, wave, lane);
+    gemm_bf<B_ACT_STEPS, 4>(buf0, accB, lane, first, relu_of(accA));
+    // h5 = relu(B * bias): alpha_linear reads it in fp32; feature_linear gets it finished on the fly like every other layer
     float sigma;
-    {   // layer 5 on cat([pts, h4]): L5a in buf1, L5b in buf0
-        gemm_b<B_PE_STEPS, 4>(buf1, acc, lane, enc);
-        BP_STAMP();
-        slabb_sync();
-        BP_STAMP();
-        if (!ALPHA_ONLY) slabp_dma(buf1, wq + L.feat, ACT, wave, lane);
-        gemm_b<B_ACT_STEPS, 4>(buf0, acc, lane, act);
-        BP_STAMP();
-        if (!ALPHA_ONLY && young) { slabb_sync(); slabp_dma(buf0, wq + L.views, b_seg(B_VIEW_STEPS, 2), wave, lane); }
+    {
+        const float* wa = vec + V_WA + half * 64;
         float part = 0.0f;
-        finish_b(true, vec + V_WA + half * 64, part);                                 // alpha_linear on the fp32 activations, as they are produced
+#pragma unroll
+        for (int q = 0; q < 64; ++q) part = fmaf(wa[q], fmaxf(accB[q >> 4][q & 15] * bias[q], 0.0f), part);
         part += __shfl_xor(part, 32);
         sigma = fmaxf(part + vec[V_BA], 0.0f);
-        if (!ALPHA_ONLY) init_acc_b<4>(acc, vec + V_FEAT + half * 64);
-        BP_STAMP();
-        if (!ALPHA_ONLY && !young) { slabb_sync(); slabp_dma(buf0, wq + L.views, b_seg(B_VIEW_STEPS, 2), wave, lane); }
-        BP_STAMP();
     }
     if (ALPHA_ONLY) {
         if (live && half == 0) raw[p_raw] = sigma;
         return;
     }
-    gemm_b<B_ACT_STEPS, 4>(buf1, acc, lane, act);                                     // feature_linear (no activation)
-    BP_STAMP();
-    if (young) slabb_sync();
-    finish_b(false, nullptr, no_head);
-    const bf16x8 d8 = pack8(dl);
+    init_acc_b<4>(accA, vec + V_FEAT + half * 64);
+    first = first_relu(accB);
+    slabb_sync();
+    slabp_dma(buf0, wq + L.views, b_seg(B_VIEW_STEPS, 2), wave, lane);
+    gemm_bf<B_ACT_STEPS, 4>(buf1, accA, lane, first, relu_of(accB));                 // feature_linear (no activation) -> A
+    // views_linears[0] on [feature | direction]: the feature values go in as they are
     f32x16 av[2];
     init_acc_b<2>(av, vec + V_VIEWS + half * 32);
-    BP_STAMP();
-    if (!young) slabb_sync();
-    BP_STAMP();
-    gemm_b<B_VIEW_STEPS, 2>(buf0, av, lane, [&](int s) { return s < 8 ? hb[s < 8 ? s : 0] : d8; });
-    BP_STAMP();
+    {
+        float v8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = accA[0][j];
+        first = pack8(v8);
+    }
+    const unsigned d01 = cvt_pk_bf16(dl0, dl1);
+    slabb_sync();
+    gemm_bf<B_VIEW_STEPS, 2>(buf0, av, lane, first, [&](int s, int j) {
+        if (s < 8) { const int q = 8 * s + 2 * j; return cvt_pk_bf16(accA[q >> 4][q & 15], accA[(q + 1) >> 4][(q + 1) & 15]); }
+        return j == 0 ? d01 : 0u;
+    });
     float rgb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -491,7 +535,6 @@ __global__ __launch_bounds__(BP_THREADS) void mlp_fwd_bf16_pair_kernel(
         rgb[c] = 1.0f / (1.0f + expf(-(part + vec[V_BR + c])));
     }
     if (live && half == 0) *reinterpret_cast<f32x4*>(raw + p_raw * 4) = f32x4{rgb[0], rgb[1], rgb[2], sigma};
-    BP_STAMP();
 }
 
 

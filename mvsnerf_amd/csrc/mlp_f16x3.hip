@@ -334,7 +334,8 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
         dir1 = half ? 0.0f : dirs[ray * dirs_stride + 2];
     }
     float fv[24];                                 // F/2 <= 20 feature operands of this lane half
-    {
+    // (buf1 is idle until layer 1's slab is asked for behind the first barrier: 4 KB of it per wave stage the features - mlp_b16_dev.h)
+    if (!stage_features(fv, feat, feat_stride, F, ((int64_t)blockIdx.x * H3_WAVES + wave) * 32, P, buf1 + wave * 4096, lane)) {
         const float* fp = feat + p * feat_stride + half * (F / 2);
         // (the compiler turns this into one scalar branch + one load per element; issuing all 24 unconditionally - padding slots re-reading element 0 - measured
         // SLOWER, 34.4 -> 41.9 us in the bf16 kernel: a 64-lane dword load at an 80-byte stride is ~20 cache lines per instruction, the address unit is what waits)
@@ -457,9 +458,7 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
         float t8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) t8[j] = pe_op_hw(8 * s + j, half, px, py, pz);
-        // v_sin_f32 is a transcendental: its consumer needs one wait state that the compiler inserts for instructions it knows - the split statements are not
-        // among them (first version: wrong pieces wherever a v_cvt_pk followed its v_sin directly; sigma off by 1e-4)
-        asm volatile("s_nop 0" : "+v"(t8[0]), "+v"(t8[1]), "+v"(t8[2]), "+v"(t8[3]), "+v"(t8[4]), "+v"(t8[5]), "+v"(t8[6]), "+v"(t8[7]));
+        trans_fence8(t8);                                                             // (v_sin_f32 -> asm consumer: mlp_b16_dev.h)
         pe[s] = split8h(t8);
     }
     // The encoding pieces wait for layer 5 in the wave's private segment (32 dwords per lane, stored here, loaded once behind layer 4): between the two a wave
