@@ -414,6 +414,7 @@ def main():
                 "config5_default_frame_ms": None if dig(extras, "config5", "frame_guarded_default_mlp", "seconds") is None
                 else round(dig(extras, "config5", "frame_guarded_default_mlp", "seconds") * 1e3, 2),
                 "strong_scaling_frame_512x640_default": dig(multi, "strong_scaling", "frame_512x640_default", "speedup"),
+                "strong_scaling_frame_512x640_default_scene_encoded_once": dig(multi, "strong_scaling", "frame_512x640_default_scene_encoded_once", "speedup"),
                 "strong_scaling_frame_512x640_fp32": dig(multi, "strong_scaling", "frame_512x640_fp32_kernels", "speedup"),
                 "strong_scaling_frame_config5": dig(multi, "strong_scaling", "frame_config5_1008x756_fp32_kernels", "speedup"),
                 "strong_scaling_train_step_ray_dp_fp32": dig(multi, "strong_scaling", "train_step_ray_dp_fp32", "speedup"),

@@ -17,7 +17,7 @@ COL_BYTES_PER_SAMPLE = 204        # 3 views x 48 B + 12 B + 48 B out
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
 PEAK_16BIT_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16 matrix peak (v_mfma_f32_32x32x16_{bf16,f16})
-PMC_FILE = "profiles/r05_pmc_summary.json"
+PMC_FILE = "profiles/r06_pmc_summary.json"
 
 
 def csrc_sha16():

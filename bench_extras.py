@@ -126,7 +126,17 @@ def multi_gpu_legs(dev, rank, world, train_steps=5, shared_gpu=False):
             dt_d1, (rgb_d1, _) = timed_alone(lambda: system.render_view(batch), dev)
     strong["frame_512x640_default"] = {"seconds_1_rank": round(dt_d1, 4), "seconds_n_ranks": round(dt_d, 4), "speedup": round(dt_d1 / dt_d, 3),
                                        "equals_single_rank_frame": all_ranks_true(torch.equal(rgb_d, rgb_d1), dev, world)}
-    del rgb_d, rgb_d1
+    # ... and with the scene encoded ONCE (MVSSystem.encode_scene; a camera path over one scene, as renderer_video.ipynb renders it): only the rays are left,
+    # the replicated encode no longer caps the ratio
+    with ops.mlp_precision("auto"):
+        vol_once = system.encode_scene(batch)
+        system.render_view(batch, volume=vol_once)
+        dt_c, (rgb_c, _) = timed_collective(lambda: system.render_view(batch, volume=vol_once), dev, world)
+        with D.single_rank():
+            dt_c1, (rgb_c1, _) = timed_alone(lambda: system.render_view(batch, volume=vol_once), dev)
+    strong["frame_512x640_default_scene_encoded_once"] = {"seconds_1_rank": round(dt_c1, 4), "seconds_n_ranks": round(dt_c, 4), "speedup": round(dt_c1 / dt_c, 3),
+                                                          "equals_the_encoding_frame": bool(torch.equal(rgb_c1, rgb_d1))}
+    del rgb_d, rgb_d1, rgb_c, rgb_c1, vol_once
     out["strong_scaling"] = strong
     out["frame_tile_parallel"] = {"seconds": round(dt, 4), "rays_per_s_incl_encode": round(H_IMG * W_IMG / dt, 1), "n_ranks": world,
                                   "equals_single_rank_frame": same, "frame_comparisons_repeated": mismatches,

@@ -8,7 +8,7 @@
  * Two tiers (ABI v12).  THIS header is the stage-level surface SURVEY.md 8(b) asks for - plane sweep forward / backward, the generic
  * CostRegNet / FeatureNet layer calls (any shape), volume / colour lookups, MLP pack / forward / backward in every arithmetic, compositing, the
  * one-call ray march (mvsnerf_raymarch_{fwd, fwd_batched, train_fwd, bwd}, mvsnerf_render_pixels_fwd), ray generation, importance sampling,
- * Adam: 68 entries, frozen (tests/test_abi_surface.py holds the list; a change here is an ABI bump).  Everything a scene encode or a training
+ * Adam: 70 entries, frozen (tests/test_abi_surface.py holds the list; a change here is an ABI bump).  Everything a scene encode or a training
  * step needs can be written against it.  include/mvsnerf_hip_internal.h declares the 63 further exports that mvsnerf_amd's own host layer
  * drives its TUNED layer loop with - per-shape matrix-core convolutions and their *_tiles / *_parts / *_packed_elems queries, blocked /
  * bf16 / two-piece-fp16 cost-volume layouts, multi-job pack and reduction helpers, the guarded conv sequences: plumbing that moves with the
@@ -356,6 +356,13 @@ int mvsnerf_composite_bwd(const float* raw, const float* z, int64_t N, int S, in
  * (train_mvs_nerf_finetuning_pl.py:54) and, through the encoder, by generalizable training. */
 int mvsnerf_volume_sample_bwd(int D, int H, int W, int C, const float* ndc, int64_t P,
                               const float* g, int g_stride, float* gvol, void* stream);
+/* The same gradient with an ORDER-INDEPENDENT reduction (ABI v12; like mvsnerf_planesweep_costvar_bwd_det): contributions are accumulated in 64-bit fixed point
+ * (integer atomics commute; scale from max |g| found on the device: a contribution resolves 2^-40 of the largest one), then added to gvol.  Two runs - and N ranks
+ * against one - give bit-identical volume gradients; two extra passes (max, finish) and 8 bytes of zeroed workspace per volume element.
+ * workspace_zeroed: mvsnerf_volume_sample_bwd_det_workspace_words(D, H, W, C) int64 words, 8-byte aligned, zeroed before every call. */
+size_t mvsnerf_volume_sample_bwd_det_workspace_words(int D, int H, int W, int C);
+int mvsnerf_volume_sample_bwd_det(int D, int H, int W, int C, const float* ndc, int64_t P, const float* g, int g_stride, float* gvol,
+                                  void* workspace_zeroed, void* stream);
 
 /* Alpha compositing: raw2alpha + raw2outputs (renderer.py:18-26, 65-92).
  * raw[N][S][4], z[N][S] -> rgb_map[N][3], disp[N], acc[N], weights[N][S], depth[N], alpha[N][S].

@@ -212,6 +212,8 @@ SIGNATURES = {
     "mvsnerf_mlp_bwd": (_c_i, [_c_fp, _c_fp, _c_i, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp, _c_i, ctypes.POINTER(_c_fp), ctypes.POINTER(_c_fp), _c_fp, _c_fp, _c_fp]),
     "mvsnerf_composite_bwd": (_c_i, [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_volume_sample_bwd": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_fp, _c_l, _c_fp, _c_i, _c_fp, _c_fp]),
+    "mvsnerf_volume_sample_bwd_det_workspace_words": (ctypes.c_size_t, [_c_i] * 4),
+    "mvsnerf_volume_sample_bwd_det": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_fp, _c_l, _c_fp, _c_i, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_composite_fwd": (_c_i, [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_raymarch_fwd": (_c_i, [ctypes.POINTER(RaymarchArgs), _c_fp]),
     "mvsnerf_raymarch_fwd_batched": (_c_i, [ctypes.POINTER(RaymarchArgs), _c_i, _c_fp]),

@@ -538,6 +538,99 @@ extern "C" int mvsnerf_volume_sample_bwd(int D, int H, int W, int C, const float
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same scatter with an ORDER-INDEPENDENT reduction (round 6; the plane sweep has had one since round 4): float atomics make the volume gradient depend
+// on the order in which samples arrive, and under use_amp one flipped last bit there grows 3-5x per layer through the bf16 encoder backward.  Here every
+// contribution is rounded ONCE to 64-bit fixed point - scale 2^(40 - e) with max |g| < 2^e found on the device, so a contribution resolves 2^-40 of the largest
+// one and 4 M of them fit a word - integer atomics commute, and a last pass adds the sums to gvol.  Two runs, and N ranks against one, give identical bits.
+// workspace (int64 words, zeroed by the caller): [0] = bit pattern of max |g|, [8 ..] = one accumulator per volume element.
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ g, int64_t P, int C, int g_stride, unsigned* __restrict__ out)
+{
+    unsigned m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P * C; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / C;
+        m = max(m, __float_as_uint(fabsf(g[p * g_stride + (i - p * C)])) & 0x7fffffffu);
+    }
+    for (int o = 32; o; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+__device__ __forceinline__ int det_exponent(unsigned max_bits)        // e with max |g| < 2^e (finite, non-zero input)
+{
+    int e;
+    (void)frexpf(__uint_as_float(max_bits), &e);
+    return e;
+}
+
+__global__ __launch_bounds__(256) void volume_sample_bwd_det_scatter_kernel(
+    int D, int H, int W, int C, const float* __restrict__ ndc, int64_t P, const float* __restrict__ g, int g_stride,
+    const unsigned* __restrict__ max_bits, unsigned long long* __restrict__ acc)
+{
+    const unsigned mb = *max_bits;
+    if (mb == 0 || mb >= 0x7f800000u) return;                       // all-zero gradient; a non-finite one is left to the float path's semantics (finish reports nothing)
+    const double scale = ldexp(1.0, 40 - det_exponent(mb));
+    const int Q = C >> 2;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = tid / Q;
+    const int ch = (int)(tid - p * Q) * 4;
+    if (p >= P) return;
+    const float gx = ndc[p * 3 + 0] * 2.0f - 1.0f, gy = ndc[p * 3 + 1] * 2.0f - 1.0f, gz = ndc[p * 3 + 2] * 2.0f - 1.0f;
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1), iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1), iz = ((gz + 1.0f) / 2.0f) * (float)(D - 1);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + p * g_stride + ch);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int zc = k >> 2, yc = (k >> 1) & 1, xc = k & 1;
+        const float cxf = fx + (float)xc, cyf = fy + (float)yc, czf = fz + (float)zc;
+        if (!((cxf >= 0.0f) && (cxf <= (float)(W - 1)) && (cyf >= 0.0f) && (cyf <= (float)(H - 1)) && (czf >= 0.0f) && (czf <= (float)(D - 1)))) continue;
+        const float w = (xc ? (ix - fx) : ((fx + 1.0f) - ix)) * (yc ? (iy - fy) : ((fy + 1.0f) - iy)) * (zc ? (iz - fz) : ((fz + 1.0f) - iz));
+        unsigned long long* dst = acc + ((((int64_t)czf * H + (int)cyf) * W + (int)cxf) * C + ch);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const long long q = __double2ll_rn((double)(gv[c] * w) * scale);        // the float product of the atomic path, rounded once more to the fixed grid
+            if (q) atomicAdd(dst + c, (unsigned long long)q);                        // (two's complement: unsigned addition is the signed one)
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void volume_sample_bwd_det_finish_kernel(const long long* __restrict__ acc, int64_t n, const unsigned* __restrict__ max_bits,
+                                                                           float* __restrict__ gvol)
+{
+    const unsigned mb = *max_bits;
+    if (mb == 0 || mb >= 0x7f800000u) return;
+    const double inv = ldexp(1.0, det_exponent(mb) - 40);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const long long q = acc[i];
+        if (q) gvol[i] += (float)((double)q * inv);
+    }
+}
+
+extern "C" size_t mvsnerf_volume_sample_bwd_det_workspace_words(int D, int H, int W, int C)
+{
+    if (D < 1 || H < 1 || W < 1 || C < 4 || (C & 3)) return 0;
+    return (size_t)8 + (size_t)D * H * W * C;
+}
+
+extern "C" int mvsnerf_volume_sample_bwd_det(int D, int H, int W, int C, const float* ndc, int64_t P, const float* g, int g_stride, float* gvol,
+                                             void* workspace_zeroed, void* stream)
+{
+    if (!ndc || !g || !gvol || !workspace_zeroed || D < 1 || H < 1 || W < 1 || P < 0 || g_stride < C) return MVSNERF_EINVAL;
+    if (C < 4 || (C & 3)) return MVSNERF_EUNSUPPORTED;
+    if ((g_stride & 3) || !mvs_aligned16(g) || (reinterpret_cast<uintptr_t>(workspace_zeroed) & 7)) return MVSNERF_EALIGN;
+    if (P == 0) return MVSNERF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* mb = reinterpret_cast<unsigned*>(workspace_zeroed);
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(workspace_zeroed) + 8;
+    const int64_t n = (int64_t)D * H * W * C;
+    absmax_bits_kernel<<<1024, 256, 0, st>>>(g, P, C, g_stride, mb);
+    MVS_LAUNCH_CHECK();
+    volume_sample_bwd_det_scatter_kernel<<<mvs_cdiv(P * (C >> 2), 256), 256, 0, st>>>(D, H, W, C, ndc, P, g, g_stride, mb, acc);
+    MVS_LAUNCH_CHECK();
+    volume_sample_bwd_det_finish_kernel<<<4096, 256, 0, st>>>(reinterpret_cast<const long long*>(acc), n, mb, gvol);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Ray generation: the arithmetic of build_rays / build_rays_test (utils.py:86-108, 148-297) after the RNG draws.
 // Pixel ids (CPU RNG) and the stratified jitter (device RNG) stay with the caller, so ray indices are bit-exact with
 // the reference; everything downstream of them is one kernel instead of ~25 ATen launches per batch:

@@ -695,7 +695,8 @@ class RayMarchFunction(torch.autograd.Function):
         from . import distributed as DD
         # data-parallel fine-tuning of the volume: see volume_grad_from_all_ranks below (the scatter then runs after the call)
         exchange = dp_samples and gvol_cl is not None and DD._collective_needed()
-        gvol_arg = None if exchange else gvol_cl
+        # VOLUME_BWD_DETERMINISTIC: the scatter runs behind the call too, through the fixed-point accumulators (mvsnerf_volume_sample_bwd_det)
+        gvol_arg = None if (exchange or VOLUME_BWD_DETERMINISTIC) else gvol_cl
         a = _lib.RaymarchBwdArgs(
             packed_mlp=packed.data_ptr(), packed_bwd=packed_bwd.data_ptr(), bf16=int(bf16), F=F,
             raw=raw.data_ptr(), saved=saved.data_ptr(), z_vals=z_vals.data_ptr(), rays_ndc=rays_ndc.data_ptr(), N=N, S=S, white_bkgd=int(white),
@@ -707,6 +708,8 @@ class RayMarchFunction(torch.autograd.Function):
         check(lib.mvsnerf_raymarch_bwd(ctypes.byref(a), stream_ptr()), "raymarch_bwd")
         if exchange:
             volume_grad_from_all_ranks(d_feat, rays_ndc.reshape(-1, 3), gvol_cl)
+        elif VOLUME_BWD_DETERMINISTIC and gvol_cl is not None:
+            _scatter_hip(gvol_cl, rays_ndc.reshape(-1, 3), d_feat)
         g_vol = None
         if gvol_cl is not None:
             g_vol = gvol_cl.permute(3, 0, 1, 2)
@@ -718,9 +721,20 @@ class RayMarchFunction(torch.autograd.Function):
         return (g_vol, None, None, None, None, None, None, None, None, None, None, *param_grads)
 
 
+VOLUME_BWD_DETERMINISTIC = False   # True: the volume gradient's scatter through 64-bit fixed-point accumulators (integer atomics commute: two runs, and N ranks
+                                   # against one, give bit-identical gradients; mvsnerf_volume_sample_bwd_det) - two extra passes and 8 bytes of zeroed workspace
+                                   # per volume element (300 MB at config 2) instead of float atomics
+
+
 def _scatter_hip(gvol_cl, ndc, g):
     D, H, W, C = gvol_cl.shape
-    check(_lib.lib().mvsnerf_volume_sample_bwd(D, H, W, C, ndc.data_ptr(), ndc.shape[0], g.data_ptr(), C, gvol_cl.data_ptr(), stream_ptr()), "volume_sample_bwd")
+    lib = _lib.lib()
+    if VOLUME_BWD_DETERMINISTIC:
+        ws = torch.zeros(lib.mvsnerf_volume_sample_bwd_det_workspace_words(D, H, W, C), device=gvol_cl.device, dtype=torch.int64)
+        check(lib.mvsnerf_volume_sample_bwd_det(D, H, W, C, ndc.data_ptr(), ndc.shape[0], g.data_ptr(), g.shape[-1], gvol_cl.data_ptr(), ws.data_ptr(), stream_ptr()),
+              "volume_sample_bwd_det")
+        return
+    check(lib.mvsnerf_volume_sample_bwd(D, H, W, C, ndc.data_ptr(), ndc.shape[0], g.data_ptr(), C, gvol_cl.data_ptr(), stream_ptr()), "volume_sample_bwd")
 
 
 def volume_grad_from_all_ranks(d_feat, ndc, gvol_cl, group=None, scatter=_scatter_hip):

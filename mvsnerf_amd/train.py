@@ -220,7 +220,18 @@ class MVSSystem(_ModuleShim):
         return {"loss": scaled, "loss_unscaled": loss.detach()}
 
     @torch.no_grad()
-    def render_view(self, batch, chunk=None, whole_frame_off=False, target=None, batch_rays=16384):
+    def encode_scene(self, batch):
+        """The scene encode of render_view alone: MVSNet on the batch's source views -> the neural volume (1,8,D,h,w).  The reference's video path encodes a scene
+        ONCE and renders every camera pose of the path from that volume (renderer_video.ipynb cell 8: `volume_feature` outside the pose loop); pass the result to
+        render_view(..., volume=...) for the same.  Under tile-parallel inference this is what removes the replicated encode from the per-frame time."""
+        data_mvs, pose_ref = self.decode_batch(dict(batch))
+        imgs, proj_mats, near_fars = data_mvs["images"], data_mvs["proj_mats"], pose_ref["near_fars"]
+        V = imgs.shape[1] - 1
+        self.MVSNet.train()                                              # :182 batch-statistics ABN also at inference
+        return self.MVSNet(imgs[:, :V], proj_mats[:, :V], near_fars[0], pad=self.args.pad)[0]
+
+    @torch.no_grad()
+    def render_view(self, batch, chunk=None, whole_frame_off=False, target=None, batch_rays=16384, volume=None):
         """The rendering part of validation_step (:172-254): encode once, then the chunk loop over the target view's
         pixels - tile-parallel over ranks (contiguous chunk ranges + one all_gather).  Returns (rgb (H,W,3), depth (H,W)).
         whole_frame_off=True keeps the per-chunk Python loop (build_rays_test + rendering per chunk) instead of the single
@@ -230,15 +241,19 @@ class MVSSystem(_ModuleShim):
         coordinates with the *target* size and intrinsics (utils.py:252-253, fine when all views share both); with `target` the
         reference view's own intrinsics and size are used, which is what the volume is aligned with.
         batch_rays: rays per sub-batch inside the library call (free parameter: the pixels do not depend on it; measured on a 512x640
-        frame: 1024 -> 85.5 ms, 4096 -> 81.7, 16384 -> 80.5, 65536 -> 80.9; the workspace is 16 KB per ray)."""
+        frame: 1024 -> 85.5 ms, 4096 -> 81.7, 16384 -> 80.5, 65536 -> 80.9; the workspace is 16 KB per ray).
+        volume: the result of encode_scene(batch) - the encode is skipped (a camera path over one scene; the pixels are the same)."""
         args = self.args
         chunk = chunk or args.chunk
         data_mvs, pose_ref = self.decode_batch(dict(batch))
         imgs, proj_mats, near_fars = data_mvs["images"], data_mvs["proj_mats"], pose_ref["near_fars"]
         H, W = int(imgs.shape[-2]), int(imgs.shape[-1])
         V = imgs.shape[1] - 1                                            # source views (3 in the reference's batches, :193)
-        self.MVSNet.train()                                              # :182 batch-statistics ABN also at inference
-        volume_feature, _, _ = self.MVSNet(imgs[:, :V], proj_mats[:, :V], near_fars[0], pad=args.pad)
+        if volume is None:
+            self.MVSNet.train()                                          # :182 batch-statistics ABN also at inference
+            volume_feature, _, _ = self.MVSNet(imgs[:, :V], proj_mats[:, :V], near_fars[0], pad=args.pad)
+        else:
+            volume_feature = volume
         imgs = self.unpreprocess(imgs)
         world_to_ref, tgt_to_world, intrinsic = pose_ref["w2cs"][0], pose_ref["c2ws"][-1], pose_ref["intrinsics"][-1]
         k_ref, ref_hw, nf_tgt = None, None, near_fars[-1]

@@ -28,7 +28,7 @@ abi_version ncdhw_to_ndhwc ndhwc_to_ncdhw nchw_to_nhwc resize_bilinear
 planesweep_costvar_fwd planesweep_costvar_bwd planesweep_costvar_bwd_det_workspace_words planesweep_costvar_bwd_det homo_warp_fwd
 conv3d_pack_weights conv3d_fwd conv_transpose3d_fwd abn_workspace_floats abn_stats abn_apply_add abn_apply_add_hwdc abn_bwd
 conv3d_wgrad_workspace_floats conv3d_wgrad conv2d_pack_weights conv2d_fwd conv2d_wgrad_workspace_floats conv2d_wgrad channel_sum_workspace_floats channel_sum
-raygen_fwd raygen_train_fwd volume_sample_fwd volume_sample_bwd color_sample_fwd color_feat_sample_fwd dir_feature_fwd gather_fwd posenc_fwd
+raygen_fwd raygen_train_fwd volume_sample_fwd volume_sample_bwd volume_sample_bwd_det_workspace_words volume_sample_bwd_det color_sample_fwd color_feat_sample_fwd dir_feature_fwd gather_fwd posenc_fwd
 mlp_packed_floats mlp_pack mlp_fwd mlp_packed_bf16_elems mlp_pack_bf16 mlp_fwd_bf16 mlp_fwd_bf16_train mlp_packed_bwd_bf16_elems mlp_pack_bwd_bf16 mlp_bwd_bf16
 mlp_saved_floats mlp_gradslot_floats mlp_packed_bwd_floats mlp_bwd_workspace_floats mlp_pack_bwd mlp_fwd_train mlp_bwd
 mlp_packed_split_elems mlp_pack_split mlp_fwd_split mlp_fwd_guarded

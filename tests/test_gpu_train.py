@@ -118,6 +118,13 @@ def test_render_view_full_frame():
     # one-call pixel-range render (mvsnerf_render_pixels_fwd) vs. the per-chunk loop build_rays_test + rendering
     rgb3, depth3 = sys_.render_view(batch, chunk=1000, whole_frame_off=True)
     assert float((rgb - rgb3).abs().max()) < 1e-6 and float((depth - depth3).abs().max()) < 1e-5
+    # a scene encoded once (the reference's video path, renderer_video.ipynb cell 8: the volume outside the pose loop): the same pixels, bit for bit, from
+    # render_view(volume=...) - the library call and the per-chunk loop
+    vol = sys_.encode_scene(batch)
+    rgb4, depth4 = sys_.render_view(batch, chunk=1000, volume=vol)
+    assert torch.equal(rgb4, rgb) and torch.equal(depth4, depth)
+    rgb5, _ = sys_.render_view(batch, chunk=1000, whole_frame_off=True, volume=vol)
+    assert torch.equal(rgb5, rgb3)
 
 
 def test_render_pixels_subrange_and_oracle():
