@@ -277,20 +277,25 @@ __device__ __forceinline__ void planesweep_tile(
                 for (int k = threadIdx.x; k < n_k; k += VPB) {
                     const int cb = k / per, rem = k - cb * per, vox = rem >> 1, c0 = cb * 16 + (rem & 1) * 8;
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + vox * RS + c0), hi = *reinterpret_cast<const f32x4*>(stage + vox * RS + c0 + 4);
-                    f16x8_t h0, h1;
+                    // (round 6: the same two roundings in three instructions per PAIR - v_cvt_pk_f16_f32, then v_fma_mix{lo,hi}_f16 form fp16(v - hi) straight
+                    // from the packed hi pieces - instead of six; the flush was a quarter of this VALU-bound kernel's instructions)
+                    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                    u32x4_t h0, h1;
                     float big = 0.0f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float x = (e < 4 ? lo[e] : hi[e - 4]) * 0.0625f;
-                        big = fmaxf(big, fabsf(x));
-                        const float v = fminf(fmaxf(x, -65504.0f), 65504.0f);
-                        const _Float16 a = (_Float16)v;
-                        h0[e] = a; h1[e] = (_Float16)(v - (float)a);
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        const float x0 = (e2 < 2 ? lo[2 * e2] : hi[2 * e2 - 4]) * 0.0625f, x1 = (e2 < 2 ? lo[2 * e2 + 1] : hi[2 * e2 - 3]) * 0.0625f;
+                        big = fmaxf(big, fmaxf(fabsf(x0), fabsf(x1)));
+                        const float v0 = __builtin_amdgcn_fmed3f(x0, -65504.0f, 65504.0f), v1 = __builtin_amdgcn_fmed3f(x1, -65504.0f, 65504.0f);
+                        unsigned hp, lp;
+                        asm("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                            : "=&v"(hp), "=&v"(lp) : "v"(v0), "v"(v1));
+                        h0[e2] = hp; h1[e2] = lp;
                     }
                     if (guard && big > 65504.0f) guard[0] = 1;          // saturated: the fp32 sweep + conv0 behind this launch take over
                     const int64_t at = (((int64_t)cb * nvox + p0 + vox) << 4) + (rem & 1) * 8;
-                    *reinterpret_cast<f16x8_t*>(cost16 + at) = h0;
-                    *reinterpret_cast<f16x8_t*>(cost16 + lo_plane + at) = h1;
+                    *reinterpret_cast<u32x4_t*>(cost16 + at) = h0;
+                    *reinterpret_cast<u32x4_t*>(cost16 + lo_plane + at) = h1;
                 }
             } else {
                 // channel block cb (four channels) of these nv voxels is one contiguous run of nv * 16 bytes: k -> (cb, voxel)

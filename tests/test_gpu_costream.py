@@ -212,3 +212,32 @@ def test_training_kernels_bit_for_bit_next_to_16bit_mfma_waves_of_a_second_strea
         E.PSW_BWD_DETERMINISTIC = prev
     print(f"co-stream, use_amp={amp}: tensors that differ from the quiet run in any of 6 aggressed runs:", {k: {n: v[:2] for n, v in b.items()} for k, b in report.items()})
     assert not report["ray march"] and not report["encoder"], report
+
+
+@pytest.mark.parametrize("mode", ["fp16x3", "bf16", "fp32"])
+def test_inference_mlp_kernels_next_to_16bit_mfma_waves_of_a_second_stream(mode):
+    """Round 6: the fp16x3 MLP kernel splits its activations with v_fma_mix{lo,hi}_f16 - VOP3P instructions with an operand select (op_sel:[1,0,0]: src0's high
+    half), the instruction class whose packed-fp32 members returned wrong lanes next to v_mfma_f32_16x16x32_{f16,bf16} waves of another stream (DESIGN.md
+    section 8; there it was op_sel on SRC1 of v_pk_{fma,mul,add}_f32).  The MLP kernels are deterministic, so the check is bit for bit: 24 queries of 512 x 128
+    points while the fp16x3 conv0 (or, with MVSNERF_TEST_MFMA_HOG, the distilled aggressor) runs on a second stream against the quiet result - for the fp16x3
+    kernel, the bf16 inference kernel (v_cvt_pk_bf16_f32 in asm) and the fp32 kernel."""
+    from mvsnerf_amd import ops
+    from tests.test_gpu_fp16x3 import _load_net
+    net = _load_net()
+    g = torch.Generator().manual_seed(21)
+    N, S = 512, 128
+    ndc = (torch.rand((N, S, 3), generator=g) * 1.2 - 0.1).to(DEV)
+    feat = torch.randn((N, S, 20), generator=g).to(DEV)
+    dirs = torch.nn.functional.normalize(torch.randn((N, 3), generator=g), dim=-1).to(DEV)
+    aggress = _aggressor()
+
+    def query():
+        with ops.mlp_precision(mode), torch.no_grad():
+            return net.nerf.query(ndc, feat, dirs, N, S).clone()
+    quiet = _with_aggressor(query, None)
+    assert torch.equal(_with_aggressor(query, None), quiet)
+    bad = 0
+    for _ in range(24):
+        cur = _with_aggressor(query, aggress, n=3)
+        bad += int(not torch.equal(cur.view(torch.int32), quiet.view(torch.int32)))
+    assert bad == 0, f"{bad} of 24 {mode} MLP queries differ from the quiet result while 16-bit MFMA waves of a second stream share the GPU"
