@@ -220,40 +220,23 @@ def main():
         from bench_extras import multi_gpu_legs
         multi = multi_gpu_legs(dev, rank, world)
     # ---------------- per-kernel launch durations (HIP events on the launch stream), rank 0
-    roof, roofs, cpu = None, [], None
+    roof, roofs, cpu, o = None, [], None, None
     if rank == 0:
         with torch.no_grad():
             pts, ndc, z, ro, rdir = batches[0]
             vol_cl = ops.channels_last_volume(vol)
             P = N_RAYS * N_SAMPLES
             F = args.feat_dim
-            feat = torch.empty((N_RAYS, N_SAMPLES, F), device=dev)
-            dirs = ops.dir_feature(rdir, pose["w2cs"][0].contiguous())
-            packed = net.packed(F)
             w2c3, k3 = pose["w2cs"][:N_SRC].contiguous(), pose["intrinsics"][:N_SRC].contiguous()
+            feat, dirs = ops.gather(vol_cl, src[0], w2c3, k3, pts, ndc, rdir)      # the MLP's inputs of batch 0 (the lookups' own timings: bench_extras.lookup_rooflines)
+            packed = net.packed(F)
             lib = _lib.lib()
             st = torch.cuda.current_stream
             raw = torch.empty((N_RAYS, N_SAMPLES, 4), device=dev)
-            outs = [torch.empty(sh, device=dev) for sh in ((N_RAYS, 3), (N_RAYS,), (N_RAYS,), (N_RAYS, N_SAMPLES), (N_RAYS,), (N_RAYS, N_SAMPLES))]
-            # raw C-ABI calls with pre-allocated outputs (capturable into a hipGraph)
-            vol_p, vol_l = ops.vol_ptr_layout(vol_cl)          # the encoder's volume: depth-fastest (MVSNERF_VOL_HWDC)
-            k_vol = lambda: lib.mvsnerf_volume_sample_fwd(vol_p, vol_cl.shape[0], vol_cl.shape[1], vol_cl.shape[2], 8, ndc.data_ptr(), P,
-                                                          feat.data_ptr(), F, vol_l, st().cuda_stream)
-            k_col = lambda: lib.mvsnerf_color_sample_fwd(src[0].data_ptr(), N_SRC, H_IMG, W_IMG, w2c3.data_ptr(), k3.data_ptr(), pts.data_ptr(), P, 1,
-                                                         feat.data_ptr() + 32, F, st().cuda_stream)
+            # raw C-ABI call with pre-allocated outputs
             k_mlp = lambda: lib.mvsnerf_mlp_fwd(packed.data_ptr(), F, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3, N_RAYS, N_SAMPLES, 0,
                                                 raw.data_ptr(), st().cuda_stream)
-            k_cmp = lambda: lib.mvsnerf_composite_fwd(raw.data_ptr(), z.data_ptr(), N_RAYS, N_SAMPLES, 0, *[o.data_ptr() for o in outs], st().cuda_stream)
-            icl = ops.channels_last_images(src[0])
-            dirs_g = torch.empty_like(dirs)
-            k_gat = lambda: lib.mvsnerf_gather_fwd(vol_p, vol_cl.shape[0], vol_cl.shape[1], vol_cl.shape[2], icl.data_ptr(), N_SRC, H_IMG, W_IMG,
-                                                   w2c3.data_ptr(), k3.data_ptr(), pts.data_ptr(), ndc.data_ptr(), N_RAYS, N_SAMPLES, rdir.data_ptr(),
-                                                   feat.data_ptr(), F, dirs_g.data_ptr(), vol_l, st().cuda_stream)
-            t_gat = event_time(k_gat, 400, graph_batch=40)
-            t_vol = event_time(k_vol, 400, graph_batch=40)
-            t_col = event_time(k_col, 400, graph_batch=40)
             t_mlp = event_time(k_mlp, 60)
-            t_cmp = event_time(k_cmp, 400, graph_batch=40)
             k_mlp_cen = lambda cen: lib.mvsnerf_mlp_fwd_census(packed.data_ptr(), F, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3, N_RAYS, N_SAMPLES, 0,
                                                                raw.data_ptr(), cen.data_ptr(), st().cuda_stream)
             for _ in range(50):
@@ -270,156 +253,19 @@ def main():
                 # rate at THAT clock is 64 FLOP/clk/SIMD x 1024 SIMDs x clock - what the matrix pipes could deliver in this launch at most
                 "peak_at_sustained_clock": round(64 * 1024 * clock / 1e3, 1),
                 "frac_of_sustained_clock_peak": round(tf / (64 * 1024 * clock / 1e3), 4)}
-        if a.mlp_precision != "fp32":
-            # --mlp-precision <opt-in mode>: the timed step ran that mode's kernel, so `roofline` describes THAT kernel (issued 16-bit
-            # matrix-core work = pieces products x the algorithmic FLOPs, against the dense bf16/fp16 peak); the fp32 kernel's object moves to `rooflines`
-            n_mfma = {"bf16": 1, "bf16x3": 3, "bf16x6": 6, "fp16x3": 3}[a.mlp_precision]
-            with torch.no_grad():
-                if a.mlp_precision == "bf16":
-                    pbm = net.packed_bf16(F)
-                    k_mode = lambda: lib.mvsnerf_mlp_fwd_bf16(pbm.data_ptr(), packed.data_ptr(), F, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3,
-                                                              N_RAYS, N_SAMPLES, 0, raw.data_ptr(), st().cuda_stream)
-                    kname = "mlp_fwd_bf16_pair_kernel"
-                else:
-                    psm, nsm = net.packed_split(F, ops.N_SPLIT[a.mlp_precision])
-                    k_mode = lambda: lib.mvsnerf_mlp_fwd_split(psm.data_ptr(), packed.data_ptr(), F, nsm, ndc.data_ptr(), 3, feat.data_ptr(), F, dirs.data_ptr(), 3,
-                                                               N_RAYS, N_SAMPLES, 0, raw.data_ptr(), st().cuda_stream)
-                    kname = "mlp_fwd_f16x3_kernel" if a.mlp_precision == "fp16x3" else "mlp_fwd_split_kernel"
-                t_mode = event_time(k_mode, 100)
+        import bench_extras
+        if a.mlp_precision != "fp32":         # an opt-in arithmetic was timed: `roofline` describes ITS kernel, the fp32 kernel's object moves to `rooflines`
             roofs.append(roof)
-            tfm = n_mfma * FLOP_PER_SAMPLE * P / (t_mode * 1e-3) / 1e12
-            roof = {"kernel": kname, "bound": "mfma", "achieved": round(tfm, 1), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tfm / PEAK_16BIT_MFMA_TFLOPS, 4), "traffic": pmc_traffic(kname), "traffic_source": _pmc_summary()[1],
-                    "avg_launch_ms": round(t_mode, 4), "piece_products_per_product": n_mfma,
-                    "fp32_equivalent_tflops": round(FLOP_PER_SAMPLE * P / (t_mode * 1e-3) / 1e12, 1)}
-        # the names are the LAUNCHED kernels' (rocprofv3 kernel trace): the encoder's volume is depth-fastest, so the stand-alone lookup is the _zfast_ form
-        vs_name = "volume_sample_c8_zfast_kernel" if vol_l == ops.VOL_HWDC else "volume_sample_c8_kernel"
-        cache_note = ("the 150 MB volume (and the 15 MB of source images) stay resident in the 256 MB Infinity Cache / the L2s across launches: `achieved` is SURVEY 8(d)'s "
-                      "gather-count model (no reuse assumed) over the launch duration, i.e. a cache-bandwidth figure held against the HBM peak; `traffic` (PMC FETCH_SIZE + "
-                      "WRITE_SIZE at the L2-fabric boundary) is what actually crossed it and is far below the algorithmic bytes")
-        for name, t, bps in (("gather_fused_kernel", t_gat, VOL_BYTES_PER_SAMPLE + COL_BYTES_PER_SAMPLE),
-                             (vs_name, t_vol, VOL_BYTES_PER_SAMPLE), ("color_sample_kernel", t_col, COL_BYTES_PER_SAMPLE),
-                             ("composite_kernel", t_cmp, 28)):
-            gbs = bps * P / (t * 1e-3) / 1e9
-            tr = pmc_traffic(name)
-            roofs.append({"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                          "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": tr, "avg_launch_ms": round(t, 5),
-                          "algorithmic_bytes_per_launch": bps * P,
-                          "bound_note": "Infinity-Cache resident: " + cache_note if name != "composite_kernel" else "launch-latency sized (5 us): 3.7 MB per launch",
-                          # what the memory system actually moved per launch (PMC) over the same duration: random 64-byte x-pairs that start
-                          # on an odd voxel straddle two fetch granules, so the HBM is busier than the algorithmic bytes say
-                          "frac_of_peak_by_pmc_traffic": None if tr is None else round(tr / (t * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                          "timing": "hipGraph replay of 40 back-to-back launches (includes the ~1.5 us launch boundary)"})
-        # ---------------- CPU baseline: the oracle (torch CPU kernels) on a bounded sample of the same workload
+            roof = bench_extras.mode_roofline(dict(locals()))
+        roofs += bench_extras.lookup_rooflines(dict(locals()))
+        # ---------------- CPU baseline: the oracle (torch CPU kernels) on a bounded sample of the same workload, + parity of the timed workload (bench_extras.py)
         if a.cpu_batches > 0 and world == 1:          # reported at N=1 only (bench contract)
-            from oracle import mvsnerf_oracle as O
-            sd = load_mlp_weights()
-            cpose = {k: v.cpu() for k, v in pose.items()}
-            cvol = vol.detach().cpu().contiguous()               # the logical (1,8,D,h,w) tensor, reference layout, for the CPU oracle
-            cb = [tuple(t.cpu() for t in b) for b in batches[:4]]
-            csrc = src.cpu()
-            n_default = torch.get_num_threads()
-            with torch.no_grad():
-                # the thread count this path runs fastest at on this host (all hardware threads is rarely it: the batch is
-                # 45 MB of activations per layer and the ATen kernels stop scaling long before 128 threads)
-                probe = {}
-                for nt in sorted({t for t in (8, 16, 32, 64, n_default) if t <= n_default}):
-                    torch.set_num_threads(nt)
-                    O.rendering(cpose, cb[0][0], cb[0][1], cb[0][2], cb[0][4], cvol, csrc, sd)    # warm
-                    p0 = time.perf_counter()
-                    O.rendering(cpose, cb[1][0], cb[1][1], cb[1][2], cb[1][4], cvol, csrc, sd)
-                    probe[nt] = time.perf_counter() - p0
-                best = min(probe, key=probe.get)
-                torch.set_num_threads(best)
-                O.rendering(cpose, cb[0][0], cb[0][1], cb[0][2], cb[0][4], cvol, csrc, sd)        # warm
-                c0 = time.perf_counter()
-                for i in range(a.cpu_batches):
-                    b = cb[i % len(cb)]
-                    out = O.rendering(cpose, b[0], b[1], b[2], b[4], cvol, csrc, sd)
-                cdt = time.perf_counter() - c0
-                # the per-core figure SURVEY 8(d) asks for: the same path on ONE thread, a bounded sample of 2 batches after a warm one
-                torch.set_num_threads(1)
-                O.rendering(cpose, cb[0][0], cb[0][1], cb[0][2], cb[0][4], cvol, csrc, sd)
-                c1 = time.perf_counter()
-                for i in range(2):
-                    b = cb[(i + 1) % len(cb)]
-                    O.rendering(cpose, b[0], b[1], b[2], b[4], cvol, csrc, sd)
-                cdt1 = (time.perf_counter() - c1) / 2
-                torch.set_num_threads(n_default)
-            cpu = {"value": round(a.cpu_batches * N_RAYS / cdt, 1), "value_1_thread": round(N_RAYS / cdt1, 1), "unit": "rays/s", "cores": best, "host_cores": os.cpu_count(), "kind": "port",
-                   "kind_note": "oracle/mvsnerf_oracle.py: a restatement of the reference on the torch CPU kernels the reference itself would run on a "
-                                "CPU (the reference is Python and cannot travel to the GPU box); pinned to outputs of the imported reference (tests/golden)",
-                   "sample": f"{a.cpu_batches} batches of {N_RAYS}x{N_SAMPLES} (oracle.rendering, torch CPU fp32, no_grad), {cdt:.1f} s, at the fastest of "
-                             f"{sorted(probe)} threads (one probe batch each: " + ", ".join(f"{t}: {N_RAYS / probe[t]:.0f} rays/s" for t in sorted(probe)) + ")"}
-            # parity of the timed workload itself (same batch, GPU vs CPU oracle)
-            with torch.no_grad():
-                g = step(0)
-                b = cb[0]
-                o = O.rendering(cpose, b[0], b[1], b[2], b[4], cvol, csrc, sd)
-                err = float((g[0].cpu() - o[0]).abs().max())
-                mse = float(((g[0].cpu() - o[0]) ** 2).mean())
-            import math
-            sg, so = renderer.rendering.last_raw.view(N_RAYS, N_SAMPLES, 4)[..., 3].cpu(), o[6][..., 3]
-            cpu["max_abs_sigma_err_same_volume"] = float((sg - so).abs().max())
-            cpu["n_sigma_over_1e-4_same_volume"] = int(((sg - so).abs() > 1e-4).sum())
-            cpu["max_abs_rgb_err_vs_gpu"] = err
-            cpu["psnr_gpu_vs_cpu_db"] = round(10 * math.log10(1.0 / max(mse, 1e-20)), 1)
-            cpu["max_abs_rgb_err_vs_gpu_note"] = "same GPU-built volume on both sides: the ray march alone"
-            # end to end: images -> volume on the CPU oracle as well (FeatureNet, plane sweep, CostRegNet), then the same batch;
-            # the GPU side is the timed step on the HIP-built volume.  tests/test_gpu_headline_parity.py breaks this down by stage.
-            if enc_ready:
-                import numpy as np
-                zz = np.load(os.path.join(ROOT, "tests", "golden", "mvsnerf_v0_weights.npz"))
-                mvs_sd = {k[4:]: torch.from_numpy(zz[k]) for k in zz.files if k.startswith("mvs/")}
-                with torch.no_grad():
-                    torch.set_num_threads(min(32, n_default))
-                    e0 = time.perf_counter()
-                    ovol = O.mvsnet_forward(rig["images"][:, :3], rig["proj_mats"][:, :3], rig["near_fars"][0, 0], mvs_sd, pad=PAD, D=D_PLANES)[0]
-                    cpu["encode_seconds_cpu"] = round(time.perf_counter() - e0, 2)
-                    o2 = O.rendering(cpose, b[0], b[1], b[2], b[4], ovol, csrc, sd)
-                    torch.set_num_threads(n_default)
-                cpu["max_abs_rgb_err_end_to_end"] = float((g[0].cpu() - o2[0]).abs().max())
-                cpu["max_abs_volume_err_end_to_end"] = float((cvol - ovol).abs().max())
-                raw_g = renderer.rendering.last_raw.view(N_RAYS, N_SAMPLES, 4).cpu()
-                cpu["max_abs_sigma_err_end_to_end"] = float((raw_g[..., 3] - o2[6][..., 3]).abs().max())
-                serr = (raw_g[..., 3] - o2[6][..., 3]).abs().flatten()
-                cpu["n_sigma_over_1e-4_end_to_end"] = int((serr > 1e-4).sum())
-                cpu["n_sigma_samples"] = int(serr.numel())
-                cpu["sigma_abs_err_p99.9_end_to_end"] = float(serr.kthvalue(int(0.999 * serr.numel()))[0])
-                cpu["sigma_abs_max"] = float(o2[6][..., 3].abs().max())
-                del ovol
+            cpu, o = bench_extras.cpu_baseline_leg(dict(locals()))
 
         extras = {}
         if not a.no_extras and world == 1:
-            import bench_extras
             extras = bench_extras.single_gpu_extras(dict(locals()))
-        # the numbers beyond the headline that later rounds are judged on, as top-level scalars (a driver that keeps only flat keys keeps these)
-        def dig(obj, *path):
-            for k in path:
-                if not isinstance(obj, dict) or k not in obj:
-                    return None
-                obj = obj[k]
-            return obj
-        flat = {"encode_ms_free_running": dig(encode_ms, "forward_free_running"),
-                "default_step_ms": dig(extras, "guarded_default_mlp_mode", "ms_per_step"),
-                "default_mlp_kernel_ms": dig(extras, "guarded_default_mlp_mode", "mlp_kernel_ms"),
-                "default_mlp_frac": dig(extras, "guarded_default_mlp_mode", "roofline", "frac"),
-                "fp16x3_mlp_frac": dig(extras, "fp16x3_mlp_mode", "roofline", "frac"),
-                "frame_512x640_ms": None if dig(extras, "frame_512x640", "seconds") is None else round(dig(extras, "frame_512x640", "seconds") * 1e3, 2),
-                "train_step_fp32_ms": dig(extras, "train_step", "ms"), "train_step_bf16_ms": dig(extras, "train_step_bf16", "ms"),
-                "config4_mlp_frac": dig(extras, "config4", "mlp_kernel_roofline", "frac"),
-                "config4_default_frame_ms": None if dig(extras, "config4", "frame_800x800_guarded_default_mlp", "seconds") is None
-                else round(dig(extras, "config4", "frame_800x800_guarded_default_mlp", "seconds") * 1e3, 2),
-                "config4_default_frame_guard_fallbacks": dig(extras, "config4", "frame_800x800_guarded_default_mlp", "guard_fallbacks"),
-                "config5_default_frame_ms": None if dig(extras, "config5", "frame_guarded_default_mlp", "seconds") is None
-                else round(dig(extras, "config5", "frame_guarded_default_mlp", "seconds") * 1e3, 2),
-                "strong_scaling_frame_512x640_default": dig(multi, "strong_scaling", "frame_512x640_default", "speedup"),
-                "strong_scaling_frame_512x640_default_scene_encoded_once": dig(multi, "strong_scaling", "frame_512x640_default_scene_encoded_once", "speedup"),
-                "strong_scaling_frame_512x640_fp32": dig(multi, "strong_scaling", "frame_512x640_fp32_kernels", "speedup"),
-                "strong_scaling_frame_config5": dig(multi, "strong_scaling", "frame_config5_1008x756_fp32_kernels", "speedup"),
-                "strong_scaling_train_step_ray_dp_fp32": dig(multi, "strong_scaling", "train_step_ray_dp_fp32", "speedup"),
-                "strong_scaling_train_step_ray_dp_bf16": dig(multi, "strong_scaling", "train_step_ray_dp_bf16", "speedup"),
-                "dp_step_ms_ray_fp32": dig(multi, "train_step_dp_ray", "ms"), "dp_step_ms_ray_bf16": dig(multi, "train_step_dp_ray_bf16", "ms")}
+        flat = bench_extras.flat_scalars(encode_ms, extras, multi)     # the numbers beyond the headline as top-level scalars (a driver that keeps only flat keys keeps these)
         print(json.dumps({
             "metric": "rendered rays/sec (1024-ray batch, 128 samples)", "value": round(rays_per_s, 1), "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
