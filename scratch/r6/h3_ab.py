@@ -16,7 +16,7 @@ dev = torch.device("cuda", 0)
 net = models.MVSNeRF(D=6, W=128, input_ch_pts=63, input_ch_views=3, input_ch_feat=20, skips=[4], net_type="v0")
 net.load_state_dict(bench.load_mlp_weights())
 net = net.to(dev)
-N, S, F = 1024, 128, 20
+N, S, F = int(os.environ.get("H3_N", "1024")), 128, 20
 g = torch.Generator().manual_seed(0)
 ndc = (torch.rand((N, S, 3), generator=g) * 1.2 - 0.1).to(dev)
 feat = torch.randn((N, S, F), generator=g).to(dev)
