@@ -857,26 +857,59 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_c16to8_mfma4_kernel(ActSrc x
                     }
         }
     }
-    // D: register q of lane (mb, nb, li) = (voxel 4 mb + q of the M-tile, channel 4 nb + li)
+    // D: register q of lane (mb, nb, li) = (voxel 4 mb + q of the M-tile, channel 4 nb + li).  Stored from there, a lane writes ONE float per instruction and a
+    // wave-instruction touches eight 32-byte pieces 256 bytes apart (64 such instructions per wave: the kernel was bound by them, 98 us for 190 MB).  An input row
+    // of 16 voxels and one output-row parity (pz, py) make 32 CONSECUTIVE output voxels = 1 KB of the channel-last output: the accumulators go through the (now
+    // free) input tile - a wave-private stage of four such rows at a time, padded so that writes and reads are conflict-free - and leave as one 1 KB
+    // global_store_dwordx4 per row (16 per wave).
     const int Ho = 2 * Hi, Wo = 2 * Wi;
     float ssum = 0.f, ssq = 0.f;
+    if (stats) {                                                      // the InPlaceABN partial sums, in the order the direct stores took them (same bits as before)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int mt = wave * 2 + r, jz = z0 + (mt >> 2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int mm = mb * 4 + q, jy = y0 + (mt & 3) * 2 + (mm >> 4), jx = x0 + (mm & 15);
+                if (jz >= Di || jy >= Hi || jx >= Wi) continue;
+#pragma unroll
+                for (int cls = 0; cls < 8; ++cls) { ssum += acc[cls][r][q]; ssq = fmaf(acc[cls][r][q], acc[cls][r][q], ssq); }
+            }
+        }
+    }
+    __syncthreads();                                                  // every wave has read its A operands: the input tile is free
+    constexpr int CT8_RS = 304;                                       // floats per staged row: 32 voxels x 8 + 4 x 8 padding, 2 rows = 32 banks apart
+    float* stg = xt + wave * (4 * CT8_RS);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int mt = wave * 2 + r, jz = z0 + (mt >> 2);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int mm = mb * 4 + q, jy = y0 + (mt & 3) * 2 + (mm >> 4), jx = x0 + (mm & 15);
-            if (jz >= Di || jy >= Hi || jx >= Wi) continue;
+        for (int pz = 0; pz < 2; ++pz) {
 #pragma unroll
-            for (int cls = 0; cls < 8; ++cls) {
-                const int oz = 2 * jz + (cls >> 2), oy = 2 * jy + ((cls >> 1) & 1), ox = 2 * jx + (cls & 1);
-                out[(((int64_t)oz * Ho + oy) * Wo + ox) * 8 + nb * 4 + li] = acc[cls][r][q];
-                ssum += acc[cls][r][q]; ssq = fmaf(acc[cls][r][q], acc[cls][r][q], ssq);
+            for (int q = 0; q < 4; ++q) {
+                const int mm = mb * 4 + q, row = mm >> 4, jxl = mm & 15;
+#pragma unroll
+                for (int pyx = 0; pyx < 4; ++pyx) {
+                    const int py = pyx >> 1, px = pyx & 1, cls = pz * 4 + pyx;
+                    const int ox = 2 * jxl + px;
+                    stg[(row * 2 + py) * CT8_RS + ox * 8 + (ox >> 3) * 8 + nb * 4 + li] = acc[cls][r][q];
+                }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // wave-private stage: no barrier
+            const int ox = lane >> 1, chq = lane & 1;
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const int row = ri >> 1, py = ri & 1;
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(stg + ri * CT8_RS + ox * 8 + (ox >> 3) * 8 + chq * 4);
+                const int jy = y0 + (mt & 3) * 2 + row;
+                const int oz = 2 * jz + pz, oy = 2 * jy + py, oxg = 2 * x0 + ox;
+                if (jz < Di && jy < Hi && oxg < Wo) *reinterpret_cast<f32x4*>(out + (((int64_t)oz * Ho + oy) * Wo + oxg) * 8 + chq * 4) = v4;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the rows are read before the next pass overwrites them
         }
     }
     if (stats) {
-        __syncthreads();                                              // the input tile is free
+        __syncthreads();                                              // the output stages are free
         c8_tile_stats(ssum, ssq, lane, wave, xt, stats, tile_id, gridDim.x);
     }
 }
