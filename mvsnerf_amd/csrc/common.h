@@ -40,6 +40,34 @@ __host__ __device__ inline int64_t abn_part_at(int which, int c, int C, int64_t 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Linear voxel / pixel index -> (x, y, z) of a [.][H][W] grid.  A 64-bit division is ~10x the instructions of a 32-bit one and a lane of the direct-load
+// implicit-GEMM kernels did three of them before its first load (half of the VALU instructions of the deep CostRegNet layers): indices below 2^32 - every
+// tensor of this network - take the 32-bit path.
+__device__ __forceinline__ void mvs_unflatten3(int64_t v, int W, int H, int& x, int& y, int& z)
+{
+    if (((uint64_t)v >> 32) == 0) {
+        const unsigned u = (unsigned)v, r = u / (unsigned)W;
+        x = (int)(u - r * (unsigned)W);
+        const unsigned q = r / (unsigned)H;
+        y = (int)(r - q * (unsigned)H);
+        z = (int)q;
+    } else {
+        x = (int)(v % W); y = (int)((v / W) % H); z = (int)(v / ((int64_t)W * H));
+    }
+}
+// (x0 + off, y0, z0) carried into the grid for a SMALL off >= 0 (x0 + off < 2^20, W < 2^12): quotients by a float reciprocal, exact in that range
+// ((n + 0.5) / W is never closer than 0.5 / W to an integer; the product's rounding error is below that while n < ~2.8e6)
+__device__ __forceinline__ void mvs_carry3(int x0, int y0, int z0, int off, int W, int H, float rW, float rH, int& x, int& y, int& z)
+{
+    const int xs = x0 + off;
+    const int qx = (int)(((float)xs + 0.5f) * rW);
+    x = xs - qx * W;
+    const int ys = y0 + qx;
+    const int qy = (int)(((float)ys + 0.5f) * rH);
+    y = ys - qy * H;
+    z = z0 + qy;
+}
+
 // Workgroups are dealt to the 8 XCDs round-robin by their linear id (workgroup i runs on XCD i % 8) and every XCD has its own L2.
 // Kernels whose neighbouring workgroups share input (convolution halos) renumber their tiles so that an XCD walks a CONTIGUOUS
 // range of tile ids: tile = xcd_contiguous_tile(blockIdx.x, gridDim.x).

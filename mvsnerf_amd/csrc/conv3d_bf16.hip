@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ActSrc a, ActSrc b, int 
     const int64_t vox = tile0 + m;
     const bool live = vox < nvox;
     const int64_t vc = live ? vox : nvox - 1;
-    const int x = (int)(vc % Wo), y = (int)((vc / Wo) % Ho), z = (int)(vc / ((int64_t)Wo * Ho));
+    int x, y, z;
+    mvs_unflatten3(vc, Wo, Ho, x, y, z);
     const int zb = z * SZ - PZ, yb = y * S - P, xb = x * S - P;
     f32x4 acc[NT];
 #pragma unroll
@@ -337,14 +338,16 @@ __global__ __launch_bounds__(256) void convT3d_k3s2_bf16_kernel(ActSrc a, ActSrc
     const int64_t vox = tile0 + m;
     const bool live = vox < nvox;
     const int64_t vc = live ? vox : nvox - 1;
-    const int x = (int)(vc % Wi), y = (int)((vc / Wi) % Hi), z = (int)(vc / ((int64_t)Wi * Hi));
+    int x, y, z;
+    mvs_unflatten3(vc, Wi, Hi, x, y, z);
     const int Ho = 2 * Hi, Wo = 2 * Wi;
     // rows of the D fragment this lane stores: positions tile0 + 4 g + r
     int64_t obase[4];                                             // float offset of output voxel (2 iz, 2 iy, 2 ix), -1: no such position
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t i = tile0 + 4 * g + r;
-        const int ix = (int)(i % Wi), iy = (int)((i / Wi) % Hi), iz = (int)(i / ((int64_t)Wi * Hi));
+        int ix, iy, iz;
+        mvs_unflatten3(i, Wi, Hi, ix, iy, iz);
         obase[r] = i < nvox ? (((int64_t)(2 * iz) * Ho + 2 * iy) * Wo + 2 * ix) * Cout : (int64_t)-1;
     }
     float ssum[NT], ssq[NT];

@@ -449,7 +449,8 @@ __global__ __launch_bounds__(512) void conv3d_k3_mfma32_kernel(ActSrc a, int ld,
     const int64_t vox = (int64_t)blockIdx.x * 32 + m;
     const bool live = vox < nvox;
     const int64_t vc = live ? vox : nvox - 1;
-    const int x = (int)(vc % Wo), y = (int)((vc / Wo) % Ho), z = (int)(vc / ((int64_t)Wo * Ho));
+    int x, y, z;
+    mvs_unflatten3(vc, Wo, Ho, x, y, z);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -546,7 +547,8 @@ __global__ __launch_bounds__(64 * WAVES * TPW) void convT3d_k3s2_mfma32_kernel(c
     const int64_t pos = tile * 32 + m;
     const bool live = pos < nin;
     const int64_t pc = live ? pos : nin - 1;
-    const int ix = (int)(pc % Wi), iy = (int)((pc / Wi) % Hi), iz = (int)(pc / ((int64_t)Wi * Hi));
+    int ix, iy, iz;
+    mvs_unflatten3(pc, Wi, Hi, ix, iy, iz);
     // contraction entries per dimension: (input offset, kernel tap or -1) - uniform per workgroup for outer dims, per column for merged
     const int nz = pz ? 2 : 1;
     const int ny = MD == 2 ? 2 : (py_o ? 2 : 1);
@@ -585,6 +587,11 @@ __global__ __launch_bounds__(64 * WAVES * TPW) void convT3d_k3s2_mfma32_kernel(c
     if (wave == 0) {
         const int Ho = 2 * Hi, Wo = 2 * Wi;
         float ssum = 0.f, ssq = 0.f;
+        // the 16 input positions of this lane's results lie within 28 of tile * 32 + 4 kh: one decomposition, then small carries (16 x three 64-bit
+        // divisions per lane were most of this kernel's VALU instructions)
+        int bx, by, bz;
+        mvs_unflatten3(tile * 32 + 4 * kh, Wi, Hi, bx, by, bz);
+        const float rW = 1.0f / (float)Wi, rH = 1.0f / (float)Hi;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = acc[r];
@@ -595,7 +602,8 @@ __global__ __launch_bounds__(64 * WAVES * TPW) void convT3d_k3s2_mfma32_kernel(c
             // D: register r of lane (column m, half kh) = input position (r&3) + 8 (r>>2) + 4 kh of the tile
             const int64_t ip = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             if (ip < nin) {
-                const int jx = (int)(ip % Wi), jy = (int)((ip / Wi) % Hi), jz = (int)(ip / ((int64_t)Wi * Hi));
+                int jx, jy, jz;
+                mvs_carry3(bx, by, bz, (r & 3) + 8 * (r >> 2), Wi, Hi, rW, rH, jx, jy, jz);
                 out[((((int64_t)(2 * jz + pz)) * Ho + 2 * jy + py_c) * Wo + 2 * jx + px_c) * COUT + co] = v;
                 ssum += v; ssq = fmaf(v, v, ssq);
             }

@@ -137,7 +137,8 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ActSrc a, int ld, int 
     const int64_t pix = tile * MT + m;
     const bool live = pix < npix;
     const int64_t pc = live ? pix : npix - 1;
-    const int x = (int)(pc % Wo), y = (int)((pc / Wo) % Ho), n = (int)(pc / ((int64_t)Wo * Ho));
+    int x, y, n;
+    mvs_unflatten3(pc, Wo, Ho, x, y, n);
     const bool lazy = a.scale != nullptr;
     facc acc;
 #pragma unroll
