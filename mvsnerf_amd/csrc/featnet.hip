@@ -109,6 +109,88 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ActSrc a, int ld, int Hi, i
     }
 }
 
+// conv0.0 / conv0.1 (3(4) -> 8 and 8 -> 8 channels at FULL resolution, 3x3, stride 1) with the halo staged through LDS.  conv2d_kernel above re-reads every
+// tap from L1 and applies the pending InPlaceABN of its input nine times per pixel (a third of its VALU instructions); here the 18 x 18 halo of a 16 x 16
+// tile is activated ONCE on its way into LDS - from channel-last memory, or (NCHW3) straight from the caller's (N, 3, H, W) images, which removes the
+// nchw_to_nhwc_pad pass of a no-grad encode - and a pixel's nine taps are ds_read_b128s.  Same tile numbering, same products in the same order (ky, kx, channel),
+// same InPlaceABN partial sums as conv2d_kernel<CIN, 8, 3, 1, 8>: the results are its bits.
+template <int CIN, bool NCHW3>
+__global__ __launch_bounds__(256) void conv2d_c8_lds_kernel(ActSrc a, int ld, int Hi, int Wi, const float* __restrict__ wp, float* __restrict__ out,
+                                                            float* __restrict__ stats)
+{
+    static_assert(CIN == 4 || CIN == 8, "4 or 8 input channels");
+    constexpr int HW = 18, NH = HW * HW;
+    __shared__ __attribute__((aligned(16))) float halo[NH * CIN];
+    __shared__ float red[8 * 256];
+    const int nbx = (Wi + 15) >> 4, nby = (Hi + 15) >> 4;
+    const int tile_id = xcd_contiguous_tile(blockIdx.x, gridDim.x);      // halo neighbours share an XCD's L2 (common.h)
+    const int bx = tile_id % nbx, by = (tile_id / nbx) % nby, n = tile_id / (nbx * nby);
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int x = bx * 16 + tx, y = by * 16 + ty;
+    const bool live = x < Wi && y < Hi;
+    const int64_t img0 = (int64_t)n * Hi * Wi;
+    for (int i = threadIdx.x; i < NH; i += 256) {
+        const int hy = i / HW, hx = i - hy * HW;
+        const int yi = by * 16 - 1 + hy, xi = bx * 16 - 1 + hx;
+        const bool in = yi >= 0 && yi < Hi && xi >= 0 && xi < Wi;
+        const int64_t pix = in ? (int64_t)yi * Wi + xi : 0;
+        if constexpr (NCHW3) {                                           // (N, 3, H, W) images: three coalesced plane reads, channel 3 = the zero pad
+            const float* p0 = a.x + (int64_t)n * 3 * Hi * Wi + pix;
+            f32x4 v = {p0[0], p0[(int64_t)Hi * Wi], p0[2 * (int64_t)Hi * Wi], 0.0f};
+            if (!in) v = f32x4{0, 0, 0, 0};
+            *reinterpret_cast<f32x4*>(halo + i * 4) = v;
+        } else {
+#pragma unroll
+            for (int c = 0; c < CIN; c += 4) {
+                f32x4 v;
+                load_act4<CIN>(a, ActSrc{nullptr, nullptr, nullptr}, img0 + pix, ld, c, v);
+                if (!in) v = f32x4{0, 0, 0, 0};                          // zero padding of the *activated* input
+                *reinterpret_cast<f32x4*>(halo + i * CIN + c) = v;
+            }
+        }
+    }
+    __syncthreads();
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float* hp = halo + ((ty + ky) * HW + tx + kx) * CIN;
+            const float* wt = wp + (int64_t)(ky * 3 + kx) * CIN * 8;
+#pragma unroll 1
+            for (int c = 0; c < CIN; c += 4) {                          // (a real loop, like conv2d_kernel's: the weights stay on the scalar path)
+                const f32x4 v = *reinterpret_cast<const f32x4*>(hp + c);
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] = fmaf(v[k4], wt[(c + k4) * 8 + k], acc[k]);
+            }
+        }
+    }
+    if (live) {
+        float* o = out + (img0 + (int64_t)y * Wi + x) * 8;
+        *reinterpret_cast<f32x4*>(o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        *reinterpret_cast<f32x4*>(o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+    }
+    if (stats) {                                                         // as conv2d_kernel: channel k gets the 32 lanes tid / 32 == k, fixed order
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[k * 256 + threadIdx.x] = live ? acc[k] : 0.0f;
+        __syncthreads();
+        const int k = threadIdx.x >> 5, part = threadIdx.x & 31;
+        float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float v = red[k * 256 + part * 8 + i]; ssum += v; ssq = fmaf(v, v, ssq); }
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) { ssum += __shfl_xor(ssum, o); ssq += __shfl_xor(ssq, o); }
+        if (part == 0) {
+            stats[abn_part_at(0, k, 8, tile_id, gridDim.x)] = ssum;
+            stats[abn_part_at(1, k, 8, tile_id, gridDim.x)] = ssq;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // The 16- and 32-output-channel layers (conv1.x, conv2.x and the data gradients of the stride-1 ones: 83 % of FeatureNet's multiply-adds)
 // on the fp32 matrix cores.  (the VALU kernel above ran FeatureNet at 10.7 % of the fp32 peak.)  Implicit GEMM, one WAVE
@@ -251,13 +333,27 @@ extern "C" int mvsnerf_conv2d_fwd_stats(const float* x, const float* scale, cons
     if (conv2d_valu_stats_shape(Cin, Cout, ksize, stride)) {
         const ActSrc a{x, scale, shift};
         const unsigned tiles = (unsigned)mvsnerf_conv2d_mfma_tiles(Cin, Cout, N, H, W, ksize, stride);
-        if (Cin == 4) conv2d_kernel<4, 8, 3, 1, 8><<<dim3(tiles, 1), 256, 0, (hipStream_t)stream>>>(a, cin_ld, H, W, wpacked, nullptr, out, H, W, stats_part);
-        else conv2d_kernel<8, 8, 3, 1, 8><<<dim3(tiles, 1), 256, 0, (hipStream_t)stream>>>(a, cin_ld, H, W, wpacked, nullptr, out, H, W, stats_part);
+        if (Cin == 4) conv2d_c8_lds_kernel<4, false><<<tiles, 256, 0, (hipStream_t)stream>>>(a, cin_ld, H, W, wpacked, out, stats_part);
+        else conv2d_c8_lds_kernel<8, false><<<tiles, 256, 0, (hipStream_t)stream>>>(a, cin_ld, H, W, wpacked, out, stats_part);
         MVS_LAUNCH_CHECK();
         return MVSNERF_OK;
     }
     if (!conv2d_mfma_shape(Cin, Cout, ksize, stride)) return MVSNERF_EUNSUPPORTED;
     return conv2d_mfma_launch(ActSrc{x, scale, shift}, Cin, cin_ld, N, H, W, wpacked, Cout, ksize, stride, out, stats_part, (hipStream_t)stream);
+}
+
+// FeatureNet's first layer (models.py:693: 3 -> 8 channels, 3x3) straight from the caller's (N, 3, H, W) images: the layer stages its halo through LDS anyway,
+// so the channel-last, zero-padded copy that mvsnerf_nchw_to_nhwc would make (one more pass over the images per encode) is not needed when nothing else
+// reads it (a no-grad encode; the weight gradient of a training step reads the copy).  wpacked: the layer's packed weights with cin_pad = 4; results = the bits
+// of mvsnerf_conv2d_fwd_stats on the padded copy.
+extern "C" int mvsnerf_conv2d_c3_nchw_fwd_stats(const float* imgs_nchw, int N, int H, int W, const float* wpacked, float* out, float* stats_part, void* stream)
+{
+    if (!imgs_nchw || !wpacked || !out || !stats_part || N < 1 || H < 1 || W < 1) return MVSNERF_EINVAL;
+    if (!mvs_aligned16(out)) return MVSNERF_EALIGN;
+    const unsigned tiles = (unsigned)mvsnerf_conv2d_mfma_tiles(4, 8, N, H, W, 3, 1);
+    conv2d_c8_lds_kernel<4, true><<<tiles, 256, 0, (hipStream_t)stream>>>(ActSrc{imgs_nchw, nullptr, nullptr}, 4, H, W, wpacked, out, stats_part);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
 }
 
 extern "C" int mvsnerf_conv2d_fwd(const float* x, const float* scale, const float* shift, int Cin, int cin_ld,

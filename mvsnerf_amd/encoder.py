@@ -204,16 +204,23 @@ def _get_bf16_2d(pk, mode="fwd"):
     return buf
 
 
+class _Nchw3:
+    """Marker for _conv2d: the input is the caller's contiguous (N,3,H,W) fp32 image tensor itself (no channel-last copy was made)."""
+
+    def __init__(self, x):
+        self.x = x
+
+
 def _conv2d(src, dims_in, cin_ld, wbuf, cin_k, cout_k, ksize, stride, bias=None, want_stats=False, packed=None, mode="fwd"):
     """2-D convolution kernel launch (padding k//2): input (N,H,W) with channel stride cin_ld -> raw (N,Ho,Wo,cout_k).
     want_stats: returns (raw, InPlaceABN partial sums | None) - the matrix-core layers leave them from their own launch."""
     N, H, W, _ = dims_in
     P = ksize // 2
     Ho, Wo = (H + 2 * P - ksize) // stride + 1, (W + 2 * P - ksize) // stride + 1
-    dev = (src.x if isinstance(src, _Lazy) else src).device
+    dev = (src.x if isinstance(src, (_Lazy, _Nchw3)) else src).device
     out = torch.empty((N, Ho, Wo, cout_k), device=dev, dtype=torch.float32)
     lib = _lib.lib()
-    wq = _get_bf16_2d(packed, mode) if (_LAYER_BF16[0] and packed is not None) else None
+    wq = _get_bf16_2d(packed, mode) if (_LAYER_BF16[0] and packed is not None and not isinstance(src, _Nchw3)) else None
     if wq is not None:               # use_amp: FeatureNet on the bf16 matrix cores (csrc/conv3d_bf16.hip), statistics from the same launch
         part, nblk = None, 0
         if want_stats and bias is None and FUSED_ABN_STATS:
@@ -224,6 +231,11 @@ def _conv2d(src, dims_in, cin_ld, wbuf, cin_k, cout_k, ksize, stride, bias=None,
         return (out, None if part is None else (part, nblk)) if want_stats else out
     if callable(wbuf):
         wbuf = wbuf()
+    if isinstance(src, _Nchw3):      # FeatureNet's first layer of a no-grad encode: straight from the (N,3,H,W) images (csrc/featnet.hip conv2d_c8_lds_kernel)
+        nblk = lib.mvsnerf_conv2d_mfma_tiles(4, 8, N, H, W, 3, 1)
+        part = torch.empty(nblk * 2 * cout_k, device=out.device, dtype=torch.float32)
+        check(lib.mvsnerf_conv2d_c3_nchw_fwd_stats(src.x.data_ptr(), N, H, W, wbuf.data_ptr(), out.data_ptr(), part.data_ptr(), stream_ptr()), "conv2d_c3_nchw_fwd_stats")
+        return out, (part, nblk)
     if want_stats and bias is None and FUSED_ABN_STATS:
         nblk = lib.mvsnerf_conv2d_mfma_tiles(cin_k, cout_k, N, H, W, ksize, stride)
         if nblk > 0:
@@ -297,21 +309,28 @@ class FeatureNet(nn.Module):
     def _layers(self):
         return [*self.conv0, *self.conv1, *self.conv2]
 
-    def _run(self, x):
+    def _run(self, x, keep_input=True):
+        """keep_input = False (a no-grad forward: nobody reads the channel-last copy of the images afterwards): the first layer reads the (N,3,H,W) tensor itself."""
         if x.dim() != 4 or x.shape[1] != 3:
             raise RuntimeError(f"FeatureNet: expected (N,3,H,W) images, got {tuple(x.shape)}")
         N, _, H, W = x.shape
-        img, ld = _images_channel_last(x, 4)
-        src, dims = img, (N, H, W, ld)
+        bf16 = ENCODER_PRECISION == "bf16" and BF16_LAYERS
+        if (not keep_input and not bf16 and FUSED_ABN_STATS and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+                and x.data_ptr() % 4 == 0 and self.conv0[0].bn.training):
+            img, ld = None, 4
+            src, dims = _Nchw3(x.detach()), (N, H, W, 4)
+        else:
+            img, ld = _images_channel_last(x, 4)
+            src, dims = img, (N, H, W, ld)
         lz = []
-        with _layer_precision(ENCODER_PRECISION == "bf16" and BF16_LAYERS):      # use_amp: the 2-D layers on the bf16 matrix cores as well
+        with _layer_precision(bf16):      # use_amp: the 2-D layers on the bf16 matrix cores as well
             for lay in self._layers():
                 z = lay.lazy(src, dims, ld)
                 lz.append(z)
                 src, dims, ld = z, z.dims, z.dims[3]      # (materialising the activation here, as the 3-D up-blocks do, is 3 % slower)
             top = _conv2d(src, dims, ld, self._top_packed.get, 32, 32, 1, 1, bias=dev_f32_tensor(self.toplayer.bias), packed=self._top_packed)
         _flush_nbt()
-        return (img, img.shape[3]), lz, top
+        return (img, 4 if img is None else img.shape[3]), lz, top
 
     def forward(self, x):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
@@ -319,7 +338,7 @@ class FeatureNet(nn.Module):
             for lay in self._layers():
                 params += [lay.conv.weight, lay.bn.weight, lay.bn.bias]
             return _FeatureNetFunction.apply(x, self, *params, self.toplayer.weight, self.toplayer.bias)
-        _, _, top = self._run(x)
+        _, _, top = self._run(x, keep_input=False)
         return top.permute(0, 3, 1, 2)
 
 
