@@ -165,6 +165,9 @@ int mvsnerf_partial_sum_multi(int n_jobs, const float* const* partial, const int
 int mvsnerf_conv2d_mfma_tiles(int Cin, int Cout, int N, int H, int W, int ksize, int stride);
 int mvsnerf_conv2d_fwd_stats(const float* x, const float* scale, const float* shift, int Cin, int cin_ld, int N, int H, int W,
                              const float* wpacked, int Cout, int ksize, int stride, float* out, float* stats_part, void* stream);
+/* The depth hypotheses of MVSNet.forward (models.py:903-906, linear in depth): out[i] = near_far[0] * (1 - t[i]) + near_far[1] * t[i] with the roundings of the
+ * four elementwise kernels the reference runs; t = linspace(0, 1, D) and near_far on the device (one launch, no host synchronisation). */
+int mvsnerf_depth_values(const float* t, const float* near_far, int D, float* out, void* stream);
 /* FeatureNet's first layer (models.py:693) from the caller's (N, 3, H, W) images, without the channel-last copy: a no-grad encode; the bits of
  * mvsnerf_conv2d_fwd_stats(Cin = 4) on the zero-padded copy.  wpacked: that layer's packed weights (cin_pad 4, cout 8). */
 int mvsnerf_conv2d_c3_nchw_fwd_stats(const float* imgs_nchw, int N, int H, int W, const float* wpacked, float* out, float* stats_part, void* stream);

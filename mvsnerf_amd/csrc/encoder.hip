@@ -64,6 +64,28 @@ extern "C" int mvsnerf_resize_bilinear(const float* src, float* dst, int NC, int
     return MVSNERF_OK;
 }
 
+// depth hypotheses of MVSNet.forward (models.py:903-906, linear in depth): depth[i] = near * (1 - t[i]) + far * t[i], every operation rounded to fp32 on its own like the
+// four ATen kernels it replaces (t = torch.linspace(0, 1, D), cached by the caller; near_far = the two floats on the device: no host synchronisation)
+__global__ __launch_bounds__(256) void depth_values_kernel(const float* __restrict__ t, const float* __restrict__ near_far, int D, float* __restrict__ out)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    const float near = near_far[0], far = near_far[1];
+    const float a = 1.0f - t[i];
+    const float b = near * a;
+    const float c = far * t[i];
+    out[i] = b + c;
+}
+
+extern "C" int mvsnerf_depth_values(const float* t, const float* near_far, int D, float* out, void* stream)
+{
+    if (!t || !near_far || !out || D < 1) return MVSNERF_EINVAL;
+    depth_values_kernel<<<mvs_cdiv(D, 256), 256, 0, (hipStream_t)stream>>>(t, near_far, D, out);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
 // =============================================================================================
 // plane sweep forward (homo_warp + build_volume_costvar[_img] in one pass): csrc/planesweep.hip - its own translation unit, compiled
 // WITHOUT packed fp32 instructions (see the header there); the guarded encode head below reaches it through mvs_planesweep_launch.

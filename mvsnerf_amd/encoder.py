@@ -664,12 +664,13 @@ def _abn_stats(raw, n_vox, bn, update_running=True, partials=None):
 
 
 _NBT_PENDING = []
+_NBT_DEFER = [0]           # > 0: MVSNet.forward is running FeatureNet - its layers' counters wait for the flush behind CostRegNet (one launch per encode, not two)
 
 
 def _flush_nbt():
     """`num_batches_tracked += 1` of every layer that ran, as ONE foreach launch per network pass instead of one tiny ATen
     kernel per layer (18 of them per scene encode)."""
-    if _NBT_PENDING:
+    if _NBT_PENDING and not _NBT_DEFER[0]:
         torch._foreach_add_(list(_NBT_PENDING), 1)
         _NBT_PENDING.clear()
 
@@ -1411,6 +1412,7 @@ class MVSNet(nn.Module):
         # BASELINE config 4 (5 views => 47 input channels, no shipped checkpoint fits)
         self.cost_reg_2 = CostRegNet(32 + 3 * n_views, norm_act)
         self.D = 128          # number of depth planes (hard-coded `D = 128` at models.py:914; settable here for config 1)
+        self._t_vals = {}     # linspace(0, 1, D) per (device, dtype, D)
         self._pack_log = []   # weight re-layouts the last forward/backward asked for (see _PackBatch)
         for m in self.modules():
             for name in ("_packed", "_top_packed"):
@@ -1435,6 +1437,21 @@ class MVSNet(nn.Module):
         if tp is not None:
             tp.cache.clear()
 
+    def _depth_values(self, near_far, imgs, lindisp):
+        """models.py:903-906.  The linear case with near_far on the device is ONE launch (mvsnerf_depth_values: the same four roundings as linspace / rsub / mul / mul /
+        add, without their five launches); t_vals is cached per (device, dtype, D)."""
+        key = (imgs.device, imgs.dtype, self.D)
+        t_vals = self._t_vals.get(key)
+        if t_vals is None:
+            t_vals = self._t_vals[key] = torch.linspace(0.0, 1.0, steps=self.D, device=imgs.device, dtype=imgs.dtype)
+        if (not lindisp and torch.is_tensor(near_far) and near_far.is_cuda and near_far.dtype == torch.float32 and near_far.numel() == 2 and near_far.is_contiguous()
+                and imgs.dtype == torch.float32 and not near_far.requires_grad):
+            out = torch.empty(self.D, device=imgs.device, dtype=torch.float32)
+            check(_lib.lib().mvsnerf_depth_values(t_vals.data_ptr(), near_far.data_ptr(), self.D, out.data_ptr(), stream_ptr()), "depth_values")
+            return out
+        near, far = near_far
+        return (near * (1.0 - t_vals) + far * t_vals) if not lindisp else 1.0 / (1.0 / near * (1.0 - t_vals) + 1.0 / far * t_vals)
+
     def _sweep(self, imgs, feats, proj_mats, depth_values, pad, with_img, blocked=False):
         if feats.shape[0] != 1:
             raise RuntimeError("MVSNet: batch size must be 1 (the reference assumes it, models.py:916)")
@@ -1457,12 +1474,20 @@ class MVSNet(nn.Module):
         """reference models.py:895-932.  imgs (B,V,3,H,W) normalised; proj_mats (B,V,3,4); near_far (2,)."""
         B, V, _, H, W = imgs.shape
         self.prepack()
-        feats = self.feature(imgs.reshape(B * V, 3, H, W))
+        _NBT_DEFER[0] += 1
+        try:
+            feats = self.feature(imgs.reshape(B * V, 3, H, W))
+        finally:
+            _NBT_DEFER[0] -= 1
+        try:
+            return self._forward_behind_features(imgs, feats, proj_mats, near_far, pad, return_color, lindisp)
+        finally:
+            _flush_nbt()                 # (a no-op when CostRegNet's own flush took FeatureNet's counters along)
+
+    def _forward_behind_features(self, imgs, feats, proj_mats, near_far, pad, return_color, lindisp):
+        B, V, _, H, W = imgs.shape
         feats_l = feats.view(B, V, *feats.shape[1:])
-        t_vals = torch.linspace(0.0, 1.0, steps=self.D, device=imgs.device, dtype=imgs.dtype)
-        near, far = near_far
-        depth_values = (near * (1.0 - t_vals) + far * t_vals) if not lindisp else 1.0 / (1.0 / near * (1.0 - t_vals) + 1.0 / far * t_vals)
-        depth_values = depth_values.unsqueeze(0)
+        depth_values = self._depth_values(near_far, imgs, lindisp).unsqueeze(0)
         # inference (no gradient anywhere): the cost volume goes to conv0 in channel blocks of 8 and never takes its NCDHW form
         fast = (BLOCKED_COST and not return_color and not feats_l.requires_grad
                 and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.cost_reg_2.parameters()))

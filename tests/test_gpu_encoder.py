@@ -391,3 +391,23 @@ def test_partial_sum_multi_matches_float64_sums():
                                        (ctypes.c_int64 * n)(*[s[1] for s in shapes]), (ctypes.c_void_p * n)(*[d.data_ptr() for d in d2]),
                                        scratch.data_ptr(), stream_ptr()) == 0
     assert all(torch.equal(a, b) for a, b in zip(dsts, d2))
+
+
+@pytest.mark.parametrize("D,near,far", [(128, 2.125, 6.0), (16, 0.5, 1000.0), (192, 1.3333334, 4.7), (7, 3.0, 3.0)])
+def test_depth_values_are_the_bits_of_the_aten_formula(D, near, far):
+    """MVSNet.forward's depth hypotheses (models.py:903-906) come from ONE launch (mvsnerf_depth_values) instead of linspace / rsub / mul / mul / add:
+    the same tensor, bit for bit; the inverse-depth form and host-side near_far keep the ATen path."""
+    from mvsnerf_amd import encoder
+    dev = torch.device("cuda", 0)
+    net = encoder.MVSNet().to(dev)
+    net.D = D
+    imgs = torch.zeros((1, 3, 3, 8, 8), device=dev)
+    nf = torch.tensor([near, far], device=dev)
+    t = torch.linspace(0.0, 1.0, steps=D, device=dev)
+    want = nf[0] * (1.0 - t) + nf[1] * t
+    got = net._depth_values(nf, imgs, False)
+    assert got.shape == want.shape and torch.equal(got, want)
+    assert torch.equal(net._depth_values(nf, imgs, False), want)                       # second call: cached t_vals
+    want_inv = 1.0 / (1.0 / nf[0] * (1.0 - t) + 1.0 / nf[1] * t)
+    assert torch.equal(net._depth_values(nf, imgs, True), want_inv)
+    assert torch.equal(net._depth_values((nf[0], nf[1]), imgs, False), want)            # a pair of 0-dim tensors: the ATen path
