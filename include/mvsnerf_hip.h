@@ -9,7 +9,7 @@
  * CostRegNet / FeatureNet layer calls (any shape), volume / colour lookups, MLP pack / forward / backward in every arithmetic, compositing, the
  * one-call ray march (mvsnerf_raymarch_{fwd, fwd_batched, train_fwd, bwd}, mvsnerf_render_pixels_fwd), ray generation, importance sampling,
  * Adam: 70 entries, frozen (tests/test_abi_surface.py holds the list; a change here is an ABI bump).  Everything a scene encode or a training
- * step needs can be written against it.  include/mvsnerf_hip_internal.h declares the 65 further exports that mvsnerf_amd's own host layer
+ * step needs can be written against it.  include/mvsnerf_hip_internal.h declares the 66 further exports that mvsnerf_amd's own host layer
  * drives its TUNED layer loop with - per-shape matrix-core convolutions and their *_tiles / *_parts / *_packed_elems queries, blocked /
  * bf16 / two-piece-fp16 cost-volume layouts, multi-job pack and reduction helpers, the guarded conv sequences: plumbing that moves with the
  * kernels and carries no stability promise.

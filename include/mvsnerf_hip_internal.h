@@ -165,6 +165,9 @@ int mvsnerf_partial_sum_multi(int n_jobs, const float* const* partial, const int
 int mvsnerf_conv2d_mfma_tiles(int Cin, int Cout, int N, int H, int W, int ksize, int stride);
 int mvsnerf_conv2d_fwd_stats(const float* x, const float* scale, const float* shift, int Cin, int cin_ld, int N, int H, int W,
                              const float* wpacked, int Cout, int ksize, int stride, float* out, float* stats_part, void* stream);
+/* mvsnerf_resize_bilinear (models.py:859) of N three-channel images written as [N][Ho][Wo][4] (fourth channel 0) - the plane sweep's thumbnail input - in one
+ * launch instead of resize + mvsnerf_nchw_to_nhwc; the same values. */
+int mvsnerf_resize_bilinear_nhwc4(const float* src_n3hw, float* dst_nhw4, int N, int Hi, int Wi, int Ho, int Wo, void* stream);
 /* The depth hypotheses of MVSNet.forward (models.py:903-906, linear in depth): out[i] = near_far[0] * (1 - t[i]) + near_far[1] * t[i] with the roundings of the
  * four elementwise kernels the reference runs; t = linspace(0, 1, D) and near_far on the device (one launch, no host synchronisation). */
 int mvsnerf_depth_values(const float* t, const float* near_far, int D, float* out, void* stream);

@@ -161,6 +161,7 @@ SIGNATURES = {
     "mvsnerf_conv2d_fwd": (_c_i, [_c_fp] * 3 + [_c_i] * 5 + [_c_fp, _c_fp] + [_c_i] * 3 + [_c_fp, _c_fp]),
     "mvsnerf_conv2d_mfma_tiles": (_c_i, [_c_i] * 7),
     "mvsnerf_conv2d_fwd_stats": (_c_i, [_c_fp] * 3 + [_c_i] * 5 + [_c_fp] + [_c_i] * 3 + [_c_fp, _c_fp, _c_fp]),
+    "mvsnerf_resize_bilinear_nhwc4": (_c_i, [_c_fp, _c_fp] + [_c_i] * 5 + [_c_fp]),
     "mvsnerf_depth_values": (_c_i, [_c_fp, _c_fp, _c_i, _c_fp, _c_fp]),
     "mvsnerf_conv2d_c3_nchw_fwd_stats": (_c_i, [_c_fp] + [_c_i] * 3 + [_c_fp, _c_fp, _c_fp, _c_fp]),
     "mvsnerf_conv2d_dgrad_k5s2": (_c_i, [_c_fp] + [_c_i] * 4 + [_c_fp] + [_c_i] * 3 + [_c_fp, _c_fp]),

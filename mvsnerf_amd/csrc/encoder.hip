@@ -56,6 +56,39 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
              ly * (hx * p[(int64_t)y1 * Wi + x0] + lx * p[(int64_t)y1 * Wi + x1]);
 }
 
+// the same interpolation of N three-channel images written channel-last with a zero fourth channel ([N][Ho][Wo][4]: what the plane sweep reads): one launch
+// instead of resize + mvsnerf_nchw_to_nhwc, the same operations per value
+__global__ __launch_bounds__(256) void resize_bilinear_nhwc4_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int Hi, int Wi, int Ho, int Wo)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * Ho * Wo) return;
+    int x, y, n;
+    mvs_unflatten3(i, Wo, Ho, x, y, n);
+    const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;     // area_pixel_compute_scale
+    float fy = sh * ((float)y + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
+    float fx = sw * ((float)x + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* p = src + ((int64_t)n * 3 + c) * Hi * Wi;
+        o[c] = hy * (hx * p[(int64_t)y0 * Wi + x0] + lx * p[(int64_t)y0 * Wi + x1]) +
+               ly * (hx * p[(int64_t)y1 * Wi + x0] + lx * p[(int64_t)y1 * Wi + x1]);
+    }
+    *reinterpret_cast<f32x4*>(dst + i * 4) = o;
+}
+
+extern "C" int mvsnerf_resize_bilinear_nhwc4(const float* src, float* dst, int N, int Hi, int Wi, int Ho, int Wo, void* stream)
+{
+    if (!src || !dst || N < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1) return MVSNERF_EINVAL;
+    if (!mvs_aligned16(dst)) return MVSNERF_EALIGN;
+    resize_bilinear_nhwc4_kernel<<<mvs_cdiv((int64_t)N * Ho * Wo, 256), 256, 0, (hipStream_t)stream>>>(src, dst, N, Hi, Wi, Ho, Wo);
+    MVS_LAUNCH_CHECK();
+    return MVSNERF_OK;
+}
+
 extern "C" int mvsnerf_resize_bilinear(const float* src, float* dst, int NC, int Hi, int Wi, int Ho, int Wo, void* stream)
 {
     if (!src || !dst || NC < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1) return MVSNERF_EINVAL;

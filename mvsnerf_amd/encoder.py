@@ -1249,10 +1249,8 @@ def _plane_sweep(imgs, feats, proj_mats, depth_values, pad, with_img, blocked=Fa
     imgs_cl_p = 0
     if with_img:
         Hi, Wi = imgs.shape[-2:]
-        small = torch.empty((V, 3, H, W), device=dev, dtype=torch.float32)                      # models.py:859
-        check(lib.mvsnerf_resize_bilinear(dev_f32(imgs[0].contiguous(), "imgs"), small.data_ptr(), V * 3, Hi, Wi, H, W, stream_ptr()), "resize_bilinear")
-        imgs_cl = torch.empty((V, H, W, 4), device=dev, dtype=torch.float32)
-        check(lib.mvsnerf_nchw_to_nhwc(small.data_ptr(), imgs_cl.data_ptr(), V, 3, H, W, 4, stream_ptr()), "nchw_to_nhwc")
+        imgs_cl = torch.empty((V, H, W, 4), device=dev, dtype=torch.float32)                     # models.py:859, written channel-last in the same launch
+        check(lib.mvsnerf_resize_bilinear_nhwc4(dev_f32(imgs[0].contiguous(), "imgs"), imgs_cl.data_ptr(), V, Hi, Wi, H, W, stream_ptr()), "resize_bilinear_nhwc4")
         imgs_cl_p = imgs_cl.data_ptr()
     n_ch = (3 * V if with_img else 0) + C
     CP = (n_ch + 3) // 4 * 4
