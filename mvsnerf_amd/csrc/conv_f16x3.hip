@@ -157,27 +157,42 @@ __global__ __launch_bounds__(64 * H_WAVES, 4) void conv3d_k3s1_c8_f16x3_kernel(c
     }
     // D: lane (column n = lane & 15, g = lane >> 4): register r = voxel x 4 g + r of the M-tile.  Output row t, channel n < 8:
     // left(P[t]) sits in lane n, right(P[t + 1]) in lane n + 8 of the same 16-lane row: one DPP row rotation by 8 brings it over.
-    const int n = lane & 15, g4 = lane >> 4;
-    const int oz = bz * HTZ + wave;
+    // (everything the epilogue addresses with is derived HERE from an opaque copy of the thread index: computed from the kernel's `lane` / `wave` it is hoisted
+    // above the main loop, which runs at the 128-register bound of four waves per SIMD - seven registers spilled)
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, wave_e = tid_e >> 6;
+    const int n = lane_e & 15, g4 = lane_e >> 4;
+    const int oz = bz * HTZ + wave_e;
     float ssum = 0.f, ssq = 0.f;
-    f32x4 acc[8];
+    // Stored from the D fragment a lane writes ONE float per instruction, half the lanes (n >= 8) are masked and an instruction touches four 32-byte pieces
+    // (32 such instructions per wave for 150 MB of output).  A wave's plane is 8 rows of 16 voxels x 8 channels = 512 contiguous bytes each: the values go through
+    // a wave-private stage in the (free: barrier above) tile buffer - padded by 8 floats per 4 voxels, so that the four voxel groups of a write and the quarter
+    // rows of a read fall on different banks - and leave as four 1 KB global_store_dwordx4 (two rows each).  One pass over the rows: row t's values are formed,
+    // counted for the InPlaceABN partial sums (in the order the direct stores took them) and staged, nothing else of the fragment stays live.
+    constexpr int RS = 16 * 8 + 4 * 8;                            // floats per staged row
+    float* stg = reinterpret_cast<float*>(lds) + wave_e * (8 * RS) + g4 * 40 + n;
+    const bool mine = oz < D && n < 8;
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
+    for (int t = 0; t < 8; ++t) {
+        const int oy = by * HTY + t;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            acc[t][r] = P[t][r] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P[t + 1][r]), 0x128, 0xf, 0xf, false));   // row_ror:8
-    if (oz < D && n < 8) {
+        for (int r = 0; r < 4; ++r) {
+            const float v = P[t][r] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P[t + 1][r]), 0x128, 0xf, 0xf, false));   // row_ror:8
+            if (n < 8) stg[t * RS + r * 8] = v;
+            if (mine && bx * HTX + g4 * 4 + r < W && oy < H) { ssum += v; ssq = fmaf(v, v, ssq); }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // wave-private: no barrier
+    {
+        const int xr = (lane_e & 31) >> 1, hq = lane_e & 1;
+        const float* rd = reinterpret_cast<const float*>(lds) + wave_e * (8 * RS) + (lane_e >> 5) * RS + xr * 8 + (xr >> 2) * 8 + hq * 4;
+        const int ox = bx * HTX + xr;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int oy = by * HTY + t;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ox = bx * HTX + g4 * 4 + r;
-                if (ox < W && oy < H) {
-                    out[(((int64_t)oz * H + oy) * W + ox) * 8 + n] = acc[t][r];
-                    ssum += acc[t][r]; ssq = fmaf(acc[t][r], acc[t][r], ssq);
-                }
-            }
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(rd + 2 * k * RS);
+            const int oy = by * HTY + 2 * k + (lane_e >> 5);
+            if (oz < D && oy < H && ox < W) *reinterpret_cast<f32x4*>(out + (((int64_t)oz * H + oy) * W + ox) * 8 + hq * 4) = v4;
         }
     }
     if (stats) {          // InPlaceABN partial sums in the 4-plane slots of mvsnerf_conv0_bf16_tiles (abn_finalize_kernel's layout): waves 0..3 -> slot of the
