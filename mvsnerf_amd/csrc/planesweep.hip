@@ -259,8 +259,9 @@ __device__ __forceinline__ void planesweep_tile(
                 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
                 __bf16* cost16 = reinterpret_cast<__bf16*>(cost);
                 const int nb16 = (CP + 15) >> 4, per = nv * 2, n_k = per * nb16;
+                const float inv_per = 1.0f / (float)per;
                 for (int k = threadIdx.x; k < n_k; k += VPB) {
-                    const int cb = k / per, rem = k - cb * per, vox = rem >> 1, c0 = cb * 16 + (rem & 1) * 8;
+                    const int cb = (int)(((float)k + 0.5f) * inv_per), rem = k - cb * per, vox = rem >> 1, c0 = cb * 16 + (rem & 1) * 8;      // k / per, exact for these sizes
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + vox * RS + c0), hi = *reinterpret_cast<const f32x4*>(stage + vox * RS + c0 + 4);
                     bf16x8_t h;
 #pragma unroll
@@ -274,8 +275,9 @@ __device__ __forceinline__ void planesweep_tile(
                 _Float16* cost16 = reinterpret_cast<_Float16*>(cost);
                 const int nb16 = (CP + 15) >> 4, per = nv * 2, n_k = per * nb16;
                 const int64_t lo_plane = (int64_t)nb16 * nvox * 16;
+                const float inv_per = 1.0f / (float)per;                // (an integer division per 16-byte chunk was 6 % of this kernel's VALU instructions)
                 for (int k = threadIdx.x; k < n_k; k += VPB) {
-                    const int cb = k / per, rem = k - cb * per, vox = rem >> 1, c0 = cb * 16 + (rem & 1) * 8;
+                    const int cb = (int)(((float)k + 0.5f) * inv_per), rem = k - cb * per, vox = rem >> 1, c0 = cb * 16 + (rem & 1) * 8;      // k / per, exact for these sizes (k < 96, per <= 32)
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + vox * RS + c0), hi = *reinterpret_cast<const f32x4*>(stage + vox * RS + c0 + 4);
                     // (round 6: the same two roundings in three instructions per PAIR - v_cvt_pk_f16_f32, then v_fma_mix{lo,hi}_f16 form fp16(v - hi) straight
                     // from the packed hi pieces - instead of six; the flush was a quarter of this VALU-bound kernel's instructions)
@@ -300,8 +302,9 @@ __device__ __forceinline__ void planesweep_tile(
             } else {
                 // channel block cb (four channels) of these nv voxels is one contiguous run of nv * 16 bytes: k -> (cb, voxel)
                 const int nblk = CP >> 2, n_k = nv * nblk;
+                const float inv_nv = 1.0f / (float)nv;
                 for (int k = threadIdx.x; k < n_k; k += VPB) {
-                    const int cb = k / nv, vox = k - cb * nv;
+                    const int cb = (int)(((float)k + 0.5f) * inv_nv), vox = k - cb * nv;      // k / nv, exact for these sizes (k < 16 * 16)
                     *reinterpret_cast<f32x4*>(cost + (((int64_t)cb * nvox + p0 + vox) << 2)) =
                         *reinterpret_cast<const f32x4*>(stage + vox * RS + cb * 4);
                 }
