@@ -282,20 +282,37 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_bf16_dgrad_kernel(const
                 }
             }
     }
-    const int g4 = lane >> 4, oz = bz * BTZ + wave;
-    if (oz < D) {
+    // Stored from the D fragment a lane writes one float per instruction (64 instructions per wave, each four 64-byte pieces a row apart) for the 600 MB this
+    // kernel writes.  A row of the wave's plane is 16 voxels x 16 NCB channels = 1 or 2 KB of CONTIGUOUS output: two rows at a time go through a wave-private stage
+    // in the (free: barrier) g tile - padded by 16 floats per 4 voxels, so that the four voxel groups of a write fall on different banks - and leave as 1 KB
+    // global_store_dwordx4.  (The epilogue's indices come from an opaque copy of the thread index: nothing of it can be hoisted above the MFMA loops.)
+    __syncthreads();                                              // every wave has read its A operands: the g tile is free
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, wave_e = tid_e >> 6;
+    const int n_e = lane_e & 15, g4 = lane_e >> 4, oz = bz * BTZ + wave_e;
+    constexpr int CW = 16 * NCB;                                  // channels per voxel
+    constexpr int RS = 16 * CW + 4 * 16;                          // floats per staged row
+    constexpr int QV = CW / 4;                                    // 16-byte chunks per voxel
+    float* stg = reinterpret_cast<float*>(lds) + wave_e * (2 * RS);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int oy = by * BTY + t;
+    for (int t2 = 0; t2 < 8; t2 += 2) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ox = bx * BTX + g4 * 4 + r;
-                if (ox < W && oy < H) {
+        for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                    for (int cb = 0; cb < NCB; ++cb) gx[(((int64_t)oz * H + oy) * W + ox) * (16 * NCB) + cb * 16 + n] = acc[t][cb][r];
-                }
-            }
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) stg[tt * RS + (g4 * 4 + r) * CW + g4 * 16 + cb * 16 + n_e] = acc[t2 + tt][cb][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // wave-private: no barrier
+#pragma unroll
+        for (int k = 0; k < (2 * 16 * QV) / 64; ++k) {
+            const int c = k * 64 + lane_e;                        // 16-byte chunk of the two rows
+            const int tt = c / (16 * QV), cc = c - tt * (16 * QV), x = cc / QV, q = cc - x * QV;
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(stg + tt * RS + x * CW + (x >> 2) * 16 + q * 4);
+            const int oy = by * BTY + t2 + tt, ox = bx * BTX + x;
+            if (oz < D && oy < H && ox < W) *reinterpret_cast<f32x4*>(gx + (((int64_t)oz * H + oy) * W + ox) * CW + q * 4) = v4;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the rows are read before the next pair overwrites them
     }
 }
 
