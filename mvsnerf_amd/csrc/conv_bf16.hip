@@ -118,28 +118,38 @@ __global__ __launch_bounds__(256, 3) void conv3d_k3s1_c8_bf16_kernel(const __bf1
         __syncthreads();                                          // everybody is done reading the buffer
     }
     // D: lane (column n = lane & 15, g = lane >> 4): register r = voxel x 4 g + r of the M-tile; left(P[t]) sits in lane n, right(P[t + 1]) in
-    // lane n + 8 of the same 16-lane row (DPP row rotation by 8)
-    const int n = lane & 15, g4 = lane >> 4;
-    const int oz = bz * BTZ + wave;
+    // lane n + 8 of the same 16-lane row (DPP row rotation by 8).  As in conv_f16x3.hip the values leave through a wave-private LDS stage (the tile buffer is
+    // free: barrier above) as 1 KB row stores instead of 32 half-masked dword stores per wave; the epilogue's indices come from an opaque copy of the thread
+    // index (nothing to hoist above the main loop); the InPlaceABN partial sums are taken in the order the direct stores took them.
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, wave_e = tid_e >> 6;
+    const int n = lane_e & 15, g4 = lane_e >> 4;
+    const int oz = bz * BTZ + wave_e;
     float ssum = 0.f, ssq = 0.f;
-    f32x4 acc[8];
+    constexpr int RS = 16 * 8 + 4 * 8;                            // floats per staged row
+    float* stg = reinterpret_cast<float*>(lds) + wave_e * (8 * RS) + g4 * 40 + n;
+    const bool mine = oz < D && n < 8;
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
+    for (int t = 0; t < 8; ++t) {
+        const int oy = by * BTY + t;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            acc[t][r] = P[t][r] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P[t + 1][r]), 0x128, 0xf, 0xf, false));   // row_ror:8
-    if (oz < D && n < 8) {
+        for (int r = 0; r < 4; ++r) {
+            const float v = P[t][r] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P[t + 1][r]), 0x128, 0xf, 0xf, false));   // row_ror:8
+            if (n < 8) stg[t * RS + r * 8] = v;
+            if (mine && bx * BTX + g4 * 4 + r < W && oy < H) { ssum += v; ssq = fmaf(v, v, ssq); }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // wave-private: no barrier
+    {
+        const int xr = (lane_e & 31) >> 1, hq = lane_e & 1;
+        const float* rd = reinterpret_cast<const float*>(lds) + wave_e * (8 * RS) + (lane_e >> 5) * RS + xr * 8 + (xr >> 2) * 8 + hq * 4;
+        const int ox = bx * BTX + xr;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int oy = by * BTY + t;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ox = bx * BTX + g4 * 4 + r;
-                if (ox < W && oy < H) {
-                    out[(((int64_t)oz * H + oy) * W + ox) * 8 + n] = acc[t][r];
-                    ssum += acc[t][r]; ssq = fmaf(acc[t][r], acc[t][r], ssq);
-                }
-            }
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(rd + 2 * k * RS);
+            const int oy = by * BTY + 2 * k + (lane_e >> 5);
+            if (oz < D && oy < H && ox < W) *reinterpret_cast<f32x4*>(out + (((int64_t)oz * H + oy) * W + ox) * 8 + hq * 4) = v4;
         }
     }
     if (stats) {          // InPlaceABN partial sums of this tile: abn_part_at(...) of common.h, slot = tile (abn_finalize_kernel's layout)
