@@ -387,24 +387,43 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3s1_c8_mfma4_kernel(const floa
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMA pieces have landed ...
         __syncthreads();                                          // ... everybody's have, and everybody is done reading `cur`
     }
-    const int blk = lane >> 2, i = lane & 3, mb = blk >> 1, nb = blk & 1;
-    const int oz = bz * TZ + wave;
+    // D: lane (mb, nb, i) holds, in register r of accumulator t, channel 4 nb + i of voxel (x = 4 (mb & 3) + r, row t + 8 (mb >> 2)) of the wave's plane.  Stored from
+    // there a lane writes one float per instruction (32 instructions per wave, eight 32-byte pieces each); a row of the plane is 512 contiguous bytes: the values go
+    // through a wave-private stage in the (free: barrier above) tile buffers - 8 floats of padding per 4 voxels and 4 per row keep writes and reads off each
+    // other's banks - and leave as eight 1 KB global_store_dwordx4 (two rows each).  Indices from an opaque copy of the thread index (nothing is hoisted above
+    // the chunk loop); the InPlaceABN partial sums are taken in the order the direct stores took them.
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, wave_e = tid_e >> 6;
+    const int blk = lane_e >> 2, i = lane_e & 3, mb = blk >> 1, nb = blk & 1;
+    const int oz = bz * TZ + wave_e;
     float ssum = 0.f, ssq = 0.f;
-    if (oz < D) {
+    constexpr int RS = 16 * 8 + 4 * 8 + 4;                        // floats per staged row
+    float* stg = lds4 + wave_e * (16 * RS);
+    {
+        float* wr = stg + (mb >> 2) * (8 * RS) + (mb & 3) * 40 + nb * 4 + i;
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                wr[t * RS + r * 8] = acc[t][r];
                 const int m = mb * 4 + r;
                 const int ox = bx * TX + (m & 15), oy = by * TY + t + 8 * (m >> 4);
-                if (ox < W && oy < H) {
-                    out[(((int64_t)oz * H + oy) * W + ox) * 8 + nb * 4 + i] = acc[t][r];
-                    ssum += acc[t][r]; ssq = fmaf(acc[t][r], acc[t][r], ssq);
-                }
+                if (oz < D && ox < W && oy < H) { ssum += acc[t][r]; ssq = fmaf(acc[t][r], acc[t][r], ssq); }
             }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // wave-private: no barrier
+        const int xr = (lane_e & 31) >> 1, hq = lane_e & 1;
+        const float* rd = stg + (lane_e >> 5) * RS + xr * 8 + (xr >> 2) * 8 + hq * 4;
+        const int ox = bx * TX + xr;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(rd + 2 * k * RS);
+            const int oy = by * TY + 2 * k + (lane_e >> 5);
+            if (oz < D && oy < H && ox < W) *reinterpret_cast<f32x4*>(out + (((int64_t)oz * H + oy) * W + ox) * 8 + hq * 4) = v4;
+        }
     }
     if (stats) {
-        __syncthreads();                                          // the tiles are free: reuse their first floats
+        __syncthreads();                                          // the output stages are read: reuse the tiles' first floats
         c8_tile_stats(ssum, ssq, lane, wave, lds4, stats, tile_id, gridDim.x);
     }
 }
