@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_bf16_kernel(
     // the view direction of the point's ray: asked for HERE, used by the last GEMM (loaded there its latency sat in front of the rgb head: ~1 000 cycles per wave)
     float dl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (!ALPHA_ONLY) {
-        const int64_t ray = p / S;
+        const int64_t ray = ((uint64_t)p >> 32) == 0 ? (int64_t)((unsigned)p / (unsigned)S) : p / S;      // (a 64-bit division is ~10x a 32-bit one)
         dl[0] = half ? dirs[ray * dirs_stride + 1] : dirs[ray * dirs_stride + 0];
         dl[1] = half ? 0.0f : dirs[ray * dirs_stride + 2];
     }
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(BP_THREADS, BP_WAVES == 4 ? 2 : 1) void mlp_fwd_bf1
     const float px = ndc[p * ndc_stride + 0], py = ndc[p * ndc_stride + 1], pz = ndc[p * ndc_stride + 2];
     float dl0 = 0.0f, dl1 = 0.0f;                                                     // the view direction: asked for here, used by the last GEMM
     if (!ALPHA_ONLY) {
-        const int64_t ray = p / S;
+        const int64_t ray = ((uint64_t)p >> 32) == 0 ? (int64_t)((unsigned)p / (unsigned)S) : p / S;      // (a 64-bit division is ~10x a 32-bit one)
         dl0 = half ? dirs[ray * dirs_stride + 1] : dirs[ray * dirs_stride + 0];
         dl1 = half ? 0.0f : dirs[ray * dirs_stride + 2];
     }
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(256, SCHED == 1 ? 1 : 2) void mlp_fwd_split_kernel(
         finish(acc, false, false);
     }
     {   // views_linears[0] + rgb head
-        const int64_t ray = p / S;
+        const int64_t ray = ((uint64_t)p >> 32) == 0 ? (int64_t)((unsigned)p / (unsigned)S) : p / S;      // (a 64-bit division is ~10x a 32-bit one)
         float dl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         dl[0] = half ? dirs[ray * dirs_stride + 1] : dirs[ray * dirs_stride + 0];
         dl[1] = half ? 0.0f : dirs[ray * dirs_stride + 2];

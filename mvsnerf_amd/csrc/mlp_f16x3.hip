@@ -329,7 +329,7 @@ __global__ __launch_bounds__(H3_THREADS) void mlp_fwd_f16x3_kernel(
     // the view direction of the point's ray: asked for HERE, used by the last GEMM (loaded there, its latency sat in front of that GEMM)
     float dir0 = 0.0f, dir1 = 0.0f;
     if (!ALPHA_ONLY) {
-        const int64_t ray = p / S;
+        const int64_t ray = ((uint64_t)p >> 32) == 0 ? (int64_t)((unsigned)p / (unsigned)S) : p / S;      // (a 64-bit division is ~10x a 32-bit one)
         dir0 = half ? dirs[ray * dirs_stride + 1] : dirs[ray * dirs_stride + 0];
         dir1 = half ? 0.0f : dirs[ray * dirs_stride + 2];
     }

@@ -671,11 +671,17 @@ __global__ __launch_bounds__(256) void raygen_kernel(RayGenArgs a)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.N * a.S) return;
-    const int64_t n = t / a.S;
+    // (three 64-bit divisions per SAMPLE were most of this kernel's instructions: sample and pixel ids below 2^32 - every frame - take 32-bit ones)
+    int64_t n;
+    if (((uint64_t)t >> 32) == 0) n = (int64_t)((unsigned)t / (unsigned)a.S); else n = t / a.S;
     const int s = (int)(t - n * a.S);
     float x, y;
     if (a.xs) { x = a.xs[n]; y = a.ys[n]; }
-    else { const int64_t p = a.first_pixel + n; y = (float)(p / a.W_img); x = (float)(p % a.W_img); }
+    else {
+        const int64_t p = a.first_pixel + n;
+        if (((uint64_t)p >> 32) == 0) { const unsigned q = (unsigned)p / (unsigned)a.W_img; y = (float)q; x = (float)((unsigned)p - q * (unsigned)a.W_img); }
+        else { y = (float)(p / a.W_img); x = (float)(p % a.W_img); }
+    }
     float near = a.nf_tgt[0], far = a.nf_tgt[1];
     const float near_ref = a.nf_ref[0], far_ref = a.nf_ref[1];
     const int64_t pix_off = (int64_t)y * a.W_img + (int64_t)x;            // pixel_coordinates.long() (:189): ids are non-negative integers
